@@ -1,0 +1,851 @@
+"""Torch-CPU restatement of the TF-Ranking math core (TEST INFRASTRUCTURE ONLY).
+
+Every function cites the reference lines it follows; paths are relative to
+/root/reference/tensorflow_ranking/python/.  All arithmetic is fp32 unless the
+caller passes fp64 tensors (used by the gradient tests as a higher-precision
+arbiter).  The structure deliberately mirrors the reference's op graph -- the
+``[B, L, L]`` broadcast tensors are materialised -- because this file is also
+the timed CPU baseline ("torch-CPU restatement of the TF-Ranking op graph").
+
+Deterministic tie rule (the reference shuffles ties at random): descending by
+score, equal scores keep index order, masked-out entries last in index order.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+_EPSILON = 1e-10          # losses_impl.py:28
+_PADDING_LABEL = -1.0     # utils.py:21
+_PADDING_PREDICTION = -1e6  # utils.py:22
+_PADDING_WEIGHT = 0.0     # utils.py:23
+
+
+def _t(x, dtype=torch.float32):
+    if torch.is_tensor(x):
+        return x
+    return torch.as_tensor(x, dtype=dtype)
+
+
+# ----------------------------------------------------------------------------
+# utils.py
+# ----------------------------------------------------------------------------
+def is_label_valid(labels):
+    """utils.py:78-81."""
+    return _t(labels) >= 0.0
+
+
+def _get_shuffle_indices(shape, mask=None):
+    """utils.py:84-112 with shuffle_ties=False (zeros, +2.0 where masked out)."""
+    shuffle_values = torch.zeros(shape, dtype=torch.float32)
+    if mask is not None:
+        shuffle_values = torch.where(mask, shuffle_values, shuffle_values + 2.0)
+    return torch.sort(shuffle_values, dim=-1, stable=True).indices
+
+
+def sort_by_scores(scores, features_list, topn=None, mask=None):
+    """utils.py:115-164, deterministic tie rule.  Returns sorted features."""
+    scores = _t(scores).to(torch.float32)
+    assert scores.dim() == 2
+    list_size = scores.shape[1]
+    if topn is None:
+        topn = list_size
+    topn = min(topn, list_size)
+    shuffle_ind = None
+    if mask is not None:
+        mask = _t(mask, torch.bool)
+        scores = torch.where(mask, scores, scores.min())          # :150 (global min)
+        shuffle_ind = _get_shuffle_indices(scores.shape, mask)
+        scores = torch.gather(scores, 1, shuffle_ind)
+    # tf.math.top_k(sorted=True): descending, ties -> lower index first.
+    indices = torch.sort(scores, dim=1, descending=True, stable=True).indices[:, :topn]
+    if shuffle_ind is not None:
+        indices = torch.gather(shuffle_ind, 1, indices)
+    out = []
+    for f in features_list:
+        f = _t(f)
+        if f.dim() == 2:
+            out.append(torch.gather(f, 1, indices))
+        else:
+            idx = indices.unsqueeze(-1).expand(-1, -1, f.shape[2])
+            out.append(torch.gather(f, 1, idx))
+    return out
+
+
+def sorted_ranks(scores):
+    """utils.py:167-195: 1-based int ranks."""
+    scores = _t(scores)
+    b, l = scores.shape
+    positions = torch.arange(l).unsqueeze(0).expand(b, l)
+    sorted_positions = sort_by_scores(scores, [positions])[0]
+    return (torch.sort(sorted_positions, dim=1, stable=True).indices + 1).to(torch.int32)
+
+
+def ragged_to_dense(labels, predictions, weights):
+    """utils.py:421-443.  Ragged inputs are python lists of lists."""
+    n = len(labels)
+    width = max((len(r) for r in labels), default=0)
+
+    def pad(rows, value):
+        out = torch.full((n, width), value, dtype=torch.float32)
+        for i, r in enumerate(rows):
+            if len(r):
+                out[i, :len(r)] = torch.as_tensor(r, dtype=torch.float32)
+        return out
+
+    mask = pad([[1.0] * len(r) for r in labels], 0.0).to(torch.bool)
+    dense_labels = pad(labels, _PADDING_LABEL)
+    dense_pred = pad(predictions, _PADDING_PREDICTION) if predictions is not None else None
+    if isinstance(weights, (list, tuple)) and len(weights) == n and all(
+            isinstance(w, (list, tuple)) and len(w) == len(r) for w, r in zip(weights, labels)):
+        weights = pad(weights, _PADDING_WEIGHT)   # ragged per-item weights
+    elif weights is not None:
+        weights = _t(weights)
+    return dense_labels, dense_pred, weights, mask
+
+
+# ----------------------------------------------------------------------------
+# Reductions.
+# ----------------------------------------------------------------------------
+class Reduction:
+    """tf.compat.v1.losses.Reduction / tf.keras.losses.Reduction strings."""
+    NONE = 'none'
+    SUM = 'weighted_sum'
+    MEAN = 'weighted_mean'
+    SUM_OVER_BATCH_SIZE = 'weighted_sum_over_batch_size'
+    SUM_BY_NONZERO_WEIGHTS = 'weighted_sum_by_nonzero_weights'
+    AUTO = 'auto'
+    KERAS_SUM = 'sum'
+    KERAS_SUM_OVER_BATCH_SIZE = 'sum_over_batch_size'
+
+
+def _safe_div(num, den):
+    return torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)),
+                       torch.zeros_like(num))
+
+
+def compute_weighted_loss_v1(losses, weights, reduction):
+    """tf.compat.v1.losses.compute_weighted_loss semantics (third-party TF op,
+    call sites losses_impl.py:813,1167)."""
+    losses = _t(losses)
+    weights = _t(weights).to(losses.dtype)
+    weighted = losses * weights
+    if reduction == Reduction.NONE:
+        return weighted
+    total = weighted.sum()
+    bw = torch.broadcast_to(weights, weighted.shape) if weights.dim() <= weighted.dim() \
+        else weights
+    if reduction == Reduction.SUM:
+        return total
+    if reduction == Reduction.MEAN:
+        return _safe_div(total, bw.sum())
+    if reduction == Reduction.SUM_BY_NONZERO_WEIGHTS:
+        return _safe_div(total, (bw != 0).sum().to(losses.dtype))
+    if reduction == Reduction.SUM_OVER_BATCH_SIZE:
+        return total / weighted.numel()
+    raise ValueError('Invalid reduction: %s' % reduction)
+
+
+def keras_compute_weighted_loss(losses, sample_weight, reduction):
+    """tf.keras losses_utils.compute_weighted_loss (call sites
+    keras/losses.py:272,831-832).  sample_weight of rank losses.rank+1 with a
+    trailing 1 is squeezed; rank losses.rank-1 is expanded."""
+    losses = _t(losses)
+    if sample_weight is None:
+        sample_weight = 1.0
+    w = _t(sample_weight).to(losses.dtype)
+    if w.dim() == losses.dim() + 1 and w.shape[-1] == 1:
+        w = w.squeeze(-1)
+    elif w.dim() == losses.dim() - 1 and w.dim() > 0:
+        w = w.unsqueeze(-1)
+    weighted = losses * w
+    if reduction in (Reduction.NONE,):
+        return weighted
+    if reduction in (Reduction.KERAS_SUM, Reduction.SUM):
+        return weighted.sum()
+    if reduction in (Reduction.AUTO, Reduction.KERAS_SUM_OVER_BATCH_SIZE,
+                     Reduction.SUM_OVER_BATCH_SIZE):
+        return weighted.sum() / weighted.numel()
+    raise ValueError('Invalid reduction: %s' % reduction)
+
+
+# ----------------------------------------------------------------------------
+# Gain / discount functions (keras/utils.py:51-121, metrics_impl.py:31-33).
+# ----------------------------------------------------------------------------
+def identity(label):
+    return label
+
+
+def inverse(rank):
+    rank = _t(rank)
+    return _safe_div(torch.ones_like(rank), rank)
+
+
+def pow_minus_1(label):
+    label = _t(label)
+    return torch.pow(torch.tensor(2.0, dtype=label.dtype), label) - 1.0
+
+
+def log2_inverse(rank):
+    rank = _t(rank)
+    return _safe_div(torch.full_like(rank, math.log(2.0)), torch.log1p(rank))
+
+
+def log1p_inverse(rank):
+    """1/log1p(rank): losses_impl.py:111 default, losses.py:455."""
+    return 1.0 / torch.log1p(_t(rank))
+
+
+# ----------------------------------------------------------------------------
+# losses_impl.py helpers.
+# ----------------------------------------------------------------------------
+def _safe_default_gain_fn(labels):
+    """losses_impl.py:33-49."""
+    max_labels = labels.max(dim=-1, keepdim=True).values
+    two = torch.tensor(2.0, dtype=labels.dtype)
+    return torch.pow(two, labels - max_labels) - torch.pow(two, -max_labels)
+
+
+def _apply_pairwise_op(op, tensor):
+    """losses_impl.py:61-64."""
+    return op(tensor.unsqueeze(2), tensor.unsqueeze(1))
+
+
+def _get_valid_pairs_and_clean_labels(labels):
+    """losses_impl.py:67-74."""
+    is_valid = is_label_valid(labels)
+    valid_pairs = _apply_pairwise_op(torch.logical_and, is_valid)
+    labels = torch.where(is_valid, labels, torch.zeros_like(labels))
+    return valid_pairs, labels
+
+
+def approx_ranks(logits):
+    """losses_impl.py:77-106 (tile, tile, sub, sigmoid, sum)."""
+    logits = _t(logits)
+    list_size = logits.shape[1]
+    x = logits.unsqueeze(2).repeat(1, 1, list_size)
+    y = logits.unsqueeze(1).repeat(1, list_size, 1)
+    pairs = torch.sigmoid(y - x)
+    return pairs.sum(dim=-1) + 0.5
+
+
+def inverse_max_dcg(labels, gain_fn=pow_minus_1, rank_discount_fn=log1p_inverse, topn=None):
+    """losses_impl.py:109-134."""
+    labels = _t(labels)
+    ideal_sorted_labels, = sort_by_scores(labels, [labels], topn=topn)
+    rank = torch.arange(ideal_sorted_labels.shape[1]) + 1
+    discounted_gain = gain_fn(ideal_sorted_labels) * rank_discount_fn(rank.to(labels.dtype))
+    discounted_gain = discounted_gain.sum(dim=1, keepdim=True)
+    return torch.where(discounted_gain > 0.0, 1.0 / discounted_gain,
+                       torch.zeros_like(discounted_gain))
+
+
+def ndcg(labels, ranks=None):
+    """losses_impl.py:137-167 (ranks path; perm_mat is out of scope)."""
+    labels = _t(labels)
+    if ranks is None:
+        ranks = torch.arange(labels.shape[1]) + 1
+    discounts = 1.0 / torch.log1p(_t(ranks).to(labels.dtype))
+    gains = _safe_default_gain_fn(labels)
+    dcg = (gains * discounts).sum(dim=-1, keepdim=True)
+    return dcg * inverse_max_dcg(labels, gain_fn=_safe_default_gain_fn)
+
+
+def _compute_ranks(logits, is_valid):
+    """losses_impl.py:483-500."""
+    scores = torch.where(is_valid, logits,
+                         -1e-6 * torch.ones_like(logits) + logits.min(dim=1, keepdim=True).values)
+    return sorted_ranks(scores)
+
+
+def _pairwise_comparison(labels, logits, mask):
+    """losses_impl.py:503-537."""
+    pairwise_label_diff = _apply_pairwise_op(torch.sub, labels)
+    pairwise_logits = _apply_pairwise_op(torch.sub, logits)
+    pairwise_labels = (pairwise_label_diff > 0).to(logits.dtype)
+    valid_pair = _apply_pairwise_op(torch.logical_and, mask)
+    pairwise_labels = pairwise_labels * valid_pair.to(logits.dtype)
+    return pairwise_labels, pairwise_logits
+
+
+# ----------------------------------------------------------------------------
+# Lambda weights (losses_impl.py:170-369).
+# ----------------------------------------------------------------------------
+class LabelDiffLambdaWeight:
+    """losses_impl.py:210-217."""
+
+    def pair_weights(self, labels, ranks):
+        return torch.abs(_apply_pairwise_op(torch.sub, _t(labels)))
+
+    def individual_weights(self, labels, ranks):
+        return labels
+
+
+class DCGLambdaWeight:
+    """losses_impl.py:219-369 (AbstractDCGLambdaWeight + DCGLambdaWeight)."""
+
+    def __init__(self, topn=None, gain_fn=identity, rank_discount_fn=inverse,
+                 normalized=False, smooth_fraction=0.0):
+        if not 0.0 <= smooth_fraction <= 1.0:
+            raise ValueError('smooth_fraction %s should be in range [0, 1].' % smooth_fraction)
+        self._topn = topn
+        self._gain_fn = gain_fn
+        self._rank_discount_fn = rank_discount_fn
+        self._normalized = normalized
+        self._smooth_fraction = smooth_fraction
+
+    def _pair_rank_discount(self, ranks, topn):
+        """losses_impl.py:334-369."""
+        f32 = torch.float32
+        pair_valid_rank = _apply_pairwise_op(torch.logical_or, ranks <= topn)
+        rank_diff = torch.abs(_apply_pairwise_op(torch.sub, ranks)).to(f32)
+        u = torch.where(
+            torch.logical_and(rank_diff > 0, pair_valid_rank),
+            torch.abs(self._rank_discount_fn(torch.clamp(rank_diff, min=1.0))
+                      - self._rank_discount_fn(rank_diff + 1)),
+            torch.zeros_like(rank_diff))
+        rank_discount = torch.where(ranks > topn, torch.zeros_like(ranks.to(f32)),
+                                    self._rank_discount_fn(ranks.to(f32)))
+        v = torch.abs(_apply_pairwise_op(torch.sub, rank_discount))
+        pair_discount = (1.0 - self._smooth_fraction) * u + self._smooth_fraction * v
+        pair_mask = _apply_pairwise_op(torch.logical_or, ranks <= topn)
+        return pair_discount * pair_mask.to(f32)
+
+    def pair_weights(self, labels, ranks):
+        """losses_impl.py:255-279."""
+        labels = _t(labels)
+        ranks = _t(ranks, torch.int32)
+        valid_pair, labels = _get_valid_pairs_and_clean_labels(labels)
+        gain = self._gain_fn(labels)
+        if self._normalized:
+            gain = gain * inverse_max_dcg(labels, gain_fn=self._gain_fn,
+                                          rank_discount_fn=self._rank_discount_fn,
+                                          topn=self._topn)
+        pair_gain = _apply_pairwise_op(torch.sub, gain)
+        pair_gain = pair_gain * valid_pair.to(torch.float32)
+        list_size = labels.shape[1]
+        topn = self._topn or list_size
+        pair_weight = torch.abs(pair_gain) * self._pair_rank_discount(ranks, topn)
+        pair_weight = pair_weight * float(list_size)
+        return pair_weight
+
+    def individual_weights(self, labels, ranks):
+        """losses_impl.py:281-296."""
+        labels = _t(labels)
+        labels = torch.where(is_label_valid(labels), labels, torch.zeros_like(labels))
+        gain = self._gain_fn(labels)
+        if self._normalized:
+            gain = gain * inverse_max_dcg(labels, gain_fn=self._gain_fn,
+                                          rank_discount_fn=self._rank_discount_fn,
+                                          topn=self._topn)
+        rank_discount = self._rank_discount_fn(_t(ranks).to(torch.float32))
+        return gain * rank_discount
+
+
+def NDCGLambdaWeight(topn=None, gain_fn=None, rank_discount_fn=None, smooth_fraction=0.0):
+    """keras/losses.py:197-212."""
+    return DCGLambdaWeight(topn, gain_fn or pow_minus_1, rank_discount_fn or log2_inverse,
+                           normalized=True, smooth_fraction=smooth_fraction)
+
+
+def create_ndcg_lambda_weight(topn=None, smooth_fraction=0.0):
+    """losses.py:450-457."""
+    return DCGLambdaWeight(topn, gain_fn=pow_minus_1, rank_discount_fn=log1p_inverse,
+                           normalized=True, smooth_fraction=smooth_fraction)
+
+
+# ----------------------------------------------------------------------------
+# Gumbel sampler (losses_impl.py:540-649).
+# ----------------------------------------------------------------------------
+def gumbel_noise_from_uniform(u, eps=1e-20):
+    """losses_impl.py:647-649."""
+    return -torch.log(-torch.log(u + eps) + eps)
+
+
+class GumbelSampler:
+    """losses_impl.py:540-644.  The uniform noise is injected (``uniform``
+    [B, S, L]) or drawn from a torch generator; TF's Philox stream cannot be
+    reproduced ("parity unpinned" for the noise values)."""
+
+    def __init__(self, sample_size=8, temperature=1.0, seed=None):
+        self._sample_size = sample_size
+        self._temperature = temperature
+        self._seed = seed
+
+    def sample(self, labels, logits, weights=None, uniform=None):
+        labels = _t(labels)
+        logits = _t(logits)
+        b, l = labels.shape
+        s = self._sample_size
+        expanded_labels = labels.unsqueeze(1).repeat(1, s, 1).reshape(b * s, l)
+        if uniform is None:
+            gen = torch.Generator().manual_seed(0 if self._seed is None else self._seed)
+            uniform = torch.rand((b, s, l), generator=gen, dtype=torch.float32)
+        sampled = logits.unsqueeze(1).repeat(1, s, 1) + gumbel_noise_from_uniform(uniform)
+        sampled = sampled.reshape(b * s, l)
+        valid = is_label_valid(expanded_labels)
+        sampled = torch.where(valid, sampled / self._temperature,
+                              math.log(1e-20) * torch.ones_like(sampled))
+        sampled = torch.log(torch.softmax(sampled, dim=-1) + 1e-20)
+        expanded_weights = weights
+        if expanded_weights is not None:
+            w = _t(expanded_weights)
+            if w.dim() == 1:
+                w = w.unsqueeze(1).unsqueeze(1)
+            else:
+                w = w.unsqueeze(1)
+            w = w.repeat(1, s, 1)
+            expanded_weights = w.reshape(b * s, -1)
+        return expanded_labels, sampled, expanded_weights
+
+
+# ----------------------------------------------------------------------------
+# Losses (losses_impl.py:652-1603).
+# ----------------------------------------------------------------------------
+class _RankingLoss:
+    """losses_impl.py:652-860."""
+
+    def __init__(self, name=None, lambda_weight=None, temperature=1.0, ragged=False):
+        self._name = name
+        self._lambda_weight = lambda_weight
+        self._temperature = temperature
+        self._ragged = ragged
+
+    def _prepare_and_validate_params(self, labels, logits, weights, mask):
+        if self._ragged:
+            labels, logits, weights, mask = ragged_to_dense(labels, logits, weights)
+        labels = _t(labels)
+        if mask is None:
+            mask = is_label_valid(labels)
+        if weights is None:
+            weights = 1.0
+        return labels, _t(logits), _t(weights), _t(mask, torch.bool)
+
+    def compute_unreduced_loss(self, labels, logits, mask=None):
+        labels, logits, _, mask = self._prepare_and_validate_params(labels, logits, None, mask)
+        return self._compute_unreduced_loss_impl(labels, logits, mask)
+
+    def normalize_weights(self, labels, weights):
+        if self._ragged:
+            labels, _, weights, _ = ragged_to_dense(labels, None, weights)
+        return self._normalize_weights_impl(_t(labels), None if weights is None else _t(weights))
+
+    def _normalize_weights_impl(self, labels, weights):
+        return 1.0 if weights is None else weights
+
+    def get_logits(self, logits):
+        return _t(logits) / self._temperature
+
+    def compute(self, labels, logits, weights, reduction, mask=None):
+        """losses_impl.py:787-814."""
+        labels = _t(labels)
+        logits = self.get_logits(logits)
+        if mask is not None:
+            mask = _t(mask, torch.bool)
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        weights = _t(self._normalize_weights_impl(labels, None if weights is None else _t(weights))) \
+            * loss_weights
+        return compute_weighted_loss_v1(losses, weights, reduction)
+
+
+class _PairwiseLoss(_RankingLoss):
+    """losses_impl.py:863-930."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        ranks = _compute_ranks(logits, mask)
+        pairwise_labels, pairwise_logits = _pairwise_comparison(labels, logits, mask)
+        pairwise_weights = pairwise_labels
+        if self._lambda_weight is not None:
+            pairwise_weights = pairwise_weights * self._lambda_weight.pair_weights(labels, ranks)
+        pairwise_weights = pairwise_weights.detach()
+        return self._pairwise_loss(pairwise_logits), pairwise_weights
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        labels, logits, weights, mask = self._prepare_and_validate_params(
+            labels, logits, weights, mask)
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        weights = self._normalize_weights_impl(labels, weights) * loss_weights
+        weighted = losses * weights
+        per_list_weights = weights.sum(dim=(1, 2))
+        per_list_losses = weighted.sum(dim=(1, 2))
+        return _safe_div(per_list_losses, per_list_weights), per_list_weights
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            weights = 1.0
+        weights = torch.where(is_label_valid(labels), torch.ones_like(labels) * weights,
+                              torch.zeros_like(labels))
+        return weights.unsqueeze(2)
+
+
+class PairwiseLogisticLoss(_PairwiseLoss):
+    """losses_impl.py:933-940."""
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.relu(-pairwise_logits) + torch.log1p(torch.exp(-torch.abs(pairwise_logits)))
+
+
+class PairwiseHingeLoss(_PairwiseLoss):
+    """losses_impl.py:943-948 (used only to pin compute_per_list goldens)."""
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.relu(1 - pairwise_logits)
+
+
+class _ListwiseLoss(_RankingLoss):
+    """losses_impl.py:1001-1033."""
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            return 1.0
+        weights = _t(weights)
+        is_valid = is_label_valid(labels)
+        labels = torch.where(is_valid, labels, torch.zeros_like(labels))
+        return _safe_div((weights * labels).sum(dim=1, keepdim=True),
+                         labels.sum(dim=1, keepdim=True))
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        # NB: no temperature here (losses_impl.py:1017-1033); weights=None has
+        # already become 1.0 in _prepare_and_validate_params (:689-690).
+        labels, logits, weights, mask = self._prepare_and_validate_params(
+            labels, logits, weights, mask)
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        weights = _t(self._normalize_weights_impl(labels, weights)) * loss_weights
+        return losses.squeeze(1), weights.squeeze(1)
+
+
+class SoftmaxLoss(_ListwiseLoss):
+    """losses_impl.py:1119-1197."""
+
+    def precompute(self, labels, logits, weights, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        ranks = _compute_ranks(logits, mask)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, math.log(_EPSILON) * torch.ones_like(logits))
+        if self._lambda_weight is not None and isinstance(self._lambda_weight, DCGLambdaWeight):
+            labels = self._lambda_weight.individual_weights(labels, ranks)
+        if weights is not None:
+            labels = labels * weights
+        return labels, logits
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        padded_labels = torch.where(nonzero_mask.unsqueeze(1), labels,
+                                    _EPSILON * torch.ones_like(labels))
+        padded_labels = torch.where(mask, padded_labels, torch.zeros_like(padded_labels))
+        padded_label_sum = padded_labels.sum(dim=1, keepdim=True)
+        labels_for_softmax = _safe_div(padded_labels, padded_label_sum)
+        weights_for_softmax = label_sum.reshape(-1)
+        losses = -(labels_for_softmax * torch.log_softmax(logits, dim=1)).sum(dim=1)
+        return losses, weights_for_softmax
+
+    def compute(self, labels, logits, weights, reduction, mask=None):
+        labels, logits, weights, mask = self._prepare_and_validate_params(
+            labels, logits, weights, mask)
+        logits = self.get_logits(logits)
+        labels, logits = self.precompute(labels, logits, weights, mask)
+        losses, weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        return compute_weighted_loss_v1(losses, weights, reduction)
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        labels, logits, weights, mask = self._prepare_and_validate_params(
+            labels, logits, weights, mask)
+        logits = self.get_logits(logits)
+        labels, logits = self.precompute(labels, logits, weights, mask)
+        return self._compute_unreduced_loss_impl(labels, logits, mask)
+
+    def compute_unreduced_loss(self, labels, logits, mask=None):
+        labels, logits, _, mask = self._prepare_and_validate_params(labels, logits, None, mask)
+        logits = self.get_logits(logits)
+        labels, logits = self.precompute(labels, logits, weights=None, mask=mask)
+        return self._compute_unreduced_loss_impl(labels, logits, mask)
+
+
+class ApproxNDCGLoss(_ListwiseLoss):
+    """losses_impl.py:1579-1603."""
+
+    def __init__(self, name=None, lambda_weight=None, temperature=0.1, ragged=False):
+        super().__init__(name, lambda_weight, temperature, ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits,
+                             -1e3 * torch.ones_like(logits)
+                             + logits.min(dim=-1, keepdim=True).values)
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        labels = torch.where(nonzero_mask.unsqueeze(1), labels, _EPSILON * torch.ones_like(labels))
+        ranks = approx_ranks(logits)
+        return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
+
+
+class _PointwiseLoss(_RankingLoss):
+    """losses_impl.py:1284-1321."""
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            weights = 1.0
+        return torch.where(is_label_valid(labels), torch.ones_like(labels) * weights,
+                           torch.zeros_like(labels))
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        labels, logits, weights, mask = self._prepare_and_validate_params(
+            labels, logits, weights, mask)
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        weights = self._normalize_weights_impl(labels, weights) * loss_weights
+        per_list_weights = weights.sum(dim=1)
+        per_list_losses = (losses * weights).sum(dim=1)
+        return _safe_div(per_list_losses, per_list_weights), per_list_weights
+
+
+class SigmoidCrossEntropyLoss(_PointwiseLoss):
+    """losses_impl.py:1425-1446 (config 1, CPU reference path only)."""
+
+    def __init__(self, name=None, temperature=1.0, ragged=False):
+        super().__init__(name, None, temperature, ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        losses = torch.relu(logits) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
+        return losses, mask.to(logits.dtype)
+
+
+# ----------------------------------------------------------------------------
+# Keras-level wrappers (keras/losses.py:247-335, 824-832, 1332-1341).
+# ----------------------------------------------------------------------------
+def keras_loss_call(loss, y_true, y_pred, sample_weight=None, reduction=Reduction.AUTO,
+                    gumbel_sampler: Optional[GumbelSampler] = None, uniform=None):
+    """Restates ``tfr.keras.losses.<Loss>.__call__`` for an L1 ``loss`` object."""
+    if gumbel_sampler is not None:       # keras/losses.py:1332-1341
+        y_true, y_pred, sample_weight = gumbel_sampler.sample(
+            y_true, y_pred, weights=sample_weight, uniform=uniform)
+    if isinstance(loss, SoftmaxLoss):    # keras/losses.py:824-832
+        losses, sw = loss.compute_per_list(y_true, y_pred, sample_weight)
+        return keras_compute_weighted_loss(losses, sw, reduction)
+    sw = loss.normalize_weights(y_true, sample_weight)          # :270
+    logits = y_pred
+    if not loss._ragged:
+        logits = loss.get_logits(y_pred)                         # :277
+        losses, weights = loss.compute_unreduced_loss(labels=y_true, logits=logits)
+    else:
+        # ragged: get_logits on the dense view (temperature is a scalar divide).
+        dl, dp, _, _ = ragged_to_dense(y_true, y_pred, None)
+        saved, loss._ragged = loss._ragged, False
+        try:
+            losses, weights = loss.compute_unreduced_loss(labels=dl, logits=loss.get_logits(dp))
+        finally:
+            loss._ragged = saved
+    out = losses * weights
+    if isinstance(loss, _PairwiseLoss):  # keras/losses.py:324-335
+        out = out.sum(dim=2)
+    return keras_compute_weighted_loss(out, sw, reduction)
+
+
+# ----------------------------------------------------------------------------
+# metrics_impl.py
+# ----------------------------------------------------------------------------
+def tree_sum(x):
+    """Fixed-order fp32 row sum shared with the HIP metric kernel so that
+    NDCG@k is bit-reproducible: zero-pad the row to P = next power of two, then
+    repeatedly fold the upper half onto the lower half (t[i] += t[i + h]).
+    (The reference's tf.reduce_sum order is TF/Eigen-internal and unknowable
+    here; any order is within 1e-6 of the reference literals.)"""
+    x = _t(x)
+    n = x.shape[1]
+    p = 1
+    while p < n:
+        p *= 2
+    if p != n:
+        x = torch.cat([x, torch.zeros(x.shape[0], p - n, dtype=x.dtype)], dim=1)
+    h = p // 2
+    while h >= 1:
+        x = x[:, :h] + x[:, h:2 * h]
+        h //= 2
+    return x  # [B, 1]
+
+
+def _per_example_weights_to_per_list_weights(weights, relevance, row_sum=None):
+    """metrics_impl.py:63-119."""
+    rs = row_sum or (lambda t: t.sum(dim=1, keepdim=True))
+    nonzero_weights = rs(weights) > 0.0
+    per_list_relevance = rs(relevance)
+    nonzero_relevance = torch.where(nonzero_weights, (per_list_relevance > 0.0).to(torch.float32),
+                                    torch.zeros_like(per_list_relevance))
+    nonzero_relevance_count = nonzero_relevance.sum(dim=0, keepdim=True)
+    per_list_weights = _safe_div(rs(weights * relevance), per_list_relevance)
+    sum_weights = per_list_weights.sum(dim=0, keepdim=True)
+    avg_weight = torch.where(nonzero_relevance_count > 0.0,
+                             _safe_div(sum_weights, nonzero_relevance_count),
+                             torch.ones_like(nonzero_relevance_count))
+    return torch.where(nonzero_weights,
+                       torch.where(per_list_relevance > 0.0, per_list_weights,
+                                   torch.ones_like(per_list_weights) * avg_weight),
+                       torch.zeros_like(per_list_weights))
+
+
+def _discounted_cumulative_gain(labels, weights, gain_fn=pow_minus_1,
+                                rank_discount_fn=log2_inverse, row_sum=None):
+    """metrics_impl.py:122-151."""
+    rs = row_sum or (lambda t: t.sum(dim=1, keepdim=True))
+    list_size = labels.shape[1]
+    position = torch.arange(1, list_size + 1, dtype=torch.float32)
+    gain = gain_fn(labels.to(torch.float32))
+    discount = rank_discount_fn(position)
+    return rs(weights * gain * discount)
+
+
+class _RankingMetric:
+    """metrics_impl.py:210-310."""
+
+    def __init__(self, ragged=False):
+        self._ragged = ragged
+
+    def _prepare_and_validate_params(self, labels, predictions, weights, mask):
+        labels = _t(labels)
+        predictions = _t(predictions)
+        weights = 1.0 if weights is None else _t(weights)
+        example_weights = torch.ones_like(labels) * weights
+        if mask is None:
+            mask = is_label_valid(labels)
+        mask = torch.logical_and(_t(mask, torch.bool), example_weights > 0.0)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        predictions = torch.where(
+            mask, predictions,
+            -1e-6 * torch.ones_like(predictions) + predictions.min(dim=1, keepdim=True).values)
+        return labels, predictions, example_weights, mask
+
+    def compute(self, labels, predictions, weights=None, mask=None):
+        if self._ragged:
+            labels, predictions, weights, mask = ragged_to_dense(labels, predictions, weights)
+        labels, predictions, weights, mask = self._prepare_and_validate_params(
+            labels, predictions, weights, mask)
+        return self._compute_impl(labels, predictions, weights, mask)
+
+
+class MRRMetric(_RankingMetric):
+    """metrics_impl.py:429-459."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        sorted_labels, = sort_by_scores(predictions, [labels], topn=topn, mask=mask)
+        n = sorted_labels.shape[1]
+        relevance = (sorted_labels >= 1.0).to(torch.float32)
+        reciprocal_rank = 1.0 / torch.arange(1, n + 1, dtype=torch.float32)
+        mrr = (relevance * reciprocal_rank).max(dim=1, keepdim=True).values
+        per_list_weights = _per_example_weights_to_per_list_weights(
+            weights=weights, relevance=(labels >= 1.0).to(torch.float32), row_sum=tree_sum)
+        return mrr, per_list_weights
+
+
+class NDCGMetric(_RankingMetric):
+    """metrics_impl.py:631-670.  Row sums use ``tree_sum`` (see its docstring)."""
+
+    def __init__(self, name=None, topn=None, gain_fn=pow_minus_1, rank_discount_fn=log2_inverse,
+                 ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+        self._gain_fn = gain_fn
+        self._rank_discount_fn = rank_discount_fn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        sorted_labels, sorted_weights = sort_by_scores(
+            predictions, [labels, weights], topn=topn, mask=mask)
+        dcg = _discounted_cumulative_gain(sorted_labels, sorted_weights, self._gain_fn,
+                                          self._rank_discount_fn, row_sum=tree_sum)
+        weighted_gains = weights * self._gain_fn(labels.to(torch.float32))
+        ideal_sorted_labels, ideal_sorted_weights = sort_by_scores(
+            weighted_gains, [labels, weights], topn=topn, mask=mask)
+        ideal_dcg = _discounted_cumulative_gain(ideal_sorted_labels, ideal_sorted_weights,
+                                                self._gain_fn, self._rank_discount_fn,
+                                                row_sum=tree_sum)
+        per_list_ndcg = _safe_div(dcg, ideal_dcg)
+        per_list_weights = _per_example_weights_to_per_list_weights(
+            weights=weights, relevance=self._gain_fn(labels.to(torch.float32)), row_sum=tree_sum)
+        return per_list_ndcg, per_list_weights
+
+
+def keras_metric_mean(metric, batches):
+    """keras/metrics.py:156-193: running weighted mean over update_state calls.
+    ``batches`` = iterable of (y_true, y_pred, sample_weight)."""
+    total = torch.zeros((), dtype=torch.float32)
+    count = torch.zeros((), dtype=torch.float32)
+    for y_true, y_pred, sw in batches:
+        val, w = metric.compute(y_true, y_pred, sw)
+        total = total + (val * w).sum()
+        count = count + w.sum()
+    return _safe_div(total, count)
+
+
+# ----------------------------------------------------------------------------
+# Scorer pieces (keras/layers.py:26-77,126-175,231-265; model.py:164-244,341-421).
+# ----------------------------------------------------------------------------
+def padded_nd_indices(is_valid):
+    """utils.py:308-356 with shuffle=False: per row, valid indices first (in
+    order), then padding slots filled circularly with the valid indices.
+    Returns the [B, L] index of the source item for each slot."""
+    is_valid = _t(is_valid, torch.bool)
+    b, l = is_valid.shape
+    # organize_valid_indices: valid first, stable.
+    keys = torch.where(is_valid, torch.zeros(b, l), torch.ones(b, l))
+    order = torch.sort(keys, dim=1, stable=True).indices
+    n_valid = is_valid.sum(dim=1, keepdim=True)
+    pos = torch.arange(l).unsqueeze(0).expand(b, l)
+    circ = torch.where(n_valid > 0, pos % torch.clamp(n_valid, min=1), torch.zeros_like(pos))
+    return torch.gather(order, 1, circ)
+
+
+def flatten_list(context, example, mask):
+    """keras/layers.py:126-175 (circular padding, tile context, flatten)."""
+    mask = _t(mask, torch.bool)
+    b, l = mask.shape
+    idx = padded_nd_indices(mask)
+    flat_ctx = None
+    if context is not None:
+        flat_ctx = context.unsqueeze(1).repeat(1, l, 1).reshape(b * l, -1)
+    g = torch.gather(example, 1, idx.unsqueeze(-1).expand(-1, -1, example.shape[2]))
+    return flat_ctx, g.reshape(b * l, -1)
+
+
+def restore_list(flattened_logits, mask):
+    """keras/layers.py:231-265: reshape to [B, L]; invalid := log(1e-10)."""
+    mask = _t(mask, torch.bool)
+    logits = flattened_logits.reshape(mask.shape)
+    return torch.where(mask, logits, math.log(_EPSILON) * torch.ones_like(logits))
+
+
+def dnn_tower(x, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+              activation=torch.relu):
+    """keras/layers.py:26-77 with use_batch_norm=False, dropout=0 (inference /
+    deterministic path): Dense->act for hidden layers, final Dense(output_units)."""
+    for i, (w, bias) in enumerate(zip(weights, biases)):
+        x = x @ w + bias
+        if i < len(weights) - 1:
+            x = activation(x)
+    return x
+
+
+def rolling_window_indices(size, rw_size, num_valid_entries):
+    """model.py:164-202."""
+    num_valid_entries = torch.as_tensor(num_valid_entries).reshape(-1, 1, 1)
+    rw = (torch.arange(rw_size).unsqueeze(0) + torch.arange(size).unsqueeze(1)).unsqueeze(0)
+    batch = num_valid_entries.shape[0]
+    rw = rw.repeat(batch, 1, 1)
+    return torch.remainder(rw, torch.clamp(num_valid_entries, min=1)) * (num_valid_entries > 0)
