@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- lists/sec of the ranking-loss hot path on MI355X.
+
+Headline (BASELINE.json `metric`): ranked lists/sec, loss forward+backward,
+ApproxNDCG (temperature 0.1) at list_size=200, 16384 lists per GPU per step
+(SURVEY.md 8d row H), synthetic inputs already resident in HBM.  A "step" is one
+pass of the hot path over one batch: one fused kernel launch that produces the
+per-list loss AND d loss / d logits, plus the [B]-vector dot that reduces the
+loss to a scalar.
+
+    python bench.py --gpus N --steps K --warmup W [--workload NAME]
+
+For N > 1 the driver launches one rank per GPU with torch.distributed.run; lists
+shard across ranks with no data-path collective (the loss path has no exchange
+step: SURVEY.md 8e) -> "scaling": "weak".  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (B per GPU, L, description, algorithmic HBM bytes per list)
+    'approx_ndcg': (16384, 200, 'ApproxNDCGLoss(T=0.1) loss fwd+bwd, B=16384/GPU, L=200 (SURVEY 8d row H)',
+                    lambda L: 12 * L + 12),
+    'approx_ndcg_l1000': (512, 1000, 'ApproxNDCGLoss(T=0.1) loss fwd+bwd, B=512/GPU, L=1000 (config 4 shard)',
+                          lambda L: 12 * L + 12),
+    'pairwise_lambda': (4096, 200, 'PairwiseLogisticLoss+NDCGLambdaWeight loss fwd+bwd, B=4096, L=200 (config 3)',
+                        lambda L: 12 * L + 12),
+    'softmax': (4096, 100, 'SoftmaxLoss loss fwd+bwd, B=4096, L=100 (config 2 loss part)',
+                lambda L: 12 * L + 12),
+    'gumbel_approx_ndcg': (512, 50, 'GumbelApproxNDCGLoss(S=8) loss fwd+bwd, B=512/GPU, L=50 (config 5 loss part)',
+                           lambda L: 12 * L + 12),
+    'ndcg_metric': (16384, 200, 'NDCG@{1,3,5,10,all} metric, B=16384, L=200',
+                    lambda L: 8 * L + 6 * 4),
+}
+
+
+def make_inputs(B, L, seed, device):
+    from tests.common import make_batch
+    labels, logits = make_batch(B, L, seed)
+    return labels.to(device), logits.to(device)
+
+
+def build_step(workload, labels, logits):
+    """Returns (step_fn, kernel_fn) -- kernel_fn launches only the dominant kernel."""
+    from ranking_amd import _ops
+    from ranking_amd.keras import losses as K
+    from ranking_amd import metrics_impl
+    if workload.startswith('approx_ndcg'):
+        loss = K.ApproxNDCGLoss()
+        B = labels.shape[0]
+        scale = torch.full((B,), 1.0 / B, dtype=torch.float32, device=labels.device)
+        return (lambda: loss.loss_and_grad(labels, logits),
+                lambda: _ops.approx_ndcg(logits, labels, None, scale, 0.1, 0, True))
+    if workload == 'pairwise_lambda':
+        loss = K.PairwiseLogisticLoss(lambda_weight=K.NDCGLambdaWeight())
+        return (lambda: loss.loss_and_grad(labels, logits)), None
+    if workload == 'softmax':
+        loss = K.SoftmaxLoss()
+        return (lambda: loss.loss_and_grad(labels, logits)), None
+    if workload == 'gumbel_approx_ndcg':
+        loss = K.GumbelApproxNDCGLoss(seed=1)
+        return (lambda: loss.loss_and_grad(labels, logits)), None
+    if workload == 'ndcg_metric':
+        m = metrics_impl.NDCGMetric(None, None)
+        return (lambda: m.compute_multi(labels, logits, None, None, [1, 3, 5, 10, None])), None
+    raise ValueError(workload)
+
+
+def cpu_baseline(workload, L, budget_s=12.0):
+    """Times the torch-CPU restatement of the reference op graph (oracle/) on a
+    bounded sample of the same workload: fwd + autograd bwd, all host cores."""
+    from oracle import tfr_ref as R
+    from tests.common import make_batch
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    if not workload.startswith('approx_ndcg'):
+        return None
+    loss = R.ApproxNDCGLoss()
+
+    def run(labels, logits):
+        lg = logits.clone().requires_grad_(True)
+        out = R.keras_loss_call(loss, labels, lg)
+        out.backward()
+        return lg.grad
+
+    Bc = max(8, min(1024, int(2.0e7 // (L * L))))       # [Bc, L, L] fp32 tensors of <= 80 MB
+    labels, logits = make_batch(Bc, L, seed=4)
+    run(labels, logits)                                 # warm-up
+    t0 = time.perf_counter()
+    run(labels, logits)
+    one = time.perf_counter() - t0
+    iters = max(3, min(200, int(budget_s / max(one, 1e-4))))
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        run(labels, logits)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {'value': Bc / med, 'unit': 'lists/s', 'cores': cores, 'kind': 'port',
+            'sample': 'torch-CPU restatement of the TF-Ranking op graph (oracle/tfr_ref.py), '
+                      'ApproxNDCG fwd+autograd bwd, %d lists x L=%d per iteration, median of %d '
+                      'iterations, fp32' % (Bc, L, iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--traffic-bytes', type=float, default=None,
+                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+
+    B, L, desc, bytes_per_list = WORKLOADS[args.workload]
+    if args.batch > 0:
+        B = args.batch
+    labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
+    step, kernel_only = build_step(args.workload, labels, logits)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant-kernel duration: HIP events on the launch stream, kernel launches only.
+    kernel_ms = None
+    if kernel_only is not None:
+        stream = torch.cuda.current_stream()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+               for _ in range(args.steps)]
+        torch.cuda.synchronize()
+        for a, b in evs:
+            a.record(stream)
+            kernel_only()
+            b.record(stream)
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in evs)
+        kernel_ms = sum(ts) / len(ts)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    lists = B * world * args.steps
+    value = lists / elapsed
+    result = {
+        'metric': 'ranked lists/sec (fwd+bwd), ApproxNDCG list_size=200' if args.workload == 'approx_ndcg'
+                  else 'ranked lists/sec, %s' % args.workload,
+        'value': value, 'unit': 'lists/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': desc, 'lists_per_gpu_per_step': B, 'list_size': L,
+                   'valid_length': 'U{ceil(L/2)..L}', 'labels': 'randint{0..4}, -1 padding',
+                   'logits': 'N(0,1) tie-free', 'parallelism': 'dp%d (lists sharded, no collective)' % world},
+    }
+    if kernel_ms is not None:
+        algo_bytes = bytes_per_list(L) * B
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        result['roofline'] = {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': args.traffic_bytes,
+            'kernel': 'approx_ndcg_kernel', 'kernel_ms': kernel_ms,
+            'algorithmic_bytes_per_launch': algo_bytes,
+            'note': 'O(L^2) pair work is on-chip: the kernel is VALU/transcendental bound, the HBM '
+                    'fraction is reported as the contract asks; see DESIGN.md for the VALU roofline',
+            'pairs_per_s': None,
+        }
+        n_valid_sq = float(((labels >= 0).sum(dim=1).double() ** 2).sum().item())
+        result['roofline']['pairs_per_s'] = 2.0 * n_valid_sq / (kernel_ms * 1e-3)   # fwd + bwd evaluations
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(args.workload, L)
+        if cb is not None:
+            result['cpu_baseline'] = cb
+            result['gpu_over_cpu'] = value / cb['value']
+    print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,141 @@
+/* tfr_hip.h -- C ABI of libtfr_hip.so: the MI355X (gfx950) ranking-loss hot path.
+ *
+ * The reference (tensorflow/ranking) has NO native / FFI boundary: its hot path
+ * is a chain of TensorFlow ops behind duck-typed Python classes.  This header
+ * is therefore the boundary we DEFINE; each entry point cites the reference
+ * Python interface it replaces (paths relative to
+ * /root/reference/tensorflow_ranking/python/).  The Python mirror of those
+ * classes lives in ranking_amd/ and binds these symbols with ctypes
+ * (see INTEGRATION.md for the stub a reference maintainer would add).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller unless the name
+ *     ends in _host; kernels allocate nothing and keep no state;
+ *   - tensors are dense row-major fp32 [B, L] unless stated; `mask` is uint8
+ *     (0/1) and nullable: when NULL an item is valid iff label >= 0
+ *     (utils.py:78-81);
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); the call
+ *     never synchronises and is re-entrant;
+ *   - return 0 = ok, <0 = invalid argument (TFR_EINVAL -1, TFR_ETOOLARGE -2:
+ *     L > 8192), >0 = hipError_t from the launch.
+ *   - tie rule (the reference shuffles ties at random, utils.py:100-112):
+ *     descending score, equal scores by `tiebreak` then by index, invalid last.
+ */
+#ifndef TFR_HIP_H_
+#define TFR_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFR_MAX_TOPN 8
+
+/* gain_kind */
+#define TFR_GAIN_IDENTITY 0   /* keras/utils.py:51  identity                  */
+#define TFR_GAIN_POW2M1 1     /* keras/utils.py:79  2^l - 1                   */
+#define TFR_GAIN_CUSTOM 2     /* caller passes gains[B,L] = gain_fn(clean l)  */
+
+/* lambda_kind */
+#define TFR_LAMBDA_NONE 0
+#define TFR_LAMBDA_DCG 2      /* losses_impl.py:299-369 DCGLambdaWeight       */
+#define TFR_LAMBDA_LABELDIFF 1 /* losses_impl.py:210-217                      */
+
+int tfr_hip_abi_version(void);
+
+/* utils.sort_by_scores / utils.sorted_ranks / losses_impl._compute_ranks
+ * (utils.py:115-195, losses_impl.py:483-500).
+ *   valid_i = mask ? mask_i : (labels ? labels_i >= 0 : 1)
+ *   order_out[b, p]  = index of the item at sorted position p (nullable)
+ *   ranks_out[b, i]  = 1-based rank of item i (nullable)
+ *   tiebreak[b, i]   = optional int32 secondary key in [0, 32768) (nullable). */
+int tfr_sort_ranks_f32(const float* scores, const float* labels, const uint8_t* mask,
+                       const int32_t* tiebreak, int B, int L,
+                       int32_t* ranks_out, int32_t* order_out, void* stream);
+
+/* metrics_impl.NDCGMetric.compute (metrics_impl.py:228-291, 631-670) for up
+ * to TFR_MAX_TOPN cutoffs at once.
+ *   weights      nullable; [B, L] per item, or [B] per list when weights_per_list
+ *   gains        nullable [B, L] = gain_fn(label or 0 if masked) for a custom
+ *                gain_fn; NULL -> 2^l - 1 evaluated in-kernel
+ *   discount     [L] fp32: rank_discount_fn(r), r = 1..L (host computed table)
+ *   topn_host    HOST array of K cutoffs (<= 0 means L)
+ *   ndcg_out     [K, B]
+ *   stats_out    [B, 3] = (sum w, sum gain, sum w*gain) in tree_sum order; the
+ *                cross-list part of _per_example_weights_to_per_list_weights
+ *                (metrics_impl.py:63-119) is done by the caller on [B] vectors. */
+int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const float* weights,
+                        int weights_per_list, const uint8_t* mask, const float* gains,
+                        const float* discount, const int32_t* topn_host, int K, int B, int L,
+                        float* ndcg_out, float* stats_out, void* stream);
+
+/* metrics_impl.MRRMetric.compute (metrics_impl.py:429-459).
+ *   mrr_out [K, B]; stats_out [B, 3] = (sum w, sum rel, sum w*rel), rel = 1{l>=1}. */
+int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,
+                       int weights_per_list, const uint8_t* mask, const int32_t* topn_host,
+                       int K, int B, int L, float* mrr_out, float* stats_out, void* stream);
+
+/* losses_impl.ApproxNDCGLoss._compute_unreduced_loss_impl fused with its
+ * backward (losses_impl.py:77-167, 1579-1603).
+ *   x = logits / temperature is applied inside (losses_impl.py:773-785)
+ *   inv_log1p    [L] fp32: 1/log1p(r), r = 1..L (host computed table)
+ *   list_scale   nullable [B]: dlogits_out rows are multiplied by it
+ *   loss_out     [B]  -ApproxNDCG per list
+ *   weight_out   [B]  1{sum label > 0}
+ *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
+ *   lanes_per_row  tuning knob (1,2,4,..,64; 0 = default). */
+int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
+                        const float* inv_log1p, const float* list_scale, int B, int L,
+                        float temperature, int lanes_per_row, float* loss_out, float* weight_out,
+                        float* dlogits_out, void* stream);
+
+/* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
+ * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
+ *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)
+ *   list_weights nullable [B]   (per-list weight, multiplies every row)
+ *   gains        nullable [B, L] when gain_kind == TFR_GAIN_CUSTOM
+ *   discount     [L + 1] fp32: rank_discount_fn(r), r = 1..L+1 (DCG lambda only)
+ *   topn <= 0 means L
+ *   row_loss_out   [B, L] sum_j w_i W_ij loss_ij    (nullable)
+ *   row_weight_out [B, L] sum_j w_i W_ij            (nullable)
+ *   nnz_out        [B]    #{(i,j): w_i W_ij != 0}    (nullable)
+ *   dlogits_out    [B, L] d(sum_ij w_i W_ij loss_ij)/d logits (nullable). */
+int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const uint8_t* mask,
+                              const float* item_weights, const float* list_weights,
+                              int lambda_kind, int topn, float smooth_fraction, int normalized,
+                              int gain_kind, const float* gains, const float* discount,
+                              int B, int L, float temperature,
+                              float* row_loss_out, float* row_weight_out, float* nnz_out,
+                              float* dlogits_out, void* stream);
+
+/* losses_impl.SoftmaxLoss.precompute + _compute_unreduced_loss_impl fused with
+ * the backward (losses_impl.py:1119-1197, 281-296).
+ *   item_weights nullable, [B, L] or [B] when weights_per_list
+ *   lambda_kind  TFR_LAMBDA_NONE or TFR_LAMBDA_DCG (individual_weights)
+ *   loss_out     [B] per-list cross entropy
+ *   weight_out   [B] sum of (weighted) labels
+ *   dlogits_out  nullable [B, L] = weight_b * d loss_b / d logits. */
+int tfr_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                         const float* item_weights, int weights_per_list,
+                         int lambda_kind, int topn, int normalized, int gain_kind,
+                         const float* gains, const float* discount, int B, int L,
+                         float temperature, float* loss_out, float* weight_out,
+                         float* dlogits_out, void* stream);
+
+/* losses_impl.GumbelSampler.sample (losses_impl.py:556-649), dense path.
+ *   uniform      nullable [B, S, L] injected U(0,1) noise; NULL -> in-kernel
+ *                Philox4x32-10 keyed by (seed, offset)
+ *   sampled_out  [B*S, L] = log(softmax((logits + G)/gumbel_temperature) + 1e-20)
+ * Backward: dlogits_out[B, L] = sum_s J^T upstream[b*S+s, :]. */
+int tfr_gumbel_sample_f32(const float* logits, const float* labels, const uint8_t* mask,
+                          const float* uniform, uint64_t seed, uint64_t offset, int B, int S,
+                          int L, float gumbel_temperature, float* sampled_out, void* stream);
+int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const uint8_t* mask,
+                              const float* upstream, int B, int S, int L,
+                              float gumbel_temperature, float* dlogits_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* TFR_HIP_H_ */

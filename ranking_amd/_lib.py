@@ -1,0 +1,122 @@
+"""Builds and binds ``libtfr_hip.so`` (the C ABI declared in include/tfr_hip.h).
+
+There is deliberately NO fallback: if the shared library cannot be built or
+loaded, or a tensor is not resident on a HIP device, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
+LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
+SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip']
+HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+               '-fvisibility=default']
+
+_lock = threading.Lock()
+_lib = None
+
+c_f32p = ctypes.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    'tfr_hip_abi_version': (ctypes.c_int, []),
+    'tfr_sort_ranks_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
+    'tfr_ndcg_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+    'tfr_mrr_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p]
+                           + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+    'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                            + [ctypes.c_int] + [ctypes.c_void_p] * 4),
+    'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                                  + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
+                                  + [ctypes.c_float] + [ctypes.c_void_p] * 5),
+    'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
+                             + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
+    'tfr_gumbel_sample_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_uint64] * 2 + [ctypes.c_int] * 3
+                              + [ctypes.c_float] + [ctypes.c_void_p] * 2),
+    'tfr_gumbel_sample_bwd_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float]
+                                  + [ctypes.c_void_p] * 2),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class TfrHipError(RuntimeError):
+    pass
+
+
+def sources_present():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
+    deps.append(os.path.join(INCLUDE, 'tfr_hip.h'))
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compiles every HIP translation unit for gfx950 into libtfr_hip.so (in-tree)."""
+    with _lock:
+        if not force and not _stale():
+            return LIB_PATH
+        hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+        if not os.path.exists(hipcc):
+            raise TfrHipError('hipcc not found: cannot build %s' % LIB_PATH)
+        srcs = [os.path.join(CSRC, s) for s in sources_present()]
+        cmd = [hipcc] + HIPCC_FLAGS + ['-I', INCLUDE] + srcs + ['-o', LIB_PATH + '.tmp']
+        if verbose:
+            print(' '.join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise TfrHipError('hipcc failed:\n%s\n%s' % (res.stdout, res.stderr))
+        os.replace(LIB_PATH + '.tmp', LIB_PATH)
+        return LIB_PATH
+
+
+def load():
+    """Returns the ctypes handle; builds first when the in-tree .so is missing/stale
+    and hipcc is available.  Raises TfrHipError otherwise -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if _stale():
+        hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+        if os.path.exists(hipcc):
+            build()
+        elif not os.path.exists(LIB_PATH):
+            raise TfrHipError('%s is missing and hipcc is unavailable; the HIP extension is '
+                              'mandatory (no CPU fallback).' % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:   # pragma: no cover
+        raise TfrHipError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise TfrHipError('%s does not export %s' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code == -1:
+        raise ValueError('%s: invalid argument (TFR_EINVAL)' % what)
+    if code == -2:
+        raise ValueError('%s: list_size exceeds what one workgroup can hold in LDS '
+                         '(TFR_ETOOLARGE)' % what)
+    raise TfrHipError('%s: hipError_t %d' % (what, code))

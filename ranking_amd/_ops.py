@@ -1,0 +1,254 @@
+"""Torch-tensor level bindings of the C ABI (include/tfr_hip.h).
+
+PyTorch is used here for device memory and streams only: every function
+checks that its tensors live on a HIP device, enqueues ONE kernel on torch's
+current stream and returns freshly allocated outputs.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+GAIN_IDENTITY, GAIN_POW2M1, GAIN_CUSTOM = 0, 1, 2
+LAMBDA_NONE, LAMBDA_LABELDIFF, LAMBDA_DCG = 0, 1, 2
+MAX_TOPN = 8
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not torch.is_tensor(t):
+        raise TypeError('%s must be a torch.Tensor' % name)
+    if not t.is_cuda:
+        raise _lib.TfrHipError(
+            '%s is on %s: ranking_amd runs on MI355X only (no CPU fallback). Move the tensor to '
+            'a HIP device.' % (name, t.device))
+    return t
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    require_device(t, name)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _u8(t, name):
+    if t is None:
+        return None
+    require_device(t, name)
+    if t.dtype != torch.uint8:
+        t = t.to(torch.uint8)
+    return t.contiguous()
+
+
+def _check2d(t, name):
+    if t.dim() != 2:
+        raise ValueError('%s must have rank 2, got shape %s' % (name, tuple(t.shape)))
+
+
+def _same_shape(a, b, na, nb):
+    if a.shape != b.shape:
+        raise ValueError('%s %s is not compatible with %s %s' % (na, tuple(a.shape), nb, tuple(b.shape)))
+
+
+# ------------------------------------------------------------------ tables
+_table_cache: Dict[Tuple, torch.Tensor] = {}
+
+
+def rank_table(fn: Callable, n: int, device) -> torch.Tensor:
+    """fp32 table fn(r), r = 1..n, evaluated ONCE on the host (so that it is
+    bit-identical to what the CPU oracle uses) and cached on the device."""
+    key = (fn, int(n), str(device))
+    t = _table_cache.get(key)
+    if t is None:
+        r = torch.arange(1, n + 1, dtype=torch.float32)
+        v = fn(r)
+        if not torch.is_tensor(v):
+            v = torch.as_tensor(v, dtype=torch.float32)
+        v = torch.broadcast_to(v.to(torch.float32), r.shape).contiguous()
+        t = v.to(device)
+        if len(_table_cache) > 256:
+            _table_cache.clear()
+        _table_cache[key] = t
+    return t
+
+
+def _inv_log1p(rank):
+    return 1.0 / torch.log1p(rank)
+
+
+# -------------------------------------------------------------------- sort
+def sort_ranks(scores, labels=None, mask=None, tiebreak=None, want_ranks=True, want_order=True):
+    scores = _f32(scores, 'scores'); _check2d(scores, 'scores')
+    labels = _f32(labels, 'labels'); mask = _u8(mask, 'mask')
+    if tiebreak is not None:
+        tiebreak = require_device(tiebreak, 'tiebreak').to(torch.int32).contiguous()
+    B, L = scores.shape
+    ranks = torch.empty((B, L), dtype=torch.int32, device=scores.device) if want_ranks else None
+    order = torch.empty((B, L), dtype=torch.int32, device=scores.device) if want_order else None
+    rc = _lib.load().tfr_sort_ranks_f32(_ptr(scores), _ptr(labels), _ptr(mask), _ptr(tiebreak), B, L,
+                                        _ptr(ranks), _ptr(order), _stream())
+    _lib.check(rc, 'tfr_sort_ranks_f32')
+    return ranks, order
+
+
+def _topn_array(topns: Sequence[Optional[int]]):
+    if not 1 <= len(topns) <= MAX_TOPN:
+        raise ValueError('between 1 and %d cutoffs per call' % MAX_TOPN)
+    arr = (ctypes.c_int32 * len(topns))(*[0 if t is None else int(t) for t in topns])
+    return arr
+
+
+def _weights_arg(weights, labels):
+    """Returns (tensor or None, per_list flag) for [B,L] / [B,1] / [B] / scalar weights."""
+    if weights is None:
+        return None, 0
+    if not torch.is_tensor(weights):
+        weights = torch.as_tensor(weights, dtype=torch.float32, device=labels.device)
+    weights = _f32(weights, 'weights')
+    B, L = labels.shape
+    if weights.dim() == 0:
+        return weights.expand(B).contiguous(), 1
+    if weights.dim() == 1 and weights.shape[0] == B:
+        return weights, 1
+    if weights.dim() == 2 and weights.shape == (B, 1):
+        return weights.reshape(B).contiguous(), 1
+    if weights.dim() == 2 and weights.shape == (B, L):
+        return weights, 0
+    raise ValueError('weights shape %s is not compatible with labels %s'
+                     % (tuple(weights.shape), (B, L)))
+
+
+def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns):
+    labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
+    _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
+    w, per_list = _weights_arg(weights, labels)
+    mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
+    B, L = labels.shape
+    K = len(topns)
+    out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
+    stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().tfr_ndcg_metric_f32(_ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
+                                         _ptr(gains), _ptr(discount), _topn_array(topns), K, B, L,
+                                         _ptr(out), _ptr(stats), _stream())
+    _lib.check(rc, 'tfr_ndcg_metric_f32')
+    return out, stats
+
+
+def mrr_metric(labels, predictions, weights, mask, topns):
+    labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
+    _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
+    w, per_list = _weights_arg(weights, labels)
+    mask = _u8(mask, 'mask')
+    B, L = labels.shape
+    K = len(topns)
+    out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
+    stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().tfr_mrr_metric_f32(_ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
+                                        _topn_array(topns), K, B, L, _ptr(out), _ptr(stats), _stream())
+    _lib.check(rc, 'tfr_mrr_metric_f32')
+    return out, stats
+
+
+# ------------------------------------------------------------------ losses
+def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lanes_per_row=0,
+                want_grad=True):
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
+    B, L = logits.shape
+    tab = rank_table(_inv_log1p, L, logits.device)
+    loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    rc = _lib.load().tfr_approx_ndcg_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
+                                         _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
+                                         _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_approx_ndcg_f32')
+    return loss, weight, dlogits
+
+
+def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
+                      lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
+                      gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
+                      want_grad=True, want_rows=True):
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); item_weights = _f32(item_weights, 'item_weights')
+    list_weights = _f32(list_weights, 'list_weights'); gains = _f32(gains, 'gains')
+    discount = _f32(discount, 'discount')
+    B, L = logits.shape
+    dev = logits.device
+    row_loss = torch.empty((B, L), dtype=torch.float32, device=dev) if want_rows else None
+    row_weight = torch.empty((B, L), dtype=torch.float32, device=dev) if want_rows else None
+    nnz = torch.empty((B,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
+    rc = _lib.load().tfr_pairwise_logistic_f32(
+        _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
+        int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
+        _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
+        _ptr(nnz), _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_pairwise_logistic_f32')
+    return row_loss, row_weight, nnz, dlogits
+
+
+def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NONE, topn=0,
+                 normalized=False, gain_kind=GAIN_IDENTITY, gains=None, discount=None,
+                 temperature=1.0, want_grad=True):
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
+    w, per_list = _weights_arg(weights, labels)
+    B, L = logits.shape
+    dev = logits.device
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    weight = torch.empty((B,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
+    rc = _lib.load().tfr_softmax_loss_f32(
+        _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),
+        int(bool(normalized)), int(gain_kind), _ptr(gains), _ptr(discount), B, L, float(temperature),
+        _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_softmax_loss_f32')
+    return loss, weight, dlogits
+
+
+def gumbel_sample(logits, labels, mask=None, uniform=None, seed=0, offset=0, sample_size=8,
+                  gumbel_temperature=1.0):
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); uniform = _f32(uniform, 'uniform')
+    B, L = logits.shape
+    S = int(sample_size)
+    if uniform is not None and tuple(uniform.shape) != (B, S, L):
+        raise ValueError('uniform noise must have shape [B, S, L]')
+    out = torch.empty((B * S, L), dtype=torch.float32, device=logits.device)
+    rc = _lib.load().tfr_gumbel_sample_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(uniform),
+                                           int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), B, S, L,
+                                           float(gumbel_temperature), _ptr(out), _stream())
+    _lib.check(rc, 'tfr_gumbel_sample_f32')
+    return out
+
+
+def gumbel_sample_bwd(sampled, labels, mask, upstream, sample_size, gumbel_temperature):
+    sampled = _f32(sampled, 'sampled'); labels = _f32(labels, 'labels')
+    upstream = _f32(upstream, 'upstream'); mask = _u8(mask, 'mask')
+    B, L = labels.shape
+    S = int(sample_size)
+    out = torch.empty((B, L), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().tfr_gumbel_sample_bwd_f32(_ptr(sampled), _ptr(labels), _ptr(mask), _ptr(upstream),
+                                               B, S, L, float(gumbel_temperature), _ptr(out), _stream())
+    _lib.check(rc, 'tfr_gumbel_sample_bwd_f32')
+    return out

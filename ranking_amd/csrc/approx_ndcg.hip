@@ -1,0 +1,298 @@
+// ApproxNDCG loss, forward + backward fused in one launch, for gfx950.
+//
+// Reference behaviour restated (losses_impl.py): approx_ranks :77-106,
+// inverse_max_dcg :109-134, ndcg :137-167, _safe_default_gain_fn :33-49,
+// ApproxNDCGLoss._compute_unreduced_loss_impl :1587-1603, get_logits :773-785.
+// Backward formulas: SURVEY.md Appendix B (the reference relies on TF autodiff).
+//
+// Design.  One workgroup per list.  The reference materialises four
+// [B, L, L] tensors forward (tile, tile, sub, sigmoid) and as many again
+// backward; here a list costs 12*L + 12 bytes of HBM traffic and the L^2 pair
+// work never leaves registers:
+//   * valid items are compacted to the front of LDS arrays (ragged lists cost
+//     n_valid^2, not L^2);
+//   * the pair sigmoid is factorised, sigma(x_j - x_i) = 1/(1 + E_i*F_j) with
+//     E_i = exp(x_i - m), F_j = exp(m - x_j) computed ONCE per item (to ~1ulp
+//     through a double-float argument), so a pair costs one v_fma + one v_rcp
+//     + one v_add instead of sub/exp/add/rcp/add -- the transcendental count
+//     per pair drops from 2 to 1.  Lists whose logit range exceeds 160 (where
+//     E/F would leave the fp32 normal range) take a per-pair exp path;
+//   * a row of the pair matrix is split over `C` adjacent lanes (columns in
+//     float4 groups read from LDS as ds_read_b128) so that ragged row counts
+//     still fill 64-wide waves; the C partial sums are combined with
+//     wave shuffles.
+#include "common.h"
+#include "../../include/tfr_hip.h"
+
+#include <stdlib.h>
+
+using namespace tfr;
+
+namespace {
+
+constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kFastRange = 160.0f;
+
+struct Smem {
+  float* red;      // [32]
+  int* wc;         // [16]
+  float* Xr;       // [Lp] x = logit / T, original order
+  float* Lb;       // [Lp] cleaned labels, original order
+  uint8_t* V;      // [Lp] validity, original order
+  uint32_t* sortbuf;  // [P]
+  float* CX;       // [Lp] compact x       (pad -inf)
+  int* CI;         // [Lp] compact -> original index
+  float* CG;       // [Lp] compact gain
+  float* E;        // [Lp] exp(x - m)
+  float* F;        // [Lp] exp(m - x)      (pad +inf)
+  float* A;        // [Lp] d loss / d rank (pad 0)
+  float* Rk;       // [Lp] approx ranks
+};
+
+__host__ __device__ inline size_t smem_bytes(int Lp, int P) {
+  return 128 + 64 + (size_t)Lp * 4 * 9 + (size_t)Lp + 16 + (size_t)P * 4;
+}
+
+__device__ __forceinline__ Smem carve(unsigned char* raw, int Lp, int P) {
+  Smem s;
+  s.red = reinterpret_cast<float*>(raw);
+  s.wc = reinterpret_cast<int*>(raw + 128);
+  float* f = reinterpret_cast<float*>(raw + 192);
+  s.Xr = f; f += Lp;
+  s.Lb = f; f += Lp;
+  s.CX = f; f += Lp;
+  s.CI = reinterpret_cast<int*>(f); f += Lp;
+  s.CG = f; f += Lp;
+  s.E = f; f += Lp;
+  s.F = f; f += Lp;
+  s.A = f; f += Lp;
+  s.Rk = f; f += Lp;
+  s.sortbuf = reinterpret_cast<uint32_t*>(f); f += P;
+  s.V = reinterpret_cast<uint8_t*>(f);
+  return s;
+}
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sum_j sigma(x_j - x_i) over a float4 column group, factorised form.
+__device__ __forceinline__ void pair_fwd_fast(float Ei, const float4 f, float& a0, float& a1,
+                                              float& a2, float& a3) {
+  a0 += fast_rcp(__builtin_fmaf(Ei, f.x, 1.0f));
+  a1 += fast_rcp(__builtin_fmaf(Ei, f.y, 1.0f));
+  a2 += fast_rcp(__builtin_fmaf(Ei, f.z, 1.0f));
+  a3 += fast_rcp(__builtin_fmaf(Ei, f.w, 1.0f));
+}
+__device__ __forceinline__ float sig_slow(float xi, float xj) {
+  // sigma(xj - xi) = 1 / (1 + exp(xi - xj))
+  return fast_rcp(1.0f + __builtin_amdgcn_exp2f((xi - xj) * kLog2e));
+}
+
+__global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                   const uint8_t* __restrict__ mask, const float* __restrict__ inv_log1p,
+                                   const float* __restrict__ list_scale, int L, int Lp, int P,
+                                   float temperature, int C, float* __restrict__ loss_out,
+                                   float* __restrict__ weight_out, float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const Smem s = carve(smem_raw, Lp, P);
+  const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = T >> 6;
+  const int b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+
+  // ---- 1. load, clean (losses_impl.py:1589-1594), per-list label statistics.
+  float lmax = -INFINITY, lsum = 0.f, xmin = INFINITY, xmax = -INFINITY;
+  for (int i = tid; i < L; i += T) {
+    const float lab = labels[base + i];
+    const float x = logits[base + i] / temperature;
+    const bool v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+    const float labc = v ? lab : 0.0f;
+    s.Xr[i] = x; s.Lb[i] = labc; s.V[i] = v ? 1 : 0;
+    lmax = fmaxf(lmax, labc); lsum += labc;
+    if (v) { xmin = fminf(xmin, x); xmax = fmaxf(xmax, x); }
+  }
+  lmax = block_max(lmax, s.red);
+  lsum = block_sum(lsum, s.red);
+  xmin = block_min(xmin, s.red);
+  xmax = block_max(xmax, s.red);
+  const bool nonzero = lsum > 0.0f;
+  if (!nonzero) lmax = 1e-10f;                       // labels := 1e-10 everywhere (:1598-1599)
+
+  // ---- 2. gains (safe gain :33-49) and inverse max DCG (:109-134): sort the gains.
+  const float g0 = exp2f(-lmax);
+  for (int i = tid; i < P; i += T) {
+    float g = 0.f;
+    if (i < L) {
+      const float labc = nonzero ? s.Lb[i] : 1e-10f;
+      g = exp2f(labc - lmax) - g0;
+      s.Lb[i] = g;                                    // Lb now holds the gain
+    }
+    s.sortbuf[i] = __float_as_uint(g);                // g >= 0: bit order == value order
+  }
+  block_bitonic_sort_desc(s.sortbuf, P);
+  float idcg = 0.f;
+  for (int p = tid; p < L; p += T) idcg += __uint_as_float(s.sortbuf[p]) * inv_log1p[p];
+  idcg = block_sum(idcg, s.red);
+  const float inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+
+  // ---- 3. stable compaction of the valid items.
+  int n = 0;
+  for (int i0 = 0; i0 < L; i0 += T) {
+    const int i = i0 + tid;
+    const bool v = (i < L) && (s.V[i] != 0);
+    const unsigned long long bal = __ballot(v);
+    const int lane_prefix = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) s.wc[wid] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) { const int c = s.wc[w]; woff += (w < wid) ? c : 0; tot += c; }
+    if (v) {
+      const int pos = n + woff + lane_prefix;
+      s.CX[pos] = s.Xr[i]; s.CI[pos] = i; s.CG[pos] = s.Lb[i];
+    }
+    n += tot;
+  }
+  __syncthreads();
+  const int n4 = (n + 3) >> 2;                        // float4 column groups
+
+  // ---- 4. per-item exponentials of the factorised sigmoid.
+  const float m = 0.5f * (xmax + xmin);
+  const bool fast = (xmax - xmin) <= kFastRange;
+  for (int i = tid; i < n4 * 4; i += T) {
+    float e = 0.f, f = INFINITY, x = -INFINITY;
+    if (i < n) {
+      x = s.CX[i];
+      const float t_hi = x - m;
+      const float bb = t_hi - x;
+      const float t_lo = (x - (t_hi - bb)) + (-m - bb);
+      e = exp_df(t_hi, t_lo);
+      f = exp_df(-t_hi, -t_lo);
+    }
+    s.E[i] = e; s.F[i] = f; s.A[i] = 0.f;
+    if (i >= n) s.CX[i] = x;
+  }
+  __syncthreads();
+
+  // ---- 5. approximate ranks r_i = 0.5 + sum_j sigma(x_j - x_i)   (:77-106)
+  const int rows_per_pass = T / C;
+  const int c = tid % C, rsub = tid / C;
+  const float4* F4 = reinterpret_cast<const float4*>(s.F);
+  const float4* X4 = reinterpret_cast<const float4*>(s.CX);
+  const float4* A4 = reinterpret_cast<const float4*>(s.A);
+  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    if (!__any(active)) continue;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (fast) {
+      const float Ei = active ? s.E[row] : 0.f;
+      for (int g = c; g < n4; g += C) pair_fwd_fast(Ei, F4[g], a0, a1, a2, a3);
+    } else {
+      const float xi = active ? s.CX[row] : 0.f;
+      for (int g = c; g < n4; g += C) {
+        const float4 xx = X4[g];
+        a0 += sig_slow(xi, xx.x); a1 += sig_slow(xi, xx.y);
+        a2 += sig_slow(xi, xx.z); a3 += sig_slow(xi, xx.w);
+      }
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (active && c == 0) s.Rk[row] = acc + 0.5f;
+  }
+  __syncthreads();
+
+  // ---- 6. loss = -(sum_i G_i / log1p(r_i)) * invMaxDCG  (:137-167); a_i = dloss/dr_i.
+  float dcg = 0.f;
+  for (int i = tid; i < n; i += T) {
+    const float r = s.Rk[i];
+    const float lr = log1pf(r);
+    const float g = s.CG[i];
+    dcg += g * (1.0f / lr);
+    s.A[i] = (g * inv_max_dcg) / (lr * lr * (1.0f + r));
+  }
+  dcg = block_sum(dcg, s.red);          // (ends with the barrier that publishes A)
+  if (tid == 0) {
+    loss_out[b] = -(dcg * inv_max_dcg);
+    weight_out[b] = nonzero ? 1.0f : 0.0f;
+  }
+  if (!dlogits_out) return;
+  __syncthreads();
+
+  // ---- 7. backward: dloss/ds_k = (1/T) * sum_i (a_i - a_k) * sigma'(x_i - x_k).
+  const float scale = list_scale ? list_scale[b] : 1.0f;
+  for (int i = tid; i < L; i += T)
+    if (!s.V[i]) dlogits_out[base + i] = 0.0f;
+  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    if (!__any(active)) continue;
+    const float ak = active ? s.A[row] : 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (fast) {
+      const float Ek = active ? s.E[row] : 0.f;
+      for (int g = c; g < n4; g += C) {
+        const float4 f = F4[g];
+        const float4 aj = A4[g];
+        const float s0 = fast_rcp(__builtin_fmaf(Ek, f.x, 1.0f));
+        const float s1 = fast_rcp(__builtin_fmaf(Ek, f.y, 1.0f));
+        const float s2 = fast_rcp(__builtin_fmaf(Ek, f.z, 1.0f));
+        const float s3 = fast_rcp(__builtin_fmaf(Ek, f.w, 1.0f));
+        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
+        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
+        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
+        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      }
+    } else {
+      const float xk = active ? s.CX[row] : 0.f;
+      for (int g = c; g < n4; g += C) {
+        const float4 xx = X4[g];
+        const float4 aj = A4[g];
+        const float s0 = sig_slow(xk, xx.x), s1 = sig_slow(xk, xx.y);
+        const float s2 = sig_slow(xk, xx.z), s3 = sig_slow(xk, xx.w);
+        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
+        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
+        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
+        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      }
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (active && c == 0) dlogits_out[base + s.CI[row]] = scale * (acc / temperature);
+  }
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                   const float* inv_log1p, const float* list_scale, int B, int L,
+                                   float temperature, int lanes_per_row, float* loss_out,
+                                   float* weight_out, float* dlogits_out, void* stream) {
+  if (!logits || !labels || !inv_log1p || !loss_out || !weight_out || B < 0 || L <= 0)
+    return TFR_EINVAL;
+  if (!(temperature > 0.0f)) return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  static const int env_threads = env_int("TFR_APPROX_THREADS", 0);
+  static const int env_lanes = env_int("TFR_APPROX_LANES", 0);
+  int C = lanes_per_row > 0 ? lanes_per_row : (env_lanes > 0 ? env_lanes : 4);
+  if (C > 64 || (C & (C - 1))) return TFR_EINVAL;
+  int T = env_threads > 0 ? env_threads : (L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 512 ? 256 : 512)));
+  if (T % 64 || T > 1024) return TFR_EINVAL;
+  const int Lp = ((L + 3) / 4) * 4 + 4;
+  const int P = pow2_ceil(L < 2 ? 2 : L);
+  const size_t lds = smem_bytes(Lp, P);
+  if (lds > 160 * 1024) return TFR_ETOOLARGE;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(approx_ndcg_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(approx_ndcg_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, logits, labels,
+                     mask, inv_log1p, list_scale, L, Lp, P, temperature, C, loss_out, weight_out,
+                     dlogits_out);
+  return (int)hipGetLastError();
+}

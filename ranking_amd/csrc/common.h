@@ -1,0 +1,143 @@
+// Device-side helpers shared by the gfx950 ranking kernels.
+//
+// Execution model used by every kernel in this directory: ONE workgroup per
+// ranked list, the list's rows resident in LDS for the whole kernel, 64-wide
+// wavefront reductions (DPP/ds_swizzle shuffles) inside a wave and one LDS
+// hop across waves.  Nothing O(L^2) ever leaves LDS/registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TFR_WAVE 64
+#define TFR_MAX_THREADS 1024
+#define TFR_MAX_LIST 8192
+
+#define TFR_OK 0
+#define TFR_EINVAL (-1)
+#define TFR_ETOOLARGE (-2)
+
+namespace tfr {
+
+__host__ __device__ inline int pow2_ceil(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+// Monotone map float -> uint32 (a < b  <=>  ord(a) < ord(b)); -0 is folded
+// onto +0 so that tied zeros compare equal like tf.math.top_k treats them.
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+  f = f + 0.0f;
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ---------------------------------------------------------------- wave ops
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block reductions: every thread gets the result.  `red` = LDS scratch of at
+// least 17 floats.  Two barriers; safe to call back-to-back on the same scratch.
+template <typename Op>
+__device__ __forceinline__ float block_reduce(float v, float identity, float* red, Op op) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o, 64));
+  if (nw == 1) return v;
+  __syncthreads();                 // previous users of `red` are done
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float r = (lane < nw) ? red[lane] : identity;
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) r = op(r, __shfl_xor(r, o, 64));
+  return __shfl(r, 0, 64);
+}
+struct OpSum { __device__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+struct OpMin { __device__ float operator()(float a, float b) const { return fminf(a, b); } };
+
+__device__ __forceinline__ float block_sum(float v, float* red) { return block_reduce(v, 0.f, red, OpSum()); }
+__device__ __forceinline__ float block_max(float v, float* red) { return block_reduce(v, -INFINITY, red, OpMax()); }
+__device__ __forceinline__ float block_min(float v, float* red) { return block_reduce(v, INFINITY, red, OpMin()); }
+
+// Fixed-order fp32 sum shared bit-for-bit with oracle.tfr_ref.tree_sum:
+// t[0..P) (P power of two, zero padded) is folded upper half onto lower half.
+// On return t[0] holds the sum (all threads must call; ends with a barrier).
+__device__ __forceinline__ void block_tree_sum(float* t, int P) {
+  for (int h = P >> 1; h >= 1; h >>= 1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < h; i += blockDim.x) t[i] = t[i] + t[i + h];
+  }
+  __syncthreads();
+}
+
+// Bitonic sort, DESCENDING, of P (power of two) keys resident in LDS.
+// All threads of the block must call.  Ends with a barrier.
+template <typename K>
+__device__ __forceinline__ void block_bitonic_sort_desc(K* keys, int P) {
+  const int half = P >> 1;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < half; t += blockDim.x) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const K a = keys[i], b = keys[p];
+        const bool down = ((i & k) == 0);          // this run sorts descending
+        const bool swap = down ? (a < b) : (a > b);
+        if (swap) { keys[i] = b; keys[p] = a; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Sort key for "valid first, score descending, tie-break ascending, then
+// index" (utils.py:84-164 with the deterministic tie rule).
+//   bit 63      valid
+//   bits 62..31 ordered(score)        (0 for invalid entries)
+//   bits 30..16 0x7fff - tiebreak     (tiebreak < 32768; default = 0)
+//   bits 15..0  0xffff - index        (index < 65536)
+// Sorting the packed keys DESCENDING yields the required order and the low 16
+// bits recover the item index.
+__device__ __forceinline__ uint64_t make_sort_key(bool valid, float score, int tiebreak, int index) {
+  const uint64_t s = valid ? (uint64_t)float_to_ordered(score) : 0ull;
+  return ((uint64_t)(valid ? 1 : 0) << 63) | (s << 31) |
+         ((uint64_t)(0x7fff - (tiebreak & 0x7fff)) << 16) | (uint64_t)(0xffff - (index & 0xffff));
+}
+__device__ __forceinline__ int sort_key_index(uint64_t key) { return 0xffff - (int)(key & 0xffffull); }
+
+// exp(t) for a fp32 t given as an exact double-float (t_hi + t_lo), to ~1ulp:
+// used once per ITEM (never per pair) so that the factorised sigmoid
+// 1/(1 + E_i*F_j) keeps full fp32 accuracy even when |x - m| is large.
+__device__ __forceinline__ float exp_df(float t_hi, float t_lo) {
+  const float LOG2E_HI = 1.44269502162933349609375f;      // fp32(log2 e)
+  const float LOG2E_LO = 1.92596299112661746e-08f;        // log2 e - LOG2E_HI
+  const float y_hi = t_hi * LOG2E_HI;
+  float y_lo = __builtin_fmaf(t_hi, LOG2E_HI, -y_hi);
+  y_lo = __builtin_fmaf(t_hi, LOG2E_LO, y_lo);
+  y_lo = __builtin_fmaf(t_lo, LOG2E_HI, y_lo);
+  const float n = rintf(y_hi);
+  const float f = (y_hi - n) + y_lo;
+  return ldexpf(exp2f(f), (int)n);
+}
+
+}  // namespace tfr

@@ -1,0 +1,290 @@
+// Softmax (ListNet) loss fwd+bwd and the Gumbel-softmax sampler fwd / bwd for
+// gfx950.  These are the O(L) members of the hot path: one workgroup per list,
+// a handful of 64-wide wave reductions, every HBM byte touched exactly once.
+//
+// Reference behaviour restated (losses_impl.py): SoftmaxLoss.precompute
+// :1122-1137, _compute_unreduced_loss_impl :1139-1158, AbstractDCGLambdaWeight
+// .individual_weights :281-296, _compute_ranks :483-500, inverse_max_dcg
+// :109-134, GumbelSampler.sample :556-644, _sample_gumbel :647-649.
+#include "common.h"
+#include "../../include/tfr_hip.h"
+
+using namespace tfr;
+
+namespace {
+
+constexpr float kLogEps10 = -23.02585092994045684f;   // ln(1e-10)  (losses_impl.py:28,1130)
+constexpr float kLogEps20 = -46.0517018598809137f;    // ln(1e-20)  (losses_impl.py:603)
+
+struct SmArgs {
+  const float* logits; const float* labels; const uint8_t* mask; const float* item_weights;
+  int weights_per_list; int lambda_kind; int topn; int normalized; int gain_kind;
+  const float* gains; const float* discount; int L; int Lp; int P; float temperature;
+  float* loss; float* weight; float* dlogits;
+};
+
+__global__ void softmax_loss_kernel(const SmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P] (lambda only)
+  const bool dcg_lambda = a.lambda_kind == TFR_LAMBDA_DCG;
+  float* fbase = reinterpret_cast<float*>(keys + (dcg_lambda ? a.P : 0));
+  float* Z = fbase;                 // [Lp] logits for softmax
+  float* Y = fbase + a.Lp;          // [Lp] labels for softmax (un-normalised)
+  float* Gr = fbase + 2 * a.Lp;     // [Lp] gain (lambda only)
+  int* Rk = reinterpret_cast<int*>(fbase + 3 * a.Lp);   // [Lp] ranks (lambda only)
+  uint8_t* MV = reinterpret_cast<uint8_t*>(fbase + 4 * a.Lp);
+
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x, L = a.L, P = a.P;
+  const size_t base = (size_t)b * L;
+  const int topn = (a.topn <= 0 || a.topn > L) ? L : a.topn;
+
+  // ---- precompute (:1122-1137)
+  for (int i = tid; i < L; i += T) {
+    const float lab = a.labels[base + i];
+    const bool mv = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
+    const float x = a.logits[base + i] / a.temperature;
+    MV[i] = mv;
+    Z[i] = mv ? x : kLogEps10;
+    Y[i] = mv ? lab : 0.0f;
+    if (dcg_lambda) keys[i] = make_sort_key(mv, x, 0, i);
+  }
+  if (dcg_lambda) {
+    for (int i = L + tid; i < P; i += T) keys[i] = 0;
+    block_bitonic_sort_desc(keys, P);                 // ranks by logits (:483-500)
+    for (int p = tid; p < L; p += T) Rk[sort_key_index(keys[p])] = p + 1;
+    __syncthreads();
+    // individual_weights (:281-296): (gain(clean label) [* invMaxDCG]) * discount(rank)
+    for (int i = tid; i < P; i += T) {
+      uint64_t key = 0;
+      if (i < L) {
+        const float yl = Y[i];
+        const float labc = (yl >= 0.0f) ? yl : 0.0f;
+        float g;
+        if (a.gain_kind == TFR_GAIN_CUSTOM) g = a.gains[base + i];
+        else if (a.gain_kind == TFR_GAIN_POW2M1) g = exp2f(labc) - 1.0f;
+        else g = labc;
+        Gr[i] = g;
+        key = ((uint64_t)float_to_ordered(labc) << 32) | (uint64_t)__float_as_uint(g);
+      }
+      keys[i] = key;
+    }
+    float inv = 1.0f;
+    if (a.normalized) {
+      block_bitonic_sort_desc(keys, P);               // ideal order (:109-134)
+      float idcg = 0.f;
+      for (int p = tid; p < topn; p += T)
+        idcg += __uint_as_float((uint32_t)(keys[p] & 0xffffffffull)) * a.discount[p];
+      idcg = block_sum(idcg, red);
+      inv = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < L; i += T) {
+      float g = Gr[i];
+      if (a.normalized) g = g * inv;
+      Y[i] = g * a.discount[Rk[i] - 1];
+    }
+  }
+  __syncthreads();
+  // item / list weights (:1135-1136)
+  if (a.item_weights) {
+    const float wl = a.weights_per_list ? a.item_weights[b] : 1.0f;
+    for (int i = tid; i < L; i += T)
+      Y[i] = Y[i] * (a.weights_per_list ? wl : a.item_weights[base + i]);
+  }
+  __syncthreads();
+
+  // ---- _compute_unreduced_loss_impl (:1139-1158)
+  float lsum = 0.f, zmax = -INFINITY;
+  for (int i = tid; i < L; i += T) { lsum += Y[i]; zmax = fmaxf(zmax, Z[i]); }
+  lsum = block_sum(lsum, red);
+  zmax = block_max(zmax, red);
+  const bool nonzero = lsum > 0.0f;
+  float psum = 0.f, esum = 0.f;
+  for (int i = tid; i < L; i += T) {
+    float y = nonzero ? Y[i] : 1e-10f;
+    y = MV[i] ? y : 0.0f;
+    Y[i] = y;
+    psum += y;
+    esum += expf(Z[i] - zmax);
+  }
+  psum = block_sum(psum, red);
+  esum = block_sum(esum, red);
+  const float lse = logf(esum);
+  float loss = 0.f, ptot = 0.f;
+  for (int i = tid; i < L; i += T) {
+    const float p = (psum != 0.0f) ? (Y[i] / psum) : 0.0f;   // divide_no_nan
+    loss += p * (lse - (Z[i] - zmax));
+    ptot += p;
+    Y[i] = p;
+  }
+  loss = block_sum(loss, red);
+  ptot = block_sum(ptot, red);
+  if (tid == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
+  if (!a.dlogits) return;
+  // ---- backward: d(weight * loss)/d logits_k = (w/T) (sum_p * softmax_k - p_k), valid k.
+  for (int i = tid; i < L; i += T) {
+    float g = 0.f;
+    if (MV[i]) {
+      const float sm = expf(Z[i] - zmax) / esum;
+      g = lsum * ((ptot * sm - Y[i]) / a.temperature);
+    }
+    a.dlogits[base + i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ Gumbel
+__device__ __forceinline__ uint32_t mulhi32(uint32_t a, uint32_t b) { return __umulhi(a, b); }
+
+// Philox4x32-10 (Salmon et al. 2011); returns the first output word.
+__device__ __forceinline__ uint32_t philox_first(uint64_t ctr_lo, uint64_t ctr_hi, uint64_t key) {
+  uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32);
+  uint32_t c2 = (uint32_t)ctr_hi, c3 = (uint32_t)(ctr_hi >> 32);
+  uint32_t k0 = (uint32_t)key, k1 = (uint32_t)(key >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return c0;
+}
+
+__global__ void gumbel_sample_kernel(const float* __restrict__ logits, const float* __restrict__ labels,
+                                     const uint8_t* __restrict__ mask, const float* __restrict__ uniform,
+                                     uint64_t seed, uint64_t offset, int S, int L, int Lp,
+                                     float gumbel_temperature, float* __restrict__ sampled_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);
+  float* Z = reinterpret_cast<float*>(smem_raw + 128);
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int bs = blockIdx.x;               // b * S + s
+  const int b = bs / S;
+  const size_t ibase = (size_t)b * L, obase = (size_t)bs * L;
+  float zmax = -INFINITY;
+  for (int i = tid; i < L; i += T) {
+    const float lab = labels[ibase + i];
+    const bool v = mask ? (mask[ibase + i] != 0) : (lab >= 0.0f);
+    float u;
+    if (uniform) u = uniform[obase + i];
+    else u = (float)(philox_first(obase + i, offset, seed) >> 8) * (1.0f / 16777216.0f);
+    const float g = -logf(-logf(u + 1e-20f) + 1e-20f);            // :647-649
+    const float z = v ? ((logits[ibase + i] + g) / gumbel_temperature) : kLogEps20;
+    Z[i] = z;
+    zmax = fmaxf(zmax, z);
+  }
+  zmax = block_max(zmax, red);
+  float esum = 0.f;
+  for (int i = tid; i < L; i += T) esum += expf(Z[i] - zmax);
+  esum = block_sum(esum, red);
+  for (int i = tid; i < L; i += T)
+    sampled_out[obase + i] = logf(expf(Z[i] - zmax) / esum + 1e-20f);   // :605
+}
+
+__global__ void gumbel_sample_bwd_kernel(const float* __restrict__ sampled, const float* __restrict__ labels,
+                                         const uint8_t* __restrict__ mask, const float* __restrict__ upstream,
+                                         int S, int L, float gumbel_temperature,
+                                         float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);
+  float* ACC = reinterpret_cast<float*>(smem_raw + 128);
+  const int tid = threadIdx.x, T = blockDim.x;
+  const int b = blockIdx.x;
+  const size_t ibase = (size_t)b * L;
+  for (int i = tid; i < L; i += T) ACC[i] = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t obase = ((size_t)b * S + s) * L;
+    // out_k = log(p_k + eps): d out_k / d z_j = c_k (delta_kj - p_j), c_k = p_k / (p_k + eps)
+    float dot = 0.f;
+    for (int i = tid; i < L; i += T) {
+      const float e = expf(sampled[obase + i]);           // p + eps
+      const float p = fmaxf(e - 1e-20f, 0.0f);
+      dot += upstream[obase + i] * (p / e);
+    }
+    dot = block_sum(dot, red);
+    for (int i = tid; i < L; i += T) {
+      const float e = expf(sampled[obase + i]);
+      const float p = fmaxf(e - 1e-20f, 0.0f);
+      ACC[i] += upstream[obase + i] * (p / e) - p * dot;
+    }
+  }
+  for (int i = tid; i < L; i += T) {
+    const float lab = labels[ibase + i];
+    const bool v = mask ? (mask[ibase + i] != 0) : (lab >= 0.0f);
+    dlogits_out[ibase + i] = v ? (ACC[i] / gumbel_temperature) : 0.0f;
+  }
+}
+
+inline int threads_for(int L) {
+  int t = ((L + 63) / 64) * 64;
+  if (t > 256) t = 256;
+  return t;
+}
+
+}  // namespace
+
+extern "C" int tfr_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                    const float* item_weights, int weights_per_list, int lambda_kind,
+                                    int topn, int normalized, int gain_kind, const float* gains,
+                                    const float* discount, int B, int L, float temperature,
+                                    float* loss_out, float* weight_out, float* dlogits_out,
+                                    void* stream) {
+  if (!logits || !labels || !loss_out || !weight_out || B < 0 || L <= 0 || !(temperature > 0.0f))
+    return TFR_EINVAL;
+  if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG) return TFR_EINVAL;
+  if (lambda_kind == TFR_LAMBDA_DCG && (!discount || (gain_kind == TFR_GAIN_CUSTOM && !gains)))
+    return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  SmArgs a;
+  a.logits = logits; a.labels = labels; a.mask = mask; a.item_weights = item_weights;
+  a.weights_per_list = weights_per_list; a.lambda_kind = lambda_kind; a.topn = topn;
+  a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains; a.discount = discount;
+  a.L = L; a.Lp = ((L + 3) / 4) * 4; a.P = pow2_ceil(L < 2 ? 2 : L); a.temperature = temperature;
+  a.loss = loss_out; a.weight = weight_out; a.dlogits = dlogits_out;
+  const size_t lds = 128 + (lambda_kind == TFR_LAMBDA_DCG ? (size_t)a.P * 8 : 0) +
+                     (size_t)a.Lp * 17 + 16;
+  if (lds > 160 * 1024) return TFR_ETOOLARGE;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(softmax_loss_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  int T = threads_for(L);
+  if (lambda_kind == TFR_LAMBDA_DCG && a.P / 2 > T) T = a.P / 2 > 1024 ? 1024 : a.P / 2;
+  hipLaunchKernelGGL(softmax_loss_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_gumbel_sample_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                     const float* uniform, uint64_t seed, uint64_t offset, int B,
+                                     int S, int L, float gumbel_temperature, float* sampled_out,
+                                     void* stream) {
+  if (!logits || !labels || !sampled_out || B < 0 || S <= 0 || L <= 0 || !(gumbel_temperature > 0.0f))
+    return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  const int Lp = ((L + 3) / 4) * 4;
+  hipLaunchKernelGGL(gumbel_sample_kernel, dim3(B * S), dim3(threads_for(L)), 128 + (size_t)Lp * 4,
+                     (hipStream_t)stream, logits, labels, mask, uniform, seed, offset, S, L, Lp,
+                     gumbel_temperature, sampled_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const uint8_t* mask,
+                                         const float* upstream, int B, int S, int L,
+                                         float gumbel_temperature, float* dlogits_out, void* stream) {
+  if (!sampled || !labels || !upstream || !dlogits_out || B < 0 || S <= 0 || L <= 0 ||
+      !(gumbel_temperature > 0.0f))
+    return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  const int Lp = ((L + 3) / 4) * 4;
+  hipLaunchKernelGGL(gumbel_sample_bwd_kernel, dim3(B), dim3(threads_for(L)), 128 + (size_t)Lp * 4,
+                     (hipStream_t)stream, sampled, labels, mask, upstream, S, L, gumbel_temperature,
+                     dlogits_out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,216 @@
+// Masked descending sort / ranks and the sort-based ranking metrics (NDCG@k,
+// MRR@k) for gfx950.  One workgroup per list; the packed 64-bit sort keys live
+// in LDS and are ordered by an in-LDS bitonic network.
+//
+// Reference behaviour restated: utils.py:84-195 (sort_by_scores, sorted_ranks),
+// metrics_impl.py:228-266 (_prepare_and_validate_params), :122-151 (DCG),
+// :429-459 (MRR), :631-670 (NDCG).
+#include "common.h"
+#include "../../include/tfr_hip.h"
+
+using namespace tfr;
+
+namespace {
+
+struct TopN { int k[TFR_MAX_TOPN]; int n; };
+
+__device__ __forceinline__ bool item_valid(const float* labels, const uint8_t* mask, size_t off) {
+  if (mask) return mask[off] != 0;
+  if (labels) return labels[off] >= 0.0f;
+  return true;
+}
+
+__global__ void sort_ranks_kernel(const float* __restrict__ scores, const float* __restrict__ labels,
+                                  const uint8_t* __restrict__ mask, const int32_t* __restrict__ tiebreak,
+                                  int L, int P, int32_t* __restrict__ ranks_out,
+                                  int32_t* __restrict__ order_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw);
+  const size_t base = (size_t)blockIdx.x * L;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    uint64_t key = 0;
+    if (i < L) {
+      const bool v = item_valid(labels, mask, base + i);
+      key = make_sort_key(v, scores[base + i], tiebreak ? tiebreak[base + i] : 0, i);
+    }
+    keys[i] = key;
+  }
+  block_bitonic_sort_desc(keys, P);
+  for (int p = threadIdx.x; p < L; p += blockDim.x) {
+    const int idx = sort_key_index(keys[p]);
+    if (order_out) order_out[base + p] = idx;
+    if (ranks_out) ranks_out[base + idx] = p + 1;
+  }
+}
+
+// kind 0 = NDCG, 1 = MRR.
+template <int KIND>
+__global__ void rank_metric_kernel(const float* __restrict__ labels, const float* __restrict__ predictions,
+                                   const float* __restrict__ weights, int weights_per_list,
+                                   const uint8_t* __restrict__ mask, const float* __restrict__ gains,
+                                   const float* __restrict__ discount, TopN topn, int B, int L, int P,
+                                   float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32] reduction scratch + dcg[8]
+  float* dcg = red + 20;
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* term = reinterpret_cast<float*>(keys + P);               // [P] tree-sum scratch
+  float* term0 = term + P;                                        // [P] un-cut terms
+  float* W = term0 + P;                                           // [P] example weights
+  float* G = W + P;                                               // [P] gain / relevance
+  uint8_t* M = reinterpret_cast<uint8_t*>(G + P);                 // [P] metric mask
+
+  const int b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  // ---- _prepare_and_validate_params (metrics_impl.py:228-266)
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    float w = 0.f, g = 0.f;
+    bool m = false;
+    if (i < L) {
+      const float lab = labels[base + i];
+      w = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      m = v0 && (w > 0.0f);
+      const float labc = m ? lab : 0.0f;
+      if (KIND == 0) g = gains ? gains[base + i] : (exp2f(labc) - 1.0f);
+      else g = (labc >= 1.0f) ? 1.0f : 0.0f;
+    }
+    W[i] = w; G[i] = g; M[i] = m ? 1 : 0;
+  }
+  __syncthreads();
+
+  // ---- per-list weight statistics, tree_sum order over the original index.
+  float s_w, s_g, s_wg;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = W[i];
+  block_tree_sum(term, P); s_w = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = G[i];
+  block_tree_sum(term, P); s_g = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = W[i] * G[i];
+  block_tree_sum(term, P); s_wg = term[0]; __syncthreads();
+  if (threadIdx.x == 0) {
+    stats_out[(size_t)b * 3 + 0] = s_w;
+    stats_out[(size_t)b * 3 + 1] = s_g;
+    stats_out[(size_t)b * 3 + 2] = s_wg;
+  }
+
+  // ---- sort by prediction (masked entries last): utils.py:115-164.
+  for (int i = threadIdx.x; i < P; i += blockDim.x)
+    keys[i] = (i < L) ? make_sort_key(M[i] != 0, predictions[base + i], 0, i) : 0ull;
+  block_bitonic_sort_desc(keys, P);
+
+  if (KIND == 1) {
+    // MRR: first sorted position holding a relevant item (metrics_impl.py:443-459).
+    float pmin = INFINITY;
+    for (int p = threadIdx.x; p < L; p += blockDim.x)
+      if (G[sort_key_index(keys[p])] > 0.0f) pmin = fminf(pmin, (float)p);
+    pmin = block_min(pmin, red);
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < topn.n; ++q) {
+        const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+        metric_out[(size_t)q * B + b] = (pmin < (float)k) ? (1.0f / (pmin + 1.0f)) : 0.0f;
+      }
+    }
+    return;
+  }
+
+  // ---- DCG terms in sorted order: (w * gain) * discount(rank)  (:122-151)
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float t = 0.f;
+    if (p < L) { const int idx = sort_key_index(keys[p]); t = (W[idx] * G[idx]) * discount[p]; }
+    term0[p] = t;
+  }
+  __syncthreads();
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    for (int p = threadIdx.x; p < P; p += blockDim.x) term[p] = (p < k) ? term0[p] : 0.0f;
+    block_tree_sum(term, P);
+    if (threadIdx.x == 0) dcg[q] = term[0];
+    __syncthreads();
+  }
+
+  // ---- ideal ordering: sort by weighted gain (metrics_impl.py:660-666)
+  for (int i = threadIdx.x; i < P; i += blockDim.x)
+    keys[i] = (i < L) ? make_sort_key(M[i] != 0, W[i] * G[i], 0, i) : 0ull;
+  block_bitonic_sort_desc(keys, P);
+  for (int p = threadIdx.x; p < P; p += blockDim.x) {
+    float t = 0.f;
+    if (p < L) { const int idx = sort_key_index(keys[p]); t = (W[idx] * G[idx]) * discount[p]; }
+    term0[p] = t;
+  }
+  __syncthreads();
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    for (int p = threadIdx.x; p < P; p += blockDim.x) term[p] = (p < k) ? term0[p] : 0.0f;
+    block_tree_sum(term, P);
+    const float idcg = term[0];
+    if (threadIdx.x == 0)
+      metric_out[(size_t)q * B + b] = (idcg != 0.0f) ? (dcg[q] / idcg) : 0.0f;   // divide_no_nan
+    __syncthreads();
+  }
+}
+
+inline int block_threads_for(int P) {
+  int t = P / 2;
+  if (t < 64) t = 64;
+  if (t > 1024) t = 1024;
+  return t;
+}
+
+}  // namespace
+
+extern "C" int tfr_hip_abi_version(void) { return 1; }
+
+extern "C" int tfr_sort_ranks_f32(const float* scores, const float* labels, const uint8_t* mask,
+                                  const int32_t* tiebreak, int B, int L, int32_t* ranks_out,
+                                  int32_t* order_out, void* stream) {
+  if (!scores || B < 0 || L <= 0 || (!ranks_out && !order_out)) return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  const int P = pow2_ceil(L < 2 ? 2 : L);
+  const int T = block_threads_for(P);
+  hipLaunchKernelGGL(sort_ranks_kernel, dim3(B), dim3(T), (size_t)P * sizeof(uint64_t),
+                     (hipStream_t)stream, scores, labels, mask, tiebreak, L, P, ranks_out, order_out);
+  return (int)hipGetLastError();
+}
+
+static int launch_metric(int kind, const float* labels, const float* predictions, const float* weights,
+                         int weights_per_list, const uint8_t* mask, const float* gains,
+                         const float* discount, const int32_t* topn_host, int K, int B, int L,
+                         float* metric_out, float* stats_out, void* stream) {
+  if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
+  if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
+  if (kind == 0 && !discount) return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  TopN tn; tn.n = K;
+  for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
+  const int P = pow2_ceil(L < 2 ? 2 : L);
+  const int T = block_threads_for(P);
+  const size_t lds = 128 + (size_t)P * (sizeof(uint64_t) + 4 * sizeof(float) + 1) + 16;
+  if (kind == 0)
+    hipLaunchKernelGGL(rank_metric_kernel<0>, dim3(B), dim3(T), lds, (hipStream_t)stream, labels,
+                       predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P,
+                       metric_out, stats_out);
+  else
+    hipLaunchKernelGGL(rank_metric_kernel<1>, dim3(B), dim3(T), lds, (hipStream_t)stream, labels,
+                       predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P,
+                       metric_out, stats_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const float* weights,
+                                   int weights_per_list, const uint8_t* mask, const float* gains,
+                                   const float* discount, const int32_t* topn_host, int K, int B,
+                                   int L, float* ndcg_out, float* stats_out, void* stream) {
+  return launch_metric(0, labels, predictions, weights, weights_per_list, mask, gains, discount,
+                       topn_host, K, B, L, ndcg_out, stats_out, stream);
+}
+
+extern "C" int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,
+                                  int weights_per_list, const uint8_t* mask, const int32_t* topn_host,
+                                  int K, int B, int L, float* mrr_out, float* stats_out, void* stream) {
+  return launch_metric(1, labels, predictions, weights, weights_per_list, mask, nullptr, nullptr,
+                       topn_host, K, B, L, mrr_out, stats_out, stream);
+}

@@ -1,0 +1,140 @@
+"""Mirror of ``tensorflow_ranking/python/keras/metrics.py`` for NDCG and MRR.
+
+``tf.keras.metrics.Mean`` semantics (keras/metrics.py:156-193): each
+``update_state`` adds sum(value * weight) and sum(weight) of the per-list
+metric; ``result()`` is their ratio.  Accumulators are device scalars (no host
+sync per step).  Under data parallelism ``result()`` all-reduces the two sums
+ when ``torch.distributed`` is initialised.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from .. import metrics_impl
+from . import utils
+
+
+class RankingMetricKey(object):
+    """keras/metrics.py:31-66."""
+    MRR = 'mrr'
+    ARP = 'arp'
+    NDCG = 'ndcg'
+    DCG = 'dcg'
+    PRECISION = 'precision'
+    MAP = 'map'
+    ORDERED_PAIR_ACCURACY = 'ordered_pair_accuracy'
+    ALPHA_DCG = 'alpha_dcg'
+    HITS = 'hits'
+
+
+def get(key: str, name: Optional[str] = None, dtype=None, topn: Optional[int] = None, **kwargs):
+    """keras/metrics.py:69-128."""
+    if not isinstance(key, str):
+        raise ValueError('Input `key` needs to be string.')
+    key_to_cls = {RankingMetricKey.MRR: MRRMetric, RankingMetricKey.NDCG: NDCGMetric}
+    metric_kwargs = {'name': name, 'dtype': dtype}
+    if topn:
+        metric_kwargs.update({'topn': topn})
+    if kwargs:
+        metric_kwargs.update(kwargs)
+    if key in key_to_cls:
+        return key_to_cls[key](**metric_kwargs)
+    raise ValueError('Unsupported metric: {}'.format(key))
+
+
+def default_keras_metrics(**kwargs) -> List['_RankingMetric']:
+    """keras/metrics.py:131-153, restricted to the metrics on the hot path
+    (NDCG@{1,3,5,10,all}, MRR); the remaining sort-based metrics are SURVEY 8f."""
+    list_kwargs = [dict(key='ndcg', topn=topn, name='metric/ndcg_{}'.format(topn), **kwargs)
+                   for topn in [1, 3, 5, 10]]
+    list_kwargs += [dict(key='mrr', name='metric/mrr', **kwargs),
+                    dict(key='ndcg', name='metric/ndcg', **kwargs)]
+    return [get(**kw) for kw in list_kwargs]
+
+
+class _RankingMetric(object):
+    """keras/metrics.py:156-201."""
+
+    def __init__(self, name=None, dtype=None, ragged=False, **kwargs):
+        self.name = name
+        self._dtype = dtype or torch.float32
+        self._metric = None
+        self._ragged = ragged
+        self.total = None
+        self.count = None
+
+    def update_state(self, y_true, y_pred, sample_weight=None):
+        val, w = self._metric.compute(y_true, y_pred, sample_weight)
+        t = (val * w).sum()
+        c = w.sum()
+        if self.total is None:
+            self.total, self.count = t, c
+        else:
+            self.total = self.total + t
+            self.count = self.count + c
+        return self
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        return self.update_state(y_true, y_pred, sample_weight).result()
+
+    def result(self, sync: bool = True):
+        if self.total is None:
+            return torch.zeros((), dtype=torch.float32)
+        total, count = self.total, self.count
+        if sync and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            buf = torch.stack([total, count])
+            torch.distributed.all_reduce(buf)
+            total, count = buf[0], buf[1]
+        return torch.where(count != 0, total / torch.where(count != 0, count, torch.ones_like(count)),
+                           torch.zeros_like(total))
+
+    def reset_state(self):
+        self.total = None
+        self.count = None
+
+    reset_states = reset_state
+
+    def get_config(self) -> Dict[str, Any]:
+        return {'name': self.name, 'dtype': self._dtype, 'ragged': self._ragged}
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**config)
+
+
+@utils.register_keras_serializable()
+class MRRMetric(_RankingMetric):
+    """keras/metrics.py:204-268."""
+
+    def __init__(self, name=None, topn=None, dtype=None, ragged=False, **kwargs):
+        super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+        self._topn = topn
+        self._metric = metrics_impl.MRRMetric(name=name, topn=topn, ragged=ragged)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'topn': self._topn})
+        return config
+
+
+@utils.register_keras_serializable()
+class NDCGMetric(_RankingMetric):
+    """keras/metrics.py:710-800."""
+
+    def __init__(self, name=None, topn=None, gain_fn=None, rank_discount_fn=None, dtype=None,
+                 ragged=False, **kwargs):
+        super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+        self._topn = topn
+        self._gain_fn = gain_fn or utils.pow_minus_1
+        self._rank_discount_fn = rank_discount_fn or utils.log2_inverse
+        self._metric = metrics_impl.NDCGMetric(name=name, topn=topn, gain_fn=self._gain_fn,
+                                               rank_discount_fn=self._rank_discount_fn, ragged=ragged)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'topn': self._topn, 'gain_fn': self._gain_fn,
+                       'rank_discount_fn': self._rank_discount_fn})
+        return config

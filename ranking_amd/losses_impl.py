@@ -1,0 +1,634 @@
+"""Mirror of ``tensorflow_ranking/python/losses_impl.py`` for the hot-path losses.
+
+Same class names, constructor arguments and method protocol as the reference
+(`compute`, `compute_per_list`, `compute_unreduced_loss`, `normalize_weights`,
+`get_logits`, `pair_weights`, `individual_weights`), but every reduced entry
+point runs ONE fused gfx950 kernel (forward + backward) instead of a chain of
+`[B, L, L]` TensorFlow ops.  Tensors are torch tensors on a HIP device.
+
+The two methods whose *contract* is a materialised `[B, L, L]` tensor
+(`_PairwiseLoss.compute_unreduced_loss`, `_LambdaWeight.pair_weights`) are
+API-parity utilities implemented with torch device ops in `_materialized.py`;
+no reduced path uses them.
+"""
+from __future__ import annotations
+
+import abc
+import math
+from typing import Callable, Optional
+
+import torch
+
+from . import _materialized as _mat
+from . import _ops
+from . import utils
+
+_EPSILON = 1e-10
+
+
+class Reduction:
+    """tf.compat.v1.losses.Reduction values (strings identical to TF's)."""
+    NONE = 'none'
+    SUM = 'weighted_sum'
+    MEAN = 'weighted_mean'
+    SUM_OVER_BATCH_SIZE = 'weighted_sum_over_batch_size'
+    SUM_OVER_NONZERO_WEIGHTS = 'weighted_sum_by_nonzero_weights'
+    SUM_BY_NONZERO_WEIGHTS = 'weighted_sum_by_nonzero_weights'
+
+    @classmethod
+    def all(cls):
+        return (cls.NONE, cls.SUM, cls.MEAN, cls.SUM_OVER_BATCH_SIZE, cls.SUM_BY_NONZERO_WEIGHTS)
+
+
+def _safe_div(num, den):
+    den_t = torch.as_tensor(den, dtype=num.dtype, device=num.device)
+    ok = den_t != 0
+    return torch.where(ok, num / torch.where(ok, den_t, torch.ones_like(den_t)), torch.zeros_like(num))
+
+
+def compute_weighted_loss(losses, weights, reduction):
+    """tf.compat.v1.losses.compute_weighted_loss semantics (call sites
+    losses_impl.py:813,1167)."""
+    weights = torch.as_tensor(weights, dtype=losses.dtype, device=losses.device)
+    weighted = losses * weights
+    if reduction == Reduction.NONE:
+        return weighted
+    total = weighted.sum()
+    bw = torch.broadcast_to(weights, weighted.shape)
+    if reduction == Reduction.SUM:
+        return total
+    if reduction == Reduction.MEAN:
+        return _safe_div(total, bw.sum())
+    if reduction == Reduction.SUM_BY_NONZERO_WEIGHTS:
+        return _safe_div(total, (bw != 0).sum().to(losses.dtype))
+    if reduction == Reduction.SUM_OVER_BATCH_SIZE:
+        return total / weighted.numel()
+    raise ValueError('Invalid reduction: {}'.format(reduction))
+
+
+# --- default gain / discount functions (named so that the kernels can recognise them).
+def _identity_gain(label):
+    return label
+
+
+def _inverse_rank(rank):
+    return 1. / rank
+
+
+def _pow2_minus_1(label):
+    return torch.pow(torch.tensor(2.0, dtype=label.dtype, device=label.device), label) - 1.
+
+
+def _inverse_log1p(rank):
+    return 1. / torch.log1p(rank)
+
+
+_KNOWN_GAINS = {}
+
+
+def register_gain_kind(fn: Callable, kind: int):
+    """Lets the kernels evaluate a known gain function in-register."""
+    _KNOWN_GAINS[fn] = kind
+
+
+register_gain_kind(_identity_gain, _ops.GAIN_IDENTITY)
+register_gain_kind(_pow2_minus_1, _ops.GAIN_POW2M1)
+
+
+def _gain_args(gain_fn, clean_labels_fn):
+    """(gain_kind, gains tensor or None) for a gain callable."""
+    kind = _KNOWN_GAINS.get(gain_fn)
+    if kind is not None:
+        return kind, None
+    return _ops.GAIN_CUSTOM, gain_fn(clean_labels_fn()).to(torch.float32).contiguous()
+
+
+def _check_tensor_shapes(tensors):
+    """losses_impl.py:52-58."""
+    first = tensors[0]
+    for t in tensors:
+        if t.dim() != 2:
+            raise ValueError('Shape %s must have rank 2' % (tuple(t.shape),))
+        if t.shape != first.shape:
+            raise ValueError('Shapes %s and %s are incompatible' % (tuple(t.shape), tuple(first.shape)))
+
+
+def approx_ranks(logits):
+    """losses_impl.py:77-106 (API parity; torch device ops)."""
+    return _mat.approx_ranks(logits)
+
+
+def inverse_max_dcg(labels, gain_fn=_pow2_minus_1, rank_discount_fn=_inverse_log1p, topn=None):
+    """losses_impl.py:109-134 (API parity)."""
+    return _mat.inverse_max_dcg(labels, gain_fn, rank_discount_fn, topn)
+
+
+def ndcg(labels, ranks=None, perm_mat=None):
+    """losses_impl.py:137-167 (API parity)."""
+    if ranks is not None and perm_mat is not None:
+        raise ValueError('Cannot use both ranks and perm_mat simultaneously.')
+    return _mat.ndcg(labels, ranks, perm_mat)
+
+
+# ------------------------------------------------------------- lambda weights
+class _LambdaWeight(object, metaclass=abc.ABCMeta):
+    """losses_impl.py:170-207."""
+
+    @abc.abstractmethod
+    def pair_weights(self, labels, ranks):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def individual_weights(self, labels, ranks):
+        del ranks
+        return labels
+
+
+class LabelDiffLambdaWeight(_LambdaWeight):
+    """losses_impl.py:210-217."""
+
+    def pair_weights(self, labels, ranks):
+        del ranks
+        return _mat.label_diff_pair_weights(labels)
+
+
+class AbstractDCGLambdaWeight(_LambdaWeight):
+    """losses_impl.py:219-296."""
+
+    def __init__(self, topn=None, gain_fn=_identity_gain, rank_discount_fn=_inverse_rank,
+                 normalized=False):
+        self._topn = topn
+        self._gain_fn = gain_fn
+        self._rank_discount_fn = rank_discount_fn
+        self._normalized = normalized
+
+    @abc.abstractmethod
+    def _pair_rank_discount(self, ranks, topn):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def pair_weights(self, labels, ranks):
+        _check_tensor_shapes([labels, ranks])
+        return _mat.dcg_pair_weights(self, labels, ranks)
+
+    def individual_weights(self, labels, ranks):
+        _check_tensor_shapes([labels, ranks])
+        return _mat.dcg_individual_weights(self, labels, ranks)
+
+
+class DCGLambdaWeight(AbstractDCGLambdaWeight):
+    """losses_impl.py:299-369."""
+
+    def __init__(self, topn=None, gain_fn=_identity_gain, rank_discount_fn=_inverse_rank,
+                 normalized=False, smooth_fraction=0.):
+        super().__init__(topn, gain_fn, rank_discount_fn, normalized)
+        if not 0. <= smooth_fraction <= 1.:
+            raise ValueError('smooth_fraction %s should be in range [0, 1].' % smooth_fraction)
+        self._smooth_fraction = smooth_fraction
+
+    def _pair_rank_discount(self, ranks, topn):
+        return _mat.dcg_pair_rank_discount(self, ranks, topn)
+
+    # -- what the fused kernels need
+    def _kernel_args(self, labels, list_size, device):
+        kind, gains = _gain_args(
+            self._gain_fn,
+            lambda: torch.where(labels >= 0, labels, torch.zeros_like(labels)))
+        return dict(lambda_kind=_ops.LAMBDA_DCG, topn=self._topn or 0,
+                    smooth_fraction=self._smooth_fraction, normalized=self._normalized,
+                    gain_kind=kind, gains=gains,
+                    discount=_ops.rank_table(self._rank_discount_fn, list_size + 1, device))
+
+
+def _lambda_kernel_args(lambda_weight, labels, list_size, device):
+    if lambda_weight is None:
+        return dict(lambda_kind=_ops.LAMBDA_NONE)
+    if isinstance(lambda_weight, DCGLambdaWeight):
+        return lambda_weight._kernel_args(labels, list_size, device)
+    if isinstance(lambda_weight, LabelDiffLambdaWeight):
+        return dict(lambda_kind=_ops.LAMBDA_LABELDIFF)
+    return None   # not fusable: caller falls back to the materialised API-parity path
+
+
+def _compute_ranks(logits, is_valid):
+    """losses_impl.py:483-500 via the sort kernel (invalid strictly last)."""
+    _check_tensor_shapes([logits, is_valid])
+    ranks, _ = _ops.sort_ranks(logits, None, is_valid, None, want_ranks=True, want_order=False)
+    return ranks
+
+
+# -------------------------------------------------------------------- sampler
+class _GumbelSampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, uniform, seed, offset, sample_size, temperature):
+        out = _ops.gumbel_sample(logits, labels, None, uniform, seed, offset, sample_size, temperature)
+        ctx.save_for_backward(out, labels)
+        ctx.sample_size, ctx.temperature = sample_size, temperature
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        out, labels = ctx.saved_tensors
+        d = _ops.gumbel_sample_bwd(out, labels, None, g.contiguous(), ctx.sample_size, ctx.temperature)
+        return d, None, None, None, None, None, None
+
+
+class GumbelSampler(object):
+    """losses_impl.py:540-644.  Noise: in-kernel Philox4x32-10 keyed by ``seed``
+    and a per-call offset, or an injected ``uniform`` [B, S, L] tensor (the
+    reference's TF random stream cannot be reproduced)."""
+
+    def __init__(self, name=None, sample_size=8, temperature=1.0, seed=None, ragged=False):
+        self._name = name
+        self._sample_size = sample_size
+        self._temperature = temperature
+        self._seed = seed
+        self._ragged = ragged
+        self._calls = 0
+
+    def sample(self, labels, logits, weights=None, uniform=None):
+        if self._ragged:
+            labels, logits, weights, _ = utils.ragged_to_dense(labels, logits, weights)
+        labels = _ops.require_device(torch.as_tensor(labels), 'labels').to(torch.float32)
+        logits = _ops.require_device(logits, 'logits').to(torch.float32)
+        if labels.dim() != 2:
+            raise NotImplementedError('3-D (subtopic) labels are outside the hot path.')
+        b, l = labels.shape
+        s = self._sample_size
+        seed = self._seed
+        if seed is None:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        offset = self._calls
+        self._calls += 1
+        sampled = _GumbelSampleFn.apply(logits, labels.contiguous(), uniform, seed, offset, s,
+                                        float(self._temperature))
+        expanded_labels = labels.unsqueeze(1).expand(b, s, l).reshape(b * s, l)
+        expanded_weights = weights
+        if expanded_weights is not None:
+            w = torch.as_tensor(expanded_weights, dtype=torch.float32, device=labels.device)
+            w = w.reshape(b, 1, 1) if w.dim() == 1 else w.unsqueeze(1)
+            expanded_weights = w.expand(b, s, w.shape[-1]).reshape(b * s, -1)
+        return expanded_labels, sampled, expanded_weights
+
+
+# --------------------------------------------------------------- autograd glue
+class _PerListLossFn(torch.autograd.Function):
+    """Wraps a fused fwd+bwd kernel: the kernel already produced
+    d(per_list[b])/d(logits[b, :]); backward only scales rows by the upstream."""
+
+    @staticmethod
+    def forward(ctx, logits, runner):
+        per_list, dlogits, aux = runner(logits.detach(), logits.requires_grad)
+        ctx.has_grad = dlogits is not None
+        if ctx.has_grad:
+            ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(*aux)
+        return (per_list,) + tuple(aux)
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        if not ctx.has_grad:
+            return None, None
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g.unsqueeze(1), None
+
+
+# -------------------------------------------------------------------- losses
+class _RankingLoss(object, metaclass=abc.ABCMeta):
+    """losses_impl.py:652-860."""
+
+    def __init__(self, name, lambda_weight=None, temperature=1.0, ragged=False):
+        self._name = name
+        self._lambda_weight = lambda_weight
+        self._temperature = temperature
+        self._ragged = ragged
+
+    @property
+    def name(self):
+        return self._name
+
+    def _prepare_and_validate_params(self, labels, logits, weights, mask):
+        if self._ragged:
+            labels, logits, weights, mask = utils.ragged_to_dense(labels, logits, weights)
+        logits = _ops.require_device(torch.as_tensor(logits), 'logits')
+        labels = torch.as_tensor(labels, dtype=torch.float32, device=logits.device)
+        if weights is None:
+            weights = 1.0
+        weights = torch.as_tensor(weights, dtype=torch.float32, device=logits.device)
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=logits.device).to(torch.bool)
+        _check_tensor_shapes([labels, logits] + ([mask] if mask is not None else []))
+        return labels, logits.to(torch.float32), weights, mask
+
+    def compute_unreduced_loss(self, labels, logits, mask=None):
+        labels, logits, _, mask = self._prepare_and_validate_params(labels, logits, None, mask)
+        return self._compute_unreduced_loss_impl(labels, logits, mask)
+
+    @abc.abstractmethod
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def normalize_weights(self, labels, weights):
+        if self._ragged:
+            labels, _, weights, _ = utils.ragged_to_dense(labels, None, weights)
+        labels = torch.as_tensor(labels, dtype=torch.float32)
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float32, device=labels.device)
+        return self._normalize_weights_impl(labels, weights)
+
+    def _normalize_weights_impl(self, labels, weights):
+        del labels
+        return 1.0 if weights is None else weights
+
+    def get_logits(self, logits):
+        return torch.as_tensor(logits) / self._temperature
+
+    def compute(self, labels, logits, weights, reduction, mask=None):
+        """losses_impl.py:787-814 (temperature applied inside the kernel)."""
+        labels, logits, _, mask = self._prepare_and_validate_params(labels, logits, None, mask)
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float32, device=logits.device)
+        return self._compute_reduced(labels, logits, weights, reduction, mask)
+
+    @abc.abstractmethod
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def eval_metric(self, labels, logits, weights, mask=None):
+        """losses_impl.py:838-860: weighted mean of the losses."""
+        return self.compute(labels, logits, weights, Reduction.MEAN, mask)
+
+
+# ------------------------------------------------------------------ pairwise
+class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
+    """losses_impl.py:863-930."""
+
+    _fused_kind = None   # subclasses with a fused kernel set this
+
+    @abc.abstractmethod
+    def _pairwise_loss(self, pairwise_logits):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            weights = 1.
+        weights = torch.where(utils.is_label_valid(labels), torch.ones_like(labels) * weights,
+                              torch.zeros_like(labels))
+        return weights.unsqueeze(2)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        """[B, L, L] losses and weights: API-parity path (torch device ops)."""
+        return _mat.pairwise_unreduced(self, labels, logits, mask)
+
+    # fused path -----------------------------------------------------------
+    def _fused(self, labels, logits, weights, mask, apply_temperature=True):
+        """Returns (list_loss [B] differentiable, row_loss [B,L], row_weight [B,L], nnz [B])."""
+        b, l = logits.shape
+        lam = _lambda_kernel_args(self._lambda_weight, labels, l, logits.device)
+        if lam is None or self._fused_kind is None:
+            return None
+        item_w = list_w = None
+        if weights is not None and weights.dim() > 0 and weights.numel() > 1:
+            if weights.dim() == 2 and weights.shape == (b, l):
+                item_w = weights
+            elif weights.numel() == b:
+                list_w = weights.reshape(b)
+            else:
+                raise ValueError('weights shape %s incompatible with [%d, %d]' % (tuple(weights.shape), b, l))
+        elif weights is not None:
+            list_w = torch.broadcast_to(weights.reshape(()), (b,)).contiguous()
+        temperature = self._temperature if apply_temperature else 1.0
+
+        def runner(lg, want_grad):
+            row_loss, row_weight, nnz, d = _ops.pairwise_logistic(
+                lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad, **lam)
+            return row_loss.sum(dim=1), d, (row_loss, row_weight, nnz)
+
+        return _PerListLossFn.apply(logits, runner)
+
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):
+        fused = self._fused(labels, logits, weights, mask)
+        if fused is None:
+            losses, loss_weights = self._compute_unreduced_loss_impl(labels, self.get_logits(logits), mask)
+            w = self._normalize_weights_impl(labels, weights) * loss_weights
+            return compute_weighted_loss(losses, w, reduction)
+        list_loss, row_loss, row_weight, nnz = fused
+        b, l = logits.shape
+        total = list_loss.sum()
+        if reduction == Reduction.SUM:
+            return total
+        if reduction == Reduction.MEAN:
+            return _safe_div(total, row_weight.sum())
+        if reduction == Reduction.SUM_BY_NONZERO_WEIGHTS:
+            return _safe_div(total, nnz.sum())
+        if reduction == Reduction.SUM_OVER_BATCH_SIZE:
+            return total / float(b * l * l)
+        raise ValueError('Invalid reduction: {}'.format(reduction))
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        """losses_impl.py:886-915 (NB: no temperature, like the reference)."""
+        labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
+        fused = self._fused(labels, logits, weights, mask, apply_temperature=False)
+        if fused is None:
+            losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+            w = self._normalize_weights_impl(labels, weights) * loss_weights
+            per_list_weights = w.sum(dim=(1, 2))
+            return _safe_div((losses * w).sum(dim=(1, 2)), per_list_weights), per_list_weights
+        list_loss, _, row_weight, _ = fused
+        per_list_weights = row_weight.sum(dim=1)
+        return _safe_div(list_loss, per_list_weights), per_list_weights
+
+
+class PairwiseLogisticLoss(_PairwiseLoss):
+    """losses_impl.py:933-940; fused kernel tfr_pairwise_logistic_f32."""
+    _fused_kind = 'logistic'
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.relu(-pairwise_logits) + torch.log1p(torch.exp(-torch.abs(pairwise_logits)))
+
+
+class PairwiseHingeLoss(_PairwiseLoss):
+    """losses_impl.py:943-948 (materialised path only; SURVEY 8f "next")."""
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.relu(1 - pairwise_logits)
+
+
+class PairwiseSoftZeroOneLoss(_PairwiseLoss):
+    """losses_impl.py:951-958 (materialised path only; SURVEY 8f "next")."""
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.where(pairwise_logits > 0, 1. - torch.sigmoid(pairwise_logits),
+                           torch.sigmoid(-pairwise_logits))
+
+
+# ------------------------------------------------------------------ listwise
+class _ListwiseLoss(_RankingLoss):
+    """losses_impl.py:1001-1033."""
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            return 1.0
+        weights = torch.as_tensor(weights, dtype=torch.float32, device=labels.device)
+        is_valid = utils.is_label_valid(labels)
+        labels = torch.where(is_valid, labels, torch.zeros_like(labels))
+        return _safe_div((weights * labels).sum(dim=1, keepdim=True), labels.sum(dim=1, keepdim=True))
+
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):
+        losses, loss_weights = self._unreduced(labels, logits, mask, self._temperature)
+        w = self._normalize_weights_impl(labels, weights) * loss_weights
+        return compute_weighted_loss(losses, w, reduction)
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        # NB: the reference does not apply the temperature here (losses_impl.py:1017-1033).
+        labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
+        losses, loss_weights = self._unreduced(labels, logits, mask, 1.0)
+        w = self._normalize_weights_impl(labels, weights) * loss_weights
+        return losses.squeeze(1), w.squeeze(1)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        # `logits` are already temperature-scaled by the caller (reference protocol).
+        return self._unreduced(labels, logits, mask, 1.0)
+
+    @abc.abstractmethod
+    def _unreduced(self, labels, logits, mask, temperature):
+        """([B,1] losses, [B,1] weights) with `logits / temperature` applied in-kernel."""
+
+
+class ApproxNDCGLoss(_ListwiseLoss):
+    """losses_impl.py:1579-1603; fused kernel tfr_approx_ndcg_f32."""
+
+    def __init__(self, name, lambda_weight=None, temperature=0.1, ragged=False):
+        super().__init__(name, lambda_weight, temperature, ragged)
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        def runner(lg, want_grad):
+            loss, weight, d = _ops.approx_ndcg(lg, labels, mask, None, temperature, 0, want_grad)
+            return loss, d, (weight,)
+        loss, weight = _PerListLossFn.apply(logits, runner)
+        return loss.unsqueeze(1), weight.unsqueeze(1)
+
+
+class SoftmaxLoss(_ListwiseLoss):
+    """losses_impl.py:1119-1197; fused kernel tfr_softmax_loss_f32."""
+
+    def _run(self, labels, logits, weights, mask, temperature):
+        lam = _lambda_kernel_args(self._lambda_weight, labels, logits.shape[1], logits.device)
+        if lam is None or lam['lambda_kind'] == _ops.LAMBDA_LABELDIFF:
+            lam = dict(lambda_kind=_ops.LAMBDA_NONE)     # only DCGLambdaWeight applies (:1132)
+        lam.pop('smooth_fraction', None)
+        if lam.get('gain_kind') == _ops.GAIN_CUSTOM:
+            m = mask if mask is not None else labels >= 0
+            clean = torch.where(m, labels, torch.zeros_like(labels))
+            clean = torch.where(clean >= 0, clean, torch.zeros_like(clean))
+            lam['gains'] = self._lambda_weight._gain_fn(clean).to(torch.float32).contiguous()
+
+        def runner(lg, want_grad):
+            loss, weight, d = _ops.softmax_loss(lg, labels, mask, weights, temperature=temperature,
+                                                want_grad=want_grad, **lam)
+            # kernel's dlogits = weight * dloss/dlogits; per_list output is weight*loss.
+            return loss * weight, d, (loss, weight)
+        weighted, loss, weight = _PerListLossFn.apply(logits, runner)
+        return weighted, loss, weight
+
+    def precompute(self, labels, logits, weights, mask=None):
+        """losses_impl.py:1122-1137 (API parity; torch device ops)."""
+        return _mat.softmax_precompute(self, labels, logits, weights, mask)
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        _, loss, weight = self._run(labels, logits, None, mask, temperature)
+        return loss, weight
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        # reference protocol: inputs are the *precomputed* labels/logits.
+        return _mat.softmax_unreduced(labels, logits, mask)
+
+    def _reduce(self, weighted, loss, weight, reduction):
+        # sum(loss * weight) must stay attached to the fused backward: use `weighted`.
+        total = weighted.sum()
+        if reduction == Reduction.NONE:
+            return weighted
+        if reduction == Reduction.SUM:
+            return total
+        if reduction == Reduction.MEAN:
+            return _safe_div(total, weight.sum())
+        if reduction == Reduction.SUM_BY_NONZERO_WEIGHTS:
+            return _safe_div(total, (weight != 0).sum().to(total.dtype))
+        if reduction == Reduction.SUM_OVER_BATCH_SIZE:
+            return total / weighted.numel()
+        raise ValueError('Invalid reduction: {}'.format(reduction))
+
+    def compute(self, labels, logits, weights, reduction, mask=None):
+        """losses_impl.py:1160-1167."""
+        labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
+        weighted, loss, weight = self._run(labels, logits, weights, mask, self._temperature)
+        return self._reduce(weighted, loss, weight, reduction)
+
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):   # pragma: no cover
+        raise AssertionError('SoftmaxLoss overrides compute')
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        """losses_impl.py:1178-1189 (temperature IS applied here, :1187)."""
+        labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
+        weighted, loss, weight = self._run(labels, logits, weights, mask, self._temperature)
+        return _AttachFn.apply(loss, weighted, weight), weight
+
+    def compute_unreduced_loss(self, labels, logits, mask=None):
+        """losses_impl.py:1191-1197."""
+        labels, logits, _, mask = self._prepare_and_validate_params(labels, logits, None, mask)
+        weighted, loss, weight = self._run(labels, logits, None, mask, self._temperature)
+        return _AttachFn.apply(loss, weighted, weight), weight
+
+
+class _AttachFn(torch.autograd.Function):
+    """Returns `loss` (values) while routing gradients through `weighted = loss *
+    weight`, whose backward is the fused kernel's: d loss = d weighted / weight."""
+
+    @staticmethod
+    def forward(ctx, loss, weighted, weight):
+        ctx.save_for_backward(weight)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (weight,) = ctx.saved_tensors
+        return None, _safe_div(g, weight), None
+
+
+class _PointwiseLoss(_RankingLoss):
+    """losses_impl.py:1284-1321 (config 1, elementwise; torch device ops suffice)."""
+
+    def _normalize_weights_impl(self, labels, weights):
+        if weights is None:
+            weights = 1.
+        return torch.where(utils.is_label_valid(labels), torch.ones_like(labels) * weights,
+                           torch.zeros_like(labels))
+
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, self.get_logits(logits), mask)
+        return compute_weighted_loss(losses, self._normalize_weights_impl(labels, weights) * loss_weights,
+                                     reduction)
+
+    def compute_per_list(self, labels, logits, weights, mask=None):
+        labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
+        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+        w = self._normalize_weights_impl(labels, weights) * loss_weights
+        per_list_weights = w.sum(dim=1)
+        return _safe_div((losses * w).sum(dim=1), per_list_weights), per_list_weights
+
+
+class SigmoidCrossEntropyLoss(_PointwiseLoss):
+    """losses_impl.py:1425-1446."""
+
+    def __init__(self, name, temperature=1.0, ragged=False):
+        super().__init__(name, None, temperature, ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = utils.is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        losses = torch.relu(logits) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
+        return losses, mask.to(torch.float32)

@@ -1,0 +1,146 @@
+"""Mirror of ``tensorflow_ranking/python/metrics_impl.py`` for NDCG and MRR.
+
+``compute(labels, predictions, weights=None, mask=None)`` returns the same
+``(per_list_metric [B, 1], per_list_weights [B, 1])`` pair as the reference; the
+per-list work (validation, two masked sorts, DCG sums) is one gfx950 kernel
+launch (``tfr_ndcg_metric_f32`` / ``tfr_mrr_metric_f32``).  Only the cross-list
+"batch mean" fix-up of the list weights (metrics_impl.py:101-113) is done with
+torch ops on ``[B]`` vectors.
+"""
+from __future__ import annotations
+
+import abc
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _ops
+from . import utils
+
+
+def _pow2_minus_1(label):
+    """metrics_impl.py:31 _DEFAULT_GAIN_FN."""
+    return torch.pow(torch.tensor(2.0, dtype=label.dtype, device=label.device), label) - 1.
+
+
+def _log2_inverse(rank):
+    """metrics_impl.py:33 _DEFAULT_RANK_DISCOUNT_FN."""
+    return math.log(2.) / torch.log1p(rank)
+
+
+_DEFAULT_GAIN_FN = _pow2_minus_1
+_DEFAULT_RANK_DISCOUNT_FN = _log2_inverse
+_IN_KERNEL_GAINS = {_pow2_minus_1}
+
+
+def register_pow2_gain(fn):
+    """Declares that ``fn`` computes 2^label - 1 (evaluated in-kernel)."""
+    _IN_KERNEL_GAINS.add(fn)
+
+
+def _safe_div(num, den):
+    ok = den != 0
+    return torch.where(ok, num / torch.where(ok, den, torch.ones_like(den)), torch.zeros_like(num))
+
+
+def per_list_weights_from_stats(stats):
+    """metrics_impl.py:63-119 given per-list (sum w, sum rel, sum w*rel)."""
+    sw, sr, swr = stats[:, 0:1], stats[:, 1:2], stats[:, 2:3]
+    nonzero_weights = sw > 0.0
+    nonzero_relevance = torch.where(nonzero_weights, (sr > 0.0).to(torch.float32), torch.zeros_like(sr))
+    count = nonzero_relevance.sum(dim=0, keepdim=True)
+    per_list = _safe_div(swr, sr)
+    sum_weights = per_list.sum(dim=0, keepdim=True)
+    avg = torch.where(count > 0.0, _safe_div(sum_weights, count), torch.ones_like(count))
+    return torch.where(nonzero_weights,
+                       torch.where(sr > 0.0, per_list, torch.ones_like(per_list) * avg),
+                       torch.zeros_like(per_list))
+
+
+class _RankingMetric(object, metaclass=abc.ABCMeta):
+    """metrics_impl.py:210-310."""
+
+    def __init__(self, ragged=False):
+        self._ragged = ragged
+
+    @property
+    @abc.abstractmethod
+    def name(self):
+        raise NotImplementedError('Calling an abstract method.')
+
+    def _prepare(self, labels, predictions, weights, mask):
+        if any(utils.is_ragged(t) for t in (labels, predictions, weights)):
+            if not self._ragged:
+                raise ValueError('labels, predictions and/or weights are ragged tensors, '
+                                 'use ragged=True to enable ragged support for metrics.')
+            labels, predictions, weights, mask = utils.ragged_to_dense(labels, predictions, weights)
+        predictions = _ops.require_device(torch.as_tensor(predictions), 'predictions').to(torch.float32)
+        labels = torch.as_tensor(labels, dtype=torch.float32, device=predictions.device)
+        if predictions.dim() != 2:
+            raise ValueError('predictions must have rank 2')
+        if labels.shape != predictions.shape:
+            raise ValueError('labels %s and predictions %s are incompatible'
+                             % (tuple(labels.shape), tuple(predictions.shape)))
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float32, device=predictions.device)
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=predictions.device).to(torch.bool)
+        return labels, predictions, weights, mask
+
+    def compute(self, labels, predictions, weights=None, mask=None):
+        labels, predictions, weights, mask = self._prepare(labels, predictions, weights, mask)
+        out, w = self._compute_multi(labels, predictions, weights, mask, [self._topn])
+        return out[0].unsqueeze(1), w
+
+    def compute_multi(self, labels, predictions, weights=None, mask=None,
+                      topns: Sequence[Optional[int]] = (None,)):
+        """Several cutoffs in ONE launch: returns ([K, B] metric, [B, 1] weights)."""
+        labels, predictions, weights, mask = self._prepare(labels, predictions, weights, mask)
+        return self._compute_multi(labels, predictions, weights, mask, list(topns))
+
+
+class MRRMetric(_RankingMetric):
+    """metrics_impl.py:429-459."""
+
+    def __init__(self, name, topn, ragged=False):
+        super().__init__(ragged=ragged)
+        self._name = name
+        self._topn = topn
+
+    @property
+    def name(self):
+        return self._name
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, stats = _ops.mrr_metric(labels, predictions, weights, mask, topns)
+        return out, per_list_weights_from_stats(stats)
+
+
+class NDCGMetric(_RankingMetric):
+    """metrics_impl.py:631-670."""
+
+    def __init__(self, name, topn, gain_fn=_DEFAULT_GAIN_FN, rank_discount_fn=_DEFAULT_RANK_DISCOUNT_FN,
+                 ragged=False):
+        super().__init__(ragged=ragged)
+        self._name = name
+        self._topn = topn
+        self._gain_fn = gain_fn
+        self._rank_discount_fn = rank_discount_fn
+
+    @property
+    def name(self):
+        return self._name
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        gains = None
+        if self._gain_fn not in _IN_KERNEL_GAINS:
+            # metrics_impl.py:256-262: mask &= weights > 0; invalid labels -> 0.
+            m = mask if mask is not None else labels >= 0
+            if weights is not None:
+                m = torch.logical_and(m, torch.broadcast_to(
+                    weights if weights.dim() == 2 else weights.reshape(-1, 1), labels.shape) > 0)
+            gains = self._gain_fn(torch.where(m, labels, torch.zeros_like(labels))).to(torch.float32)
+        discount = _ops.rank_table(self._rank_discount_fn, labels.shape[1], labels.device)
+        out, stats = _ops.ndcg_metric(labels, predictions, weights, mask, gains, discount, topns)
+        return out, per_list_weights_from_stats(stats)

@@ -1,0 +1,626 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs, against the reference's golden literals, and -- at the
+BASELINE.json sizes -- through size-independent properties.
+
+Tolerances (BASELINE.json north_star): integer ranks / orders and NDCG@k
+bit-exact; fp32 losses |delta| <= 1e-5; gradients max|delta| <= 1e-5 * max|g|
+(+1e-7) per batch, the oracle's gradient coming from torch autograd through the
+materialised op graph (the reference has no gradient tests: SURVEY.md 8c).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import tfr_ref as R
+from tests.common import make_batch, make_weights
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+LOSS_TOL = 1e-5
+GRAD_RTOL = 1e-5
+
+
+def ra():
+    import ranking_amd
+    return ranking_amd
+
+
+def assert_loss_close(got, want, tol=LOSS_TOL, what=''):
+    got = got.detach().cpu().double().reshape(-1)
+    want = want.detach().cpu().double().reshape(-1)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    err = (got - want).abs()
+    lim = tol * torch.clamp(want.abs(), min=1.0)
+    assert bool((err <= lim).all()), '%s: max err %.3e (tol %.1e) at %d: got %r want %r' % (
+        what, err.max().item(), tol, int(err.argmax()), got[err.argmax()].item(), want[err.argmax()].item())
+
+
+def assert_grad_close(got, want, rtol=GRAD_RTOL, what=''):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    assert err <= rtol * scale + 1e-7, '%s: max grad err %.3e vs scale %.3e (rel %.2e)' % (
+        what, err, scale, err / max(scale, 1e-30))
+
+
+SHAPES = [(1, 1), (3, 2), (4, 7), (5, 50), (8, 64), (6, 65), (7, 200), (3, 257), (2, 1000)]
+
+
+# ------------------------------------------------------------------ sort / ranks
+@pytest.mark.parametrize('B,L', SHAPES + [(2, 2048), (1, 5000)])
+def test_sort_ranks_bit_exact(B, L):
+    labels, logits = make_batch(B, L, seed=11 + L)
+    mask = labels >= 0
+    want_ranks = R._compute_ranks(logits, mask)
+    want_order, = R.sort_by_scores(logits, [torch.arange(L).expand(B, L)], mask=mask)
+    from ranking_amd import _ops
+    ranks, order = _ops.sort_ranks(logits.to(DEV), labels.to(DEV), None, None)
+    assert torch.equal(ranks.cpu(), want_ranks)
+    assert torch.equal(order.cpu().long(), want_order)
+    # property: every row of `order` is a permutation
+    assert torch.equal(torch.sort(order.cpu().long(), dim=1).values, torch.arange(L).expand(B, L))
+
+
+def test_sort_reference_goldens():
+    u = ra().utils
+    scores = torch.tensor([[1., 3., 2.], [1., 2., 3.]], device=DEV)
+    pos = torch.tensor([[1, 2, 3], [4, 5, 6]], device=DEV)
+    out, = u.sort_by_scores(scores, [pos], shuffle_ties=False)          # utils_test.py:64-72
+    assert out.tolist() == [[2, 3, 1], [6, 5, 4]]
+    out, = u.sort_by_scores(scores, [pos], topn=2, shuffle_ties=False)
+    assert out.tolist() == [[2, 3], [6, 5]]
+    s = torch.tensor([[0., math.inf, 2., -math.inf, 1.]], device=DEV)   # utils_test.py:114-126
+    names = torch.tensor([[0, 1, 2, 3, 4]], device=DEV)
+    m1 = torch.tensor([[True, False, True, True, False]], device=DEV)
+    m2 = torch.tensor([[False, True, False, True, True]], device=DEV)
+    assert u.sort_by_scores(s, [names], mask=m1, shuffle_ties=False)[0].tolist() == [[2, 0, 3, 1, 4]]
+    assert u.sort_by_scores(s, [names], mask=m2, shuffle_ties=False)[0].tolist() == [[1, 4, 3, 0, 2]]
+    assert u.sort_by_scores(s, [names], shuffle_ties=False)[0].tolist() == [[1, 2, 4, 0, 3]]
+    assert u.sorted_ranks(torch.tensor([[1., 3., 2.]], device=DEV)).tolist() == [[3, 1, 2]]  # :144-152
+    assert u.sorted_ranks(torch.tensor([[1., 2., 1.]], device=DEV), shuffle_ties=False).tolist() == [[2, 1, 3]]
+    # shuffled ties: still a valid ranking of the tie-free part
+    r = u.sorted_ranks(torch.tensor([[1., 2., 1.]], device=DEV), shuffle_ties=True, seed=1).tolist()[0]
+    assert r[1] == 1 and sorted(r) == [1, 2, 3]
+    sf = torch.tensor([[[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]],
+                       [[10., 20., 30.], [40., 50., 60.], [70., 80., 90.]]], device=DEV)
+    out, = u.sort_by_scores(scores, [sf], topn=2, shuffle_ties=False)    # utils_test.py:83-102
+    assert out.tolist() == [[[4., 5., 6.], [7., 8., 9.]], [[70., 80., 90.], [40., 50., 60.]]]
+
+
+# ---------------------------------------------------------------------- metrics
+@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('weighted', [False, True])
+def test_ndcg_mrr_bit_exact(B, L, weighted):
+    labels, preds = make_batch(B, L, seed=100 + L)
+    w = make_weights(B, L, seed=L) if weighted else None
+    if weighted and L > 2:
+        w[:, 1] = 0.0            # zero-weight items are masked out (metrics_impl.py:256)
+    mi = ra().metrics_impl
+    topns = [1, 3, 5, 10, None]
+    got, got_w = mi.NDCGMetric(None, None).compute_multi(
+        labels.to(DEV), preds.to(DEV), None if w is None else w.to(DEV), None, topns)
+    for q, k in enumerate(topns):
+        want, want_w = R.NDCGMetric(topn=k).compute(labels, preds, w)
+        assert torch.equal(got[q].cpu(), want.reshape(-1)), 'NDCG@%s not bit-exact: max diff %g' % (
+            k, (got[q].cpu() - want.reshape(-1)).abs().max())
+    assert_loss_close(got_w, want_w, 1e-6, 'ndcg list weights')
+    got, got_w = mi.MRRMetric(None, None).compute_multi(
+        labels.to(DEV), preds.to(DEV), None if w is None else w.to(DEV), None, topns)
+    for q, k in enumerate(topns):
+        want, want_w = R.MRRMetric(topn=k).compute(labels, preds, w)
+        assert torch.equal(got[q].cpu(), want.reshape(-1)), 'MRR@%s' % k
+    assert_loss_close(got_w, want_w, 1e-6, 'mrr list weights')
+
+
+def test_metric_reference_goldens():
+    km = ra().keras.metrics
+    t = lambda x: torch.tensor(x, device=DEV)
+    log2p1 = lambda x: math.log2(1. + x)
+    # keras/metrics.py:218-229, 729-740 doc values
+    assert abs(km.MRRMetric()(t([[0., 1., 1.]]), t([[3., 1., 2.]])).item() - 0.5) < 1e-6
+    assert abs(km.NDCGMetric()(t([[0., 1., 1.]]), t([[3., 1., 2.]])).item() - 0.6934264) < 1e-6
+    assert abs(km.NDCGMetric(ragged=True)([[0., 1.], [1., 2., 0.]], [t([2., 1.]), t([2., 5., 4.])]).item()
+               - 0.7974351) < 1e-6
+    assert abs(km.MRRMetric(ragged=True)([[0., 1.], [1., 2., 0.]], [t([2., 1.]), t([2., 5., 4.])]).item()
+               - 0.75) < 1e-6
+    mi = ra().metrics_impl
+    # metrics_impl_test.py:665-674 graded relevance
+    out, _ = mi.NDCGMetric(None, None).compute(t([[0., 3., 1., 0.]]), t([[4., 3., 2., 1.]]))
+    dcg = (2. ** 3. - 1.) / log2p1(2.) + 1. / log2p1(3.)
+    mx = (2. ** 3. - 1.) / log2p1(1.) + 1. / log2p1(2.)
+    assert abs(out.item() - dcg / mx) < 1e-6
+    # :676-699 custom gain / discount
+    out, _ = mi.NDCGMetric(None, None, gain_fn=lambda l: l / 2.).compute(
+        t([[0., 3., 1., 0.]]), t([[4., 3., 2., 1.]]))
+    assert abs(out.item() - ((3. / 2.) / log2p1(2.) + .5 / log2p1(3.)) /
+               ((3. / 2.) / log2p1(1.) + .5 / log2p1(2.))) < 1e-6
+    out, _ = mi.NDCGMetric(None, None, rank_discount_fn=lambda r: 1.0 / (r + 10.0)).compute(
+        t([[0., 3., 1., 0.]]), t([[4., 3., 2., 1.]]))
+    assert abs(out.item() - ((2. ** 3. - 1.) / 12. + 1. / 13.) / ((2. ** 3. - 1.) / 11. + 1. / 12.)) < 1e-6
+    # :701-722 padded / masked
+    e = ((2. ** 2. - 1.) / log2p1(3.) + 1. / log2p1(1.)) / ((2. ** 2. - 1.) / log2p1(1.) + 1. / log2p1(2.))
+    out, _ = mi.NDCGMetric(None, None).compute(t([[2., -1., 1., 0.]]), t([[1., 4., 3., 2.]]))
+    assert abs(out.item() - e) < 1e-6
+    out, _ = mi.NDCGMetric(None, None).compute(t([[2., 2., 1., 0.]]), t([[1., 4., 3., 2.]]),
+                                               mask=t([[True, False, True, True]]))
+    assert abs(out.item() - e) < 1e-6
+    # :795-839 weights
+    _, w = mi.NDCGMetric(None, None).compute(t([[1., 0., 2.]]), t([[1., 3., 2.]]), t([[3., 7., 9.]]))
+    assert abs(w.item() - (1. * 3. + 3. * 9.) / 4.) < 1e-6
+    out, w = mi.NDCGMetric(None, None).compute(t([[1., 2., 3.]]), t([[1., 2., 3.]]), t([[0., 0., 0.]]))
+    assert out.item() == 0.0 and w.item() == 0.0
+    # MRR :29-136
+    out, _ = mi.MRRMetric(None, 2).compute(t([[1., 0., 0.], [0., 1., 0.], [0., 0., 1.]]),
+                                            t([[3., 2., 1.]] * 3))
+    assert out.reshape(-1).tolist() == [1., .5, 0.]
+    _, w = mi.MRRMetric(None, None).compute(t([[0., 0., 0.], [0., 0., 0.]]), t([[1., 3., 2.], [1., 3., 2.]]),
+                                            t([[2., 5., 1.], [1., 1., 0.]]))
+    assert w.reshape(-1).tolist() == [1., 1.]
+    with pytest.raises(ValueError):      # metrics_impl.py:245-248
+        mi.NDCGMetric(None, None).compute([[0., 1.], [1., 2., 0.]], [t([2., 1.]), t([2., 5., 4.])])
+
+
+# -------------------------------------------------------------------- ApproxNDCG
+def _oracle_grad(fn, logits):
+    lg = logits.clone().requires_grad_(True)
+    out = fn(lg)
+    out.sum().backward()
+    return out.detach(), lg.grad
+
+
+@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('temperature', [0.1, 1.0])
+def test_approx_ndcg_parity(B, L, temperature):
+    labels, logits = make_batch(B, L, seed=200 + L)
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.zeros_like(labels[0]), labels[0])  # all-zero labels
+        labels[1] = -1.0                                                                  # fully padded
+    oracle = R.ApproxNDCGLoss(temperature=temperature)
+    want, want_g = _oracle_grad(
+        lambda lg: oracle._compute_unreduced_loss_impl(labels, lg / temperature)[0], logits)
+    want_w = oracle._compute_unreduced_loss_impl(labels, logits / temperature)[1]
+    from ranking_amd import _ops
+    for lanes in (1, 4, 16):
+        loss, weight, d = _ops.approx_ndcg(logits.to(DEV), labels.to(DEV), None, None, temperature, lanes)
+        assert_loss_close(loss, want, what='approx_ndcg loss lanes=%d' % lanes)
+        assert torch.equal(weight.cpu(), want_w.reshape(-1))
+        assert_grad_close(d, want_g, what='approx_ndcg grad lanes=%d' % lanes)
+
+
+def test_approx_ndcg_wide_range_path():
+    """Logit ranges > 160 take the per-pair exp path; both paths must agree with the oracle."""
+    labels, logits = make_batch(6, 40, seed=5)
+    logits = logits * 60.0
+    oracle = R.ApproxNDCGLoss(temperature=1.0)
+    want, want_g = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels, lg)[0], logits)
+    from ranking_amd import _ops
+    loss, _, d = _ops.approx_ndcg(logits.to(DEV), labels.to(DEV), None, None, 1.0)
+    assert_loss_close(loss, want, what='wide range loss')
+    assert_grad_close(d, want_g, 1e-4, what='wide range grad')
+
+
+def test_approx_ndcg_fp64_arbiter():
+    """The kernel must be as close to an fp64 evaluation as the fp32 oracle is."""
+    labels, logits = make_batch(32, 200, seed=9)
+    o64 = R.ApproxNDCGLoss(temperature=0.1)
+    l64, g64 = _oracle_grad(lambda lg: o64._compute_unreduced_loss_impl(labels.double(), lg / 0.1)[0],
+                            logits.double())
+    l32, g32 = _oracle_grad(lambda lg: o64._compute_unreduced_loss_impl(labels, lg / 0.1)[0], logits)
+    from ranking_amd import _ops
+    loss, _, d = _ops.approx_ndcg(logits.to(DEV), labels.to(DEV), None, None, 0.1)
+    e_kernel = (loss.cpu().double() - l64.reshape(-1)).abs().max().item()
+    e_oracle = (l32.double().reshape(-1) - l64.reshape(-1)).abs().max().item()
+    assert e_kernel <= max(4 * e_oracle, 2e-6), (e_kernel, e_oracle)
+    g_kernel = (d.cpu().double() - g64).abs().max().item()
+    g_oracle = (g32.double() - g64).abs().max().item()
+    assert g_kernel <= max(4 * g_oracle, 1e-6 * g64.abs().max().item()), (g_kernel, g_oracle)
+
+
+def test_approx_ndcg_reference_goldens():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    ln = math.log
+    # losses_impl_test.py:543-554 (compute_per_list: temperature NOT applied)
+    losses, weights = L.ApproxNDCGLoss(None).compute_per_list(
+        t([[0., 0., 1.], [0., 0., 2.]]), t([[1., 3., 2.], [1., 2., 3.]]), t([[2., 3., 4.], [1., 1., 1.]]))
+    assert_loss_close(losses, torch.tensor([-0.63093, -0.796248]), 1e-5)
+    assert weights.tolist() == [4., 1.]
+    # losses_impl_test.py:1665-1692
+    scores = t([[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]])
+    labels = t([[0., 2., 1.], [1., 0., -1.], [0., 0., 0.]])
+    base = (1 / (3 / ln(2) + 1 / ln(3))) * (3 / ln(4) + 1 / ln(3))
+    loss = L.ApproxNDCGLoss(None, temperature=0.1)
+    RED = L.Reduction
+    assert abs(loss.compute(labels, scores, None, RED.SUM).item() + (base + ln(2) / ln(3))) < 1e-5
+    assert abs(loss.compute(labels, scores, t([[2.], [1.], [1.]]), RED.SUM).item()
+               + (2 * base + ln(2) / ln(3))) < 1e-5
+    ew = [[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]]
+    nw = [(2 * 2 + 3 * 1) / 3., 4.]
+    assert abs(loss.compute(labels, scores, t(ew), RED.SUM).item()
+               + (nw[0] * base + nw[1] * ln(2) / ln(3))) < 1e-5
+    # :1694-1724 mask + extreme label
+    for big in (1., 1000.):
+        r = L.ApproxNDCGLoss(None, temperature=1.).compute(
+            t([[0., 0., big]]), t([[1., 3., 2.]]), None, RED.SUM_BY_NONZERO_WEIGHTS,
+            mask=t([[True, False, True]]))
+        approxrank = 1. + 1. / (1. + math.exp(-(1. - 2.)))
+        assert abs(r.item() + (1. / math.log(1. + approxrank)) * math.log(2.)) < 1e-5
+    # keras/losses.py:1183-1194 doc values
+    assert abs(K.ApproxNDCGLoss()(t([[1., 0.]]), t([[0.6, 0.8]])).item() + 0.655107) < 1e-6
+    assert abs(K.ApproxNDCGLoss(ragged=True)([[1., 0.], [0., 1., 0.]],
+                                             [t([0.6, 0.8]), t([0.5, 0.8, 0.4])]).item() + 0.80536866) < 1e-6
+
+
+# ---------------------------------------------------------------------- pairwise
+def _lambda_pairs():
+    """(ranking_amd lambda, oracle lambda) constructors."""
+    L = ra().losses_impl
+    K = ra().keras.losses
+    return [
+        (lambda: None, lambda: None),
+        (lambda: L.DCGLambdaWeight(), lambda: R.DCGLambdaWeight()),
+        (lambda: K.NDCGLambdaWeight(), lambda: R.NDCGLambdaWeight()),
+        (lambda: K.NDCGLambdaWeight(topn=5, smooth_fraction=0.3),
+         lambda: R.NDCGLambdaWeight(topn=5, smooth_fraction=0.3)),
+        (lambda: L.DCGLambdaWeight(topn=3, smooth_fraction=1.0), lambda: R.DCGLambdaWeight(topn=3, smooth_fraction=1.0)),
+        (lambda: ra().losses.create_ndcg_lambda_weight(topn=10), lambda: R.create_ndcg_lambda_weight(topn=10)),
+        (lambda: L.DCGLambdaWeight(gain_fn=lambda l: l * 0.5 + 1.0, normalized=True),
+         lambda: R.DCGLambdaWeight(gain_fn=lambda l: l * 0.5 + 1.0, normalized=True)),
+        (lambda: L.LabelDiffLambdaWeight(), lambda: R.LabelDiffLambdaWeight()),
+    ]
+
+
+@pytest.mark.parametrize('B,L', [(3, 2), (4, 7), (5, 50), (6, 65), (4, 200), (2, 600)])
+@pytest.mark.parametrize('lam_idx', range(8))
+@pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
+def test_pairwise_logistic_parity(B, L, lam_idx, wkind):
+    labels, logits = make_batch(B, L, seed=300 + L)
+    mine, theirs = _lambda_pairs()[lam_idx]
+    weights = None
+    if wkind == 'item':
+        weights = make_weights(B, L, seed=L)
+    elif wkind == 'list':
+        weights = make_weights(B, 1, seed=L)
+    T = 0.7
+    oracle = R.PairwiseLogisticLoss(lambda_weight=theirs(), temperature=T)
+
+    def oracle_rows(lg):
+        losses, w = oracle._compute_unreduced_loss_impl(labels, lg / T, labels >= 0)
+        nw = oracle._normalize_weights_impl(labels, weights)
+        return (losses * w * nw).sum(dim=2), (w * nw)
+
+    lg = logits.clone().requires_grad_(True)
+    want_rows, want_w = oracle_rows(lg)
+    want_rows.sum().backward()
+    loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=mine(), temperature=T)
+    lgd = logits.to(DEV).requires_grad_(True)
+    fused = loss._fused(labels.to(DEV), lgd, None if weights is None else weights.to(DEV), None)
+    list_loss, row_loss, row_weight, nnz = fused
+    scale = max(1.0, want_rows.abs().max().item())
+    assert_loss_close(row_loss / scale, want_rows.detach() / scale, what='pairwise rows')
+    assert_loss_close(row_weight / max(1., want_w.sum(2).max().item()),
+                      want_w.sum(dim=2) / max(1., want_w.sum(2).max().item()), what='pairwise row weights')
+    assert torch.equal(nnz.cpu(), (want_w != 0).sum(dim=(1, 2)).float())
+    list_loss.sum().backward()
+    assert_grad_close(lgd.grad, lg.grad, what='pairwise grad')
+    # reduced entry points
+    for red_mine, red_or in [('weighted_sum', R.Reduction.SUM), ('weighted_mean', R.Reduction.MEAN),
+                             ('weighted_sum_by_nonzero_weights', R.Reduction.SUM_BY_NONZERO_WEIGHTS),
+                             ('weighted_sum_over_batch_size', R.Reduction.SUM_OVER_BATCH_SIZE)]:
+        got = loss.compute(labels.to(DEV), logits.to(DEV), None if weights is None else weights.to(DEV),
+                           red_mine)
+        want = oracle.compute(labels, logits, weights, red_or)
+        assert_loss_close(got / scale, want / scale, what='pairwise compute %s' % red_mine)
+
+
+def test_pairwise_materialized_api_matches_fused():
+    """compute_unreduced_loss ([B,L,L], torch device ops) agrees with the fused kernel."""
+    labels, logits = make_batch(4, 33, seed=77)
+    K = ra().keras.losses
+    loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
+    losses, weights = loss.compute_unreduced_loss(labels.to(DEV), logits.to(DEV))
+    _, row_loss, _, _ = loss._fused(labels.to(DEV), logits.to(DEV), None, None)
+    assert_loss_close((losses * weights).sum(dim=2), row_loss, what='materialised vs fused')
+    o_l, o_w = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight()).compute_unreduced_loss(labels, logits)
+    assert_loss_close(losses * weights, o_l * o_w, what='materialised vs oracle')
+
+
+def test_pairwise_reference_goldens():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    logloss = lambda x: math.log(1. + math.exp(-x))
+    scores = t([[1., 3., 2.], [1., 2., 3.]])
+    labels = t([[0., 0., 1.], [0., 0., 2.]])
+    MEAN = L.Reduction.MEAN
+    loss = L.PairwiseLogisticLoss(None)
+    # losses_impl_test.py:641-652
+    e = (logloss(3. - 2.) + logloss(1. - 2.) + logloss(3. - 1.) + logloss(3. - 2.)) / 4.
+    assert abs(loss.compute(labels, scores, None, MEAN).item() - e) < 1e-5
+    # :654-667 list weights, :669-682 example weights
+    e = (1. * (logloss(1.) + logloss(-1.)) + 2. * (logloss(1.) + logloss(2.))) / 6.
+    assert abs(loss.compute(labels, scores, t([[1.], [2.]]), MEAN).item() - e) < 1e-5
+    e = ((2. * logloss(1.) + 2. * logloss(-1.)) + (logloss(2.) + logloss(1.))) / 6.
+    assert abs(loss.compute(labels, scores, t([[1., 1., 2.], [1., 1., 1.]]), MEAN).item() - e) < 1e-5
+    # :684-699 lambda weights
+    lw = L.PairwiseLogisticLoss(None, lambda_weight=L.DCGLambdaWeight())
+    e = ((1.5 * logloss(1.) + 1.5 * logloss(-1.)) + (1. * logloss(2.) + 3. * logloss(1.))) / 7.
+    assert abs(lw.compute(labels, scores, None, MEAN).item() - e) < 1e-5
+    # :701-711 invalid labels; :713-724 mask
+    assert abs(loss.compute(t([[0., -1., 1.]]), t([[1., 3., 2.]]), None, MEAN).item() - logloss(1.)) < 1e-5
+    r = loss.compute(t([[1., 0., 0.], [0., 0., 2.]]), scores, None, MEAN,
+                     mask=t([[True, False, True], [True, True, True]]))
+    assert abs(r.item() - (logloss(-1.) + logloss(2.) + logloss(1.)) / 3.) < 1e-5
+    # ragged per-list / unreduced literals :556-611
+    rl, rs, rw = [[0., 0., 1.], [0., 2.]], [t([1., 3., 2.]), t([1., 3.])], [[2., 3., 4.], [1., 1.]]
+    losses, weights = L.PairwiseLogisticLoss(None, ragged=True).compute_per_list(rl, rs, rw)
+    assert_loss_close(losses, torch.tensor([0.813262, 0.126928]))
+    assert weights.tolist() == [8., 1.]
+    # keras doc values keras/losses.py:417-428
+    assert abs(K.PairwiseLogisticLoss()(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.39906943) < 1e-6
+    assert abs(K.PairwiseLogisticLoss(ragged=True)([[1., 0.], [0., 1., 0.]],
+                                                   [t([0.6, 0.8]), t([0.5, 0.8, 0.4])]).item()
+               - 0.3109182) < 1e-6
+    # lambda-weight API literals :342-433
+    ranks = t([[1, 2, 3]]).int()
+    w = L.DCGLambdaWeight().pair_weights(t([[2.0, 1.0, 0.0]]), ranks) / 3.
+    assert_loss_close(w, torch.tensor([[[0., .5, 1. / 3.], [.5, 0., .5], [1. / 3., .5, 0.]]]))
+    w = L.DCGLambdaWeight(topn=1, smooth_fraction=1.0).pair_weights(t([[2.0, 1.0, 0.0]]), ranks) / 3.
+    assert_loss_close(w, torch.tensor([[[0., 1., 2.], [1., 0., 0.], [2., 0., 0.]]]))
+    w = L.DCGLambdaWeight(normalized=True).individual_weights(t([[1.0, 2.0]]), t([[1, 2]]).int())
+    assert_loss_close(w, torch.tensor([[1. / 2.5, 2. / 2.5 / 2.]]))
+    with pytest.raises(ValueError):
+        L.DCGLambdaWeight(smooth_fraction=1.5)
+
+
+# ----------------------------------------------------------------------- softmax
+@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
+@pytest.mark.parametrize('lam_idx', [0, 1, 2, 3, 6])
+def test_softmax_parity(B, L, wkind, lam_idx):
+    labels, logits = make_batch(B, L, seed=400 + L)
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.zeros_like(labels[0]), labels[0])
+    mine, theirs = _lambda_pairs()[lam_idx]
+    weights = None
+    if wkind == 'item':
+        weights = make_weights(B, L, seed=L)
+    elif wkind == 'list':
+        weights = make_weights(B, 1, seed=L)
+    T = 0.5
+    oracle = R.SoftmaxLoss(lambda_weight=theirs(), temperature=T)
+    lg = logits.clone().requires_grad_(True)
+    o_loss, o_w = oracle.compute_per_list(labels, lg, weights)
+    (o_loss * o_w).sum().backward()
+    loss = ra().losses_impl.SoftmaxLoss(None, lambda_weight=mine(), temperature=T)
+    lgd = logits.to(DEV).requires_grad_(True)
+    g_loss, g_w = loss.compute_per_list(labels.to(DEV), lgd, None if weights is None else weights.to(DEV))
+    assert_loss_close(g_loss, o_loss.detach(), what='softmax per-list loss')
+    assert_loss_close(g_w / max(1., o_w.max().item()), o_w / max(1., o_w.max().item()), what='softmax weights')
+    (g_loss * g_w).sum().backward()
+    assert_grad_close(lgd.grad, lg.grad, what='softmax grad')
+    for red in ('weighted_sum', 'weighted_mean', 'weighted_sum_by_nonzero_weights'):
+        got = loss.compute(labels.to(DEV), logits.to(DEV), None if weights is None else weights.to(DEV), red)
+        want = oracle.compute(labels, logits, weights, red)
+        assert_loss_close(got / max(1., want.abs().item()), want / max(1., want.abs().item()),
+                          what='softmax compute %s' % red)
+
+
+def test_softmax_reference_goldens():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    ln = math.log
+
+    def softmax(v):
+        tot = sum(math.exp(x) for x in v)
+        return [math.exp(x) / tot for x in v]
+
+    scores = t([[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]])
+    sc = scores.tolist()
+    red = L.Reduction.SUM_BY_NONZERO_WEIGHTS
+    loss = L.SoftmaxLoss(None)
+    # losses_impl_test.py:1089-1101
+    r = loss.compute(t([[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]), scores, None, red)
+    assert abs(r.item() + (ln(softmax(sc[0])[2]) + ln(softmax(sc[1])[2]) * 2.) / 2.) < 1e-5
+    # :1103-1119 example weights
+    p = [softmax(s) for s in sc]
+    r = loss.compute(t([[0., 0., 1.], [1., 1., 2.], [0., 0., 0.]]), scores,
+                     t([[1., 1., 1.], [1., 2., 3.], [1., 0., 1.]]), red)
+    assert abs(r.item() + (ln(p[0][2]) + ln(p[1][0]) + ln(p[1][1]) * 2. + ln(p[1][2]) * 6.) / 2.) < 1e-5
+    # :1121-1136 list weights
+    r = loss.compute(t([[1., 2., 1.], [0., 0., 2.], [0., 0., 0.]]), scores, t([[2.], [1.], [1.]]), red)
+    assert abs(r.item() + (ln(p[0][0]) * 2. + ln(p[0][1]) * 4. + ln(p[0][2]) * 2. + ln(p[1][2]) * 2.) / 2.) < 1e-5
+    # :1138-1151 lambda weights
+    lw = L.DCGLambdaWeight(rank_discount_fn=lambda r: 1. / torch.log1p(r))
+    r = L.SoftmaxLoss(None, lambda_weight=lw).compute(
+        t([[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]), scores, None, red)
+    assert abs(r.item() + (ln(softmax(sc[0])[2]) / ln(3.) + ln(softmax(sc[1])[2]) * 2. / ln(2.)) / 2.) < 1e-5
+    # :1153-1162 per list
+    losses, weights = loss.compute_per_list(t([[0., 0., 1.], [0., 0., 2.]]), t([[1., 3., 2.], [1., 2., 3.]]),
+                                            t([[2., 3., 4.], [1., 1., 1.]]))
+    assert_loss_close(losses, torch.tensor([1.407606, 0.407606]))
+    assert weights.tolist() == [4., 2.]
+    # :1164-1183 invalid labels / mask
+    r = loss.compute(t([[0., -1., 1.]]), t([[1., 3., 2.]]), None, red)
+    assert abs(r.item() + ln(softmax([1, 2])[1])) < 1e-5
+    r = loss.compute(t([[0., 1., 1.]]), t([[1., 2., 3.]]), None, red, mask=t([[True, False, True]]))
+    assert abs(r.item() + ln(softmax([1, 3])[1])) < 1e-5
+    # :1185-1205 padded zero / fully padded
+    a = loss.compute_unreduced_loss(t([[0., -1.]]), t([[0., 0.]]))[0]
+    b = loss.compute_unreduced_loss(t([[0.]]), t([[0.]]))[0]
+    assert abs(a.item() - b.item()) < 1e-6
+    assert abs(loss.compute_unreduced_loss(t([[-1., -1.]]), t([[0., 0.]]))[0].item()) < 1e-6
+    # keras doc values keras/losses.py:770-781
+    assert abs(K.SoftmaxLoss()(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.7981389) < 1e-6
+    assert abs(K.SoftmaxLoss(ragged=True)([[1., 0.], [0., 1., 0.]],
+                                          [t([0.6, 0.8]), t([0.5, 0.8, 0.4])]).item() - 0.83911896) < 1e-6
+
+
+# ------------------------------------------------------------------------ gumbel
+@pytest.mark.parametrize('B,L,S', [(3, 5, 2), (4, 50, 8), (2, 200, 4)])
+def test_gumbel_sampler_parity(B, L, S):
+    labels, logits = make_batch(B, L, seed=500 + L)
+    g = torch.Generator().manual_seed(3)
+    u = torch.rand((B, S, L), generator=g)
+    Tg = 0.8
+    oracle = R.GumbelSampler(sample_size=S, temperature=Tg)
+    lg = logits.clone().requires_grad_(True)
+    ol, os_, _ = oracle.sample(labels, lg, None, uniform=u)
+    up = torch.randn(os_.shape, generator=g)
+    (os_ * up).sum().backward()
+    sampler = ra().losses_impl.GumbelSampler(sample_size=S, temperature=Tg, seed=1)
+    lgd = logits.to(DEV).requires_grad_(True)
+    gl, gs, _ = sampler.sample(labels.to(DEV), lgd, None, uniform=u.to(DEV))
+    assert torch.equal(gl.cpu(), ol)
+    assert_loss_close(gs, os_.detach(), 1e-5, 'gumbel sampled logits')
+    (gs * up.to(DEV)).sum().backward()
+    assert_grad_close(lgd.grad, lg.grad, 1e-5, 'gumbel grad')
+
+
+def test_gumbel_approx_ndcg_keras_parity():
+    B, L, S = 6, 50, 8
+    labels, logits = make_batch(B, L, seed=66)
+    u = torch.rand((B, S, L), generator=torch.Generator().manual_seed(8))
+    K = ra().keras.losses
+    mine = K.GumbelApproxNDCGLoss(sample_size=S, gumbel_temperature=1.0, temperature=0.1, seed=3)
+    lgd = logits.to(DEV).requires_grad_(True)
+    got = mine(labels.to(DEV), lgd, None, uniform=u.to(DEV))
+    got.backward()
+    lg = logits.clone().requires_grad_(True)
+    want = R.keras_loss_call(R.ApproxNDCGLoss(temperature=0.1), labels, lg,
+                             gumbel_sampler=R.GumbelSampler(sample_size=S, temperature=1.0), uniform=u)
+    want.backward()
+    assert_loss_close(got, want.detach(), what='gumbel approx ndcg')
+    assert_grad_close(lgd.grad, lg.grad, 2e-5, 'gumbel approx ndcg grad')
+    l2, d2 = mine.loss_and_grad(labels.to(DEV), logits.to(DEV), None, uniform=u.to(DEV))
+    assert_loss_close(l2, want.detach(), what='gumbel loss_and_grad')
+    assert_grad_close(d2, lg.grad, 2e-5, 'gumbel loss_and_grad grad')
+    # in-kernel Philox: deterministic for a fixed (seed, call index), different across calls
+    a = ra().losses_impl.GumbelSampler(sample_size=S, seed=5).sample(labels.to(DEV), logits.to(DEV))[1]
+    b = ra().losses_impl.GumbelSampler(sample_size=S, seed=5).sample(labels.to(DEV), logits.to(DEV))[1]
+    c = ra().losses_impl.GumbelSampler(sample_size=S, seed=6).sample(labels.to(DEV), logits.to(DEV))[1]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    valid = (labels >= 0).unsqueeze(1).expand(B, S, L).reshape(B * S, L)
+    lse = torch.logsumexp(torch.where(valid, a.cpu(), torch.full_like(a.cpu(), -1e9)), dim=1)
+    assert lse.abs().max().item() < 1e-4      # rows are normalised log-probabilities
+
+
+# -------------------------------------------------------- keras-level + fused path
+@pytest.mark.parametrize('name', ['approx', 'pairwise', 'pairwise_lambda', 'softmax'])
+@pytest.mark.parametrize('red', ['auto', 'sum'])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_keras_loss_and_grad_matches_autograd_and_oracle(name, red, weighted):
+    B, L = 16, 100
+    labels, logits = make_batch(B, L, seed=600)
+    sw = make_weights(B, 1, seed=1) if weighted else None
+    K = ra().keras.losses
+    mk = {'approx': (lambda: K.ApproxNDCGLoss(reduction=red), lambda: R.ApproxNDCGLoss()),
+          'pairwise': (lambda: K.PairwiseLogisticLoss(reduction=red), lambda: R.PairwiseLogisticLoss()),
+          'pairwise_lambda': (lambda: K.PairwiseLogisticLoss(reduction=red, lambda_weight=K.NDCGLambdaWeight()),
+                              lambda: R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight())),
+          'softmax': (lambda: K.SoftmaxLoss(reduction=red), lambda: R.SoftmaxLoss())}[name]
+    mine, theirs = mk[0](), mk[1]()
+    lg = logits.clone().requires_grad_(True)
+    want = R.keras_loss_call(theirs, labels, lg, sw,
+                             R.Reduction.AUTO if red == 'auto' else R.Reduction.KERAS_SUM)
+    want.backward()
+    lgd = logits.to(DEV).requires_grad_(True)
+    got = mine(labels.to(DEV), lgd, None if sw is None else sw.to(DEV))
+    got.backward()
+    s = max(1., abs(want.item()))
+    assert_loss_close(got / s, want.detach() / s, what='keras %s' % name)
+    assert_grad_close(lgd.grad, lg.grad, what='keras %s grad' % name)
+    l2, d2 = mine.loss_and_grad(labels.to(DEV), logits.to(DEV), None if sw is None else sw.to(DEV))
+    assert_loss_close(l2 / s, want.detach() / s, what='loss_and_grad %s' % name)
+    assert_grad_close(d2, lg.grad, what='loss_and_grad %s grad' % name)
+
+
+def test_make_loss_fn_and_metric_fn():
+    B, L = 8, 30
+    labels, logits = make_batch(B, L, seed=42)
+    w = make_weights(B, 1, seed=2)
+    rl = ra().losses
+    fn = rl.make_loss_fn('softmax_loss:0.5,approx_ndcg_loss:2.0', weights_feature_name='w')
+    got = fn(labels.to(DEV), logits.to(DEV), {'w': w.to(DEV)})
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    want = 0.5 * R.SoftmaxLoss().compute(labels, logits, w, red) \
+        + 2.0 * R.ApproxNDCGLoss().compute(labels, logits, w, red)
+    assert_loss_close(got, want, what='make_loss_fn')
+    with pytest.raises(ValueError):
+        rl.make_loss_fn('nope_loss')(labels.to(DEV), logits.to(DEV), {})
+    with pytest.raises(ValueError):
+        rl.make_loss_fn('softmax_loss', reduction='none')
+    mfn = ra().metrics.make_ranking_metric_fn('ndcg', topn=10)
+    got = mfn(labels.to(DEV), logits.to(DEV), {})
+    v, lw = R.NDCGMetric(topn=10).compute(labels, logits)
+    assert_loss_close(got, (v * lw).sum() / lw.sum(), 1e-6, 'metric fn')
+
+
+# ---------------------------------------------- full-size properties (BASELINE sizes)
+def test_headline_size_properties():
+    """B=16384, L=200 (headline config): size-independent properties."""
+    B, L = 16384, 200
+    labels, logits = make_batch(B, L, seed=4)
+    labels, logits = labels.to(DEV), logits.to(DEV)
+    from ranking_amd import _ops
+    loss, weight, d = _ops.approx_ndcg(logits, labels, None, None, 0.1)
+    assert torch.isfinite(loss).all() and torch.isfinite(d).all()
+    assert (loss <= 1e-6).all() and (loss >= -1.0 - 1e-5).all()          # -NDCG in [-1, 0]
+    assert (d[labels < 0] == 0).all()                                    # padding gets no gradient
+    assert d.sum(dim=1).abs().max().item() < 1e-3                       # shift invariance: sum_k grad_k = 0
+    # permutation equivariance
+    perm = torch.stack([torch.randperm(L, device=DEV) for _ in range(8)])
+    sub_l, sub_s = labels[:8], logits[:8]
+    l2, _, d2 = _ops.approx_ndcg(torch.gather(sub_s, 1, perm), torch.gather(sub_l, 1, perm), None, None, 0.1)
+    assert (l2 - loss[:8]).abs().max().item() < 2e-6
+    assert (torch.gather(d[:8], 1, perm) - d2).abs().max().item() <= 2e-5 * d[:8].abs().max().item()
+    # metrics: NDCG in [0,1]; predictions == labels order gives NDCG == 1; ranks are permutations
+    mi = ra().metrics_impl
+    out, _ = mi.NDCGMetric(None, None).compute_multi(labels, logits, None, None, [10, None])
+    assert (out >= 0).all() and (out <= 1.0 + 1e-6).all()
+    perfect, _ = mi.NDCGMetric(None, 10).compute(labels, labels + 0.001 * torch.rand_like(labels))
+    has_rel = (torch.clamp(labels, min=0).sum(dim=1) > 0)
+    assert (perfect.reshape(-1)[has_rel] - 1.0).abs().max().item() < 1e-6
+    ranks, order = _ops.sort_ranks(logits, labels, None, None)
+    assert torch.equal(torch.sort(ranks, dim=1).values,
+                       torch.arange(1, L + 1, device=DEV, dtype=torch.int32).expand(B, L))
+    # sortedness: scores of valid items are non-increasing along `order`
+    srt = torch.gather(torch.where(labels >= 0, logits, torch.full_like(logits, -1e30)), 1, order.long())
+    assert (srt[:, 1:] <= srt[:, :-1]).all()
+    # NDCG@10 bit-exact vs the oracle on a 256-list slice
+    want, _ = R.NDCGMetric(topn=10).compute(labels[:256].cpu(), logits[:256].cpu())
+    assert torch.equal(out[0, :256].cpu(), want.reshape(-1))
+
+
+def test_config4_size_smoke():
+    """L=1000, 512 lists per GPU (config 4 shard): finite, bounded, oracle parity on a slice."""
+    B, L = 512, 1000
+    labels, logits = make_batch(B, L, seed=5)
+    from ranking_amd import _ops
+    loss, _, d = _ops.approx_ndcg(logits.to(DEV), labels.to(DEV), None, None, 0.1)
+    assert torch.isfinite(loss).all() and torch.isfinite(d).all()
+    oracle = R.ApproxNDCGLoss(temperature=0.1)
+    want, want_g = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels[:4], lg / 0.1)[0],
+                                logits[:4])
+    assert_loss_close(loss[:4], want, what='L=1000 loss')
+    assert_grad_close(d[:4], want_g, what='L=1000 grad')
+
+
+def test_errors():
+    from ranking_amd import _ops, _lib
+    with pytest.raises(_lib.TfrHipError):
+        _ops.approx_ndcg(torch.zeros(2, 3), torch.zeros(2, 3))
+    with pytest.raises(ValueError):
+        _ops.approx_ndcg(torch.zeros(2, 3, device=DEV), torch.zeros(2, 4, device=DEV))
+    with pytest.raises(ValueError):
+        _ops.approx_ndcg(torch.zeros(1, 9000, device=DEV), torch.zeros(1, 9000, device=DEV))
+    with pytest.raises(ValueError):
+        ra().keras.losses.get('no_such_loss')
+    with pytest.raises(ValueError):
+        ra().keras.metrics.get('no_such_metric')
