@@ -697,13 +697,16 @@ def _per_example_weights_to_per_list_weights(weights, relevance, row_sum=None):
 
 
 def _discounted_cumulative_gain(labels, weights, gain_fn=pow_minus_1,
-                                rank_discount_fn=log2_inverse, row_sum=None):
-    """metrics_impl.py:122-151."""
+                                rank_discount_fn=log2_inverse, row_sum=None, full_list_size=None):
+    """metrics_impl.py:122-151.  The discount is evaluated for the positions of the
+    FULL list and sliced to the (top-n truncated) length: mathematically identical to
+    the reference, and independent of torch's vectorised-vs-scalar log1p paths so
+    that NDCG@k stays bit-reproducible against the kernel's shared table."""
     rs = row_sum or (lambda t: t.sum(dim=1, keepdim=True))
     list_size = labels.shape[1]
-    position = torch.arange(1, list_size + 1, dtype=torch.float32)
+    position = torch.arange(1, (full_list_size or list_size) + 1, dtype=torch.float32)
     gain = gain_fn(labels.to(torch.float32))
-    discount = rank_discount_fn(position)
+    discount = rank_discount_fn(position)[:list_size]
     return rs(weights * gain * discount)
 
 
@@ -769,13 +772,14 @@ class NDCGMetric(_RankingMetric):
         sorted_labels, sorted_weights = sort_by_scores(
             predictions, [labels, weights], topn=topn, mask=mask)
         dcg = _discounted_cumulative_gain(sorted_labels, sorted_weights, self._gain_fn,
-                                          self._rank_discount_fn, row_sum=tree_sum)
+                                          self._rank_discount_fn, row_sum=tree_sum,
+                                          full_list_size=predictions.shape[1])
         weighted_gains = weights * self._gain_fn(labels.to(torch.float32))
         ideal_sorted_labels, ideal_sorted_weights = sort_by_scores(
             weighted_gains, [labels, weights], topn=topn, mask=mask)
         ideal_dcg = _discounted_cumulative_gain(ideal_sorted_labels, ideal_sorted_weights,
                                                 self._gain_fn, self._rank_discount_fn,
-                                                row_sum=tree_sum)
+                                                row_sum=tree_sum, full_list_size=predictions.shape[1])
         per_list_ndcg = _safe_div(dcg, ideal_dcg)
         per_list_weights = _per_example_weights_to_per_list_weights(
             weights=weights, relevance=self._gain_fn(labels.to(torch.float32)), row_sum=tree_sum)

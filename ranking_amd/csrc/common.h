@@ -125,6 +125,14 @@ __device__ __forceinline__ uint64_t make_sort_key(bool valid, float score, int t
 }
 __device__ __forceinline__ int sort_key_index(uint64_t key) { return 0xffff - (int)(key & 0xffffull); }
 
+// 2^l - 1 (keras/utils.py:79-92): exact for integer grades (the hardware exp2 is
+// only 1-ulp accurate, which would break bit-exact NDCG on integer labels).
+__device__ __forceinline__ float gain_pow2m1(float l) {
+  const float r = rintf(l);
+  const float p = (r == l && fabsf(l) < 120.0f) ? ldexpf(1.0f, (int)r) : exp2f(l);
+  return p - 1.0f;
+}
+
 // exp(t) for a fp32 t given as an exact double-float (t_hi + t_lo), to ~1ulp:
 // used once per ITEM (never per pair) so that the factorised sigmoid
 // 1/(1 + E_i*F_j) keeps full fp32 accuracy even when |x - m| is large.

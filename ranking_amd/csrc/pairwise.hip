@@ -75,7 +75,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       float g = 0.f;
       if (dcg_lambda) {
         if (a.gain_kind == TFR_GAIN_CUSTOM) g = a.gains[base + i];
-        else if (a.gain_kind == TFR_GAIN_POW2M1) g = exp2f(labc) - 1.0f;
+        else if (a.gain_kind == TFR_GAIN_POW2M1) g = gain_pow2m1(labc);
         else g = labc;
       }
       float w = a.item_weights ? a.item_weights[base + i] : 1.0f;

@@ -63,7 +63,7 @@ __global__ void softmax_loss_kernel(const SmArgs a) {
         const float labc = (yl >= 0.0f) ? yl : 0.0f;
         float g;
         if (a.gain_kind == TFR_GAIN_CUSTOM) g = a.gains[base + i];
-        else if (a.gain_kind == TFR_GAIN_POW2M1) g = exp2f(labc) - 1.0f;
+        else if (a.gain_kind == TFR_GAIN_POW2M1) g = gain_pow2m1(labc);
         else g = labc;
         Gr[i] = g;
         key = ((uint64_t)float_to_ordered(labc) << 32) | (uint64_t)__float_as_uint(g);

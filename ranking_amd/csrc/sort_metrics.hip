@@ -74,7 +74,7 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
       const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
       m = v0 && (w > 0.0f);
       const float labc = m ? lab : 0.0f;
-      if (KIND == 0) g = gains ? gains[base + i] : (exp2f(labc) - 1.0f);
+      if (KIND == 0) g = gains ? gains[base + i] : gain_pow2m1(labc);
       else g = (labc >= 1.0f) ? 1.0f : 0.0f;
     }
     W[i] = w; G[i] = g; M[i] = m ? 1 : 0;

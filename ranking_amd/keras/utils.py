@@ -53,7 +53,8 @@ def log2_inverse(rank):
     rank = _t(rank)
     den = torch.log1p(rank)
     ok = den != 0
-    return torch.where(ok, math.log(2.) / torch.where(ok, den, torch.ones_like(den)),
+    # true division (python `scalar / tensor` is reciprocal*scalar in torch: 2 roundings)
+    return torch.where(ok, torch.full_like(den, math.log(2.)) / torch.where(ok, den, torch.ones_like(den)),
                        torch.zeros_like(den))
 
 

@@ -26,7 +26,9 @@ def _pow2_minus_1(label):
 
 def _log2_inverse(rank):
     """metrics_impl.py:33 _DEFAULT_RANK_DISCOUNT_FN."""
-    return math.log(2.) / torch.log1p(rank)
+    den = torch.log1p(rank)
+    # true division (python `scalar / tensor` is reciprocal*scalar in torch: 2 roundings)
+    return torch.full_like(den, math.log(2.)) / den
 
 
 _DEFAULT_GAIN_FN = _pow2_minus_1
