@@ -1,0 +1,155 @@
+// Micro-benchmarks that size the VALU / transcendental roofline of the pair
+// kernels on gfx950: wave-instruction issue cost of v_fma/v_pk_fma/v_rcp/v_exp/
+// v_log and of candidate inner loops of the ApproxNDCG pair sweep.
+//   hipcc --offload-arch=gfx950 -O3 -o ubench tools/ubench.hip && ./ubench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+constexpr int ITERS = 4096;
+
+template <int OP>
+__global__ void k_inst(float* out, float seed) {
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = seed + threadIdx.x * 1e-3f + i;
+  const float b = seed * 0.5f + 1.0f, c = seed + 0.25f;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (OP == 0) a[i] = __builtin_fmaf(a[i], b, c);
+      if (OP == 1) a[i] = __builtin_amdgcn_rcpf(a[i]);
+      if (OP == 2) a[i] = __builtin_amdgcn_exp2f(a[i]);
+      if (OP == 3) a[i] = __builtin_amdgcn_logf(a[i]);
+      if (OP == 4) a[i] = a[i] + b;
+      if (OP == 5) a[i] = __builtin_amdgcn_sqrtf(a[i]);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += a[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_pkfma(float* out, float seed) {
+  float2v a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) a[i] = float2v{seed + threadIdx.x * 1e-3f + i, seed + i};
+  const float2v b = {seed * 0.5f + 1.0f, seed * 0.25f + 1.0f}, c = {seed + 0.25f, seed};
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = __builtin_elementwise_fma(a[i], b, c);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += a[i].x + a[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// Candidate inner loops.  LDS holds N floats F (and A); each lane sweeps all of it.
+// VAR 0: fwd scalar   acc += rcp(fma(E, F, 1))
+// VAR 1: fwd packed   pk_fma + 2 rcp + pk_add
+// VAR 2: bwd scalar   s = rcp(fma(E,F,1)); acc = fma(A - ak, fma(-s,s,s), acc)
+// VAR 3: bwd packed
+// VAR 4: fwd scalar with exp path  acc += rcp(1 + exp2(x - F))
+template <int VAR>
+__global__ void k_pair(float* out, float seed, int N) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* F = lds;
+  float* A = lds + N;
+  for (int i = threadIdx.x; i < N; i += blockDim.x) { F[i] = seed + i * 1e-3f; A[i] = seed * i; }
+  __syncthreads();
+  const float E = seed + threadIdx.x * 1e-4f, ak = seed * 3.f;
+  const float4* F4 = reinterpret_cast<const float4*>(F);
+  const float4* A4 = reinterpret_cast<const float4*>(A);
+  float a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  float2v p0 = {0, 0}, p1 = {0, 0};
+  for (int rep = 0; rep < 16; ++rep) {
+    for (int g = 0; g < N / 4; ++g) {
+      const float4 f = F4[g];
+      if (VAR == 0) {
+        a0 += __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.x, 1.0f));
+        a1 += __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.y, 1.0f));
+        a2 += __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.z, 1.0f));
+        a3 += __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.w, 1.0f));
+      } else if (VAR == 1) {
+        const float2v e2 = {E, E}, one = {1.0f, 1.0f};
+        float2v u0 = __builtin_elementwise_fma(e2, float2v{f.x, f.y}, one);
+        float2v u1 = __builtin_elementwise_fma(e2, float2v{f.z, f.w}, one);
+        u0 = float2v{__builtin_amdgcn_rcpf(u0.x), __builtin_amdgcn_rcpf(u0.y)};
+        u1 = float2v{__builtin_amdgcn_rcpf(u1.x), __builtin_amdgcn_rcpf(u1.y)};
+        p0 += u0; p1 += u1;
+      } else if (VAR == 2) {
+        const float4 aj = A4[g];
+        const float s0 = __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.x, 1.0f));
+        const float s1 = __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.y, 1.0f));
+        const float s2 = __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.z, 1.0f));
+        const float s3 = __builtin_amdgcn_rcpf(__builtin_fmaf(E, f.w, 1.0f));
+        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
+        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
+        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
+        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      } else if (VAR == 3) {
+        const float4 aj = A4[g];
+        const float2v e2 = {E, E}, one = {1.0f, 1.0f}, ak2 = {ak, ak};
+        float2v u0 = __builtin_elementwise_fma(e2, float2v{f.x, f.y}, one);
+        float2v u1 = __builtin_elementwise_fma(e2, float2v{f.z, f.w}, one);
+        u0 = float2v{__builtin_amdgcn_rcpf(u0.x), __builtin_amdgcn_rcpf(u0.y)};
+        u1 = float2v{__builtin_amdgcn_rcpf(u1.x), __builtin_amdgcn_rcpf(u1.y)};
+        const float2v d0 = __builtin_elementwise_fma(-u0, u0, u0);
+        const float2v d1 = __builtin_elementwise_fma(-u1, u1, u1);
+        p0 = __builtin_elementwise_fma(float2v{aj.x, aj.y} - ak2, d0, p0);
+        p1 = __builtin_elementwise_fma(float2v{aj.z, aj.w} - ak2, d1, p1);
+      } else if (VAR == 4) {
+        a0 += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(E - f.x));
+        a1 += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(E - f.y));
+        a2 += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(E - f.z));
+        a3 += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(E - f.w));
+      }
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y;
+}
+
+template <typename Fn>
+double time_ms(Fn launch, int reps = 5) {
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  launch();
+  CHECK(hipDeviceSynchronize());
+  double best = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    CHECK(hipEventRecord(a));
+    launch();
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
+int main() {
+  const int blocks = 256 * 8, threads = 256;
+  float* out; CHECK(hipMalloc(&out, blocks * threads * sizeof(float)));
+  const double waves = (double)blocks * threads / 64.0;
+  const char* names[] = {"v_fma_f32", "v_rcp_f32", "v_exp_f32", "v_log_f32", "v_add_f32", "v_sqrt_f32"};
+  printf("%-14s %10s %14s %22s\n", "inst", "ms", "Gwaveinst/s", "cyc/waveinst/SIMD@2.4GHz");
+#define RUN_INST(OP) { double ms = time_ms([&] { hipLaunchKernelGGL(k_inst<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1.5f); }); \
+    double wi = waves * ITERS * 8; printf("%-14s %10.4f %14.2f %22.2f\n", names[OP], ms, wi / ms / 1e6, 1024.0 * 2.4e9 * ms * 1e-3 / wi); }
+  RUN_INST(0) RUN_INST(1) RUN_INST(2) RUN_INST(3) RUN_INST(4) RUN_INST(5)
+  { double ms = time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(threads), 0, 0, out, 1.5f); });
+    double wi = waves * ITERS * 8; printf("%-14s %10.4f %14.2f %22.2f\n", "v_pk_fma_f32", ms, wi / ms / 1e6, 1024.0 * 2.4e9 * ms * 1e-3 / wi); }
+  const int N = 256;
+  const char* vn[] = {"fwd scalar", "fwd packed", "bwd scalar", "bwd packed", "fwd exp path"};
+  printf("%-14s %10s %16s %22s\n", "pair loop", "ms", "Gpair-evals/s", "cyc/64pairs/SIMD@2.4GHz");
+#define RUN_PAIR(V) { double ms = time_ms([&] { hipLaunchKernelGGL(k_pair<V>, dim3(blocks), dim3(threads), 2 * N * sizeof(float), 0, out, 1.5f, N); }); \
+    double pe = (double)blocks * threads * 16.0 * N; printf("%-14s %10.4f %16.2f %22.2f\n", vn[V], ms, pe / ms / 1e6, 1024.0 * 2.4e9 * ms * 1e-3 / (pe / 64.0)); }
+  RUN_PAIR(0) RUN_PAIR(1) RUN_PAIR(2) RUN_PAIR(3) RUN_PAIR(4)
+  return 0;
+}
