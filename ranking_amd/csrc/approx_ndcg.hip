@@ -260,6 +260,272 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
   }
 }
 
+
+// ===========================================================================
+// Wave-per-list variant (L <= 64 * IPL).  One 64-lane wavefront owns a list:
+// no workgroup barriers, reductions are wave shuffles, the ideal-DCG sort is a
+// bitonic network held entirely in registers (IPL keys per lane), and the
+// per-item scalar work uses single-instruction transcendentals.  Profiling the
+// block kernel showed ~50 % of its VALU time in the per-list set-up (LDS sort,
+// block reductions, libm calls) rather than in the pair sweep; this variant
+// removes most of it and is used whenever there are enough lists to fill the
+// chip with single waves.
+// ===========================================================================
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wmin(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Descending bitonic sort of 64*IPL non-negative floats (as uint32 bit patterns),
+// element e = lane + 64*r lives in a[r] of `lane`.
+template <int IPL>
+__device__ __forceinline__ void wave_sort_desc(uint32_t (&a)[IPL], int lane) {
+  constexpr int N = 64 * IPL;
+#pragma unroll
+  for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & jr) == 0) {
+            const int r2 = r | jr;
+            const bool desc = (((r << 6) & kk) == 0);
+            const uint32_t hi = a[r] > a[r2] ? a[r] : a[r2];
+            const uint32_t lo = a[r] > a[r2] ? a[r2] : a[r];
+            a[r] = desc ? hi : lo;
+            a[r2] = desc ? lo : hi;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const uint32_t p = (uint32_t)__shfl_xor((int)a[r], j, 64);
+          const int e = lane | (r << 6);
+          const bool desc = ((e & kk) == 0);
+          const bool lower = ((lane & j) == 0);
+          const uint32_t mx = a[r] > p ? a[r] : p;
+          const uint32_t mn = a[r] > p ? p : a[r];
+          a[r] = (lower == desc) ? mx : mn;
+        }
+      }
+    }
+  }
+}
+
+// exp(t_hi + t_lo) with hardware exp2 / ldexp (1 ulp), see exp_df in common.h.
+__device__ __forceinline__ float exp_df_fast(float t_hi, float t_lo) {
+  const float LOG2E_HI = 1.44269502162933349609375f;
+  const float LOG2E_LO = 1.92596299112661746e-08f;
+  const float y_hi = t_hi * LOG2E_HI;
+  float y_lo = __builtin_fmaf(t_hi, LOG2E_HI, -y_hi);
+  y_lo = __builtin_fmaf(t_hi, LOG2E_LO, y_lo);
+  y_lo = __builtin_fmaf(t_lo, LOG2E_HI, y_lo);
+  const float n = rintf(y_hi);
+  const float f = (y_hi - n) + y_lo;
+  return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+template <int IPL>
+__global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
+    float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
+    float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
+  float* E = X + Lp;                               // [Lp] exp(x - m)
+  float* F = E + Lp;                               // [Lp] exp(m - x)   (pad +inf)
+  float* A = F + Lp;                               // [Lp] dloss/drank  (pad 0)
+  float* G = A + Lp;                               // [Lp] compact gain
+  int* CI = reinterpret_cast<int*>(G + Lp);        // [Lp] compact -> original index
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  constexpr float kLn2 = 0.69314718055994530942f;
+
+  // ---- 1. load + clean; label / logit statistics (wave reductions).
+  float x[IPL], g[IPL];
+  bool v[IPL];
+  float lmax = -INFINITY, lsum = 0.f, xmin = INFINITY, xmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    x[r] = 0.f; g[r] = 0.f; v[r] = false;
+    if (e < L) {
+      const float lab = labels[base + e];
+      x[r] = logits[base + e] / temperature;
+      v[r] = mask ? (mask[base + e] != 0) : (lab >= 0.0f);
+      g[r] = v[r] ? lab : 0.0f;                      // cleaned label for now
+      lmax = fmaxf(lmax, g[r]); lsum += g[r];
+      if (v[r]) { xmin = fminf(xmin, x[r]); xmax = fmaxf(xmax, x[r]); }
+    }
+  }
+  lmax = wmax(lmax); lsum = wsum(lsum); xmin = wmin(xmin); xmax = wmax(xmax);
+  const bool nonzero = lsum > 0.0f;
+  if (!nonzero) lmax = 1e-10f;
+
+  // ---- 2. gains, ideal DCG through an in-register bitonic sort.
+  const float g0 = exp2f(-lmax);
+  uint32_t sk[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    float gg = 0.f;
+    if (e < L) gg = exp2f((nonzero ? g[r] : 1e-10f) - lmax) - g0;
+    g[r] = gg;
+    sk[r] = __float_as_uint(gg);
+  }
+  wave_sort_desc<IPL>(sk, lane);
+  float idcg = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    if (e < L) idcg += __uint_as_float(sk[r]) * inv_log1p[e];
+  }
+  idcg = wsum(idcg);
+  const float inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+
+  // ---- 3. stable compaction of valid items into LDS (order = original index).
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const unsigned long long bal = __ballot(v[r]);
+    if (v[r]) {
+      const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+      X[pos] = x[r]; G[pos] = g[r]; CI[pos] = lane + 64 * r;
+    }
+    n += __popcll(bal);
+  }
+  __syncthreads();
+  const int n4 = (n + 3) >> 2;
+  const float m = 0.5f * (xmax + xmin);
+  const bool fast = (xmax - xmin) <= kFastRange;
+  for (int i = lane; i < n4 * 4; i += 64) {
+    float e = 0.f, f = INFINITY;
+    if (i < n) {
+      const float xv = X[i];
+      const float t_hi = xv - m;
+      const float bb = t_hi - xv;
+      const float t_lo = (xv - (t_hi - bb)) + (-m - bb);
+      e = exp_df_fast(t_hi, t_lo);
+      f = exp_df_fast(-t_hi, -t_lo);
+    } else {
+      X[i] = -INFINITY;
+    }
+    E[i] = e; F[i] = f; A[i] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- 4. ranks + loss terms.  Row = C adjacent lanes; 64/C rows per pass.
+  const int rows_per_pass = 64 / C;
+  const int c = lane % C, rsub = lane / C;
+  const float4* F4 = reinterpret_cast<const float4*>(F);
+  const float4* X4 = reinterpret_cast<const float4*>(X);
+  const float4* A4 = reinterpret_cast<const float4*>(A);
+  float dcg = 0.f;
+  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (fast) {
+      const float Ei = active ? E[row] : 0.f;
+      for (int gI = c; gI < n4; gI += C) pair_fwd_fast(Ei, F4[gI], a0, a1, a2, a3);
+    } else {
+      const float xi = active ? X[row] : 0.f;
+      for (int gI = c; gI < n4; gI += C) {
+        const float4 xx = X4[gI];
+        a0 += sig_slow(xi, xx.x); a1 += sig_slow(xi, xx.y);
+        a2 += sig_slow(xi, xx.z); a3 += sig_slow(xi, xx.w);
+      }
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (active && c == 0) {
+      const float r = acc + 0.5f;
+      const float lr = __builtin_amdgcn_logf(1.0f + r) * kLn2;      // log1p(r), r >= 1
+      const float ilr = fast_rcp(lr);
+      const float gg = G[row];
+      dcg = __builtin_fmaf(gg, ilr, dcg);
+      A[row] = (gg * inv_max_dcg) * ilr * ilr * fast_rcp(1.0f + r);   // not read until step 5
+    }
+  }
+  dcg = wsum(dcg);
+  if (lane == 0) {
+    loss_out[b] = -(dcg * inv_max_dcg);
+    weight_out[b] = nonzero ? 1.0f : 0.0f;
+  }
+  if (!dlogits_out) return;
+  __syncthreads();
+
+  // ---- 5. backward.
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) * (1.0f / temperature);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    if (e < L && !v[r]) dlogits_out[base + e] = 0.0f;
+  }
+  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    const float ak = active ? A[row] : 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (fast) {
+      const float Ek = active ? E[row] : 0.f;
+      for (int gI = c; gI < n4; gI += C) {
+        const float4 f = F4[gI];
+        const float4 aj = A4[gI];
+        const float s0 = fast_rcp(__builtin_fmaf(Ek, f.x, 1.0f));
+        const float s1 = fast_rcp(__builtin_fmaf(Ek, f.y, 1.0f));
+        const float s2 = fast_rcp(__builtin_fmaf(Ek, f.z, 1.0f));
+        const float s3 = fast_rcp(__builtin_fmaf(Ek, f.w, 1.0f));
+        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
+        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
+        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
+        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      }
+    } else {
+      const float xk = active ? X[row] : 0.f;
+      for (int gI = c; gI < n4; gI += C) {
+        const float4 xx = X4[gI];
+        const float4 aj = A4[gI];
+        const float s0 = sig_slow(xk, xx.x), s1 = sig_slow(xk, xx.y);
+        const float s2 = sig_slow(xk, xx.z), s3 = sig_slow(xk, xx.w);
+        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
+        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
+        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
+        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      }
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    if (active && c == 0) dlogits_out[base + CI[row]] = acc * gscale;
+  }
+}
+
+template <int IPL>
+int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
+                const float* list_scale, int B, int L, float temperature, int C, float* loss_out,
+                float* weight_out, float* dlogits_out, hipStream_t stream) {
+  const int Lp = ((L + 3) / 4) * 4 + 4;
+  const size_t lds = (size_t)Lp * 4 * 6;
+  hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
+                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out);
+  return (int)hipGetLastError();
+}
+
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
@@ -278,9 +544,21 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
   if (B == 0) return TFR_OK;
   static const int env_threads = env_int("TFR_APPROX_THREADS", 0);
   static const int env_lanes = env_int("TFR_APPROX_LANES", 0);
-  int C = lanes_per_row > 0 ? lanes_per_row : (env_lanes > 0 ? env_lanes : 4);
+  static const int env_wave = env_int("TFR_APPROX_WAVE", 1);      // 0 forces the block kernel
+  static const int env_wave_min_b = env_int("TFR_APPROX_WAVE_MIN_B", 2048);
+  int C = lanes_per_row > 0 ? lanes_per_row : (env_lanes > 0 ? env_lanes : 2);
   if (C > 64 || (C & (C - 1))) return TFR_EINVAL;
-  int T = env_threads > 0 ? env_threads : (L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 512 ? 256 : 512)));
+  // Wave-per-list kernel: always for L <= 256; for L <= 1024 only when the batch
+  // alone fills the chip with single waves (otherwise several waves share a list).
+  if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+  }
+  int T = env_threads > 0 ? env_threads : (L <= 128 ? 64 : (L <= 512 ? 128 : 512));
   if (T % 64 || T > 1024) return TFR_EINVAL;
   const int Lp = ((L + 3) / 4) * 4 + 4;
   const int P = pow2_ceil(L < 2 ? 2 : L);
