@@ -1,0 +1,98 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: list
+sharding, the single flat-bucket all-reduce, global normalisers, metric sync."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ranking_amd import distributed as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _toy_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(5, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+
+
+def _toy_loss(model, feats, labels):
+    """A list-wise stand-in loss with a data-dependent GLOBAL normaliser (count of
+    lists with a relevant item), like SUM_BY_NONZERO_WEIGHTS (losses.py:66-67)."""
+    logits = model(feats).squeeze(-1)                       # [B, L]
+    w = (labels.sum(dim=1) > 0).float()
+    per_list = -(torch.log_softmax(logits, dim=1) * labels).sum(dim=1)
+    return (per_list * w).sum(), w.sum()
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(7, 4, 5, generator=g)
+    labels = (torch.rand(7, 4, generator=g) > 0.6).float()
+    labels[2] = 0.0
+    model = _toy_model()
+    bucket = D.FlatGradBucket(model.parameters(), n_scalars=2)
+    f, l = D.shard_lists([feats, labels])
+    num, den = _toy_loss(model, f, l)
+    bucket.zero()
+    num.backward()
+    loss = D.global_normalizer_step(bucket, num, den)
+    # metric sync (keras/metrics.py Mean accumulators)
+    from ranking_amd.keras.metrics import _RankingMetric
+    m = _RankingMetric()
+    m.total, m.count = torch.tensor(float(rank + 1)), torch.tensor(2.0)
+    out[rank] = (loss.item(), bucket.flat[:bucket.numel].clone(), m.result().item(), f.shape[0])
+    dist.destroy_process_group()
+
+
+def test_dp_world2_matches_single_process():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(1)
+    feats = torch.randn(7, 4, 5, generator=g)
+    labels = (torch.rand(7, 4, generator=g) > 0.6).float()
+    labels[2] = 0.0
+    model = _toy_model()
+    num, den = _toy_loss(model, feats, labels)
+    (num / den).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert out[0][3] + out[1][3] == 7 and out[0][3] == 4           # remainder goes to the first ranks
+    for r in range(world):
+        assert abs(out[r][0] - (num / den).item()) < 1e-5
+        assert torch.allclose(out[r][1], want, atol=1e-6)
+        assert abs(out[r][2] - (1.0 + 2.0) / 4.0) < 1e-6           # (sum totals)/(sum counts)
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 16, 4096):
+        for w in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_flat_bucket_single_process():
+    model = _toy_model()
+    bucket = D.FlatGradBucket(model.parameters(), n_scalars=3)
+    assert bucket.flat.numel() == sum(p.numel() for p in model.parameters()) + 3
+    model(torch.ones(2, 5)).sum().backward()
+    assert bucket.flat[:bucket.numel].abs().sum() > 0             # grads landed in the bucket
+    s = bucket.all_reduce(torch.tensor([1., 2., 3.]))
+    assert s.tolist() == [1., 2., 3.]
+    with pytest.raises(ValueError):
+        D.FlatGradBucket([])

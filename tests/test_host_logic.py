@@ -1,0 +1,197 @@
+"""CPU-side tests: the C-ABI library loads and exports every symbol declared in
+include/tfr_hip.h, host-side argument / error conventions, serialisation, and
+that the product path refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import ranking_amd as ra
+from ranking_amd import _lib, _ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
+    return sorted(set(re.findall(r'^int\s+(tfr_\w+)\s*\(', src, flags=re.M)))
+
+
+def test_header_and_library_agree():
+    lib = _lib.load()
+    names = declared_symbols()
+    assert names, 'no entry points parsed from include/tfr_hip.h'
+    for n in names:
+        assert hasattr(lib, n), 'libtfr_hip.so does not export %s' % n
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert lib.tfr_hip_abi_version() >= 1
+
+
+def test_library_is_in_tree_and_for_gfx950():
+    assert _lib.LIB_PATH.startswith(ROOT)
+    assert '--offload-arch=gfx950' in _lib.HIPCC_FLAGS
+    blob = open(_lib.LIB_PATH, 'rb').read()
+    assert b'gfx950' in blob
+
+
+def test_invalid_arguments_are_rejected_before_any_launch():
+    lib = _lib.load()
+    # null pointers / bad sizes -> TFR_EINVAL (-1); L > 8192 -> TFR_ETOOLARGE (-2).  No GPU needed.
+    assert lib.tfr_sort_ranks_f32(None, None, None, None, 1, 4, None, None, None) == -1
+    one = ctypes.c_void_p(16)
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 9000, 0.1, 0, one, one, None, None) == -2
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, -1.0, 0, one, one, None, None) == -1
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, 0.1, 3, one, one, None, None) == -1
+    assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 2, 0, 1.5, 0, 0, None, one, 1, 8, 1.0,
+                                         None, None, None, None, None) == -1       # smooth_fraction
+    assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 7, 0, 0.0, 0, 0, None, one, 1, 8, 1.0,
+                                         None, None, None, None, None) == -1       # lambda kind
+    topn = (ctypes.c_int32 * 1)(10)
+    assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
+    assert lib.tfr_gumbel_sample_f32(one, one, None, None, 0, 0, 1, 0, 8, 1.0, one, None) == -1
+    # B == 0 is a no-op
+    assert lib.tfr_softmax_loss_f32(one, one, None, None, 0, 0, 0, 0, 0, None, None, 0, 8, 1.0, one, one,
+                                    None, None) == 0
+    with pytest.raises(ValueError):
+        _lib.check(-1, 'x')
+    with pytest.raises(ValueError):
+        _lib.check(-2, 'x')
+    with pytest.raises(_lib.TfrHipError):
+        _lib.check(719, 'x')
+
+
+def test_no_cpu_fallback():
+    y = torch.tensor([[1., 0.]])
+    s = torch.tensor([[0.6, 0.8]])
+    for loss in (ra.keras.losses.ApproxNDCGLoss(), ra.keras.losses.SoftmaxLoss(),
+                 ra.keras.losses.PairwiseLogisticLoss(), ra.keras.losses.GumbelApproxNDCGLoss(seed=1)):
+        with pytest.raises(_lib.TfrHipError):
+            loss(y, s)
+        with pytest.raises(_lib.TfrHipError):
+            loss.loss_and_grad(y, s)
+    with pytest.raises(_lib.TfrHipError):
+        ra.keras.metrics.NDCGMetric()(y, s)
+    with pytest.raises(_lib.TfrHipError):
+        ra.utils.sort_by_scores(s, [s])
+    with pytest.raises(_lib.TfrHipError):
+        ra.losses.make_loss_fn('approx_ndcg_loss')(y, s, {})
+
+
+def test_product_never_imports_the_oracle():
+    import ast
+    pkg = os.path.join(ROOT, 'ranking_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                tree = ast.parse(open(os.path.join(dirpath, f)).read())
+                for node in ast.walk(tree):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or '']
+                    assert not any(n.split('.')[0] == 'oracle' for n in names), (f, names)
+
+
+def test_keys_and_factories():
+    K = ra.keras.losses
+    assert K.RankingLossKey.APPROX_NDCG_LOSS == 'approx_ndcg_loss'
+    assert set(['pairwise_logistic_loss', 'softmax_loss', 'gumbel_approx_ndcg_loss']) <= set(
+        K.RankingLossKey.all_keys())
+    assert isinstance(K.get('pairwise_logistic_loss', lambda_weight=K.NDCGLambdaWeight()),
+                      K.PairwiseLogisticLoss)
+    assert isinstance(K.get('gumbel_approx_ndcg_loss', sample_size=4), K.GumbelApproxNDCGLoss)
+    with pytest.raises(ValueError):
+        K.get('list_mle_loss_typo')
+    with pytest.raises(ValueError):
+        K.ApproxNDCGLoss(reduction='mean')
+    with pytest.raises(ValueError):
+        ra.keras.metrics.get('nope')
+    with pytest.raises(ValueError):
+        ra.keras.metrics.get(3)
+    assert [m.name for m in ra.keras.metrics.default_keras_metrics()][:4] == [
+        'metric/ndcg_1', 'metric/ndcg_3', 'metric/ndcg_5', 'metric/ndcg_10']
+    with pytest.raises(ValueError):
+        ra.losses.make_loss_fn([], None)
+    with pytest.raises(ValueError):
+        ra.losses.make_loss_fn(['softmax_loss'], [1.0, 2.0])
+    with pytest.raises(ValueError):
+        ra.losses.make_loss_fn('softmax_loss:0.5', [1.0])
+    with pytest.raises(ValueError):
+        ra.losses_impl.DCGLambdaWeight(smooth_fraction=-0.1)          # losses_impl.py:329-331
+    with pytest.raises(ValueError):
+        ra.losses_impl.ndcg(torch.zeros(1, 2), ranks=torch.ones(1, 2), perm_mat=torch.ones(1, 2, 2))
+    assert ra.utils.parse_keys_and_weights('a:0.5, b:2,c') == {'a': 0.5, 'b': 2.0, 'c': 1.0}
+
+
+def test_config_round_trips():
+    K = ra.keras.losses
+    lw = K.NDCGLambdaWeight(topn=5, smooth_fraction=0.25)
+    for loss in (K.PairwiseLogisticLoss(lambda_weight=lw, temperature=0.5, name='p'),
+                 K.SoftmaxLoss(lambda_weight=K.DCGLambdaWeight(normalized=True), ragged=True),
+                 K.ApproxNDCGLoss(temperature=0.3),
+                 K.GumbelApproxNDCGLoss(sample_size=4, gumbel_temperature=2.0, seed=7)):
+        cfg = loss.get_config()
+        clone = type(loss).from_config(cfg)
+        assert clone.get_config() == cfg
+    cfg = lw.get_config()       # keras/losses_test.py:1359-1459 style
+    assert cfg['topn'] == 5 and cfg['smooth_fraction'] == 0.25 and cfg['normalized'] is True
+    assert cfg['gain_fn'] is ra.keras.utils.pow_minus_1 and cfg['rank_discount_fn'] is ra.keras.utils.log2_inverse
+    m = ra.keras.metrics.NDCGMetric(name='n', topn=10)
+    assert type(m).from_config(m.get_config()).get_config() == m.get_config()
+    s = ra.keras.utils.serialize_keras_object(lw)
+    back = ra.keras.utils.deserialize_keras_object(s)
+    assert isinstance(back, K.NDCGLambdaWeight) and back._topn == 5
+
+
+def test_keras_utils_functions():   # keras/utils_test.py
+    u = ra.keras.utils
+    assert u.identity(3.0) == 3.0
+    assert torch.allclose(u.inverse(torch.tensor([1., 2., 0.])), torch.tensor([1., .5, 0.]))
+    assert torch.allclose(u.pow_minus_1(torch.tensor([0., 1., 3.])), torch.tensor([0., 1., 7.]))
+    assert torch.allclose(u.log2_inverse(torch.tensor([1., 3.])), torch.tensor([1., .5]))
+    assert u.is_greater_equal_1(torch.tensor([0.5, 1.0])).tolist() == [False, True]
+
+
+def test_ragged_to_dense_and_indices():   # utils.py:421-443, 203-356
+    l, p, w, m = ra.utils.ragged_to_dense([[1., 0.], [0., 1., 2.]], [[.1, .2], [.3, .4, .5]],
+                                          [[1., 2.], [3., 4., 5.]], device=torch.device('cpu'))
+    assert l.tolist() == [[1., 0., -1.], [0., 1., 2.]]
+    assert p[0, 2].item() == -1e6 and w[0, 2].item() == 0.0
+    assert m.tolist() == [[True, True, False], [True, True, True]]
+    idx, mask = ra.utils.padded_nd_indices(torch.tensor([[True, True, False], [False, True, False]]))
+    assert idx.tolist() == [[0, 1, 0], [1, 1, 1]] and mask.tolist() == [[True, True, False], [True, False, False]]
+    org = ra.utils.organize_valid_indices(torch.tensor([[False, True, True]]), shuffle=False)
+    assert org.tolist() == [[1, 2, 0]]
+
+
+def test_flatten_restore_and_tower_shapes():   # keras/layers.py:87-108,195-216
+    import math
+    L = ra.keras.layers
+    ctx = {'c': torch.tensor([[1.], [0.]])}
+    ex = {'e': torch.tensor([[[1.], [0.], [-1.]], [[0.], [1.], [0.]]])}
+    mask = torch.tensor([[True, True, False], [True, False, False]])
+    fc, fe = L.FlattenList()((ctx, ex, mask))
+    assert fc['c'].reshape(-1).tolist() == [1., 1., 1., 0., 0., 0.]
+    assert fe['e'].reshape(-1).tolist() == [1., 0., 1., 0., 0., 0.]
+    out = L.RestoreList()((torch.tensor([1., 2., 3., 4., 5., 6.]), mask))
+    e = math.log(1e-10)
+    assert torch.allclose(out, torch.tensor([[1., 2., e], [4., e, e]]))
+    out = L.RestoreList(by_scatter=True)((torch.tensor([1., 2., 3., 4., 5., 6.]), mask))
+    assert torch.allclose(out, torch.tensor([[2., 2., e], [5., e, e]]))
+    doc = torch.tensor([1., .5, 2., 0., -1., 0.])                            # layers.py:195-216
+    assert torch.allclose(L.RestoreList()((doc, mask)), torch.tensor([[1., .5, e], [0., e, e]]))
+    assert torch.allclose(L.RestoreList(by_scatter=True)((doc, mask)),
+                          torch.tensor([[1.5, .5, e], [-1. / 3., e, e]]))
+    with pytest.raises(ValueError):
+        L.FlattenList()(({}, {}, mask))
+    with pytest.raises(ValueError):
+        L.RestoreList()((torch.zeros(5), mask))
+    tower = L.create_tower([8, 4], 1, activation=torch.relu, input_dim=3)
+    assert tower(torch.zeros(6, 3)).shape == (6, 1)
+    scorer = ra.keras.model.DNNScorer(input_dim=2, hidden_layer_dims=[4], output_units=1,
+                                      activation=torch.relu, use_batch_norm=False, dropout=0.)
+    logits = scorer(ctx, ex, mask)
+    assert logits.shape == (2, 3) and logits[0, 2].item() == pytest.approx(e)
