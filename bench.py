@@ -45,6 +45,12 @@ WORKLOADS = {
                            lambda L: 12 * L + 12),
     'ndcg_metric': (16384, 200, 'NDCG@{1,3,5,10,all} metric, B=16384, L=200',
                     lambda L: 8 * L + 6 * 4),
+    # end-to-end data-parallel training steps: scorer fwd/bwd (bf16 MFMA GEMMs) + fused loss +
+    # ONE all-reduce of the flat gradient bucket + optimizer.
+    'e2e_softmax': (4096, 100, 'config 2: DNNScorer 136-512-512-512-1 bf16 + SoftmaxLoss, 4096 lists/GPU, '
+                               'L=100, SGD, 1 all-reduce/step', lambda L: 0),
+    'e2e_approx_ndcg_l1000': (512, 1000, 'config 4: DNNScorer 136-512-512-512-1 bf16 + ApproxNDCGLoss, '
+                                         '512 lists/GPU, L=1000, 1 all-reduce/step', lambda L: 0),
 }
 
 
@@ -77,7 +83,44 @@ def build_step(workload, labels, logits):
     if workload == 'ndcg_metric':
         m = metrics_impl.NDCGMetric(None, None)
         return (lambda: m.compute_multi(labels, logits, None, None, [1, 3, 5, 10, None])), None
+    if workload.startswith('e2e_'):
+        return build_e2e_step(workload, labels), None
     raise ValueError(workload)
+
+
+def build_e2e_step(workload, labels):
+    """One data-parallel training step: features [B, L, 136] ~ U(-1, 1) resident in HBM."""
+    import ranking_amd as ra
+    from ranking_amd import distributed as D
+    dev = labels.device
+    B, L = labels.shape
+    g = torch.Generator(device=dev).manual_seed(1234 + int(os.environ.get('RANK', '0')))
+    feats = torch.rand((B, L, 136), generator=g, device=dev) * 2 - 1
+    mask = labels >= 0
+    torch.manual_seed(0)                                  # identical replicas on every rank
+    scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
+                                      activation=torch.relu, use_batch_norm=True, dropout=0.0,
+                                      compute_dtype=torch.bfloat16).to(dev)
+    bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
+    lr = 0.01
+    loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
+    _, world = D.world()
+    params = [p for p in scorer.parameters() if p.requires_grad]
+    flat_params = None
+
+    def step():
+        bucket.zero()
+        logits = scorer({}, {'x': feats}, mask)
+        value, dlogits = loss.loss_and_grad(labels, logits.detach())
+        logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
+        s = bucket.all_reduce(torch.stack([value, value.new_tensor(1.0)]), average=True)
+        with torch.no_grad():                              # SGD on the fp32 master weights
+            off = 0
+            for p in params:
+                p.add_(bucket.flat[off:off + p.numel()].view_as(p), alpha=-lr)
+                off += p.numel()
+        return s[0] / max(world, 1)
+    return step
 
 
 def cpu_baseline(workload, L, budget_s=12.0):

@@ -853,3 +853,33 @@ def rolling_window_indices(size, rw_size, num_valid_entries):
     batch = num_valid_entries.shape[0]
     rw = rw.repeat(batch, 1, 1)
     return torch.remainder(rw, torch.clamp(num_valid_entries, min=1)) * (num_valid_entries > 0)
+
+
+def form_group_indices(is_valid, group_size):
+    """model.py:205-244 with shuffle=False: ([B, G=L, group_size] item indices, [B, G] mask)."""
+    is_valid = _t(is_valid, torch.bool)
+    b, l = is_valid.shape
+    n_valid = is_valid.sum(dim=1)
+    rw = rolling_window_indices(l, group_size, n_valid)                       # [B, L, gs]
+    rw_raw = torch.arange(group_size).unsqueeze(0) + torch.arange(l).unsqueeze(1)
+    mask = rw_raw.min(dim=1).values.unsqueeze(0) < n_valid.reshape(-1, 1)     # model.py:190-192
+    keys = torch.where(is_valid, torch.zeros(b, l), torch.ones(b, l))
+    organized = torch.sort(keys, dim=1, stable=True).indices                  # utils.py:203-230
+    idx = torch.gather(organized.unsqueeze(1).expand(b, l, l), 2, rw)
+    return idx, mask
+
+
+def groupwise_logits(score_fn, example_features, is_valid, group_size):
+    """model.py:341-421 (single example feature tensor [B, L, F]; shuffle off):
+    gather groups -> score [B*G, gs] -> masked scatter-add -> divide by counts."""
+    b, l, f = example_features.shape
+    idx, mask = form_group_indices(is_valid, group_size)
+    g = idx.shape[1]
+    gathered = torch.gather(example_features.unsqueeze(1).expand(b, g, l, f), 2,
+                            idx.unsqueeze(-1).expand(b, g, group_size, f))
+    scores = score_fn(gathered.reshape(b * g, group_size, f)).reshape(b, g, group_size)
+    scores_mask = mask.unsqueeze(2).expand(b, g, group_size)
+    counts = torch.zeros(b, l).scatter_add_(1, idx.reshape(b, -1), scores_mask.reshape(b, -1).float())
+    scores = torch.where(scores_mask, scores, torch.zeros_like(scores))
+    logits = torch.zeros(b, l).scatter_add(1, idx.reshape(b, -1), scores.reshape(b, -1))
+    return _safe_div(logits, counts)

@@ -1,0 +1,90 @@
+"""Mirror of the groupwise multi-item scoring of ``tensorflow_ranking/python/model.py``
+(`_rolling_window_indices` :164-202, `_form_group_indices_nd` :205-244,
+`_GroupwiseRankingModel._compute_logits_impl` :341-421).
+
+Groups are rolling windows of ``group_size`` consecutive items (mod n_valid) over
+a valid-first ordering of the list; every group is scored by ``group_score_fn``
+and an item's logit is the average of the scores that landed on it.  The
+gather / scatter-average is index plumbing on device tensors; the GEMMs inside
+``group_score_fn`` are where the time goes (config 5: 272-512-512-512-2).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from . import utils
+
+
+def _rolling_window_indices(size: int, rw_size: int, num_valid_entries) -> Tuple[torch.Tensor, torch.Tensor]:
+    """model.py:164-202."""
+    n = torch.as_tensor(num_valid_entries).reshape(-1)
+    dev = n.device
+    rw = torch.arange(rw_size, device=dev).unsqueeze(0) + torch.arange(size, device=dev).unsqueeze(1)
+    batch_rw = rw.unsqueeze(0).expand(n.shape[0], size, rw_size)
+    mask = batch_rw.min(dim=2).values < n.reshape(-1, 1)
+    n1 = torch.where(n < 1, torch.ones_like(n), n)
+    return torch.remainder(batch_rw, n1.reshape(-1, 1, 1)), mask
+
+
+def _form_group_indices_nd(is_valid, group_size: int, shuffle: bool = False, seed: Optional[int] = None):
+    """model.py:205-244: ([B, G, group_size] item indices, [B, G] mask).  The batch
+    coordinate of the reference's nd-indices is implicit."""
+    is_valid = torch.as_tensor(is_valid).to(torch.bool)
+    b, l = is_valid.shape
+    n_valid = is_valid.sum(dim=1)
+    rw, mask = _rolling_window_indices(l, group_size, n_valid)
+    organized = utils.organize_valid_indices(is_valid, shuffle=shuffle, seed=seed)
+    idx = torch.gather(organized.unsqueeze(1).expand(b, l, l), 2, rw)
+    return idx, mask
+
+
+class GroupwiseScorer(torch.nn.Module):
+    """model.py:276-421: ``group_score_fn(context, group_features) -> [B*G, group_size]``."""
+
+    def __init__(self, group_score_fn: Callable, group_size: int, num_shuffles: Optional[int] = None):
+        super().__init__()
+        self._score_fn = group_score_fn
+        self._group_size = group_size
+        self._num_shuffles = num_shuffles
+
+    def _indices(self, is_valid, training: bool):
+        """model.py:313-339."""
+        if self._group_size == 1:
+            shuffle, n = False, 1
+        elif not training:
+            shuffle, n = self._num_shuffles is not None, self._num_shuffles or 1
+        else:
+            shuffle, n = True, self._num_shuffles or 1
+        parts = [_form_group_indices_nd(is_valid, self._group_size, shuffle=shuffle, seed=i + 77)
+                 for i in range(n)]
+        return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts], dim=1)
+
+    def forward(self, context_features: Dict[str, torch.Tensor], example_features: Dict[str, torch.Tensor],
+                is_valid, shuffle: Optional[bool] = None) -> torch.Tensor:
+        is_valid = torch.as_tensor(is_valid).to(torch.bool)
+        b, l = is_valid.shape
+        if shuffle is False:
+            idx, mask = _form_group_indices_nd(is_valid, self._group_size, shuffle=False)
+        else:
+            idx, mask = self._indices(is_valid, self.training)
+        g, gs = idx.shape[1], self._group_size
+        big_ctx = {k: v.unsqueeze(1).expand((b, g) + tuple(v.shape[1:])).reshape((b * g,) + tuple(v.shape[1:]))
+                   for k, v in (context_features or {}).items()}
+        big_ex = {}
+        for k, v in example_features.items():
+            f = v.reshape(b, l, -1)
+            gathered = torch.gather(f.unsqueeze(1).expand(b, g, l, f.shape[2]), 2,
+                                    idx.unsqueeze(-1).expand(b, g, gs, f.shape[2]))
+            big_ex[k] = gathered.reshape(b * g, gs, f.shape[2])
+        scores = self._score_fn(big_ctx, big_ex).reshape(b, g, gs)
+        scores_mask = mask.unsqueeze(2).expand(b, g, gs)
+        flat_idx = idx.reshape(b, g * gs)
+        counts = torch.zeros((b, l), dtype=scores.dtype, device=scores.device).scatter_add_(
+            1, flat_idx, scores_mask.reshape(b, -1).to(scores.dtype))
+        scores = torch.where(scores_mask, scores, torch.zeros_like(scores))
+        logits = torch.zeros((b, l), dtype=scores.dtype, device=scores.device).scatter_add(
+            1, flat_idx, scores.reshape(b, -1))
+        return torch.where(counts != 0, logits / torch.where(counts != 0, counts, torch.ones_like(counts)),
+                           torch.zeros_like(logits))
