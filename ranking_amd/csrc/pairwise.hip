@@ -38,6 +38,56 @@ __host__ __device__ inline size_t pw_smem_bytes(int Lp, int P) {
   return 256 + (size_t)P * 8 + (size_t)Lp * 4 * 12 + (size_t)Lp * 2 + 32;
 }
 
+constexpr float kLn2 = 0.69314718055994530942f;
+
+// One (row i, column j) term.  rec = (x, raw label, gain, item weight); rk = signed
+// rank as float (negative: label-invalid item), dp = D'(rank).
+template <int LAMBDA, bool GENERIC>
+__device__ __forceinline__ void pair_term(const float4 ri, const float rki, const float dpi,
+                                          const float4 rj, const float rkj, const float dpj,
+                                          const float* __restrict__ U, const float ftopn,
+                                          const float one_minus_s, const float smooth, const float fL,
+                                          float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
+  float wl = 1.0f;
+  if (LAMBDA == TFR_LAMBDA_DCG) {
+    const float ai = fabsf(rki), aj = fabsf(rkj);
+    const int dr = (int)fabsf(ai - aj);
+    const float u = U[dr];                                   // U[0] = 0
+    if (GENERIC) {
+      const bool in_top = (ai <= ftopn) || (aj <= ftopn);
+      const float v = fabsf(dpi - dpj);
+      float pd = one_minus_s * u + smooth * v;
+      pd = in_top ? pd : 0.0f;
+      const float pg = (rki > 0.0f && rkj > 0.0f) ? fabsf(ri.z - rj.z) : 0.0f;
+      wl = (pg * pd) * fL;
+    } else {
+      wl = (fabsf(ri.z - rj.z) * u) * fL;
+    }
+  } else if (LAMBDA == TFR_LAMBDA_LABELDIFF) {
+    wl = fabsf(ri.y - rj.y);
+  }
+  const bool hi = ri.y > rj.y;            // row item preferred
+  const bool lo = rj.y > ri.y;            // column item preferred
+  const float d0 = ri.x - rj.x;
+  const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
+  const float w1 = 1.0f + e;
+  const float q = __builtin_amdgcn_rcpf(w1);
+  // log1p(e) = log(w1) - ((w1 - 1) - e) / w1   (first-order compensation of fl(1 + e))
+  const float l1p = __builtin_fmaf(-((w1 - 1.0f) - e), q, __builtin_amdgcn_logf(w1) * kLn2);
+  const float loss = fmaxf(-d0, 0.0f) + l1p;                       // only used when hi (d = d0)
+  const float eq = e * q;
+  const float sig_hi = (d0 >= 0.0f) ? eq : q;                      // sigma(-d0)
+  const float sig_lo = (d0 >= 0.0f) ? q : eq;                      // sigma(+d0)
+  const float ww_hi = hi ? wl * ri.w : 0.0f;
+  const float ww_lo = lo ? wl * rj.w : 0.0f;
+  acc_loss = __builtin_fmaf(ww_hi, loss, acc_loss);
+  acc_w += ww_hi;
+  acc_nz += (ww_hi != 0.0f) ? 1.0f : 0.0f;
+  acc_g = __builtin_fmaf(-ww_hi, sig_hi, acc_g);
+  acc_g = __builtin_fmaf(ww_lo, sig_lo, acc_g);
+}
+
+template <int LAMBDA, bool GENERIC>
 __global__ void pairwise_logistic_kernel(const PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);            // [32]
@@ -133,15 +183,21 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       const float g = LV[i] ? Gr[i] * (a.normalized ? inv_max_dcg : 1.0f) : 0.0f;
       rec0[pos] = make_float4(Xr[i], a.labels[base + i], g, Wr[i]);
       const float dprime = (dcg_lambda && r <= topn) ? a.discount[r - 1] : 0.0f;
-      rec1[pos] = make_float2(dprime, __int_as_float(LV[i] ? r : -r));
+      rec1[pos] = make_float2(dprime, LV[i] ? (float)r : -(float)r);
       CI[pos] = i;
     }
     n += tot;
   }
   __syncthreads();
 
-  // ---- 4. pair sweep.  Row i (C lanes) against every column j.
+  // ---- 4. pair sweep.  Row i (C lanes) against every column j (two columns per trip).
   const int C = a.C;
+  const int iters = ((n + C - 1) / C + 1) & ~1;                    // uniform, even trip count
+  for (int p = n + tid; p < iters * C; p += T) {                   // neutral padding records
+    rec0[p] = make_float4(0.f, NAN, 0.f, 0.f);
+    rec1[p] = make_float2(0.f, 1.0f);
+  }
+  __syncthreads();
   const int rows_per_pass = T / C;
   const int c = tid % C, rsub = tid / C;
   const float fL = (float)L;
@@ -154,56 +210,28 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       if (a.dlogits) a.dlogits[base + i] = 0.f;
     }
   }
+  const float ftopn = (float)topn;
   for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
     const int row = row0 + rsub;
     const bool active = row < n;
     if (!__any(active)) continue;
-    const float4 ri = rec0[active ? row : 0];
+    float4 ri = rec0[active ? row : 0];
     const float2 qi = rec1[active ? row : 0];
-    const int rsi = __float_as_int(qi.y);
-    const int ranki = rsi < 0 ? -rsi : rsi;
-    const bool lvi = rsi > 0;
-    float acc_loss = 0.f, acc_w = 0.f, acc_g = 0.f;
-    for (int j = c; j < n; j += C) {
-      const float4 rj = rec0[j];
-      const bool hi = ri.y > rj.y;            // row item is the preferred one
-      const bool lo = rj.y > ri.y;            // column item is the preferred one
-      float wl = 1.0f;
-      if (a.lambda_kind == TFR_LAMBDA_DCG) {
-        const float2 qj = rec1[j];
-        const int rsj = __float_as_int(qj.y);
-        const int rankj = rsj < 0 ? -rsj : rsj;
-        const bool lvj = rsj > 0;
-        const int dr = ranki > rankj ? ranki - rankj : rankj - ranki;
-        const bool in_top = (ranki <= topn) || (rankj <= topn);
-        const float u = in_top ? U[dr] : 0.0f;               // U[0] = 0
-        const float v = fabsf(qi.x - qj.x);
-        float pd = one_minus_s * u + a.smooth * v;
-        pd = in_top ? pd : 0.0f;
-        const float pg = (lvi && lvj) ? fabsf(ri.z - rj.z) : 0.0f;
-        wl = (pg * pd) * fL;
-      } else if (a.lambda_kind == TFR_LAMBDA_LABELDIFF) {
-        wl = fabsf(ri.y - rj.y);
-      }
-      const float d = hi ? (ri.x - rj.x) : (rj.x - ri.x);    // winner - loser
-      const float ww = wl * (hi ? ri.w : rj.w);               // winner's item weight
-      const float u = __builtin_amdgcn_exp2f(-fabsf(d) * kLog2e);
-      const float q = __builtin_amdgcn_rcpf(1.0f + u);
-      const float loss = fmaxf(-d, 0.0f) + log1pf(u);         // :936-940
-      const float sig_neg = (d >= 0.0f) ? u * q : q;          // sigma(-d) = -loss'(d)
-      const float gterm = ww * sig_neg;
-      if (hi) {
-        acc_loss = __builtin_fmaf(ww, loss, acc_loss);
-        acc_w += ww;
-        nnz_local += (active && ww != 0.0f) ? 1.0f : 0.0f;
-        acc_g -= gterm;
-      } else if (lo) {
-        acc_g += gterm;
-      }
+    if (!active) ri.y = NAN;
+    float acc_loss = 0.f, acc_w = 0.f, acc_nz = 0.f, acc_g = 0.f;
+    for (int it = 0; it < iters; it += 2) {
+      const int j0 = c + it * C, j1 = j0 + C;
+      const float4 r0 = rec0[j0], r1 = rec0[j1];
+      const float2 q0 = rec1[j0], q1 = rec1[j1];
+      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r0, q0.y, q0.x, U, ftopn, one_minus_s, a.smooth, fL,
+                                 acc_loss, acc_w, acc_nz, acc_g);
+      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r1, q1.y, q1.x, U, ftopn, one_minus_s, a.smooth, fL,
+                                 acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
       acc_loss += __shfl_xor(acc_loss, o, 64);
       acc_w += __shfl_xor(acc_w, o, 64);
+      acc_nz += __shfl_xor(acc_nz, o, 64);
       acc_g += __shfl_xor(acc_g, o, 64);
     }
     if (active && c == 0) {
@@ -211,10 +239,238 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       if (a.row_loss) a.row_loss[base + oi] = acc_loss;
       if (a.row_weight) a.row_weight[base + oi] = acc_w;
       if (a.dlogits) a.dlogits[base + oi] = acc_g / a.temperature;
+      nnz_local += acc_nz;
     }
   }
   nnz_local = block_sum(nnz_local, red);
   if (tid == 0 && a.nnz) a.nnz[b] = nnz_local;
+}
+
+
+// ===========================================================================
+// Wave-per-list variant (L <= 64 * IPL): one wavefront owns a list, no
+// workgroup barriers; ranks come from a counting sweep over the packed LDS
+// records, the ideal DCG from an in-register bitonic sort, and the pair body is
+// branch-free with single-instruction transcendentals (v_exp / v_rcp / v_log;
+// the libm log1pf the first version called cost ~120 VALU instructions per pair).
+// ===========================================================================
+
+template <int IPL>
+__device__ __forceinline__ void wave_sort_desc_u32(uint32_t (&a)[IPL], int lane) {
+  constexpr int N = 64 * IPL;
+#pragma unroll
+  for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & jr) == 0) {
+            const int r2 = r | jr;
+            const bool desc = (((r << 6) & kk) == 0);
+            const uint32_t hi = a[r] > a[r2] ? a[r] : a[r2];
+            const uint32_t lo = a[r] > a[r2] ? a[r2] : a[r];
+            a[r] = desc ? hi : lo;
+            a[r2] = desc ? lo : hi;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const uint32_t p = (uint32_t)__shfl_xor((int)a[r], j, 64);
+          const int e = lane | (r << 6);
+          const bool desc = ((e & kk) == 0);
+          const bool lower = ((lane & j) == 0);
+          const uint32_t mx = a[r] > p ? a[r] : p;
+          const uint32_t mn = a[r] > p ? p : a[r];
+          a[r] = (lower == desc) ? mx : mn;
+        }
+      }
+    }
+  }
+}
+
+template <int IPL, int LAMBDA, bool GENERIC>
+__global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int Lp = a.Lp;
+  float4* rec0 = reinterpret_cast<float4*>(smem_raw);                  // [Lp] (x, raw label, gain, weight)
+  float2* rec1 = reinterpret_cast<float2*>(rec0 + Lp);                 // [Lp] (D'(rank), signed rank)
+  float* U = reinterpret_cast<float*>(rec1 + Lp);                      // [Lp]
+  int* CI = reinterpret_cast<int*>(U + Lp);                            // [Lp]
+  const int lane = threadIdx.x, b = blockIdx.x, L = a.L;
+  const size_t base = (size_t)b * L;
+  const int topn = (a.topn <= 0 || a.topn > L) ? L : a.topn;
+  const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
+
+  // ---- 1. load; gains; compaction of the mask-valid items.
+  float g[IPL];
+  bool lv[IPL], mv[IPL];
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    g[r] = 0.f; lv[r] = false; mv[r] = false;
+    float x = 0.f, lab = 0.f, w = 0.f;
+    if (e < L) {
+      lab = a.labels[base + e];
+      x = a.logits[base + e] / a.temperature;
+      lv[r] = lab >= 0.0f;
+      mv[r] = a.mask ? (a.mask[base + e] != 0) : lv[r];
+      const float labc = lv[r] ? lab : 0.0f;
+      if (LAMBDA == TFR_LAMBDA_DCG) {
+        if (a.gain_kind == TFR_GAIN_CUSTOM) g[r] = a.gains[base + e];
+        else if (a.gain_kind == TFR_GAIN_POW2M1) g[r] = gain_pow2m1(labc);
+        else g[r] = labc;
+      }
+      w = a.item_weights ? a.item_weights[base + e] : 1.0f;
+      w = lv[r] ? (w * lw) : 0.0f;
+      if (!mv[r]) {
+        if (a.row_loss) a.row_loss[base + e] = 0.f;
+        if (a.row_weight) a.row_weight[base + e] = 0.f;
+        if (a.dlogits) a.dlogits[base + e] = 0.f;
+      }
+    }
+    const unsigned long long bal = __ballot(mv[r]);
+    if (mv[r]) {
+      const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
+      rec0[pos] = make_float4(x, lab, lv[r] ? g[r] : 0.0f, w);
+      CI[pos] = lv[r] ? e : -e - 1;                        // sign carries label validity
+    }
+    n += __popcll(bal);
+  }
+
+  // ---- 2. ideal DCG@topn of the cleaned labels (:109-134), in registers.
+  float inv_max_dcg = 1.0f;
+  if (LAMBDA == TFR_LAMBDA_DCG) {
+    for (int m = lane; m < Lp; m += 64)
+      U[m] = (m >= 1 && m < L) ? fabsf(a.discount[m - 1] - a.discount[m]) : 0.0f;
+    if (a.normalized) {
+      // gains of monotone gain functions sort like the labels; a custom gain_fn
+      // sorts by label and carries the gain (two-key compare through a u32 pair).
+      uint32_t sk[IPL];
+      float idcg = 0.f;
+      if (a.gain_kind != TFR_GAIN_CUSTOM) {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) sk[r] = (lane + 64 * r < L) ? float_to_ordered(g[r]) : 0u;
+        wave_sort_desc_u32<IPL>(sk, lane);
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const int e = lane + 64 * r;
+          if (e < topn) {
+            const uint32_t o = sk[r];
+            const float gv = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+            idcg += gv * a.discount[e];
+          }
+        }
+      } else {
+        // rank of every label by counting (ties: lower index first), then scatter by rank.
+        float* sl = reinterpret_cast<float*>(rec1);          // [2*Lp] scratch (rec1 is filled in step 3)
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const int e = lane + 64 * r;
+          if (e < L) { const float lab = a.labels[base + e]; sl[e] = lab >= 0.0f ? lab : 0.0f; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const int e = lane + 64 * r;
+          if (e < L) {
+            const float me = sl[e];
+            int cnt = 0;
+            for (int j = 0; j < L; ++j) {
+              const float o = sl[j];
+              cnt += (o > me || (o == me && j < e)) ? 1 : 0;
+            }
+            if (cnt < topn) idcg += g[r] * a.discount[cnt];
+          }
+        }
+        __syncthreads();
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) idcg += __shfl_xor(idcg, o, 64);
+      inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. ranks by counting (valid first, score desc, ties by index) (:483-500).
+  const int n4 = (n + 3) >> 2;
+  for (int p = n + lane; p < n4 * 4; p += 64) rec0[p] = make_float4(-INFINITY, -2.0f, 0.f, 0.f);
+  __syncthreads();
+  const float ftopn = (float)topn;
+  for (int p = lane; p < n; p += 64) {
+    const float xi = rec0[p].x;
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) {
+      const float xj = rec0[j].x;
+      cnt += (xj > xi || (xj == xi && j < p)) ? 1 : 0;
+    }
+    const int rank = cnt + 1;
+    const bool lvp = CI[p] >= 0;
+    float dprime = 0.f;
+    if (LAMBDA == TFR_LAMBDA_DCG) {
+      dprime = (rank <= topn) ? a.discount[rank - 1] : 0.0f;
+      if (a.normalized) rec0[p].z *= inv_max_dcg;
+    }
+    rec1[p] = make_float2(dprime, lvp ? (float)rank : -(float)rank);
+  }
+  for (int p = n + lane; p < n4 * 4; p += 64) rec1[p] = make_float2(0.f, -1.0f);
+  __syncthreads();
+
+  // ---- 4. pair sweep: row = C adjacent lanes, 64/C rows per pass.
+  const int C = a.C;
+  const int rows_per_pass = 64 / C;
+  const int c = lane % C, rsub = lane / C;
+  const float fL = (float)L;
+  const float one_minus_s = 1.0f - a.smooth;
+  float nnz_local = 0.f;
+  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    float4 ri = rec0[active ? row : 0];
+    const float2 qi = rec1[active ? row : 0];
+    if (!active) ri.y = NAN;                                   // compares false: contributes nothing
+    float acc_loss = 0.f, acc_w = 0.f, acc_nz = 0.f, acc_g = 0.f;
+    for (int j = c; j < n; j += C) {
+      const float4 rj = rec0[j];
+      const float2 qj = rec1[j];
+      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, rj, qj.y, qj.x, U, ftopn, one_minus_s, a.smooth, fL,
+                                 acc_loss, acc_w, acc_nz, acc_g);
+    }
+    for (int o = 1; o < C; o <<= 1) {
+      acc_loss += __shfl_xor(acc_loss, o, 64);
+      acc_w += __shfl_xor(acc_w, o, 64);
+      acc_nz += __shfl_xor(acc_nz, o, 64);
+      acc_g += __shfl_xor(acc_g, o, 64);
+    }
+    if (active && c == 0) {
+      const int ci = CI[row];
+      const int oi = ci >= 0 ? ci : -ci - 1;
+      if (a.row_loss) a.row_loss[base + oi] = acc_loss;
+      if (a.row_weight) a.row_weight[base + oi] = acc_w;
+      if (a.dlogits) a.dlogits[base + oi] = acc_g / a.temperature;
+      nnz_local += acc_nz;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
+  if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
+}
+
+template <int IPL>
+int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
+  const size_t lds = (size_t)a.Lp * (16 + 8 + 4 + 4);
+  const bool generic = (a.lambda_kind == TFR_LAMBDA_DCG) &&
+                       (a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) || a.mask != nullptr);
+#define PW_LAUNCH(LAM, GEN) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN>), dim3(B), dim3(64), lds, stream, a)
+  if (a.lambda_kind == TFR_LAMBDA_DCG) { if (generic) PW_LAUNCH(TFR_LAMBDA_DCG, true); else PW_LAUNCH(TFR_LAMBDA_DCG, false); }
+  else if (a.lambda_kind == TFR_LAMBDA_LABELDIFF) PW_LAUNCH(TFR_LAMBDA_LABELDIFF, false);
+  else PW_LAUNCH(TFR_LAMBDA_NONE, false);
+#undef PW_LAUNCH
+  return (int)hipGetLastError();
 }
 
 int env_int(const char* name, int dflt) {
@@ -243,8 +499,25 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
   if (B == 0) return TFR_OK;
   static const int env_threads = env_int("TFR_PAIRWISE_THREADS", 0);
   static const int env_lanes = env_int("TFR_PAIRWISE_LANES", 0);
-  const int C = env_lanes > 0 ? env_lanes : 4;
+  static const int env_wave = env_int("TFR_PAIRWISE_WAVE", 1);
+  static const int env_wave_min_b = env_int("TFR_PAIRWISE_WAVE_MIN_B", 2048);
+  const int C = env_lanes > 0 ? env_lanes : 2;
   if (C > 64 || (C & (C - 1))) return TFR_EINVAL;
+  if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
+    PwArgs w;
+    w.logits = logits; w.labels = labels; w.mask = mask; w.item_weights = item_weights;
+    w.list_weights = list_weights; w.lambda_kind = lambda_kind; w.topn = topn;
+    w.smooth = smooth_fraction; w.normalized = normalized; w.gain_kind = gain_kind; w.gains = gains;
+    w.discount = discount; w.L = L; w.Lp = ((L + 3) / 4) * 4 + 4; w.P = 0;
+    w.temperature = temperature; w.C = C; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
+    w.nnz = nnz_out; w.dlogits = dlogits_out;
+    hipStream_t st = (hipStream_t)stream;
+    if (L <= 64) return launch_pw_wave<1>(w, B, st);
+    if (L <= 128) return launch_pw_wave<2>(w, B, st);
+    if (L <= 256) return launch_pw_wave<4>(w, B, st);
+    if (L <= 512) return launch_pw_wave<8>(w, B, st);
+    return launch_pw_wave<16>(w, B, st);
+  }
   const int T = env_threads > 0 ? env_threads : (L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 512 ? 256 : 512)));
   if (T % 64 || T > 1024) return TFR_EINVAL;
   PwArgs a;
@@ -256,11 +529,22 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
   a.nnz = nnz_out; a.dlogits = dlogits_out;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pairwise_logistic_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  hipLaunchKernelGGL(pairwise_logistic_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, a);
+  const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
+                       (smooth_fraction != 0.0f || (topn > 0 && topn < L) || mask != nullptr);
+#define PW_BLOCK(LAM, GEN)                                                                        \
+  do {                                                                                            \
+    if (lds > 64 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute(                                                         \
+          reinterpret_cast<const void*>(&pairwise_logistic_kernel<LAM, GEN>),                     \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                  \
+      if (e != hipSuccess) return (int)e;                                                         \
+    }                                                                                             \
+    hipLaunchKernelGGL((pairwise_logistic_kernel<LAM, GEN>), dim3(B), dim3(T), lds,               \
+                       (hipStream_t)stream, a);                                                   \
+  } while (0)
+  if (lambda_kind == TFR_LAMBDA_DCG) { if (generic) PW_BLOCK(TFR_LAMBDA_DCG, true); else PW_BLOCK(TFR_LAMBDA_DCG, false); }
+  else if (lambda_kind == TFR_LAMBDA_LABELDIFF) PW_BLOCK(TFR_LAMBDA_LABELDIFF, false);
+  else PW_BLOCK(TFR_LAMBDA_NONE, false);
+#undef PW_BLOCK
   return (int)hipGetLastError();
 }
