@@ -135,6 +135,65 @@ int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const u
                               const float* upstream, int B, int S, int L,
                               float gumbel_temperature, float* dlogits_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Scorer tower: tfr.keras.layers.create_tower (keras/layers.py:26-77) on the flattened
+ * [M = B*L, F] matrix of DNNScorer._score_flattened (keras/model.py:800-817); the groupwise
+ * scorer's group_score_fn (model.py:276-306) is the same tower on [B*G, group_size*F].
+ * bf16 operands / fp32 accumulation on the MFMA units; "bf16" pointers are uint16 bit
+ * patterns, row-major with the stated pitch (elements).  prologue: 0 = A as is,
+ * 1 = A*scale[k] + shift[k], 2 = relu(A*scale[k] + shift[k]) -- i.e. the BatchNormalization +
+ * Activation of the layer below applied while its pre-activation is loaded.
+ * epilogue: 0 = plain, 1 = + per-column partial sums (sum z, sum z^2) per 64-row half tile into
+ * stats[tfr_tower_gemm_stats_rows(M)][2][N] (the next BatchNormalization's batch statistics),
+ * 2 = backward of relu/BN-input: C = acc * 1[Zp*e_scale + e_shift > 0], stats = partial
+ * (sum dy, sum dy * zhat) with zhat = (Zp - e_mean) * e_rstd.                              */
+
+/* Dense input cast: fp32 x[M, F] (pitch ldx) -> bf16 out[M, Kp], Kp = F rounded up to 8, zero
+ * padded; optional per-column affine (an input BatchNormalization folded in). */
+int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
+                            const float* shift, void* out_bf16, void* stream);
+/* fp32 w[R, C] -> bf16 [R, pitch] or (transpose) bf16 [C, pitch]: the per-step operand copy of a
+ * Dense kernel (fp32 master weights stay with the optimizer). */
+int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,
+                          void* stream);
+/* Dense (+ fused neighbours): C[M, N] = prologue(A)[M, K] . B[N, K]^T + bias, bf16 out. */
+int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                        int M, int N, int K, int prologue, const float* a_scale, const float* a_shift,
+                        const float* bias, int epilogue, float* stats, const void* Zp, long ldz,
+                        const float* e_scale, const float* e_shift, const float* e_mean,
+                        const float* e_rstd, void* stream);
+int tfr_tower_gemm_stats_rows(int M);            /* rows of `stats` for a given M            */
+int tfr_tower_reduce_scratch_rows(int T);     /* rows of the `scratch` buffers below      */
+/* BatchNormalization (training): partial[T][2][N] -> mean / biased variance -> scale = gamma *
+ * rsqrt(var + eps), shift = beta - mean * scale; moving averages updated in place
+ * (moving * momentum + batch * (1 - momentum)).  scratch: [scratch_rows(T)][2N] or NULL. */
+int tfr_tower_bn_finalize(const float* partial, int T, int N, long M, const float* gamma,
+                          const float* beta, float eps, float momentum, float* moving_mean,
+                          float* moving_var, float* scale, float* shift, float* mean_out,
+                          float* rstd_out, float* scratch, void* stream);
+/* out[i] = sum_t partial[t][i], i < W.  scratch: [scratch_rows(T)][W] or NULL. */
+int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, float* scratch,
+                              void* stream);
+/* Output Dense(output_units <= 4): out[M, O] = prologue(z)[M, K] . w[O, K]^T + b (fp32). */
+int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                      const float* shift, const float* w, const float* b, int O, float* out,
+                      void* stream);
+/* Its backward: dy[M, K] (bf16) = (dlogits . w) * relu mask; partial[n_blocks][2 + O][K] =
+ * per-block (sum dy, sum dy * zhat, d w[o, :]). */
+int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                      const float* shift, const float* mean, const float* rstd, const float* w,
+                      const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
+                      int n_blocks, void* stream);
+/* BatchNormalization backward, in place: dy <- p[k]*dy + q[k]*z + r[k]; pqr is fp32 [3][K]. */
+int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, long ldz, int M, int K,
+                           const float* pqr, void* stream);
+/* Dense kernel gradient: slab[s][N][ldw] = partial dz[M, N]^T . prologue(A)[M, K] over the
+ * s-th slice of M (fp32); tfr_tower_slab_reduce sums the slices. */
+int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int M, int N, int K,
+                         int prologue, const float* a_scale, const float* a_shift, float* slab,
+                         long ldw, int splits, void* stream);
+int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

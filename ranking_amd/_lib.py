@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
-SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip']
+SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                '-fvisibility=default']
 
@@ -42,6 +42,29 @@ _SIGNATURES = {
                               + [ctypes.c_float] + [ctypes.c_void_p] * 2),
     'tfr_gumbel_sample_bwd_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float]
                                   + [ctypes.c_void_p] * 2),
+    # scorer tower (tower.hip)
+    'tfr_tower_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
+                                + [ctypes.c_void_p] * 4),
+    'tfr_tower_weight_cast': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2),
+    'tfr_tower_gemm_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_int] * 4
+                            + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_long]
+                            + [ctypes.c_void_p] * 5),
+    'tfr_tower_gemm_stats_rows': (ctypes.c_int, [ctypes.c_int]),
+    'tfr_tower_reduce_scratch_rows': (ctypes.c_int, [ctypes.c_int]),
+    'tfr_tower_bn_finalize': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_long]
+                              + [ctypes.c_void_p] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 8),
+    'tfr_tower_reduce_partials': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
+    'tfr_tower_out_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
+                          + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 2),
+    'tfr_tower_out_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
+                          + [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long]
+                          + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    'tfr_tower_bn_bwd_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 2
+                               + [ctypes.c_void_p] * 2),
+    'tfr_tower_wgrad_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 4
+                             + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
+    'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_void_p]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -1,0 +1,162 @@
+"""Torch-tensor level bindings of the scorer-tower entry points of the C ABI
+(include/tfr_hip.h, ranking_amd/csrc/tower.hip).  Device memory and streams only;
+no CPU fallback."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._ops import _ptr, _stream, require_device
+
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_RELU = 0, 1, 2
+EPI_PLAIN, EPI_STATS, EPI_RELU_BWD = 0, 1, 2
+
+
+def _bf16(t, name):
+    require_device(t, name)
+    if t.dtype != torch.bfloat16:
+        raise TypeError('%s must be bfloat16' % name)
+    if t.stride(-1) != 1:
+        raise ValueError('%s must be row-major' % name)
+    return t
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None):
+    """fp32 [M, F] -> bf16 [M, pad8(F)] (zero padded), optional per-column affine."""
+    require_device(x, 'x')
+    x = x.to(torch.float32)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    M, F = x.shape
+    Kp = pad8(F)
+    out = torch.empty((M, Kp), dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().tfr_tower_cast_f32_bf16(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
+                                                   _ptr(out), _stream()), 'tfr_tower_cast_f32_bf16')
+    return out
+
+
+def cast_weight(w: torch.Tensor, transpose: bool = False):
+    """fp32 [R, C] -> bf16 [R, pad8(C)], or (transpose) bf16 [C, pad8(R)]."""
+    require_device(w, 'w')
+    w = w.detach().to(torch.float32).contiguous()
+    R, C = w.shape
+    pitch = pad8(R if transpose else C)
+    out = torch.empty((C if transpose else R, pitch), dtype=torch.bfloat16, device=w.device)
+    _lib.check(_lib.load().tfr_tower_weight_cast(_ptr(w), R, C, int(transpose), pitch, _ptr(out), _stream()),
+               'tfr_tower_weight_cast')
+    return out
+
+
+def stats_rows(M: int) -> int:
+    return 2 * ((M + 127) // 128)
+
+
+def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, epilogue=EPI_PLAIN,
+         Zp=None, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, out=None):
+    """C[M, N] = pro(A)[M, :K] . B[N, :K]^T (+ bias) as bf16; returns (C, stats_partial | None)."""
+    _bf16(A, 'A'); _bf16(B, 'B')
+    M = A.shape[0]
+    C = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
+    stats = None
+    if epilogue != EPI_PLAIN:
+        stats = torch.empty((stats_rows(M), 2, N), dtype=torch.float32, device=A.device)
+    _lib.check(_lib.load().tfr_tower_gemm_bf16(
+        _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), M, N, K, prologue,
+        _ptr(a_scale), _ptr(a_shift), _ptr(bias), epilogue, _ptr(stats), _ptr(Zp),
+        Zp.stride(0) if Zp is not None else 0, _ptr(e_scale), _ptr(e_shift), _ptr(e_mean), _ptr(e_rstd),
+        _stream()), 'tfr_tower_gemm_bf16')
+    return C, stats
+
+
+def _scratch(T, W, dev):
+    """Stage-1 buffer of the two-stage column reduction (None when one stage is enough)."""
+    if T <= 64:
+        return None
+    return torch.empty(((T + 63) // 64, W), dtype=torch.float32, device=dev)
+
+
+def bn_finalize(partial, M, gamma, beta, eps, momentum, moving_mean, moving_var):
+    T, _, N = partial.shape
+    dev = partial.device
+    scale = torch.empty(N, dtype=torch.float32, device=dev)
+    shift = torch.empty_like(scale); mean = torch.empty_like(scale); rstd = torch.empty_like(scale)
+    scratch = _scratch(T, 2 * N, dev)
+    _lib.check(_lib.load().tfr_tower_bn_finalize(_ptr(partial), T, N, M, _ptr(gamma), _ptr(beta), eps, momentum,
+                                                 _ptr(moving_mean), _ptr(moving_var), _ptr(scale), _ptr(shift),
+                                                 _ptr(mean), _ptr(rstd), _ptr(scratch), _stream()),
+               'tfr_tower_bn_finalize')
+    return scale, shift, mean, rstd
+
+
+def reduce_partials(partial):
+    """[T, J, N] per-workgroup column partials -> [J, N] sums."""
+    T, J, N = partial.shape
+    out = torch.empty((J, N), dtype=torch.float32, device=partial.device)
+    scratch = _scratch(T, J * N, partial.device)
+    _lib.check(_lib.load().tfr_tower_reduce_partials(_ptr(partial), T, J * N, _ptr(out), _ptr(scratch), _stream()),
+               'tfr_tower_reduce_partials')
+    return out
+
+
+def out_layer(z, K, prologue, scale, shift, w, b):
+    """logits[M, O] = act(z)[M, :K] . w[O, K]^T + b (fp32)."""
+    _bf16(z, 'z')
+    M = z.shape[0]
+    w = w.detach().to(torch.float32).contiguous()
+    O = w.shape[0]
+    out = torch.empty((M, O), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().tfr_tower_out_f32(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift),
+                                             _ptr(w), _ptr(b), O, _ptr(out), _stream()), 'tfr_tower_out_f32')
+    return out
+
+
+def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=512):
+    """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
+    sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]."""
+    _bf16(z, 'z')
+    M = z.shape[0]
+    w = w.detach().to(torch.float32).contiguous()
+    O = w.shape[0]
+    dlogits = dlogits.to(torch.float32).contiguous()
+    n_blocks = max(1, min(n_blocks, (M + 15) // 16))
+    dy = torch.empty((M, K), dtype=torch.bfloat16, device=z.device)
+    partial = torch.empty((n_blocks, 2 + O, K), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().tfr_tower_out_bwd(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift),
+                                             _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dlogits), O, _ptr(dy),
+                                             dy.stride(0), _ptr(partial), n_blocks, _stream()),
+               'tfr_tower_out_bwd')
+    return dy, reduce_partials(partial)
+
+
+def bn_bwd_apply_(dy, z, K, pqr):
+    """In place: dy <- p * dy + q * z + r (per column); pqr is fp32 [3, K]."""
+    _bf16(dy, 'dy'); _bf16(z, 'z')
+    pqr = pqr.to(torch.float32).contiguous()
+    _lib.check(_lib.load().tfr_tower_bn_bwd_apply(_ptr(dy), dy.stride(0), _ptr(z), z.stride(0), dy.shape[0], K,
+                                                  _ptr(pqr), _stream()), 'tfr_tower_bn_bwd_apply')
+    return dy
+
+
+def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0):
+    """dW[N, K] = dz[M, :N]^T . pro(A)[M, :K] (fp32)."""
+    _bf16(dz, 'dz'); _bf16(A, 'A')
+    M = dz.shape[0]
+    if splits <= 0:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
+    slab = torch.empty((splits, N, K), dtype=torch.float32, device=dz.device)
+    lib = _lib.load()
+    _lib.check(lib.tfr_tower_wgrad_bf16(_ptr(dz), dz.stride(0), _ptr(A), A.stride(0), M, N, K, prologue,
+                                        _ptr(a_scale), _ptr(a_shift), _ptr(slab), K, splits, _stream()),
+               'tfr_tower_wgrad_bf16')
+    out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 0, _stream()),
+               'tfr_tower_slab_reduce')
+    return out

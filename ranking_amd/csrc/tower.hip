@@ -1,0 +1,896 @@
+// Feed-forward scorer tower (Dense -> BatchNorm -> activation blocks) for gfx950:
+// bf16 MFMA GEMMs with the BatchNorm / ReLU / bias / cast work fused into the
+// GEMM prologues and epilogues, forward and backward.
+//
+// Reference behaviour restated: keras/layers.py:26-77 (create_tower: Dense,
+// BatchNormalization(momentum), Activation, Dropout per hidden layer, then
+// Dense(output_units)) driven by keras/model.py:780-817 (DNNScorer over the
+// flattened [B*L, F] matrix).  The reference runs these as separate fp32 TF ops
+// (MatMul, BiasAdd, FusedBatchNormV3, Relu); SURVEY.md 8a row a21.
+//
+// Design (MI355X).  A hidden layer is ONE launch:
+//     Z_l = act_{l-1}(Z_{l-1}) . W_l^T + b_l            (bf16 operands, fp32 accumulate)
+// where act_{l-1}(z) = relu(z * scale + shift) is the previous layer's BatchNorm +
+// ReLU applied WHILE the A tile is staged into LDS (the normalised activation is
+// never written to HBM), and the epilogue adds the bias, writes Z_l as bf16 and
+// emits the per-column partial sums (sum z, sum z^2) the NEXT BatchNorm needs, so a
+// [M, 512] layer costs one read + one write of an [M, 512] bf16 matrix.  At
+// M = 409600, N = K = 512 that is 0.84 GB against 0.215 TFLOP: 256 FLOP/B, below
+// the machine balance (2.5 PFLOP/s / ~6 TB/s = ~420 FLOP/B), i.e. the layer is
+// HBM-bound once the MFMA pipe runs above ~55 % -- which is why nothing else is
+// allowed to touch HBM.
+//
+// GEMM kernel: 128x128 output tile, BK = 64, 4 wavefronts (2x2, 64x64 each as 4x4
+// v_mfma_f32_16x16x32_bf16 fragments), LDS double buffer (64 KB -> 2 workgroups per
+// CU), register-staged global->LDS copy (the prologue transform needs the registers
+// anyway) issued one tile ahead, XOR-swizzled 16-byte chunks so that the
+// ds_read_b128 fragment reads are (nearly) conflict free, and an XCD-aware
+// workgroup -> tile map that keeps the N-tiles of one M-tile on one XCD (its A tile
+// is then served by that XCD's L2).  The MFMA operands are swapped (weights as
+// "A", activations as "B") so that a lane ends up with 4 consecutive output
+// COLUMNS of one row: 8-byte bf16 stores and a 16-lane DPP reduction for the
+// column statistics.
+#include "common.h"
+#include "../../include/tfr_hip.h"
+
+#include <stdlib.h>
+
+using namespace tfr;
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KB per operand tile
+
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {     // RNE (v_cvt_pk_bf16_f32)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+
+// byte offset of 16-byte chunk c (0..7) of row r inside a swizzled [128][64] bf16 tile
+__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+struct GemmArgs {
+  const uint16_t* A; long lda;       // [M, K] activations (bf16; pre-BN z when PRO != 0)
+  const uint16_t* B; long ldb;       // [N, K] weights (bf16)
+  uint16_t* C; long ldc;             // [M, N] bf16
+  const float* bias;                 // [N] nullable
+  const float* a_scale;              // [K] (PRO != 0)
+  const float* a_shift;              // [K]
+  float* stats;                      // [2 tiles_m][2][N] partials per 64-row half tile  (EPI != 0)
+  const uint16_t* Zp; long ldz;      // [M, N] pre-BN z of the layer below               (EPI == 2)
+  const float* e_scale;              // [N] its BN scale / shift (relu mask) ...
+  const float* e_shift;
+  const float* e_mean;               // ... and mean / rstd (z_hat for d gamma)
+  const float* e_rstd;
+  int M, N, K, tiles_m, tiles_n;
+  int ablate;                        // diagnostics only (TFR_TOWER_ABLATE): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no C stores
+};
+
+enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_RELU_BWD = 2 };
+
+template <int PRO>
+__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh) {
+  if (PRO == PRO_NONE) return v;
+  uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float a = __builtin_fmaf(bf16_lo(w[i]), sc[2 * i], sh[2 * i]);
+    float b = __builtin_fmaf(bf16_hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
+    if (PRO == PRO_AFFINE_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    w[i] = pack_bf16(a, b);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// 16-lane row sum with DPP (result in lane 15 of every 16-lane row).
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+  return v;
+}
+
+constexpr int WPITCH = 144;                      // bytes per row of a wave's 64 x 64 bf16 epilogue tile (128 + 16 pad)
+
+// C[M, N] = pro(A)[M, K] . B[N, K]^T (+ bias), bf16 out.
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [buf][A tile | B tile], then the per-column prologue coefficients.
+  unsigned char* tiles = smem;
+  float* s_scale = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);
+  float* s_shift = s_scale + ((g.K + 63) & ~63);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware tile map: workgroup id -> (m tile, n tile); the n tiles of one m tile
+  // run back to back on one XCD (ids congruent mod 8 share an XCD).
+  const int id = blockIdx.x;
+  const int xcd = id & 7, j = id >> 3;
+  const int tn = j % g.tiles_n;
+  const int tm = (j / g.tiles_n) * 8 + xcd;
+  if (tm >= g.tiles_m) return;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = (g.K + BK - 1) / BK;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (g.ablate & 16) ts0 = __builtin_amdgcn_s_memtime();
+
+  // staging: thread owns chunk column c = tid & 7 of rows (tid >> 3) + 32 * i.
+  const int c = tid & 7, r0 = tid >> 3;
+  struct RegsA { uint4 a[4]; };
+  struct RegsB { uint4 b[4]; };
+  auto load_a = [&](int kt, RegsA& R) {
+    const int k = kt * BK + c * 8;
+    const bool kin = k < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long am = m0 + r0 + 32 * i;
+      R.a[i] = (kin && am < g.M) ? *reinterpret_cast<const uint4*>(g.A + am * g.lda + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto load_b = [&](int kt, RegsB& R) {
+    const int k = kt * BK + c * 8;
+    const bool kin = k < g.K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long bn = n0 + r0 + 32 * i;
+      R.b[i] = (kin && bn < g.N) ? *reinterpret_cast<const uint4*>(g.B + bn * g.ldb + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int kt, int buf, const RegsA& RA, const RegsB& RB) {
+    unsigned char* ta = tiles + buf * 2 * TILE_BYTES;
+    unsigned char* tb = ta + TILE_BYTES;
+    const int k = kt * BK + c * 8;
+    float sc[8], sh[8];
+    if (PRO != PRO_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = s_scale[k + e]; sh[e] = s_shift[k + e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 32 * i;
+      uint4 va = RA.a[i];
+      // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh);
+      *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
+      *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
+    }
+  };
+
+  f32x4 acc[4][4];      // [fn][fm]: D[n][m]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](int buf) {
+    const unsigned char* ta = tiles + buf * 2 * TILE_BYTES;
+    const unsigned char* tb = ta + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        fb[f] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 64 + f * 16 + fr, kk * 4 + fq));   // weights
+        fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));   // activations
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+          acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fn], fa[fm], acc[fn][fm], 0, 0, 0);
+    }
+  };
+
+  // A (streamed from HBM) is requested two tiles ahead in two register sets, B (the weights,
+  // L2 resident) one tile ahead: an A load has two compute phases to land.
+  RegsA A0, A1;
+  RegsB Bx;
+  load_a(0, A0);
+  load_b(0, Bx);
+  if (nk > 1) load_a(1, A1);
+  if (PRO != PRO_NONE) {
+    for (int k = tid; k < nk * BK; k += 256) {
+      s_scale[k] = (k < g.K) ? g.a_scale[k] : 0.f;
+      s_shift[k] = (k < g.K) ? g.a_shift[k] : 0.f;
+    }
+    __syncthreads();
+  }
+  store_tile(0, 0, A0, Bx);
+  __syncthreads();
+  if (g.ablate & 16) ts1 = __builtin_amdgcn_s_memtime();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) load_b(kt + 1, Bx);
+    if (kt + 2 < nk) load_a(kt + 2, A0);
+    compute(0);
+    if (kt + 1 < nk) store_tile(kt + 1, 1, A1, Bx);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 2 < nk) load_b(kt + 2, Bx);
+    if (kt + 3 < nk) load_a(kt + 3, A1);
+    compute(1);
+    if (kt + 2 < nk) store_tile(kt + 2, 0, A0, Bx);
+    __syncthreads();
+  }
+  if (g.ablate & 16) ts2 = __builtin_amdgcn_s_memtime();
+
+  // ---- epilogue.  Lane holds D[n = nb + 4*fq + r][m = mb + fr], r = 0..3.  The staging
+  // buffers are dead: every wave transposes its 64 x 64 bf16 result through a private LDS
+  // region so that the global stores (and the Zp loads of EPI_RELU_BWD) are 16 bytes per
+  // lane and 128 contiguous bytes per row.  No workgroup barrier from here on.
+  unsigned char* wl = smem + wave * (64 * WPITCH);
+  const long mb = m0 + wm * 64;
+  const int nb = n0 + wn * 64;
+  if (EPI == EPI_RELU_BWD) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
+      uint4 zz = make_uint4(0, 0, 0, 0);
+      if (mb + row < g.M && nb + cc * 8 < g.N)
+        zz = *reinterpret_cast<const uint4*>(g.Zp + (mb + row) * g.ldz + nb + cc * 8);
+      *reinterpret_cast<uint4*>(wl + row * WPITCH + cc * 16) = zz;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float s1[4][4], s2[4][4];
+#pragma unroll
+  for (int fn = 0; fn < 4; ++fn) {
+    const int n = nb + fn * 16 + fq * 4;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias4[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
+    }
+    float em[4], er[4], es[4], eh[4];
+    if (EPI == EPI_RELU_BWD) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool in = n + r < g.N;
+        es[r] = in ? g.e_scale[n + r] : 0.f; eh[r] = in ? g.e_shift[n + r] : 0.f;
+        em[r] = in ? g.e_mean[n + r] : 0.f;  er[r] = in ? g.e_rstd[n + r] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[fn][r] = 0.f; s2[fn][r] = 0.f; }
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm) {
+      const int row = fm * 16 + fr;
+      const bool min = mb + row < g.M;
+      unsigned char* slot = wl + row * WPITCH + (fn * 16 + fq * 4) * 2;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[fn][fm][r] + bias4[r];
+      if (EPI == EPI_RELU_BWD) {
+        // dy = da * 1[y > 0], y = z * scale + shift;  column partials: sum dy, sum dy * z_hat
+        const uint2 zz = *reinterpret_cast<const uint2*>(slot);
+        const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float y = __builtin_fmaf(z[r], es[r], eh[r]);
+          v[r] = (y > 0.f && min) ? v[r] : 0.f;
+          s1[fn][r] += v[r];
+          s2[fn][r] = __builtin_fmaf(v[r], (z[r] - em[r]) * er[r], s2[fn][r]);
+        }
+      } else if (EPI == EPI_STATS) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = min ? v[r] : 0.f;
+          s1[fn][r] += t;
+          s2[fn][r] = __builtin_fmaf(t, t, s2[fn][r]);
+        }
+      }
+      *reinterpret_cast<uint2*>(slot) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    }
+  }
+  if (EPI != EPI_PLAIN && !(g.ablate & 16)) {
+    // column partials of this wave's 64 rows: stats[(2 tm + wm)][which][n]
+    float* st = g.stats + ((long)(tm * 2 + wm) * 2) * g.N;
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = row16_sum(s1[fn][r]), b = row16_sum(s2[fn][r]);
+        const int n = nb + fn * 16 + fq * 4 + r;
+        if (fr == 15 && n < g.N) { st[n] = a; st[g.N + n] = b; }
+      }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
+    if (mb + row < g.M && nb + cc * 8 < g.N)      // N % 8 == 0 is checked on the host
+      *reinterpret_cast<uint4*>(g.C + (mb + row) * g.ldc + nb + cc * 8) =
+          *reinterpret_cast<const uint4*>(wl + row * WPITCH + cc * 16);
+  }
+  if ((g.ablate & 16) && tid == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.stats) + (long)(tm * g.tiles_n + tn) * 5;
+    dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
+    dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 [M, F] -> bf16 [M, Kp] (zero padded columns), optional per-column affine (input BN).
+__global__ void tower_cast_kernel(const float* __restrict__ x, long ldx, int M, int F, int Kp,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  uint16_t* __restrict__ out) {
+  const long chunks_per_row = Kp / 8;
+  const long total = (long)M * chunks_per_row;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const long m = q / chunks_per_row;
+    const int k = (int)(q % chunks_per_row) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (k + e < F) ? x[m * ldx + k + e] : 0.f;
+      if (scale && k + e < F) t = __builtin_fmaf(t, scale[k + e], shift[k + e]);
+      v[e] = t;
+    }
+    *reinterpret_cast<uint4*>(out + m * Kp + k) =
+        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+  }
+}
+
+// fp32 [R, C] -> bf16 [R, Cp] row-major, or its transpose bf16 [C, Rp] (weights: once per step).
+__global__ void tower_weight_cast_kernel(const float* __restrict__ w, int R, int C, int transpose,
+                                         int pitch, uint16_t* __restrict__ out) {
+  const int total = transpose ? C * pitch : R * pitch;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    const int orow = q / pitch, ocol = q % pitch;
+    float v = 0.f;
+    if (!transpose) { if (ocol < C) v = w[(long)orow * C + ocol]; }
+    else            { if (ocol < R) v = w[(long)ocol * C + orow]; }
+    out[q] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
+  }
+}
+
+// Column sums of per-workgroup partials, stage 1: out[c][i] = sum_{t in chunk c} partial[t][i].
+// Grid (ceil(W / 256), ceil(T / 64)); fully coalesced, deterministic (fixed order), so that the
+// finishing kernels below only walk ceil(T / 64) rows.
+constexpr int kReduceChunk = 64;
+__global__ void tower_reduce_rows_kernel(const float* __restrict__ partial, int T, int W, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W) return;
+  const int t0 = blockIdx.y * kReduceChunk;
+  const int t1 = (t0 + kReduceChunk < T) ? t0 + kReduceChunk : T;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int t = t0;
+  for (; t + 3 < t1; t += 4) {
+    s0 += partial[(long)t * W + i];       s1 += partial[(long)(t + 1) * W + i];
+    s2 += partial[(long)(t + 2) * W + i]; s3 += partial[(long)(t + 3) * W + i];
+  }
+  for (; t < t1; ++t) s0 += partial[(long)t * W + i];
+  out[(long)blockIdx.y * W + i] = (s0 + s1) + (s2 + s3);
+}
+
+// BatchNorm statistics: partial [T][2][N] (fp32) -> mean, biased variance (fp64 combine),
+// scale = gamma * rsqrt(var + eps), shift = beta - mean * scale; moving averages updated in
+// place (Keras: moving = moving * momentum + batch * (1 - momentum); biased variance).
+__global__ void tower_bn_finalize_kernel(const float* __restrict__ partial, int T, int N, long M,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, float momentum, float* __restrict__ moving_mean,
+                                         float* __restrict__ moving_var, float* __restrict__ scale,
+                                         float* __restrict__ shift, float* __restrict__ mean_out,
+                                         float* __restrict__ rstd_out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double s = 0.0, ss = 0.0;
+  for (int t = 0; t < T; ++t) {
+    s += (double)partial[((long)t * 2 + 0) * N + n];
+    ss += (double)partial[((long)t * 2 + 1) * N + n];
+  }
+  const double mean = s / (double)M;
+  double var = ss / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
+  const float sc = ga * rstd;
+  scale[n] = sc;
+  shift[n] = be - (float)mean * sc;
+  mean_out[n] = (float)mean;
+  rstd_out[n] = rstd;
+  if (moving_mean) moving_mean[n] = moving_mean[n] * momentum + (float)mean * (1.f - momentum);
+  if (moving_var) moving_var[n] = moving_var[n] * momentum + (float)var * (1.f - momentum);
+}
+
+// Finishes per-workgroup column partials: out[i] = sum_t partial[t][i], i < W (fp64 combine).
+__global__ void tower_reduce_partials_kernel(const float* __restrict__ partial, int T, int W,
+                                             float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= W) return;
+  double s = 0.0;
+  for (int t = 0; t < T; ++t) s += (double)partial[(long)t * W + i];
+  out[i] = (float)s;
+}
+
+// Output layer: logits[m, o] = sum_k act(z[m, k]) * w[o, k] + b[o], O <= 4 (GEMV class:
+// one read of z).  A row is owned by 16 lanes, 8 bf16 (16 B) per lane per trip; the
+// per-column coefficients live in LDS as [K/8][(2 + O)][8] floats (one float4 pair each).
+template <int PRO>
+__global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restrict__ z, long ldz, int M, int K,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        const float* __restrict__ w, const float* __restrict__ b,
+                                                        int O, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* coef = reinterpret_cast<float*>(smem);          // [K/8][2 + O][8]
+  const int stride = (2 + O) * 8;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float* cc = coef + (k >> 3) * stride + (k & 7);
+    cc[0] = (PRO != PRO_NONE) ? scale[k] : 1.f;
+    cc[8] = (PRO != PRO_NONE) ? shift[k] : 0.f;
+    for (int o = 0; o < O; ++o) cc[16 + 8 * o] = w[(long)o * K + k];
+  }
+  __syncthreads();
+  const int lane16 = threadIdx.x & 15;
+  const long row_in_grid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const long rows_per_grid = ((long)gridDim.x * blockDim.x) >> 4;
+  for (long m = row_in_grid; m < M; m += rows_per_grid) {   // the 16 lanes of a row share m
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane16 * 8; k < K; k += 128) {
+      const uint4 v = *reinterpret_cast<const uint4*>(z + m * ldz + k);
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      const float* cc = coef + (k >> 3) * stride;
+      float a[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { a[2 * i] = bf16_lo(u[i]); a[2 * i + 1] = bf16_hi(u[i]); }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = a[e];
+        if (PRO != PRO_NONE) t = __builtin_fmaf(t, cc[e], cc[8 + e]);
+        if (PRO == PRO_AFFINE_RELU) t = fmaxf(t, 0.f);
+        a[e] = t;
+      }
+      for (int o = 0; o < O; ++o) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[o] = __builtin_fmaf(a[e], cc[16 + 8 * o + e], acc[o]);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int s = 8; s > 0; s >>= 1) acc[o] += __shfl_xor(acc[o], s, 64);
+    if (lane16 == 0)
+      for (int o = 0; o < O; ++o) out[m * O + o] = acc[o] + (b ? b[o] : 0.f);
+  }
+}
+
+// ====================================================================================
+// Backward.
+//
+// Per hidden layer l (z_l = a_{l-1} W_l^T + b_l, y_l = BN(z_l), a_l = relu(y_l)):
+//   dy_l  = da_l * 1[y_l > 0]                       (fused: output-layer backward / dgrad epilogue)
+//   c1 = sum_m dy_l, c2 = sum_m dy_l * zhat_l       (column partials from the same epilogue)
+//   dz_l  = scale * (dy_l - c1/M - zhat_l * c2/M) = p*dy + q*z + r  per column  (bn_bwd_apply)
+//   dW_l  = dz_l^T a_{l-1}  (wgrad: transposed-operand MFMA GEMM, split over M)
+//   da_{l-1} = dz_l W_l     (dgrad: the forward GEMM kernel on W_l^T, EPI_RELU_BWD)
+//   d gamma = c2, d beta = c1, d b_l = sum_m dz_l (= 0 under BatchNorm).
+
+// Output layer backward.  logits[m, o] = sum_k a[m, k] w[o, k] + b[o], a = act(z):
+//   dy[m, k] = (sum_o dlogits[m, o] w[o, k]) * 1[y > 0]   -> bf16 [M, K]
+//   partial[blk][0][k] = sum_m dy, [1][k] = sum_m dy * zhat, [2 + o][k] = sum_m dlogits[m, o] a[m, k]
+template <int PRO>
+__global__ __launch_bounds__(256) void tower_out_bwd_kernel(
+    const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
+    float* __restrict__ partial, int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // [16][(2 + O) * 128]
+  const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long mb = (long)blockIdx.x * rows_per_block;
+  const long me = (mb + rows_per_block < M) ? mb + rows_per_block : M;
+  const int J = 2 + O;
+  for (int kp = 0; kp < K; kp += 128) {
+    const int k = kp + lane16 * 8;
+    const bool kin = k < K;
+    float sc[8], sh[8], mu[8], rs[8], ww[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = (kin && PRO != PRO_NONE) ? scale[k + e] : 1.f;
+      sh[e] = (kin && PRO != PRO_NONE) ? shift[k + e] : 0.f;
+      mu[e] = (kin && mean) ? mean[k + e] : 0.f;
+      rs[e] = (kin && rstd) ? rstd[k + e] : 1.f;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) ww[o][e] = (kin && o < O) ? w[(long)o * K + k + e] : 0.f;
+    }
+    float s1[8], s2[8], dw[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; dw[0][e] = dw[1][e] = dw[2][e] = dw[3][e] = 0.f; }
+    if (kin) {
+      for (long m = mb + grp; m < me; m += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(z + m * ldz + k);
+        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+        float dl[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < O; ++o) dl[o] = dlogits[m * O + o];
+        float out[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
+          const float y = __builtin_fmaf(zz, sc[e], sh[e]);
+          const float a = (PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y;
+          float da = 0.f;
+#pragma unroll
+          for (int o = 0; o < 4; ++o) { da = __builtin_fmaf(dl[o], ww[o][e], da); dw[o][e] = __builtin_fmaf(dl[o], a, dw[o][e]); }
+          const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da;
+          s1[e] += d;
+          s2[e] = __builtin_fmaf(d, (zz - mu[e]) * rs[e], s2[e]);
+          out[e] = d;
+        }
+        *reinterpret_cast<uint4*>(dy + m * lddy + k) =
+            make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]), pack_bf16(out[6], out[7]));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float* rr = red + grp * (J * 128) + lane16 * 8 + e;
+      rr[0] = s1[e]; rr[128] = s2[e];
+      for (int o = 0; o < O; ++o) rr[(2 + o) * 128] = dw[o][e];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < J * 128; i += 256) {
+      const int jj = i / 128, kk = kp + (i & 127);
+      if (kk < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) t += red[gq * (J * 128) + i];
+        partial[((long)blockIdx.x * J + jj) * K + kk] = t;
+      }
+    }
+  }
+}
+
+// dz = p[k] * dy + q[k] * z + r[k], in place over dy (bf16 [M, K]).
+__global__ __launch_bounds__(256) void tower_bn_bwd_apply_kernel(uint16_t* __restrict__ dy, long lddy,
+                                                                 const uint16_t* __restrict__ z, long ldz,
+                                                                 int M, int K, const float* __restrict__ pqr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* c = reinterpret_cast<float*>(smem);                   // [3][K]
+  for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) c[i] = pqr[i];
+  __syncthreads();
+  const int cpr = K / 8;
+  const long total = (long)M * cpr;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const long m = q / cpr;
+    const int k = (int)(q % cpr) * 8;
+    const uint4 a = *reinterpret_cast<const uint4*>(dy + m * lddy + k);
+    const uint4 b = *reinterpret_cast<const uint4*>(z + m * ldz + k);
+    const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k0 = k + 2 * i, k1 = k0 + 1;
+      const float lo = __builtin_fmaf(c[k0], bf16_lo(ua[i]), __builtin_fmaf(c[K + k0], bf16_lo(ub[i]), c[2 * K + k0]));
+      const float hi = __builtin_fmaf(c[k1], bf16_hi(ua[i]), __builtin_fmaf(c[K + k1], bf16_hi(ub[i]), c[2 * K + k1]));
+      o[i] = pack_bf16(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(dy + m * lddy + k) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// Weight gradient: dW[n, k] = sum_m dz[m, n] * pro(A)[m, k], both operands row-major in m
+// (the contraction index is the ROW of both), so the MFMA fragments are read from LDS with
+// the gfx950 transpose load ds_read_b64_tr_b16: the 16 lanes of a group each supply the
+// address of an 8-byte piece of a [4 rows][16 cols] block and receive one COLUMN of it.
+// Tile 128 (n) x 128 (k), 64 rows of m per step, double-buffered LDS, split over M
+// (blockIdx.z) into fp32 slabs [split][N][ldw] that tower_slab_reduce sums.
+struct WgradArgs {
+  const uint16_t* DZ; long lddz;     // [M, N]
+  const uint16_t* A; long lda;       // [M, K] (pre-BN z of the layer below when PRO != 0)
+  const float* a_scale; const float* a_shift;
+  float* slab; long ldw;             // [splits][N][ldw]
+  int M, N, K, rows_per_split;
+};
+
+// byte offset of 16-byte chunk cc (0..15) of row r in a swizzled [64][128] bf16 tile
+__device__ __forceinline__ int swz_t(int r, int cc) { return r * 256 + ((cc ^ (((r & 3) | ((r >> 1) & 4)) << 1)) << 4); }
+// byte offset of the 8-byte slot s (0..31) of row r in the same tile
+__device__ __forceinline__ int swz_t8(int r, int s) { return r * 256 + ((s ^ (((r & 3) | ((r >> 1) & 4)) << 2)) << 3); }
+
+__device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+      (__attribute__((address_space(3))) bf16x4*)(uintptr_t)(uint32_t)(uintptr_t)p);
+}
+
+template <int PRO>
+__global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, split = blockIdx.z;
+  const long ms = (long)split * g.rows_per_split;
+  const long me = (ms + g.rows_per_split < g.M) ? ms + g.rows_per_split : g.M;
+  const int steps = (int)((me - ms + 63) / 64);
+
+  const int cc = tid & 15, r0 = tid >> 4;         // chunk column, first row (rows r0 + 16 i)
+  float sc[8], sh[8];
+  if (PRO != PRO_NONE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = k0 + cc * 8 + e;
+      sc[e] = k < g.K ? g.a_scale[k] : 0.f;
+      sh[e] = k < g.K ? g.a_shift[k] : 0.f;
+    }
+  }
+  const bool nin = n0 + cc * 8 < g.N, kin = k0 + cc * 8 < g.K;
+  uint4 rd[4], ra[4];
+  auto load_tile = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long m = ms + (long)st * 64 + r0 + 16 * i;
+      const bool min = m < me;
+      rd[i] = (min && nin) ? *reinterpret_cast<const uint4*>(g.DZ + m * g.lddz + n0 + cc * 8) : make_uint4(0, 0, 0, 0);
+      ra[i] = (min && kin) ? *reinterpret_cast<const uint4*>(g.A + m * g.lda + k0 + cc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* td = smem + buf * 32768;
+    unsigned char* ta = td + 16384;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 16 * i;
+      uint4 va = ra[i];
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh);
+      *reinterpret_cast<uint4*>(td + swz_t(row, cc)) = rd[i];
+      *reinterpret_cast<uint4*>(ta + swz_t(row, cc)) = va;
+    }
+  };
+
+  f32x4 acc[4][4];      // [fn][fk]: D[n][k]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (steps > 0) {
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    if (steps > 1) load_tile(1);
+  }
+  const int fr = lane & 15, fq = lane >> 4;
+  const int trow = fr >> 2, tslot = fr & 3;       // this lane's piece of the [4][16] block
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    const unsigned char* td = smem + cur * 32768;
+    const unsigned char* ta = td + 16384;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {              // 32 rows of m per MFMA
+      bf16x8 fd[4], fa[4];
+      const int rb = kk * 32 + fq * 8 + trow;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const int sd = (wn * 64 + f * 16) / 4 + tslot, sa = (wk * 64 + f * 16) / 4 + tslot;
+        const bf16x4 d0 = lds_tr16(td + swz_t8(rb, sd)), d1 = lds_tr16(td + swz_t8(rb + 4, sd));
+        const bf16x4 a0 = lds_tr16(ta + swz_t8(rb, sa)), a1 = lds_tr16(ta + swz_t8(rb + 4, sa));
+        fd[f] = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+        fa[f] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+        for (int fk = 0; fk < 4; ++fk)
+          acc[fn][fk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[fn], fa[fk], acc[fn][fk], 0, 0, 0);
+    }
+    if (st + 1 < steps) store_tile(cur ^ 1);
+    __syncthreads();
+    if (st + 2 < steps) load_tile(st + 2);
+  }
+  // D[n = nb + 4 fq + r][k = kb + fr]
+  float* out = g.slab + (long)split * g.N * g.ldw;
+#pragma unroll
+  for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < 4; ++fk) {
+      const int k = k0 + wk * 64 + fk * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + fn * 16 + fq * 4 + r;
+        if (n < g.N && k < g.K) out[(long)n * g.ldw + k] = acc[fn][fk][r];
+      }
+    }
+}
+
+// out[i] (+)= sum_s slab[s][i]
+__global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, long n, float* __restrict__ out,
+                                         int accumulate) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += slab[(long)s * n + i];
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
+int grid_for(long work_items, int block) {
+  long g = (work_items + block - 1) / block;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <int PRO, int EPI>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  const int kpad = (g.K + 63) & ~63;
+  const size_t lds = 4 * TILE_BYTES + 2 * (size_t)kpad * sizeof(float);
+  auto fn = tower_gemm_kernel<PRO, EPI>;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int groups = (g.tiles_m + 7) / 8;
+  hipLaunchKernelGGL(fn, dim3(groups * 8 * g.tiles_n), dim3(256), lds, st, g);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
+                                       const float* shift, void* out_bf16, void* stream) {
+  if (!x || !out_bf16 || M < 0 || F <= 0 || Kp < F || (Kp & 7)) return TFR_EINVAL;
+  if (M == 0) return TFR_OK;
+  hipLaunchKernelGGL(tower_cast_kernel, dim3(grid_for((long)M * (Kp / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, ldx, M, F, Kp, scale, shift, (uint16_t*)out_bf16);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,
+                                     void* stream) {
+  if (!w || !out_bf16 || R <= 0 || C <= 0 || pitch < (transpose ? R : C)) return TFR_EINVAL;
+  const int total = transpose ? C * pitch : R * pitch;
+  hipLaunchKernelGGL(tower_weight_cast_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     w, R, C, transpose, pitch, (uint16_t*)out_bf16);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                   int M, int N, int K, int prologue, const float* a_scale,
+                                   const float* a_shift, const float* bias, int epilogue, float* stats,
+                                   const void* Zp, long ldz, const float* e_scale, const float* e_shift,
+                                   const float* e_mean, const float* e_rstd, void* stream) {
+  if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return TFR_EINVAL;
+  if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7) || (K & 7) || lda < K || ldb < K || ldc < N) return TFR_EINVAL;
+  if (prologue < 0 || prologue > 2 || epilogue < 0 || epilogue > 2) return TFR_EINVAL;
+  if (prologue != PRO_NONE && (!a_scale || !a_shift)) return TFR_EINVAL;
+  if (epilogue != EPI_PLAIN && !stats) return TFR_EINVAL;
+  if (epilogue == EPI_RELU_BWD && (!Zp || !e_scale || !e_shift || !e_mean || !e_rstd || (ldz & 7))) return TFR_EINVAL;
+  if (K > 4096) return TFR_ETOOLARGE;
+  if (M == 0) return TFR_OK;
+  GemmArgs g;
+  g.A = (const uint16_t*)A; g.lda = lda; g.B = (const uint16_t*)B; g.ldb = ldb;
+  g.C = (uint16_t*)C; g.ldc = ldc; g.bias = bias; g.a_scale = a_scale; g.a_shift = a_shift;
+  g.stats = stats; g.Zp = (const uint16_t*)Zp; g.ldz = ldz; g.e_scale = e_scale; g.e_shift = e_shift;
+  g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  { const char* e = getenv("TFR_TOWER_ABLATE"); g.ablate = (e && *e) ? atoi(e) : 0; }
+  hipStream_t st = (hipStream_t)stream;
+#define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
+  TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);
+#undef TG
+  return TFR_EINVAL;
+}
+
+extern "C" int tfr_tower_gemm_stats_rows(int M) { return 2 * ((M + BM - 1) / BM); }
+
+extern "C" int tfr_tower_reduce_scratch_rows(int T) { return (T + kReduceChunk - 1) / kReduceChunk; }
+
+extern "C" int tfr_tower_bn_finalize(const float* partial, int T, int N, long M, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* moving_mean,
+                                     float* moving_var, float* scale, float* shift, float* mean_out,
+                                     float* rstd_out, float* scratch, void* stream) {
+  if (!partial || T <= 0 || N <= 0 || M <= 0 || !scale || !shift || !mean_out || !rstd_out) return TFR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = partial;
+  int rows = T;
+  if (T > kReduceChunk && scratch) {          // stage 1: [T][2N] -> [ceil(T/64)][2N]
+    rows = (T + kReduceChunk - 1) / kReduceChunk;
+    hipLaunchKernelGGL(tower_reduce_rows_kernel, dim3((2 * N + 255) / 256, rows), dim3(256), 0, st, partial, T,
+                       2 * N, scratch);
+    src = scratch;
+  }
+  hipLaunchKernelGGL(tower_bn_finalize_kernel, dim3((N + 63) / 64), dim3(64), 0, st, src, rows, N, M, gamma, beta,
+                     eps, momentum, moving_mean, moving_var, scale, shift, mean_out, rstd_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, float* scratch,
+                                         void* stream) {
+  if (!partial || T <= 0 || W <= 0 || !out) return TFR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* src = partial;
+  int rows = T;
+  if (T > kReduceChunk && scratch) {
+    rows = (T + kReduceChunk - 1) / kReduceChunk;
+    hipLaunchKernelGGL(tower_reduce_rows_kernel, dim3((W + 255) / 256, rows), dim3(256), 0, st, partial, T, W, scratch);
+    src = scratch;
+  }
+  hipLaunchKernelGGL(tower_reduce_partials_kernel, dim3((W + 63) / 64), dim3(64), 0, st, src, rows, W, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                                 const float* shift, const float* w, const float* b, int O, float* out,
+                                 void* stream) {
+  if (!z || !w || !out || M < 0 || K <= 0 || (K & 7) || (ldz & 7) || O < 1 || O > 4) return TFR_EINVAL;
+  if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
+  if (M == 0) return TFR_OK;
+  const int grid = grid_for((long)M * 16, 256) > 2048 ? 2048 : grid_for((long)M * 16, 256);
+  const size_t lds = (size_t)(K / 8) * (2 + O) * 8 * sizeof(float);
+  if (lds > 64 * 1024) return TFR_ETOOLARGE;
+  hipStream_t st = (hipStream_t)stream;
+  const uint16_t* zz = (const uint16_t*)z;
+  if (prologue == PRO_NONE) hipLaunchKernelGGL(tower_out_kernel<PRO_NONE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
+  else if (prologue == PRO_AFFINE) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
+  else if (prologue == PRO_AFFINE_RELU) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_RELU>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
+  else return TFR_EINVAL;
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, const float* w,
+                                 const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
+                                 int n_blocks, void* stream) {
+  if (!z || !w || !dlogits || !dy_bf16 || !partial || M <= 0 || K <= 0 || (K & 7) || (ldz & 7) || (lddy & 7) ||
+      O < 1 || O > 4 || n_blocks < 1) return TFR_EINVAL;
+  if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
+  int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
+  rows = (rows + 15) / 16 * 16;
+  const size_t lds = (size_t)16 * (2 + O) * 128 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+#define OB(P) hipLaunchKernelGGL(tower_out_bwd_kernel<P>, dim3(n_blocks), dim3(256), lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows)
+  if (prologue == PRO_NONE) OB(PRO_NONE); else if (prologue == PRO_AFFINE) OB(PRO_AFFINE);
+  else if (prologue == PRO_AFFINE_RELU) OB(PRO_AFFINE_RELU); else return TFR_EINVAL;
+#undef OB
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, long ldz, int M, int K,
+                                      const float* pqr, void* stream) {
+  if (!dy_bf16 || !z || !pqr || M < 0 || K <= 0 || (K & 7) || (lddy & 7) || (ldz & 7)) return TFR_EINVAL;
+  if (3 * (size_t)K * 4 > 64 * 1024) return TFR_ETOOLARGE;
+  if (M == 0) return TFR_OK;
+  hipLaunchKernelGGL(tower_bn_bwd_apply_kernel, dim3(grid_for((long)M * (K / 8), 256) > 2048 ? 2048 : grid_for((long)M * (K / 8), 256)),
+                     dim3(256), 3 * (size_t)K * 4, (hipStream_t)stream, (uint16_t*)dy_bf16, lddy,
+                     (const uint16_t*)z, ldz, M, K, pqr);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int M, int N, int K,
+                                    int prologue, const float* a_scale, const float* a_shift, float* slab,
+                                    long ldw, int splits, void* stream) {
+  if (!DZ || !A || !slab || M <= 0 || N <= 0 || K <= 0 || (lddz & 7) || (lda & 7) || (N & 7) || (K & 7) ||
+      ldw < K || splits < 1 || splits > 65535) return TFR_EINVAL;
+  if (prologue < 0 || prologue > 2 || (prologue != PRO_NONE && (!a_scale || !a_shift))) return TFR_EINVAL;
+  WgradArgs g;
+  g.DZ = (const uint16_t*)DZ; g.lddz = lddz; g.A = (const uint16_t*)A; g.lda = lda; g.a_scale = a_scale;
+  g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+  int rows = (int)(((long)M + splits - 1) / splits);
+  g.rows_per_split = (rows + 63) / 64 * 64;
+  const dim3 grid((N + 127) / 128, (K + 127) / 128, splits);
+  hipStream_t st = (hipStream_t)stream;
+#define WG(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad_kernel<P>, grid, dim3(256), 65536, st, g); } while (0)
+  if (prologue == PRO_NONE) WG(PRO_NONE); else if (prologue == PRO_AFFINE) WG(PRO_AFFINE); else WG(PRO_AFFINE_RELU);
+#undef WG
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream) {
+  if (!slab || !out || S < 1 || n <= 0) return TFR_EINVAL;
+  hipLaunchKernelGGL(tower_slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, S,
+                     n, out, accumulate);
+  return (int)hipGetLastError();
+}

@@ -40,6 +40,17 @@ def create_tower(hidden_layer_dims: List[int], output_units: int, activation: Op
     from ..scorer import make_dense
     if input_dim is None:
         raise ValueError('input_dim is required')
+    if compute_dtype == torch.bfloat16 and hidden_layer_dims and not input_batch_norm and not dropout:
+        # MI355X fast path: one fused MFMA launch per layer, forward and backward (ranking_amd/tower.py).
+        from ..tower import FusedTower, _act_code
+        try:
+            act = _act_code(activation)
+            fusable = all(int(h) % 8 == 0 for h in hidden_layer_dims) and 1 <= int(output_units) <= 4
+        except ValueError:
+            fusable = False
+        if fusable:
+            return FusedTower(input_dim, list(hidden_layer_dims), output_units, activation=act,
+                              use_batch_norm=use_batch_norm, batch_norm_moment=batch_norm_moment)
     layers: List[nn.Module] = []
     if input_batch_norm:
         layers.append(nn.BatchNorm1d(input_dim, momentum=1.0 - batch_norm_moment, eps=1e-3))

@@ -44,4 +44,5 @@ class DNNScorer(UnivariateScorer):
                for k in sorted(context_features)]
         ex = [example_features[k].reshape(example_features[k].shape[0], -1)
               for k in sorted(example_features)]
-        return self._tower(torch.cat(ctx + ex, dim=1))
+        cols = ctx + ex
+        return self._tower(cols[0] if len(cols) == 1 else torch.cat(cols, dim=1))

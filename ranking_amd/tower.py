@@ -1,0 +1,205 @@
+"""MI355X-native feed-forward scorer tower.
+
+Mirror of ``tfr.keras.layers.create_tower`` (keras/layers.py:26-77): per hidden layer
+``Dense -> BatchNormalization -> Activation -> Dropout``, then ``Dense(output_units)``,
+evaluated on the flattened ``[B * L, F]`` matrix (keras/model.py:800-817).  The
+reference runs it as separate fp32 TensorFlow ops; here a hidden layer is ONE bf16
+MFMA GEMM launch with the previous layer's BatchNorm + ReLU fused into its operand
+load and bias / bf16 cast / BatchNorm statistics fused into its epilogue
+(``csrc/tower.hip``), forward and backward.  Parameters stay fp32 (master copy); the
+bf16 operand copies are rebuilt per call.
+
+What the fused path covers: ``activation`` in {None, relu}, ``use_batch_norm`` on or
+off, training (batch statistics, moving averages updated) and inference (moving
+averages).  ``input_batch_norm`` and training-time dropout are not fused: ``create_tower``
+builds the plain torch tower for those (same GPU, fp32, unfused).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from . import _tower_ops as T
+
+_BN_EPS = 1e-3          # tf.keras.layers.BatchNormalization default epsilon
+
+
+def _act_code(activation) -> Optional[str]:
+    if activation is None:
+        return None
+    if activation in ('relu', torch.relu, torch.nn.functional.relu) or isinstance(activation, nn.ReLU):
+        return 'relu'
+    raise ValueError('FusedTower supports activation None or relu, got %r' % (activation,))
+
+
+class _TowerFn(torch.autograd.Function):
+    """forward(x, training, tower, *params) -> logits [M, O] (fp32)."""
+
+    @staticmethod
+    def forward(ctx, x, tower, training, *params):
+        n_h = len(tower.hidden_layer_dims)
+        use_bn, relu = tower.use_batch_norm, tower.activation == 'relu'
+        Ws = params[0:n_h]
+        bs = params[n_h:2 * n_h]
+        gammas = params[2 * n_h:3 * n_h] if use_bn else [None] * n_h
+        betas = params[3 * n_h:4 * n_h] if use_bn else [None] * n_h
+        w_out, b_out = params[-2], params[-1]
+        M = x.shape[0]
+        dev = x.device
+        x0 = x if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 else T.cast_rows(x)
+        a_in, pro, sc, sh = x0, T.PRO_NONE, None, None
+        zs, coefs = [], []
+        k_in = x0.shape[1]
+        for l in range(n_h):
+            n_out = Ws[l].shape[0]
+            wb = T.cast_weight(Ws[l])                      # [N, pad8(K)]
+            z, stats = T.gemm(a_in, wb, n_out, k_in, prologue=pro, a_scale=sc, a_shift=sh, bias=bs[l],
+                              epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN)
+            if use_bn:
+                if training:
+                    sc, sh, mean, rstd = T.bn_finalize(stats, M, gammas[l], betas[l], _BN_EPS, tower.momentum,
+                                                       tower.moving_mean[l], tower.moving_var[l])
+                else:
+                    rstd = torch.rsqrt(tower.moving_var[l] + _BN_EPS)
+                    mean = tower.moving_mean[l]
+                    sc = gammas[l].detach() * rstd
+                    sh = betas[l].detach() - mean * sc
+                pro = T.PRO_AFFINE_RELU if relu else T.PRO_AFFINE
+            else:
+                mean = rstd = None
+                if relu:
+                    sc = torch.ones(n_out, device=dev); sh = torch.zeros(n_out, device=dev)
+                    pro = T.PRO_AFFINE_RELU
+                else:
+                    sc = sh = None
+                    pro = T.PRO_NONE
+            zs.append(z); coefs.append((pro, sc, sh, mean, rstd))
+            a_in, k_in = z, n_out
+        logits = T.out_layer(a_in, k_in, pro, sc, sh, w_out, b_out)
+        ctx.tower, ctx.training = tower, training
+        ctx.x0, ctx.zs, ctx.coefs = x0, zs, coefs
+        ctx.params = params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        tower, params = ctx.tower, ctx.params
+        n_h = len(tower.hidden_layer_dims)
+        use_bn = tower.use_batch_norm
+        if use_bn and not ctx.training:
+            raise RuntimeError('FusedTower backward in inference mode (moving statistics) is not supported')
+        Ws = params[0:n_h]
+        gammas = params[2 * n_h:3 * n_h] if use_bn else [None] * n_h
+        w_out = params[-2]
+        x0, zs, coefs = ctx.x0, ctx.zs, ctx.coefs
+        M = x0.shape[0]
+        dev = x0.device
+        dlogits = dlogits.to(torch.float32).contiguous()
+        dW, db = [None] * n_h, [None] * n_h
+        dgam, dbet = [None] * n_h, [None] * n_h
+        # output layer
+        pro, sc, sh, mean, rstd = coefs[-1]
+        n_last = zs[-1].shape[1]
+        dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits)
+        dw_out = sums[2:].contiguous()
+        db_out = dlogits.sum(dim=0)
+        c1, c2 = sums[0], sums[1]
+        for l in range(n_h - 1, -1, -1):
+            n_out = zs[l].shape[1]
+            pro_l, sc_l, sh_l, mean_l, rstd_l = coefs[l]
+            if use_bn:
+                dgam[l], dbet[l] = c2.clone(), c1.clone()
+                s = gammas[l].detach() * rstd_l
+                pqr = torch.stack([s, -s * rstd_l * c2 / M, s * (rstd_l * c2 * mean_l - c1) / M])
+                dz = T.bn_bwd_apply_(dy, zs[l], n_out, pqr)
+                db[l] = torch.zeros(n_out, device=dev)
+            else:
+                dz = dy
+                db[l] = c1.clone()
+            if l > 0:
+                pro_p, sc_p, sh_p, mean_p, rstd_p = coefs[l - 1]
+                a_prev, k_in = zs[l - 1], zs[l - 1].shape[1]
+            else:
+                pro_p, sc_p, sh_p, mean_p, rstd_p = T.PRO_NONE, None, None, None, None
+                a_prev, k_in = x0, x0.shape[1]
+            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p)
+            dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
+            if l > 0:
+                wt = T.cast_weight(Ws[l], transpose=True)          # [K, pad8(N)]
+                ones = torch.ones(k_in, device=dev); zeros = torch.zeros(k_in, device=dev)
+                if pro_p == T.PRO_AFFINE_RELU:
+                    e_sc, e_sh = sc_p, sh_p
+                else:                                                # identity activation: mask always on
+                    e_sc, e_sh = zeros, ones
+                e_mean = mean_p if mean_p is not None else zeros
+                e_rstd = rstd_p if rstd_p is not None else ones
+                dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD,
+                                     Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd)
+                cc = T.reduce_partials(partial)
+                c1, c2 = cc[0], cc[1]
+        grads = list(dW) + list(db)
+        if use_bn:
+            grads += list(dgam) + list(dbet)
+        grads += [dw_out, db_out]
+        return (None, None, None) + tuple(grads)
+
+
+class FusedTower(nn.Module):
+    """create_tower(...) as one fused module; call with the flattened ``[M, F]`` features."""
+
+    def __init__(self, input_dim: int, hidden_layer_dims: List[int], output_units: int = 1, activation=None,
+                 use_batch_norm: bool = True, batch_norm_moment: float = 0.999):
+        super().__init__()
+        if not hidden_layer_dims:
+            raise ValueError('FusedTower needs at least one hidden layer')
+        if any(int(h) % 8 for h in hidden_layer_dims):
+            raise ValueError('FusedTower needs hidden widths that are multiples of 8, got %r' % (hidden_layer_dims,))
+        if not 1 <= int(output_units) <= 4:
+            raise ValueError('FusedTower supports 1..4 output units')
+        self.input_dim = int(input_dim)
+        self.hidden_layer_dims = [int(h) for h in hidden_layer_dims]
+        self.output_units = int(output_units)
+        self.activation = _act_code(activation)
+        self.use_batch_norm = bool(use_batch_norm)
+        self.momentum = float(batch_norm_moment)
+        self.weights = nn.ParameterList()
+        self.biases = nn.ParameterList()
+        self.gammas = nn.ParameterList()
+        self.betas = nn.ParameterList()
+        self._mm, self._mv = [], []
+        width = self.input_dim
+        for i, h in enumerate(self.hidden_layer_dims):
+            w = torch.empty(h, width)
+            nn.init.xavier_uniform_(w)                      # Keras Dense: glorot_uniform, zero bias
+            self.weights.append(nn.Parameter(w))
+            self.biases.append(nn.Parameter(torch.zeros(h)))
+            if self.use_batch_norm:
+                self.gammas.append(nn.Parameter(torch.ones(h)))
+                self.betas.append(nn.Parameter(torch.zeros(h)))
+                self.register_buffer('moving_mean_%d' % i, torch.zeros(h))
+                self.register_buffer('moving_var_%d' % i, torch.ones(h))
+            width = h
+        w = torch.empty(self.output_units, width)
+        nn.init.xavier_uniform_(w)
+        self.out_weight = nn.Parameter(w)
+        self.out_bias = nn.Parameter(torch.zeros(self.output_units))
+
+    @property
+    def moving_mean(self):
+        return [getattr(self, 'moving_mean_%d' % i) for i in range(len(self.hidden_layer_dims))]
+
+    @property
+    def moving_var(self):
+        return [getattr(self, 'moving_var_%d' % i) for i in range(len(self.hidden_layer_dims))]
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 2 or x.shape[1] not in (self.input_dim, T.pad8(self.input_dim)):
+            raise ValueError('expected [M, %d] features, got %s' % (self.input_dim, tuple(x.shape)))
+        params = list(self.weights) + list(self.biases)
+        if self.use_batch_norm:
+            params += list(self.gammas) + list(self.betas)
+        params += [self.out_weight, self.out_bias]
+        return _TowerFn.apply(x, self, self.training, *params)

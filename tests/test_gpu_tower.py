@@ -1,0 +1,235 @@
+"""GPU tests of the scorer-tower kernels (ranking_amd/csrc/tower.hip) through the
+C ABI against a plain fp32 torch reference of the same op on the same bf16-rounded
+operands.  Tolerance: the kernels accumulate bf16 products in fp32 (MFMA) and write
+bf16, so |delta| <= 1 bf16 ulp of the result (2^-8 relative) + 1e-3 absolute
+(accumulation order); fp32 outputs (statistics, logits) 2e-3 relative to the column
+scale."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def T():
+    from ranking_amd import _tower_ops
+    return _tower_ops
+
+
+def bf16_close(got, want, what=''):
+    got = got.float().cpu()
+    want = want.float().cpu()
+    err = (got - want).abs()
+    lim = want.abs() * 2.0 ** -7 + 2e-3 * max(1.0, want.abs().max().item()) * 0.5
+    assert bool((err <= lim).all()), '%s: max err %.4e at %s (want %.5f got %.5f)' % (
+        what, err.max().item(), tuple(torch.nonzero(err == err.max())[0].tolist()),
+        want.flatten()[err.argmax()].item(), got.flatten()[err.argmax()].item())
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize('M,F', [(1, 8), (5, 136), (300, 137), (1000, 3)])
+def test_cast_rows(M, F):
+    x = rnd((M, F), 1).to(DEV)
+    out = T().cast_rows(x)
+    Kp = (F + 7) // 8 * 8
+    assert out.shape == (M, Kp) and out.dtype == torch.bfloat16
+    assert torch.equal(out[:, :F], x.to(torch.bfloat16))
+    assert bool((out[:, F:] == 0).all())
+    sc, sh = rnd((F,), 2).to(DEV), rnd((F,), 3).to(DEV)
+    out2 = T().cast_rows(x, sc, sh)
+    ref = x * sc + sh
+    assert bool(((out2[:, :F].float() - ref).abs() <= ref.abs() * 2.0 ** -7 + 1e-6).all())
+
+
+def test_cast_weight():
+    w = rnd((132, 136), 4).to(DEV)
+    a = T().cast_weight(w)
+    assert torch.equal(a, w.to(torch.bfloat16))
+    b = T().cast_weight(w, transpose=True)
+    assert b.shape == (136, 136)
+    assert torch.equal(b[:, :132], w.t().contiguous().to(torch.bfloat16))
+    assert bool((b[:, 132:] == 0).all())
+
+
+@pytest.mark.parametrize('M,N,K', [(1, 8, 8), (128, 128, 64), (300, 136, 136), (257, 512, 512), (1000, 128, 200),
+                                   (129, 520, 72)])
+@pytest.mark.parametrize('pro', [0, 1, 2])
+def test_gemm_forward_modes(M, N, K, pro):
+    t = T()
+    A = rnd((M, K), 10 + M).to(DEV).to(torch.bfloat16)
+    W = rnd((N, K), 11 + N, 0.1).to(DEV).to(torch.bfloat16)
+    bias = rnd((N,), 12).to(DEV)
+    sc = (rnd((K,), 13) * 0.5 + 1.0).to(DEV)
+    sh = rnd((K,), 14, 0.3).to(DEV)
+    # asymmetric operands: row / column dependent offsets catch swapped fragment maps
+    A = (A.float() + torch.arange(M, device=DEV).unsqueeze(1) % 7 * 0.125).to(torch.bfloat16)
+    W = (W.float() + torch.arange(N, device=DEV).unsqueeze(1) % 5 * 0.0625).to(torch.bfloat16)
+    a = A.float()
+    if pro >= 1:
+        a = a * sc + sh
+    if pro == 2:
+        a = torch.relu(a)
+    a = a.to(torch.bfloat16).float() if pro else a
+    want = a @ W.float().t() + bias
+    C, stats = t.gemm(A, W, N, K, prologue=pro, a_scale=sc if pro else None, a_shift=sh if pro else None,
+                      bias=bias, epilogue=t.EPI_STATS)
+    bf16_close(C, want, 'C')
+    assert stats.shape == (t.stats_rows(M), 2, N)
+    s = stats.sum(dim=0)
+    lim = 2e-3 * max(1.0, want.abs().max().item())
+    assert (s[0] - want.sum(dim=0)).abs().max().item() <= lim * M ** 0.5 + 1e-2
+    assert (s[1] - (want * want).sum(dim=0)).abs().max().item() <= 4e-3 * (want * want).sum(dim=0).max().item() + 1e-2
+    C2, none = t.gemm(A, W, N, K, prologue=pro, a_scale=sc if pro else None, a_shift=sh if pro else None,
+                      bias=None, epilogue=t.EPI_PLAIN)
+    assert none is None
+    bf16_close(C2, want - bias, 'C (plain)')
+
+
+def test_bn_finalize_and_out_layer():
+    t = T()
+    M, K, O = 1000, 512, 2
+    z = (rnd((M, K), 20) * 2.0 + 0.7).to(DEV).to(torch.bfloat16)
+    zf = z.float()
+    partial = torch.stack([torch.stack([zf[i:i + 128].sum(0), (zf[i:i + 128] ** 2).sum(0)]) for i in range(0, M, 128)])
+    gamma = (rnd((K,), 21) * 0.2 + 1.0).to(DEV)
+    beta = rnd((K,), 22, 0.1).to(DEV)
+    mm = torch.zeros(K, device=DEV); mv = torch.ones(K, device=DEV)
+    scale, shift, mean, rstd = t.bn_finalize(partial.contiguous(), M, gamma, beta, 1e-3, 0.9, mm, mv)
+    want_mean = zf.mean(0); want_var = zf.var(0, unbiased=False)
+    assert torch.allclose(mean, want_mean, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(rstd, torch.rsqrt(want_var + 1e-3), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(scale, gamma * torch.rsqrt(want_var + 1e-3), atol=1e-4, rtol=1e-4)
+    assert torch.allclose(shift, beta - want_mean * scale, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(mm, 0.1 * want_mean, atol=1e-5, rtol=1e-4)
+    assert torch.allclose(mv, 0.9 + 0.1 * want_var, atol=1e-5, rtol=1e-4)
+    w = rnd((O, K), 23, 0.05).to(DEV); b = rnd((O,), 24).to(DEV)
+    for pro in (0, 1, 2):
+        a = zf
+        if pro >= 1:
+            a = a * scale + shift
+        if pro == 2:
+            a = torch.relu(a)
+        want = a @ w.t() + b
+        got = t.out_layer(z, K, pro, scale, shift, w, b)
+        assert torch.allclose(got, want, atol=2e-3, rtol=1e-4), (pro, (got - want).abs().max().item())
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 128, 128), (1, 8, 8), (300, 136, 512), (1000, 512, 136), (4097, 264, 200)])
+@pytest.mark.parametrize('pro', [0, 2])
+def test_wgrad(M, N, K, pro):
+    t = T()
+    dz = (rnd((M, N), 30 + M, 0.5).to(DEV) + (torch.arange(N, device=DEV) % 5) * 0.125).to(torch.bfloat16)
+    A = (rnd((M, K), 31 + K).to(DEV) + (torch.arange(M, device=DEV).unsqueeze(1) % 3) * 0.25).to(torch.bfloat16)
+    sc = (rnd((K,), 32) * 0.5 + 1.0).to(DEV); sh = rnd((K,), 33, 0.3).to(DEV)
+    a = A.float()
+    if pro:
+        a = torch.relu(a * sc + sh).to(torch.bfloat16).float()
+    want = dz.float().t() @ a
+    for splits in (0, 1, 3):
+        got = t.wgrad(dz, A, N, K, prologue=pro, a_scale=sc if pro else None, a_shift=sh if pro else None,
+                      splits=splits)
+        err = (got - want).abs().max().item()
+        assert err <= 2e-3 * max(1.0, want.abs().max().item()), (splits, err, want.abs().max().item())
+
+
+def test_out_layer_bwd_and_bn_apply():
+    t = T()
+    M, K, O = 1000, 264, 2
+    z = (rnd((M, K), 40) * 1.5 + 0.2).to(DEV).to(torch.bfloat16)
+    zf = z.float()
+    sc = (rnd((K,), 41) * 0.3 + 1.0).to(DEV); sh = rnd((K,), 42, 0.4).to(DEV)
+    mean = zf.mean(0); rstd = torch.rsqrt(zf.var(0, unbiased=False) + 1e-3)
+    w = rnd((O, K), 43, 0.2).to(DEV); dl = rnd((M, O), 44).to(DEV)
+    for pro in (0, 2):
+        y = zf * sc + sh if pro else zf
+        a = torch.relu(y) if pro == 2 else y
+        da = dl @ w
+        dy_want = da * (y > 0) if pro == 2 else da
+        dy, sums = t.out_layer_bwd(z, K, pro, sc if pro else None, sh if pro else None, mean, rstd, w, dl, n_blocks=7)
+        bf16_close(dy, dy_want, 'dy')
+        zhat = (zf - mean) * rstd
+        tol = 2e-3 * M ** 0.5
+        assert (sums[0] - dy_want.sum(0)).abs().max().item() <= tol
+        assert (sums[1] - (dy_want * zhat).sum(0)).abs().max().item() <= tol * 3
+        assert (sums[2:] - dl.t() @ a).abs().max().item() <= tol * 3
+    pqr = torch.stack([sc, sh * 0.1, rnd((K,), 45, 0.01).to(DEV)])
+    dy0 = rnd((M, K), 46).to(DEV).to(torch.bfloat16)
+    want = pqr[0] * dy0.float() + pqr[1] * zf + pqr[2]
+    got = t.bn_bwd_apply_(dy0.clone(), z, K, pqr)
+    bf16_close(got, want, 'dz')
+
+
+def _ste(x):
+    return x + (x.to(torch.bfloat16).float() - x).detach()
+
+
+def ref_tower(x, tower, training=True):
+    """fp32 torch restatement of create_tower with the kernel's bf16 rounding points
+    (straight-through), differentiable by autograd."""
+    a = _ste(x)
+    n_h = len(tower.hidden_layer_dims)
+    for l in range(n_h):
+        z32 = a @ _ste(tower.weights[l]).t() + tower.biases[l]
+        z = _ste(z32)
+        if tower.use_batch_norm:
+            mean = z32.mean(0); var = z32.var(0, unbiased=False)
+            y = (z - mean) * torch.rsqrt(var + 1e-3) * tower.gammas[l] + tower.betas[l]
+        else:
+            y = z
+        a = torch.relu(y) if tower.activation == 'relu' else y
+        if l < n_h - 1:
+            a = _ste(a)
+    return a @ tower.out_weight.t() + tower.out_bias
+
+
+@pytest.mark.parametrize('M,F,hidden,O,act,bn', [
+    (2000, 136, [64, 32], 1, 'relu', True),
+    (1500, 136, [512, 512, 512], 1, 'relu', True),
+    (700, 20, [128, 64], 2, None, True),
+    (900, 50, [64, 64], 1, 'relu', False),
+    (513, 16, [32], 1, None, False),
+])
+def test_fused_tower_forward_backward(M, F, hidden, O, act, bn):
+    from ranking_amd.tower import FusedTower
+    torch.manual_seed(0)
+    tower = FusedTower(F, hidden, O, activation=act, use_batch_norm=bn).to(DEV)
+    with torch.no_grad():
+        for p in list(tower.biases) + [tower.out_bias]:
+            p.normal_(0, 0.1)
+        for g in tower.gammas:
+            g.uniform_(0.5, 1.5)
+        for b in tower.betas:
+            b.normal_(0, 0.2)
+    x = rnd((M, F), 50).to(DEV)
+    up = rnd((M, O), 51).to(DEV)
+    tower.train()
+    got = tower(x)
+    got.backward(up)
+    g_got = [p.grad.clone() for p in tower.parameters()]
+    tower.zero_grad()
+    want = ref_tower(x, tower)
+    want.backward(up)
+    g_want = [p.grad.clone() for p in tower.parameters()]
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-2 * max(1.0, scale), (got - want).abs().max().item()
+    names = [n for n, _ in tower.named_parameters()]
+    # gradients that are analytically ~0 (e.g. d beta below another BatchNorm) carry the bf16
+    # rounding noise of dz: judge them against the overall gradient scale.
+    gscale = max(b.abs().max().item() for b in g_want)
+    for n, a, b in zip(names, g_got, g_want):
+        denom = b.norm().item() + 1e-6 * b.numel() ** 0.5
+        rel = (a - b).norm().item() / denom
+        assert rel <= 3e-2 or (a - b).abs().max().item() <= 2e-2 * gscale, (
+            n, rel, (a - b).abs().max().item(), denom, gscale)
+    # moving averages moved towards the batch statistics
+    if bn:
+        assert all(bool((m != 0).any()) for m in tower.moving_mean)
+    # inference mode uses the moving statistics
+    tower.eval()
+    with torch.no_grad():
+        out_eval = tower(x)
+    assert out_eval.shape == (M, O) and bool(torch.isfinite(out_eval).all())

@@ -102,9 +102,15 @@ def test_scorer_on_device_bf16_close_to_fp32():
     s16 = ra.keras.model.DNNScorer(input_dim=f, hidden_layer_dims=[512, 512, 512], output_units=1,
                                    activation=torch.relu, use_batch_norm=False, dropout=0.,
                                    compute_dtype=torch.bfloat16).to(dev)
+    lin = [m for m in s32._tower if isinstance(m, torch.nn.Linear)]
+    from ranking_amd.tower import FusedTower
+    assert isinstance(s16._tower, FusedTower)          # bf16 -> the fused MFMA tower (csrc/tower.hip)
+    with torch.no_grad():
+        for i, m in enumerate(lin[:-1]):
+            s16._tower.weights[i].copy_(m.weight); s16._tower.biases[i].copy_(m.bias)
+        s16._tower.out_weight.copy_(lin[-1].weight); s16._tower.out_bias.copy_(lin[-1].bias)
     a = s32({}, {'x': x.to(dev)}, mask.to(dev))
     bb = s16({}, {'x': x.to(dev)}, mask.to(dev))
-    lin = [m for m in s32._tower if isinstance(m, torch.nn.Linear)]
     want = R.dnn_tower(x.reshape(b * l, f), [m.weight.t().cpu() for m in lin],
                        [m.bias.cpu() for m in lin]).reshape(b, l)
     assert torch.allclose(a.cpu(), want, atol=1e-4, rtol=1e-4)                 # fp32 path vs oracle
