@@ -51,7 +51,21 @@ WORKLOADS = {
                                'L=100, SGD, 1 all-reduce/step', lambda L: 0),
     'e2e_approx_ndcg_l1000': (512, 1000, 'config 4: DNNScorer 136-512-512-512-1 bf16 + ApproxNDCGLoss, '
                                          '512 lists/GPU, L=1000, 1 all-reduce/step', lambda L: 0),
+    'e2e_groupwise_gumbel': (512, 50, 'config 5: groupwise scorer (group_size=2) 272-512-512-512-2 bf16 + '
+                                      'GumbelApproxNDCGLoss(S=8), 512 lists/GPU, L=50, 1 all-reduce/step',
+                             lambda L: 0),
 }
+
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
+
+
+def e2e_flops_per_list(workload, L):
+    """Algorithmic scorer flops per list, fwd + bwd (3 x 2 x MACs)."""
+    if workload == 'e2e_groupwise_gumbel':
+        macs = 272 * 512 + 512 * 512 * 2 + 512 * 2          # per group; L groups per list
+    else:
+        macs = 136 * 512 + 512 * 512 * 2 + 512              # per document
+    return 6.0 * macs * L
 
 
 def make_inputs(B, L, seed, device):
@@ -98,19 +112,36 @@ def build_e2e_step(workload, labels):
     feats = torch.rand((B, L, 136), generator=g, device=dev) * 2 - 1
     mask = labels >= 0
     torch.manual_seed(0)                                  # identical replicas on every rank
-    scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
-                                      activation=torch.relu, use_batch_norm=True, dropout=0.0,
-                                      compute_dtype=torch.bfloat16).to(dev)
+    if workload == 'e2e_groupwise_gumbel':
+        from ranking_amd import model as gmodel
+        tower = ra.keras.layers.create_tower([512, 512, 512], 2, activation=torch.relu, use_batch_norm=True,
+                                             dropout=0.0, input_dim=272, compute_dtype=torch.bfloat16)
+
+        def group_score_fn(ctx, group_features):
+            x = group_features['x']
+            return tower(x.reshape(x.shape[0], -1))
+        gw = gmodel.GroupwiseScorer(group_score_fn, group_size=2).to(dev)
+        gw.add_module('tower', tower)
+        gw.to(dev)
+        scorer = gw
+        run_scorer = lambda: gw({}, {'x': feats}, mask)
+        loss = ra.keras.losses.GumbelApproxNDCGLoss(seed=1)
+    else:
+        scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
+                                          activation=torch.relu, use_batch_norm=True, dropout=0.0,
+                                          compute_dtype=torch.bfloat16).to(dev)
+        run_scorer = lambda: scorer({}, {'x': feats}, mask)
+        loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
+    scorer.train()
     bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
     lr = 0.01
-    loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
     _, world = D.world()
     params = [p for p in scorer.parameters() if p.requires_grad]
     flat_params = None
 
     def step():
         bucket.zero()
-        logits = scorer({}, {'x': feats}, mask)
+        logits = run_scorer()
         value, dlogits = loss.loss_and_grad(labels, logits.detach())
         logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
         s = bucket.all_reduce(torch.stack([value, value.new_tensor(1.0)]), average=True)
@@ -275,6 +306,15 @@ def main():
         }
         n_valid_sq = float(((labels >= 0).sum(dim=1).double() ** 2).sum().item())
         result['roofline']['pairs_per_s'] = 2.0 * n_valid_sq / (kernel_ms * 1e-3)   # fwd + bwd evaluations
+    if args.workload.startswith('e2e_'):
+        tflops = e2e_flops_per_list(args.workload, L) * B * world / (elapsed / args.steps) / 1e12
+        result['dtype'] = 'bf16'
+        result['roofline'] = {
+            'bound': 'mfma', 'achieved': tflops / world, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tflops / world / MFMA_PEAK_TFLOPS, 'traffic': None,
+            'kernel': 'whole training step (tower_gemm_kernel / tower_wgrad_kernel dominate; profiles/)',
+            'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / step time, per GPU; the [M,512] layers '
+                    'are HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
     if not args.no_cpu_baseline:
         cb = cpu_baseline(args.workload, L)
         if cb is not None:

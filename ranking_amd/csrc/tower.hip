@@ -593,7 +593,7 @@ struct WgradArgs {
   const uint16_t* A; long lda;       // [M, K] (pre-BN z of the layer below when PRO != 0)
   const float* a_scale; const float* a_shift;
   float* slab; long ldw;             // [splits][N][ldw]
-  int M, N, K, rows_per_split;
+  int M, N, K, rows_per_split, splits, tiles_n, tiles_k;
 };
 
 // byte offset of 16-byte chunk cc (0..15) of row r in a swizzled [64][128] bf16 tile
@@ -611,7 +611,12 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
-  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128, split = blockIdx.z;
+  // XCD-aware map: the tiles_n * tiles_k output tiles of one M-slice run on ONE XCD at about
+  // the same time, so each dz / A row block is fetched from HBM once and re-read from that L2.
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3, tiles = g.tiles_n * g.tiles_k;
+  const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;
+  if (split >= g.splits) return;
+  const int n0 = (tile % g.tiles_n) * 128, k0 = (tile / g.tiles_n) * 128;
   const long ms = (long)split * g.rows_per_split;
   const long me = (ms + g.rows_per_split < g.M) ? ms + g.rows_per_split : g.M;
   const int steps = (int)((me - ms + 63) / 64);
@@ -880,7 +885,8 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
   g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
   int rows = (int)(((long)M + splits - 1) / splits);
   g.rows_per_split = (rows + 63) / 64 * 64;
-  const dim3 grid((N + 127) / 128, (K + 127) / 128, splits);
+  g.splits = splits; g.tiles_n = (N + 127) / 128; g.tiles_k = (K + 127) / 128;
+  const dim3 grid((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
   hipStream_t st = (hipStream_t)stream;
 #define WG(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad_kernel<P>, grid, dim3(256), 65536, st, g); } while (0)
   if (prologue == PRO_NONE) WG(PRO_NONE); else if (prologue == PRO_AFFINE) WG(PRO_AFFINE); else WG(PRO_AFFINE_RELU);
