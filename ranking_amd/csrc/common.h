@@ -148,4 +148,64 @@ __device__ __forceinline__ float exp_df(float t_hi, float t_lo) {
   return ldexpf(exp2f(f), (int)n);
 }
 
+
+// ---------------------------------------------------------------- wave-per-list helpers
+// Bitonic sort, DESCENDING, of 64*IPL keys held in registers: element e = lane + 64*r
+// lives in a[r] of `lane`.  No LDS, no barriers (cross-lane exchanges are wave shuffles).
+template <typename K, int IPL>
+__device__ __forceinline__ void wave_bitonic_sort_desc(K (&a)[IPL], int lane) {
+  constexpr int N = 64 * IPL;
+#pragma unroll
+  for (int kk = 2; kk <= N; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          if ((r & jr) == 0) {
+            const int r2 = r | jr;
+            const bool desc = (((r << 6) & kk) == 0);
+            const K hi = a[r] > a[r2] ? a[r] : a[r2];
+            const K lo = a[r] > a[r2] ? a[r2] : a[r];
+            a[r] = desc ? hi : lo;
+            a[r2] = desc ? lo : hi;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const K p = __shfl_xor(a[r], j, 64);
+          const int e = lane | (r << 6);
+          const bool desc = ((e & kk) == 0);
+          const bool lower = ((lane & j) == 0);
+          const K mx = a[r] > p ? a[r] : p;
+          const K mn = a[r] > p ? p : a[r];
+          a[r] = (lower == desc) ? mx : mn;
+        }
+      }
+    }
+  }
+}
+
+// tree_sum (see block_tree_sum) of P = pow2 >= L values laid out e = lane + 64*r, zero padded:
+// bit-identical pairing to the LDS version.  Every lane returns the sum.
+template <int IPL>
+__device__ __forceinline__ float wave_tree_sum(float (&t)[IPL], int P) {
+#pragma unroll
+  for (int hr = IPL >> 1; hr >= 1; hr >>= 1) {        // h = 64 * hr >= 64: register-level folds
+    if (64 * hr * 2 <= P) {
+#pragma unroll
+      for (int r = 0; r < hr; ++r) t[r] = t[r] + t[r + hr];
+    }
+  }
+  float v = t[0];
+#pragma unroll
+  for (int h = 32; h >= 1; h >>= 1) {
+    const float o = __shfl_down(v, h, 64);
+    if (2 * h <= P) v = v + o;                           // lanes >= h hold don't-care values
+  }
+  return __shfl(v, 0, 64);
+}
+
 }  // namespace tfr

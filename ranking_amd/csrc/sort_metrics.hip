@@ -8,6 +8,8 @@
 #include "common.h"
 #include "../../include/tfr_hip.h"
 
+#include <stdlib.h>
+
 using namespace tfr;
 
 namespace {
@@ -151,6 +153,180 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
   }
 }
 
+// ===========================================================================
+// Wave-per-list variants (L <= 64 * IPL <= 1024): one wavefront owns a list, the
+// packed 64-bit keys live in registers and are ordered by an in-register bitonic
+// network (wave shuffles), the fixed-order tree sums run on registers + shuffles:
+// no workgroup barriers at all.  Bit-identical to the workgroup kernels above.
+// ===========================================================================
+template <int IPL>
+__global__ __launch_bounds__(64) void sort_ranks_wave_kernel(const float* __restrict__ scores,
+                                                             const float* __restrict__ labels,
+                                                             const uint8_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ tiebreak, int L,
+                                                             int32_t* __restrict__ ranks_out,
+                                                             int32_t* __restrict__ order_out) {
+  const int lane = threadIdx.x;
+  const size_t base = (size_t)blockIdx.x * L;
+  uint64_t key[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    key[r] = 0;
+    if (i < L) {
+      const bool v = item_valid(labels, mask, base + i);
+      key[r] = make_sort_key(v, scores[base + i], tiebreak ? tiebreak[base + i] : 0, i);
+    }
+  }
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    if (p < L) {
+      const int idx = sort_key_index(key[r]);
+      if (order_out) order_out[base + p] = idx;
+      if (ranks_out) ranks_out[base + idx] = p + 1;
+    }
+  }
+}
+
+template <int KIND, int IPL>
+__global__ __launch_bounds__(64) void rank_metric_wave_kernel(
+    const float* __restrict__ labels, const float* __restrict__ predictions, const float* __restrict__ weights,
+    int weights_per_list, const uint8_t* __restrict__ mask, const float* __restrict__ gains,
+    const float* __restrict__ discount, TopN topn, int B, int L, int P, float* __restrict__ metric_out,
+    float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* WG = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] w * gain by original index
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  // ---- _prepare_and_validate_params (metrics_impl.py:228-266)
+  float w[IPL], g[IPL], wg[IPL];
+  bool m[IPL];
+  uint64_t key[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    w[r] = 0.f; g[r] = 0.f; m[r] = false; key[r] = 0;
+    if (i < L) {
+      const float lab = labels[base + i];
+      w[r] = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      m[r] = v0 && (w[r] > 0.0f);
+      const float labc = m[r] ? lab : 0.0f;
+      if (KIND == 0) g[r] = gains ? gains[base + i] : gain_pow2m1(labc);
+      else g[r] = (labc >= 1.0f) ? 1.0f : 0.0f;
+      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+    }
+    wg[r] = w[r] * g[r];
+    WG[i] = (KIND == 0) ? wg[r] : g[r];
+  }
+  // ---- per-list weight statistics, tree_sum order over the original index.
+  {
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = w[r];
+    const float s_w = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = g[r];
+    const float s_g = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = wg[r];
+    const float s_wg = wave_tree_sum<IPL>(t, P);
+    if (lane == 0) {
+      stats_out[(size_t)b * 3 + 0] = s_w;
+      stats_out[(size_t)b * 3 + 1] = s_g;
+      stats_out[(size_t)b * 3 + 2] = s_wg;
+    }
+  }
+  __syncthreads();                                      // WG visible (single wave: a waitcnt)
+
+  if (KIND == 1) {
+    // MRR (metrics_impl.py:443-459): position of the first relevant item in the order
+    // "prediction descending, masked last" = number of keys above the best relevant key
+    // (keys are unique: they end in the item index) -- no sort needed.
+    uint64_t best = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r)
+      if (g[r] > 0.0f && key[r] > best) best = key[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t other = __shfl_xor(best, o, 64);
+      best = other > best ? other : best;
+    }
+    int above = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) above += __popcll(__ballot(key[r] > best));
+    const float pmin = (best != 0) ? (float)above : INFINITY;
+    if (lane == 0) {
+      for (int q = 0; q < topn.n; ++q) {
+        const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+        metric_out[(size_t)q * B + b] = (pmin < (float)k) ? (1.0f / (pmin + 1.0f)) : 0.0f;
+      }
+    }
+    return;
+  }
+
+  // ---- sort by prediction (masked entries last): utils.py:115-164.
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+
+  // ---- DCG terms in sorted order: (w * gain) * discount(rank)  (:122-151)
+  float term[IPL], dcg[TFR_MAX_TOPN];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    term[r] = (p < L) ? WG[sort_key_index(key[r])] * discount[p] : 0.0f;
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? term[r] : 0.0f;
+    dcg[q] = wave_tree_sum<IPL>(t, P);
+  }
+  // ---- ideal ordering: sort by weighted gain (metrics_impl.py:660-666)
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    key[r] = (i < L) ? make_sort_key(m[r], wg[r], 0, i) : 0ull;
+  }
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    term[r] = (p < L) ? WG[sort_key_index(key[r])] * discount[p] : 0.0f;
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? term[r] : 0.0f;
+    const float idcg = wave_tree_sum<IPL>(t, P);
+    if (lane == 0) metric_out[(size_t)q * B + b] = (idcg != 0.0f) ? (dcg[q] / idcg) : 0.0f;   // divide_no_nan
+  }
+}
+
+template <int KIND, int IPL>
+void launch_metric_wave(const float* labels, const float* predictions, const float* weights, int weights_per_list,
+                        const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
+                        int L, int P, float* metric_out, float* stats_out, hipStream_t st) {
+  hipLaunchKernelGGL((rank_metric_wave_kernel<KIND, IPL>), dim3(B), dim3(64), (size_t)64 * IPL * sizeof(float), st,
+                     labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P,
+                     metric_out, stats_out);
+}
+
+template <int KIND>
+void dispatch_metric_wave(int L, const float* labels, const float* predictions, const float* weights,
+                          int weights_per_list, const uint8_t* mask, const float* gains, const float* discount,
+                          const TopN& tn, int B, int P, float* metric_out, float* stats_out, hipStream_t st) {
+#define MW(I) launch_metric_wave<KIND, I>(labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out, st)
+  if (L <= 64) MW(1); else if (L <= 128) MW(2); else if (L <= 256) MW(4);
+  else if (KIND == 0) { if (L <= 512) MW(8); else MW(16); }
+#undef MW
+}
+
 inline int block_threads_for(int P) {
   int t = P / 2;
   if (t < 64) t = 64;
@@ -169,6 +345,14 @@ extern "C" int tfr_sort_ranks_f32(const float* scores, const float* labels, cons
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   const int P = pow2_ceil(L < 2 ? 2 : L);
+  static const int env_wave = [] { const char* e = getenv("TFR_SORT_WAVE"); return (e && *e) ? atoi(e) : 1; }();
+  if (env_wave && L <= 1024 && (L <= 256 || B >= 1024)) {
+    hipStream_t st = (hipStream_t)stream;
+#define SW(I) hipLaunchKernelGGL(sort_ranks_wave_kernel<I>, dim3(B), dim3(64), 0, st, scores, labels, mask, tiebreak, L, ranks_out, order_out)
+    if (L <= 64) SW(1); else if (L <= 128) SW(2); else if (L <= 256) SW(4); else if (L <= 512) SW(8); else SW(16);
+#undef SW
+    return (int)hipGetLastError();
+  }
   const int T = block_threads_for(P);
   hipLaunchKernelGGL(sort_ranks_kernel, dim3(B), dim3(T), (size_t)P * sizeof(uint64_t),
                      (hipStream_t)stream, scores, labels, mask, tiebreak, L, P, ranks_out, order_out);
@@ -187,6 +371,13 @@ static int launch_metric(int kind, const float* labels, const float* predictions
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
+  static const int env_wave = [] { const char* e = getenv("TFR_SORT_WAVE"); return (e && *e) ? atoi(e) : 1; }();
+  // (the MRR wave kernel is only instantiated usefully up to IPL = 4: hipcc spills the IPL >= 8 forms)
+  if (env_wave && L <= (kind == 0 ? 1024 : 256) && (L <= 256 || B >= 1024)) {
+    if (kind == 0) dispatch_metric_wave<0>(L, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, P, metric_out, stats_out, (hipStream_t)stream);
+    else dispatch_metric_wave<1>(L, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, P, metric_out, stats_out, (hipStream_t)stream);
+    return (int)hipGetLastError();
+  }
   const int T = block_threads_for(P);
   const size_t lds = 128 + (size_t)P * (sizeof(uint64_t) + 4 * sizeof(float) + 1) + 16;
   if (kind == 0)

@@ -51,7 +51,7 @@ SHAPES = [(1, 1), (3, 2), (4, 7), (5, 50), (8, 64), (6, 65), (7, 200), (3, 257),
 
 
 # ------------------------------------------------------------------ sort / ranks
-@pytest.mark.parametrize('B,L', SHAPES + [(2, 2048), (1, 5000)])
+@pytest.mark.parametrize('B,L', SHAPES + [(2, 2048), (1, 5000), (1100, 300), (1024, 700)])
 def test_sort_ranks_bit_exact(B, L):
     labels, logits = make_batch(B, L, seed=11 + L)
     mask = labels >= 0
@@ -92,7 +92,7 @@ def test_sort_reference_goldens():
 
 
 # ---------------------------------------------------------------------- metrics
-@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (1024, 700)])   # the last two: wave kernels, IPL 8 / 16
 @pytest.mark.parametrize('weighted', [False, True])
 def test_ndcg_mrr_bit_exact(B, L, weighted):
     labels, preds = make_batch(B, L, seed=100 + L)
