@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
+PROF_LIB_PATH = os.path.join(CSRC, 'libtfr_hip_prof.so')     # developer aid: -DTFR_PROFILE_STAMPS build
 SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                '-fvisibility=default']
@@ -104,6 +105,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise TfrHipError('hipcc failed:\n%s\n%s' % (res.stdout, res.stderr))
         os.replace(LIB_PATH + '.tmp', LIB_PATH)
         return LIB_PATH
+
+
+def build_profiling(verbose: bool = False) -> str:
+    """Developer aid: the same sources with -DTFR_PROFILE_STAMPS (in-kernel s_memtime stamps);
+    used by tools/phase_profile.py only, never by the product path."""
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    srcs = [os.path.join(CSRC, s) for s in sources_present()]
+    cmd = [hipcc] + HIPCC_FLAGS + ['-DTFR_PROFILE_STAMPS', '-I', INCLUDE] + srcs + ['-o', PROF_LIB_PATH]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise TfrHipError('hipcc failed:\n%s\n%s' % (res.stdout, res.stderr))
+    return PROF_LIB_PATH
 
 
 def load():

@@ -184,7 +184,9 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
 def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
-                      want_grad=True, want_rows=True):
+                      want_grad=True, want_rows=True, want_aux=True):
+    """want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
+    SUM_BY_NONZERO_WEIGHTS reductions and compute_per_list need them): a leaner kernel variant."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); item_weights = _f32(item_weights, 'item_weights')
@@ -193,8 +195,8 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
     B, L = logits.shape
     dev = logits.device
     row_loss = torch.empty((B, L), dtype=torch.float32, device=dev) if want_rows else None
-    row_weight = torch.empty((B, L), dtype=torch.float32, device=dev) if want_rows else None
-    nnz = torch.empty((B,), dtype=torch.float32, device=dev)
+    row_weight = torch.empty((B, L), dtype=torch.float32, device=dev) if (want_rows and want_aux) else None
+    nnz = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
     rc = _lib.load().tfr_pairwise_logistic_f32(
         _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),

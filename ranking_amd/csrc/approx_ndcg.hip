@@ -338,12 +338,21 @@ __device__ __forceinline__ float exp_df_fast(float t_hi, float t_lo) {
   return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
+// Developer aid (never in the product build): -DTFR_PROFILE_STAMPS makes lane 0 record
+// s_memtime at the phase boundaries into a buffer set with tfr_prof_set_buffer().
+#ifdef TFR_PROFILE_STAMPS
+__device__ unsigned long long* g_prof_buf = nullptr;
+#define TFR_STAMP(i) do { if (lane == 0) prof_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TFR_STAMP(i) do { } while (0)
+#endif
+
 template <int IPL>
 __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
     float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
-    float* __restrict__ dlogits_out) {
+    float* __restrict__ dlogits_out, int max_runs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
   float* E = X + Lp;                               // [Lp] exp(x - m)
@@ -355,6 +364,10 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   const int b = blockIdx.x;
   const size_t base = (size_t)b * L;
   constexpr float kLn2 = 0.69314718055994530942f;
+#ifdef TFR_PROFILE_STAMPS
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  TFR_STAMP(0);
 
   // ---- 1. load + clean; label / logit statistics (wave reductions).
   float x[IPL], g[IPL];
@@ -373,10 +386,11 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       if (v[r]) { xmin = fminf(xmin, x[r]); xmax = fmaxf(xmax, x[r]); }
     }
   }
-  lmax = wmax(lmax); lsum = wsum(lsum); xmin = wmin(xmin); xmax = wmax(xmax);
+  lmax = wave_max_u(lmax); lsum = wave_sum_u(lsum); xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
   const bool nonzero = lsum > 0.0f;
   if (!nonzero) lmax = 1e-10f;
 
+  TFR_STAMP(1);
   // ---- 2. gains, ideal DCG through an in-register bitonic sort.
   const float g0 = exp2f(-lmax);
   uint32_t sk[IPL];
@@ -388,16 +402,23 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     g[r] = gg;
     sk[r] = __float_as_uint(gg);
   }
-  wave_sort_desc<IPL>(sk, lane);
   float idcg = 0.f;
+  {
+    float tbl[IPL];
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) {
-    const int e = lane + 64 * r;
-    if (e < L) idcg += __uint_as_float(sk[r]) * inv_log1p[e];
+    for (int r = 0; r < IPL; ++r) tbl[r] = (lane + 64 * r < L) ? inv_log1p[lane + 64 * r] : 0.0f;
+    // graded labels: a handful of distinct gains -> run-length form, no sort
+    if (!wave_sorted_dot_runs<IPL>(g, tbl, lane, L, max_runs, idcg)) {
+      wave_sort_desc<IPL>(sk, lane);
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) t += __uint_as_float(sk[r]) * tbl[r];
+      idcg = wsum(t);
+    }
   }
-  idcg = wsum(idcg);
   const float inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
 
+  TFR_STAMP(2);
   // ---- 3. stable compaction of valid items into LDS (order = original index).
   int n = 0;
 #pragma unroll
@@ -429,6 +450,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   }
   __syncthreads();
 
+  TFR_STAMP(3);
   // ---- 4. ranks + loss terms.  Row = C adjacent lanes; 64/C rows per pass.
   const int rows_per_pass = 64 / C;
   const int c = lane % C, rsub = lane / C;
@@ -462,11 +484,12 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       A[row] = (gg * inv_max_dcg) * ilr * ilr * fast_rcp(1.0f + r);   // not read until step 5
     }
   }
-  dcg = wsum(dcg);
+  dcg = wave_sum_u(dcg);
   if (lane == 0) {
     loss_out[b] = -(dcg * inv_max_dcg);
     weight_out[b] = nonzero ? 1.0f : 0.0f;
   }
+  TFR_STAMP(4);
   if (!dlogits_out) return;
   __syncthreads();
 
@@ -513,7 +536,17 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (active && c == 0) dlogits_out[base + CI[row]] = acc * gscale;
   }
+  TFR_STAMP(5);
+#ifdef TFR_PROFILE_STAMPS
+  if (lane == 0 && g_prof_buf) {
+    prof_t[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    prof_t[7] = (unsigned long long)n;
+    for (int i = 0; i < 8; ++i) g_prof_buf[(size_t)b * 8 + i] = prof_t[i];
+  }
+#endif
 }
+
+int env_int(const char* name, int dflt);
 
 template <int IPL>
 int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
@@ -521,8 +554,9 @@ int launch_wave(const float* logits, const float* labels, const uint8_t* mask, c
                 float* weight_out, float* dlogits_out, hipStream_t stream) {
   const int Lp = ((L + 3) / 4) * 4 + 4;
   const size_t lds = (size_t)Lp * 4 * 6;
+  static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
-                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out);
+                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs);
   return (int)hipGetLastError();
 }
 
@@ -574,3 +608,10 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
                      dlogits_out);
   return (int)hipGetLastError();
 }
+
+#ifdef TFR_PROFILE_STAMPS
+extern "C" int tfr_prof_set_buffer(void* device_u64_buffer) {
+  unsigned long long* p = (unsigned long long*)device_u64_buffer;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf), &p, sizeof(p));
+}
+#endif

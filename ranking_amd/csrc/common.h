@@ -208,4 +208,74 @@ __device__ __forceinline__ float wave_tree_sum(float (&t)[IPL], int P) {
   return __shfl(v, 0, 64);
 }
 
+// Wave-wide reductions on the DPP network (no LDS traffic, unlike __shfl_xor which lowers to
+// ds_bpermute): 4 row_shr steps inside each 16-lane row, row_bcast:15 / row_bcast:31 across
+// rows, result read from lane 63 into an SGPR (wave-uniform return value).
+#define TFR_DPP_F(old, src, ctrl, rmask, bmask, bc)                                                   \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)),        \
+                                                        __builtin_bit_cast(int, (float)(src)), ctrl,  \
+                                                        rmask, bmask, bc))
+__device__ __forceinline__ float wave_max_u(float v) {
+  const float ninf = -INFINITY;
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x111, 0xf, 0xf, false));
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x112, 0xf, 0xf, false));
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x114, 0xf, 0xf, false));
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x118, 0xf, 0xf, false));
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x142, 0xa, 0xf, false));
+  v = fmaxf(v, TFR_DPP_F(ninf, v, 0x143, 0xc, 0xf, false));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_min_u(float v) { return -wave_max_u(-v); }
+__device__ __forceinline__ float wave_sum_u(float v) {
+  v += TFR_DPP_F(0.f, v, 0x111, 0xf, 0xf, true);
+  v += TFR_DPP_F(0.f, v, 0x112, 0xf, 0xf, true);
+  v += TFR_DPP_F(0.f, v, 0x114, 0xf, 0xf, true);
+  v += TFR_DPP_F(0.f, v, 0x118, 0xf, 0xf, true);
+  v += TFR_DPP_F(0.f, v, 0x142, 0xa, 0xf, false);
+  v += TFR_DPP_F(0.f, v, 0x143, 0xc, 0xf, false);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// sum_p sorted_desc(g)[p] * table[p] for NON-NEGATIVE g (element e = lane + 64*r, zero beyond
+// L) without sorting: the sorted sequence is a few runs of equal values, so repeatedly take the
+// largest remaining value v, its multiplicity c, and add v * sum(table[pos .. pos + c)).  Graded
+// relevance labels have a handful of distinct values; returns false (result unusable) when
+// there are more than `max_runs` of them -- the caller then sorts.
+template <int IPL>
+__device__ __forceinline__ bool wave_sorted_dot_runs(const float (&g)[IPL], const float (&table)[IPL], int lane,
+                                                      int L, int max_runs, float& out) {
+  float rem[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) rem[r] = (lane + 64 * r < L) ? g[r] : -1.0f;
+  float acc = 0.f;
+  int pos = 0;
+  for (int it = 0; it < max_runs; ++it) {
+    float m = rem[0];
+#pragma unroll
+    for (int r = 1; r < IPL; ++r) m = fmaxf(m, rem[r]);
+    const float v = wave_max_u(m);
+    if (v < 0.0f) { out = acc; return true; }
+    int c = 0;
+    float part = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const bool hit = rem[r] == v;
+      c += __popcll(__ballot(hit));
+      rem[r] = hit ? -1.0f : rem[r];
+    }
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int e = lane + 64 * r;
+      part += (e >= pos && e < pos + c) ? table[r] : 0.0f;
+    }
+    acc = __builtin_fmaf(v, wave_sum_u(part), acc);
+    pos += c;
+  }
+  float m = rem[0];
+#pragma unroll
+  for (int r = 1; r < IPL; ++r) m = fmaxf(m, rem[r]);
+  if (wave_max_u(m) < 0.0f) { out = acc; return true; }
+  return false;
+}
+
 }  // namespace tfr

@@ -25,6 +25,10 @@ namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
 
+// LDS hand-off inside ONE wavefront (its lanes exchange data through the wave's private LDS
+// slice): DS operations of a wave complete in order, so draining the counter is enough.
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 struct PwArgs {
   const float* logits; const float* labels; const uint8_t* mask;
   const float* item_weights; const float* list_weights;
@@ -33,6 +37,8 @@ struct PwArgs {
   int L; int Lp; int P; float temperature; int C;
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
 };
+
+__host__ __device__ inline size_t pw_wave_lds(int Lp) { return (size_t)Lp * (16 + 16 + 8 + 4 + 4 + 4 + 4) + 16; }
 
 __host__ __device__ inline size_t pw_smem_bytes(int Lp, int P) {
   return 256 + (size_t)P * 8 + (size_t)Lp * 4 * 12 + (size_t)Lp * 2 + 32;
@@ -85,6 +91,53 @@ __device__ __forceinline__ void pair_term(const float4 ri, const float rki, cons
   acc_nz += (ww_hi != 0.0f) ? 1.0f : 0.0f;
   acc_g = __builtin_fmaf(-ww_hi, sig_hi, acc_g);
   acc_g = __builtin_fmaf(ww_lo, sig_lo, acc_g);
+}
+
+// The same term for the rank-ordered wave kernel: ranks are positions (ai, aj), the
+// rank-difference discount `u` was fetched by the caller (already multiplied by list_size when
+// !GENERIC), q = (D'(rank), label-valid flag).  AUX: the caller wants sum of weights / pair
+// counts; ITEMW: per-item weights differ (otherwise the common list weight is applied once
+// per row by the caller).  18 VALU + 3 transcendental instructions per pair in the lean form.
+template <int LAMBDA, bool GENERIC, bool AUX, bool ITEMW>
+__device__ __forceinline__ void pair_term_ranked(const float4 ri, const float2 qi, const float ai, const float4 rj,
+                                                 const float2 qj, const float aj, const float u, const float ftopn,
+                                                 const float one_minus_s, const float smooth, const float fL,
+                                                 float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
+  float wl = 1.0f;
+  if (LAMBDA == TFR_LAMBDA_DCG) {
+    if (GENERIC) {
+      const bool in_top = (ai <= ftopn) || (aj <= ftopn);
+      const float v = fabsf(qi.x - qj.x);
+      float pd = one_minus_s * u + smooth * v;
+      pd = in_top ? pd : 0.0f;
+      const float pg = (qi.y > 0.0f && qj.y > 0.0f) ? fabsf(ri.z - rj.z) : 0.0f;
+      wl = (pg * pd) * fL;
+    } else {
+      wl = fabsf(ri.z - rj.z) * u;
+    }
+  } else if (LAMBDA == TFR_LAMBDA_LABELDIFF) {
+    wl = fabsf(ri.y - rj.y);
+  }
+  const bool hi = ri.y > rj.y;            // row item preferred
+  const bool lo = rj.y > ri.y;            // column item preferred
+  const float d0 = ri.x - rj.x;
+  const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
+  const float w1 = 1.0f + e;
+  const float q = __builtin_amdgcn_rcpf(w1);
+  // relu(-d) + log1p(exp(-|d|)); fl(1 + e) costs <= 6e-8 absolute per pair, far inside 1e-5
+  const float loss = __builtin_fmaf(__builtin_amdgcn_logf(w1), kLn2, fmaxf(-d0, 0.0f));
+  const float eq = e * q;
+  const bool pos = d0 >= 0.0f;
+  const float sel = (pos == hi) ? eq : q;                          // hi: sigma(-d0), lo: sigma(+d0)
+  float ww_hi, ww_lo;
+  if (ITEMW) { ww_hi = hi ? wl * ri.w : 0.0f; ww_lo = lo ? wl * rj.w : 0.0f; }
+  else       { ww_hi = hi ? wl : 0.0f;        ww_lo = lo ? wl : 0.0f; }
+  acc_loss = __builtin_fmaf(ww_hi, loss, acc_loss);
+  if (AUX) {
+    acc_w += ww_hi;
+    acc_nz += (ww_hi != 0.0f) ? 1.0f : 0.0f;
+  }
+  acc_g = __builtin_fmaf(ww_lo - ww_hi, sel, acc_g);
 }
 
 template <int LAMBDA, bool GENERIC>
@@ -291,15 +344,25 @@ __device__ __forceinline__ void wave_sort_desc_u32(uint32_t (&a)[IPL], int lane)
   }
 }
 
-template <int IPL, int LAMBDA, bool GENERIC>
-__global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+template <int IPL, int LAMBDA, bool GENERIC, bool AUX, bool ITEMW>
+__global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
+  // blockDim.x = 64 * S: S wavefronts share one list when the batch alone cannot fill the
+  // chip.  Every wave repeats the (cheap) per-list set-up in its OWN LDS slice -- no workgroup
+  // barrier anywhere -- and sweeps rows wave, wave + S, ... of the pair matrix.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, S = blockDim.x >> 6;
+  unsigned char* smem_raw = smem_all + (size_t)wave * pw_wave_lds(a.Lp);
+  float* nz_slot = reinterpret_cast<float*>(smem_all + (size_t)S * pw_wave_lds(a.Lp));   // [S]
   const int Lp = a.Lp;
-  float4* rec0 = reinterpret_cast<float4*>(smem_raw);                  // [Lp] (x, raw label, gain, weight)
-  float2* rec1 = reinterpret_cast<float2*>(rec0 + Lp);                 // [Lp] (D'(rank), signed rank)
-  float* U = reinterpret_cast<float*>(rec1 + Lp);                      // [Lp]
-  int* CI = reinterpret_cast<int*>(U + Lp);                            // [Lp]
-  const int lane = threadIdx.x, b = blockIdx.x, L = a.L;
+  float4* rec0 = reinterpret_cast<float4*>(smem_raw);                  // [Lp] (x, raw label, gain, weight), compaction order
+  float4* recS = rec0 + Lp;                                            // [Lp] the same records in RANK order
+  float2* auxS = reinterpret_cast<float2*>(recS + Lp);                 // [Lp] (D'(rank), label-valid flag), rank order
+  float* XS = reinterpret_cast<float*>(auxS + Lp);                     // [Lp] compact x (pad -inf) for the rank count
+  float* U = XS + Lp;                                                  // [Lp] |D(m) - D(m+1)|
+  int* CI = reinterpret_cast<int*>(U + Lp);                            // [Lp] compact -> original (sign: label validity)
+  int* CIS = CI + Lp;                                                  // [Lp] rank position -> original
+  float2* rec1 = auxS;                                                 // scratch alias for the custom-gain ideal DCG
+  const int lane = threadIdx.x & 63, b = blockIdx.x, L = a.L;
   const size_t base = (size_t)b * L;
   const int topn = (a.topn <= 0 || a.topn > L) ? L : a.topn;
   const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
@@ -336,6 +399,7 @@ __global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
     if (mv[r]) {
       const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
       rec0[pos] = make_float4(x, lab, lv[r] ? g[r] : 0.0f, w);
+      XS[pos] = x;
       CI[pos] = lv[r] ? e : -e - 1;                        // sign carries label validity
     }
     n += __popcll(bal);
@@ -344,36 +408,53 @@ __global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
   // ---- 2. ideal DCG@topn of the cleaned labels (:109-134), in registers.
   float inv_max_dcg = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
-    for (int m = lane; m < Lp; m += 64)
-      U[m] = (m >= 1 && m < L) ? fabsf(a.discount[m - 1] - a.discount[m]) : 0.0f;
+    for (int m = lane; m < Lp; m += 64) {
+      const float um = (m >= 1 && m < L) ? fabsf(a.discount[m - 1] - a.discount[m]) : 0.0f;
+      U[m] = GENERIC ? um : um * (float)L;              // the final x list_size (:278) folded in
+    }
     if (a.normalized) {
       // gains of monotone gain functions sort like the labels; a custom gain_fn
       // sorts by label and carries the gain (two-key compare through a u32 pair).
       uint32_t sk[IPL];
       float idcg = 0.f;
       if (a.gain_kind != TFR_GAIN_CUSTOM) {
-#pragma unroll
-        for (int r = 0; r < IPL; ++r) sk[r] = (lane + 64 * r < L) ? float_to_ordered(g[r]) : 0u;
-        wave_sort_desc_u32<IPL>(sk, lane);
+        // built-in gains are non-negative and graded labels have a handful of distinct values:
+        // run-length form of sum_p sorted(g)[p] * D(p+1), p < topn; bitonic sort as the fallback.
+        float gc[IPL], tbl[IPL];
 #pragma unroll
         for (int r = 0; r < IPL; ++r) {
           const int e = lane + 64 * r;
-          if (e < topn) {
-            const uint32_t o = sk[r];
-            const float gv = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
-            idcg += gv * a.discount[e];
-          }
+          gc[r] = (e < L && lv[r]) ? g[r] : 0.0f;
+          tbl[r] = (e < topn) ? a.discount[e] : 0.0f;
         }
+        if (!wave_sorted_dot_runs<IPL>(gc, tbl, lane, L, 8, idcg)) {
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) sk[r] = (lane + 64 * r < L) ? float_to_ordered(g[r]) : 0u;
+          wave_sort_desc_u32<IPL>(sk, lane);
+          idcg = 0.f;
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) {
+            const int e = lane + 64 * r;
+            if (e < topn) {
+              const uint32_t o = sk[r];
+              const float gv = __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+              idcg += gv * a.discount[e];
+            }
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) idcg += __shfl_xor(idcg, o, 64);
+        }
+        inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
       } else {
         // rank of every label by counting (ties: lower index first), then scatter by rank.
         float* sl = reinterpret_cast<float*>(rec1);          // [2*Lp] scratch (rec1 is filled in step 3)
-        __syncthreads();
+        WAVE_LDS_SYNC();
 #pragma unroll
         for (int r = 0; r < IPL; ++r) {
           const int e = lane + 64 * r;
           if (e < L) { const float lab = a.labels[base + e]; sl[e] = lab >= 0.0f ? lab : 0.0f; }
         }
-        __syncthreads();
+        WAVE_LDS_SYNC();
 #pragma unroll
         for (int r = 0; r < IPL; ++r) {
           const int e = lane + 64 * r;
@@ -387,58 +468,78 @@ __global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
             if (cnt < topn) idcg += g[r] * a.discount[cnt];
           }
         }
-        __syncthreads();
-      }
+        WAVE_LDS_SYNC();
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) idcg += __shfl_xor(idcg, o, 64);
-      inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+        for (int o = 32; o > 0; o >>= 1) idcg += __shfl_xor(idcg, o, 64);
+        inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+      }
     }
   }
-  __syncthreads();
+  WAVE_LDS_SYNC();
 
-  // ---- 3. ranks by counting (valid first, score desc, ties by index) (:483-500).
+  // ---- 3. ranks by counting (valid first, score desc, ties by index) (:483-500); the
+  // records are then re-homed in RANK order so that in the sweep the rank of a column is its
+  // position and the |rank_i - rank_j| discount is an affine (data independent) LDS address.
   const int n4 = (n + 3) >> 2;
-  for (int p = n + lane; p < n4 * 4; p += 64) rec0[p] = make_float4(-INFINITY, -2.0f, 0.f, 0.f);
-  __syncthreads();
-  const float ftopn = (float)topn;
+  for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
+  WAVE_LDS_SYNC();
+  const float4* X4 = reinterpret_cast<const float4*>(XS);
   for (int p = lane; p < n; p += 64) {
-    const float xi = rec0[p].x;
+    const float4 me = rec0[p];
+    const float xi = me.x;
     int cnt = 0;
-    for (int j = 0; j < n; ++j) {
-      const float xj = rec0[j].x;
-      cnt += (xj > xi || (xj == xi && j < p)) ? 1 : 0;
+    for (int gq = 0; gq < n4; ++gq) {
+      const float4 xx = X4[gq];
+      const int j = gq * 4;
+      cnt += (xx.x > xi || (xx.x == xi && j < p)) ? 1 : 0;
+      cnt += (xx.y > xi || (xx.y == xi && j + 1 < p)) ? 1 : 0;
+      cnt += (xx.z > xi || (xx.z == xi && j + 2 < p)) ? 1 : 0;
+      cnt += (xx.w > xi || (xx.w == xi && j + 3 < p)) ? 1 : 0;
     }
-    const int rank = cnt + 1;
-    const bool lvp = CI[p] >= 0;
+    const int ci = CI[p];
     float dprime = 0.f;
+    float gz = me.z;
     if (LAMBDA == TFR_LAMBDA_DCG) {
-      dprime = (rank <= topn) ? a.discount[rank - 1] : 0.0f;
-      if (a.normalized) rec0[p].z *= inv_max_dcg;
+      dprime = (cnt < topn) ? a.discount[cnt] : 0.0f;
+      if (a.normalized) gz *= inv_max_dcg;
     }
-    rec1[p] = make_float2(dprime, lvp ? (float)rank : -(float)rank);
+    recS[cnt] = make_float4(xi, me.y, gz, me.w);
+    auxS[cnt] = make_float2(dprime, ci >= 0 ? 1.0f : 0.0f);
+    CIS[cnt] = ci >= 0 ? ci : -ci - 1;
   }
-  for (int p = n + lane; p < n4 * 4; p += 64) rec1[p] = make_float2(0.f, -1.0f);
-  __syncthreads();
-
-  // ---- 4. pair sweep: row = C adjacent lanes, 64/C rows per pass.
   const int C = a.C;
+  const int npad = ((n + 2 * C - 1) / (2 * C)) * (2 * C);            // two columns per trip per lane
+  for (int p = n + lane; p < npad && p < Lp; p += 64) {               // neutral padding: label NaN -> no pair
+    recS[p] = make_float4(0.f, NAN, 0.f, 0.f);
+    auxS[p] = make_float2(0.f, 0.0f);
+  }
+  WAVE_LDS_SYNC();
+
+  // ---- 4. pair sweep: row = C adjacent lanes, 64/C rows per pass, two columns per trip.
   const int rows_per_pass = 64 / C;
   const int c = lane % C, rsub = lane / C;
   const float fL = (float)L;
   const float one_minus_s = 1.0f - a.smooth;
+  const float ftopn = (float)topn;
   float nnz_local = 0.f;
-  for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
+  for (int row0 = wave * rows_per_pass; row0 < n; row0 += S * rows_per_pass) {
     const int row = row0 + rsub;
     const bool active = row < n;
-    float4 ri = rec0[active ? row : 0];
-    const float2 qi = rec1[active ? row : 0];
+    float4 ri = recS[active ? row : 0];
+    const float2 qi = auxS[active ? row : 0];
     if (!active) ri.y = NAN;                                   // compares false: contributes nothing
     float acc_loss = 0.f, acc_w = 0.f, acc_nz = 0.f, acc_g = 0.f;
-    for (int j = c; j < n; j += C) {
-      const float4 rj = rec0[j];
-      const float2 qj = rec1[j];
-      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, rj, qj.y, qj.x, U, ftopn, one_minus_s, a.smooth, fL,
-                                 acc_loss, acc_w, acc_nz, acc_g);
+    for (int j0 = c; j0 < npad; j0 += 2 * C) {
+      const int j1 = j0 + C;
+      const float4 r0 = recS[j0], r1 = recS[j1];
+      float u0 = 0.f, u1 = 0.f;
+      if (LAMBDA == TFR_LAMBDA_DCG) { const int rc = active ? row : 0; u0 = U[abs(rc - j0)]; u1 = U[abs(rc - j1)]; }
+      float2 q0 = make_float2(0.f, 1.f), q1 = q0;
+      if (GENERIC) { q0 = auxS[j0]; q1 = auxS[j1]; }
+      pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r0, q0, (float)(j0 + 1), u0, ftopn,
+                                                    one_minus_s, a.smooth, fL, acc_loss, acc_w, acc_nz, acc_g);
+      pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r1, q1, (float)(j1 + 1), u1, ftopn,
+                                                    one_minus_s, a.smooth, fL, acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
       acc_loss += __shfl_xor(acc_loss, o, 64);
@@ -447,28 +548,52 @@ __global__ __launch_bounds__(64) void pairwise_wave_kernel(const PwArgs a) {
       acc_g += __shfl_xor(acc_g, o, 64);
     }
     if (active && c == 0) {
-      const int ci = CI[row];
-      const int oi = ci >= 0 ? ci : -ci - 1;
+      const int oi = CIS[row];
+      if (!ITEMW) { acc_loss *= lw; acc_w *= lw; acc_g *= lw; if (lw == 0.0f) acc_nz = 0.f; }
       if (a.row_loss) a.row_loss[base + oi] = acc_loss;
-      if (a.row_weight) a.row_weight[base + oi] = acc_w;
+      if (AUX && a.row_weight) a.row_weight[base + oi] = acc_w;
       if (a.dlogits) a.dlogits[base + oi] = acc_g / a.temperature;
       nnz_local += acc_nz;
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
-  if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
+  if (!AUX) return;
+  if (S == 1) {
+    if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
+  } else {                                    // the only workgroup-level exchange: S pair counts
+    if (lane == 0) nz_slot[wave] = nnz_local;
+    __syncthreads();
+    if (threadIdx.x == 0 && a.nnz) {
+      float t = 0.f;
+      for (int w2 = 0; w2 < S; ++w2) t += nz_slot[w2];
+      a.nnz[b] = t;
+    }
+  }
 }
+
+int env_int(const char* name, int dflt);
 
 template <int IPL>
 int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
-  const size_t lds = (size_t)a.Lp * (16 + 8 + 4 + 4);
+  static const int env_s = env_int("TFR_PAIRWISE_WAVES_PER_LIST", 0);
+  int S = env_s > 0 ? env_s : (B >= 8192 ? 1 : (B >= 4096 ? 2 : 4));
+  if (S > 4) S = 4;
+  if (a.L <= 64) S = 1;
+  while (S > 1 && (size_t)S * pw_wave_lds(a.Lp) + 16 > 60 * 1024) S >>= 1;
+  const size_t lds = (size_t)S * pw_wave_lds(a.Lp) + 16;
+  if (lds > 64 * 1024) return -3;          // (caller falls back to the workgroup kernel)
   const bool generic = (a.lambda_kind == TFR_LAMBDA_DCG) &&
                        (a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) || a.mask != nullptr);
-#define PW_LAUNCH(LAM, GEN) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN>), dim3(B), dim3(64), lds, stream, a)
+  const bool aux = a.row_weight != nullptr || a.nnz != nullptr;
+  const bool itemw = generic || a.item_weights != nullptr || a.mask != nullptr;
+#define PW_L2(LAM, GEN, AUX, IW) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, AUX, IW>), dim3(B), dim3(64 * S), lds, stream, a)
+#define PW_LAUNCH(LAM, GEN) do { if (aux) { if (itemw) PW_L2(LAM, GEN, true, true); else PW_L2(LAM, GEN, true, false); } \
+                                 else { if (itemw) PW_L2(LAM, GEN, false, true); else PW_L2(LAM, GEN, false, false); } } while (0)
   if (a.lambda_kind == TFR_LAMBDA_DCG) { if (generic) PW_LAUNCH(TFR_LAMBDA_DCG, true); else PW_LAUNCH(TFR_LAMBDA_DCG, false); }
   else if (a.lambda_kind == TFR_LAMBDA_LABELDIFF) PW_LAUNCH(TFR_LAMBDA_LABELDIFF, false);
   else PW_LAUNCH(TFR_LAMBDA_NONE, false);
+#undef PW_L2
 #undef PW_LAUNCH
   return (int)hipGetLastError();
 }
@@ -500,23 +625,21 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
   static const int env_threads = env_int("TFR_PAIRWISE_THREADS", 0);
   static const int env_lanes = env_int("TFR_PAIRWISE_LANES", 0);
   static const int env_wave = env_int("TFR_PAIRWISE_WAVE", 1);
-  static const int env_wave_min_b = env_int("TFR_PAIRWISE_WAVE_MIN_B", 2048);
   const int C = env_lanes > 0 ? env_lanes : 2;
   if (C > 64 || (C & (C - 1))) return TFR_EINVAL;
-  if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
+  if (env_wave && env_threads == 0 && L <= 256) {      // longer lists: workgroup-per-list kernel below
     PwArgs w;
     w.logits = logits; w.labels = labels; w.mask = mask; w.item_weights = item_weights;
     w.list_weights = list_weights; w.lambda_kind = lambda_kind; w.topn = topn;
     w.smooth = smooth_fraction; w.normalized = normalized; w.gain_kind = gain_kind; w.gains = gains;
-    w.discount = discount; w.L = L; w.Lp = ((L + 3) / 4) * 4 + 4; w.P = 0;
+    const int c2 = (2 * C > 4) ? 2 * C : 4;
+    w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
     w.temperature = temperature; w.C = C; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
     w.nnz = nnz_out; w.dlogits = dlogits_out;
     hipStream_t st = (hipStream_t)stream;
     if (L <= 64) return launch_pw_wave<1>(w, B, st);
     if (L <= 128) return launch_pw_wave<2>(w, B, st);
-    if (L <= 256) return launch_pw_wave<4>(w, B, st);
-    if (L <= 512) return launch_pw_wave<8>(w, B, st);
-    return launch_pw_wave<16>(w, B, st);
+    return launch_pw_wave<4>(w, B, st);
   }
   const int T = env_threads > 0 ? env_threads : (L <= 64 ? 64 : (L <= 128 ? 128 : (L <= 512 ? 256 : 512)));
   if (T % 64 || T > 1024) return TFR_EINVAL;

@@ -236,7 +236,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
         y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
         fused = None
         if self.reduction != Reduction.NONE:
-            fused = self._loss._fused(y_true, y_pred, sample_weight, mask)
+            fused = self._loss._fused(y_true, y_pred, sample_weight, mask, want_aux=False)
         if fused is None:   # NONE reduction or a loss without a fused kernel
             saved, self._loss._ragged = self._loss._ragged, False
             try:
@@ -270,7 +270,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
                 list_w = list_w * torch.broadcast_to(sample_weight.reshape(-1), (b,))
         row_loss, _, _, dlogits = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-            want_grad=True, **lam)
+            want_grad=True, want_aux=False, **lam)
         return row_loss.sum(), dlogits
 
 

@@ -280,7 +280,7 @@ class _PerListLossFn(torch.autograd.Function):
         ctx.has_grad = dlogits is not None
         if ctx.has_grad:
             ctx.save_for_backward(dlogits)
-        ctx.mark_non_differentiable(*aux)
+        ctx.mark_non_differentiable(*[t for t in aux if t is not None])
         return (per_list,) + tuple(aux)
 
     @staticmethod
@@ -383,7 +383,7 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
         return _mat.pairwise_unreduced(self, labels, logits, mask)
 
     # fused path -----------------------------------------------------------
-    def _fused(self, labels, logits, weights, mask, apply_temperature=True):
+    def _fused(self, labels, logits, weights, mask, apply_temperature=True, want_aux=True):
         """Returns (list_loss [B] differentiable, row_loss [B,L], row_weight [B,L], nnz [B])."""
         b, l = logits.shape
         lam = _lambda_kernel_args(self._lambda_weight, labels, l, logits.device)
@@ -403,13 +403,15 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
 
         def runner(lg, want_grad):
             row_loss, row_weight, nnz, d = _ops.pairwise_logistic(
-                lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad, **lam)
+                lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad,
+                want_aux=want_aux, **lam)
             return row_loss.sum(dim=1), d, (row_loss, row_weight, nnz)
 
         return _PerListLossFn.apply(logits, runner)
 
     def _compute_reduced(self, labels, logits, weights, reduction, mask):
-        fused = self._fused(labels, logits, weights, mask)
+        fused = self._fused(labels, logits, weights, mask,
+                            want_aux=reduction in (Reduction.MEAN, Reduction.SUM_BY_NONZERO_WEIGHTS))
         if fused is None:
             losses, loss_weights = self._compute_unreduced_loss_impl(labels, self.get_logits(logits), mask)
             w = self._normalize_weights_impl(labels, weights) * loss_weights

@@ -624,3 +624,24 @@ def test_errors():
         ra().keras.losses.get('no_such_loss')
     with pytest.raises(ValueError):
         ra().keras.metrics.get('no_such_metric')
+
+
+# ------------------------------------------------------------------ many distinct label values
+@pytest.mark.parametrize('B,L', [(6, 50), (5, 200), (3, 257)])
+def test_continuous_labels_take_the_sort_fallback(B, L):
+    """Graded labels normally have a handful of distinct values (run-length ideal DCG); continuous
+    labels have ~L distinct values and must fall back to the in-register sort with equal results."""
+    g = torch.Generator().manual_seed(900 + L)
+    labels, logits = make_batch(B, L, seed=901 + L)
+    cont = torch.rand((B, L), generator=g) * 3.0
+    labels = torch.where(labels >= 0, cont, labels)
+    k = ra().keras.losses
+    for mine, ref in [(k.ApproxNDCGLoss(), R.ApproxNDCGLoss()),
+                      (k.PairwiseLogisticLoss(lambda_weight=k.NDCGLambdaWeight()),
+                       R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight()))]:
+        got, dl = mine.loss_and_grad(labels.to(DEV), logits.to(DEV))
+        lg = logits.clone().requires_grad_(True)
+        want = R.keras_loss_call(ref, labels, lg)
+        want.backward()
+        assert_loss_close(got, want, what=type(mine).__name__)
+        assert_grad_close(dl, lg.grad, what=type(mine).__name__)

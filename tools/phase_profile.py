@@ -1,0 +1,75 @@
+#!/usr/bin/env python
+"""Developer aid: per-phase cycle breakdown of the ApproxNDCG wave kernel from in-kernel
+s_memtime stamps (libtfr_hip_prof.so = the product sources + -DTFR_PROFILE_STAMPS)."""
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ranking_amd import _lib  # noqa: E402
+from tests.common import make_batch  # noqa: E402
+
+
+def main():
+    if not os.path.exists(_lib.PROF_LIB_PATH):
+        _lib.build_profiling()
+    lib = ctypes.CDLL(_lib.PROF_LIB_PATH)
+    B, L = 16384, 200
+    labels, logits = make_batch(B, L, seed=4)
+    order = os.environ.get('ORDER', '')
+    if order:
+        nv = (labels >= 0).sum(1)
+        perm = torch.argsort(nv, descending=(order == 'desc'))
+        labels, logits = labels[perm].contiguous(), logits[perm].contiguous()
+    dev = 'cuda'
+    labels, logits = labels.to(dev), logits.to(dev)
+    r = torch.arange(1, L + 1, dtype=torch.float32)
+    inv = (1.0 / torch.log1p(r)).to(dev)
+    loss = torch.empty(B, device=dev); wout = torch.empty(B, device=dev); dl = torch.empty((B, L), device=dev)
+    buf = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+    lib.tfr_prof_set_buffer(ctypes.c_void_p(buf.data_ptr()))
+    f = lib.tfr_approx_ndcg_f32
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] + [ctypes.c_void_p] * 4
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        rc = f(logits.data_ptr(), labels.data_ptr(), None, inv.data_ptr(), None, B, L, 0.1, 0, loss.data_ptr(),
+               wout.data_ptr(), dl.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert rc == 0
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        f(logits.data_ptr(), labels.data_ptr(), None, inv.data_ptr(), None, B, L, 0.1, 0, loss.data_ptr(),
+          wout.data_ptr(), dl.data_ptr(), st)
+    e1.record(); torch.cuda.synchronize()
+    print('ORDER=%r kernel %.4f ms' % (order, e0.elapsed_time(e1) / 20))
+    d = buf.cpu()
+    t = d[:, :6].double()
+    names = ['load+stats', 'gains+idealDCG', 'compact+exp', 'fwd sweep', 'bwd sweep']
+    tot = (t[:, 5] - t[:, 0]).mean().item()
+    print('mean ticks per list-wave: total %.0f' % tot)
+    for i, nme in enumerate(names):
+        dt = (t[:, i + 1] - t[:, i]).mean().item()
+        print('  %-16s %8.0f  %5.1f %%' % (nme, dt, 100 * dt / tot))
+    import numpy as np
+    st_, en_ = t[:, 0].numpy(), t[:, 5].numpy()
+    lo = st_.min()
+    span_ = en_.max() - lo
+    grid = np.linspace(0, span_, 21)
+    act = [(int(((st_ - lo) <= g_) .sum() - ((en_ - lo) <= g_).sum())) for g_ in grid]
+    print('active waves at 0,5,..,100 %% of the span (%.0f cycles): %s' % (span_, act))
+    span = (t[:, 5].max() - t[:, 0].min()).item()
+    print('kernel span %.0f ticks; sum of wave lifetimes / span = %.1f concurrent waves (chip)' % (
+        span, (t[:, 5] - t[:, 0]).sum().item() / span))
+    n = d[:, 7].double()
+    print('mean n_valid %.1f, mean n^2 %.0f' % (n.mean().item(), (n * n).mean().item()))
+    # concurrency per SIMD: decode HW_ID (wave_id[3:0], simd_id[5:4], cu_id[11:8], sh_id[12], se_id[15:13]), xcc in upper bits
+    hw = d[:, 6]
+    key = (hw >> 4) & 0xfffffff
+    print('distinct simd keys:', len(set(key.tolist())))
+
+
+if __name__ == '__main__':
+    main()
