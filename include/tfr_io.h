@@ -1,0 +1,82 @@
+/* tfr_io.h -- C ABI of libtfr_io.so: the input side of the ranking hot path (host code, no GPU).
+ *
+ * Replaces, for numeric features, the TensorFlow ops the reference's input pipeline is built
+ * from (paths relative to /root/reference/tensorflow_ranking/):
+ *   - tf.data.TFRecordDataset              (python/data.py:914-1017 build_ranking_dataset_with_parsing_fn)
+ *   - tf.io.parse_example on ExampleListWithContext protos: decode, truncate / pad to
+ *     list_size, sizes and mask     (python/data.py:59-96, 133-208 _ExampleInExampleParser.parse,
+ *                                    383-540 _ExampleListParser / parse_from_example_list)
+ *   - the LibSVM loader of the canonical example (examples/tf_ranking_libsvm.py:137-195).
+ * Output is what the scorer consumes: dense row-major fp32 [B, list_size, F] with the label as
+ * one more feature whose default (-1) marks padding (python/data.py:41, utils.py:78-81).
+ *
+ * Conventions: all pointers are HOST pointers owned by the caller; nothing is allocated or
+ * retained; thread-safe.  Return >= 0 on success, < 0 on error:
+ *   TFR_IO_EINVAL -1 bad argument, TFR_IO_ECORRUPT -2 truncated / malformed record or protobuf,
+ *   TFR_IO_ECRC -3 checksum mismatch, TFR_IO_ESHAPE -4 a feature is present with a length
+ *   different from its spec (tf.io.parse_example raises in that case), TFR_IO_ETYPE -5 a feature
+ *   holds a bytes_list (numeric path only).
+ */
+#ifndef TFR_IO_H_
+#define TFR_IO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFR_IO_EINVAL (-1)
+#define TFR_IO_ECORRUPT (-2)
+#define TFR_IO_ECRC (-3)
+#define TFR_IO_ESHAPE (-4)
+#define TFR_IO_ETYPE (-5)
+
+int tfr_io_abi_version(void);
+
+/* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
+uint32_t tfr_io_crc32c(const uint8_t* data, size_t n);
+uint32_t tfr_io_masked_crc32c(const uint8_t* data, size_t n);
+
+/* TFRecord framing: [u64 length][u32 masked crc of length][data][u32 masked crc of data].
+ * Fills offsets[i] / lengths[i] (payload position and size inside `buf`) for up to max_records
+ * records (both arrays may be NULL to count only); returns the number of records in `buf`. */
+int64_t tfr_io_tfrecord_index(const uint8_t* buf, size_t nbytes, int verify_crc, uint64_t* offsets,
+                              uint64_t* lengths, int64_t max_records);
+
+/* FixedLenFeature([width], float32 | int64, default): values are written as fp32. */
+typedef struct tfr_io_feature_spec {
+  const char* name;
+  int32_t width;        /* number of values per example (>= 1)                         */
+  float default_value;  /* used when the feature is absent and for padded examples     */
+} tfr_io_feature_spec;
+
+/* Largest number of `examples` among the records (list_size=None in the reference means "pad to
+ * the longest list of the batch"). */
+int64_t tfr_io_elwc_max_list_size(const uint8_t* const* records, const uint64_t* lengths, int32_t B);
+
+/* Parses B serialized ExampleListWithContext protos.
+ *   example_out  [B, list_size, sum(example widths)]  features in spec order
+ *   context_out  [B, sum(context widths)]             (nullable when n_context == 0)
+ *   sizes_out    [B]  number of examples in the record, BEFORE truncation (data.py:149-152)
+ *   mask_out     [B, list_size]  1 for positions < min(size, list_size)       (nullable)
+ *   num_threads  <= 1: caller's thread; otherwise records are split across threads. */
+int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                            int32_t list_size, const tfr_io_feature_spec* example_specs,
+                            int32_t n_example, const tfr_io_feature_spec* context_specs,
+                            int32_t n_context, float* example_out, float* context_out,
+                            int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads);
+
+/* LibSVM text ("label qid:Q fid:val ... # comment" per line, features named 1..num_features).
+ * Pass 1 (features_out == NULL): returns the number of distinct qids (first-seen order).
+ * Pass 2: fills features_out [Q, list_size, num_features] (zeros) and labels_out [Q, list_size]
+ * (-1 padding), keeping the first list_size documents of each query; stats_out[0] = documents
+ * seen, stats_out[1] = documents discarded (nullable).  Returns Q. */
+int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t list_size, int32_t num_features,
+                           float* features_out, float* labels_out, int64_t* stats_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* TFR_IO_H_ */

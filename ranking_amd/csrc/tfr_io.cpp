@@ -1,0 +1,406 @@
+// libtfr_io.so -- host-side input path of the ranking framework (see include/tfr_io.h):
+// TFRecord framing, ExampleListWithContext -> padded dense fp32 tensors, LibSVM loader.
+//
+// Reference behaviour restated: python/data.py:59-96 (ELWC wire format: `repeated bytes
+// examples = 1; bytes context = 2`, each a serialized tf.Example), :133-208 (truncate / pad to
+// list_size, sizes, mask), :383-540; examples/tf_ranking_libsvm.py:137-195 (LibSVM loader).
+// The reference delegates the byte work to TensorFlow C++ ops (tf.io.parse_example,
+// TFRecordDataset); here it is a small protobuf wire reader with no dependencies.
+#include "../../include/tfr_io.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------ crc32c
+struct Crc32cTable {
+  uint32_t t[8][256];
+  Crc32cTable() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82f63b78u : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 8; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xff];
+  }
+};
+const Crc32cTable& crc_table() { static const Crc32cTable tab; return tab; }
+
+uint32_t crc32c(const uint8_t* p, size_t n) {
+  const Crc32cTable& T = crc_table();
+  uint32_t c = 0xffffffffu;
+  while (n >= 8) {                                   // slice-by-8
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = T.t[7][lo & 0xff] ^ T.t[6][(lo >> 8) & 0xff] ^ T.t[5][(lo >> 16) & 0xff] ^ T.t[4][lo >> 24] ^
+        T.t[3][hi & 0xff] ^ T.t[2][(hi >> 8) & 0xff] ^ T.t[1][(hi >> 16) & 0xff] ^ T.t[0][hi >> 24];
+    p += 8; n -= 8;
+  }
+  while (n--) c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return c ^ 0xffffffffu;
+}
+inline uint32_t mask_crc(uint32_t crc) { return ((crc >> 15) | (crc << 17)) + 0xa282ead8u; }
+
+// ------------------------------------------------------------------ protobuf wire reader
+struct Reader {
+  const uint8_t* p; const uint8_t* end; bool ok = true;
+  Reader(const uint8_t* b, size_t n) : p(b), end(b + n) {}
+  bool done() const { return p >= end || !ok; }
+  uint64_t varint() {
+    uint64_t v = 0; int shift = 0;
+    while (p < end && shift < 64) {
+      const uint8_t b = *p++;
+      v |= (uint64_t)(b & 0x7f) << shift;
+      if (!(b & 0x80)) return v;
+      shift += 7;
+    }
+    ok = false; return 0;
+  }
+  // length-delimited payload
+  bool bytes(const uint8_t*& b, size_t& n) {
+    const uint64_t len = varint();
+    if (!ok || len > (uint64_t)(end - p)) { ok = false; return false; }
+    b = p; n = (size_t)len; p += len; return true;
+  }
+  void skip(uint32_t wire) {
+    switch (wire) {
+      case 0: varint(); break;
+      case 1: if (end - p < 8) ok = false; else p += 8; break;
+      case 2: { const uint8_t* b; size_t n; bytes(b, n); break; }
+      case 5: if (end - p < 4) ok = false; else p += 4; break;
+      default: ok = false;
+    }
+  }
+};
+
+struct SpecTable {
+  std::unordered_map<std::string_view, int> index;       // name -> spec index
+  std::vector<int> offset;                                // column offset of each spec
+  std::vector<int> width;
+  std::vector<float> dflt;
+  int total = 0;
+  SpecTable(const tfr_io_feature_spec* specs, int n) {
+    offset.resize(n); width.resize(n); dflt.resize(n);
+    for (int i = 0; i < n; ++i) {
+      index.emplace(std::string_view(specs[i].name), i);
+      offset[i] = total; width[i] = specs[i].width; dflt[i] = specs[i].default_value;
+      total += specs[i].width;
+    }
+  }
+  void fill_defaults(float* row) const {
+    for (size_t i = 0; i < offset.size(); ++i)
+      for (int k = 0; k < width[i]; ++k) row[offset[i] + k] = dflt[i];
+  }
+};
+
+// Feature { oneof kind { BytesList bytes_list = 1; FloatList float_list = 2; Int64List int64_list = 3; } }
+// Writes exactly `width` values; returns 0, TFR_IO_ESHAPE, TFR_IO_ETYPE or TFR_IO_ECORRUPT.
+int decode_feature(const uint8_t* b, size_t n, int width, float* out) {
+  Reader r(b, n);
+  int count = 0;
+  bool seen = false;
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    const uint32_t field = (uint32_t)(tag >> 3), wire = (uint32_t)(tag & 7);
+    if (wire != 2) { r.skip(wire); continue; }
+    const uint8_t* lb; size_t ln;
+    if (!r.bytes(lb, ln)) return TFR_IO_ECORRUPT;
+    if (field == 1) {                                     // bytes_list
+      if (ln > 0) return TFR_IO_ETYPE;                    // an empty list is "feature absent"
+      continue;
+    }
+    if (field != 2 && field != 3) continue;
+    seen = true;
+    Reader l(lb, ln);
+    while (!l.done()) {
+      const uint64_t t2 = l.varint();
+      if (!l.ok) return TFR_IO_ECORRUPT;
+      const uint32_t f2 = (uint32_t)(t2 >> 3), w2 = (uint32_t)(t2 & 7);
+      if (f2 != 1) { l.skip(w2); continue; }
+      if (field == 2) {                                   // FloatList.value (packed or not)
+        if (w2 == 2) {
+          const uint8_t* pb; size_t pn;
+          if (!l.bytes(pb, pn) || (pn & 3)) return TFR_IO_ECORRUPT;
+          for (size_t i = 0; i < pn; i += 4) {
+            float v; memcpy(&v, pb + i, 4);
+            if (count < width) out[count] = v;
+            ++count;
+          }
+        } else if (w2 == 5) {
+          if (l.end - l.p < 4) return TFR_IO_ECORRUPT;
+          float v; memcpy(&v, l.p, 4); l.p += 4;
+          if (count < width) out[count] = v;
+          ++count;
+        } else {
+          return TFR_IO_ECORRUPT;
+        }
+      } else {                                            // Int64List.value (packed or not)
+        if (w2 == 2) {
+          const uint8_t* pb; size_t pn;
+          if (!l.bytes(pb, pn)) return TFR_IO_ECORRUPT;
+          Reader pv(pb, pn);
+          while (!pv.done()) {
+            const int64_t v = (int64_t)pv.varint();
+            if (!pv.ok) return TFR_IO_ECORRUPT;
+            if (count < width) out[count] = (float)v;
+            ++count;
+          }
+        } else if (w2 == 0) {
+          const int64_t v = (int64_t)l.varint();
+          if (!l.ok) return TFR_IO_ECORRUPT;
+          if (count < width) out[count] = (float)v;
+          ++count;
+        } else {
+          return TFR_IO_ECORRUPT;
+        }
+      }
+    }
+    if (!l.ok) return TFR_IO_ECORRUPT;
+  }
+  if (!r.ok) return TFR_IO_ECORRUPT;
+  if (!seen || count == 0) return 1;                      // absent (or empty list): keep the default
+  return count == width ? 0 : TFR_IO_ESHAPE;
+}
+
+// tf.Example { Features features = 1; }  Features { map<string, Feature> feature = 1; }
+int decode_example(const uint8_t* b, size_t n, const SpecTable& specs, float* row) {
+  specs.fill_defaults(row);
+  Reader r(b, n);
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    if ((tag >> 3) != 1 || (tag & 7) != 2) { r.skip((uint32_t)(tag & 7)); continue; }
+    const uint8_t* fb; size_t fn;
+    if (!r.bytes(fb, fn)) return TFR_IO_ECORRUPT;
+    Reader f(fb, fn);                                     // Features
+    while (!f.done()) {
+      const uint64_t t2 = f.varint();
+      if (!f.ok) return TFR_IO_ECORRUPT;
+      if ((t2 >> 3) != 1 || (t2 & 7) != 2) { f.skip((uint32_t)(t2 & 7)); continue; }
+      const uint8_t* eb; size_t en;
+      if (!f.bytes(eb, en)) return TFR_IO_ECORRUPT;
+      Reader e(eb, en);                                   // map entry { key = 1; value = 2; }
+      std::string_view key; const uint8_t* vb = nullptr; size_t vn = 0;
+      while (!e.done()) {
+        const uint64_t t3 = e.varint();
+        if (!e.ok) return TFR_IO_ECORRUPT;
+        const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+        if (w3 != 2) { e.skip(w3); continue; }
+        const uint8_t* xb; size_t xn;
+        if (!e.bytes(xb, xn)) return TFR_IO_ECORRUPT;
+        if (f3 == 1) key = std::string_view(reinterpret_cast<const char*>(xb), xn);
+        else if (f3 == 2) { vb = xb; vn = xn; }
+      }
+      if (!e.ok) return TFR_IO_ECORRUPT;
+      const auto it = specs.index.find(key);
+      if (it == specs.index.end() || vb == nullptr) continue;
+      const int s = it->second;
+      const int rc = decode_feature(vb, vn, specs.width[s], row + specs.offset[s]);
+      if (rc < 0) return rc;
+      if (rc == 1)                                        // present but empty: default
+        for (int k = 0; k < specs.width[s]; ++k) row[specs.offset[s] + k] = specs.dflt[s];
+    }
+    if (!f.ok) return TFR_IO_ECORRUPT;
+  }
+  return r.ok ? 0 : TFR_IO_ECORRUPT;
+}
+
+// ExampleListWithContext { repeated bytes examples = 1; bytes context = 2; }   (data.py:59-77)
+int decode_elwc(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, const SpecTable* ctx,
+                float* example_rows, float* context_row, int32_t* size_out, uint8_t* mask_row) {
+  Reader r(b, n);
+  int count = 0;
+  bool ctx_seen = false;
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    const uint32_t field = (uint32_t)(tag >> 3), wire = (uint32_t)(tag & 7);
+    if (wire != 2 || (field != 1 && field != 2)) { r.skip(wire); continue; }
+    const uint8_t* pb; size_t pn;
+    if (!r.bytes(pb, pn)) return TFR_IO_ECORRUPT;
+    if (field == 1) {
+      if (count < list_size) {                            // truncation keeps the first list_size (:170-172)
+        const int rc = decode_example(pb, pn, ex, example_rows + (size_t)count * ex.total);
+        if (rc < 0) return rc;
+      }
+      ++count;
+    } else if (ctx && context_row) {
+      const int rc = decode_example(pb, pn, *ctx, context_row);
+      if (rc < 0) return rc;
+      ctx_seen = true;
+    }
+  }
+  if (!r.ok) return TFR_IO_ECORRUPT;
+  for (int i = std::min(count, list_size); i < list_size; ++i)   // padding = empty Example = defaults (:174-178)
+    ex.fill_defaults(example_rows + (size_t)i * ex.total);
+  if (ctx && context_row && !ctx_seen) ctx->fill_defaults(context_row);
+  if (size_out) *size_out = count;
+  if (mask_row)
+    for (int i = 0; i < list_size; ++i) mask_row[i] = i < count ? 1 : 0;
+  return 0;
+}
+
+int count_examples(const uint8_t* b, size_t n) {
+  Reader r(b, n);
+  int count = 0;
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    const uint32_t wire = (uint32_t)(tag & 7);
+    if ((tag >> 3) == 1 && wire == 2) ++count;
+    r.skip(wire);
+  }
+  return r.ok ? count : TFR_IO_ECORRUPT;
+}
+
+}  // namespace
+
+extern "C" int tfr_io_abi_version(void) { return 1; }
+
+extern "C" uint32_t tfr_io_crc32c(const uint8_t* data, size_t n) { return crc32c(data, n); }
+extern "C" uint32_t tfr_io_masked_crc32c(const uint8_t* data, size_t n) { return mask_crc(crc32c(data, n)); }
+
+extern "C" int64_t tfr_io_tfrecord_index(const uint8_t* buf, size_t nbytes, int verify_crc, uint64_t* offsets,
+                                         uint64_t* lengths, int64_t max_records) {
+  if (!buf && nbytes) return TFR_IO_EINVAL;
+  size_t pos = 0;
+  int64_t n = 0;
+  while (pos < nbytes) {
+    if (nbytes - pos < 12) return TFR_IO_ECORRUPT;
+    uint64_t len; uint32_t lcrc;
+    memcpy(&len, buf + pos, 8); memcpy(&lcrc, buf + pos + 8, 4);
+    if (verify_crc && mask_crc(crc32c(buf + pos, 8)) != lcrc) return TFR_IO_ECRC;
+    if (len > nbytes - pos - 12 || nbytes - pos - 12 - len < 4) return TFR_IO_ECORRUPT;
+    const size_t data = pos + 12;
+    if (verify_crc) {
+      uint32_t dcrc; memcpy(&dcrc, buf + data + len, 4);
+      if (mask_crc(crc32c(buf + data, (size_t)len)) != dcrc) return TFR_IO_ECRC;
+    }
+    if (n < max_records) {
+      if (offsets) offsets[n] = data;
+      if (lengths) lengths[n] = len;
+    }
+    ++n;
+    pos = data + (size_t)len + 4;
+  }
+  return n;
+}
+
+extern "C" int64_t tfr_io_elwc_max_list_size(const uint8_t* const* records, const uint64_t* lengths, int32_t B) {
+  if (B < 0 || (B > 0 && (!records || !lengths))) return TFR_IO_EINVAL;
+  int64_t best = 0;
+  for (int b = 0; b < B; ++b) {
+    const int c = count_examples(records[b], (size_t)lengths[b]);
+    if (c < 0) return c;
+    best = std::max<int64_t>(best, c);
+  }
+  return best;
+}
+
+extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                       int32_t list_size, const tfr_io_feature_spec* example_specs,
+                                       int32_t n_example, const tfr_io_feature_spec* context_specs,
+                                       int32_t n_context, float* example_out, float* context_out,
+                                       int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads) {
+  if (B < 0 || list_size <= 0 || n_example <= 0 || !example_specs || !example_out || n_context < 0) return TFR_IO_EINVAL;
+  if (B > 0 && (!records || !lengths)) return TFR_IO_EINVAL;
+  if (n_context > 0 && (!context_specs || !context_out)) return TFR_IO_EINVAL;
+  for (int i = 0; i < n_example; ++i) if (!example_specs[i].name || example_specs[i].width < 1) return TFR_IO_EINVAL;
+  for (int i = 0; i < n_context; ++i) if (!context_specs[i].name || context_specs[i].width < 1) return TFR_IO_EINVAL;
+  const SpecTable ex(example_specs, n_example);
+  const SpecTable cx(context_specs, n_context);
+  std::atomic<int> err{0};
+  auto work = [&](int lo, int hi) {
+    for (int b = lo; b < hi && err.load(std::memory_order_relaxed) == 0; ++b) {
+      const int rc = decode_elwc(records[b], (size_t)lengths[b], list_size, ex, n_context ? &cx : nullptr,
+                                 example_out + (size_t)b * list_size * ex.total,
+                                 n_context ? context_out + (size_t)b * cx.total : nullptr,
+                                 sizes_out ? sizes_out + b : nullptr,
+                                 mask_out ? mask_out + (size_t)b * list_size : nullptr);
+      if (rc < 0) { int z = 0; err.compare_exchange_strong(z, rc); }
+    }
+  };
+  int T = num_threads > 1 ? std::min(num_threads, std::max(1, B)) : 1;
+  if (T <= 1) {
+    work(0, B);
+  } else {
+    std::vector<std::thread> pool;
+    const int per = (B + T - 1) / T;
+    for (int t = 0; t < T; ++t) pool.emplace_back(work, std::min(B, t * per), std::min(B, (t + 1) * per));
+    for (auto& th : pool) th.join();
+  }
+  return err.load();
+}
+
+extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t list_size, int32_t num_features,
+                                      float* features_out, float* labels_out, int64_t* stats_out) {
+  if ((!text && nbytes) || list_size <= 0 || num_features <= 0) return TFR_IO_EINVAL;
+  if ((features_out == nullptr) != (labels_out == nullptr)) return TFR_IO_EINVAL;
+  std::unordered_map<std::string, int64_t> qid_index;
+  std::vector<int32_t> ndoc;
+  int64_t total = 0, discarded = 0;
+  const char* p = text; const char* end = text + nbytes;
+  while (p < end) {
+    const char* eol = static_cast<const char*>(memchr(p, '\n', (size_t)(end - p)));
+    if (!eol) eol = end;
+    const char* hash = static_cast<const char*>(memchr(p, '#', (size_t)(eol - p)));
+    const char* le = hash ? hash : eol;
+    // tokens separated by whitespace
+    auto skip_ws = [&](const char* s) { while (s < le && (*s == ' ' || *s == '\t' || *s == '\r')) ++s; return s; };
+    auto tok_end = [&](const char* s) { while (s < le && *s != ' ' && *s != '\t' && *s != '\r') ++s; return s; };
+    const char* s = skip_ws(p);
+    if (s < le) {
+      const char* e = tok_end(s);
+      const std::string label_tok(s, e);
+      char* endp = nullptr;
+      const float label = strtof(label_tok.c_str(), &endp);
+      if (endp == label_tok.c_str()) return TFR_IO_ECORRUPT;
+      s = skip_ws(e);
+      if (s >= le) return TFR_IO_ECORRUPT;                  // "Ill-formatted line" (:143)
+      e = tok_end(s);
+      const std::string qid(s, e);                          // the whole token, like the reference (:145)
+      auto it = qid_index.find(qid);
+      int64_t q;
+      if (it == qid_index.end()) {
+        q = (int64_t)qid_index.size();
+        qid_index.emplace(qid, q);
+        ndoc.push_back(0);
+      } else {
+        q = it->second;
+      }
+      ++total;
+      const int32_t d = ndoc[q]++;
+      if (d >= list_size) {
+        ++discarded;                                        // keep the first list_size docs only (:176-179)
+      } else if (features_out) {
+        labels_out[q * list_size + d] = label;
+        float* row = features_out + ((size_t)q * list_size + d) * num_features;
+        s = skip_ws(e);
+        while (s < le) {
+          e = tok_end(s);
+          const char* colon = static_cast<const char*>(memchr(s, ':', (size_t)(e - s)));
+          if (!colon) return TFR_IO_ECORRUPT;
+          const long fid = strtol(std::string(s, colon).c_str(), nullptr, 10);
+          if (fid < 1 || fid > num_features) return TFR_IO_ESHAPE;   // "Key not found in features" (:181)
+          row[fid - 1] = strtof(std::string(colon + 1, e).c_str(), nullptr);
+          s = skip_ws(e);
+        }
+      }
+    }
+    p = eol + 1;
+  }
+  if (stats_out) { stats_out[0] = total; stats_out[1] = discarded; }
+  return (int64_t)qid_index.size();
+}

@@ -1,0 +1,229 @@
+"""Input side of the ranking path: mirror of the numeric-feature subset of
+``tensorflow_ranking/python/data.py`` and of the LibSVM loader in
+``examples/tf_ranking_libsvm.py:137-195`` on top of the native ``libtfr_io.so``
+(include/tfr_io.h): TFRecord framing with CRC-32C, ``ExampleListWithContext`` decoding,
+truncation / padding to ``list_size``, list sizes and mask.
+
+Same entry-point names and keyword arguments as the reference where they exist
+(``parse_from_example_list``, ``make_parsing_fn``, ``build_ranking_dataset``,
+``build_ranking_dataset_with_parsing_fn``); feature specs are ``FixedLenFeature`` objects
+(numeric, with a default value).  Tensors are returned on the host (pin + copy to the GPU is
+the caller's choice); ``shuffle_examples`` permutes the valid examples of each list like
+``utils.shuffle_valid_indices`` (the TF random stream itself is not reproducible: SURVEY 8c).
+"""
+from __future__ import annotations
+
+import collections
+import ctypes
+import glob as _glob
+import mmap
+import os
+from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _io_lib
+
+EIE = 'example_in_example'
+ELWC = 'example_list_with_context'
+SEQ = 'sequence_example'
+_PADDING_LABEL = -1.
+
+FixedLenFeature = collections.namedtuple('FixedLenFeature', ['shape', 'dtype', 'default_value'])
+FixedLenFeature.__new__.__defaults__ = (None,)
+
+
+def _spec_width(spec) -> int:
+    shape = tuple(spec.shape) if not isinstance(spec.shape, int) else (spec.shape,)
+    w = 1
+    for s in shape:
+        w *= int(s)
+    return max(w, 1)
+
+
+def _spec_array(feature_spec: Dict[str, FixedLenFeature]):
+    names = list(feature_spec)
+    arr = (_io_lib.FeatureSpec * max(len(names), 1))()
+    keep = []
+    for i, name in enumerate(names):
+        spec = feature_spec[name]
+        if spec.default_value is None:
+            raise ValueError('feature %r needs a default_value (padded examples take it)' % name)
+        dv = spec.default_value
+        if isinstance(dv, (list, tuple, np.ndarray)):
+            dv = np.asarray(dv).reshape(-1)[0]
+        b = name.encode('utf-8')
+        keep.append(b)
+        arr[i] = _io_lib.FeatureSpec(b, _spec_width(spec), float(dv))
+    return names, arr, keep
+
+
+def crc32c(data: bytes) -> int:
+    return int(_io_lib.load().tfr_io_crc32c(ctypes.c_char_p(data), len(data)))
+
+
+def masked_crc32c(data: bytes) -> int:
+    return int(_io_lib.load().tfr_io_masked_crc32c(ctypes.c_char_p(data), len(data)))
+
+
+def write_tfrecord(path: str, records: Iterable[bytes]) -> None:
+    """tf.io.TFRecordWriter framing (used for synthetic ELWC inputs and tests)."""
+    with open(path, 'wb') as f:
+        for r in records:
+            hdr = len(r).to_bytes(8, 'little')
+            f.write(hdr); f.write(masked_crc32c(hdr).to_bytes(4, 'little'))
+            f.write(r); f.write(masked_crc32c(r).to_bytes(4, 'little'))
+
+
+def read_tfrecord(path: str, verify_crc: bool = True) -> List[bytes]:
+    """All records of one TFRecord file (tf.data.TFRecordDataset semantics)."""
+    lib = _io_lib.load()
+    size = os.path.getsize(path)
+    if size == 0:
+        return []
+    with open(path, 'rb') as f:
+        buf = f.read()
+    cbuf = ctypes.c_char_p(buf)
+    n = _io_lib.check(lib.tfr_io_tfrecord_index(cbuf, len(buf), int(verify_crc), None, None, 0),
+                      'tfr_io_tfrecord_index(%s)' % path)
+    off = np.zeros(n, dtype=np.uint64); ln = np.zeros(n, dtype=np.uint64)
+    _io_lib.check(lib.tfr_io_tfrecord_index(cbuf, len(buf), 0, off.ctypes.data, ln.ctypes.data, n),
+                  'tfr_io_tfrecord_index')
+    return [buf[int(o):int(o) + int(l)] for o, l in zip(off, ln)]
+
+
+def _record_arrays(serialized: Sequence[bytes]):
+    B = len(serialized)
+    ptrs = (ctypes.c_char_p * max(B, 1))(*serialized)
+    lens = np.asarray([len(s) for s in serialized], dtype=np.uint64)
+    return ptrs, lens
+
+
+def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int] = None,
+                            context_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                            example_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                            size_feature_name: Optional[str] = None, mask_feature_name: Optional[str] = None,
+                            shuffle_examples: bool = False, seed: Optional[int] = None,
+                            num_threads: int = 0) -> Dict[str, torch.Tensor]:
+    """data.py:391-540: a batch of serialized ELWC protos -> feature map.  Example features are
+    ``[B, list_size, width]`` (fp32; int64 features are converted), context features ``[B, width]``."""
+    if not example_feature_spec:
+        raise ValueError('example_feature_spec {} must not be empty.'.format(example_feature_spec))
+    lib = _io_lib.load()
+    serialized = list(serialized)
+    B = len(serialized)
+    ptrs, lens = _record_arrays(serialized)
+    if list_size is None or list_size <= 0:
+        list_size = max(1, int(_io_lib.check(lib.tfr_io_elwc_max_list_size(ptrs, lens.ctypes.data, B),
+                                             'tfr_io_elwc_max_list_size')))
+    ex_names, ex_arr, _k1 = _spec_array(example_feature_spec)
+    cx_names, cx_arr, _k2 = _spec_array(context_feature_spec or {})
+    ex_w = [_spec_width(example_feature_spec[n]) for n in ex_names]
+    cx_w = [_spec_width(context_feature_spec[n]) for n in cx_names]
+    ex_out = np.empty((B, list_size, sum(ex_w)), dtype=np.float32)
+    cx_out = np.empty((B, max(sum(cx_w), 1)), dtype=np.float32)
+    sizes = np.zeros(B, dtype=np.int32)
+    mask = np.zeros((B, list_size), dtype=np.uint8)
+    if num_threads <= 0:
+        num_threads = min(16, os.cpu_count() or 1) if B >= 64 else 1
+    _io_lib.check(lib.tfr_io_parse_elwc_batch(
+        ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
+        ex_out.ctypes.data, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
+        num_threads), 'tfr_io_parse_elwc_batch')
+    ex_t = torch.from_numpy(ex_out)
+    if shuffle_examples:
+        from . import utils
+        is_valid = torch.from_numpy(mask.astype(bool))
+        idx = utils.shuffle_valid_indices(is_valid, seed=seed)
+        ex_t = torch.gather(ex_t, 1, idx.unsqueeze(-1).expand(-1, -1, ex_t.shape[2]))
+    features: Dict[str, torch.Tensor] = {}
+    off = 0
+    for name, w in zip(ex_names, ex_w):
+        spec = example_feature_spec[name]
+        t = ex_t[:, :, off:off + w]
+        features[name] = t.to(spec.dtype) if spec.dtype not in (None, torch.float32) else t
+        off += w
+    off = 0
+    cx_t = torch.from_numpy(cx_out)
+    for name, w in zip(cx_names, cx_w):
+        spec = context_feature_spec[name]
+        t = cx_t[:, off:off + w]
+        features[name] = t.to(spec.dtype) if spec.dtype not in (None, torch.float32) else t
+        off += w
+    if size_feature_name:
+        features[size_feature_name] = torch.from_numpy(sizes)
+    if mask_feature_name:
+        features[mask_feature_name] = torch.from_numpy(mask.astype(bool))
+    return features
+
+
+def make_parsing_fn(data_format, list_size=None, context_feature_spec=None, example_feature_spec=None,
+                    size_feature_name=None, mask_feature_name=None, shuffle_examples=False, seed=None):
+    """data.py:857-911."""
+    if data_format != ELWC:
+        raise ValueError('Format {} is not supported: the native reader covers example_list_with_context '
+                         '(SURVEY.md 8f)'.format(data_format))
+
+    def _fn(serialized):
+        return parse_from_example_list(serialized, list_size=list_size, context_feature_spec=context_feature_spec,
+                                       example_feature_spec=example_feature_spec,
+                                       size_feature_name=size_feature_name, mask_feature_name=mask_feature_name,
+                                       shuffle_examples=shuffle_examples, seed=seed)
+    return _fn
+
+
+def build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, reader=None, reader_args=None,
+                                          num_epochs=None, shuffle=True, shuffle_buffer_size=10000,
+                                          shuffle_seed=None, prefetch_buffer_size=None, reader_num_threads=None,
+                                          sloppy_ordering=False, drop_final_batch=False,
+                                          num_parser_threads=None) -> Iterator[Dict[str, torch.Tensor]]:
+    """data.py:914-1017 as a Python generator of parsed batches (file and record shuffling with a
+    ``torch.Generator``; the reference's interleave / prefetch knobs are accepted and ignored)."""
+    files = sorted(sum((_glob.glob(p) for p in ([file_pattern] if isinstance(file_pattern, str) else file_pattern)), []))
+    if not files:
+        raise ValueError('no files match %r' % (file_pattern,))
+    g = torch.Generator().manual_seed(0 if shuffle_seed is None else int(shuffle_seed))
+    epoch = 0
+    while num_epochs is None or epoch < num_epochs:
+        order = torch.randperm(len(files), generator=g).tolist() if shuffle else range(len(files))
+        records: List[bytes] = []
+        for fi in order:
+            records.extend(read_tfrecord(files[fi]))
+        if shuffle:
+            perm = torch.randperm(len(records), generator=g).tolist()
+            records = [records[i] for i in perm]
+        for lo in range(0, len(records), batch_size):
+            chunk = records[lo:lo + batch_size]
+            if len(chunk) < batch_size and drop_final_batch:
+                break
+            yield parsing_fn(chunk)
+        epoch += 1
+
+
+def build_ranking_dataset(file_pattern, data_format, batch_size, context_feature_spec, example_feature_spec,
+                          list_size=None, size_feature_name=None, mask_feature_name=None, shuffle_examples=False,
+                          seed=None, **kwargs):
+    """data.py:1020-1068."""
+    parsing_fn = make_parsing_fn(data_format, list_size, context_feature_spec, example_feature_spec,
+                                 size_feature_name=size_feature_name, mask_feature_name=mask_feature_name,
+                                 shuffle_examples=shuffle_examples, seed=seed)
+    return build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, **kwargs)
+
+
+def load_libsvm_data(path: str, list_size: int, num_features: int = 136) -> Tuple[torch.Tensor, torch.Tensor]:
+    """examples/tf_ranking_libsvm.py:137-195: (features [Q, list_size, num_features] fp32,
+    labels [Q, list_size] fp32 with -1 padding); feature k of the reference's per-name map is
+    ``features[:, :, k - 1:k]``."""
+    lib = _io_lib.load()
+    with open(path, 'rb') as f:
+        text = f.read()
+    ctext = ctypes.c_char_p(text)
+    q = _io_lib.check(lib.tfr_io_libsvm_load(ctext, len(text), list_size, num_features, None, None, None),
+                      'tfr_io_libsvm_load')
+    feats = np.zeros((q, list_size, num_features), dtype=np.float32)
+    labels = np.full((q, list_size), _PADDING_LABEL, dtype=np.float32)
+    stats = np.zeros(2, dtype=np.int64)
+    _io_lib.check(lib.tfr_io_libsvm_load(ctext, len(text), list_size, num_features, feats.ctypes.data,
+                                         labels.ctypes.data, stats.ctypes.data), 'tfr_io_libsvm_load')
+    return torch.from_numpy(feats), torch.from_numpy(labels)

@@ -119,6 +119,11 @@ def parse_keys_and_weights(key: str) -> Dict[str, float]:
     return dict(_parse(p) for p in key.split(','))
 
 
+def shuffle_valid_indices(is_valid, seed=None):
+    """utils.py:198-200."""
+    return organize_valid_indices(is_valid, shuffle=True, seed=seed)
+
+
 def organize_valid_indices(is_valid, shuffle=True, seed=None):
     """utils.py:203-230: per-row order that puts valid entries first (in index
     order, or shuffled).  Returns [B, L] column indices (the nd batch index is

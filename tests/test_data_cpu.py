@@ -1,0 +1,245 @@
+"""Input path: libtfr_io.so / ranking_amd.data against the pure-Python
+restatement (oracle/data_ref.py), against the golden fixture cut from the reference's own data
+files (tests/golden/elwc_golden.json) and, when /root/reference is present (build container
+only), against those files in full.  Integer / byte work: bit-exact."""
+import base64
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import data_ref as D
+from ranking_amd import _io_lib, data
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'elwc_golden.json')))
+REF = '/root/reference/tensorflow_ranking/examples/data'
+F32 = torch.float32
+
+
+def test_io_header_and_library_agree():
+    import re
+    text = open(os.path.join(ROOT, 'include', 'tfr_io.h')).read()
+    names = sorted(set(re.findall(r'\b(tfr_io_[a-z0-9_]+)\s*\(', text)))
+    lib = _io_lib.load()
+    for n in names:
+        assert hasattr(lib, n), n
+    assert names == sorted(_io_lib.EXPORTED_SYMBOLS)
+    assert lib.tfr_io_abi_version() >= 1
+
+
+def test_crc32c_known_answers():
+    assert data.crc32c(b'123456789') == 0xE3069283            # the CRC-32C check value
+    assert data.crc32c(b'') == 0
+    assert data.crc32c(bytes(32)) == 0x8A9136AA               # RFC 3720 B.4: 32 zero bytes
+    assert data.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43      # RFC 3720 B.4: 32 0xff bytes
+    rng = np.random.RandomState(0)
+    for n in (1, 7, 8, 9, 63, 64, 1000):
+        b = rng.bytes(n)
+        assert data.crc32c(b) == D.crc32c(b)
+        assert data.masked_crc32c(b) == D.masked_crc32c(b)
+
+
+def test_tfrecord_round_trip_and_corruption(tmp_path):
+    recs = [b'', b'a', bytes(range(256)) * 3, b'x' * 100000]
+    p = str(tmp_path / 'a.tfrecord')
+    data.write_tfrecord(p, recs)
+    assert open(p, 'rb').read() == D.write_tfrecord(recs)
+    assert data.read_tfrecord(p) == recs
+    raw = bytearray(open(p, 'rb').read())
+    raw[16 + 17 + 12 + 5] ^= 0x01                            # flip a payload bit of the third record
+    open(p, 'wb').write(bytes(raw))
+    with pytest.raises(_io_lib.TfrIoError):
+        data.read_tfrecord(p)
+    assert len(data.read_tfrecord(p, verify_crc=False)) == 4
+    open(p, 'wb').write(bytes(raw[:-3]))                       # truncated tail
+    with pytest.raises(_io_lib.TfrIoError):
+        data.read_tfrecord(p, verify_crc=False)
+    open(p, 'wb').write(b'')
+    assert data.read_tfrecord(p) == []
+
+
+def _spec(names, default=0.0, width=1):
+    return {n: data.FixedLenFeature([width], F32, default) for n in names}
+
+
+def test_golden_records_decode_like_the_oracle():
+    recs = [base64.b64decode(s) for s in GOLDEN['records_b64']]
+    names = sorted({k for d in GOLDEN['decoded'] for e in d['examples'] for k in e})
+    assert 'utility' in names and len(names) > 100           # sparse: only the non-zero features are stored
+    spec = _spec([n for n in names if n != 'utility'])
+    spec['utility'] = data.FixedLenFeature([1], F32, -1.0)
+    for list_size in (None, 3, 9, 12):
+        got = data.parse_from_example_list(recs, list_size=list_size, example_feature_spec=spec,
+                                           size_feature_name='n', mask_feature_name='mask')
+        L = got['utility'].shape[1]
+        assert L == (9 if list_size is None else list_size)
+        assert got['n'].tolist() == [4, 4, 9]
+        for b, d in enumerate(GOLDEN['decoded']):
+            for i in range(L):
+                assert bool(got['mask'][b, i]) == (i < len(d['examples']))
+                for k in names:
+                    want = (d['examples'][i].get(k, [None, []])[1] if i < len(d['examples']) else [])
+                    want = np.float32(want[0]) if want else np.float32(-1.0 if k == 'utility' else 0.0)
+                    assert got[k][b, i, 0].item() == want, (b, i, k)
+    # and the oracle's own batch parser agrees wholesale
+    ospec = {k: (1, -1.0 if k == 'utility' else 0.0) for k in names}
+    feats, _, sizes, mask = D.parse_from_example_list(recs, 6, ospec)
+    got = data.parse_from_example_list(recs, list_size=6, example_feature_spec=spec, mask_feature_name='m')
+    for k in names:
+        assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32))
+    assert got['m'].tolist() == mask
+
+
+def test_synthetic_elwc_all_encodings(tmp_path):
+    rng = np.random.RandomState(1)
+    records, truth = [], []
+    for b in range(7):
+        n = int(rng.randint(0, 6))
+        exs = []
+        for i in range(n):
+            e = {'f': ('float', [float(np.float32(rng.randn())) for _ in range(3)]),
+                 'label': ('float', [float(rng.randint(0, 5))]),
+                 'id': ('int64', [int(rng.randint(-5, 1 << 40))]),
+                 'tok': ('bytes', [b'abc', b'd'])}
+            if rng.rand() < 0.3:
+                del e['f']                                   # absent -> default
+            exs.append(e)
+        ctx = {'q': ('float', [1.5, -2.5]), 'qlen': ('int64', [int(b)])} if b % 2 == 0 else None
+        records.append(D.encode_elwc(ctx, exs, packed=(b % 3 != 0)))
+        truth.append((ctx, exs))
+    ex_spec = {'f': data.FixedLenFeature([3], F32, 0.25), 'label': data.FixedLenFeature([1], F32, -1.0),
+               'id': data.FixedLenFeature([1], torch.int64, 0)}
+    cx_spec = {'q': data.FixedLenFeature([2], F32, 9.0), 'qlen': data.FixedLenFeature([1], torch.int64, -7)}
+    p = str(tmp_path / 'syn.tfrecord')
+    data.write_tfrecord(p, records)
+    recs = data.read_tfrecord(p)
+    assert recs == records
+    got = data.parse_from_example_list(recs, list_size=4, context_feature_spec=cx_spec, example_feature_spec=ex_spec,
+                                       size_feature_name='size', mask_feature_name='mask', num_threads=3)
+    assert got['f'].shape == (7, 4, 3) and got['id'].dtype == torch.int64 and got['q'].shape == (7, 2)
+    for b, (ctx, exs) in enumerate(truth):
+        assert got['size'][b].item() == len(exs)
+        for i in range(4):
+            assert bool(got['mask'][b, i]) == (i < len(exs))
+            if i < len(exs):
+                f = exs[i].get('f', ('float', [0.25] * 3))[1]
+                assert got['f'][b, i].tolist() == [np.float32(x) for x in f]
+                assert got['label'][b, i, 0].item() == exs[i]['label'][1][0]
+                assert got['id'][b, i, 0].item() == int(np.float32(exs[i]['id'][1][0]))   # via fp32 (documented)
+            else:
+                assert got['f'][b, i].tolist() == [0.25] * 3 and got['label'][b, i, 0].item() == -1.0
+        if ctx is None:
+            assert got['q'][b].tolist() == [9.0, 9.0] and got['qlen'][b, 0].item() == -7
+        else:
+            assert got['q'][b].tolist() == [1.5, -2.5] and got['qlen'][b, 0].item() == b
+    # error behaviour
+    with pytest.raises(ValueError):                           # wrong width (tf.io.parse_example raises too)
+        data.parse_from_example_list(records, list_size=4, example_feature_spec={'f': data.FixedLenFeature([2], F32, 0.)})
+    with pytest.raises(ValueError):                           # numeric spec on a bytes feature
+        data.parse_from_example_list(records, list_size=4, example_feature_spec={'tok': data.FixedLenFeature([1], F32, 0.)})
+    with pytest.raises(ValueError):
+        data.parse_from_example_list(records, example_feature_spec={})
+    with pytest.raises(_io_lib.TfrIoError):                   # truncated protobuf
+        data.parse_from_example_list([records[1][:-2]], list_size=4, example_feature_spec=ex_spec)
+    with pytest.raises(ValueError):
+        data.make_parsing_fn('sequence_example', example_feature_spec=ex_spec)
+
+
+def test_shuffle_examples_permutes_only_valid_items():
+    exs = [{'x': ('float', [float(i)])} for i in range(5)]
+    rec = D.encode_elwc(None, exs)
+    spec = {'x': data.FixedLenFeature([1], F32, -1.0)}
+    got = data.parse_from_example_list([rec] * 4, list_size=8, example_feature_spec=spec, shuffle_examples=True, seed=3)
+    x = got['x'][:, :, 0]
+    assert (x[:, 5:] == -1).all()
+    assert all(sorted(row[:5].tolist()) == [0., 1., 2., 3., 4.] for row in x)
+
+
+def test_dataset_builder_batches(tmp_path):
+    recs = [D.encode_elwc(None, [{'x': ('float', [float(q * 10 + i)])} for i in range(q % 3 + 1)]) for q in range(10)]
+    data.write_tfrecord(str(tmp_path / 'p0.tfrecord'), recs[:6])
+    data.write_tfrecord(str(tmp_path / 'p1.tfrecord'), recs[6:])
+    spec = {'x': data.FixedLenFeature([1], F32, -1.0)}
+    ds = data.build_ranking_dataset(str(tmp_path / 'p*.tfrecord'), data.ELWC, 4, None, spec, list_size=3,
+                                    mask_feature_name='mask', num_epochs=1, shuffle=False)
+    batches = list(ds)
+    assert [b['x'].shape[0] for b in batches] == [4, 4, 2]
+    allx = torch.cat([b['x'] for b in batches])[:, 0, 0].tolist()
+    assert allx == [float(q * 10) for q in range(10)]
+    ds = data.build_ranking_dataset(str(tmp_path / 'p*.tfrecord'), data.ELWC, 4, None, spec, list_size=3,
+                                    num_epochs=2, shuffle=True, shuffle_seed=5, drop_final_batch=True)
+    assert sum(1 for _ in ds) == 4
+
+
+def test_libsvm_golden_and_synthetic(tmp_path):
+    g = GOLDEN['libsvm']
+    p = str(tmp_path / 'head.txt')
+    open(p, 'w').write(GOLDEN['libsvm_head'])
+    feats, labels = data.load_libsvm_data(p, g['list_size'], g['num_features'])
+    assert labels.tolist() == g['labels']
+    want = torch.zeros_like(feats)
+    for b, d, k, v in g['nonzero']:
+        want[b, d, k] = v
+    assert torch.equal(feats, want)
+    text = '2 qid:7 1:0.5 3:-1e-3 # c\n0 qid:8 2:1\n\n1 qid:7 136:2.5\n3 qid:7 1:1\n'
+    open(p, 'w').write(text)
+    f2, l2 = data.load_libsvm_data(p, 2, 136)
+    of, ol, total, disc = D.load_libsvm_data(text, 2, 136)
+    assert l2.tolist() == ol and torch.equal(f2, torch.tensor(of, dtype=F32)) and (total, disc) == (4, 1)
+    open(p, 'w').write('1 qid:1 137:1\n')
+    with pytest.raises(ValueError):
+        data.load_libsvm_data(p, 2, 136)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference data files only exist in the build container')
+def test_against_the_reference_data_files_in_full():
+    for name in ('train_numerical_elwc.tfrecord', 'vali_numerical_elwc.tfrecord', 'test_numerical_elwc.tfrecord'):
+        path = os.path.join(REF, name)
+        buf = open(path, 'rb').read()
+        want_records = D.read_tfrecord(buf)
+        recs = data.read_tfrecord(path)
+        assert recs == want_records
+        if name.startswith('train'):
+            assert len(recs) == GOLDEN['n_records_in_file'] and data.crc32c(buf) == GOLDEN['file_crc32c']
+        names = sorted({k for r in recs for e in D.decode_elwc(r)[1] for k in e})
+        ospec = {k: (1, -1.0 if k == 'utility' else 0.0) for k in names}
+        spec = {k: data.FixedLenFeature([1], F32, d) for k, (w, d) in ospec.items()}
+        feats, _, sizes, mask = D.parse_from_example_list(recs, None, ospec)
+        got = data.parse_from_example_list(recs, example_feature_spec=spec, size_feature_name='n', mask_feature_name='m')
+        assert got['n'].tolist() == sizes and got['m'].tolist() == mask
+        for k in names:
+            assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), k
+    for name in ('train.txt', 'vali.txt', 'test.txt'):
+        text = open(os.path.join(REF, name)).read()
+        of, ol, _, _ = D.load_libsvm_data(text, 10, 136)
+        f, l = data.load_libsvm_data(os.path.join(REF, name), 10, 136)
+        assert l.tolist() == ol and torch.equal(f, torch.tensor(of, dtype=F32))
+
+
+def test_synthetic_bench_batch_survives_the_elwc_round_trip(tmp_path):
+    """The bench / parity inputs (tests.common.make_batch + U(-1,1) features) written as ELWC
+    TFRecords and read back through the native parser are bit-identical: "identical synthetic
+    ELWC inputs" (BASELINE.json north_star) is literal."""
+    from tests.common import make_batch
+    B, L, F = 6, 40, 136
+    labels, _ = make_batch(B, L, seed=12)
+    g = torch.Generator().manual_seed(12)
+    feats = torch.rand((B, L, F), generator=g) * 2 - 1
+    records = []
+    for b in range(B):
+        n = int((labels[b] >= 0).sum())
+        exs = [{'x': ('float', feats[b, i].tolist()), 'utility': ('float', [labels[b, i].item()])} for i in range(n)]
+        records.append(D.encode_elwc(None, exs))
+    p = str(tmp_path / 'syn.tfrecord')
+    data.write_tfrecord(p, records)
+    spec = {'x': data.FixedLenFeature([F], F32, 0.0), 'utility': data.FixedLenFeature([1], F32, -1.0)}
+    got = data.parse_from_example_list(data.read_tfrecord(p), list_size=L, example_feature_spec=spec,
+                                       mask_feature_name='mask')
+    assert torch.equal(got['utility'][:, :, 0], labels)
+    assert torch.equal(got['mask'], labels >= 0)
+    valid = (labels >= 0).unsqueeze(-1)
+    assert torch.equal(torch.where(valid, got['x'], torch.zeros(())), torch.where(valid, feats, torch.zeros(())))
