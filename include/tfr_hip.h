@@ -90,6 +90,13 @@ int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t*
                         float temperature, int lanes_per_row, float* loss_out, float* weight_out,
                         float* dlogits_out, void* stream);
 
+/* losses_impl.ApproxMRRLoss._compute_unreduced_loss_impl fused with its backward
+ * (losses_impl.py:77-106, 1606-1632): loss_b = -sum_i (l_i / sum l) / approx_rank_i; same
+ * conventions as tfr_approx_ndcg_f32 (temperature applied inside, weight_out = 1{sum label > 0}). */
+int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* mask,
+                       const float* list_scale, int B, int L, float temperature, float* loss_out,
+                       float* weight_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

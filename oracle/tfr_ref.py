@@ -589,6 +589,28 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
+class ApproxMRRLoss(_ListwiseLoss):
+    """losses_impl.py:1606-1632."""
+
+    def __init__(self, name=None, lambda_weight=None, temperature=0.1, ragged=False):
+        super().__init__(name, lambda_weight, temperature, ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits,
+                             -1e3 * torch.ones_like(logits)
+                             + logits.min(dim=-1, keepdim=True).values)
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        labels = torch.where(nonzero_mask.unsqueeze(1), labels, _EPSILON * torch.ones_like(labels))
+        rr = 1. / approx_ranks(logits)
+        rr = (rr * labels).sum(dim=-1, keepdim=True)
+        mrr = rr / labels.sum(dim=-1, keepdim=True)
+        return -mrr, nonzero_mask.to(logits.dtype).reshape(-1, 1)
+
+
 class _PointwiseLoss(_RankingLoss):
     """losses_impl.py:1284-1321."""
 

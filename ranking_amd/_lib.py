@@ -34,6 +34,8 @@ _SIGNATURES = {
                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                             + [ctypes.c_int] + [ctypes.c_void_p] * 4),
+    'tfr_approx_mrr_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                           + [ctypes.c_void_p] * 4),
     'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                   + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),

@@ -28,6 +28,9 @@
 
 using namespace tfr;
 
+#define TFR_APPROX_NDCG 0
+#define TFR_APPROX_MRR 1
+
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
@@ -91,7 +94,7 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
                                    const uint8_t* __restrict__ mask, const float* __restrict__ inv_log1p,
                                    const float* __restrict__ list_scale, int L, int Lp, int P,
                                    float temperature, int C, float* __restrict__ loss_out,
-                                   float* __restrict__ weight_out, float* __restrict__ dlogits_out) {
+                                   float* __restrict__ weight_out, float* __restrict__ dlogits_out, int metric) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Smem s = carve(smem_raw, Lp, P);
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = T >> 6;
@@ -117,21 +120,29 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
   if (!nonzero) lmax = 1e-10f;                       // labels := 1e-10 everywhere (:1598-1599)
 
   // ---- 2. gains (safe gain :33-49) and inverse max DCG (:109-134): sort the gains.
-  const float g0 = exp2f(-lmax);
-  for (int i = tid; i < P; i += T) {
-    float g = 0.f;
-    if (i < L) {
-      const float labc = nonzero ? s.Lb[i] : 1e-10f;
-      g = exp2f(labc - lmax) - g0;
-      s.Lb[i] = g;                                    // Lb now holds the gain
+  // (ApproxMRR, :1606-1632: the cleaned labels and 1 / their sum instead.)
+  float inv_max_dcg;
+  if (metric == TFR_APPROX_MRR) {
+    for (int i = tid; i < L; i += T) s.Lb[i] = nonzero ? s.Lb[i] : 1e-10f;
+    __syncthreads();
+    inv_max_dcg = 1.0f / (nonzero ? lsum : (float)L * 1e-10f);
+  } else {
+    const float g0 = exp2f(-lmax);
+    for (int i = tid; i < P; i += T) {
+      float g = 0.f;
+      if (i < L) {
+        const float labc = nonzero ? s.Lb[i] : 1e-10f;
+        g = exp2f(labc - lmax) - g0;
+        s.Lb[i] = g;                                    // Lb now holds the gain
+      }
+      s.sortbuf[i] = __float_as_uint(g);                // g >= 0: bit order == value order
     }
-    s.sortbuf[i] = __float_as_uint(g);                // g >= 0: bit order == value order
+    block_bitonic_sort_desc(s.sortbuf, P);
+    float idcg = 0.f;
+    for (int p = tid; p < L; p += T) idcg += __uint_as_float(s.sortbuf[p]) * inv_log1p[p];
+    idcg = block_sum(idcg, s.red);
+    inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
   }
-  block_bitonic_sort_desc(s.sortbuf, P);
-  float idcg = 0.f;
-  for (int p = tid; p < L; p += T) idcg += __uint_as_float(s.sortbuf[p]) * inv_log1p[p];
-  idcg = block_sum(idcg, s.red);
-  const float inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
 
   // ---- 3. stable compaction of the valid items.
   int n = 0;
@@ -204,10 +215,15 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
   float dcg = 0.f;
   for (int i = tid; i < n; i += T) {
     const float r = s.Rk[i];
-    const float lr = log1pf(r);
     const float g = s.CG[i];
-    dcg += g * (1.0f / lr);
-    s.A[i] = (g * inv_max_dcg) / (lr * lr * (1.0f + r));
+    if (metric == TFR_APPROX_MRR) {
+      dcg += g * (1.0f / r);
+      s.A[i] = (g * inv_max_dcg) / (r * r);
+    } else {
+      const float lr = log1pf(r);
+      dcg += g * (1.0f / lr);
+      s.A[i] = (g * inv_max_dcg) / (lr * lr * (1.0f + r));
+    }
   }
   dcg = block_sum(dcg, s.red);          // (ends with the barrier that publishes A)
   if (tid == 0) {
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
     float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
-    float* __restrict__ dlogits_out, int max_runs) {
+    float* __restrict__ dlogits_out, int max_runs, int metric) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
   float* E = X + Lp;                               // [Lp] exp(x - m)
@@ -391,19 +407,26 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   if (!nonzero) lmax = 1e-10f;
 
   TFR_STAMP(1);
-  // ---- 2. gains, ideal DCG through an in-register bitonic sort.
-  const float g0 = exp2f(-lmax);
-  uint32_t sk[IPL];
+  // ---- 2. gains and normaliser.  NDCG: safe gains + inverse ideal DCG (:33-49, :109-134);
+  // MRR (ApproxMRRLoss, :1606-1632): the cleaned labels themselves, normalised by their sum.
+  float inv_max_dcg;
+  if (metric == TFR_APPROX_MRR) {
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) {
-    const int e = lane + 64 * r;
-    float gg = 0.f;
-    if (e < L) gg = exp2f((nonzero ? g[r] : 1e-10f) - lmax) - g0;
-    g[r] = gg;
-    sk[r] = __float_as_uint(gg);
-  }
-  float idcg = 0.f;
-  {
+    for (int r = 0; r < IPL; ++r) g[r] = (lane + 64 * r < L) ? (nonzero ? g[r] : 1e-10f) : 0.f;
+    const float denom = nonzero ? lsum : (float)L * 1e-10f;
+    inv_max_dcg = 1.0f / denom;
+  } else {
+    const float g0 = exp2f(-lmax);
+    uint32_t sk[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int e = lane + 64 * r;
+      float gg = 0.f;
+      if (e < L) gg = exp2f((nonzero ? g[r] : 1e-10f) - lmax) - g0;
+      g[r] = gg;
+      sk[r] = __float_as_uint(gg);
+    }
+    float idcg = 0.f;
     float tbl[IPL];
 #pragma unroll
     for (int r = 0; r < IPL; ++r) tbl[r] = (lane + 64 * r < L) ? inv_log1p[lane + 64 * r] : 0.0f;
@@ -415,8 +438,8 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       for (int r = 0; r < IPL; ++r) t += __uint_as_float(sk[r]) * tbl[r];
       idcg = wsum(t);
     }
+    inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
   }
-  const float inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
 
   TFR_STAMP(2);
   // ---- 3. stable compaction of valid items into LDS (order = original index).
@@ -477,11 +500,17 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (active && c == 0) {
       const float r = acc + 0.5f;
-      const float lr = __builtin_amdgcn_logf(1.0f + r) * kLn2;      // log1p(r), r >= 1
-      const float ilr = fast_rcp(lr);
       const float gg = G[row];
-      dcg = __builtin_fmaf(gg, ilr, dcg);
-      A[row] = (gg * inv_max_dcg) * ilr * ilr * fast_rcp(1.0f + r);   // not read until step 5
+      if (metric == TFR_APPROX_MRR) {                                 // term = l / r, d term / d r = -l / r^2
+        const float ir = 1.0f / r;                                    // (per row, not per pair: exact division)
+        dcg = __builtin_fmaf(gg, ir, dcg);
+        A[row] = (gg * inv_max_dcg) / (r * r);
+      } else {
+        const float lr = __builtin_amdgcn_logf(1.0f + r) * kLn2;      // log1p(r), r >= 1
+        const float ilr = fast_rcp(lr);
+        dcg = __builtin_fmaf(gg, ilr, dcg);
+        A[row] = (gg * inv_max_dcg) * ilr * ilr * fast_rcp(1.0f + r);   // not read until step 5
+      }
     }
   }
   dcg = wave_sum_u(dcg);
@@ -551,12 +580,12 @@ int env_int(const char* name, int dflt);
 template <int IPL>
 int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
                 const float* list_scale, int B, int L, float temperature, int C, float* loss_out,
-                float* weight_out, float* dlogits_out, hipStream_t stream) {
+                float* weight_out, float* dlogits_out, hipStream_t stream, int metric) {
   const int Lp = ((L + 3) / 4) * 4 + 4;
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
-                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs);
+                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric);
   return (int)hipGetLastError();
 }
 
@@ -567,11 +596,11 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
-                                   const float* inv_log1p, const float* list_scale, int B, int L,
-                                   float temperature, int lanes_per_row, float* loss_out,
-                                   float* weight_out, float* dlogits_out, void* stream) {
-  if (!logits || !labels || !inv_log1p || !loss_out || !weight_out || B < 0 || L <= 0)
+static int approx_dispatch(int metric, const float* logits, const float* labels, const uint8_t* mask,
+                           const float* inv_log1p, const float* list_scale, int B, int L,
+                           float temperature, int lanes_per_row, float* loss_out,
+                           float* weight_out, float* dlogits_out, void* stream) {
+  if (!logits || !labels || (!inv_log1p && metric == TFR_APPROX_NDCG) || !loss_out || !weight_out || B < 0 || L <= 0)
     return TFR_EINVAL;
   if (!(temperature > 0.0f)) return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
@@ -586,11 +615,11 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
   // alone fills the chip with single waves (otherwise several waves share a list).
   if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
     hipStream_t st = (hipStream_t)stream;
-    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
-    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
-    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
-    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
-    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st);
+    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
+    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
+    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
+    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
+    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
   }
   int T = env_threads > 0 ? env_threads : (L <= 128 ? 64 : (L <= 512 ? 128 : 512));
   if (T % 64 || T > 1024) return TFR_EINVAL;
@@ -605,8 +634,24 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
   }
   hipLaunchKernelGGL(approx_ndcg_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, logits, labels,
                      mask, inv_log1p, list_scale, L, Lp, P, temperature, C, loss_out, weight_out,
-                     dlogits_out);
+                     dlogits_out, metric);
   return (int)hipGetLastError();
+}
+
+
+extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                   const float* inv_log1p, const float* list_scale, int B, int L,
+                                   float temperature, int lanes_per_row, float* loss_out,
+                                   float* weight_out, float* dlogits_out, void* stream) {
+  return approx_dispatch(TFR_APPROX_NDCG, logits, labels, mask, inv_log1p, list_scale, B, L, temperature,
+                         lanes_per_row, loss_out, weight_out, dlogits_out, stream);
+}
+
+extern "C" int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                  const float* list_scale, int B, int L, float temperature,
+                                  float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
+  return approx_dispatch(TFR_APPROX_MRR, logits, labels, mask, nullptr, list_scale, B, L, temperature, 0,
+                         loss_out, weight_out, dlogits_out, stream);
 }
 
 #ifdef TFR_PROFILE_STAMPS

@@ -50,6 +50,7 @@ _SUPPORTED = {
     RankingLossKey.SOFTMAX_LOSS: (losses_impl.SoftmaxLoss, True, False),
     RankingLossKey.SIGMOID_CROSS_ENTROPY_LOSS: (losses_impl.SigmoidCrossEntropyLoss, False, False),
     RankingLossKey.APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, False),
+    RankingLossKey.APPROX_MRR_LOSS: (losses_impl.ApproxMRRLoss, False, False),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
 }
 

@@ -513,6 +513,20 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return loss.unsqueeze(1), weight.unsqueeze(1)
 
 
+class ApproxMRRLoss(_ListwiseLoss):
+    """losses_impl.py:1606-1632; fused kernel tfr_approx_mrr_f32."""
+
+    def __init__(self, name, lambda_weight=None, temperature=0.1, ragged=False):
+        super().__init__(name, lambda_weight, temperature, ragged)
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        def runner(lg, want_grad):
+            loss, weight, d = _ops.approx_mrr(lg, labels, mask, None, temperature, want_grad)
+            return loss, d, (weight,)
+        loss, weight = _PerListLossFn.apply(logits, runner)
+        return loss.unsqueeze(1), weight.unsqueeze(1)
+
+
 class SoftmaxLoss(_ListwiseLoss):
     """losses_impl.py:1119-1197; fused kernel tfr_softmax_loss_f32."""
 

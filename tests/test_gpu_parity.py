@@ -645,3 +645,67 @@ def test_continuous_labels_take_the_sort_fallback(B, L):
         want.backward()
         assert_loss_close(got, want, what=type(mine).__name__)
         assert_grad_close(dl, lg.grad, what=type(mine).__name__)
+
+
+# ------------------------------------------------------------------ ApproxMRR
+@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('temperature', [0.1, 1.0])
+def test_approx_mrr_parity(B, L, temperature):
+    labels, logits = make_batch(B, L, seed=700 + L)
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.zeros_like(labels[0]), labels[0])
+        labels[1] = -1.0
+    oracle = R.ApproxMRRLoss(temperature=temperature)
+    ow = oracle._compute_unreduced_loss_impl(labels, logits / temperature)[1]
+    # lists whose labels sum to zero carry weight 0: compare the WEIGHTED loss (what every reduction uses)
+    want, want_g = _oracle_grad(
+        lambda lg: (lambda lw: lw[0] * lw[1])(oracle._compute_unreduced_loss_impl(labels, lg / temperature)), logits)
+    from ranking_amd import _ops
+    loss, weight, d = _ops.approx_mrr(logits.to(DEV), labels.to(DEV), None, None, temperature)
+    assert torch.equal(weight.cpu(), ow.reshape(-1))
+    assert_loss_close(loss * weight, want, what='approx_mrr loss')
+    # gradient: 1e-5 of the batch scale against the fp32 oracle, or -- where the fp32 oracle itself is
+    # further than that from an fp64 evaluation (tiny lists, 1/T = 10 amplification) -- as close to fp64
+    # as the oracle is (x4), like test_approx_ndcg_fp64_arbiter.
+    got_g = (d * weight.unsqueeze(1)).cpu().double()
+    _, g64 = _oracle_grad(
+        lambda lg: (lambda lw: lw[0] * lw[1])(oracle._compute_unreduced_loss_impl(labels.double(), lg / temperature)),
+        logits.double())
+    scale = g64.abs().max().item()
+    e_kernel = (got_g - g64).abs().max().item()
+    e_oracle = (want_g.double() - g64).abs().max().item()
+    # (sigma' = s - s*s, the form TF's SigmoidGrad uses too, loses ~ulp(1)/sigma' relative accuracy when
+    #  s -> 1; with 2-item lists nothing averages it out: 3e-5 of the scale is the fp32 floor here)
+    assert e_kernel <= max(3e-5 * scale + 1e-7, 4 * e_oracle), (e_kernel, e_oracle, scale)
+
+
+def test_approx_mrr_reference_goldens_and_keras():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    scores = t([[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]])
+    labels = t([[0., 0., 1.], [1., 0., 1.], [0., 0., 0.]])
+    loss = L.ApproxMRRLoss(None)
+    RED = L.Reduction
+    assert abs(loss.compute(labels, scores, None, RED.SUM).item() + ((1 / 2.) + 1 / 2. * (1 / 3. + 1 / 1.))) < 1e-5
+    assert abs(loss.compute(labels, scores, t([[2.], [1.], [1.]]), RED.SUM).item()
+               + (2 * 1 / 2. + 1 * 1 / 2. * (1 / 3. + 1 / 1.))) < 1e-5
+    got = L.ApproxMRRLoss(None, temperature=1.).compute(t([[0., 0., 1.]]), t([[1., 3., 2.]]), None,
+                                                        RED.SUM_BY_NONZERO_WEIGHTS, mask=t([[True, False, True]]))
+    assert abs(got.item() + 1. / (1. + 1. / (1. + math.exp(1.)))) < 1e-5
+    # losses_impl_test.py:556-580 (ragged inputs, here as their dense -1 padded form; NO temperature)
+    losses, w = loss.compute_per_list(t([[0., 0., 1.], [0., 2., -1.]]), t([[1., 3., 2.], [1., 3., 0.]]),
+                                      t([[2., 3., 4.], [1., 1., 0.]]))
+    assert_loss_close(losses, torch.tensor([-0.5, -0.893493]), 1e-5)
+    assert w.tolist() == [4., 1.]
+    k = K.ApproxMRRLoss()
+    assert abs(k(t([[1., 0.]]), t([[0.6, 0.8]])).item() + 0.53168947) < 1e-6          # keras/losses.py:1113-1118
+    assert abs(k(labels, scores).item() + ((1 / 2.) + 1 / 2. * (1 / 3. + 1 / 1.)) / 3.) < 1e-5
+    assert isinstance(K.get('approx_mrr_loss'), K.ApproxMRRLoss)
+    # fused training path == autograd path
+    lb, lg = make_batch(7, 33, seed=3)
+    v, d = k.loss_and_grad(lb.to(DEV), lg.to(DEV))
+    lgd = lg.to(DEV).requires_grad_(True)
+    out = k(lb.to(DEV), lgd)
+    out.backward()
+    assert abs(v.item() - out.item()) < 1e-6 and torch.allclose(d, lgd.grad, atol=1e-7)

@@ -175,6 +175,7 @@ RAGGED_W = [[2., 3., 4.], [1., 1.]]
     (R.PairwiseLogisticLoss, [0.813262, 0.126928], [8., 1.]),
     (R.SoftmaxLoss, [1.407606, 0.126928], [4., 2.]),
     (R.ApproxNDCGLoss, [-0.63093, -0.922917], [4., 1.]),
+    (R.ApproxMRRLoss, [-0.5, -0.893493], [4., 1.]),
 ])
 def test_compute_per_list_ragged(ctor, exp_l, exp_w):
     losses, weights = ctor(ragged=True).compute_per_list(RAGGED_LABELS, RAGGED_SCORES, RAGGED_W)
@@ -189,6 +190,7 @@ def test_compute_per_list_ragged(ctor, exp_l, exp_w):
     (R.PairwiseLogisticLoss, [[[0., 0., 0.], [0., 0., 0.], [0.313262, 1.313262, 0.]],
                               [[0., 0., 0.], [0.126928, 0., 0.], [0., 0., 0.]]]),
     (R.ApproxNDCGLoss, [[-0.63093], [-0.922917]]),
+    (R.ApproxMRRLoss, [[-0.5], [-0.893493]]),
 ])
 def test_compute_unreduced_loss_ragged(ctor, expected):
     losses, weights = ctor(ragged=True).compute_unreduced_loss(RAGGED_LABELS, RAGGED_SCORES)
@@ -512,3 +514,25 @@ def test_rolling_window_indices():  # model_test.py:52-73
     out = R.rolling_window_indices(3, 2, [3, 2, 1])
     assert out.tolist() == [[[0, 1], [1, 2], [2, 0]], [[0, 1], [1, 0], [0, 1]],
                             [[0, 0], [0, 0], [0, 0]]]
+
+
+# ------------------------------------------------------------------ ApproxMRR
+def test_approx_mrr_reference_literals():
+    """losses_impl_test.py:1729-1755 (the ragged :568/601 literals are in the parametrised tests above), keras/losses.py:1113-1124 doc values,
+    keras/losses_test.py:695-708."""
+    scores = torch.tensor([[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]])
+    labels = torch.tensor([[0., 0., 1.], [1., 0., 1.], [0., 0., 0.]])
+    weights = torch.tensor([[2.], [1.], [1.]])
+    loss = R.ApproxMRRLoss()
+    assert abs(loss.compute(labels, scores, None, R.Reduction.SUM).item()
+               + ((1 / 2.) + 1 / 2. * (1 / 3. + 1 / 1.))) < 1e-5
+    assert abs(loss.compute(labels, scores, weights, R.Reduction.SUM).item()
+               + (2 * 1 / 2. + 1 * 1 / 2. * (1 / 3. + 1 / 1.))) < 1e-5
+    got = R.ApproxMRRLoss(temperature=1.).compute(torch.tensor([[0., 0., 1.]]), torch.tensor([[1., 3., 2.]]), None,
+                                                  R.Reduction.SUM_BY_NONZERO_WEIGHTS,
+                                                  mask=torch.tensor([[True, False, True]]))
+    approxrank = 1. + 1. / (1. + math.exp(-(1. - 2.)))
+    assert abs(got.item() + 1. / approxrank) < 1e-5
+    assert abs(R.keras_loss_call(R.ApproxMRRLoss(), torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item()
+               + 0.53168947) < 1e-6
+    assert abs(R.keras_loss_call(loss, labels, scores).item() + ((1 / 2.) + 1 / 2. * (1 / 3. + 1 / 1.)) / 3.) < 1e-5
