@@ -37,6 +37,11 @@ extern "C" {
 #define TFR_GAIN_POW2M1 1     /* keras/utils.py:79  2^l - 1                   */
 #define TFR_GAIN_CUSTOM 2     /* caller passes gains[B,L] = gain_fn(clean l)  */
 
+/* loss_kind of tfr_pairwise_loss_f32 */
+#define TFR_PAIR_LOGISTIC 0
+#define TFR_PAIR_HINGE 1
+#define TFR_PAIR_SOFT_ZERO_ONE 2
+
 /* lambda_kind */
 #define TFR_LAMBDA_NONE 0
 #define TFR_LAMBDA_DCG 2      /* losses_impl.py:299-369 DCGLambdaWeight       */
@@ -115,6 +120,17 @@ int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const ui
                               int B, int L, float temperature,
                               float* row_loss_out, float* row_weight_out, float* nnz_out,
                               float* dlogits_out, void* stream);
+
+/* The same machinery for the other pairwise losses of losses_impl.py:936-958.
+ *   loss_kind  TFR_PAIR_LOGISTIC (PairwiseLogisticLoss), TFR_PAIR_HINGE (PairwiseHingeLoss :943-948,
+ *              relu(1 - d)), TFR_PAIR_SOFT_ZERO_ONE (PairwiseSoftZeroOneLoss :951-958, sigma(-d)). */
+int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
+                          const float* item_weights, const float* list_weights,
+                          int lambda_kind, int topn, float smooth_fraction, int normalized,
+                          int gain_kind, const float* gains, const float* discount,
+                          int B, int L, float temperature,
+                          float* row_loss_out, float* row_weight_out, float* nnz_out,
+                          float* dlogits_out, void* stream);
 
 /* losses_impl.SoftmaxLoss.precompute + _compute_unreduced_loss_impl fused with
  * the backward (losses_impl.py:1119-1197, 281-296).

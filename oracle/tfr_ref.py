@@ -490,10 +490,18 @@ class PairwiseLogisticLoss(_PairwiseLoss):
 
 
 class PairwiseHingeLoss(_PairwiseLoss):
-    """losses_impl.py:943-948 (used only to pin compute_per_list goldens)."""
+    """losses_impl.py:943-948."""
 
     def _pairwise_loss(self, pairwise_logits):
         return torch.relu(1 - pairwise_logits)
+
+
+class PairwiseSoftZeroOneLoss(_PairwiseLoss):
+    """losses_impl.py:951-958."""
+
+    def _pairwise_loss(self, pairwise_logits):
+        return torch.where(pairwise_logits > 0, 1. - torch.sigmoid(pairwise_logits),
+                           torch.sigmoid(-pairwise_logits))
 
 
 class _ListwiseLoss(_RankingLoss):

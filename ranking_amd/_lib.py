@@ -39,6 +39,9 @@ _SIGNATURES = {
     'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                   + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),
+    'tfr_pairwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
+                              + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
+                              + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                              + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
     'tfr_gumbel_sample_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_uint64] * 2 + [ctypes.c_int] * 3

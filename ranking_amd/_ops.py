@@ -15,6 +15,7 @@ from . import _lib
 
 GAIN_IDENTITY, GAIN_POW2M1, GAIN_CUSTOM = 0, 1, 2
 LAMBDA_NONE, LAMBDA_LABELDIFF, LAMBDA_DCG = 0, 1, 2
+PAIR_LOGISTIC, PAIR_HINGE, PAIR_SOFT_ZERO_ONE = 0, 1, 2
 MAX_TOPN = 8
 
 
@@ -198,8 +199,8 @@ def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want
 def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
-                      want_grad=True, want_rows=True, want_aux=True):
-    """want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
+                      want_grad=True, want_rows=True, want_aux=True, loss_kind=0):
+    """loss_kind: PAIR_LOGISTIC / PAIR_HINGE / PAIR_SOFT_ZERO_ONE.  want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
     SUM_BY_NONZERO_WEIGHTS reductions and compute_per_list need them): a leaner kernel variant."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
@@ -212,12 +213,12 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
     row_weight = torch.empty((B, L), dtype=torch.float32, device=dev) if (want_rows and want_aux) else None
     nnz = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
-    rc = _lib.load().tfr_pairwise_logistic_f32(
-        _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
+    rc = _lib.load().tfr_pairwise_loss_f32(
+        int(loss_kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
         int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
         _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
         _ptr(nnz), _ptr(dlogits), _stream())
-    _lib.check(rc, 'tfr_pairwise_logistic_f32')
+    _lib.check(rc, 'tfr_pairwise_loss_f32')
     return row_loss, row_weight, nnz, dlogits
 
 

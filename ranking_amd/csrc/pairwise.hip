@@ -24,6 +24,7 @@ using namespace tfr;
 namespace {
 
 constexpr float kLog2e = 1.44269504088896340736f;
+constexpr float kLn2 = 0.69314718055994530942f;
 
 // LDS hand-off inside ONE wavefront (its lanes exchange data through the wave's private LDS
 // slice): DS operations of a wave complete in order, so draining the counter is enough.
@@ -34,7 +35,7 @@ struct PwArgs {
   const float* item_weights; const float* list_weights;
   int lambda_kind; int topn; float smooth; int normalized; int gain_kind;
   const float* gains; const float* discount;
-  int L; int Lp; int P; float temperature; int C;
+  int L; int Lp; int P; float temperature; int C; int kind;
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
 };
 
@@ -44,7 +45,34 @@ __host__ __device__ inline size_t pw_smem_bytes(int Lp, int P) {
   return 256 + (size_t)P * 8 + (size_t)Lp * 4 * 12 + (size_t)Lp * 2 + 32;
 }
 
-constexpr float kLn2 = 0.69314718055994530942f;
+// Pairwise loss of a preference pair (losses_impl.py:936-958) as a function of the score
+// difference d0 = x_row - x_col:  `loss` = loss(t = d0) (only used when the row item is the
+// preferred one) and `sel` = -d loss / d t at t = +d0 when the row is preferred (`hi`) and at
+// t = -d0 otherwise, so that row gradient += (w_lo - w_hi) * sel.
+//   logistic      : loss = relu(-t) + log1p(exp(-|t|)),  -loss' = sigma(-t)
+//   hinge         : loss = relu(1 - t),                  -loss' = 1[t < 1]        (relu'(0) = 0)
+//   soft zero-one : loss = sigma(-t),                    -loss' = sigma(t) sigma(-t)
+__device__ __forceinline__ void pair_loss(const int kind, const float d0, const bool hi, float& loss, float& sel) {
+  if (kind == TFR_PAIR_HINGE) {
+    loss = fmaxf(1.0f - d0, 0.0f);
+    const float t = hi ? d0 : -d0;
+    sel = (t < 1.0f) ? 1.0f : 0.0f;
+    return;
+  }
+  const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
+  const float w1 = 1.0f + e;
+  const float q = __builtin_amdgcn_rcpf(w1);
+  const float eq = e * q;
+  const bool pos = d0 >= 0.0f;
+  if (kind == TFR_PAIR_SOFT_ZERO_ONE) {
+    loss = pos ? eq : q;                                           // sigma(-d0)
+    sel = q * eq;
+    return;
+  }
+  // relu(-d) + log1p(exp(-|d|)); fl(1 + e) costs <= 6e-8 absolute per pair, far inside 1e-5
+  loss = __builtin_fmaf(__builtin_amdgcn_logf(w1), kLn2, fmaxf(-d0, 0.0f));
+  sel = (pos == hi) ? eq : q;                                      // hi: sigma(-d0), lo: sigma(+d0)
+}
 
 // One (row i, column j) term.  rec = (x, raw label, gain, item weight); rk = signed
 // rank as float (negative: label-invalid item), dp = D'(rank).
@@ -52,7 +80,7 @@ template <int LAMBDA, bool GENERIC>
 __device__ __forceinline__ void pair_term(const float4 ri, const float rki, const float dpi,
                                           const float4 rj, const float rkj, const float dpj,
                                           const float* __restrict__ U, const float ftopn,
-                                          const float one_minus_s, const float smooth, const float fL,
+                                          const float one_minus_s, const float smooth, const float fL, const int kind,
                                           float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
   float wl = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
@@ -75,22 +103,14 @@ __device__ __forceinline__ void pair_term(const float4 ri, const float rki, cons
   const bool hi = ri.y > rj.y;            // row item preferred
   const bool lo = rj.y > ri.y;            // column item preferred
   const float d0 = ri.x - rj.x;
-  const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
-  const float w1 = 1.0f + e;
-  const float q = __builtin_amdgcn_rcpf(w1);
-  // log1p(e) = log(w1) - ((w1 - 1) - e) / w1   (first-order compensation of fl(1 + e))
-  const float l1p = __builtin_fmaf(-((w1 - 1.0f) - e), q, __builtin_amdgcn_logf(w1) * kLn2);
-  const float loss = fmaxf(-d0, 0.0f) + l1p;                       // only used when hi (d = d0)
-  const float eq = e * q;
-  const float sig_hi = (d0 >= 0.0f) ? eq : q;                      // sigma(-d0)
-  const float sig_lo = (d0 >= 0.0f) ? q : eq;                      // sigma(+d0)
+  float loss, sel;
+  pair_loss(kind, d0, hi, loss, sel);
   const float ww_hi = hi ? wl * ri.w : 0.0f;
   const float ww_lo = lo ? wl * rj.w : 0.0f;
   acc_loss = __builtin_fmaf(ww_hi, loss, acc_loss);
   acc_w += ww_hi;
   acc_nz += (ww_hi != 0.0f) ? 1.0f : 0.0f;
-  acc_g = __builtin_fmaf(-ww_hi, sig_hi, acc_g);
-  acc_g = __builtin_fmaf(ww_lo, sig_lo, acc_g);
+  acc_g = __builtin_fmaf(ww_lo - ww_hi, sel, acc_g);
 }
 
 // The same term for the rank-ordered wave kernel: ranks are positions (ai, aj), the
@@ -102,7 +122,8 @@ template <int LAMBDA, bool GENERIC, bool AUX, bool ITEMW>
 __device__ __forceinline__ void pair_term_ranked(const float4 ri, const float2 qi, const float ai, const float4 rj,
                                                  const float2 qj, const float aj, const float u, const float ftopn,
                                                  const float one_minus_s, const float smooth, const float fL,
-                                                 float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
+                                                 const int kind, float& acc_loss, float& acc_w, float& acc_nz,
+                                                 float& acc_g) {
   float wl = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
     if (GENERIC) {
@@ -121,14 +142,8 @@ __device__ __forceinline__ void pair_term_ranked(const float4 ri, const float2 q
   const bool hi = ri.y > rj.y;            // row item preferred
   const bool lo = rj.y > ri.y;            // column item preferred
   const float d0 = ri.x - rj.x;
-  const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
-  const float w1 = 1.0f + e;
-  const float q = __builtin_amdgcn_rcpf(w1);
-  // relu(-d) + log1p(exp(-|d|)); fl(1 + e) costs <= 6e-8 absolute per pair, far inside 1e-5
-  const float loss = __builtin_fmaf(__builtin_amdgcn_logf(w1), kLn2, fmaxf(-d0, 0.0f));
-  const float eq = e * q;
-  const bool pos = d0 >= 0.0f;
-  const float sel = (pos == hi) ? eq : q;                          // hi: sigma(-d0), lo: sigma(+d0)
+  float loss, sel;
+  pair_loss(kind, d0, hi, loss, sel);
   float ww_hi, ww_lo;
   if (ITEMW) { ww_hi = hi ? wl * ri.w : 0.0f; ww_lo = lo ? wl * rj.w : 0.0f; }
   else       { ww_hi = hi ? wl : 0.0f;        ww_lo = lo ? wl : 0.0f; }
@@ -276,9 +291,9 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       const int j0 = c + it * C, j1 = j0 + C;
       const float4 r0 = rec0[j0], r1 = rec0[j1];
       const float2 q0 = rec1[j0], q1 = rec1[j1];
-      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r0, q0.y, q0.x, U, ftopn, one_minus_s, a.smooth, fL,
+      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r0, q0.y, q0.x, U, ftopn, one_minus_s, a.smooth, fL, a.kind,
                                  acc_loss, acc_w, acc_nz, acc_g);
-      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r1, q1.y, q1.x, U, ftopn, one_minus_s, a.smooth, fL,
+      pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r1, q1.y, q1.x, U, ftopn, one_minus_s, a.smooth, fL, a.kind,
                                  acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
@@ -344,7 +359,8 @@ __device__ __forceinline__ void wave_sort_desc_u32(uint32_t (&a)[IPL], int lane)
   }
 }
 
-template <int IPL, int LAMBDA, bool GENERIC, bool AUX, bool ITEMW>
+// KIND: TFR_PAIR_LOGISTIC at compile time (the hot configuration), or -1 = a.kind at run time.
+template <int IPL, int LAMBDA, bool GENERIC, bool AUX, bool ITEMW, int KIND>
 __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   // blockDim.x = 64 * S: S wavefronts share one list when the batch alone cannot fill the
   // chip.  Every wave repeats the (cheap) per-list set-up in its OWN LDS slice -- no workgroup
@@ -521,6 +537,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   const float fL = (float)L;
   const float one_minus_s = 1.0f - a.smooth;
   const float ftopn = (float)topn;
+  const int kind = (KIND >= 0) ? KIND : a.kind;
   float nnz_local = 0.f;
   for (int row0 = wave * rows_per_pass; row0 < n; row0 += S * rows_per_pass) {
     const int row = row0 + rsub;
@@ -537,9 +554,9 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       float2 q0 = make_float2(0.f, 1.f), q1 = q0;
       if (GENERIC) { q0 = auxS[j0]; q1 = auxS[j1]; }
       pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r0, q0, (float)(j0 + 1), u0, ftopn,
-                                                    one_minus_s, a.smooth, fL, acc_loss, acc_w, acc_nz, acc_g);
+                                                    one_minus_s, a.smooth, fL, kind, acc_loss, acc_w, acc_nz, acc_g);
       pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r1, q1, (float)(j1 + 1), u1, ftopn,
-                                                    one_minus_s, a.smooth, fL, acc_loss, acc_w, acc_nz, acc_g);
+                                                    one_minus_s, a.smooth, fL, kind, acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
       acc_loss += __shfl_xor(acc_loss, o, 64);
@@ -587,12 +604,15 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
                        (a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) || a.mask != nullptr);
   const bool aux = a.row_weight != nullptr || a.nnz != nullptr;
   const bool itemw = generic || a.item_weights != nullptr || a.mask != nullptr;
-#define PW_L2(LAM, GEN, AUX, IW) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, AUX, IW>), dim3(B), dim3(64 * S), lds, stream, a)
-#define PW_LAUNCH(LAM, GEN) do { if (aux) { if (itemw) PW_L2(LAM, GEN, true, true); else PW_L2(LAM, GEN, true, false); } \
+#define PW_L2(LAM, GEN, AUX, IW) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, AUX, IW, TFR_PAIR_LOGISTIC>), dim3(B), dim3(64 * S), lds, stream, a)
+#define PW_RT(LAM, GEN) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, true, true, -1>), dim3(B), dim3(64 * S), lds, stream, a)
+#define PW_LAUNCH(LAM, GEN) do { if (a.kind != TFR_PAIR_LOGISTIC) PW_RT(LAM, GEN);                              \
+                                 else if (aux) { if (itemw) PW_L2(LAM, GEN, true, true); else PW_L2(LAM, GEN, true, false); } \
                                  else { if (itemw) PW_L2(LAM, GEN, false, true); else PW_L2(LAM, GEN, false, false); } } while (0)
   if (a.lambda_kind == TFR_LAMBDA_DCG) { if (generic) PW_LAUNCH(TFR_LAMBDA_DCG, true); else PW_LAUNCH(TFR_LAMBDA_DCG, false); }
   else if (a.lambda_kind == TFR_LAMBDA_LABELDIFF) PW_LAUNCH(TFR_LAMBDA_LABELDIFF, false);
   else PW_LAUNCH(TFR_LAMBDA_NONE, false);
+#undef PW_RT
 #undef PW_L2
 #undef PW_LAUNCH
   return (int)hipGetLastError();
@@ -605,7 +625,7 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const uint8_t* mask,
+static int pairwise_dispatch(int kind, const float* logits, const float* labels, const uint8_t* mask,
                                          const float* item_weights, const float* list_weights,
                                          int lambda_kind, int topn, float smooth_fraction,
                                          int normalized, int gain_kind, const float* gains,
@@ -613,6 +633,7 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
                                          float* dlogits_out, void* stream) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
+  if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_SOFT_ZERO_ONE) return TFR_EINVAL;
   if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG &&
       lambda_kind != TFR_LAMBDA_LABELDIFF) return TFR_EINVAL;
   if (lambda_kind == TFR_LAMBDA_DCG) {
@@ -634,7 +655,7 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
     w.smooth = smooth_fraction; w.normalized = normalized; w.gain_kind = gain_kind; w.gains = gains;
     const int c2 = (2 * C > 4) ? 2 * C : 4;
     w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
-    w.temperature = temperature; w.C = C; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
+    w.temperature = temperature; w.C = C; w.kind = kind; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
     w.nnz = nnz_out; w.dlogits = dlogits_out;
     hipStream_t st = (hipStream_t)stream;
     if (L <= 64) return launch_pw_wave<1>(w, B, st);
@@ -648,7 +669,7 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
   a.list_weights = list_weights; a.lambda_kind = lambda_kind; a.topn = topn;
   a.smooth = smooth_fraction; a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains;
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
-  a.temperature = temperature; a.C = C; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
+  a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
   a.nnz = nnz_out; a.dlogits = dlogits_out;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
@@ -670,4 +691,28 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
   else PW_BLOCK(TFR_LAMBDA_NONE, false);
 #undef PW_BLOCK
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                         const float* item_weights, const float* list_weights,
+                                         int lambda_kind, int topn, float smooth_fraction,
+                                         int normalized, int gain_kind, const float* gains,
+                                         const float* discount, int B, int L, float temperature,
+                                         float* row_loss_out, float* row_weight_out, float* nnz_out,
+                                         float* dlogits_out, void* stream) {
+  return pairwise_dispatch(TFR_PAIR_LOGISTIC, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
+                           smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, stream);
+}
+
+extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
+                                     const float* item_weights, const float* list_weights,
+                                     int lambda_kind, int topn, float smooth_fraction,
+                                     int normalized, int gain_kind, const float* gains,
+                                     const float* discount, int B, int L, float temperature,
+                                     float* row_loss_out, float* row_weight_out, float* nnz_out,
+                                     float* dlogits_out, void* stream) {
+  return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
+                           smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, stream);
 }

@@ -271,7 +271,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
                 list_w = list_w * torch.broadcast_to(sample_weight.reshape(-1), (b,))
         row_loss, _, _, dlogits = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-            want_grad=True, want_aux=False, **lam)
+            want_grad=True, want_aux=False, loss_kind=self._loss._fused_kind, **lam)
         return row_loss.sum(), dlogits
 
 

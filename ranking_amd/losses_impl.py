@@ -404,7 +404,7 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
         def runner(lg, want_grad):
             row_loss, row_weight, nnz, d = _ops.pairwise_logistic(
                 lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad,
-                want_aux=want_aux, **lam)
+                want_aux=want_aux, loss_kind=self._fused_kind, **lam)
             return row_loss.sum(dim=1), d, (row_loss, row_weight, nnz)
 
         return _PerListLossFn.apply(logits, runner)
@@ -445,21 +445,23 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
 
 class PairwiseLogisticLoss(_PairwiseLoss):
     """losses_impl.py:933-940; fused kernel tfr_pairwise_logistic_f32."""
-    _fused_kind = 'logistic'
+    _fused_kind = _ops.PAIR_LOGISTIC
 
     def _pairwise_loss(self, pairwise_logits):
         return torch.relu(-pairwise_logits) + torch.log1p(torch.exp(-torch.abs(pairwise_logits)))
 
 
 class PairwiseHingeLoss(_PairwiseLoss):
-    """losses_impl.py:943-948 (materialised path only; SURVEY 8f "next")."""
+    """losses_impl.py:943-948; fused kernel tfr_pairwise_loss_f32(TFR_PAIR_HINGE)."""
+    _fused_kind = _ops.PAIR_HINGE
 
     def _pairwise_loss(self, pairwise_logits):
         return torch.relu(1 - pairwise_logits)
 
 
 class PairwiseSoftZeroOneLoss(_PairwiseLoss):
-    """losses_impl.py:951-958 (materialised path only; SURVEY 8f "next")."""
+    """losses_impl.py:951-958; fused kernel tfr_pairwise_loss_f32(TFR_PAIR_SOFT_ZERO_ONE)."""
+    _fused_kind = _ops.PAIR_SOFT_ZERO_ONE
 
     def _pairwise_loss(self, pairwise_logits):
         return torch.where(pairwise_logits > 0, 1. - torch.sigmoid(pairwise_logits),

@@ -709,3 +709,58 @@ def test_approx_mrr_reference_goldens_and_keras():
     out = k(lb.to(DEV), lgd)
     out.backward()
     assert abs(v.item() - out.item()) < 1e-6 and torch.allclose(d, lgd.grad, atol=1e-7)
+
+
+# ------------------------------------------------------------------ hinge / soft zero-one
+@pytest.mark.parametrize('B,L', [(3, 2), (4, 7), (5, 50), (4, 200), (2, 300)])
+@pytest.mark.parametrize('kind', ['hinge', 'soft_zero_one'])
+@pytest.mark.parametrize('lam_idx', [0, 1, 3])
+@pytest.mark.parametrize('wkind', ['none', 'item'])
+def test_pairwise_other_losses_parity(B, L, kind, lam_idx, wkind):
+    labels, logits = make_batch(B, L, seed=800 + L)
+    mine_lam, their_lam = _lambda_pairs()[lam_idx]
+    weights = make_weights(B, L, seed=L) if wkind == 'item' else None
+    octor = R.PairwiseHingeLoss if kind == 'hinge' else R.PairwiseSoftZeroOneLoss
+    mctor = ra().losses_impl.PairwiseHingeLoss if kind == 'hinge' else ra().losses_impl.PairwiseSoftZeroOneLoss
+    T = 0.7
+    oracle = octor(lambda_weight=their_lam(), temperature=T)
+
+    def oracle_rows(lg):
+        losses, w = oracle._compute_unreduced_loss_impl(labels, lg / T, labels >= 0)
+        nw = oracle._normalize_weights_impl(labels, weights)
+        return (losses * w * nw).sum(dim=2), (w * nw)
+
+    lg = logits.clone().requires_grad_(True)
+    want_rows, want_w = oracle_rows(lg)
+    want_rows.sum().backward()
+    loss = mctor(None, lambda_weight=mine_lam(), temperature=T)
+    lgd = logits.to(DEV).requires_grad_(True)
+    list_loss, row_loss, row_weight, nnz = loss._fused(labels.to(DEV), lgd, None if weights is None else weights.to(DEV), None)
+    scale = max(1.0, want_rows.abs().max().item())
+    assert_loss_close(row_loss / scale, want_rows.detach() / scale, what='%s rows' % kind)
+    assert torch.equal(nnz.cpu(), (want_w != 0).sum(dim=(1, 2)).float())
+    list_loss.sum().backward()
+    # hinge: the subgradient at t == 1 is 0 on both sides; continuous scores never sit there
+    assert_grad_close(lgd.grad, lg.grad, what='%s grad' % kind)
+    got = loss.compute(labels.to(DEV), logits.to(DEV), None if weights is None else weights.to(DEV), 'weighted_mean')
+    want = oracle.compute(labels, logits, weights, R.Reduction.MEAN)
+    assert_loss_close(got, want, what='%s compute' % kind)
+
+
+def test_pairwise_other_losses_reference_goldens():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    scores = t([[1., 3., 2.], [1., 2., 3.]]); labels = t([[0., 0., 1.], [0., 0., 2.]])
+    for ctor, fn in [(L.PairwiseHingeLoss, lambda x: max(0, 1. - x)),
+                     (L.PairwiseSoftZeroOneLoss, lambda x: 1 / (1 + math.exp(x)))]:
+        loss = ctor(None)
+        got = loss.compute(labels, scores, None, L.Reduction.MEAN)                 # losses_impl_test.py:729-740, 819-830
+        assert abs(got.item() - (fn(1.) + fn(-1.) + fn(2.) + fn(1.)) / 4.) < 1e-6
+        got = loss.compute(labels, scores, t([[1.], [2.]]), L.Reduction.MEAN)     # :742-755, 832-845
+        assert abs(got.item() - (1. * (fn(1.) + fn(-1.)) + 2. * (fn(1.) + fn(2.))) / 6.) < 1e-6
+    assert abs(K.PairwiseHingeLoss()(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.6) < 1e-6             # keras/losses.py:350-354
+    assert abs(K.PairwiseSoftZeroOneLoss()(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.274917) < 1e-6  # :484-488
+    losses, w = L.PairwiseHingeLoss(None).compute_per_list(labels, scores, t([[2., 3., 4.], [1., 1., 1.]]))
+    assert_loss_close(losses, torch.tensor([1., 0.]), 1e-6)                          # losses_impl_test.py:530-541
+    assert w.tolist() == [8., 2.]

@@ -536,3 +536,24 @@ def test_approx_mrr_reference_literals():
     assert abs(R.keras_loss_call(R.ApproxMRRLoss(), torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item()
                + 0.53168947) < 1e-6
     assert abs(R.keras_loss_call(loss, labels, scores).item() + ((1 / 2.) + 1 / 2. * (1 / 3. + 1 / 1.)) / 3.) < 1e-5
+
+
+# ------------------------------------------------------------------ hinge / soft zero-one
+@pytest.mark.parametrize('ctor,fn', [
+    (R.PairwiseHingeLoss, lambda x: max(0, 1. - x)),                   # losses_impl_test.py:729-768
+    (R.PairwiseSoftZeroOneLoss, lambda x: 1 / (1 + math.exp(x))),     # losses_impl_test.py:819-858
+])
+def test_pairwise_hinge_and_soft_zero_one_reference_literals(ctor, fn):
+    scores = torch.tensor([[1., 3., 2.], [1., 2., 3.]])
+    labels = torch.tensor([[0., 0., 1.], [0., 0., 2.]])
+    loss = ctor()
+    got = loss.compute(labels, scores, None, R.Reduction.MEAN)
+    assert abs(got.item() - (fn(3. - 2.) + fn(1. - 2.) + fn(3. - 1.) + fn(3. - 2.)) / 4.) < 1e-6
+    got = loss.compute(labels, scores, torch.tensor([[1.], [2.]]), R.Reduction.MEAN)
+    assert abs(got.item() - (1. * (fn(3. - 2.) + fn(1. - 2.)) + 2. * (fn(3. - 2.) + fn(3. - 1.))) / 6.) < 1e-6
+
+
+def test_pairwise_keras_doc_values():
+    yt, yp = torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])
+    assert abs(R.keras_loss_call(R.PairwiseHingeLoss(), yt, yp).item() - 0.6) < 1e-6              # keras/losses.py:350-354
+    assert abs(R.keras_loss_call(R.PairwiseSoftZeroOneLoss(), yt, yp).item() - 0.274917) < 1e-6   # :484-488
