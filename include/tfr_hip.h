@@ -75,6 +75,26 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
                         float* ndcg_out, float* stats_out, void* stream);
 
+/* The sort-based metrics of metrics_impl.py behind one entry point; `kind`:
+ *   TFR_METRIC_NDCG / TFR_METRIC_MRR  = the two entry points above;
+ *   TFR_METRIC_DCG (:673-705)        metric_out = sum_{p<k} w gain discount (the caller divides by the list weight)
+ *   TFR_METRIC_HITS (:462-506)       TFR_METRIC_RECALL (:154-177, 539-561)   TFR_METRIC_PRECISION (:180-207, 564-586)
+ *   TFR_METRIC_MAP (:589-628)        TFR_METRIC_ARP (:509-536; stats_out[:, 2] = its per-list weight)
+ * stats_out [B, 3] = (sum w, sum rel, sum w*rel) with rel = gain (DCG), label (ARP) or 1{label >= 1}.
+ * list_size <= 1024 for the kinds other than NDCG / MRR (TFR_ETOOLARGE otherwise). */
+#define TFR_METRIC_NDCG 0
+#define TFR_METRIC_MRR 1
+#define TFR_METRIC_DCG 2
+#define TFR_METRIC_HITS 3
+#define TFR_METRIC_RECALL 4
+#define TFR_METRIC_PRECISION 5
+#define TFR_METRIC_MAP 6
+#define TFR_METRIC_ARP 7
+int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
+                        int weights_per_list, const uint8_t* mask, const float* gains,
+                        const float* discount, const int32_t* topn_host, int K, int B, int L,
+                        float* metric_out, float* stats_out, void* stream);
+
 /* metrics_impl.MRRMetric.compute (metrics_impl.py:429-459).
  *   mrr_out [K, B]; stats_out [B, 3] = (sum w, sum rel, sum w*rel), rel = 1{l>=1}. */
 int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,

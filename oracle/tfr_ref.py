@@ -816,6 +816,125 @@ class NDCGMetric(_RankingMetric):
         return per_list_ndcg, per_list_weights
 
 
+class HitsMetric(_RankingMetric):
+    """metrics_impl.py:462-506."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        sorted_labels, = sort_by_scores(predictions, [labels], topn=topn, mask=mask)
+        relevance = (sorted_labels >= 1.0).to(torch.float32)
+        hits = relevance.max(dim=1, keepdim=True).values
+        per_list_weights = _per_example_weights_to_per_list_weights(
+            weights=weights, relevance=(labels >= 1.0).to(torch.float32), row_sum=tree_sum)
+        return hits, per_list_weights
+
+
+class ARPMetric(_RankingMetric):
+    """metrics_impl.py:509-536 (row sums in the sorted order, tree_sum)."""
+
+    def __init__(self, name=None, ragged=False):
+        super().__init__(ragged)
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1]
+        sorted_labels, sorted_weights = sort_by_scores(predictions, [labels, weights], topn=topn, mask=mask)
+        weighted_labels = sorted_labels * sorted_weights
+        position = torch.arange(1, topn + 1, dtype=torch.float32) * torch.ones_like(weighted_labels)
+        per_list_weights = tree_sum(weighted_labels)
+        per_list_arp = _safe_div(tree_sum(position * weighted_labels), per_list_weights)
+        return per_list_arp, per_list_weights
+
+
+def _per_list_recall(labels, predictions, topn, mask):
+    """metrics_impl.py:154-177."""
+    sorted_labels = sort_by_scores(predictions, [labels], topn=topn, mask=mask)[0]
+    topn_positives = (sorted_labels >= 1.0).to(torch.float32)
+    rel = (labels >= 1.0).to(torch.float32)
+    return _safe_div(topn_positives.sum(dim=1, keepdim=True), rel.sum(dim=1, keepdim=True))
+
+
+def _per_list_precision(labels, predictions, topn, mask):
+    """metrics_impl.py:180-207."""
+    sorted_labels = sort_by_scores(predictions, [labels], topn=topn, mask=mask)[0]
+    relevance = (sorted_labels >= 1.0).to(torch.float32)
+    if topn is None:
+        topn = relevance.shape[1]
+    valid_topn = torch.clamp(mask.to(torch.int32).sum(dim=1, keepdim=True), max=topn)
+    return _safe_div(relevance.sum(dim=1, keepdim=True), valid_topn.to(torch.float32))
+
+
+class RecallMetric(_RankingMetric):
+    """metrics_impl.py:539-561."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        out = _per_list_recall(labels, predictions, topn, mask)
+        w = _per_example_weights_to_per_list_weights(weights, (labels >= 1.0).to(torch.float32), row_sum=tree_sum)
+        return out, w
+
+
+class PrecisionMetric(_RankingMetric):
+    """metrics_impl.py:564-586."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        out = _per_list_precision(labels, predictions, topn, mask)
+        w = _per_example_weights_to_per_list_weights(weights, (labels >= 1.0).to(torch.float32), row_sum=tree_sum)
+        return out, w
+
+
+class MeanAveragePrecisionMetric(_RankingMetric):
+    """metrics_impl.py:589-628 (float row sums: tree_sum)."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        relevance = (labels >= 1.0).to(torch.float32)
+        sorted_relevance, sorted_weights = sort_by_scores(predictions, [relevance, weights], topn=topn, mask=mask)
+        counts = torch.cumsum(sorted_relevance, dim=1)
+        cutoffs = torch.cumsum(torch.ones_like(sorted_relevance), dim=1)
+        precisions = _safe_div(counts, cutoffs)
+        total_precision = tree_sum(precisions * sorted_weights * sorted_relevance)
+        total_relevance = tree_sum(weights * relevance)
+        per_list_map = _safe_div(total_precision, total_relevance)
+        w = _per_example_weights_to_per_list_weights(weights, relevance, row_sum=tree_sum)
+        return per_list_map, w
+
+
+class DCGMetric(_RankingMetric):
+    """metrics_impl.py:673-705."""
+
+    def __init__(self, name=None, topn=None, gain_fn=pow_minus_1, rank_discount_fn=log2_inverse, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+        self._gain_fn = gain_fn
+        self._rank_discount_fn = rank_discount_fn
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        sorted_labels, sorted_weights = sort_by_scores(predictions, [labels, weights], topn=topn, mask=mask)
+        dcg = _discounted_cumulative_gain(sorted_labels, sorted_weights, self._gain_fn, self._rank_discount_fn,
+                                          row_sum=tree_sum, full_list_size=predictions.shape[1])
+        per_list_weights = _per_example_weights_to_per_list_weights(
+            weights=weights, relevance=self._gain_fn(labels.to(torch.float32)), row_sum=tree_sum)
+        return _safe_div(dcg, per_list_weights), per_list_weights
+
+
 def keras_metric_mean(metric, batches):
     """keras/metrics.py:156-193: running weighted mean over update_state calls.
     ``batches`` = iterable of (y_true, y_pred, sample_weight)."""

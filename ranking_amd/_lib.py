@@ -30,6 +30,8 @@ _SIGNATURES = {
     'tfr_sort_ranks_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
     'tfr_ndcg_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
                             + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+    'tfr_rank_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
+                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_mrr_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p]
                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]

@@ -149,6 +149,26 @@ def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns):
     return out, stats
 
 
+METRIC_NDCG, METRIC_MRR, METRIC_DCG, METRIC_HITS, METRIC_RECALL, METRIC_PRECISION, METRIC_MAP, METRIC_ARP = range(8)
+
+
+def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, discount=None):
+    """tfr_rank_metric_f32: ([K, B] metric, [B, 3] stats) for any sort-based metric kind."""
+    labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
+    _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
+    w, per_list = _weights_arg(weights, labels)
+    mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
+    B, L = labels.shape
+    K = len(topns)
+    out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
+    stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().tfr_rank_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
+                                         _ptr(gains), _ptr(discount), _topn_array(topns), K, B, L,
+                                         _ptr(out), _ptr(stats), _stream())
+    _lib.check(rc, 'tfr_rank_metric_f32')
+    return out, stats
+
+
 def mrr_metric(labels, predictions, weights, mask, topns):
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')

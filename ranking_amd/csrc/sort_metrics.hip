@@ -308,6 +308,146 @@ __global__ __launch_bounds__(64) void rank_metric_wave_kernel(
   }
 }
 
+// The other sort-based metrics of metrics_impl.py on the same wave-per-list machinery
+// (kind is wave-uniform at run time):
+//   TFR_METRIC_DCG       :673-705  sum_{p<k} w gain disc(p)   (divided by the list weight by the caller)
+//   TFR_METRIC_HITS      :462-506  1{some relevant item in the top k}                 (no sort needed)
+//   TFR_METRIC_RECALL    :154-177, 539-561   #relevant in top k / #relevant
+//   TFR_METRIC_PRECISION :180-207, 564-586   #relevant in top k / min(k, #valid)
+//   TFR_METRIC_MAP       :589-628  sum_{p<k} prec@p w rel / sum w rel
+//   TFR_METRIC_ARP       :509-536  sum_p p (w l) / sum_p (w l), sums in SORTED order; stats[2] = that denominator
+// "relevant" = label >= 1.  Sums of floats use the shared tree_sum order (bit-reproducible).
+template <int IPL>
+__global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
+    int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
+    const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
+    const float* __restrict__ gains, const float* __restrict__ discount, TopN topn, int B, int L, int P,
+    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* WG = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] w * rel by original index
+  float* G = WG + 64 * IPL;                                // [64 * IPL] rel by original index
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  float w[IPL], g[IPL], wg[IPL];
+  bool m[IPL];
+  uint64_t key[IPL];
+  int nmask = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    w[r] = 0.f; g[r] = 0.f; m[r] = false; key[r] = 0;
+    if (i < L) {
+      const float lab = labels[base + i];
+      w[r] = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      m[r] = v0 && (w[r] > 0.0f);
+      const float labc = m[r] ? lab : 0.0f;
+      if (kind == TFR_METRIC_DCG) g[r] = gains ? gains[base + i] : gain_pow2m1(labc);
+      else if (kind == TFR_METRIC_ARP) g[r] = labc;
+      else g[r] = (labc >= 1.0f) ? 1.0f : 0.0f;
+      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+    }
+    wg[r] = w[r] * g[r];
+    WG[i] = wg[r];
+    G[i] = g[r];
+    nmask += __popcll(__ballot(m[r]));
+  }
+  float t[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = w[r];
+  const float s_w = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = g[r];
+  const float s_g = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = wg[r];
+  const float s_wg = wave_tree_sum<IPL>(t, P);
+  if (lane == 0) {
+    stats_out[(size_t)b * 3 + 0] = s_w;
+    stats_out[(size_t)b * 3 + 1] = s_g;
+    if (kind != TFR_METRIC_ARP) stats_out[(size_t)b * 3 + 2] = s_wg;
+  }
+  __syncthreads();
+
+  if (kind == TFR_METRIC_HITS) {
+    uint64_t best = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r)
+      if (g[r] > 0.0f && key[r] > best) best = key[r];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t other = __shfl_xor(best, o, 64);
+      best = other > best ? other : best;
+    }
+    int above = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) above += __popcll(__ballot(key[r] > best));
+    if (lane == 0) {
+      for (int q = 0; q < topn.n; ++q) {
+        const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+        metric_out[(size_t)q * B + b] = (best != 0 && above < k) ? 1.0f : 0.0f;
+      }
+    }
+    return;
+  }
+
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+  float rel[IPL], wr[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    const int idx = sort_key_index(key[r]);
+    rel[r] = (p < L) ? G[idx] : 0.0f;
+    wr[r] = (p < L) ? WG[idx] : 0.0f;
+  }
+  float cum[IPL];                                            // inclusive prefix count of relevant items (MAP)
+  if (kind == TFR_METRIC_MAP) {
+    float carry = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      float v = rel[r];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+      }
+      cum[r] = v + carry;
+      carry += __shfl(v, 63, 64);
+    }
+  }
+  float arp_den = 0.f;
+  if (kind == TFR_METRIC_ARP) {
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = wr[r];
+    arp_den = wave_tree_sum<IPL>(t, P);
+    if (lane == 0) stats_out[(size_t)b * 3 + 2] = arp_den;
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      float v = 0.f;
+      if (p < k) {
+        if (kind == TFR_METRIC_DCG) v = wr[r] * discount[p];
+        else if (kind == TFR_METRIC_MAP) v = (cum[r] / (float)(p + 1)) * wr[r];
+        else if (kind == TFR_METRIC_ARP) v = (float)(p + 1) * wr[r];
+        else v = rel[r];                                     // recall / precision: count
+      }
+      t[r] = v;
+    }
+    const float total = wave_tree_sum<IPL>(t, P);
+    float out = total;
+    if (kind == TFR_METRIC_RECALL) out = (s_g != 0.0f) ? total / s_g : 0.0f;
+    else if (kind == TFR_METRIC_PRECISION) { const int d = k < nmask ? k : nmask; out = d > 0 ? total / (float)d : 0.0f; }
+    else if (kind == TFR_METRIC_MAP) out = (s_wg != 0.0f) ? total / s_wg : 0.0f;
+    else if (kind == TFR_METRIC_ARP) out = (arp_den != 0.0f) ? total / arp_den : 0.0f;
+    if (lane == 0) metric_out[(size_t)q * B + b] = out;
+  }
+}
+
 template <int KIND, int IPL>
 void launch_metric_wave(const float* labels, const float* predictions, const float* weights, int weights_per_list,
                         const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
@@ -404,4 +544,27 @@ extern "C" int tfr_mrr_metric_f32(const float* labels, const float* predictions,
                                   int K, int B, int L, float* mrr_out, float* stats_out, void* stream) {
   return launch_metric(1, labels, predictions, weights, weights_per_list, mask, nullptr, nullptr,
                        topn_host, K, B, L, mrr_out, stats_out, stream);
+}
+
+extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
+                                   int weights_per_list, const uint8_t* mask, const float* gains,
+                                   const float* discount, const int32_t* topn_host, int K, int B, int L,
+                                   float* metric_out, float* stats_out, void* stream) {
+  if (kind == TFR_METRIC_NDCG || kind == TFR_METRIC_MRR)
+    return launch_metric(kind, labels, predictions, weights, weights_per_list, mask, gains, discount, topn_host, K,
+                         B, L, metric_out, stats_out, stream);
+  if (kind < TFR_METRIC_DCG || kind > TFR_METRIC_ARP) return TFR_EINVAL;
+  if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
+  if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
+  if (kind == TFR_METRIC_DCG && !discount) return TFR_EINVAL;
+  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernels only (list_size <= 1024)
+  if (B == 0) return TFR_OK;
+  TopN tn; tn.n = K;
+  for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
+  const int P = pow2_ceil(L < 2 ? 2 : L);
+  hipStream_t st = (hipStream_t)stream;
+#define M2(I) hipLaunchKernelGGL(rank_metric2_wave_kernel<I>, dim3(B), dim3(64), (size_t)2 * 64 * I * sizeof(float), st, kind, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out)
+  if (L <= 64) M2(1); else if (L <= 128) M2(2); else if (L <= 256) M2(4); else if (L <= 512) M2(8); else M2(16);
+#undef M2
+  return (int)hipGetLastError();
 }

@@ -27,13 +27,17 @@ class RankingMetricKey(object):
     ORDERED_PAIR_ACCURACY = 'ordered_pair_accuracy'
     ALPHA_DCG = 'alpha_dcg'
     HITS = 'hits'
+    RECALL = 'recall'
 
 
 def get(key: str, name: Optional[str] = None, dtype=None, topn: Optional[int] = None, **kwargs):
     """keras/metrics.py:69-128."""
     if not isinstance(key, str):
         raise ValueError('Input `key` needs to be string.')
-    key_to_cls = {RankingMetricKey.MRR: MRRMetric, RankingMetricKey.NDCG: NDCGMetric}
+    key_to_cls = {RankingMetricKey.MRR: MRRMetric, RankingMetricKey.NDCG: NDCGMetric,
+                  RankingMetricKey.DCG: DCGMetric, RankingMetricKey.ARP: ARPMetric,
+                  RankingMetricKey.PRECISION: PrecisionMetric, RankingMetricKey.MAP: MeanAveragePrecisionMetric,
+                  RankingMetricKey.HITS: HitsMetric, RankingMetricKey.RECALL: RecallMetric}
     metric_kwargs = {'name': name, 'dtype': dtype}
     if topn:
         metric_kwargs.update({'topn': topn})
@@ -138,3 +142,50 @@ class NDCGMetric(_RankingMetric):
         config.update({'topn': self._topn, 'gain_fn': self._gain_fn,
                        'rank_discount_fn': self._rank_discount_fn})
         return config
+
+
+def _topn_metric(impl_cls, doc):
+    class _M(_RankingMetric):
+        __doc__ = doc
+
+        def __init__(self, name=None, topn=None, dtype=None, ragged=False, **kwargs):
+            super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+            self._topn = topn
+            self._metric = impl_cls(name=name, topn=topn, ragged=ragged)
+
+        def get_config(self):
+            config = super().get_config()
+            config.update({'topn': self._topn})
+            return config
+    return _M
+
+
+HitsMetric = utils.register_keras_serializable()(type('HitsMetric', (_topn_metric(
+    metrics_impl.HitsMetric, 'keras/metrics.py:269-332.'),), {}))
+PrecisionMetric = utils.register_keras_serializable()(type('PrecisionMetric', (_topn_metric(
+    metrics_impl.PrecisionMetric, 'keras/metrics.py:383-456.'),), {}))
+RecallMetric = utils.register_keras_serializable()(type('RecallMetric', (_topn_metric(
+    metrics_impl.RecallMetric, 'keras/metrics.py:459-531.'),), {}))
+MeanAveragePrecisionMetric = utils.register_keras_serializable()(type('MeanAveragePrecisionMetric', (_topn_metric(
+    metrics_impl.MeanAveragePrecisionMetric, 'keras/metrics.py:629-707.'),), {}))
+
+
+@utils.register_keras_serializable()
+class ARPMetric(_RankingMetric):
+    """keras/metrics.py:335-380."""
+
+    def __init__(self, name=None, dtype=None, ragged=False, **kwargs):
+        super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+        self._metric = metrics_impl.ARPMetric(name=name, ragged=ragged)
+
+
+@utils.register_keras_serializable()
+class DCGMetric(NDCGMetric):
+    """keras/metrics.py:800-883."""
+
+    def __init__(self, name=None, topn=None, gain_fn=None, rank_discount_fn=None, dtype=None,
+                 ragged=False, **kwargs):
+        super().__init__(name=name, topn=topn, gain_fn=gain_fn, rank_discount_fn=rank_discount_fn, dtype=dtype,
+                         ragged=ragged, **kwargs)
+        self._metric = metrics_impl.DCGMetric(name=name, topn=topn, gain_fn=self._gain_fn,
+                                              rank_discount_fn=self._rank_discount_fn, ragged=ragged)

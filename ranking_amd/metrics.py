@@ -55,7 +55,13 @@ def mean_reciprocal_rank(labels, predictions, weights=None, topn=None, name=None
 def compute_mean(metric_key, labels, predictions, weights=None, topn=None, name=None):
     """metrics.py:79-121."""
     fns = {RankingMetricKey.MRR: metrics_impl.MRRMetric(name, topn),
-           RankingMetricKey.NDCG: metrics_impl.NDCGMetric(name, topn)}
+           RankingMetricKey.NDCG: metrics_impl.NDCGMetric(name, topn),
+           RankingMetricKey.DCG: metrics_impl.DCGMetric(name, topn),
+           RankingMetricKey.ARP: metrics_impl.ARPMetric(name),
+           RankingMetricKey.PRECISION: metrics_impl.PrecisionMetric(name, topn),
+           RankingMetricKey.RECALL: metrics_impl.RecallMetric(name, topn),
+           RankingMetricKey.MAP: metrics_impl.MeanAveragePrecisionMetric(name, topn),
+           RankingMetricKey.HITS: metrics_impl.HitsMetric(name, topn)}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     v, w = fns[metric_key].compute(labels, predictions, weights)
@@ -78,7 +84,19 @@ def make_ranking_metric_fn(metric_key, weights_feature_name=None, topn=None, nam
         return normalized_discounted_cumulative_gain(labels, predictions, _get_weights(features), topn,
                                                      name, gain_fn, rank_discount_fn)
 
-    fns = {RankingMetricKey.MRR: _mrr, RankingMetricKey.NDCG: _ndcg}
+    def _generic(metric):
+        def fn(labels, predictions, features):
+            v, w = metric.compute(labels, predictions, _get_weights(features))
+            return _weighted_mean(v, w)
+        return fn
+
+    fns = {RankingMetricKey.MRR: _mrr, RankingMetricKey.NDCG: _ndcg,
+           RankingMetricKey.DCG: _generic(metrics_impl.DCGMetric(name, topn, gain_fn, rank_discount_fn)),
+           RankingMetricKey.ARP: _generic(metrics_impl.ARPMetric(name)),
+           RankingMetricKey.PRECISION: _generic(metrics_impl.PrecisionMetric(name, topn)),
+           RankingMetricKey.RECALL: _generic(metrics_impl.RecallMetric(name, topn)),
+           RankingMetricKey.MAP: _generic(metrics_impl.MeanAveragePrecisionMetric(name, topn)),
+           RankingMetricKey.HITS: _generic(metrics_impl.HitsMetric(name, topn))}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     return fns[metric_key]

@@ -1,4 +1,5 @@
-"""Mirror of ``tensorflow_ranking/python/metrics_impl.py`` for NDCG and MRR.
+"""Mirror of ``tensorflow_ranking/python/metrics_impl.py`` for the sort-based metrics: NDCG, MRR, DCG,
+Hits, Recall, Precision, MAP and ARP.
 
 ``compute(labels, predictions, weights=None, mask=None)`` returns the same
 ``(per_list_metric [B, 1], per_list_weights [B, 1])`` pair as the reference; the
@@ -146,3 +147,70 @@ class NDCGMetric(_RankingMetric):
         discount = _ops.rank_table(self._rank_discount_fn, labels.shape[1], labels.device)
         out, stats = _ops.ndcg_metric(labels, predictions, weights, mask, gains, discount, topns)
         return out, per_list_weights_from_stats(stats)
+
+
+class _KindMetric(_RankingMetric):
+    """Shared shape of the metrics served by ``tfr_rank_metric_f32`` (csrc/sort_metrics.hip)."""
+    _KIND = None
+
+    def __init__(self, name, topn, ragged=False):
+        super().__init__(ragged=ragged)
+        self._name = name
+        self._topn = topn
+
+    @property
+    def name(self):
+        return self._name
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns)
+        return out, per_list_weights_from_stats(stats)
+
+
+class HitsMetric(_KindMetric):
+    """metrics_impl.py:462-506."""
+    _KIND = _ops.METRIC_HITS
+
+
+class RecallMetric(_KindMetric):
+    """metrics_impl.py:539-561."""
+    _KIND = _ops.METRIC_RECALL
+
+
+class PrecisionMetric(_KindMetric):
+    """metrics_impl.py:564-586."""
+    _KIND = _ops.METRIC_PRECISION
+
+
+class MeanAveragePrecisionMetric(_KindMetric):
+    """metrics_impl.py:589-628."""
+    _KIND = _ops.METRIC_MAP
+
+
+class ARPMetric(_KindMetric):
+    """metrics_impl.py:509-536: the per-list weight is sum(label * weight) in sorted order."""
+    _KIND = _ops.METRIC_ARP
+
+    def __init__(self, name, ragged=False):
+        super().__init__(name, None, ragged=ragged)
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, [None])
+        return out, stats[:, 2:3]
+
+
+class DCGMetric(NDCGMetric):
+    """metrics_impl.py:673-705."""
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        gains = None
+        if self._gain_fn not in _IN_KERNEL_GAINS:
+            m = mask if mask is not None else labels >= 0
+            if weights is not None:
+                m = torch.logical_and(m, torch.broadcast_to(
+                    weights if weights.dim() == 2 else weights.reshape(-1, 1), labels.shape) > 0)
+            gains = self._gain_fn(torch.where(m, labels, torch.zeros_like(labels))).to(torch.float32)
+        discount = _ops.rank_table(self._rank_discount_fn, labels.shape[1], labels.device)
+        out, stats = _ops.rank_metric(_ops.METRIC_DCG, labels, predictions, weights, mask, topns, gains, discount)
+        plw = per_list_weights_from_stats(stats)
+        return _safe_div(out, plw.reshape(1, -1)), plw

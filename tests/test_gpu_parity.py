@@ -764,3 +764,61 @@ def test_pairwise_other_losses_reference_goldens():
     losses, w = L.PairwiseHingeLoss(None).compute_per_list(labels, scores, t([[2., 3., 4.], [1., 1., 1.]]))
     assert_loss_close(losses, torch.tensor([1., 0.]), 1e-6)                          # losses_impl_test.py:530-541
     assert w.tolist() == [8., 2.]
+
+
+# ------------------------------------------------------------------ more metrics
+from tests.metric_cases import CASES as _METRIC_CASES
+
+
+@pytest.mark.parametrize('case', _METRIC_CASES, ids=lambda c: '%s@%s:%d' % (c[0], c[1].get('topn'), c[8]))
+def test_more_metrics_reference_literals(case):
+    cls, kw, labels, scores, weights, mask, exp, exp_w, _line = case
+    metric = getattr(ra().metrics_impl, cls)(None, **kw)
+    t = lambda x: None if x is None else torch.tensor(x, device=DEV)
+    out, w = metric.compute(t(labels), t(scores), t(weights), t(mask))
+    if exp is not None:
+        assert_loss_close(out, torch.tensor(exp), 1e-6, cls)
+    if exp_w is not None:
+        assert_loss_close(w, torch.tensor(exp_w), 1e-6, cls + ' weights')
+
+
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300)])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_more_metrics_bit_exact(B, L, weighted):
+    labels, preds = make_batch(B, L, seed=1000 + L)
+    w = make_weights(B, L, seed=L + 1) if weighted else None
+    if weighted and L > 2:
+        w[:, 1] = 0.0
+    mi = ra().metrics_impl
+    d = lambda x: None if x is None else x.to(DEV)
+    topns = [1, 3, 10, None]
+    for name in ('HitsMetric', 'RecallMetric', 'PrecisionMetric', 'MeanAveragePrecisionMetric', 'DCGMetric'):
+        got, got_w = getattr(mi, name)(None, None).compute_multi(d(labels), d(preds), d(w), None, topns)
+        for q, k in enumerate(topns):
+            want, want_w = getattr(R, name)(topn=k).compute(labels, preds, w)
+            assert torch.equal(got[q].cpu(), want.reshape(-1)), '%s@%s: max diff %g' % (
+                name, k, (got[q].cpu() - want.reshape(-1)).abs().max())
+        assert_loss_close(got_w, want_w, 1e-6, name + ' weights')
+    got, got_w = mi.ARPMetric(None).compute(d(labels), d(preds), d(w))
+    want, want_w = R.ARPMetric().compute(labels, preds, w)
+    assert torch.equal(got.cpu(), want) and torch.equal(got_w.cpu(), want_w)
+
+
+def test_more_metrics_keras_and_factory_keys():
+    km = ra().keras.metrics
+    t = lambda x: torch.tensor(x, device=DEV)
+    yt, yp = t([[0., 1., 0.], [1., 1., 0.]]), t([[3., 2., 1.], [3., 1., 2.]])
+    for key in ('dcg', 'arp', 'precision', 'recall', 'map', 'hits', 'ndcg', 'mrr'):
+        m = km.get(key, topn=2) if key != 'arp' else km.get(key)
+        m.update_state(yt, yp)
+        v = float(m.result())
+        assert math.isfinite(v)
+        cfg = m.get_config()
+        assert type(m).from_config(cfg) is not None
+        fn = ra().metrics.make_ranking_metric_fn(key, topn=2)
+        assert abs(float(fn(yt, yp, {})) - v) < 1e-6, key
+    # keras/metrics.py:397-401 doc value
+    m = km.PrecisionMetric(topn=2); m.update_state(t([[0., 1., 1.]]), t([[3., 1., 2.]]))
+    assert abs(float(m.result()) - 0.5) < 1e-6
+    with pytest.raises(ValueError):
+        km.get('alpha_dcg')

@@ -557,3 +557,20 @@ def test_pairwise_keras_doc_values():
     yt, yp = torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])
     assert abs(R.keras_loss_call(R.PairwiseHingeLoss(), yt, yp).item() - 0.6) < 1e-6              # keras/losses.py:350-354
     assert abs(R.keras_loss_call(R.PairwiseSoftZeroOneLoss(), yt, yp).item() - 0.274917) < 1e-6   # :484-488
+
+
+# ------------------------------------------------------------------ more metrics
+from tests.metric_cases import CASES as _METRIC_CASES
+
+
+@pytest.mark.parametrize('case', _METRIC_CASES, ids=lambda c: '%s@%s:%d' % (c[0], c[1].get('topn'), c[8]))
+def test_more_metrics_reference_literals(case):
+    cls, kw, labels, scores, weights, mask, exp, exp_w, _line = case
+    metric = getattr(R, cls)(**kw)
+    out, w = metric.compute(torch.tensor(labels), torch.tensor(scores),
+                            None if weights is None else torch.tensor(weights),
+                            None if mask is None else torch.tensor(mask))
+    if exp is not None:
+        close(out, exp, 1e-6)
+    if exp_w is not None:
+        close(w, exp_w, 1e-6)
