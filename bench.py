@@ -74,7 +74,7 @@ def make_inputs(B, L, seed, device):
     return labels.to(device), logits.to(device)
 
 
-def build_step(workload, labels, logits):
+def build_step(workload, labels, logits, dropout=0.0):
     """Returns (step_fn, kernel_fn) -- kernel_fn launches only the dominant kernel."""
     from ranking_amd import _ops
     from ranking_amd.keras import losses as K
@@ -98,11 +98,11 @@ def build_step(workload, labels, logits):
         m = metrics_impl.NDCGMetric(None, None)
         return (lambda: m.compute_multi(labels, logits, None, None, [1, 3, 5, 10, None])), None
     if workload.startswith('e2e_'):
-        return build_e2e_step(workload, labels), None
+        return build_e2e_step(workload, labels, dropout), None
     raise ValueError(workload)
 
 
-def build_e2e_step(workload, labels):
+def build_e2e_step(workload, labels, dropout=0.0):
     """One data-parallel training step: features [B, L, 136] ~ U(-1, 1) resident in HBM."""
     import ranking_amd as ra
     from ranking_amd import distributed as D
@@ -115,7 +115,7 @@ def build_e2e_step(workload, labels):
     if workload == 'e2e_groupwise_gumbel':
         from ranking_amd import model as gmodel
         tower = ra.keras.layers.create_tower([512, 512, 512], 2, activation=torch.relu, use_batch_norm=True,
-                                             dropout=0.0, input_dim=272, compute_dtype=torch.bfloat16)
+                                             dropout=dropout, input_dim=272, compute_dtype=torch.bfloat16)
 
         def group_score_fn(ctx, group_features):
             x = group_features['x']
@@ -128,7 +128,7 @@ def build_e2e_step(workload, labels):
         loss = ra.keras.losses.GumbelApproxNDCGLoss(seed=1)
     else:
         scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
-                                          activation=torch.relu, use_batch_norm=True, dropout=0.0,
+                                          activation=torch.relu, use_batch_norm=True, dropout=dropout,
                                           compute_dtype=torch.bfloat16).to(dev)
         run_scorer = lambda: scorer({}, {'x': feats}, mask)
         loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
@@ -224,6 +224,7 @@ def main():
     ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
     args = ap.parse_args()
@@ -251,7 +252,7 @@ def main():
     if args.batch > 0:
         B = args.batch
     labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
-    step, kernel_only = build_step(args.workload, labels, logits)
+    step, kernel_only = build_step(args.workload, labels, logits, args.dropout)
 
     def barrier():
         if dist is not None:

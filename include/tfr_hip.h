@@ -191,6 +191,16 @@ int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const u
  * 2 = backward of relu/BN-input: C = acc * 1[Zp*e_scale + e_shift > 0], stats = partial
  * (sum dy, sum dy * zhat) with zhat = (Zp - e_mean) * e_rstd.                              */
 
+/* Dropout after a hidden activation (keras/layers.py:72-73).  HOST struct, nullable everywhere
+ * (NULL or threshold16 == 0: no dropout).  Element (row m, column k) of the layer is kept iff 16
+ * bits of hash(seed, m, k / 2) >= threshold16 = rate * 65536, and then scaled by `scale` =
+ * 1 / (1 - rate); forward prologues and backward kernels evaluate the same hash. */
+typedef struct tfr_tower_dropout {
+  uint32_t seed;
+  uint32_t threshold16;
+  float scale;
+} tfr_tower_dropout;
+
 /* Dense input cast: fp32 x[M, F] (pitch ldx) -> bf16 out[M, Kp], Kp = F rounded up to 8, zero
  * padded; optional per-column affine (an input BatchNormalization folded in). */
 int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
@@ -204,7 +214,8 @@ int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* 
                         int M, int N, int K, int prologue, const float* a_scale, const float* a_shift,
                         const float* bias, int epilogue, float* stats, const void* Zp, long ldz,
                         const float* e_scale, const float* e_shift, const float* e_mean,
-                        const float* e_rstd, void* stream);
+                        const float* e_rstd, const tfr_tower_dropout* pro_dropout,
+                        const tfr_tower_dropout* epi_dropout, void* stream);
 int tfr_tower_gemm_stats_rows(int M);            /* rows of `stats` for a given M            */
 int tfr_tower_reduce_scratch_rows(int T);     /* rows of the `scratch` buffers below      */
 /* BatchNormalization (training): partial[T][2][N] -> mean / biased variance -> scale = gamma *
@@ -220,13 +231,13 @@ int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, fl
 /* Output Dense(output_units <= 4): out[M, O] = prologue(z)[M, K] . w[O, K]^T + b (fp32). */
 int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                       const float* shift, const float* w, const float* b, int O, float* out,
-                      void* stream);
+                      const tfr_tower_dropout* dropout, void* stream);
 /* Its backward: dy[M, K] (bf16) = (dlogits . w) * relu mask; partial[n_blocks][2 + O][K] =
  * per-block (sum dy, sum dy * zhat, d w[o, :]). */
 int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                       const float* shift, const float* mean, const float* rstd, const float* w,
                       const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
-                      int n_blocks, void* stream);
+                      int n_blocks, const tfr_tower_dropout* dropout, void* stream);
 /* BatchNormalization backward, in place: dy <- p[k]*dy + q[k]*z + r[k]; pqr is fp32 [3][K]. */
 int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, long ldz, int M, int K,
                            const float* pqr, void* stream);
@@ -234,7 +245,7 @@ int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, long ldz, in
  * s-th slice of M (fp32); tfr_tower_slab_reduce sums the slices. */
 int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int M, int N, int K,
                          int prologue, const float* a_scale, const float* a_shift, float* slab,
-                         long ldw, int splits, void* stream);
+                         long ldw, int splits, const tfr_tower_dropout* dropout, void* stream);
 int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream);
 
 #ifdef __cplusplus

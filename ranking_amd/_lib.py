@@ -56,21 +56,21 @@ _SIGNATURES = {
     'tfr_tower_weight_cast': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2),
     'tfr_tower_gemm_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_int] * 4
                             + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_long]
-                            + [ctypes.c_void_p] * 5),
+                            + [ctypes.c_void_p] * 7),
     'tfr_tower_gemm_stats_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_tower_reduce_scratch_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_tower_bn_finalize': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_long]
                               + [ctypes.c_void_p] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 8),
     'tfr_tower_reduce_partials': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
     'tfr_tower_out_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
-                          + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 2),
+                          + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
     'tfr_tower_out_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                           + [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long]
-                          + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+                          + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_bn_bwd_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 2
                                + [ctypes.c_void_p] * 2),
     'tfr_tower_wgrad_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 4
-                             + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p]),
+                             + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_void_p]),
 }

@@ -11,6 +11,34 @@ import torch
 from . import _lib
 from ._ops import _ptr, _stream, require_device
 
+class Dropout(ctypes.Structure):
+    """tfr_tower_dropout (include/tfr_hip.h): counter-based keep mask shared by forward and backward."""
+    _fields_ = [('seed', ctypes.c_uint32), ('threshold16', ctypes.c_uint32), ('scale', ctypes.c_float)]
+
+    @classmethod
+    def make(cls, rate: float, seed: int):
+        thr = max(0, min(65535, int(round(float(rate) * 65536.0))))
+        return cls(int(seed) & 0xffffffff, thr, 65536.0 / (65536.0 - thr))
+
+
+def _dp(d):
+    return None if d is None else ctypes.byref(d)
+
+
+def dropout_mask(d: 'Dropout', M: int, K: int, device) -> torch.Tensor:
+    """The [M, K] keep-factor matrix the kernels apply (torch restatement of drop_hash; tests / debugging)."""
+    m = torch.arange(M, device=device, dtype=torch.int64).unsqueeze(1)
+    kp = torch.arange((K + 1) // 2, device=device, dtype=torch.int64).unsqueeze(0)
+    mask32 = 0xffffffff
+    h = (m * 0x9E3779B1 + kp * 0x85EBCA77 + int(d.seed)) & mask32
+    h = h ^ (h >> 16); h = (h * 0x7feb352d) & mask32
+    h = h ^ (h >> 15); h = (h * 0x846ca68b) & mask32
+    h = h ^ (h >> 16)
+    lo = ((h & 0xffff) >= int(d.threshold16)); hi = ((h >> 16) >= int(d.threshold16))
+    keep = torch.stack([lo, hi], dim=2).reshape(M, -1)[:, :K]
+    return keep.to(torch.float32) * float(d.scale)
+
+
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_RELU = 0, 1, 2
 EPI_PLAIN, EPI_STATS, EPI_RELU_BWD = 0, 1, 2
 
@@ -59,7 +87,8 @@ def stats_rows(M: int) -> int:
 
 
 def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, epilogue=EPI_PLAIN,
-         Zp=None, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, out=None):
+         Zp=None, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, out=None, pro_dropout=None,
+         epi_dropout=None):
     """C[M, N] = pro(A)[M, :K] . B[N, :K]^T (+ bias) as bf16; returns (C, stats_partial | None)."""
     _bf16(A, 'A'); _bf16(B, 'B')
     M = A.shape[0]
@@ -71,7 +100,7 @@ def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, e
         _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), M, N, K, prologue,
         _ptr(a_scale), _ptr(a_shift), _ptr(bias), epilogue, _ptr(stats), _ptr(Zp),
         Zp.stride(0) if Zp is not None else 0, _ptr(e_scale), _ptr(e_shift), _ptr(e_mean), _ptr(e_rstd),
-        _stream()), 'tfr_tower_gemm_bf16')
+        _dp(pro_dropout), _dp(epi_dropout), _stream()), 'tfr_tower_gemm_bf16')
     return C, stats
 
 
@@ -105,7 +134,7 @@ def reduce_partials(partial):
     return out
 
 
-def out_layer(z, K, prologue, scale, shift, w, b):
+def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
     """logits[M, O] = act(z)[M, :K] . w[O, K]^T + b (fp32)."""
     _bf16(z, 'z')
     M = z.shape[0]
@@ -113,11 +142,12 @@ def out_layer(z, K, prologue, scale, shift, w, b):
     O = w.shape[0]
     out = torch.empty((M, O), dtype=torch.float32, device=z.device)
     _lib.check(_lib.load().tfr_tower_out_f32(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift),
-                                             _ptr(w), _ptr(b), O, _ptr(out), _stream()), 'tfr_tower_out_f32')
+                                             _ptr(w), _ptr(b), O, _ptr(out), _dp(dropout), _stream()),
+               'tfr_tower_out_f32')
     return out
 
 
-def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=512):
+def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=512, dropout=None):
     """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
     sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]."""
     _bf16(z, 'z')
@@ -130,7 +160,7 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
     partial = torch.empty((n_blocks, 2 + O, K), dtype=torch.float32, device=z.device)
     _lib.check(_lib.load().tfr_tower_out_bwd(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift),
                                              _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dlogits), O, _ptr(dy),
-                                             dy.stride(0), _ptr(partial), n_blocks, _stream()),
+                                             dy.stride(0), _ptr(partial), n_blocks, _dp(dropout), _stream()),
                'tfr_tower_out_bwd')
     return dy, reduce_partials(partial)
 
@@ -144,7 +174,7 @@ def bn_bwd_apply_(dy, z, K, pqr):
     return dy
 
 
-def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0):
+def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, dropout=None):
     """dW[N, K] = dz[M, :N]^T . pro(A)[M, :K] (fp32)."""
     _bf16(dz, 'dz'); _bf16(A, 'A')
     M = dz.shape[0]
@@ -154,7 +184,7 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0):
     slab = torch.empty((splits, N, K), dtype=torch.float32, device=dz.device)
     lib = _lib.load()
     _lib.check(lib.tfr_tower_wgrad_bf16(_ptr(dz), dz.stride(0), _ptr(A), A.stride(0), M, N, K, prologue,
-                                        _ptr(a_scale), _ptr(a_shift), _ptr(slab), K, splits, _stream()),
+                                        _ptr(a_scale), _ptr(a_shift), _ptr(slab), K, splits, _dp(dropout), _stream()),
                'tfr_tower_wgrad_bf16')
     out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
     _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 0, _stream()),

@@ -55,6 +55,23 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {     // RNE (v_
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+// Dropout (keras/layers.py:72-73: tf.keras.layers.Dropout after every hidden activation).  The
+// keep mask is a counter-based hash of (layer seed, row, column pair) -- the same function in the
+// forward prologues and in the backward kernels, so nothing is stored.  threshold16 = rate * 65536;
+// an element is kept iff its 16 hash bits >= threshold16 and is then scaled by 1 / (1 - rate).
+struct Drop { uint32_t seed; uint32_t thr; float scale; };
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t m, uint32_t kpair) {
+  uint32_t h = m * 0x9E3779B1u + kpair * 0x85EBCA77u + seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+// keep factors of columns (2 * kpair, 2 * kpair + 1) of row m
+__device__ __forceinline__ void drop_pair(const Drop d, uint32_t m, uint32_t kpair, float& f0, float& f1) {
+  const uint32_t h = drop_hash(d.seed, m, kpair);
+  f0 = ((h & 0xffffu) >= d.thr) ? d.scale : 0.0f;
+  f1 = ((h >> 16) >= d.thr) ? d.scale : 0.0f;
+}
+
 // byte offset of 16-byte chunk c (0..7) of row r inside a swizzled [128][64] bf16 tile
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -71,6 +88,8 @@ struct GemmArgs {
   const float* e_shift;
   const float* e_mean;               // ... and mean / rstd (z_hat for d gamma)
   const float* e_rstd;
+  Drop pro_drop;                     // dropout of the layer below, applied in the A prologue (thr = 0: off)
+  Drop epi_drop;                     // ... and in the EPI_RELU_BWD epilogue (the layer whose Zp is given)
   int M, N, K, tiles_m, tiles_n;
   int ablate;                        // diagnostics only (TFR_TOWER_ABLATE): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no C stores
 };
@@ -79,7 +98,8 @@ enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_RELU_BWD = 2 };
 
 template <int PRO>
-__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh) {
+__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f},
+                                                 uint32_t m = 0, uint32_t k = 0) {
   if (PRO == PRO_NONE) return v;
   uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -87,6 +107,11 @@ __device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const
     float a = __builtin_fmaf(bf16_lo(w[i]), sc[2 * i], sh[2 * i]);
     float b = __builtin_fmaf(bf16_hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
     if (PRO == PRO_AFFINE_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    if (drop.thr) {                                     // wave-uniform
+      float f0, f1;
+      drop_pair(drop, m, (k >> 1) + i, f0, f1);
+      a *= f0; b *= f1;
+    }
     w[i] = pack_bf16(a, b);
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
@@ -163,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
       // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
       *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
     }
@@ -277,10 +302,15 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
         // dy = da * 1[y > 0], y = z * scale + shift;  column partials: sum dy, sum dy * z_hat
         const uint2 zz = *reinterpret_cast<const uint2*>(slot);
         const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
+        float kf[4] = {1.f, 1.f, 1.f, 1.f};
+        if (g.epi_drop.thr) {                           // d a / d relu = keep / (1 - rate): same hash as the forward
+          drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
+          drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = __builtin_fmaf(z[r], es[r], eh[r]);
-          v[r] = (y > 0.f && min) ? v[r] : 0.f;
+          v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
           s1[fn][r] += v[r];
           s2[fn][r] = __builtin_fmaf(v[r], (z[r] - em[r]) * er[r], s2[fn][r]);
         }
@@ -424,7 +454,7 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        int O, float* __restrict__ out) {
+                                                        int O, float* __restrict__ out, const Drop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* coef = reinterpret_cast<float*>(smem);          // [K/8][2 + O][8]
   const int stride = (2 + O) * 8;
@@ -453,6 +483,14 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
         if (PRO != PRO_NONE) t = __builtin_fmaf(t, cc[e], cc[8 + e]);
         if (PRO == PRO_AFFINE_RELU) t = fmaxf(t, 0.f);
         a[e] = t;
+      }
+      if (PRO != PRO_NONE && drop.thr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float f0, f1;
+          drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), f0, f1);
+          a[2 * i] *= f0; a[2 * i + 1] *= f1;
+        }
       }
       for (int o = 0; o < O; ++o) {
 #pragma unroll
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
-    float* __restrict__ partial, int rows_per_block) {
+    float* __restrict__ partial, int rows_per_block, const Drop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [16][(2 + O) * 128]
   const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -516,16 +554,21 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
         const uint32_t u[4] = {v.x, v.y, v.z, v.w};
         float dl[4] = {0.f, 0.f, 0.f, 0.f};
         for (int o = 0; o < O; ++o) dl[o] = dlogits[m * O + o];
-        float out[8];
+        float out[8], kf[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          kf[2 * i] = 1.f; kf[2 * i + 1] = 1.f;
+          if (PRO != PRO_NONE && drop.thr) drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), kf[2 * i], kf[2 * i + 1]);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
           const float y = __builtin_fmaf(zz, sc[e], sh[e]);
-          const float a = (PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y;
+          const float a = ((PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y) * kf[e];
           float da = 0.f;
 #pragma unroll
           for (int o = 0; o < 4; ++o) { da = __builtin_fmaf(dl[o], ww[o][e], da); dw[o][e] = __builtin_fmaf(dl[o], a, dw[o][e]); }
-          const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da;
+          const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da * kf[e];
           s1[e] += d;
           s2[e] = __builtin_fmaf(d, (zz - mu[e]) * rs[e], s2[e]);
           out[e] = d;
@@ -593,6 +636,7 @@ struct WgradArgs {
   const uint16_t* A; long lda;       // [M, K] (pre-BN z of the layer below when PRO != 0)
   const float* a_scale; const float* a_shift;
   float* slab; long ldw;             // [splits][N][ldw]
+  Drop drop;                         // dropout of the layer that produced A (prologue)
   int M, N, K, rows_per_split, splits, tiles_n, tiles_k;
 };
 
@@ -642,14 +686,14 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
       ra[i] = (min && kin) ? *reinterpret_cast<const uint4*>(g.A + m * g.lda + k0 + cc * 8) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, int cur_step) {
     unsigned char* td = smem + buf * 32768;
     unsigned char* ta = td + 16384;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 16 * i;
       uint4 va = ra[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.drop, (uint32_t)(ms + (long)cur_step * 64 + row), (uint32_t)(k0 + cc * 8));
       *reinterpret_cast<uint4*>(td + swz_t(row, cc)) = rd[i];
       *reinterpret_cast<uint4*>(ta + swz_t(row, cc)) = va;
     }
@@ -663,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
 
   if (steps > 0) {
     load_tile(0);
-    store_tile(0);
+    store_tile(0, 0);
     __syncthreads();
     if (steps > 1) load_tile(1);
   }
@@ -691,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
         for (int fk = 0; fk < 4; ++fk)
           acc[fn][fk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[fn], fa[fk], acc[fn][fk], 0, 0, 0);
     }
-    if (st + 1 < steps) store_tile(cur ^ 1);
+    if (st + 1 < steps) store_tile(cur ^ 1, st + 1);
     __syncthreads();
     if (st + 2 < steps) load_tile(st + 2);
   }
@@ -718,6 +762,11 @@ __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, 
     for (int s = 0; s < S; ++s) t += slab[(long)s * n + i];
     out[i] = accumulate ? out[i] + t : t;
   }
+}
+
+Drop to_drop(const tfr_tower_dropout* d) {
+  if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f};
+  return Drop{d->seed, d->threshold16 > 65535u ? 65535u : d->threshold16, d->scale};
 }
 
 int grid_for(long work_items, int block) {
@@ -766,7 +815,9 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
                                    int M, int N, int K, int prologue, const float* a_scale,
                                    const float* a_shift, const float* bias, int epilogue, float* stats,
                                    const void* Zp, long ldz, const float* e_scale, const float* e_shift,
-                                   const float* e_mean, const float* e_rstd, void* stream) {
+                                   const float* e_mean, const float* e_rstd,
+                                   const tfr_tower_dropout* pro_dropout, const tfr_tower_dropout* epi_dropout,
+                                   void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return TFR_EINVAL;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7) || (K & 7) || lda < K || ldb < K || ldc < N) return TFR_EINVAL;
   if (prologue < 0 || prologue > 2 || epilogue < 0 || epilogue > 2) return TFR_EINVAL;
@@ -781,6 +832,7 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.stats = stats; g.Zp = (const uint16_t*)Zp; g.ldz = ldz; g.e_scale = e_scale; g.e_shift = e_shift;
   g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
   { const char* e = getenv("TFR_TOWER_ABLATE"); g.ablate = (e && *e) ? atoi(e) : 0; }
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
@@ -829,7 +881,7 @@ extern "C" int tfr_tower_reduce_partials(const float* partial, int T, int W, flo
 
 extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                                  const float* shift, const float* w, const float* b, int O, float* out,
-                                 void* stream) {
+                                 const tfr_tower_dropout* dropout, void* stream) {
   if (!z || !w || !out || M < 0 || K <= 0 || (K & 7) || (ldz & 7) || O < 1 || O > 4) return TFR_EINVAL;
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
   if (M == 0) return TFR_OK;
@@ -838,9 +890,10 @@ extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prol
   if (lds > 64 * 1024) return TFR_ETOOLARGE;
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* zz = (const uint16_t*)z;
-  if (prologue == PRO_NONE) hipLaunchKernelGGL(tower_out_kernel<PRO_NONE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
-  else if (prologue == PRO_AFFINE) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
-  else if (prologue == PRO_AFFINE_RELU) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_RELU>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out);
+  const Drop dr = to_drop(dropout);
+  if (prologue == PRO_NONE) hipLaunchKernelGGL(tower_out_kernel<PRO_NONE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
+  else if (prologue == PRO_AFFINE) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
+  else if (prologue == PRO_AFFINE_RELU) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_RELU>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
   else return TFR_EINVAL;
   return (int)hipGetLastError();
 }
@@ -848,7 +901,7 @@ extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prol
 extern "C" int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                                  const float* shift, const float* mean, const float* rstd, const float* w,
                                  const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
-                                 int n_blocks, void* stream) {
+                                 int n_blocks, const tfr_tower_dropout* dropout, void* stream) {
   if (!z || !w || !dlogits || !dy_bf16 || !partial || M <= 0 || K <= 0 || (K & 7) || (ldz & 7) || (lddy & 7) ||
       O < 1 || O > 4 || n_blocks < 1) return TFR_EINVAL;
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
@@ -856,7 +909,8 @@ extern "C" int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prol
   rows = (rows + 15) / 16 * 16;
   const size_t lds = (size_t)16 * (2 + O) * 128 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
-#define OB(P) hipLaunchKernelGGL(tower_out_bwd_kernel<P>, dim3(n_blocks), dim3(256), lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows)
+  const Drop dr = to_drop(dropout);
+#define OB(P) hipLaunchKernelGGL(tower_out_bwd_kernel<P>, dim3(n_blocks), dim3(256), lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr)
   if (prologue == PRO_NONE) OB(PRO_NONE); else if (prologue == PRO_AFFINE) OB(PRO_AFFINE);
   else if (prologue == PRO_AFFINE_RELU) OB(PRO_AFFINE_RELU); else return TFR_EINVAL;
 #undef OB
@@ -876,13 +930,13 @@ extern "C" int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, l
 
 extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int M, int N, int K,
                                     int prologue, const float* a_scale, const float* a_shift, float* slab,
-                                    long ldw, int splits, void* stream) {
+                                    long ldw, int splits, const tfr_tower_dropout* dropout, void* stream) {
   if (!DZ || !A || !slab || M <= 0 || N <= 0 || K <= 0 || (lddz & 7) || (lda & 7) || (N & 7) || (K & 7) ||
       ldw < K || splits < 1 || splits > 65535) return TFR_EINVAL;
   if (prologue < 0 || prologue > 2 || (prologue != PRO_NONE && (!a_scale || !a_shift))) return TFR_EINVAL;
   WgradArgs g;
   g.DZ = (const uint16_t*)DZ; g.lddz = lddz; g.A = (const uint16_t*)A; g.lda = lda; g.a_scale = a_scale;
-  g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K;
+  g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.drop = to_drop(dropout);
   int rows = (int)(((long)M + splits - 1) / splits);
   g.rows_per_split = (rows + 63) / 64 * 64;
   g.splits = splits; g.tiles_n = (N + 127) / 128; g.tiles_k = (K + 127) / 128;

@@ -10,9 +10,10 @@ load and bias / bf16 cast / BatchNorm statistics fused into its epilogue
 bf16 operand copies are rebuilt per call.
 
 What the fused path covers: ``activation`` in {None, relu}, ``use_batch_norm`` on or
-off, training (batch statistics, moving averages updated) and inference (moving
-averages).  ``input_batch_norm`` and training-time dropout are not fused: ``create_tower``
-builds the plain torch tower for those (same GPU, fp32, unfused).
+off, training (batch statistics, moving averages updated; Dropout as a counter-based keep mask
+shared by forward and backward -- the TF random stream itself is not reproducible) and inference
+(moving averages, no dropout).  ``input_batch_norm`` is not fused: ``create_tower`` builds the plain
+torch tower for it (same GPU, fp32, unfused).
 """
 from __future__ import annotations
 
@@ -50,14 +51,18 @@ class _TowerFn(torch.autograd.Function):
         M = x.shape[0]
         dev = x.device
         x0 = x if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 else T.cast_rows(x)
-        a_in, pro, sc, sh = x0, T.PRO_NONE, None, None
+        a_in, pro, sc, sh, drop = x0, T.PRO_NONE, None, None, None
         zs, coefs = [], []
         k_in = x0.shape[1]
+        rate = tower.dropout if training else 0.0
+        if rate > 0.0:
+            tower._drop_step += 1
+            base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
         for l in range(n_h):
             n_out = Ws[l].shape[0]
             wb = T.cast_weight(Ws[l])                      # [N, pad8(K)]
             z, stats = T.gemm(a_in, wb, n_out, k_in, prologue=pro, a_scale=sc, a_shift=sh, bias=bs[l],
-                              epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN)
+                              epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN, pro_dropout=drop)
             if use_bn:
                 if training:
                     sc, sh, mean, rstd = T.bn_finalize(stats, M, gammas[l], betas[l], _BN_EPS, tower.momentum,
@@ -70,15 +75,17 @@ class _TowerFn(torch.autograd.Function):
                 pro = T.PRO_AFFINE_RELU if relu else T.PRO_AFFINE
             else:
                 mean = rstd = None
-                if relu:
+                if relu or rate > 0.0:
                     sc = torch.ones(n_out, device=dev); sh = torch.zeros(n_out, device=dev)
-                    pro = T.PRO_AFFINE_RELU
+                    pro = T.PRO_AFFINE_RELU if relu else T.PRO_AFFINE
                 else:
                     sc = sh = None
                     pro = T.PRO_NONE
-            zs.append(z); coefs.append((pro, sc, sh, mean, rstd))
+            # Dropout after this layer's activation (keras/layers.py:72-73): applied by its consumers
+            drop = T.Dropout.make(rate, base + l * 0x632BE5AB) if rate > 0.0 else None
+            zs.append(z); coefs.append((pro, sc, sh, mean, rstd, drop))
             a_in, k_in = z, n_out
-        logits = T.out_layer(a_in, k_in, pro, sc, sh, w_out, b_out)
+        logits = T.out_layer(a_in, k_in, pro, sc, sh, w_out, b_out, dropout=drop)
         ctx.tower, ctx.training = tower, training
         ctx.x0, ctx.zs, ctx.coefs = x0, zs, coefs
         ctx.params = params
@@ -101,15 +108,15 @@ class _TowerFn(torch.autograd.Function):
         dW, db = [None] * n_h, [None] * n_h
         dgam, dbet = [None] * n_h, [None] * n_h
         # output layer
-        pro, sc, sh, mean, rstd = coefs[-1]
+        pro, sc, sh, mean, rstd, drop = coefs[-1]
         n_last = zs[-1].shape[1]
-        dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits)
+        dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
         dw_out = sums[2:].contiguous()
         db_out = dlogits.sum(dim=0)
         c1, c2 = sums[0], sums[1]
         for l in range(n_h - 1, -1, -1):
             n_out = zs[l].shape[1]
-            pro_l, sc_l, sh_l, mean_l, rstd_l = coefs[l]
+            pro_l, sc_l, sh_l, mean_l, rstd_l, _ = coefs[l]
             if use_bn:
                 dgam[l], dbet[l] = c2.clone(), c1.clone()
                 s = gammas[l].detach() * rstd_l
@@ -120,12 +127,12 @@ class _TowerFn(torch.autograd.Function):
                 dz = dy
                 db[l] = c1.clone()
             if l > 0:
-                pro_p, sc_p, sh_p, mean_p, rstd_p = coefs[l - 1]
+                pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = coefs[l - 1]
                 a_prev, k_in = zs[l - 1], zs[l - 1].shape[1]
             else:
-                pro_p, sc_p, sh_p, mean_p, rstd_p = T.PRO_NONE, None, None, None, None
+                pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = T.PRO_NONE, None, None, None, None, None
                 a_prev, k_in = x0, x0.shape[1]
-            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p)
+            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p)
             dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:
                 wt = T.cast_weight(Ws[l], transpose=True)          # [K, pad8(N)]
@@ -137,7 +144,8 @@ class _TowerFn(torch.autograd.Function):
                 e_mean = mean_p if mean_p is not None else zeros
                 e_rstd = rstd_p if rstd_p is not None else ones
                 dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD,
-                                     Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd)
+                                     Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd,
+                                     epi_dropout=drop_p)
                 cc = T.reduce_partials(partial)
                 c1, c2 = cc[0], cc[1]
         grads = list(dW) + list(db)
@@ -151,7 +159,7 @@ class FusedTower(nn.Module):
     """create_tower(...) as one fused module; call with the flattened ``[M, F]`` features."""
 
     def __init__(self, input_dim: int, hidden_layer_dims: List[int], output_units: int = 1, activation=None,
-                 use_batch_norm: bool = True, batch_norm_moment: float = 0.999):
+                 use_batch_norm: bool = True, batch_norm_moment: float = 0.999, dropout: float = 0.0):
         super().__init__()
         if not hidden_layer_dims:
             raise ValueError('FusedTower needs at least one hidden layer')
@@ -165,6 +173,10 @@ class FusedTower(nn.Module):
         self.activation = _act_code(activation)
         self.use_batch_norm = bool(use_batch_norm)
         self.momentum = float(batch_norm_moment)
+        if not 0.0 <= float(dropout or 0.0) < 1.0:
+            raise ValueError('dropout rate must be in [0, 1)')
+        self.dropout = float(dropout or 0.0)
+        self._drop_step = 0
         self.weights = nn.ParameterList()
         self.biases = nn.ParameterList()
         self.gammas = nn.ParameterList()

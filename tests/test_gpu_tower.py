@@ -233,3 +233,69 @@ def test_fused_tower_forward_backward(M, F, hidden, O, act, bn):
     with torch.no_grad():
         out_eval = tower(x)
     assert out_eval.shape == (M, O) and bool(torch.isfinite(out_eval).all())
+
+
+def test_dropout_mask_statistics_and_determinism():
+    t = T()
+    for rate in (0.1, 0.5, 0.9):
+        d = t.Dropout.make(rate, 12345)
+        m = t.dropout_mask(d, 4096, 512, DEV)
+        kept = (m > 0).float().mean().item()
+        assert abs(kept - (1 - rate)) < 5e-3, (rate, kept)
+        assert abs(m.mean().item() - 1.0) < 2e-2                      # E[mask] = 1 (inverted dropout)
+        # no row / column structure
+        assert (m > 0).float().mean(0).std().item() < 2e-2 and (m > 0).float().mean(1).std().item() < 3e-2
+        assert torch.equal(m, t.dropout_mask(t.Dropout.make(rate, 12345), 4096, 512, DEV))
+        assert not torch.equal(m, t.dropout_mask(t.Dropout.make(rate, 12346), 4096, 512, DEV))
+
+
+def ref_tower_dropout(x, tower, masks):
+    a = _ste(x)
+    n_h = len(tower.hidden_layer_dims)
+    for l in range(n_h):
+        z32 = a @ _ste(tower.weights[l]).t() + tower.biases[l]
+        z = _ste(z32)
+        if tower.use_batch_norm:
+            mean = z32.mean(0); var = z32.var(0, unbiased=False)
+            y = (z - mean) * torch.rsqrt(var + 1e-3) * tower.gammas[l] + tower.betas[l]
+        else:
+            y = z
+        a = (torch.relu(y) if tower.activation == 'relu' else y) * masks[l]
+        if l < n_h - 1:
+            a = _ste(a)
+    return a @ tower.out_weight.t() + tower.out_bias
+
+
+@pytest.mark.parametrize('M,F,hidden,O,act,bn,rate', [
+    (1500, 136, [512, 256], 1, 'relu', True, 0.5),
+    (700, 24, [64, 64, 32], 2, None, False, 0.25),
+    (900, 40, [128], 1, 'relu', False, 0.1),
+])
+def test_fused_tower_dropout_forward_backward(M, F, hidden, O, act, bn, rate):
+    from ranking_amd.tower import FusedTower
+    t = T()
+    torch.manual_seed(3)
+    tower = FusedTower(F, hidden, O, activation=act, use_batch_norm=bn, dropout=rate).to(DEV)
+    x = rnd((M, F), 60).to(DEV)
+    up = rnd((M, O), 61).to(DEV)
+    tower.train()
+    got = tower(x)
+    got.backward(up)
+    g_got = [p.grad.clone() for p in tower.parameters()]
+    tower.zero_grad()
+    base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
+    masks = [t.dropout_mask(t.Dropout.make(rate, base + l * 0x632BE5AB), M, h, DEV) for l, h in enumerate(hidden)]
+    want = ref_tower_dropout(x, tower, masks)
+    want.backward(up)
+    g_want = [p.grad.clone() for p in tower.parameters()]
+    assert (got - want).abs().max().item() <= 3e-2 * max(1.0, want.abs().max().item())
+    gscale = max(b.abs().max().item() for b in g_want)
+    for n, a, b in zip([n for n, _ in tower.named_parameters()], g_got, g_want):
+        rel = (a - b).norm().item() / (b.norm().item() + 1e-6 * b.numel() ** 0.5)
+        assert rel <= 3e-2 or (a - b).abs().max().item() <= 2e-2 * gscale, (n, rel)
+    got2 = tower(x)                                  # a new step draws a new mask
+    assert not torch.equal(got2, got)
+    tower.eval()
+    with torch.no_grad():
+        e1, e2 = tower(x), tower(x)
+    assert torch.equal(e1, e2)                       # inference: no dropout
