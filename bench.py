@@ -74,7 +74,7 @@ def make_inputs(B, L, seed, device):
     return labels.to(device), logits.to(device)
 
 
-def build_step(workload, labels, logits, dropout=0.0):
+def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
     """Returns (step_fn, kernel_fn) -- kernel_fn launches only the dominant kernel."""
     from ranking_amd import _ops
     from ranking_amd.keras import losses as K
@@ -98,11 +98,11 @@ def build_step(workload, labels, logits, dropout=0.0):
         m = metrics_impl.NDCGMetric(None, None)
         return (lambda: m.compute_multi(labels, logits, None, None, [1, 3, 5, 10, None])), None
     if workload.startswith('e2e_'):
-        return build_e2e_step(workload, labels, dropout), None
+        return build_e2e_step(workload, labels, dropout, use_graph), None
     raise ValueError(workload)
 
 
-def build_e2e_step(workload, labels, dropout=0.0):
+def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     """One data-parallel training step: features [B, L, 136] ~ U(-1, 1) resident in HBM."""
     import ranking_amd as ra
     from ranking_amd import distributed as D
@@ -124,7 +124,9 @@ def build_e2e_step(workload, labels, dropout=0.0):
         gw.add_module('tower', tower)
         gw.to(dev)
         scorer = gw
-        run_scorer = lambda: gw({}, {'x': feats}, mask)
+        gw.train()
+        gidx = gw.group_indices(mask)                         # index plumbing: once per batch, outside the graph
+        run_scorer = lambda: gw({}, {'x': feats}, mask, group_indices=gidx)
         loss = ra.keras.losses.GumbelApproxNDCGLoss(seed=1)
     else:
         scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
@@ -139,19 +141,52 @@ def build_e2e_step(workload, labels, dropout=0.0):
     params = [p for p in scorer.parameters() if p.requires_grad]
     flat_params = None
 
-    def step():
+    def fwd_bwd():
         bucket.zero()
         logits = run_scorer()
         value, dlogits = loss.loss_and_grad(labels, logits.detach())
         logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
-        s = bucket.all_reduce(torch.stack([value, value.new_tensor(1.0)]), average=True)
+        return value
+
+    def sgd():
         with torch.no_grad():                              # SGD on the fp32 master weights
             off = 0
             for p in params:
                 p.add_(bucket.flat[off:off + p.numel()].view_as(p), alpha=-lr)
                 off += p.numel()
+
+    def eager_step():
+        value = fwd_bwd()
+        s = bucket.all_reduce(torch.stack([value, value.new_tensor(1.0)]), average=True)
+        sgd()
         return s[0] / max(world, 1)
-    return step
+
+    if not use_graph:
+        return eager_step
+
+    # hipGraph capture of the launch-bound parts: [zero, scorer fwd, loss, scorer bwd] and [SGD];
+    # the ONE all-reduce of the flat bucket stays between the two replays (RCCL, eager).
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            eager_step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g_fb, g_sgd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    one = torch.ones((), device=dev)
+    with torch.cuda.graph(g_fb):
+        static_value = fwd_bwd()
+        static_scalars = torch.stack([static_value, one])
+    with torch.cuda.graph(g_sgd):
+        sgd()
+
+    def graph_step():
+        g_fb.replay()
+        s = bucket.all_reduce(static_scalars, average=True)
+        g_sgd.replay()
+        return s[0] / max(world, 1)
+    return graph_step
 
 
 def measured_traffic(workload, B, L):
@@ -224,6 +259,8 @@ def main():
     ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
+                    help='e2e workloads: launch eagerly instead of replaying the step from hipGraphs')
     ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
@@ -252,7 +289,7 @@ def main():
     if args.batch > 0:
         B = args.batch
     labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
-    step, kernel_only = build_step(args.workload, labels, logits, args.dropout)
+    step, kernel_only = build_step(args.workload, labels, logits, args.dropout, args.graph)
 
     def barrier():
         if dist is not None:
@@ -331,7 +368,7 @@ def main():
             'kernel': 'whole training step (tower_gemm_kernel / tower_wgrad_kernel dominate; profiles/)',
             'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / step time, per GPU; the [M,512] layers '
                     'are HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample, ~15 s)
         cb = cpu_baseline(args.workload, L)
         if cb is not None:
             result['cpu_baseline'] = cb

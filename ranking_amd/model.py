@@ -61,14 +61,20 @@ class GroupwiseScorer(torch.nn.Module):
                  for i in range(n)]
         return torch.cat([p[0] for p in parts], dim=1), torch.cat([p[1] for p in parts], dim=1)
 
+    def group_indices(self, is_valid, shuffle: Optional[bool] = None):
+        """model.py:313-339: the ([B, G, group_size] indices, [B, G] mask) of a batch.  They depend on
+        the validity mask only, so a caller can build them once per batch (e.g. outside a captured
+        hipGraph: the shuffle draws from a torch.Generator) and pass them to ``forward``."""
+        is_valid = torch.as_tensor(is_valid).to(torch.bool)
+        if shuffle is False:
+            return _form_group_indices_nd(is_valid, self._group_size, shuffle=False)
+        return self._indices(is_valid, self.training)
+
     def forward(self, context_features: Dict[str, torch.Tensor], example_features: Dict[str, torch.Tensor],
-                is_valid, shuffle: Optional[bool] = None) -> torch.Tensor:
+                is_valid, shuffle: Optional[bool] = None, group_indices=None) -> torch.Tensor:
         is_valid = torch.as_tensor(is_valid).to(torch.bool)
         b, l = is_valid.shape
-        if shuffle is False:
-            idx, mask = _form_group_indices_nd(is_valid, self._group_size, shuffle=False)
-        else:
-            idx, mask = self._indices(is_valid, self.training)
+        idx, mask = group_indices if group_indices is not None else self.group_indices(is_valid, shuffle)
         g, gs = idx.shape[1], self._group_size
         big_ctx = {k: v.unsqueeze(1).expand((b, g) + tuple(v.shape[1:])).reshape((b * g,) + tuple(v.shape[1:]))
                    for k, v in (context_features or {}).items()}
