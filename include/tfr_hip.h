@@ -122,6 +122,16 @@ int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* 
                        const float* list_scale, int B, int L, float temperature, float* loss_out,
                        float* weight_out, float* dlogits_out, void* stream);
 
+/* losses_impl.ListMLELoss._compute_unreduced_loss_impl fused with its backward
+ * (losses_impl.py:1541-1576; ListMLELambdaWeight :457-480).
+ *   pos_weight   nullable [L]: rank_discount_fn(p + 1) of a ListMLELambdaWeight (host table)
+ *   loss_out     [B] negative log likelihood per list (the list weight is 1)
+ *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
+ * list_size <= 1024 (TFR_ETOOLARGE otherwise); ties between equal labels keep index order. */
+int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
+                     const float* pos_weight, const float* list_scale, int B, int L,
+                     float temperature, float* loss_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

@@ -597,6 +597,42 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
+class ListMLELambdaWeight:
+    """losses_impl.py:457-480."""
+
+    def __init__(self, rank_discount_fn):
+        self._rank_discount_fn = rank_discount_fn
+
+    def pair_weights(self, labels, ranks):
+        pass
+
+    def individual_weights(self, labels, ranks):
+        return torch.ones_like(_t(labels)) * self._rank_discount_fn(_t(ranks).to(torch.float32))
+
+
+class ListMLELoss(_ListwiseLoss):
+    """losses_impl.py:1541-1576 with the deterministic tie rule (the reference shuffles ties,
+    shuffle_ties=True, seed=37: parity unpinned on tied labels)."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, math.log(_EPSILON) * torch.ones_like(logits))
+        scores = torch.where(mask, labels, labels.min(dim=1, keepdim=True).values - 1e-6 * torch.ones_like(labels))
+        sorted_labels, sorted_logits = sort_by_scores(scores, [labels, logits])
+        raw_max = sorted_logits.max(dim=1, keepdim=True).values
+        sorted_logits = sorted_logits - raw_max
+        sums = torch.flip(torch.cumsum(torch.flip(torch.exp(sorted_logits), dims=[1]), dim=1), dims=[1])
+        sums = torch.log(sums) - sorted_logits
+        if self._lambda_weight is not None and isinstance(self._lambda_weight, ListMLELambdaWeight):
+            b, l = sorted_labels.shape
+            sums = sums * self._lambda_weight.individual_weights(
+                sorted_labels, (torch.arange(l) + 1).unsqueeze(0).expand(b, l))
+        nll = sums.sum(dim=1, keepdim=True)
+        return nll, torch.ones_like(nll)
+
+
 class ApproxMRRLoss(_ListwiseLoss):
     """losses_impl.py:1606-1632."""
 

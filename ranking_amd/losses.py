@@ -51,6 +51,7 @@ _SUPPORTED = {
     RankingLossKey.SIGMOID_CROSS_ENTROPY_LOSS: (losses_impl.SigmoidCrossEntropyLoss, False, False),
     RankingLossKey.APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, False),
     RankingLossKey.APPROX_MRR_LOSS: (losses_impl.ApproxMRRLoss, False, False),
+    RankingLossKey.LIST_MLE_LOSS: (losses_impl.ListMLELoss, True, False),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
 }
 

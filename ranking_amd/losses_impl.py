@@ -515,6 +515,39 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return loss.unsqueeze(1), weight.unsqueeze(1)
 
 
+class ListMLELambdaWeight(_LambdaWeight):
+    """losses_impl.py:457-480."""
+
+    def __init__(self, rank_discount_fn):
+        self._rank_discount_fn = rank_discount_fn
+
+    def pair_weights(self, labels, ranks):
+        pass
+
+    def individual_weights(self, labels, ranks):
+        _check_tensor_shapes([labels, ranks])
+        return torch.ones_like(labels) * self._rank_discount_fn(ranks.to(torch.float32))
+
+
+class ListMLELoss(_ListwiseLoss):
+    """losses_impl.py:1541-1576; fused kernel tfr_list_mle_f32 (ties between equal labels keep index
+    order; the reference shuffles them with a fixed op seed)."""
+
+    def _pos_weight(self, list_size, device):
+        if isinstance(self._lambda_weight, ListMLELambdaWeight):
+            return _ops.rank_table(self._lambda_weight._rank_discount_fn, list_size, device)
+        return None
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        pw = self._pos_weight(logits.shape[1], logits.device)
+
+        def runner(lg, want_grad):
+            loss, d = _ops.list_mle(lg, labels, mask, pw, None, temperature, want_grad)
+            return loss, d, ()
+        (loss,) = _PerListLossFn.apply(logits, runner)
+        return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)
+
+
 class ApproxMRRLoss(_ListwiseLoss):
     """losses_impl.py:1606-1632; fused kernel tfr_approx_mrr_f32."""
 

@@ -822,3 +822,48 @@ def test_more_metrics_keras_and_factory_keys():
     assert abs(float(m.result()) - 0.5) < 1e-6
     with pytest.raises(ValueError):
         km.get('alpha_dcg')
+
+
+# ------------------------------------------------------------------ ListMLE
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300)])
+@pytest.mark.parametrize('with_lambda', [False, True])
+def test_list_mle_parity(B, L, with_lambda):
+    labels, logits = make_batch(B, L, seed=1100 + L)
+    # distinct labels per list (ties are shuffled at random by the reference: unpinned)
+    g = torch.Generator().manual_seed(L)
+    labels = torch.where(labels >= 0, labels + torch.rand(labels.shape, generator=g) * 0.5, labels)
+    if B >= 3:
+        labels[1] = -1.0
+    T_ = 0.7
+    disc = (lambda rank: 1. / torch.log1p(rank)) if with_lambda else None
+    oracle = R.ListMLELoss(lambda_weight=R.ListMLELambdaWeight(disc) if with_lambda else None, temperature=T_)
+    want, want_g = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels, lg / T_)[0], logits)
+    from ranking_amd import _ops
+    pw = _ops.rank_table(disc, L, torch.device(DEV)) if with_lambda else None
+    loss, d = _ops.list_mle(logits.to(DEV), labels.to(DEV), None, pw, None, T_)
+    scale = max(1.0, want.abs().max().item())
+    assert_loss_close(loss / scale, want.reshape(-1) / scale, what='list_mle loss')
+    assert_grad_close(d, want_g, what='list_mle grad')
+
+
+def test_list_mle_reference_goldens_and_keras():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    ln = math.log
+    scores = t([[0., ln(3), ln(2)], [0., ln(2), ln(3)]]); labels = t([[0., 2., 1.], [1., 0., 2.]])
+    red = L.Reduction.SUM_BY_NONZERO_WEIGHTS
+    want = -((ln(3. / 6) + ln(2. / 3) + ln(1. / 1)) + (ln(3. / 6) + ln(1. / 3) + ln(2. / 2))) / 2
+    assert abs(L.ListMLELoss(None).compute(labels, scores, None, red).item() - want) < 1e-5      # losses_impl_test.py:1276-1291
+    lw = L.ListMLELambdaWeight(rank_discount_fn=lambda rank: torch.pow(torch.tensor(2.), 3 - rank) - 1.)
+    want = -((3 * ln(3. / 6) + 1 * ln(2. / 3)) + (3 * ln(3. / 6) + 1 * ln(1. / 3))) / 2
+    assert abs(L.ListMLELoss(None, lambda_weight=lw).compute(labels, scores, None, red).item() - want) < 1e-5   # :1304-1316
+    got = L.ListMLELoss(None).compute(t([[0., 0., 1.]]), t([[0., ln(2), ln(3)]]), None, red, mask=t([[True, False, True]]))
+    assert abs(got.item() + (ln(3. / 4) + ln(1. / 1))) < 1e-5                                    # :1318-1328
+    k = K.get('list_mle_loss')
+    assert abs(k(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.7981389) < 1e-6                      # keras/losses.py:1032-1036
+    lb, lg = make_batch(6, 30, seed=4)
+    v, d = k.loss_and_grad(lb.to(DEV), lg.to(DEV))
+    lgd = lg.to(DEV).requires_grad_(True)
+    out = k(lb.to(DEV), lgd); out.backward()
+    assert abs(v.item() - out.item()) < 1e-5 and torch.allclose(d, lgd.grad, atol=1e-6)

@@ -176,6 +176,7 @@ RAGGED_W = [[2., 3., 4.], [1., 1.]]
     (R.SoftmaxLoss, [1.407606, 0.126928], [4., 2.]),
     (R.ApproxNDCGLoss, [-0.63093, -0.922917], [4., 1.]),
     (R.ApproxMRRLoss, [-0.5, -0.893493], [4., 1.]),
+    (R.ListMLELoss, [3.534534, 0.126928], [4., 1.]),
 ])
 def test_compute_per_list_ragged(ctor, exp_l, exp_w):
     losses, weights = ctor(ragged=True).compute_per_list(RAGGED_LABELS, RAGGED_SCORES, RAGGED_W)
@@ -574,3 +575,23 @@ def test_more_metrics_reference_literals(case):
         close(out, exp, 1e-6)
     if exp_w is not None:
         close(w, exp_w, 1e-6)
+
+
+# ------------------------------------------------------------------ ListMLE
+def test_list_mle_reference_literals():
+    """losses_impl_test.py:1276-1328 (the tie test :1293-1302 depends on TF's shuffle: unpinned)."""
+    ln = math.log
+    scores = torch.tensor([[0., ln(3), ln(2)], [0., ln(2), ln(3)]])
+    labels = torch.tensor([[0., 2., 1.], [1., 0., 2.]])
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    loss = R.ListMLELoss()
+    want = -((ln(3. / 6) + ln(2. / 3) + ln(1. / 1)) + (ln(3. / 6) + ln(1. / 3) + ln(2. / 2))) / 2
+    assert abs(loss.compute(labels, scores, None, red).item() - want) < 1e-5
+    want = -(2 * (ln(3. / 6) + ln(2. / 3) + ln(1. / 1)) + (ln(3. / 6) + ln(1. / 3) + ln(2. / 2))) / 2
+    assert abs(loss.compute(labels, scores, torch.tensor([[2.], [1.]]), red).item() - want) < 1e-5
+    lw = R.ListMLELambdaWeight(rank_discount_fn=lambda rank: torch.pow(torch.tensor(2.), 3 - rank) - 1.)
+    want = -((3 * ln(3. / 6) + 1 * ln(2. / 3) + 0) + (3 * ln(3. / 6) + 1 * ln(1. / 3) + 0)) / 2
+    assert abs(R.ListMLELoss(lambda_weight=lw).compute(labels, scores, None, red).item() - want) < 1e-5
+    got = R.ListMLELoss().compute(torch.tensor([[0., 0., 1.]]), torch.tensor([[0., ln(2), ln(3)]]), None, red,
+                                  mask=torch.tensor([[True, False, True]]))
+    assert abs(got.item() + (ln(3. / 4) + ln(1. / 1))) < 1e-5
