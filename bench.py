@@ -359,6 +359,11 @@ def main():
         }
         n_valid_sq = float(((labels >= 0).sum(dim=1).double() ** 2).sum().item())
         result['roofline']['pairs_per_s'] = 2.0 * n_valid_sq / (kernel_ms * 1e-3)   # fwd + bwd evaluations
+        # VALU issue floor of the two pair sweeps alone (tools/ubench.hip on MI355X: 15.3 + 20.5 cycles per 64
+        # pair evaluations per SIMD; 1024 SIMDs at the 2.4 GHz peak clock) -- the bound that actually applies.
+        valu_floor_ms = n_valid_sq / 64.0 * (15.3 + 20.5) / (1024 * 2.4e9) * 1e3
+        result['roofline']['valu_floor_ms'] = valu_floor_ms
+        result['roofline']['valu_frac'] = valu_floor_ms / kernel_ms
     if args.workload.startswith('e2e_'):
         tflops = e2e_flops_per_list(args.workload, L) * B * world / (elapsed / args.steps) / 1e12
         result['dtype'] = 'bf16'
