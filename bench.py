@@ -260,7 +260,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
-                    help='e2e workloads: launch eagerly instead of replaying the step from hipGraphs')
+                    help='launch eagerly instead of replaying the step from hipGraphs')
     ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
@@ -290,6 +290,24 @@ def main():
         B = args.batch
     labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
     step, kernel_only = build_step(args.workload, labels, logits, args.dropout, args.graph)
+    if args.graph and not args.workload.startswith('e2e_'):
+        # The loss step is a handful of short launches (order, loss kernel, reduction): replay it from a
+        # hipGraph so that the measured rate is the GPU's, not the Python launch path's.
+        eager = step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_out = eager()
+
+        def step():
+            graph.replay()
+            return static_out
 
     def barrier():
         if dist is not None:

@@ -113,14 +113,22 @@ int tfr_mrr_metric_f32(const float* labels, const float* predictions, const floa
 int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
                         const float* inv_log1p, const float* list_scale, int B, int L,
                         float temperature, int lanes_per_row, float* loss_out, float* weight_out,
-                        float* dlogits_out, void* stream);
+                        float* dlogits_out, const int32_t* list_order, void* stream);
+
+/* Longest-first launch order for the O(n^2) loss kernels (their `list_order` argument, nullable):
+ * order_out[B] = list indices by decreasing number of valid items (16 length classes; arbitrary
+ * order inside a class).  Results of the loss kernels
+ * do not depend on it (each list is written to its own rows); it shortens the end-of-kernel tail.
+ *   workspace  int32[B] scratch owned by the caller. */
+int tfr_list_order_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
+                       int32_t* workspace, void* stream);
 
 /* losses_impl.ApproxMRRLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:77-106, 1606-1632): loss_b = -sum_i (l_i / sum l) / approx_rank_i; same
  * conventions as tfr_approx_ndcg_f32 (temperature applied inside, weight_out = 1{sum label > 0}). */
 int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* mask,
                        const float* list_scale, int B, int L, float temperature, float* loss_out,
-                       float* weight_out, float* dlogits_out, void* stream);
+                       float* weight_out, float* dlogits_out, const int32_t* list_order, void* stream);
 
 /* losses_impl.ListMLELoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:1541-1576; ListMLELambdaWeight :457-480).
@@ -160,7 +168,7 @@ int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* label
                           int gain_kind, const float* gains, const float* discount,
                           int B, int L, float temperature,
                           float* row_loss_out, float* row_weight_out, float* nnz_out,
-                          float* dlogits_out, void* stream);
+                          float* dlogits_out, const int32_t* list_order, void* stream);
 
 /* losses_impl.SoftmaxLoss.precompute + _compute_unreduced_loss_impl fused with
  * the backward (losses_impl.py:1119-1197, 281-296).

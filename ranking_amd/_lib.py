@@ -35,9 +35,10 @@ _SIGNATURES = {
     'tfr_mrr_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p]
                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                            + [ctypes.c_int] + [ctypes.c_void_p] * 4),
+                            + [ctypes.c_int] + [ctypes.c_void_p] * 5),
+    'tfr_list_order_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
     'tfr_approx_mrr_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                           + [ctypes.c_void_p] * 4),
+                           + [ctypes.c_void_p] * 5),
     'tfr_list_mle_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                          + [ctypes.c_void_p] * 3),
     'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
@@ -45,7 +46,7 @@ _SIGNATURES = {
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_pairwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                               + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
-                              + [ctypes.c_float] + [ctypes.c_void_p] * 5),
+                              + [ctypes.c_float] + [ctypes.c_void_p] * 6),
     'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                              + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
     'tfr_gumbel_sample_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_uint64] * 2 + [ctypes.c_int] * 3

@@ -185,8 +185,36 @@ def mrr_metric(labels, predictions, weights, mask, topns):
 
 
 # ------------------------------------------------------------------ losses
+_BALANCE_MIN_LISTS = 1024      # below this the ordering launch costs more than the tail it removes
+
+
+def list_order(labels, mask=None):
+    """tfr_list_order_i32: int32 [B] list indices, longest valid length first (launch order of the
+    O(n^2) loss kernels; their results do not depend on it)."""
+    labels = _f32(labels, 'labels'); mask = _u8(mask, 'mask')
+    B, L = labels.shape
+    order = torch.empty((B,), dtype=torch.int32, device=labels.device)
+    ws = torch.empty((B,), dtype=torch.int32, device=labels.device)
+    rc = _lib.load().tfr_list_order_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _stream())
+    _lib.check(rc, 'tfr_list_order_i32')
+    return order
+
+
+def _auto_order(labels, mask, balance, min_list_size):
+    """balance: None = automatic, False = index order, True = compute the order, or a ready int32 [B] order.
+    Automatic: the two ordering launches cost ~20 us; they pay for themselves when the tail they remove
+    (about one long list's wave time, ~ list_size^2) is longer -- measured break-even: ApproxNDCG around
+    list_size 300, the (4x heavier per pair) pairwise losses around 128."""
+    if torch.is_tensor(balance):
+        return balance
+    B, L = labels.shape
+    if balance is None:
+        balance = B >= _BALANCE_MIN_LISTS and L >= min_list_size
+    return list_order(labels, mask) if balance else None
+
+
 def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lanes_per_row=0,
-                want_grad=True):
+                want_grad=True, balance=None):
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
@@ -197,12 +225,13 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
     rc = _lib.load().tfr_approx_ndcg_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                          _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
-                                         _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
+                                         _ptr(loss), _ptr(weight), _ptr(dlogits),
+                                         _ptr(_auto_order(labels, mask, balance, 320)), _stream())
     _lib.check(rc, 'tfr_approx_ndcg_f32')
     return loss, weight, dlogits
 
 
-def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want_grad=True):
+def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want_grad=True, balance=None):
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
@@ -211,7 +240,8 @@ def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want
     weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
     rc = _lib.load().tfr_approx_mrr_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
-                                        float(temperature), _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
+                                        float(temperature), _ptr(loss), _ptr(weight), _ptr(dlogits),
+                                        _ptr(_auto_order(labels, mask, balance, 320)), _stream())
     _lib.check(rc, 'tfr_approx_mrr_f32')
     return loss, weight, dlogits
 
@@ -232,7 +262,7 @@ def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temper
 def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
-                      want_grad=True, want_rows=True, want_aux=True, loss_kind=0):
+                      want_grad=True, want_rows=True, want_aux=True, loss_kind=0, balance=None):
     """loss_kind: PAIR_LOGISTIC / PAIR_HINGE / PAIR_SOFT_ZERO_ONE.  want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
     SUM_BY_NONZERO_WEIGHTS reductions and compute_per_list need them): a leaner kernel variant."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
@@ -250,7 +280,7 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
         int(loss_kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
         int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
         _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
-        _ptr(nnz), _ptr(dlogits), _stream())
+        _ptr(nnz), _ptr(dlogits), _ptr(_auto_order(labels, mask, balance, 128)), _stream())
     _lib.check(rc, 'tfr_pairwise_loss_f32')
     return row_loss, row_weight, nnz, dlogits
 

@@ -94,11 +94,12 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
                                    const uint8_t* __restrict__ mask, const float* __restrict__ inv_log1p,
                                    const float* __restrict__ list_scale, int L, int Lp, int P,
                                    float temperature, int C, float* __restrict__ loss_out,
-                                   float* __restrict__ weight_out, float* __restrict__ dlogits_out, int metric) {
+                                   float* __restrict__ weight_out, float* __restrict__ dlogits_out, int metric,
+                                   const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Smem s = carve(smem_raw, Lp, P);
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = T >> 6;
-  const int b = blockIdx.x;
+  const int b = order ? order[blockIdx.x] : blockIdx.x;
   const size_t base = (size_t)b * L;
 
   // ---- 1. load, clean (losses_impl.py:1589-1594), per-list label statistics.
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
     float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
-    float* __restrict__ dlogits_out, int max_runs, int metric) {
+    float* __restrict__ dlogits_out, int max_runs, int metric, const int* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
   float* E = X + Lp;                               // [Lp] exp(x - m)
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   float* G = A + Lp;                               // [Lp] compact gain
   int* CI = reinterpret_cast<int*>(G + Lp);        // [Lp] compact -> original index
   const int lane = threadIdx.x;
-  const int b = blockIdx.x;
+  const int b = order ? order[blockIdx.x] : blockIdx.x;      // longest-first launch order (tfr_list_order_i32)
   const size_t base = (size_t)b * L;
   constexpr float kLn2 = 0.69314718055994530942f;
 #ifdef TFR_PROFILE_STAMPS
@@ -580,12 +581,12 @@ int env_int(const char* name, int dflt);
 template <int IPL>
 int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
                 const float* list_scale, int B, int L, float temperature, int C, float* loss_out,
-                float* weight_out, float* dlogits_out, hipStream_t stream, int metric) {
+                float* weight_out, float* dlogits_out, hipStream_t stream, int metric, const int* order) {
   const int Lp = ((L + 3) / 4) * 4 + 4;
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
-                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric);
+                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order);
   return (int)hipGetLastError();
 }
 
@@ -599,7 +600,7 @@ int env_int(const char* name, int dflt) {
 static int approx_dispatch(int metric, const float* logits, const float* labels, const uint8_t* mask,
                            const float* inv_log1p, const float* list_scale, int B, int L,
                            float temperature, int lanes_per_row, float* loss_out,
-                           float* weight_out, float* dlogits_out, void* stream) {
+                           float* weight_out, float* dlogits_out, const int* order, void* stream) {
   if (!logits || !labels || (!inv_log1p && metric == TFR_APPROX_NDCG) || !loss_out || !weight_out || B < 0 || L <= 0)
     return TFR_EINVAL;
   if (!(temperature > 0.0f)) return TFR_EINVAL;
@@ -615,11 +616,11 @@ static int approx_dispatch(int metric, const float* logits, const float* labels,
   // alone fills the chip with single waves (otherwise several waves share a list).
   if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
     hipStream_t st = (hipStream_t)stream;
-    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
-    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
-    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
-    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
-    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric);
+    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
+    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
+    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
+    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
+    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
   }
   int T = env_threads > 0 ? env_threads : (L <= 128 ? 64 : (L <= 512 ? 128 : 512));
   if (T % 64 || T > 1024) return TFR_EINVAL;
@@ -634,7 +635,7 @@ static int approx_dispatch(int metric, const float* logits, const float* labels,
   }
   hipLaunchKernelGGL(approx_ndcg_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, logits, labels,
                      mask, inv_log1p, list_scale, L, Lp, P, temperature, C, loss_out, weight_out,
-                     dlogits_out, metric);
+                     dlogits_out, metric, order);
   return (int)hipGetLastError();
 }
 
@@ -642,16 +643,18 @@ static int approx_dispatch(int metric, const float* logits, const float* labels,
 extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t* mask,
                                    const float* inv_log1p, const float* list_scale, int B, int L,
                                    float temperature, int lanes_per_row, float* loss_out,
-                                   float* weight_out, float* dlogits_out, void* stream) {
+                                   float* weight_out, float* dlogits_out, const int32_t* list_order,
+                                   void* stream) {
   return approx_dispatch(TFR_APPROX_NDCG, logits, labels, mask, inv_log1p, list_scale, B, L, temperature,
-                         lanes_per_row, loss_out, weight_out, dlogits_out, stream);
+                         lanes_per_row, loss_out, weight_out, dlogits_out, list_order, stream);
 }
 
 extern "C" int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* mask,
                                   const float* list_scale, int B, int L, float temperature,
-                                  float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
+                                  float* loss_out, float* weight_out, float* dlogits_out,
+                                  const int32_t* list_order, void* stream) {
   return approx_dispatch(TFR_APPROX_MRR, logits, labels, mask, nullptr, list_scale, B, L, temperature, 0,
-                         loss_out, weight_out, dlogits_out, stream);
+                         loss_out, weight_out, dlogits_out, list_order, stream);
 }
 
 #ifdef TFR_PROFILE_STAMPS

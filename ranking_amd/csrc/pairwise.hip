@@ -37,9 +37,10 @@ struct PwArgs {
   const float* gains; const float* discount;
   int L; int Lp; int P; float temperature; int C; int kind;
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
+  const int* order;                      // longest-first launch order (nullable)
 };
 
-__host__ __device__ inline size_t pw_wave_lds(int Lp) { return (size_t)Lp * (16 + 16 + 8 + 4 + 4 + 4 + 4) + 16; }
+__host__ __device__ inline size_t pw_wave_lds(int Lp) { return (size_t)Lp * (16 + 8 + 4 + 4 + 4) + 16; }
 
 __host__ __device__ inline size_t pw_smem_bytes(int Lp, int P) {
   return 256 + (size_t)P * 8 + (size_t)Lp * 4 * 12 + (size_t)Lp * 2 + 32;
@@ -175,7 +176,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
   uint8_t* LV = MV + Lp;                                      // [Lp] label-valid
 
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = T >> 6;
-  const int b = blockIdx.x, L = a.L, P = a.P;
+  const int b = a.order ? a.order[blockIdx.x] : blockIdx.x, L = a.L, P = a.P;
   const size_t base = (size_t)b * L;
   const int topn = (a.topn <= 0 || a.topn > L) ? L : a.topn;
   const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
@@ -359,6 +360,14 @@ __device__ __forceinline__ void wave_sort_desc_u32(uint32_t (&a)[IPL], int lane)
   }
 }
 
+// Developer aid (never in the product build): see approx_ndcg.hip / tools/phase_profile.py.
+#ifdef TFR_PROFILE_STAMPS
+__device__ unsigned long long* g_prof_buf_pw = nullptr;
+#define PW_STAMP(i) do { if (lane == 0 && wave == 0) prof_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PW_STAMP(i) do { } while (0)
+#endif
+
 // KIND: TFR_PAIR_LOGISTIC at compile time (the hot configuration), or -1 = a.kind at run time.
 template <int IPL, int LAMBDA, bool GENERIC, bool AUX, bool ITEMW, int KIND>
 __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
@@ -370,21 +379,26 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   unsigned char* smem_raw = smem_all + (size_t)wave * pw_wave_lds(a.Lp);
   float* nz_slot = reinterpret_cast<float*>(smem_all + (size_t)S * pw_wave_lds(a.Lp));   // [S]
   const int Lp = a.Lp;
-  float4* rec0 = reinterpret_cast<float4*>(smem_raw);                  // [Lp] (x, raw label, gain, weight), compaction order
-  float4* recS = rec0 + Lp;                                            // [Lp] the same records in RANK order
+  // Per-item data stay in REGISTERS (item e = lane + 64 r) until their rank is known and are then
+  // written once, in rank order: 36 bytes of LDS per item -> 7+ list-waves per SIMD.
+  float4* recS = reinterpret_cast<float4*>(smem_raw);                  // [Lp] (x, raw label, gain, weight) in RANK order
   float2* auxS = reinterpret_cast<float2*>(recS + Lp);                 // [Lp] (D'(rank), label-valid flag), rank order
   float* XS = reinterpret_cast<float*>(auxS + Lp);                     // [Lp] compact x (pad -inf) for the rank count
   float* U = XS + Lp;                                                  // [Lp] |D(m) - D(m+1)|
-  int* CI = reinterpret_cast<int*>(U + Lp);                            // [Lp] compact -> original (sign: label validity)
-  int* CIS = CI + Lp;                                                  // [Lp] rank position -> original
+  int* CIS = reinterpret_cast<int*>(U + Lp);                           // [Lp] rank position -> original index
   float2* rec1 = auxS;                                                 // scratch alias for the custom-gain ideal DCG
-  const int lane = threadIdx.x & 63, b = blockIdx.x, L = a.L;
+  const int lane = threadIdx.x & 63, b = a.order ? a.order[blockIdx.x] : blockIdx.x, L = a.L;
   const size_t base = (size_t)b * L;
   const int topn = (a.topn <= 0 || a.topn > L) ? L : a.topn;
   const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
+#ifdef TFR_PROFILE_STAMPS
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PW_STAMP(0);
 
   // ---- 1. load; gains; compaction of the mask-valid items.
-  float g[IPL];
+  float g[IPL], xr[IPL], labr[IPL], wr[IPL];
+  int posr[IPL];
   bool lv[IPL], mv[IPL];
   int n = 0;
 #pragma unroll
@@ -412,15 +426,13 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       }
     }
     const unsigned long long bal = __ballot(mv[r]);
-    if (mv[r]) {
-      const int pos = n + __popcll(bal & ((1ull << lane) - 1ull));
-      rec0[pos] = make_float4(x, lab, lv[r] ? g[r] : 0.0f, w);
-      XS[pos] = x;
-      CI[pos] = lv[r] ? e : -e - 1;                        // sign carries label validity
-    }
+    xr[r] = x; labr[r] = lab; wr[r] = w;
+    posr[r] = n + __popcll(bal & ((1ull << lane) - 1ull));     // compaction position (ties: lower first)
+    if (mv[r]) XS[posr[r]] = x;
     n += __popcll(bal);
   }
 
+  PW_STAMP(1);
   // ---- 2. ideal DCG@topn of the cleaned labels (:109-134), in registers.
   float inv_max_dcg = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   }
   WAVE_LDS_SYNC();
 
+  PW_STAMP(2);
   // ---- 3. ranks by counting (valid first, score desc, ties by index) (:483-500); the
   // records are then re-homed in RANK order so that in the sweep the rank of a column is its
   // position and the |rank_i - rank_j| discount is an affine (data independent) LDS address.
@@ -500,9 +513,11 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
   WAVE_LDS_SYNC();
   const float4* X4 = reinterpret_cast<const float4*>(XS);
-  for (int p = lane; p < n; p += 64) {
-    const float4 me = rec0[p];
-    const float xi = me.x;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    if (!mv[r]) continue;
+    const float xi = xr[r];
+    const int p = posr[r];
     int cnt = 0;
     for (int gq = 0; gq < n4; ++gq) {
       const float4 xx = X4[gq];
@@ -512,16 +527,15 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       cnt += (xx.z > xi || (xx.z == xi && j + 2 < p)) ? 1 : 0;
       cnt += (xx.w > xi || (xx.w == xi && j + 3 < p)) ? 1 : 0;
     }
-    const int ci = CI[p];
     float dprime = 0.f;
-    float gz = me.z;
+    float gz = lv[r] ? g[r] : 0.0f;
     if (LAMBDA == TFR_LAMBDA_DCG) {
       dprime = (cnt < topn) ? a.discount[cnt] : 0.0f;
       if (a.normalized) gz *= inv_max_dcg;
     }
-    recS[cnt] = make_float4(xi, me.y, gz, me.w);
-    auxS[cnt] = make_float2(dprime, ci >= 0 ? 1.0f : 0.0f);
-    CIS[cnt] = ci >= 0 ? ci : -ci - 1;
+    recS[cnt] = make_float4(xi, labr[r], gz, wr[r]);
+    auxS[cnt] = make_float2(dprime, lv[r] ? 1.0f : 0.0f);
+    CIS[cnt] = lane + 64 * r;
   }
   const int C = a.C;
   const int npad = ((n + 2 * C - 1) / (2 * C)) * (2 * C);            // two columns per trip per lane
@@ -531,6 +545,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   }
   WAVE_LDS_SYNC();
 
+  PW_STAMP(3);
   // ---- 4. pair sweep: row = C adjacent lanes, 64/C rows per pass, two columns per trip.
   const int rows_per_pass = 64 / C;
   const int c = lane % C, rsub = lane / C;
@@ -573,6 +588,13 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       nnz_local += acc_nz;
     }
   }
+  PW_STAMP(4);
+#ifdef TFR_PROFILE_STAMPS
+  if (lane == 0 && wave == 0 && g_prof_buf_pw) {
+    prof_t[7] = (unsigned long long)n;
+    for (int i = 0; i < 8; ++i) g_prof_buf_pw[(size_t)b * 8 + i] = prof_t[i];
+  }
+#endif
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
   if (!AUX) return;
@@ -594,7 +616,7 @@ int env_int(const char* name, int dflt);
 template <int IPL>
 int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   static const int env_s = env_int("TFR_PAIRWISE_WAVES_PER_LIST", 0);
-  int S = env_s > 0 ? env_s : (B >= 8192 ? 1 : (B >= 4096 ? 2 : 4));
+  int S = env_s > 0 ? env_s : 1;     // (S > 1 measured slower at every batch size tried)
   if (S > 4) S = 4;
   if (a.L <= 64) S = 1;
   while (S > 1 && (size_t)S * pw_wave_lds(a.Lp) + 16 > 60 * 1024) S >>= 1;
@@ -631,7 +653,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          int normalized, int gain_kind, const float* gains,
                                          const float* discount, int B, int L, float temperature,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
-                                         float* dlogits_out, void* stream) {
+                                         float* dlogits_out, const int* order, void* stream) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_SOFT_ZERO_ONE) return TFR_EINVAL;
   if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG &&
@@ -656,7 +678,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
     const int c2 = (2 * C > 4) ? 2 * C : 4;
     w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
     w.temperature = temperature; w.C = C; w.kind = kind; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
-    w.nnz = nnz_out; w.dlogits = dlogits_out;
+    w.nnz = nnz_out; w.dlogits = dlogits_out; w.order = order;
     hipStream_t st = (hipStream_t)stream;
     if (L <= 64) return launch_pw_wave<1>(w, B, st);
     if (L <= 128) return launch_pw_wave<2>(w, B, st);
@@ -670,7 +692,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   a.smooth = smooth_fraction; a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains;
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
   a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
-  a.nnz = nnz_out; a.dlogits = dlogits_out;
+  a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
   const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
@@ -702,7 +724,7 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
                                          float* dlogits_out, void* stream) {
   return pairwise_dispatch(TFR_PAIR_LOGISTIC, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
-                           row_loss_out, row_weight_out, nnz_out, dlogits_out, stream);
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, nullptr, stream);
 }
 
 extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
@@ -711,8 +733,15 @@ extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const f
                                      int normalized, int gain_kind, const float* gains,
                                      const float* discount, int B, int L, float temperature,
                                      float* row_loss_out, float* row_weight_out, float* nnz_out,
-                                     float* dlogits_out, void* stream) {
+                                     float* dlogits_out, const int32_t* list_order, void* stream) {
   return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
-                           row_loss_out, row_weight_out, nnz_out, dlogits_out, stream);
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, stream);
 }
+
+#ifdef TFR_PROFILE_STAMPS
+extern "C" int tfr_prof_set_buffer_pw(void* device_u64_buffer) {
+  unsigned long long* p = (unsigned long long*)device_u64_buffer;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf_pw), &p, sizeof(p));
+}
+#endif

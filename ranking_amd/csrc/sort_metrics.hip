@@ -467,6 +467,50 @@ void dispatch_metric_wave(int L, const float* labels, const float* predictions, 
 #undef MW
 }
 
+// Longest-first launch order for the O(n^2) loss kernels.  Their work per list goes with the
+// square of its valid length, so with lists dispatched in index order the last wavefronts to
+// start can be the longest ones and the kernel ends on a long low-occupancy tail (measured:
+// -10 % ApproxNDCG kernel time).  Two small launches:
+// (1) list_count_kernel: one wave per list counts its valid items (fully parallel);
+// (2) list_scatter_kernel: ONE workgroup buckets the lists into kOrderClasses length classes
+//     (longest first) with LDS atomics: class histogram, prefix, then cursor fetch-adds.  Within a
+//     class the order is whatever the LDS atomics gave -- the loss kernels write each list to its
+//     own rows, so their results do not depend on it.  (A histogram by GLOBAL atomics cost 50 us
+//     here: ~100 hot addresses; ballot counting on one CU 30 us.)
+constexpr int kOrderClasses = 16;
+
+__global__ __launch_bounds__(256) void list_count_kernel(const float* __restrict__ labels,
+                                                         const uint8_t* __restrict__ mask, int B, int L,
+                                                         int* __restrict__ nvalid) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+  if (b >= B) return;
+  const size_t base = (size_t)b * L;
+  int n = 0;
+  for (int c = 0; c < L; c += 64) {                         // wave-uniform trip count
+    const int i = c + lane;
+    const bool v = (i < L) && (mask ? (mask[base + i] != 0) : (labels[base + i] >= 0.0f));
+    n += __popcll(__ballot(v));
+  }
+  if (lane == 0) nvalid[b] = n;
+}
+
+__global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const int* __restrict__ nvalid,
+                                                            int* __restrict__ order_out) {
+  __shared__ int s_hist[kOrderClasses];                     // class counts, then running cursors
+  auto cls_of = [&](int n) { return kOrderClasses - 1 - (n * kOrderClasses) / (L + 1); };   // 0 = longest
+  if (threadIdx.x < kOrderClasses) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 1024) atomicAdd(&s_hist[cls_of(nvalid[i])], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {                                   // exclusive prefix over the classes
+    int run = 0;
+    for (int c = 0; c < kOrderClasses; ++c) { const int v = s_hist[c]; s_hist[c] = run; run += v; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < B; i += 1024) order_out[atomicAdd(&s_hist[cls_of(nvalid[i])], 1)] = i;
+}
+
 inline int block_threads_for(int P) {
   int t = P / 2;
   if (t < 64) t = 64;
@@ -566,5 +610,16 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
 #define M2(I) hipLaunchKernelGGL(rank_metric2_wave_kernel<I>, dim3(B), dim3(64), (size_t)2 * 64 * I * sizeof(float), st, kind, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out)
   if (L <= 64) M2(1); else if (L <= 128) M2(2); else if (L <= 256) M2(4); else if (L <= 512) M2(8); else M2(16);
 #undef M2
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
+                                  int32_t* workspace, void* stream) {
+  if ((!labels && !mask) || !order_out || !workspace || B < 0 || L <= 0) return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(list_count_kernel, dim3((B + 3) / 4), dim3(256), 0, st, labels, mask, B, L, (int*)workspace);
+  hipLaunchKernelGGL(list_scatter_kernel, dim3(1), dim3(1024), 0, st, B, L, (const int*)workspace, (int*)order_out);
   return (int)hipGetLastError();
 }

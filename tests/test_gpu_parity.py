@@ -867,3 +867,31 @@ def test_list_mle_reference_goldens_and_keras():
     lgd = lg.to(DEV).requires_grad_(True)
     out = k(lb.to(DEV), lgd); out.backward()
     assert abs(v.item() - out.item()) < 1e-5 and torch.allclose(d, lgd.grad, atol=1e-6)
+
+
+# ------------------------------------------------------------------ longest-first launch order
+@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (300, 50), (2048, 200), (4100, 33)])
+def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_it(B, L):
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=1200 + L)
+    order = _ops.list_order(labels.to(DEV)).cpu().long()
+    assert torch.equal(torch.sort(order).values, torch.arange(B))
+    n = (labels >= 0).sum(1)
+    cls = lambda v: (v * 16) // (L + 1)                     # 16 length classes, longest class first
+    assert bool((cls(n[order])[:-1] >= cls(n[order])[1:]).all())
+    mask = labels >= 0
+    mask[:, 0] = False
+    order_m = _ops.list_order(labels.to(DEV), mask.to(DEV)).cpu().long()
+    nm = mask.sum(1)
+    assert torch.equal(torch.sort(order_m).values, torch.arange(B))
+    assert bool((cls(nm[order_m])[:-1] >= cls(nm[order_m])[1:]).all())
+    for bal in (False, True):
+        outs = _ops.approx_ndcg(logits.to(DEV), labels.to(DEV), None, None, 0.1, 0, True, balance=bal)
+        if bal:
+            assert all(torch.equal(a, b) for a, b in zip(outs, ref))
+        ref = outs
+    k = ra().keras.losses
+    lam = ra().losses_impl._lambda_kernel_args(k.NDCGLambdaWeight(), labels.to(DEV), L, torch.device(DEV))
+    a = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=False, **lam)
+    b = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=True, **lam)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

@@ -41,13 +41,16 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     # null pointers / bad sizes -> TFR_EINVAL (-1); L > 8192 -> TFR_ETOOLARGE (-2).  No GPU needed.
     assert lib.tfr_sort_ranks_f32(None, None, None, None, 1, 4, None, None, None) == -1
     one = ctypes.c_void_p(16)
-    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 9000, 0.1, 0, one, one, None, None) == -2
-    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, -1.0, 0, one, one, None, None) == -1
-    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, 0.1, 3, one, one, None, None) == -1
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 9000, 0.1, 0, one, one, None, None, None) == -2
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, -1.0, 0, one, one, None, None, None) == -1
+    assert lib.tfr_approx_ndcg_f32(one, one, None, one, None, 1, 8, 0.1, 3, one, one, None, None, None) == -1
     assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 2, 0, 1.5, 0, 0, None, one, 1, 8, 1.0,
                                          None, None, None, None, None) == -1       # smooth_fraction
     assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 7, 0, 0.0, 0, 0, None, one, 1, 8, 1.0,
                                          None, None, None, None, None) == -1       # lambda kind
+    assert lib.tfr_list_order_i32(None, None, 4, 8, one, one, None) == -1
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 2000, 1.0, one, None, None) == -2
+    assert lib.tfr_rank_metric_f32(9, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, None) == -1
     topn = (ctypes.c_int32 * 1)(10)
     assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
     assert lib.tfr_gumbel_sample_f32(one, one, None, None, 0, 0, 1, 0, 8, 1.0, one, None) == -1

@@ -31,18 +31,18 @@ def main():
     buf = torch.zeros((B, 8), dtype=torch.int64, device=dev)
     lib.tfr_prof_set_buffer(ctypes.c_void_p(buf.data_ptr()))
     f = lib.tfr_approx_ndcg_f32
-    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] + [ctypes.c_void_p] * 4
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] + [ctypes.c_void_p] * 5
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         rc = f(logits.data_ptr(), labels.data_ptr(), None, inv.data_ptr(), None, B, L, 0.1, 0, loss.data_ptr(),
-               wout.data_ptr(), dl.data_ptr(), st)
+               wout.data_ptr(), dl.data_ptr(), None, st)
     torch.cuda.synchronize()
     assert rc == 0
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
         f(logits.data_ptr(), labels.data_ptr(), None, inv.data_ptr(), None, B, L, 0.1, 0, loss.data_ptr(),
-          wout.data_ptr(), dl.data_ptr(), st)
+          wout.data_ptr(), dl.data_ptr(), None, st)
     e1.record(); torch.cuda.synchronize()
     print('ORDER=%r kernel %.4f ms' % (order, e0.elapsed_time(e1) / 20))
     d = buf.cpu()
@@ -71,5 +71,47 @@ def main():
     print('distinct simd keys:', len(set(key.tolist())))
 
 
+def main_pairwise():
+    if not os.path.exists(_lib.PROF_LIB_PATH):
+        _lib.build_profiling()
+    lib = ctypes.CDLL(_lib.PROF_LIB_PATH)
+    B, L = 4096, 200
+    labels, logits = make_batch(B, L, seed=4)
+    dev = 'cuda'
+    labels, logits = labels.to(dev), logits.to(dev)
+    r = torch.arange(1, L + 2, dtype=torch.float32)
+    import math
+    disc = (math.log(2.) / torch.log1p(r)).to(dev)
+    row_loss = torch.empty((B, L), device=dev); dl = torch.empty((B, L), device=dev)
+    buf = torch.zeros((B, 8), dtype=torch.int64, device=dev)
+    lib.tfr_prof_set_buffer_pw(ctypes.c_void_p(buf.data_ptr()))
+    f = lib.tfr_pairwise_logistic_f32
+    f.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] * 2 + \
+        [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 5
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: f(logits.data_ptr(), labels.data_ptr(), None, None, None, 2, 0, 0.0, 1, 1, None, disc.data_ptr(),
+                     B, L, 1.0, row_loss.data_ptr(), None, None, dl.data_ptr(), st)
+    for _ in range(3):
+        rc = call()
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    print('pairwise (NDCG lambda) kernel %.4f ms' % (e0.elapsed_time(e1) / 20))
+    t = buf.cpu()[:, :5].double()
+    names = ['load+compact', 'ideal DCG', 'rank count + re-home', 'pair sweep']
+    tot = (t[:, 4] - t[:, 0]).mean().item()
+    print('mean ticks per list-wave: total %.0f' % tot)
+    for i, nme in enumerate(names):
+        dt = (t[:, i + 1] - t[:, i]).mean().item()
+        print('  %-22s %8.0f  %5.1f %%' % (nme, dt, 100 * dt / tot))
+
+
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'pairwise':
+        main_pairwise()
+    else:
+        main()
