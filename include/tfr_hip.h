@@ -140,6 +140,13 @@ int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* ma
                      const float* pos_weight, const float* list_scale, int B, int L,
                      float temperature, float* loss_out, float* dlogits_out, void* stream);
 
+/* losses_impl.UniqueSoftmaxLoss._compute_unreduced_loss_impl fused with its backward
+ * (losses_impl.py:1250-1281): loss_b = sum_i (2^l_i - 1) (log(e^s_i + sum_{j: l_j < l_i} e^s_j) - s_i).
+ * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 1024). */
+int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
+                           const float* list_scale, int B, int L, float temperature,
+                           float* loss_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

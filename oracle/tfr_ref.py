@@ -597,6 +597,29 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
+class UniqueSoftmaxLoss(_ListwiseLoss):
+    """losses_impl.py:1250-1281 (the [B, L, L+1] denominator tensor, op for op)."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, math.log(_EPSILON) * torch.ones_like(logits))
+        pairwise_labels, _ = _pairwise_comparison(labels, logits, mask)
+        denominator_logits = logits.unsqueeze(1) * pairwise_labels
+        denominator_logits = torch.cat([denominator_logits, logits.unsqueeze(2)], dim=2)
+        denominator_mask = torch.cat([pairwise_labels, torch.ones_like(logits).unsqueeze(2)], dim=2)
+        denominator_logits = torch.where(denominator_mask > 0.0, denominator_logits,
+                                         -1e-3 + denominator_logits.min() * torch.ones_like(denominator_logits))
+        logits_max = denominator_logits.max(dim=-1, keepdim=True).values
+        denominator_logits = denominator_logits - logits_max
+        logits = logits - logits_max.squeeze(-1)
+        gains = torch.pow(torch.tensor(2.0, dtype=labels.dtype), labels) - 1
+        per_doc_softmax = -logits + torch.log((torch.exp(denominator_logits) * denominator_mask).sum(dim=-1))
+        losses = (per_doc_softmax * gains).sum(dim=1, keepdim=True)
+        return losses, torch.ones_like(losses)
+
+
 class ListMLELambdaWeight:
     """losses_impl.py:457-480."""
 

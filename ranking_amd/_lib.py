@@ -41,6 +41,8 @@ _SIGNATURES = {
                            + [ctypes.c_void_p] * 5),
     'tfr_list_mle_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                          + [ctypes.c_void_p] * 3),
+    'tfr_unique_softmax_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                               + [ctypes.c_void_p] * 3),
     'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                   + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),

@@ -106,6 +106,166 @@ __global__ __launch_bounds__(64) void list_mle_wave_kernel(
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// UniqueSoftmaxLoss (losses_impl.py:1250-1281): every document i competes, in its own softmax,
+// only against the documents with a strictly LOWER label:
+//     loss = sum_i (2^{l_i} - 1) * ( log( e^{s_i} + sum_{j: l_j < l_i} e^{s_j} ) - s_i ),   valid i, j.
+// The reference builds the [B, L, L+1] denominator tensor; sorted by label (descending) the
+// inner sum is a SUFFIX sum starting at the end of i's tie group, and the backward
+//     d loss / d s_k = -g_k + e^{s_k} ( g_k / D_k + sum_{i: l_i > l_k} g_i / D_i )
+// a PREFIX sum ending at the start of k's tie group: O(L) after one register sort.
+template <int IPL>
+__global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ list_scale, int L, float temperature, float* __restrict__ loss_out,
+    float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* XS = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] logits by original index
+  float* LB = XS + 64 * IPL;                               // [64 * IPL] labels by original index
+  float* SUF = LB + 64 * IPL;                              // [64 * IPL + 1] suffix sums by sorted position
+  float* PRE = SUF + 64 * IPL + 1;                         // [64 * IPL + 1] exclusive prefix of g / D
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  constexpr int NP = 64 * IPL;
+
+  uint64_t key[IPL];
+  int nv = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    key[r] = 0;
+    bool v = false;
+    if (i < L) {
+      const float lab = labels[base + i];
+      v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      XS[i] = v ? logits[base + i] / temperature : 0.0f;
+      LB[i] = v ? lab : 0.0f;
+      key[r] = make_sort_key(v, v ? lab : 0.0f, 0, i);
+      if (dlogits_out && !v) dlogits_out[base + i] = 0.0f;
+    }
+    nv += __popcll(__ballot(v));
+  }
+  __syncthreads();
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);       // valid first, label descending, then index
+
+  float xs[IPL], lb[IPL], e[IPL], g[IPL];
+  int idx[IPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    idx[r] = sort_key_index(key[r]);
+    const bool in = p < nv;
+    xs[r] = in ? XS[idx[r]] : -INFINITY;
+    lb[r] = in ? LB[idx[r]] : -INFINITY;
+    g[r] = in ? gain_pow2m1(lb[r]) : 0.0f;
+    mx = fmaxf(mx, xs[r]);
+  }
+  mx = wave_max_u(mx);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) e[r] = (lane + 64 * r < nv) ? expf(xs[r] - mx) : 0.0f;
+  // suffix sums of e in sorted order -> SUF[p] = sum_{q >= p} e_q, SUF[nv..] = 0
+  float carry = 0.f;
+#pragma unroll
+  for (int r = IPL - 1; r >= 0; --r) {
+    float v = e[r];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_down(v, o, 64);
+      if (lane + o < 64) v += u;
+    }
+    SUF[lane + 64 * r] = v + carry;
+    carry += __shfl(v, 0, 64);
+  }
+  if (lane == 0) SUF[NP] = 0.0f;
+  // tie groups: gstart[p] = first position of p's label group, gend[p] = one past its last
+  int gs[IPL], ge[IPL];
+  {
+    // first-of-group flags need the previous position's label
+    float prev_carry = INFINITY;                          // label "before" position 0
+    int run_start = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      float prev = __shfl_up(lb[r], 1, 64);
+      if (lane == 0) prev = prev_carry;
+      prev_carry = __shfl(lb[r], 63, 64);
+      const bool first = (p < nv) && (lb[r] < prev || p == 0);
+      // inclusive max-scan of (first ? p : -1)  -> group start
+      int v = first ? p : -1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v = v > u ? v : u;
+      }
+      v = v > run_start ? v : run_start;
+      gs[r] = v;
+      run_start = __shfl(v, 63, 64);
+    }
+    // group end = next first-of-group position after p (or nv): reverse min-scan over positions > p
+    int next_carry = nv;
+    float next_lab_carry = -INFINITY;                     // label "after" the last position
+#pragma unroll
+    for (int r = IPL - 1; r >= 0; --r) {
+      const int p = lane + 64 * r;
+      float nxt = __shfl_down(lb[r], 1, 64);
+      if (lane == 63) nxt = next_lab_carry;
+      next_lab_carry = __shfl(lb[r], 0, 64);
+      // position p + 1 starts a new group iff label[p + 1] < label[p]  (or p + 1 >= nv)
+      const bool last = (p < nv) && (p + 1 >= nv || nxt < lb[r]);
+      int v = last ? p + 1 : 0x7fffffff;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_down(v, o, 64);
+        if (lane + o < 64) v = v < u ? v : u;
+      }
+      v = v < next_carry ? v : next_carry;
+      ge[r] = v;
+      next_carry = __shfl(v, 0, 64);
+    }
+  }
+  __syncthreads();                                        // SUF visible
+  float D[IPL], term = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    D[r] = 1.0f;
+    if (p < nv) {
+      D[r] = e[r] + SUF[ge[r] < NP ? ge[r] : NP];
+      term += g[r] * (logf(D[r]) - (xs[r] - mx));
+    }
+  }
+  const float loss = wave_sum_u(term);
+  if (lane == 0) loss_out[b] = loss;
+  if (!dlogits_out) return;
+  // exclusive prefix of c = g / D in sorted order -> PRE[p] = sum_{q < p} c_q
+  carry = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    const float c = (p < nv) ? g[r] / D[r] : 0.0f;
+    float v = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_up(v, o, 64);
+      if (lane >= o) v += u;
+    }
+    PRE[p] = v - c + carry;
+    carry += __shfl(v, 63, 64);
+  }
+  __syncthreads();
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) / temperature;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    if (p < nv) {
+      const float higher = PRE[gs[r]];                    // sum over strictly higher labels
+      dlogits_out[base + idx[r]] = (-g[r] + e[r] * (g[r] / D[r] + higher)) * gscale;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
@@ -118,5 +278,18 @@ extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const 
 #define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out)
   if (L <= 64) LM(1); else if (L <= 128) LM(2); else if (L <= 256) LM(4); else if (L <= 512) LM(8); else LM(16);
 #undef LM
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                      const float* list_scale, int B, int L, float temperature,
+                                      float* loss_out, float* dlogits_out, void* stream) {
+  if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
+  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (B == 0) return TFR_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out)
+  if (L <= 64) US(1); else if (L <= 128) US(2); else if (L <= 256) US(4); else if (L <= 512) US(8); else US(16);
+#undef US
   return (int)hipGetLastError();
 }

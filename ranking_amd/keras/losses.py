@@ -76,6 +76,7 @@ def get(loss: str, reduction: str = Reduction.AUTO, lambda_weight=None, name: Op
         RankingLossKey.APPROX_NDCG_LOSS: ApproxNDCGLoss,
         RankingLossKey.APPROX_MRR_LOSS: ApproxMRRLoss,
         RankingLossKey.LIST_MLE_LOSS: ListMLELoss,
+        RankingLossKey.UNIQUE_SOFTMAX_LOSS: UniqueSoftmaxLoss,
         RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: GumbelApproxNDCGLoss,
     }
     key_to_cls_with_lambda = {
@@ -370,6 +371,31 @@ class ApproxNDCGLoss(_ListwiseLoss):
         loss, weight, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
                                                  self._temperature, 0, True)
         return torch.dot(loss * weight, list_scale), dlogits
+
+
+@utils.register_keras_serializable()
+class UniqueSoftmaxLoss(ApproxNDCGLoss):
+    """keras/losses.py:939-1010."""
+
+    def __init__(self, reduction=Reduction.AUTO, name=None, lambda_weight=None, temperature=1.0, ragged=False):
+        _ListwiseLoss.__init__(self, reduction, name, lambda_weight, temperature, ragged)
+        self._loss = losses_impl.UniqueSoftmaxLoss(name='{}_impl'.format(name) if name else None,
+                                                   lambda_weight=lambda_weight, temperature=temperature,
+                                                   ragged=ragged)
+
+    def loss_and_grad(self, y_true, y_pred, sample_weight=None):
+        if self.reduction == Reduction.NONE:
+            raise ValueError('loss_and_grad needs a scalar reduction')
+        y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
+        b = y_pred.shape[0]
+        scale = self._scale(b)
+        sw = self._loss._normalize_weights_impl(y_true, sample_weight)
+        if torch.is_tensor(sw):
+            list_scale = (sw.reshape(b) * scale).contiguous()
+        else:
+            list_scale = torch.full((b,), scale * float(sw), dtype=torch.float32, device=y_pred.device)
+        loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
+        return torch.dot(loss, list_scale), dlogits
 
 
 @utils.register_keras_serializable()

@@ -52,6 +52,7 @@ _SUPPORTED = {
     RankingLossKey.APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, False),
     RankingLossKey.APPROX_MRR_LOSS: (losses_impl.ApproxMRRLoss, False, False),
     RankingLossKey.LIST_MLE_LOSS: (losses_impl.ListMLELoss, True, False),
+    RankingLossKey.UNIQUE_SOFTMAX_LOSS: (losses_impl.UniqueSoftmaxLoss, False, False),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
 }
 

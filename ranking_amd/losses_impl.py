@@ -548,6 +548,17 @@ class ListMLELoss(_ListwiseLoss):
         return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)
 
 
+class UniqueSoftmaxLoss(_ListwiseLoss):
+    """losses_impl.py:1250-1281; fused kernel tfr_unique_softmax_f32."""
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        def runner(lg, want_grad):
+            loss, d = _ops.unique_softmax(lg, labels, mask, None, temperature, want_grad)
+            return loss, d, ()
+        (loss,) = _PerListLossFn.apply(logits, runner)
+        return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)
+
+
 class ApproxMRRLoss(_ListwiseLoss):
     """losses_impl.py:1606-1632; fused kernel tfr_approx_mrr_f32."""
 

@@ -895,3 +895,46 @@ def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_
     a = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=False, **lam)
     b = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=True, **lam)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+# ------------------------------------------------------------------ UniqueSoftmax
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300)])
+def test_unique_softmax_parity(B, L):
+    labels, logits = make_batch(B, L, seed=1300 + L)        # graded labels: plenty of tie groups
+    if B >= 3:
+        labels[1] = -1.0
+        labels[0] = torch.where(labels[0] >= 0, torch.ones_like(labels[0]) * 2, labels[0])   # one single group
+    T_ = 0.8
+    oracle = R.UniqueSoftmaxLoss(temperature=T_)
+    want, want_g = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels, lg / T_)[0], logits)
+    from ranking_amd import _ops
+    loss, d = _ops.unique_softmax(logits.to(DEV), labels.to(DEV), None, None, T_)
+    scale = max(1.0, want.abs().max().item())
+    assert_loss_close(loss / scale, want.reshape(-1) / scale, what='unique_softmax loss')
+    assert_grad_close(d, want_g, 2e-5, what='unique_softmax grad')
+
+
+def test_unique_softmax_reference_goldens_and_keras():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    sm = lambda v: [math.exp(x) / sum(math.exp(y) for y in v) for x in v]
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = t([[0., 0., 1.], [0., 1., 2.], [0., 0., 0.]])
+    red = L.Reduction.SUM_BY_NONZERO_WEIGHTS
+    want = -(math.log(sm(scores[0])[2]) + math.log(sm(scores[1][:2])[1]) + math.log(sm(scores[1])[2]) * 3.) / 3.
+    assert abs(L.UniqueSoftmaxLoss(None).compute(labels, t(scores), None, red).item() - want) < 1e-5   # losses_impl_test.py:1231-1242
+    got = L.UniqueSoftmaxLoss(None).compute(t([[0., 1., 1., 0.]]), t([[1., 2., 3., 2.]]), None, red,
+                                            mask=t([[True, False, True, True]]))
+    assert abs(got.item() + math.log(sm([1, 3, 2])[1])) < 1e-5                                          # :1261-1271
+    losses, w = L.UniqueSoftmaxLoss(None).compute_per_list(t([[0., 0., 1.], [0., 0., 2.]]), t([[1., 3., 2.], [1., 2., 3.]]),
+                                                           t([[2., 3., 4.], [1., 1., 1.]]))
+    assert_loss_close(losses, torch.tensor([1.407606, 1.222818]), 1e-5)                                 # :1250-1259
+    assert w.tolist() == [4., 1.]
+    k = K.get('unique_softmax_loss')
+    assert abs(k(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.7981389) < 1e-6                             # keras/losses.py:961-965
+    lb, lg = make_batch(6, 30, seed=5)
+    v, d = k.loss_and_grad(lb.to(DEV), lg.to(DEV))
+    lgd = lg.to(DEV).requires_grad_(True)
+    out = k(lb.to(DEV), lgd); out.backward()
+    assert abs(v.item() - out.item()) < 1e-5 * max(1.0, abs(out.item())) and torch.allclose(d, lgd.grad, atol=1e-6)

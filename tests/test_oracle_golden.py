@@ -177,6 +177,7 @@ RAGGED_W = [[2., 3., 4.], [1., 1.]]
     (R.ApproxNDCGLoss, [-0.63093, -0.922917], [4., 1.]),
     (R.ApproxMRRLoss, [-0.5, -0.893493], [4., 1.]),
     (R.ListMLELoss, [3.534534, 0.126928], [4., 1.]),
+    (R.UniqueSoftmaxLoss, [1.407606, 0.380784], [4., 1.]),
 ])
 def test_compute_per_list_ragged(ctor, exp_l, exp_w):
     losses, weights = ctor(ragged=True).compute_per_list(RAGGED_LABELS, RAGGED_SCORES, RAGGED_W)
@@ -595,3 +596,30 @@ def test_list_mle_reference_literals():
     got = R.ListMLELoss().compute(torch.tensor([[0., 0., 1.]]), torch.tensor([[0., ln(2), ln(3)]]), None, red,
                                   mask=torch.tensor([[True, False, True]]))
     assert abs(got.item() + (ln(3. / 4) + ln(1. / 1))) < 1e-5
+
+
+# ------------------------------------------------------------------ UniqueSoftmax
+def _softmax_py(v):
+    m = [math.exp(x) for x in v]
+    return [x / sum(m) for x in m]
+
+
+def test_unique_softmax_reference_literals():
+    """losses_impl_test.py:1231-1271, keras/losses.py:961-965."""
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = torch.tensor([[0., 0., 1.], [0., 1., 2.], [0., 0., 0.]])
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    loss = R.UniqueSoftmaxLoss()
+    want = -(math.log(_softmax_py(scores[0])[2]) + math.log(_softmax_py(scores[1][:2])[1])
+             + math.log(_softmax_py(scores[1])[2]) * 3.) / 3.
+    assert abs(loss.compute(labels, torch.tensor(scores), None, red).item() - want) < 1e-5
+    want = -(math.log(_softmax_py(scores[0])[2]) * 2. + math.log(_softmax_py(scores[1][:2])[1]) * 1.
+             + math.log(_softmax_py(scores[1])[2]) * 3. * 1.) / 2.
+    assert abs(loss.compute(labels, torch.tensor(scores), torch.tensor([[2.], [1.], [1.]]), red).item() - want) < 1e-5
+    losses, w = loss.compute_per_list(torch.tensor([[0., 0., 1.], [0., 0., 2.]]), torch.tensor([[1., 3., 2.], [1., 2., 3.]]),
+                                      torch.tensor([[2., 3., 4.], [1., 1., 1.]]))
+    close(losses, [1.407606, 1.222818]); close(w, [4., 1.])
+    got = loss.compute(torch.tensor([[0., 1., 1., 0.]]), torch.tensor([[1., 2., 3., 2.]]), None, red,
+                       mask=torch.tensor([[True, False, True, True]]))
+    assert abs(got.item() + math.log(_softmax_py([1, 3, 2])[1])) < 1e-5
+    assert abs(R.keras_loss_call(loss, torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item() - 0.7981389) < 1e-6
