@@ -46,6 +46,10 @@ extern "C" {
 #define TFR_LAMBDA_NONE 0
 #define TFR_LAMBDA_DCG 2      /* losses_impl.py:299-369 DCGLambdaWeight       */
 #define TFR_LAMBDA_LABELDIFF 1 /* losses_impl.py:210-217                      */
+#define TFR_LAMBDA_DCG_V2 3    /* losses_impl.py:372-394 DCGLambdaWeightV2     */
+#define TFR_LAMBDA_YETI_DCG 4  /* losses_impl.py:397-407 YetiDCGLambdaWeight   */
+#define TFR_LAMBDA_PRECISION 5 /* losses_impl.py:410-454 PrecisionLambdaWeight: `gains` = positive_fn(labels)
+                                  as 0/1 floats (TFR_GAIN_CUSTOM), topn mandatory */
 
 int tfr_hip_abi_version(void);
 

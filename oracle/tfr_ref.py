@@ -344,6 +344,66 @@ class DCGLambdaWeight:
         return gain * rank_discount
 
 
+class DCGLambdaWeightV2(DCGLambdaWeight):
+    """losses_impl.py:372-394 (shares AbstractDCGLambdaWeight.pair_weights with the class above)."""
+
+    def __init__(self, topn=None, gain_fn=identity, rank_discount_fn=inverse, normalized=False):
+        super().__init__(topn, gain_fn, rank_discount_fn, normalized, 0.0)
+
+    def _pair_rank_discount(self, ranks, topn):
+        f32 = torch.float32
+        rank_diff = torch.abs(_apply_pairwise_op(torch.sub, ranks)).to(f32)
+        max_rank = _apply_pairwise_op(torch.maximum, ranks).to(f32)
+        multiplier = torch.where(max_rank > float(topn), 1.0 / (1.0 - self._rank_discount_fn(max_rank)),
+                                 torch.ones_like(max_rank))
+        return torch.where(
+            rank_diff > 0.0,
+            torch.abs(self._rank_discount_fn(torch.clamp(rank_diff, min=1.0))
+                      - self._rank_discount_fn(rank_diff + 1)) * multiplier,
+            torch.zeros_like(rank_diff))
+
+
+class YetiDCGLambdaWeight(DCGLambdaWeightV2):
+    """losses_impl.py:397-407."""
+
+    def pair_weights(self, labels, ranks):
+        pair_weight = super().pair_weights(labels, ranks)
+        ranks = _t(ranks, torch.int32)
+        neighbor_pair = torch.abs(_apply_pairwise_op(torch.sub, ranks)) == 1
+        return pair_weight * neighbor_pair.to(torch.float32)
+
+
+class PrecisionLambdaWeight:
+    """losses_impl.py:410-454."""
+
+    def __init__(self, topn, positive_fn=lambda label: label >= 1.0):
+        self._topn = topn
+        self._positive_fn = positive_fn
+
+    def pair_weights(self, labels, ranks):
+        labels = _t(labels)
+        ranks = _t(ranks, torch.int32)
+        valid_pair, labels = _get_valid_pairs_and_clean_labels(labels)
+        binary_labels = self._positive_fn(labels).to(torch.float32)
+        label_diff = torch.abs(_apply_pairwise_op(torch.sub, binary_labels))
+        label_diff = label_diff * valid_pair.to(torch.float32)
+        rank_mask = _apply_pairwise_op(torch.logical_xor, ranks <= self._topn)
+        return label_diff * rank_mask.to(torch.float32)
+
+    def individual_weights(self, labels, ranks):
+        return labels
+
+
+def NDCGLambdaWeightV2(topn=None, gain_fn=None, rank_discount_fn=None):
+    """keras/losses.py:151-162."""
+    return DCGLambdaWeightV2(topn, gain_fn or pow_minus_1, rank_discount_fn or log2_inverse, normalized=True)
+
+
+def KerasYetiDCGLambdaWeight(topn=None, gain_fn=None, rank_discount_fn=None, normalized=False):
+    """keras/losses.py:172-186."""
+    return YetiDCGLambdaWeight(topn, gain_fn or pow_minus_1, rank_discount_fn or log2_inverse, normalized=normalized)
+
+
 def NDCGLambdaWeight(topn=None, gain_fn=None, rank_discount_fn=None, smooth_fraction=0.0):
     """keras/losses.py:197-212."""
     return DCGLambdaWeight(topn, gain_fn or pow_minus_1, rank_discount_fn or log2_inverse,

@@ -105,6 +105,28 @@ def dcg_pair_rank_discount(lw, ranks, topn):
     return pd * in_top.to(f32)
 
 
+def dcg_v2_pair_rank_discount(lw, ranks, topn):
+    """losses_impl.py:380-394."""
+    f32 = torch.float32
+    fn = lw._rank_discount_fn
+    rank_diff = torch.abs(_pairwise(torch.sub, ranks)).to(f32)
+    max_rank = _pairwise(torch.maximum, ranks).to(f32)
+    mult = torch.where(max_rank > float(topn), 1. / (1. - fn(max_rank)), torch.ones_like(max_rank))
+    return torch.where(rank_diff > 0., torch.abs(fn(torch.clamp(rank_diff, min=1.)) - fn(rank_diff + 1)) * mult,
+                       torch.zeros_like(rank_diff))
+
+
+def precision_pair_weights(lw, labels, ranks):
+    """losses_impl.py:426-454."""
+    is_valid = _is_valid(labels)
+    valid_pair = _pairwise(torch.logical_and, is_valid)
+    labels = torch.where(is_valid, labels, torch.zeros_like(labels))
+    binary = lw._positive_fn(labels).to(torch.float32)
+    diff = torch.abs(_pairwise(torch.sub, binary)) * valid_pair.to(torch.float32)
+    rank_mask = _pairwise(torch.logical_xor, ranks <= lw._topn)
+    return diff * rank_mask.to(torch.float32)
+
+
 def dcg_pair_weights(lw, labels, ranks):
     """losses_impl.py:255-279."""
     is_valid = _is_valid(labels)

@@ -33,7 +33,7 @@ constexpr float kLn2 = 0.69314718055994530942f;
 struct PwArgs {
   const float* logits; const float* labels; const uint8_t* mask;
   const float* item_weights; const float* list_weights;
-  int lambda_kind; int topn; float smooth; int normalized; int gain_kind;
+  int lambda_kind; int lambda_sub; int topn; float smooth; int normalized; int gain_kind;
   const float* gains; const float* discount;
   int L; int Lp; int P; float temperature; int C; int kind;
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
@@ -75,6 +75,34 @@ __device__ __forceinline__ void pair_loss(const int kind, const float d0, const 
   sel = (pos == hi) ? eq : q;                                      // hi: sigma(-d0), lo: sigma(+d0)
 }
 
+// Pair weight of the GENERIC lambda path.  sub 0: DCGLambdaWeight (losses_impl.py:299-369),
+// 1: DCGLambdaWeightV2 (:372-394), 2: YetiDCGLambdaWeight (:397-407), 3: PrecisionLambdaWeight
+// (:410-454).  ai/aj = 1-based ranks, dpi/dpj = D(rank) (sub 0: zeroed beyond topn), u = |D(m) - D(m+1)|
+// at m = |ai - aj|, pg = |gain_i - gain_j| of a label-valid pair (else 0).
+#define TFR_SUB_DCG 0
+#define TFR_SUB_DCG_V2 1
+#define TFR_SUB_YETI 2
+#define TFR_SUB_PRECISION 3
+__device__ __forceinline__ float lambda_generic_weight(const int sub, const float ai, const float aj, const float dpi,
+                                                       const float dpj, const float u, const float pg,
+                                                       const float ftopn, const float one_minus_s, const float smooth,
+                                                       const float fL) {
+  if (sub == TFR_SUB_DCG) {
+    const bool in_top = (ai <= ftopn) || (aj <= ftopn);
+    const float v = fabsf(dpi - dpj);
+    float pd = one_minus_s * u + smooth * v;
+    pd = in_top ? pd : 0.0f;
+    return (pg * pd) * fL;
+  }
+  if (sub == TFR_SUB_PRECISION) return ((ai <= ftopn) != (aj <= ftopn)) ? pg : 0.0f;
+  const float mx = fmaxf(ai, aj);
+  const float dmax = (ai > aj) ? dpi : dpj;
+  const float mult = (mx > ftopn) ? (1.0f / (1.0f - dmax)) : 1.0f;
+  float pd = (ai != aj) ? u * mult : 0.0f;
+  if (sub == TFR_SUB_YETI) pd = (fabsf(ai - aj) == 1.0f) ? pd : 0.0f;
+  return (pg * pd) * fL;
+}
+
 // One (row i, column j) term.  rec = (x, raw label, gain, item weight); rk = signed
 // rank as float (negative: label-invalid item), dp = D'(rank).
 template <int LAMBDA, bool GENERIC>
@@ -82,19 +110,15 @@ __device__ __forceinline__ void pair_term(const float4 ri, const float rki, cons
                                           const float4 rj, const float rkj, const float dpj,
                                           const float* __restrict__ U, const float ftopn,
                                           const float one_minus_s, const float smooth, const float fL, const int kind,
-                                          float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
+                                          const int sub, float& acc_loss, float& acc_w, float& acc_nz, float& acc_g) {
   float wl = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
     const float ai = fabsf(rki), aj = fabsf(rkj);
     const int dr = (int)fabsf(ai - aj);
     const float u = U[dr];                                   // U[0] = 0
     if (GENERIC) {
-      const bool in_top = (ai <= ftopn) || (aj <= ftopn);
-      const float v = fabsf(dpi - dpj);
-      float pd = one_minus_s * u + smooth * v;
-      pd = in_top ? pd : 0.0f;
       const float pg = (rki > 0.0f && rkj > 0.0f) ? fabsf(ri.z - rj.z) : 0.0f;
-      wl = (pg * pd) * fL;
+      wl = lambda_generic_weight(sub, ai, aj, dpi, dpj, u, pg, ftopn, one_minus_s, smooth, fL);
     } else {
       wl = (fabsf(ri.z - rj.z) * u) * fL;
     }
@@ -123,17 +147,13 @@ template <int LAMBDA, bool GENERIC, bool AUX, bool ITEMW>
 __device__ __forceinline__ void pair_term_ranked(const float4 ri, const float2 qi, const float ai, const float4 rj,
                                                  const float2 qj, const float aj, const float u, const float ftopn,
                                                  const float one_minus_s, const float smooth, const float fL,
-                                                 const int kind, float& acc_loss, float& acc_w, float& acc_nz,
+                                                 const int kind, const int sub, float& acc_loss, float& acc_w, float& acc_nz,
                                                  float& acc_g) {
   float wl = 1.0f;
   if (LAMBDA == TFR_LAMBDA_DCG) {
     if (GENERIC) {
-      const bool in_top = (ai <= ftopn) || (aj <= ftopn);
-      const float v = fabsf(qi.x - qj.x);
-      float pd = one_minus_s * u + smooth * v;
-      pd = in_top ? pd : 0.0f;
       const float pg = (qi.y > 0.0f && qj.y > 0.0f) ? fabsf(ri.z - rj.z) : 0.0f;
-      wl = (pg * pd) * fL;
+      wl = lambda_generic_weight(sub, ai, aj, qi.x, qj.x, u, pg, ftopn, one_minus_s, smooth, fL);
     } else {
       wl = fabsf(ri.z - rj.z) * u;
     }
@@ -251,7 +271,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       // label-invalid but mask-valid items carry gain 0 and a "no lambda pair" flag (NaN-free):
       const float g = LV[i] ? Gr[i] * (a.normalized ? inv_max_dcg : 1.0f) : 0.0f;
       rec0[pos] = make_float4(Xr[i], a.labels[base + i], g, Wr[i]);
-      const float dprime = (dcg_lambda && r <= topn) ? a.discount[r - 1] : 0.0f;
+      const float dprime = (dcg_lambda && (r <= topn || a.lambda_sub != TFR_SUB_DCG)) ? a.discount[r - 1] : 0.0f;
       rec1[pos] = make_float2(dprime, LV[i] ? (float)r : -(float)r);
       CI[pos] = i;
     }
@@ -293,9 +313,9 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       const float4 r0 = rec0[j0], r1 = rec0[j1];
       const float2 q0 = rec1[j0], q1 = rec1[j1];
       pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r0, q0.y, q0.x, U, ftopn, one_minus_s, a.smooth, fL, a.kind,
-                                 acc_loss, acc_w, acc_nz, acc_g);
+                                 a.lambda_sub, acc_loss, acc_w, acc_nz, acc_g);
       pair_term<LAMBDA, GENERIC>(ri, qi.y, qi.x, r1, q1.y, q1.x, U, ftopn, one_minus_s, a.smooth, fL, a.kind,
-                                 acc_loss, acc_w, acc_nz, acc_g);
+                                 a.lambda_sub, acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
       acc_loss += __shfl_xor(acc_loss, o, 64);
@@ -530,7 +550,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
     float dprime = 0.f;
     float gz = lv[r] ? g[r] : 0.0f;
     if (LAMBDA == TFR_LAMBDA_DCG) {
-      dprime = (cnt < topn) ? a.discount[cnt] : 0.0f;
+      dprime = (cnt < topn || a.lambda_sub != TFR_SUB_DCG) ? a.discount[cnt] : 0.0f;
       if (a.normalized) gz *= inv_max_dcg;
     }
     recS[cnt] = make_float4(xi, labr[r], gz, wr[r]);
@@ -569,9 +589,9 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       float2 q0 = make_float2(0.f, 1.f), q1 = q0;
       if (GENERIC) { q0 = auxS[j0]; q1 = auxS[j1]; }
       pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r0, q0, (float)(j0 + 1), u0, ftopn,
-                                                    one_minus_s, a.smooth, fL, kind, acc_loss, acc_w, acc_nz, acc_g);
+                                                    one_minus_s, a.smooth, fL, kind, a.lambda_sub, acc_loss, acc_w, acc_nz, acc_g);
       pair_term_ranked<LAMBDA, GENERIC, AUX, ITEMW>(ri, qi, (float)(row + 1), r1, q1, (float)(j1 + 1), u1, ftopn,
-                                                    one_minus_s, a.smooth, fL, kind, acc_loss, acc_w, acc_nz, acc_g);
+                                                    one_minus_s, a.smooth, fL, kind, a.lambda_sub, acc_loss, acc_w, acc_nz, acc_g);
     }
     for (int o = 1; o < C; o <<= 1) {
       acc_loss += __shfl_xor(acc_loss, o, 64);
@@ -623,7 +643,8 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   const size_t lds = (size_t)S * pw_wave_lds(a.Lp) + 16;
   if (lds > 64 * 1024) return -3;          // (caller falls back to the workgroup kernel)
   const bool generic = (a.lambda_kind == TFR_LAMBDA_DCG) &&
-                       (a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) || a.mask != nullptr);
+                       (a.lambda_sub != TFR_SUB_DCG || a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) ||
+                        a.mask != nullptr);
   const bool aux = a.row_weight != nullptr || a.nnz != nullptr;
   const bool itemw = generic || a.item_weights != nullptr || a.mask != nullptr;
 #define PW_L2(LAM, GEN, AUX, IW) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, AUX, IW, TFR_PAIR_LOGISTIC>), dim3(B), dim3(64 * S), lds, stream, a)
@@ -656,8 +677,15 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          float* dlogits_out, const int* order, void* stream) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_SOFT_ZERO_ONE) return TFR_EINVAL;
-  if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG &&
-      lambda_kind != TFR_LAMBDA_LABELDIFF) return TFR_EINVAL;
+  if (lambda_kind < TFR_LAMBDA_NONE || lambda_kind > TFR_LAMBDA_PRECISION) return TFR_EINVAL;
+  // DCGLambdaWeightV2 / YetiDCGLambdaWeight / PrecisionLambdaWeight run as sub-kinds of the generic DCG path
+  int lambda_sub = TFR_SUB_DCG;
+  if (lambda_kind == TFR_LAMBDA_DCG_V2) { lambda_sub = TFR_SUB_DCG_V2; lambda_kind = TFR_LAMBDA_DCG; smooth_fraction = 0.0f; }
+  else if (lambda_kind == TFR_LAMBDA_YETI_DCG) { lambda_sub = TFR_SUB_YETI; lambda_kind = TFR_LAMBDA_DCG; smooth_fraction = 0.0f; }
+  else if (lambda_kind == TFR_LAMBDA_PRECISION) {
+    if (topn <= 0) return TFR_EINVAL;                   // PrecisionLambdaWeight(topn) is mandatory (:413)
+    lambda_sub = TFR_SUB_PRECISION; lambda_kind = TFR_LAMBDA_DCG; smooth_fraction = 0.0f; normalized = 0;
+  }
   if (lambda_kind == TFR_LAMBDA_DCG) {
     if (!discount) return TFR_EINVAL;
     if (gain_kind == TFR_GAIN_CUSTOM && !gains) return TFR_EINVAL;
@@ -673,7 +701,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   if (env_wave && env_threads == 0 && L <= 256) {      // longer lists: workgroup-per-list kernel below
     PwArgs w;
     w.logits = logits; w.labels = labels; w.mask = mask; w.item_weights = item_weights;
-    w.list_weights = list_weights; w.lambda_kind = lambda_kind; w.topn = topn;
+    w.list_weights = list_weights; w.lambda_kind = lambda_kind; w.lambda_sub = lambda_sub; w.topn = topn;
     w.smooth = smooth_fraction; w.normalized = normalized; w.gain_kind = gain_kind; w.gains = gains;
     const int c2 = (2 * C > 4) ? 2 * C : 4;
     w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
@@ -688,7 +716,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   if (T % 64 || T > 1024) return TFR_EINVAL;
   PwArgs a;
   a.logits = logits; a.labels = labels; a.mask = mask; a.item_weights = item_weights;
-  a.list_weights = list_weights; a.lambda_kind = lambda_kind; a.topn = topn;
+  a.list_weights = list_weights; a.lambda_kind = lambda_kind; a.lambda_sub = lambda_sub; a.topn = topn;
   a.smooth = smooth_fraction; a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains;
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
   a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
@@ -696,7 +724,8 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
   const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
-                       (smooth_fraction != 0.0f || (topn > 0 && topn < L) || mask != nullptr);
+                       (lambda_sub != TFR_SUB_DCG || smooth_fraction != 0.0f || (topn > 0 && topn < L) ||
+                        mask != nullptr);
 #define PW_BLOCK(LAM, GEN)                                                                        \
   do {                                                                                            \
     if (lds > 64 * 1024) {                                                                        \

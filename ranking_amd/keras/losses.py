@@ -129,6 +129,41 @@ class NDCGLambdaWeight(DCGLambdaWeight):
                          normalized=True, smooth_fraction=smooth_fraction)
 
 
+@utils.register_keras_serializable()
+class NDCGLambdaWeightV2(losses_impl.DCGLambdaWeightV2):
+    """keras/losses.py:151-169."""
+
+    def __init__(self, topn=None, gain_fn=None, rank_discount_fn=None, **kwargs):
+        super().__init__(topn, gain_fn or utils.pow_minus_1, rank_discount_fn or utils.log2_inverse, normalized=True)
+
+    def get_config(self) -> Dict[str, Any]:
+        return {'topn': self._topn, 'gain_fn': self._gain_fn, 'rank_discount_fn': self._rank_discount_fn}
+
+
+@utils.register_keras_serializable()
+class YetiDCGLambdaWeight(losses_impl.YetiDCGLambdaWeight):
+    """keras/losses.py:172-195."""
+
+    def __init__(self, topn=None, gain_fn=None, rank_discount_fn=None, normalized=False, **kwargs):
+        super().__init__(topn, gain_fn or utils.pow_minus_1, rank_discount_fn or utils.log2_inverse,
+                         normalized=normalized)
+
+    def get_config(self) -> Dict[str, Any]:
+        return {'topn': self._topn, 'gain_fn': self._gain_fn, 'rank_discount_fn': self._rank_discount_fn,
+                'normalized': self._normalized}
+
+
+@utils.register_keras_serializable()
+class PrecisionLambdaWeight(losses_impl.PrecisionLambdaWeight):
+    """keras/losses.py:215-231."""
+
+    def __init__(self, topn=None, positive_fn=None, **kwargs):
+        super().__init__(topn, positive_fn or utils.is_greater_equal_1)
+
+    def get_config(self) -> Dict[str, Any]:
+        return {'topn': self._topn, 'positive_fn': self._positive_fn}
+
+
 # ------------------------------------------------------------------- helpers
 def _keras_reduce(weighted, reduction):
     """tf.keras losses_utils.reduce_weighted_loss."""

@@ -198,10 +198,62 @@ class DCGLambdaWeight(AbstractDCGLambdaWeight):
                     discount=_ops.rank_table(self._rank_discount_fn, list_size + 1, device))
 
 
+class DCGLambdaWeightV2(AbstractDCGLambdaWeight):
+    """losses_impl.py:372-394; fused as TFR_LAMBDA_DCG_V2."""
+    _lambda_kind = _ops.LAMBDA_DCG_V2
+
+    def _pair_rank_discount(self, ranks, topn):
+        return _mat.dcg_v2_pair_rank_discount(self, ranks, topn)
+
+    def _kernel_args(self, labels, list_size, device):
+        kind, gains = _gain_args(
+            self._gain_fn,
+            lambda: torch.where(labels >= 0, labels, torch.zeros_like(labels)))
+        return dict(lambda_kind=self._lambda_kind, topn=self._topn or 0, smooth_fraction=0.0,
+                    normalized=self._normalized, gain_kind=kind, gains=gains,
+                    discount=_ops.rank_table(self._rank_discount_fn, list_size + 1, device))
+
+
+class YetiDCGLambdaWeight(DCGLambdaWeightV2):
+    """losses_impl.py:397-407; fused as TFR_LAMBDA_YETI_DCG."""
+    _lambda_kind = _ops.LAMBDA_YETI_DCG
+
+    def pair_weights(self, labels, ranks):
+        pw = super().pair_weights(labels, ranks)
+        ranks = torch.as_tensor(ranks, device=pw.device)
+        return pw * (torch.abs(ranks.unsqueeze(2) - ranks.unsqueeze(1)) == 1).to(pw.dtype)
+
+
+def _is_greater_equal_1(label):
+    return label >= 1.0
+
+
+class PrecisionLambdaWeight(_LambdaWeight):
+    """losses_impl.py:410-454; fused as TFR_LAMBDA_PRECISION (positive_fn evaluated on the host side
+    into a 0/1 gain array)."""
+
+    def __init__(self, topn, positive_fn=_is_greater_equal_1):
+        self._topn = topn
+        self._positive_fn = positive_fn
+
+    def pair_weights(self, labels, ranks):
+        _check_tensor_shapes([labels, ranks])
+        return _mat.precision_pair_weights(self, labels, ranks)
+
+    def _kernel_args(self, labels, list_size, device):
+        if not self._topn:
+            raise ValueError('PrecisionLambdaWeight needs topn')
+        clean = torch.where(labels >= 0, labels, torch.zeros_like(labels))
+        gains = self._positive_fn(clean).to(torch.float32).contiguous()
+        return dict(lambda_kind=_ops.LAMBDA_PRECISION, topn=self._topn, smooth_fraction=0.0, normalized=False,
+                    gain_kind=_ops.GAIN_CUSTOM, gains=gains,
+                    discount=torch.ones(list_size + 1, dtype=torch.float32, device=device))
+
+
 def _lambda_kernel_args(lambda_weight, labels, list_size, device):
     if lambda_weight is None:
         return dict(lambda_kind=_ops.LAMBDA_NONE)
-    if isinstance(lambda_weight, DCGLambdaWeight):
+    if isinstance(lambda_weight, (DCGLambdaWeight, DCGLambdaWeightV2, PrecisionLambdaWeight)):
         return lambda_weight._kernel_args(labels, list_size, device)
     if isinstance(lambda_weight, LabelDiffLambdaWeight):
         return dict(lambda_kind=_ops.LAMBDA_LABELDIFF)
@@ -577,9 +629,9 @@ class SoftmaxLoss(_ListwiseLoss):
     """losses_impl.py:1119-1197; fused kernel tfr_softmax_loss_f32."""
 
     def _run(self, labels, logits, weights, mask, temperature):
-        lam = _lambda_kernel_args(self._lambda_weight, labels, logits.shape[1], logits.device)
-        if lam is None or lam['lambda_kind'] == _ops.LAMBDA_LABELDIFF:
-            lam = dict(lambda_kind=_ops.LAMBDA_NONE)     # only DCGLambdaWeight applies (:1132)
+        lam = (self._lambda_weight._kernel_args(labels, logits.shape[1], logits.device)
+               if isinstance(self._lambda_weight, DCGLambdaWeight)
+               else dict(lambda_kind=_ops.LAMBDA_NONE))  # only DCGLambdaWeight applies (:1132)
         lam.pop('smooth_fraction', None)
         if lam.get('gain_kind') == _ops.GAIN_CUSTOM:
             m = mask if mask is not None else labels >= 0

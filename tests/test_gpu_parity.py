@@ -272,11 +272,19 @@ def _lambda_pairs():
         (lambda: L.DCGLambdaWeight(gain_fn=lambda l: l * 0.5 + 1.0, normalized=True),
          lambda: R.DCGLambdaWeight(gain_fn=lambda l: l * 0.5 + 1.0, normalized=True)),
         (lambda: L.LabelDiffLambdaWeight(), lambda: R.LabelDiffLambdaWeight()),
+        (lambda: K.NDCGLambdaWeightV2(), lambda: R.NDCGLambdaWeightV2()),
+        (lambda: K.NDCGLambdaWeightV2(topn=4), lambda: R.NDCGLambdaWeightV2(topn=4)),
+        (lambda: L.DCGLambdaWeightV2(topn=2), lambda: R.DCGLambdaWeightV2(topn=2)),
+        (lambda: K.YetiDCGLambdaWeight(), lambda: R.KerasYetiDCGLambdaWeight()),
+        (lambda: K.YetiDCGLambdaWeight(topn=3, normalized=True), lambda: R.KerasYetiDCGLambdaWeight(topn=3, normalized=True)),
+        (lambda: K.PrecisionLambdaWeight(topn=3), lambda: R.PrecisionLambdaWeight(topn=3)),
+        (lambda: L.PrecisionLambdaWeight(topn=1, positive_fn=lambda l: l >= 2.0),
+         lambda: R.PrecisionLambdaWeight(topn=1, positive_fn=lambda l: l >= 2.0)),
     ]
 
 
 @pytest.mark.parametrize('B,L', [(3, 2), (4, 7), (5, 50), (6, 65), (4, 200), (2, 600)])
-@pytest.mark.parametrize('lam_idx', range(8))
+@pytest.mark.parametrize('lam_idx', range(15))
 @pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
 def test_pairwise_logistic_parity(B, L, lam_idx, wkind):
     labels, logits = make_batch(B, L, seed=300 + L)
@@ -938,3 +946,26 @@ def test_unique_softmax_reference_goldens_and_keras():
     lgd = lg.to(DEV).requires_grad_(True)
     out = k(lb.to(DEV), lgd); out.backward()
     assert abs(v.item() - out.item()) < 1e-5 * max(1.0, abs(out.item())) and torch.allclose(d, lgd.grad, atol=1e-6)
+
+
+def test_lambda_weight_v2_yeti_precision_reference_literals():
+    """losses_impl_test.py:436-511 through the materialised pair_weights API; and the materialised
+    matrices agree with the oracle's on a random batch."""
+    L = ra().losses_impl
+    t = lambda x: torch.tensor(x, device=DEV)
+    labels, ranks = t([[2.0, 1.0, 0.0]]), t([[1, 2, 3]]).int()
+    close = lambda a, b: assert_loss_close(a.reshape(-1), torch.tensor(b).reshape(-1), 1e-6)
+    close(L.DCGLambdaWeightV2().pair_weights(labels, ranks) / 3.,
+          [[[0., 1. / 2., 2. / 6.], [1. / 2., 0., 1. / 2.], [2. / 6., 1. / 2., 0.]]])
+    close(L.DCGLambdaWeightV2(topn=1).pair_weights(labels, ranks) / 3.,
+          [[[0., 1., 1. / 2.], [1., 0., 3. / 4.], [1. / 2., 3. / 4., 0.]]])
+    close(L.YetiDCGLambdaWeight(topn=1).pair_weights(labels, ranks) / 3.,
+          [[[0., 1., 0.], [1., 0., 3. / 4.], [0., 3. / 4., 0.]]])
+    close(L.PrecisionLambdaWeight(topn=5).pair_weights(labels, ranks), [[[0.] * 3] * 3])
+    close(L.PrecisionLambdaWeight(topn=1).pair_weights(labels, ranks), [[[0., 0., 1.], [0., 0., 0.], [1., 0., 0.]]])
+    lb, lg = make_batch(4, 23, seed=77)
+    rk = R._compute_ranks(lg, lb >= 0)
+    for mine, theirs in _lambda_pairs()[8:]:
+        got = mine().pair_weights(lb.to(DEV), rk.to(DEV))
+        want = theirs().pair_weights(lb, rk)
+        assert_loss_close(got.reshape(-1) / 23., want.reshape(-1) / 23., 1e-6)

@@ -623,3 +623,25 @@ def test_unique_softmax_reference_literals():
                        mask=torch.tensor([[True, False, True, True]]))
     assert abs(got.item() + math.log(_softmax_py([1, 3, 2])[1])) < 1e-5
     assert abs(R.keras_loss_call(loss, torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item() - 0.7981389) < 1e-6
+
+
+class TestLambdaWeightV2YetiPrecision:  # losses_impl_test.py:436-511
+    labels = [[2.0, 1.0, 0.0]]
+    ranks = torch.tensor([[1, 2, 3]])
+
+    def test_v2(self):
+        close(R.DCGLambdaWeightV2().pair_weights(self.labels, self.ranks) / 3.,
+              [[[0., 1. / 2., 2. / 6.], [1. / 2., 0., 1. / 2.], [2. / 6., 1. / 2., 0.]]])
+        close(R.DCGLambdaWeightV2(topn=1).pair_weights(self.labels, self.ranks) / 3.,
+              [[[0., 1., 1. / 2.], [1., 0., 3. / 4.], [1. / 2., 3. / 4., 0.]]])
+
+    def test_yeti(self):
+        close(R.YetiDCGLambdaWeight().pair_weights(self.labels, self.ranks) / 3.,
+              [[[0., 1. / 2., 0.], [1. / 2., 0., 1. / 2.], [0., 1. / 2., 0.]]])
+        close(R.YetiDCGLambdaWeight(topn=1).pair_weights(self.labels, self.ranks) / 3.,
+              [[[0., 1., 0.], [1., 0., 3. / 4.], [0., 3. / 4., 0.]]])
+
+    def test_precision(self):
+        close(R.PrecisionLambdaWeight(topn=5).pair_weights(self.labels, self.ranks), [[[0.] * 3] * 3])
+        close(R.PrecisionLambdaWeight(topn=1).pair_weights(self.labels, self.ranks),
+              [[[0., 0., 1.], [0., 0., 0.], [1., 0., 0.]]])
