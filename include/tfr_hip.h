@@ -41,6 +41,7 @@ extern "C" {
 #define TFR_PAIR_LOGISTIC 0
 #define TFR_PAIR_HINGE 1
 #define TFR_PAIR_SOFT_ZERO_ONE 2
+#define TFR_PAIR_MSE 3           /* losses_impl.py:961-998: ((s_i - s_j) - (y_i - y_j))^2 over all i != j */
 
 /* lambda_kind */
 #define TFR_LAMBDA_NONE 0
@@ -172,7 +173,9 @@ int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const ui
 
 /* The same machinery for the other pairwise losses of losses_impl.py:936-958.
  *   loss_kind  TFR_PAIR_LOGISTIC (PairwiseLogisticLoss), TFR_PAIR_HINGE (PairwiseHingeLoss :943-948,
- *              relu(1 - d)), TFR_PAIR_SOFT_ZERO_ONE (PairwiseSoftZeroOneLoss :951-958, sigma(-d)). */
+ *              relu(1 - d)), TFR_PAIR_SOFT_ZERO_ONE (PairwiseSoftZeroOneLoss :951-958, sigma(-d)),
+ *              TFR_PAIR_MSE (PairwiseMSELoss :961-998: all ordered pairs of distinct valid items).
+ *   lambda_kind additionally accepts TFR_LAMBDA_DCG_V2 / TFR_LAMBDA_YETI_DCG / TFR_LAMBDA_PRECISION. */
 int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                           const float* item_weights, const float* list_weights,
                           int lambda_kind, int topn, float smooth_fraction, int normalized,

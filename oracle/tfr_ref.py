@@ -564,6 +564,25 @@ class PairwiseSoftZeroOneLoss(_PairwiseLoss):
                            torch.sigmoid(-pairwise_logits))
 
 
+class PairwiseMSELoss(_PairwiseLoss):
+    """losses_impl.py:961-998."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        pairwise_label_diff = _apply_pairwise_op(torch.sub, labels)
+        pairwise_logit_diff = _apply_pairwise_op(torch.sub, logits)
+        pairwise_mse_loss = torch.square(pairwise_logit_diff - pairwise_label_diff)
+        valid_pair = _apply_pairwise_op(torch.logical_and, mask)
+        pairwise_weights = torch.ones_like(pairwise_mse_loss)
+        pairwise_weights = pairwise_weights - torch.eye(labels.shape[1], dtype=pairwise_weights.dtype).unsqueeze(0)
+        pairwise_weights = pairwise_weights * valid_pair.to(torch.float32)
+        if self._lambda_weight is not None:
+            ranks = _compute_ranks(logits, mask)
+            pairwise_weights = pairwise_weights * self._lambda_weight.pair_weights(labels, ranks)
+        return pairwise_mse_loss, pairwise_weights.detach()
+
+
 class _ListwiseLoss(_RankingLoss):
     """losses_impl.py:1001-1033."""
 

@@ -165,6 +165,19 @@ def pairwise_unreduced(loss, labels, logits, mask=None):
     return loss._pairwise_loss(pairwise_logits), w.detach()
 
 
+def pairwise_mse_unreduced(loss, labels, logits, mask=None):
+    """losses_impl.py:972-998."""
+    if mask is None:
+        mask = _is_valid(labels)
+    mse = torch.square(_pairwise(torch.sub, logits) - _pairwise(torch.sub, labels))
+    l = labels.shape[1]
+    w = (1.0 - torch.eye(l, dtype=torch.float32, device=labels.device)).unsqueeze(0)
+    w = w * _pairwise(torch.logical_and, mask).to(torch.float32)
+    if loss._lambda_weight is not None:
+        w = w * loss._lambda_weight.pair_weights(labels, compute_ranks(logits, mask))
+    return mse, w.detach()
+
+
 def softmax_precompute(loss, labels, logits, weights, mask=None):
     """losses_impl.py:1122-1137."""
     from . import losses_impl

@@ -16,7 +16,7 @@ from . import _lib
 GAIN_IDENTITY, GAIN_POW2M1, GAIN_CUSTOM = 0, 1, 2
 LAMBDA_NONE, LAMBDA_LABELDIFF, LAMBDA_DCG = 0, 1, 2
 LAMBDA_DCG_V2, LAMBDA_YETI_DCG, LAMBDA_PRECISION = 3, 4, 5
-PAIR_LOGISTIC, PAIR_HINGE, PAIR_SOFT_ZERO_ONE = 0, 1, 2
+PAIR_LOGISTIC, PAIR_HINGE, PAIR_SOFT_ZERO_ONE, PAIR_MSE = 0, 1, 2, 3
 MAX_TOPN = 8
 
 

@@ -125,9 +125,19 @@ __device__ __forceinline__ void pair_term(const float4 ri, const float rki, cons
   } else if (LAMBDA == TFR_LAMBDA_LABELDIFF) {
     wl = fabsf(ri.y - rj.y);
   }
+  const float d0 = ri.x - rj.x;
+  if (kind == TFR_PAIR_MSE) {             // :961-998: every ordered pair of two distinct mask-valid items
+    const bool pv = (ri.y == ri.y) && (rj.y == rj.y) && (fabsf(rki) != fabsf(rkj));
+    const float e = pv ? d0 - (ri.y - rj.y) : 0.0f;      // padding records carry NaN labels
+    const float wa = pv ? wl * ri.w : 0.0f, wb = pv ? wl * rj.w : 0.0f;
+    acc_loss = __builtin_fmaf(wa, e * e, acc_loss);
+    acc_w += wa;
+    acc_nz += (wa != 0.0f) ? 1.0f : 0.0f;
+    acc_g = __builtin_fmaf(wa + wb, 2.0f * e, acc_g);
+    return;
+  }
   const bool hi = ri.y > rj.y;            // row item preferred
   const bool lo = rj.y > ri.y;            // column item preferred
-  const float d0 = ri.x - rj.x;
   float loss, sel;
   pair_loss(kind, d0, hi, loss, sel);
   const float ww_hi = hi ? wl * ri.w : 0.0f;
@@ -160,9 +170,19 @@ __device__ __forceinline__ void pair_term_ranked(const float4 ri, const float2 q
   } else if (LAMBDA == TFR_LAMBDA_LABELDIFF) {
     wl = fabsf(ri.y - rj.y);
   }
+  const float d0 = ri.x - rj.x;
+  if (kind == TFR_PAIR_MSE) {             // :961-998 (only reached in the AUX && ITEMW variants)
+    const bool pv = (ri.y == ri.y) && (rj.y == rj.y) && (ai != aj);
+    const float e = pv ? d0 - (ri.y - rj.y) : 0.0f;      // padding records carry NaN labels
+    const float wa = pv ? wl * ri.w : 0.0f, wb = pv ? wl * rj.w : 0.0f;
+    acc_loss = __builtin_fmaf(wa, e * e, acc_loss);
+    acc_w += wa;
+    acc_nz += (wa != 0.0f) ? 1.0f : 0.0f;
+    acc_g = __builtin_fmaf(wa + wb, 2.0f * e, acc_g);
+    return;
+  }
   const bool hi = ri.y > rj.y;            // row item preferred
   const bool lo = rj.y > ri.y;            // column item preferred
-  const float d0 = ri.x - rj.x;
   float loss, sel;
   pair_loss(kind, d0, hi, loss, sel);
   float ww_hi, ww_lo;
@@ -676,7 +696,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
                                          float* dlogits_out, const int* order, void* stream) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_SOFT_ZERO_ONE) return TFR_EINVAL;
+  if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_MSE) return TFR_EINVAL;
   if (lambda_kind < TFR_LAMBDA_NONE || lambda_kind > TFR_LAMBDA_PRECISION) return TFR_EINVAL;
   // DCGLambdaWeightV2 / YetiDCGLambdaWeight / PrecisionLambdaWeight run as sub-kinds of the generic DCG path
   int lambda_sub = TFR_SUB_DCG;

@@ -75,15 +75,17 @@ def get(loss: str, reduction: str = Reduction.AUTO, lambda_weight=None, name: Op
         RankingLossKey.SIGMOID_CROSS_ENTROPY_LOSS: SigmoidCrossEntropyLoss,
         RankingLossKey.APPROX_NDCG_LOSS: ApproxNDCGLoss,
         RankingLossKey.APPROX_MRR_LOSS: ApproxMRRLoss,
-        RankingLossKey.LIST_MLE_LOSS: ListMLELoss,
-        RankingLossKey.UNIQUE_SOFTMAX_LOSS: UniqueSoftmaxLoss,
         RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: GumbelApproxNDCGLoss,
     }
     key_to_cls_with_lambda = {
         RankingLossKey.PAIRWISE_HINGE_LOSS: PairwiseHingeLoss,
         RankingLossKey.PAIRWISE_LOGISTIC_LOSS: PairwiseLogisticLoss,
         RankingLossKey.PAIRWISE_SOFT_ZERO_ONE_LOSS: PairwiseSoftZeroOneLoss,
+        RankingLossKey.PAIRWISE_MSE_LOSS: PairwiseMSELoss,
+        RankingLossKey.YETI_LOGISTIC_LOSS: YetiLogisticLoss,
         RankingLossKey.SOFTMAX_LOSS: SoftmaxLoss,
+        RankingLossKey.LIST_MLE_LOSS: ListMLELoss,
+        RankingLossKey.UNIQUE_SOFTMAX_LOSS: UniqueSoftmaxLoss,
     }
     if loss in key_to_cls:
         return key_to_cls[loss](**loss_kwargs)
@@ -328,6 +330,42 @@ class PairwiseHingeLoss(_PairwiseLoss):
 class PairwiseSoftZeroOneLoss(_PairwiseLoss):
     """keras/losses.py:472-536 (materialised path; SURVEY 8f "next")."""
     _impl_cls = losses_impl.PairwiseSoftZeroOneLoss
+
+
+@utils.register_keras_serializable()
+class PairwiseMSELoss(_PairwiseLoss):
+    """keras/losses.py:540-606."""
+    _impl_cls = losses_impl.PairwiseMSELoss
+
+
+@utils.register_keras_serializable()
+class YetiLogisticLoss(_PairwiseLoss):
+    """keras/losses.py:608-718: Gumbel-perturbed scores (sample_size copies of every list) into
+    PairwiseLogisticLoss weighted by YetiDCGLambdaWeight (neighbour pairs only)."""
+    _impl_cls = losses_impl.PairwiseLogisticLoss
+
+    def __init__(self, reduction=Reduction.AUTO, name=None, lambda_weight=None, temperature=1.0,
+                 sample_size=8, gumbel_temperature=1.0, seed=None, ragged=False):
+        lambda_weight = lambda_weight or YetiDCGLambdaWeight()
+        super().__init__(reduction, name, lambda_weight, temperature, ragged)
+        self._sample_size = sample_size
+        self._gumbel_temperature = gumbel_temperature
+        self._seed = seed
+        self._gumbel_sampler = losses_impl.GumbelSampler(name=name, sample_size=sample_size,
+                                                         temperature=gumbel_temperature, seed=seed, ragged=ragged)
+
+    def get_config(self) -> Dict[str, Any]:
+        config = super().get_config()
+        config.update({'sample_size': self._sample_size, 'gumbel_temperature': self._gumbel_temperature,
+                       'seed': self._seed})
+        return config
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        gbl_labels, gbl_logits, gbl_weights = self._gumbel_sampler.sample(y_true, y_pred, weights=sample_weight)
+        return super().__call__(gbl_labels, gbl_logits, gbl_weights)
+
+    def loss_and_grad(self, y_true, y_pred, sample_weight=None):
+        raise NotImplementedError('YetiLogisticLoss: use __call__ (the Gumbel sampler needs autograd)')
 
 
 # ------------------------------------------------------------------ listwise

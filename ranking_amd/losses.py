@@ -52,7 +52,9 @@ _SUPPORTED = {
     RankingLossKey.APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, False),
     RankingLossKey.APPROX_MRR_LOSS: (losses_impl.ApproxMRRLoss, False, False),
     RankingLossKey.LIST_MLE_LOSS: (losses_impl.ListMLELoss, True, False),
-    RankingLossKey.UNIQUE_SOFTMAX_LOSS: (losses_impl.UniqueSoftmaxLoss, False, False),
+    RankingLossKey.UNIQUE_SOFTMAX_LOSS: (losses_impl.UniqueSoftmaxLoss, True, False),
+    RankingLossKey.PAIRWISE_MSE_LOSS: (losses_impl.PairwiseMSELoss, True, False),
+    RankingLossKey.YETI_LOGISTIC_LOSS: (losses_impl.PairwiseLogisticLoss, False, True),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
 }
 

@@ -521,6 +521,18 @@ class PairwiseSoftZeroOneLoss(_PairwiseLoss):
 
 
 # ------------------------------------------------------------------ listwise
+class PairwiseMSELoss(_PairwiseLoss):
+    """losses_impl.py:961-998; fused kernel tfr_pairwise_loss_f32(TFR_PAIR_MSE): every ordered pair of two
+    distinct valid items, ((s_i - s_j) - (y_i - y_j))^2."""
+    _fused_kind = _ops.PAIR_MSE
+
+    def _pairwise_loss(self, pairwise_logits):
+        return None
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        return _mat.pairwise_mse_unreduced(self, labels, logits, mask)
+
+
 class _ListwiseLoss(_RankingLoss):
     """losses_impl.py:1001-1033."""
 

@@ -721,15 +721,15 @@ def test_approx_mrr_reference_goldens_and_keras():
 
 # ------------------------------------------------------------------ hinge / soft zero-one
 @pytest.mark.parametrize('B,L', [(3, 2), (4, 7), (5, 50), (4, 200), (2, 300)])
-@pytest.mark.parametrize('kind', ['hinge', 'soft_zero_one'])
-@pytest.mark.parametrize('lam_idx', [0, 1, 3])
+@pytest.mark.parametrize('kind', ['hinge', 'soft_zero_one', 'mse'])
+@pytest.mark.parametrize('lam_idx', [0, 1, 3, 7, 9, 14])
 @pytest.mark.parametrize('wkind', ['none', 'item'])
 def test_pairwise_other_losses_parity(B, L, kind, lam_idx, wkind):
     labels, logits = make_batch(B, L, seed=800 + L)
     mine_lam, their_lam = _lambda_pairs()[lam_idx]
     weights = make_weights(B, L, seed=L) if wkind == 'item' else None
-    octor = R.PairwiseHingeLoss if kind == 'hinge' else R.PairwiseSoftZeroOneLoss
-    mctor = ra().losses_impl.PairwiseHingeLoss if kind == 'hinge' else ra().losses_impl.PairwiseSoftZeroOneLoss
+    octor = {'hinge': R.PairwiseHingeLoss, 'soft_zero_one': R.PairwiseSoftZeroOneLoss, 'mse': R.PairwiseMSELoss}[kind]
+    mctor = getattr(ra().losses_impl, octor.__name__)
     T = 0.7
     oracle = octor(lambda_weight=their_lam(), temperature=T)
 
@@ -969,3 +969,35 @@ def test_lambda_weight_v2_yeti_precision_reference_literals():
         got = mine().pair_weights(lb.to(DEV), rk.to(DEV))
         want = theirs().pair_weights(lb, rk)
         assert_loss_close(got.reshape(-1) / 23., want.reshape(-1) / 23., 1e-6)
+
+
+def test_pairwise_mse_and_yeti_reference_goldens():
+    L = ra().losses_impl
+    K = ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    scores = t([[1., 3., 2.], [1., 2., 3.]]); labels = t([[0., 0., 1.], [0., 0., 2.]])
+    sq = lambda a, b: (a - b) ** 2
+    red = L.Reduction.MEAN
+    want = 2 * (sq(-1., 1.) + sq(1., 1.) + sq(2., 0.) + sq(1., 2.) + sq(2., 2.) + sq(1., 0.)) / 12.
+    assert abs(L.PairwiseMSELoss(None).compute(labels, scores, None, red).item() - want) < 1e-5        # losses_impl_test.py:908-920
+    want = ((3. * sq(-1., 1.) + 3. * sq(1., 1.) + 2. * sq(2., 0.)) + 2. * (sq(1., 2.) + sq(2., 2.) + sq(1., 0.))) / 14.
+    got = L.PairwiseMSELoss(None).compute(labels, scores, t([[1., 1., 2.], [1., 1., 1.]]), red)      # :939-956
+    assert abs(got.item() - want) < 1e-5
+    want = (1.5 * sq(-1., 1.) + 1.5 * sq(1., 1.) + 3. * sq(1., 2.) + 1. * sq(2., 2.)) / 7.
+    got = L.PairwiseMSELoss(None, lambda_weight=L.DCGLambdaWeight()).compute(labels, scores, None, red)  # :958-974
+    assert abs(got.item() - want) < 1e-5
+    got = L.PairwiseMSELoss(None).compute(t([[1., 0., 0.], [0., 0., 2.]]), scores, None, red,
+                                          mask=t([[True, False, True], [True, True, True]]))           # :987-1000
+    assert abs(got.item() - 2. * (sq(1., -1.) + sq(1., 2.) + sq(2., 2.) + sq(1., 0.)) / 8.) < 1e-5
+    assert abs(K.get('pairwise_mse_loss')(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 1.44) < 1e-6       # keras/losses.py:550-554
+    got = K.PairwiseMSELoss(ragged=True)([[1., 0.], [0., 1., 0.]], [t([0.6, 0.8]), t([0.5, 0.8, 0.4])])
+    assert abs(got.item() - 0.7666667) < 1e-6                                                          # :556-561
+    # Yeti: with the sampler's own draws fed to the oracle, the rest of the chain must agree
+    yl = K.get('yeti_logistic_loss', sample_size=4, seed=3)
+    lb, lg = make_batch(5, 40, seed=9)
+    lgd = lg.to(DEV).requires_grad_(True)
+    out = yl(lb.to(DEV), lgd); out.backward()
+    gl, gs, _ = K.YetiLogisticLoss(sample_size=4, seed=3)._gumbel_sampler.sample(lb.to(DEV), lg.to(DEV))
+    want = R.keras_loss_call(R.PairwiseLogisticLoss(lambda_weight=R.KerasYetiDCGLambdaWeight()), gl.cpu(), gs.cpu())
+    assert_loss_close(out, want, what='yeti logistic')
+    assert torch.isfinite(lgd.grad).all() and lgd.grad.abs().sum() > 0

@@ -645,3 +645,28 @@ class TestLambdaWeightV2YetiPrecision:  # losses_impl_test.py:436-511
         close(R.PrecisionLambdaWeight(topn=5).pair_weights(self.labels, self.ranks), [[[0.] * 3] * 3])
         close(R.PrecisionLambdaWeight(topn=1).pair_weights(self.labels, self.ranks),
               [[[0., 0., 1.], [0., 0., 0.], [1., 0., 0.]]])
+
+
+def test_pairwise_mse_reference_literals():
+    """losses_impl_test.py:906-1000, keras/losses.py:550-561."""
+    scores = torch.tensor([[1., 3., 2.], [1., 2., 3.]])
+    labels = torch.tensor([[0., 0., 1.], [0., 0., 2.]])
+    red = R.Reduction.MEAN
+    sq = lambda a, b: (a - b) ** 2
+    want = 2 * (sq(2. - 3., 1.) + sq(2. - 1., 1.) + sq(3. - 1., 0.) + sq(3. - 2., 2.) + sq(3. - 1., 2.) + sq(2. - 1., 0.)) / 12.
+    assert abs(R.PairwiseMSELoss().compute(labels, scores, None, red).item() - want) < 1e-5
+    want = 2 * (sq(-1., 1.) + sq(1., 1.) + sq(2., 0.) + 2 * sq(1., 2.) + 2 * sq(2., 2.) + 2 * sq(1., 0.)) / 18.
+    assert abs(R.PairwiseMSELoss().compute(labels, scores, torch.tensor([[1.], [2.]]), red).item() - want) < 1e-5
+    want = ((3. * sq(-1., 1.) + 3. * sq(1., 1.) + 2. * sq(2., 0.)) + 2. * (sq(1., 2.) + sq(2., 2.) + sq(1., 0.))) / 14.
+    got = R.PairwiseMSELoss().compute(labels, scores, torch.tensor([[1., 1., 2.], [1., 1., 1.]]), red)
+    assert abs(got.item() - want) < 1e-5
+    want = (1.5 * sq(-1., 1.) + 1.5 * sq(1., 1.) + 3. * sq(1., 2.) + 1. * sq(2., 2.)) / (1.5 + 1.5 + 3. + 1.)
+    got = R.PairwiseMSELoss(lambda_weight=R.DCGLambdaWeight()).compute(labels, scores, None, red)
+    assert abs(got.item() - want) < 1e-5
+    got = R.PairwiseMSELoss().compute(torch.tensor([[0., -1., 1.]]), torch.tensor([[1., 3., 2.]]), None, red)
+    assert abs(got.item() - 0.0) < 1e-5
+    got = R.PairwiseMSELoss().compute(torch.tensor([[1., 0., 0.], [0., 0., 2.]]), scores, None, red,
+                                      mask=torch.tensor([[True, False, True], [True, True, True]]))
+    want = 2. * (sq(2. - 1., -1.) + sq(1., 2.) + sq(2., 2.) + sq(1., 0.)) / 8.
+    assert abs(got.item() - want) < 1e-5
+    assert abs(R.keras_loss_call(R.PairwiseMSELoss(), torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item() - 1.44) < 1e-6
