@@ -152,6 +152,17 @@ int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8
                            const float* list_scale, int B, int L, float temperature,
                            float* loss_out, float* dlogits_out, void* stream);
 
+/* NeuralSort losses (losses_impl.py:1635-1673 NeuralSortCrossEntropyLoss, :1676-1713 NeuralSortNDCGLoss,
+ * :1716-1801 neural_sort): per-list loss [B] and d loss / d logits [B, L] (x list_scale[b] when given),
+ * one wavefront per list, no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG
+ * kind only).  L <= 1024 (TFR_ETOOLARGE beyond).  The Gumbel variants are this kernel on the sampler's
+ * expanded batch. */
+#define TFR_NEURAL_SORT_NDCG 0
+#define TFR_NEURAL_SORT_CE 1
+int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                             const float* inv_log1p, const float* list_scale, int B, int L,
+                             float temperature, float* loss_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

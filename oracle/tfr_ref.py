@@ -242,13 +242,17 @@ def inverse_max_dcg(labels, gain_fn=pow_minus_1, rank_discount_fn=log1p_inverse,
                        torch.zeros_like(discounted_gain))
 
 
-def ndcg(labels, ranks=None):
-    """losses_impl.py:137-167 (ranks path; perm_mat is out of scope)."""
+def ndcg(labels, ranks=None, perm_mat=None):
+    """losses_impl.py:137-167."""
     labels = _t(labels)
+    if ranks is not None and perm_mat is not None:
+        raise ValueError('Cannot use both ranks and perm_mat simultaneously.')
     if ranks is None:
         ranks = torch.arange(labels.shape[1]) + 1
     discounts = 1.0 / torch.log1p(_t(ranks).to(labels.dtype))
     gains = _safe_default_gain_fn(labels)
+    if perm_mat is not None:
+        gains = (perm_mat * gains.unsqueeze(1)).sum(dim=-1)
     dcg = (gains * discounts).sum(dim=-1, keepdim=True)
     return dcg * inverse_max_dcg(labels, gain_fn=_safe_default_gain_fn)
 
@@ -674,6 +678,65 @@ class ApproxNDCGLoss(_ListwiseLoss):
         labels = torch.where(nonzero_mask.unsqueeze(1), labels, _EPSILON * torch.ones_like(labels))
         ranks = approx_ranks(logits)
         return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
+
+
+def neural_sort(logits, mask=None):
+    """losses_impl.py:1716-1801, op for op."""
+    logits = _t(logits)
+    if mask is None:
+        mask = torch.ones_like(logits, dtype=torch.bool)
+    mask = torch.as_tensor(mask, dtype=torch.bool)
+    logits = torch.where(mask, logits, torch.zeros_like(logits))
+    num_valid_entries = mask.to(torch.int32).sum(dim=1, keepdim=True)
+    logit_diff = torch.abs(logits.unsqueeze(2) - logits.unsqueeze(1))
+    valid_pair_mask = _apply_pairwise_op(torch.logical_and, mask)
+    logit_diff = torch.where(valid_pair_mask, logit_diff, torch.zeros_like(logit_diff))
+    logit_diff_sum = logit_diff.sum(dim=1, keepdim=True)
+    masked_range = torch.cumsum(mask.to(torch.int32), dim=1)
+    scaling = (num_valid_entries + 1 - 2 * masked_range).to(logits.dtype)
+    scaling = scaling.unsqueeze(2)
+    scaled_logits = scaling * logits.unsqueeze(1)
+    p_logits = scaled_logits - logit_diff_sum
+    p_logits = torch.where(valid_pair_mask, p_logits, torch.full_like(p_logits, -math.inf))
+    p_logits = torch.where(_apply_pairwise_op(torch.logical_or, mask), p_logits, torch.zeros_like(p_logits))
+    sorted_mask_indices = torch.argsort(mask.to(torch.int32), dim=1, descending=True, stable=True)
+    p_logits = torch.gather(p_logits, 1, sorted_mask_indices.unsqueeze(2).expand_as(p_logits))
+    return torch.softmax(p_logits, dim=-1)
+
+
+class NeuralSortCrossEntropyLoss(_ListwiseLoss):
+    """losses_impl.py:1635-1673."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        true_perm = neural_sort(labels, mask=mask)
+        smooth_perm = neural_sort(logits, mask=mask)
+        # tf.nn.softmax_cross_entropy_with_logits_v2(labels, logits, axis=2) = -sum labels * log_softmax(logits)
+        losses = -(true_perm * torch.log_softmax(torch.log(1e-20 + smooth_perm), dim=2)).sum(dim=2)
+        sorted_mask = torch.sort(mask.to(logits.dtype), dim=1, descending=True).values.to(torch.bool)
+        losses = torch.where(sorted_mask, losses, torch.zeros_like(losses))
+        losses = _safe_div(losses.sum(dim=-1, keepdim=True), mask.to(logits.dtype).sum(dim=-1, keepdim=True))
+        return losses, nonzero_mask.to(logits.dtype).reshape(-1, 1)
+
+
+class NeuralSortNDCGLoss(_ListwiseLoss):
+    """losses_impl.py:1676-1713."""
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        labels = torch.where(nonzero_mask.unsqueeze(1), labels, _EPSILON * torch.ones_like(labels))
+        smooth_perm = neural_sort(logits, mask=mask)
+        return -ndcg(labels, perm_mat=smooth_perm), nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
 class UniqueSoftmaxLoss(_ListwiseLoss):

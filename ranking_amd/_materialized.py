@@ -204,3 +204,41 @@ def softmax_unreduced(labels, logits, mask=None):
     p = _safe_div(padded, padded.sum(dim=1, keepdim=True))
     losses = -(p * torch.log_softmax(logits, dim=1)).sum(dim=1)
     return losses, label_sum.reshape(-1)
+
+
+def neural_sort(logits, mask=None):
+    """losses_impl.py:1716-1801: the [B, L, L] relaxed permutation matrix (API parity; the fused losses
+    never build it)."""
+    logits = torch.as_tensor(logits, dtype=torch.float32)
+    if mask is None:
+        mask = torch.ones_like(logits, dtype=torch.bool)
+    mask = torch.as_tensor(mask, device=logits.device).to(torch.bool)
+    logits = torch.where(mask, logits, torch.zeros_like(logits))
+    n_valid = mask.to(torch.int32).sum(dim=1, keepdim=True)
+    diff = torch.abs(logits.unsqueeze(2) - logits.unsqueeze(1))
+    valid_pair = _pairwise(torch.logical_and, mask)
+    diff = torch.where(valid_pair, diff, torch.zeros_like(diff))
+    diff_sum = diff.sum(dim=1, keepdim=True)
+    masked_range = torch.cumsum(mask.to(torch.int32), dim=1)
+    scaling = (n_valid + 1 - 2 * masked_range).to(torch.float32).unsqueeze(2)
+    p_logits = scaling * logits.unsqueeze(1) - diff_sum
+    p_logits = torch.where(valid_pair, p_logits, torch.full_like(p_logits, -math.inf))
+    p_logits = torch.where(_pairwise(torch.logical_or, mask), p_logits, torch.zeros_like(p_logits))
+    order = torch.argsort(mask.to(torch.int32), dim=1, descending=True, stable=True)
+    p_logits = torch.gather(p_logits, 1, order.unsqueeze(2).expand_as(p_logits))
+    return torch.softmax(p_logits, dim=-1)
+
+
+def gumbel_neural_sort(logits, sample_size=8, temperature=1.0, seed=None):
+    """losses_impl.py:1804-1847: [B, sample_size, L, L]."""
+    logits = torch.as_tensor(logits, dtype=torch.float32)
+    b, l = logits.shape
+    gen = torch.Generator(device=logits.device)
+    if seed is not None:
+        gen.manual_seed(int(seed))
+    else:
+        gen.seed()
+    u = torch.rand((b, sample_size, l), generator=gen, device=logits.device)
+    gumbel = -torch.log(-torch.log(u + 1e-20) + 1e-20)
+    sampled = (logits.unsqueeze(1) + gumbel).reshape(b * sample_size, l)
+    return neural_sort(sampled / temperature).reshape(b, sample_size, l, l)

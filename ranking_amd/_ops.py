@@ -273,6 +273,25 @@ def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, 
     return loss, dlogits
 
 
+NEURAL_SORT_NDCG, NEURAL_SORT_CE = 0, 1
+
+
+def neural_sort_loss(kind, logits, labels, mask=None, list_scale=None, temperature=1.0, want_grad=True):
+    """tfr_neural_sort_loss_f32: per-list NeuralSortNDCG / NeuralSortCrossEntropy loss and its gradient."""
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
+    B, L = logits.shape
+    tab = rank_table(_inv_log1p, L, logits.device) if kind == NEURAL_SORT_NDCG else None
+    loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    rc = _lib.load().tfr_neural_sort_loss_f32(int(kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
+                                              _ptr(list_scale), B, L, float(temperature), _ptr(loss),
+                                              _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_neural_sort_loss_f32')
+    return loss, dlogits
+
+
 def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,

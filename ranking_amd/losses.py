@@ -56,6 +56,10 @@ _SUPPORTED = {
     RankingLossKey.PAIRWISE_MSE_LOSS: (losses_impl.PairwiseMSELoss, True, False),
     RankingLossKey.YETI_LOGISTIC_LOSS: (losses_impl.PairwiseLogisticLoss, False, True),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
+    RankingLossKey.NEURAL_SORT_CROSS_ENTROPY_LOSS: (losses_impl.NeuralSortCrossEntropyLoss, False, False),
+    RankingLossKey.GUMBEL_NEURAL_SORT_CROSS_ENTROPY_LOSS: (losses_impl.NeuralSortCrossEntropyLoss, False, True),
+    RankingLossKey.NEURAL_SORT_NDCG_LOSS: (losses_impl.NeuralSortNDCGLoss, False, False),
+    RankingLossKey.GUMBEL_NEURAL_SORT_NDCG_LOSS: (losses_impl.NeuralSortNDCGLoss, False, True),
 }
 
 

@@ -623,6 +623,39 @@ class UniqueSoftmaxLoss(_ListwiseLoss):
         return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)
 
 
+def neural_sort(logits, name=None, mask=None):
+    """losses_impl.py:1716-1801."""
+    return _mat.neural_sort(logits, mask)
+
+
+def gumbel_neural_sort(logits, name=None, sample_size=8, temperature=1.0, seed=None):
+    """losses_impl.py:1804-1847."""
+    return _mat.gumbel_neural_sort(logits, sample_size, temperature, seed)
+
+
+class _NeuralSortLoss(_ListwiseLoss):
+    _kind = None
+
+    def _unreduced(self, labels, logits, mask, temperature):
+        def runner(lg, want_grad):
+            loss, d = _ops.neural_sort_loss(self._kind, lg, labels, mask, None, temperature, want_grad)
+            return loss, d, ()
+        (loss,) = _PerListLossFn.apply(logits, runner)
+        m = mask if mask is not None else utils.is_label_valid(labels)
+        nonzero = torch.where(m, labels, torch.zeros_like(labels)).sum(dim=1, keepdim=True) > 0.0
+        return loss.unsqueeze(1), nonzero.to(torch.float32)
+
+
+class NeuralSortCrossEntropyLoss(_NeuralSortLoss):
+    """losses_impl.py:1635-1673; fused kernel tfr_neural_sort_loss_f32(TFR_NEURAL_SORT_CE)."""
+    _kind = _ops.NEURAL_SORT_CE
+
+
+class NeuralSortNDCGLoss(_NeuralSortLoss):
+    """losses_impl.py:1676-1713; fused kernel tfr_neural_sort_loss_f32(TFR_NEURAL_SORT_NDCG)."""
+    _kind = _ops.NEURAL_SORT_NDCG
+
+
 class ApproxMRRLoss(_ListwiseLoss):
     """losses_impl.py:1606-1632; fused kernel tfr_approx_mrr_f32."""
 

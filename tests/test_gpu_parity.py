@@ -1001,3 +1001,75 @@ def test_pairwise_mse_and_yeti_reference_goldens():
     want = R.keras_loss_call(R.PairwiseLogisticLoss(lambda_weight=R.KerasYetiDCGLambdaWeight()), gl.cpu(), gs.cpu())
     assert_loss_close(out, want, what='yeti logistic')
     assert torch.isfinite(lgd.grad).all() and lgd.grad.abs().sum() > 0
+
+
+# ------------------------------------------------------------------ NeuralSort losses
+def _fp64_arbitrated(got, o32, truth, tol, what):
+    """fp32 evaluation of exp(c_t s_k - A_k) is conditioned by |c_t s_k| ~ L * |s|: neither the reference's
+    fp32 tensor program nor the kernel is "the" fp32 answer.  Both are judged against the oracle run in
+    fp64: the kernel must be within `tol` (relative to the output scale) or within 3x the fp32 oracle's own
+    distance from the fp64 result."""
+    got = got.detach().cpu().double().reshape(-1); o32 = o32.detach().double().reshape(-1); truth = truth.detach().reshape(-1)
+    scale = max(1.0, truth.abs().max().item())
+    err = (got - truth).abs().max().item()
+    ref_err = (o32 - truth).abs().max().item()
+    assert err <= max(tol * scale, 3.0 * ref_err), '%s: err %.3e (oracle-fp32 err %.3e, scale %.3e)' % (what, err, ref_err, scale)
+
+
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40)])
+@pytest.mark.parametrize('kind', ['ndcg', 'ce'])
+@pytest.mark.parametrize('temperature', [1.0, 0.1])
+def test_neural_sort_loss_parity(B, L, kind, temperature):
+    labels, logits = make_batch(B, L, seed=1500 + L)
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.zeros_like(labels[0]), labels[0])  # all-zero labels
+        labels[1] = -1.0                                                                  # fully padded
+    octor = R.NeuralSortNDCGLoss if kind == 'ndcg' else R.NeuralSortCrossEntropyLoss
+    oracle = octor(temperature=temperature)
+    o32, g32 = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels, lg / temperature)[0], logits)
+    truth, gt = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels.double(), lg / temperature)[0],
+                             logits.double())
+    from ranking_amd import _ops
+    k = _ops.NEURAL_SORT_NDCG if kind == 'ndcg' else _ops.NEURAL_SORT_CE
+    loss, d = _ops.neural_sort_loss(k, logits.to(DEV), labels.to(DEV), None, None, temperature)
+    _fp64_arbitrated(loss, o32, truth, 1e-5, 'neural sort %s loss' % kind)
+    _fp64_arbitrated(d, g32, gt, 2e-5, 'neural sort %s grad' % kind)
+    assert torch.isfinite(d).all()
+
+
+def test_neural_sort_reference_goldens():
+    L = ra().losses_impl
+    t = lambda x: torch.tensor(x, device=DEV)
+    ln = math.log
+    scores = t([[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]])
+    labels = t([[0., 2., 1.], [1., 0., -3.], [0., 0., 0.]])
+    weights = t([[2.], [1.], [1.]])
+    nd = L.NeuralSortNDCGLoss(None, temperature=0.1)                                   # losses_impl_test.py:1812-1828
+    a = (1 / (3 / ln(2) + 1 / ln(3))) * (3 / ln(4) + 1 / ln(3)); b = (1 / (1 / ln(2))) * (1 / ln(3))
+    assert abs(nd.compute(labels, scores, None, L.Reduction.SUM).item() + (a + b)) < 1e-4
+    assert abs(nd.compute(labels, scores, weights, L.Reduction.SUM).item() + (2 * a + b)) < 1e-4
+    red = L.Reduction.SUM_BY_NONZERO_WEIGHTS
+    assert abs(nd.compute(t([[0., -1., 1.]]), t([[1., 3., 2.]]), None, red).item() + 1.) < 1e-4   # :1830-1837
+    got = nd.compute(t([[0., 0., 1., 0., 1.]]), t([[2., 4., 3., -5., 1000.0]]), None, red,
+                     mask=t([[True, False, True, False, False]]))                      # :1839-1847
+    assert abs(got.item() + 1.) < 1e-4
+    # ragged per-list literals  (:565-566)
+    for ctor, exp in [(L.NeuralSortCrossEntropyLoss, [1.816267, 0.365334]), (L.NeuralSortNDCGLoss, [-0.761571, -0.956006])]:
+        losses, w = ctor(None, ragged=True).compute_per_list([[0., 0., 1.], [0., 2.]], [t([1., 3., 2.]), t([1., 3.])],
+                                                             [[2., 3., 4.], [1., 1.]])
+        assert_loss_close(losses, torch.tensor(exp), 1e-5)
+        assert w.tolist() == [4., 1.]
+    # CE against the oracle on the reference's own test inputs (:1760-1780) and the estimator key + Gumbel variant
+    ce = L.NeuralSortCrossEntropyLoss(None)
+    want = R.NeuralSortCrossEntropyLoss().compute(labels.cpu(), scores.cpu(), weights.cpu(), R.Reduction.SUM)
+    assert abs(ce.compute(labels, scores, weights, L.Reduction.SUM).item() - want.item()) < 1e-5
+    fn = ra().losses.make_loss_fn('neural_sort_ndcg_loss,gumbel_neural_sort_cross_entropy_loss:0.5',
+                                  gumbel_params={'sample_size': 3, 'seed': 1})
+    lgd = scores.clone().requires_grad_(True)
+    out = fn(labels, lgd, {}); out.backward()
+    assert torch.isfinite(out) and torch.isfinite(lgd.grad).all()
+    # materialised permutation matrix (API parity; :278-299)
+    got = L.neural_sort(t([[3.0, 1.0, -1.0, 1000.0, 5.0, 2.0]]), mask=t([[True, True, True, False, False, True]]))
+    want = R.neural_sort([[3.0, 1.0, -1.0, 1000.0, 5.0, 2.0]], mask=[[True, True, True, False, False, True]])
+    assert_loss_close(got, want, 1e-6)
+    assert L.gumbel_neural_sort(t([[1.4, -2.8, -0.4]]), sample_size=2, temperature=0.001, seed=1).shape == (1, 2, 3, 3)

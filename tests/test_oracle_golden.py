@@ -178,6 +178,8 @@ RAGGED_W = [[2., 3., 4.], [1., 1.]]
     (R.ApproxMRRLoss, [-0.5, -0.893493], [4., 1.]),
     (R.ListMLELoss, [3.534534, 0.126928], [4., 1.]),
     (R.UniqueSoftmaxLoss, [1.407606, 0.380784], [4., 1.]),
+    (R.NeuralSortCrossEntropyLoss, [1.816267, 0.365334], [4., 1.]),
+    (R.NeuralSortNDCGLoss, [-0.761571, -0.956006], [4., 1.]),
 ])
 def test_compute_per_list_ragged(ctor, exp_l, exp_w):
     losses, weights = ctor(ragged=True).compute_per_list(RAGGED_LABELS, RAGGED_SCORES, RAGGED_W)
@@ -193,6 +195,8 @@ def test_compute_per_list_ragged(ctor, exp_l, exp_w):
                               [[0., 0., 0.], [0.126928, 0., 0.], [0., 0., 0.]]]),
     (R.ApproxNDCGLoss, [[-0.63093], [-0.922917]]),
     (R.ApproxMRRLoss, [[-0.5], [-0.893493]]),
+    (R.NeuralSortCrossEntropyLoss, [[1.816267], [0.365334]]),
+    (R.NeuralSortNDCGLoss, [[-0.761571], [-0.956006]]),
 ])
 def test_compute_unreduced_loss_ragged(ctor, expected):
     losses, weights = ctor(ragged=True).compute_unreduced_loss(RAGGED_LABELS, RAGGED_SCORES)
@@ -670,3 +674,67 @@ def test_pairwise_mse_reference_literals():
     want = 2. * (sq(2. - 1., -1.) + sq(1., 2.) + sq(2., 2.) + sq(1., 0.)) / 8.
     assert abs(got.item() - want) < 1e-5
     assert abs(R.keras_loss_call(R.PairwiseMSELoss(), torch.tensor([[1., 0.]]), torch.tensor([[0.6, 0.8]])).item() - 1.44) < 1e-6
+
+
+# ------------------------------------------------------------------ NeuralSort
+def _neural_sort_py(logits, temperature=1.0):
+    """losses_impl_test.py:126-146 (plain-Python neural sort of the reference's tests)."""
+    out = []
+    for row in logits:
+        n = len(row)
+        dsum = [sum(abs(m - l) for m in row) for l in row]
+        perm = []
+        for i in range(n):
+            sc = n + 1 - 2 * (i + 1)
+            p = [(sc * l - s) / temperature for l, s in zip(row, dsum)]
+            mx = max(p)
+            e = [math.exp(v - mx) for v in p]
+            perm.append([v / sum(e) for v in e])
+        out.append(perm)
+    return out
+
+
+def _softmax_ce_py(p_trues, p_preds):
+    return sum(sum(-a * math.log(1e-20 + b) for a, b in zip(t, p)) for t, p in zip(p_trues, p_preds))
+
+
+def test_neural_sort_reference_literals():
+    """losses_impl_test.py:278-299."""
+    scores = [[140., -280., -40.], [0., 180., 1020.], [100., 120., -320.]]
+    want = [[[1, 0, 0], [0, 0, 1], [0, 1, 0]], [[0, 0, 1], [0, 1, 0], [1, 0, 0]], [[0, 1, 0], [1, 0, 0], [0, 0, 1]]]
+    close(R.neural_sort(scores), want, 1e-3)
+    got = R.neural_sort([[3.0, 1.0, -1.0, 1000.0, 5.0, 2.0]], mask=[[True, True, True, False, False, True]])
+    close(got, [[[0.72140, 0.01321, 0.00000, 0., 0., 0.26539], [0.21183, 0.21183, 0.00053, 0., 0., 0.57581],
+                 [0.01204, 0.65723, 0.08895, 0., 0., 0.24178], [0.00004, 0.11849, 0.87557, 0., 0., 0.0059],
+                 [0., 0., 0., 0.5, 0.5, 0.], [0., 0., 0., 0.5, 0.5, 0.]]], 1e-4)
+
+
+def test_neural_sort_losses_reference_literals():
+    """losses_impl_test.py:1758-1850."""
+    scores = torch.tensor([[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]])
+    labels = torch.tensor([[0., 2., 1.], [1., 0., -3.], [0., 0., 0.]])
+    weights = torch.tensor([[2.], [1.], [1.]])
+    p_scores = _neural_sort_py([[1.4, -2.8, -0.4], [0., 1.8, -1000.], [1., 1.2, -3.2]])
+    p_labels = _neural_sort_py([[0., 2., 1.], [1., 0., -1000.], [0., 0., 0.]])
+    ce = R.NeuralSortCrossEntropyLoss()
+    a = _softmax_ce_py(p_labels[0], p_scores[0]) / 3.
+    b = _softmax_ce_py(p_labels[1][0:2], p_scores[1][0:2]) / 2.
+    assert abs(ce.compute(labels, scores, None, R.Reduction.SUM).item() - (a + b)) < 1e-4
+    assert abs(ce.compute(labels, scores, weights, R.Reduction.SUM).item() - (2 * a + b)) < 1e-4
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    want = _softmax_ce_py(_neural_sort_py([[0., 1.]])[0], _neural_sort_py([[1., 2.]])[0]) / 2.
+    assert abs(ce.compute(torch.tensor([[0., -1., 1.]]), torch.tensor([[1., 3., 2.]]), None, red).item() - want) < 1e-5
+    want = _softmax_ce_py(_neural_sort_py([[0., 1.]])[0], _neural_sort_py([[2., 3.]])[0]) / 2.
+    got = ce.compute(torch.tensor([[0., 0., 1., 0., 1.]]), torch.tensor([[2., 4., 3., 3., -1e10]]), None, red,
+                     mask=torch.tensor([[True, False, True, False, False]]))
+    assert abs(got.item() - want) < 1e-5
+    ln = math.log
+    nd = R.NeuralSortNDCGLoss(temperature=0.1)
+    a = (1 / (3 / ln(2) + 1 / ln(3))) * (3 / ln(4) + 1 / ln(3))
+    b = (1 / (1 / ln(2))) * (1 / ln(3))
+    assert abs(nd.compute(labels, scores, None, R.Reduction.SUM).item() + (a + b)) < 1e-4
+    assert abs(nd.compute(labels, scores, weights, R.Reduction.SUM).item() + (2 * a + b)) < 1e-4
+    assert abs(nd.compute(torch.tensor([[0., -1., 1.]]), torch.tensor([[1., 3., 2.]]), None, red).item() + 1.) < 1e-4
+    got = nd.compute(torch.tensor([[0., 0., 1., 0., 1.]]), torch.tensor([[2., 4., 3., -5., 1000.0]]), None, red,
+                     mask=torch.tensor([[True, False, True, False, False]]))
+    assert abs(got.item() + 1.) < 1e-4
