@@ -163,6 +163,15 @@ int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels,
                              const float* inv_log1p, const float* list_scale, int B, int L,
                              float temperature, float* loss_out, float* dlogits_out, void* stream);
 
+/* CircleLoss (losses_impl.py:1036-1116): loss[b] = log1p(sum_{y_i > y_j} exp(gamma (a_i + b_j))) on scores
+ * clipped to [0, 1]; weight[b] = 1, or NaN for a list without any preference pair (the reference's 0 / 0);
+ * dlogits = d loss / d logits (x list_scale[b]).  clip != 0 applies get_logits' clip_by_value(0, 1) in
+ * the kernel (compute()); compute_per_list / compute_unreduced_loss hand the scores over as they are.
+ * L <= 1024. */
+int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                        const float* list_scale, int B, int L, float gamma, float margin, int clip,
+                        float* loss_out, float* weight_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

@@ -680,6 +680,33 @@ class ApproxNDCGLoss(_ListwiseLoss):
         return -ndcg(labels, ranks), nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
+class CircleLoss(_ListwiseLoss):
+    """losses_impl.py:1036-1116."""
+
+    def __init__(self, lambda_weight=None, gamma=64, margin=0.25, ragged=False):
+        super().__init__(lambda_weight=lambda_weight, temperature=1.0, ragged=ragged)
+        self._margin = margin
+        self._gamma = gamma
+
+    def get_logits(self, logits):
+        return torch.clamp(_t(logits), 0., 1.)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        score_i = logits.unsqueeze(2)
+        score_j = logits.unsqueeze(1)
+        alpha_i = torch.relu(1 - score_i + self._margin).detach()
+        alpha_j = torch.relu(score_j + self._margin).detach()
+        pairwise_logits = alpha_i * (1 - score_i - self._margin) + alpha_j * (score_j - self._margin)
+        pairwise_labels, _ = _pairwise_comparison(labels, logits, mask)
+        pairwise_weights = pairwise_labels.detach()
+        losses = torch.exp(self._gamma * pairwise_logits)
+        per_list_losses = torch.log1p((losses * pairwise_weights).sum(dim=(1, 2)))
+        per_list_weights = pairwise_weights.sum(dim=(1, 2)) / (pairwise_weights > 0).to(logits.dtype).sum(dim=(1, 2))
+        return per_list_losses.unsqueeze(1), per_list_weights.unsqueeze(1)
+
+
 def neural_sort(logits, mask=None):
     """losses_impl.py:1716-1801, op for op."""
     logits = _t(logits)

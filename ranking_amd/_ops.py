@@ -273,6 +273,23 @@ def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, 
     return loss, dlogits
 
 
+def circle_loss(logits, labels, mask=None, list_scale=None, gamma=64.0, margin=0.25, clip=True, want_grad=True):
+    """tfr_circle_loss_f32 -> (loss [B], weight [B] (NaN where a list has no pair), dlogits [B, L])."""
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
+    B, L = logits.shape
+    loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    rc = _lib.load().tfr_circle_loss_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
+                                         float(gamma), float(margin), int(bool(clip)), _ptr(loss), _ptr(weight),
+                                         _ptr(dlogits),
+                                         _stream())
+    _lib.check(rc, 'tfr_circle_loss_f32')
+    return loss, weight, dlogits
+
+
 NEURAL_SORT_NDCG, NEURAL_SORT_CE = 0, 1
 
 

@@ -115,6 +115,54 @@ __global__ __launch_bounds__(64) void list_mle_wave_kernel(
 // inner sum is a SUFFIX sum starting at the end of i's tie group, and the backward
 //     d loss / d s_k = -g_k + e^{s_k} ( g_k / D_k + sum_{i: l_i > l_k} g_i / D_i )
 // a PREFIX sum ending at the start of k's tie group: O(L) after one register sort.
+// Tie groups of a label-descending sorted sequence (element p = lane + 64 r, nv of them):
+// gs[p] = first position of p's label group, ge[p] = one past its last.
+template <int IPL>
+__device__ __forceinline__ void label_tie_groups(const float (&lb)[IPL], int nv, int lane, int (&gs)[IPL], int (&ge)[IPL]) {
+    // first-of-group flags need the previous position's label
+    float prev_carry = INFINITY;                          // label "before" position 0
+    int run_start = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      float prev = __shfl_up(lb[r], 1, 64);
+      if (lane == 0) prev = prev_carry;
+      prev_carry = __shfl(lb[r], 63, 64);
+      const bool first = (p < nv) && (lb[r] < prev || p == 0);
+      // inclusive max-scan of (first ? p : -1)  -> group start
+      int v = first ? p : -1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o, 64);
+        if (lane >= o) v = v > u ? v : u;
+      }
+      v = v > run_start ? v : run_start;
+      gs[r] = v;
+      run_start = __shfl(v, 63, 64);
+    }
+    // group end = next first-of-group position after p (or nv): reverse min-scan over positions > p
+    int next_carry = nv;
+    float next_lab_carry = -INFINITY;                     // label "after" the last position
+#pragma unroll
+    for (int r = IPL - 1; r >= 0; --r) {
+      const int p = lane + 64 * r;
+      float nxt = __shfl_down(lb[r], 1, 64);
+      if (lane == 63) nxt = next_lab_carry;
+      next_lab_carry = __shfl(lb[r], 0, 64);
+      // position p + 1 starts a new group iff label[p + 1] < label[p]  (or p + 1 >= nv)
+      const bool last = (p < nv) && (p + 1 >= nv || nxt < lb[r]);
+      int v = last ? p + 1 : 0x7fffffff;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_down(v, o, 64);
+        if (lane + o < 64) v = v < u ? v : u;
+      }
+      v = v < next_carry ? v : next_carry;
+      ge[r] = v;
+      next_carry = __shfl(v, 0, 64);
+    }
+}
+
 template <int IPL>
 __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
@@ -179,52 +227,8 @@ __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
     carry += __shfl(v, 0, 64);
   }
   if (lane == 0) SUF[NP] = 0.0f;
-  // tie groups: gstart[p] = first position of p's label group, gend[p] = one past its last
   int gs[IPL], ge[IPL];
-  {
-    // first-of-group flags need the previous position's label
-    float prev_carry = INFINITY;                          // label "before" position 0
-    int run_start = 0;
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const int p = lane + 64 * r;
-      float prev = __shfl_up(lb[r], 1, 64);
-      if (lane == 0) prev = prev_carry;
-      prev_carry = __shfl(lb[r], 63, 64);
-      const bool first = (p < nv) && (lb[r] < prev || p == 0);
-      // inclusive max-scan of (first ? p : -1)  -> group start
-      int v = first ? p : -1;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(v, o, 64);
-        if (lane >= o) v = v > u ? v : u;
-      }
-      v = v > run_start ? v : run_start;
-      gs[r] = v;
-      run_start = __shfl(v, 63, 64);
-    }
-    // group end = next first-of-group position after p (or nv): reverse min-scan over positions > p
-    int next_carry = nv;
-    float next_lab_carry = -INFINITY;                     // label "after" the last position
-#pragma unroll
-    for (int r = IPL - 1; r >= 0; --r) {
-      const int p = lane + 64 * r;
-      float nxt = __shfl_down(lb[r], 1, 64);
-      if (lane == 63) nxt = next_lab_carry;
-      next_lab_carry = __shfl(lb[r], 0, 64);
-      // position p + 1 starts a new group iff label[p + 1] < label[p]  (or p + 1 >= nv)
-      const bool last = (p < nv) && (p + 1 >= nv || nxt < lb[r]);
-      int v = last ? p + 1 : 0x7fffffff;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_down(v, o, 64);
-        if (lane + o < 64) v = v < u ? v : u;
-      }
-      v = v < next_carry ? v : next_carry;
-      ge[r] = v;
-      next_carry = __shfl(v, 0, 64);
-    }
-  }
+  label_tie_groups<IPL>(lb, nv, lane, gs, ge);
   __syncthreads();                                        // SUF visible
   float D[IPL], term = 0.f;
 #pragma unroll
@@ -251,7 +255,9 @@ __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
       const float u = __shfl_up(v, o, 64);
       if (lane >= o) v += u;
     }
-    PRE[p] = v - c + carry;
+    float ex = __shfl_up(v, 1, 64);                       // exclusive = inclusive of the previous lane
+    if (lane == 0) ex = 0.0f;                             // (never `v - c`: cancels when c dominates)
+    PRE[p] = ex + carry;
     carry += __shfl(v, 63, 64);
   }
   __syncthreads();
@@ -262,6 +268,152 @@ __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
     if (p < nv) {
       const float higher = PRE[gs[r]];                    // sum over strictly higher labels
       dlogits_out[base + idx[r]] = (-g[r] + e[r] * (g[r] / D[r] + higher)) * gscale;
+    }
+  }
+}
+
+
+// CircleLoss (losses_impl.py:1036-1116).  Scores are clipped to [0, 1] (get_logits, :1082-1085);
+// with alpha_i = relu(1 + margin - s_i), alpha'_j = relu(s_j + margin) held constant (stop_gradient),
+//     W = sum_{y_i > y_j} exp(gamma * (a_i + b_j)),  a_i = alpha_i (1 - margin - s_i),  b_j = alpha'_j (s_j - margin)
+//     loss = log1p(W);   per-list weight = (#pairs) / (#pairs) -- NaN for a list without a pair, as in
+//     the reference (:1109-1111, plain `/`).
+// The pair exponent is separable, so the [L, L] matrix of the reference collapses to a sort by label and
+// two scans:  W = sum_p e^{ga_p} * sum_{q beyond p's tie group} e^{gb_q}.  Everything is kept in the log
+// domain (gamma = 64 puts e^{ga + gb} beyond fp32 range for scores near 1; the reference overflows to inf
+// there, this kernel does not).
+template <int IPL>
+__global__ __launch_bounds__(64) void circle_wave_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ list_scale, int L, float gamma, float margin, int clip,
+    float* __restrict__ loss_out, float* __restrict__ weight_out, float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* XS = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] raw logits by original index
+  float* LB = XS + 64 * IPL;                               // [64 * IPL] labels by original index
+  float* SUF = LB + 64 * IPL;                              // [64 * IPL + 1] suffix sums of F by sorted position
+  float* PRE = SUF + 64 * IPL + 1;                         // [64 * IPL + 1] exclusive prefix sums of E
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  constexpr int NP = 64 * IPL;
+
+  uint64_t key[IPL];
+  int nv = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    key[r] = 0;
+    bool v = false;
+    if (i < L) {
+      const float lab = labels[base + i];
+      v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      XS[i] = logits[base + i];
+      LB[i] = lab;
+      key[r] = make_sort_key(v, v ? lab : 0.0f, 0, i);
+      if (dlogits_out && !v) dlogits_out[base + i] = 0.0f;
+    }
+    nv += __popcll(__ballot(v));
+  }
+  __syncthreads();
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);       // valid first, label descending, then index
+
+  float lb[IPL], ga[IPL], gb[IPL], al_i[IPL], al_j[IPL];
+  int idx[IPL];
+  bool inside[IPL];
+  float MA = -INFINITY, MB = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    idx[r] = sort_key_index(key[r]);
+    const bool in = p < nv;
+    const float raw = in ? XS[idx[r]] : 0.0f;
+    const float sc = clip ? fminf(fmaxf(raw, 0.0f), 1.0f) : raw;
+    inside[r] = in && (!clip || (raw >= 0.0f && raw <= 1.0f));   // clip_by_value passes the gradient on [0, 1]
+    lb[r] = in ? LB[idx[r]] : -INFINITY;
+    al_i[r] = fmaxf(1.0f - sc + margin, 0.0f);
+    al_j[r] = fmaxf(sc + margin, 0.0f);
+    ga[r] = in ? gamma * (al_i[r] * (1.0f - sc - margin)) : -INFINITY;
+    gb[r] = in ? gamma * (al_j[r] * (sc - margin)) : -INFINITY;
+    MA = fmaxf(MA, ga[r]); MB = fmaxf(MB, gb[r]);
+  }
+  MA = wave_max_u(MA); MB = wave_max_u(MB);
+  float E[IPL], F[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const bool in = lane + 64 * r < nv;
+    E[r] = in ? expf(ga[r] - MA) : 0.0f;
+    F[r] = in ? expf(gb[r] - MB) : 0.0f;
+  }
+  // SUF[p] = sum_{q >= p} F_q ; PRE[p] = sum_{q < p} E_q
+  float carry = 0.f;
+#pragma unroll
+  for (int r = IPL - 1; r >= 0; --r) {
+    float v = F[r];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_down(v, o, 64);
+      if (lane + o < 64) v += u;
+    }
+    SUF[lane + 64 * r] = v + carry;
+    carry += __shfl(v, 0, 64);
+  }
+  if (lane == 0) SUF[NP] = 0.0f;
+  carry = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    float v = E[r];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float u = __shfl_up(v, o, 64);
+      if (lane >= o) v += u;
+    }
+    float ex = __shfl_up(v, 1, 64);                       // exclusive = inclusive of the previous lane
+    if (lane == 0) ex = 0.0f;                             // (never `v - E`: cancels when E_p = 1 dominates)
+    PRE[lane + 64 * r] = ex + carry;
+    carry += __shfl(v, 63, 64);
+  }
+  int gs[IPL], ge[IPL];
+  label_tie_groups<IPL>(lb, nv, lane, gs, ge);
+  __syncthreads();
+
+  // t_p = log( e^{ga_p} * sum_{y_q < y_p} e^{gb_q} );  lw = logsumexp_p t_p = log W
+  float t[IPL], tm = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    t[r] = -INFINITY;
+    if (p < nv) {
+      const float lower = SUF[ge[r] < NP ? ge[r] : NP];
+      if (lower > 0.0f) t[r] = ga[r] + (MB + logf(lower));
+    }
+    tm = fmaxf(tm, t[r]);
+  }
+  tm = wave_max_u(tm);
+  const bool any_pair = tm > -INFINITY;
+  float acc = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) acc += (t[r] > -INFINITY) ? expf(t[r] - tm) : 0.0f;
+  acc = wave_sum_u(acc);
+  const float lw = any_pair ? tm + logf(acc) : -INFINITY;
+  const float loss = any_pair ? (fmaxf(lw, 0.0f) + log1pf(expf(-fabsf(lw)))) : 0.0f;      // log1p(W)
+  if (lane == 0) {
+    loss_out[b] = loss;
+    if (weight_out) weight_out[b] = any_pair ? 1.0f : NAN;
+  }
+  if (!dlogits_out) return;
+  const float sig = any_pair ? 1.0f / (1.0f + expf(-lw)) : 0.0f;                          // W / (1 + W)
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) * gamma * sig;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    if (p < nv) {
+      float gpart = 0.f;
+      if (any_pair && inside[r]) {
+        const float hi = (t[r] > -INFINITY) ? expf(t[r] - lw) : 0.0f;                    // item as the preferred one
+        const float higher = PRE[gs[r]];
+        const float lo = (higher > 0.0f) ? expf(gb[r] + (MA + logf(higher)) - lw) : 0.0f; // item as the other one
+        gpart = -al_i[r] * hi + al_j[r] * lo;
+      }
+      dlogits_out[base + idx[r]] = gscale * gpart;
     }
   }
 }
@@ -291,5 +443,18 @@ extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, 
 #define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out)
   if (L <= 64) US(1); else if (L <= 128) US(2); else if (L <= 256) US(4); else if (L <= 512) US(8); else US(16);
 #undef US
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                   const float* list_scale, int B, int L, float gamma, float margin, int clip,
+                                   float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
+  if (!logits || !labels || !loss_out || B < 0 || L <= 0) return TFR_EINVAL;
+  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (B == 0) return TFR_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define CL(I) hipLaunchKernelGGL(circle_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, gamma, margin, clip, loss_out, weight_out, dlogits_out)
+  if (L <= 64) CL(1); else if (L <= 128) CL(2); else if (L <= 256) CL(4); else if (L <= 512) CL(8); else CL(16);
+#undef CL
   return (int)hipGetLastError();
 }

@@ -55,6 +55,7 @@ _SUPPORTED = {
     RankingLossKey.UNIQUE_SOFTMAX_LOSS: (losses_impl.UniqueSoftmaxLoss, True, False),
     RankingLossKey.PAIRWISE_MSE_LOSS: (losses_impl.PairwiseMSELoss, True, False),
     RankingLossKey.YETI_LOGISTIC_LOSS: (losses_impl.PairwiseLogisticLoss, False, True),
+    RankingLossKey.CIRCLE_LOSS: (losses_impl.CircleLoss, True, False),
     RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, True),
     RankingLossKey.NEURAL_SORT_CROSS_ENTROPY_LOSS: (losses_impl.NeuralSortCrossEntropyLoss, False, False),
     RankingLossKey.GUMBEL_NEURAL_SORT_CROSS_ENTROPY_LOSS: (losses_impl.NeuralSortCrossEntropyLoss, False, True),

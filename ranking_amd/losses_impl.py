@@ -623,6 +623,35 @@ class UniqueSoftmaxLoss(_ListwiseLoss):
         return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)
 
 
+class CircleLoss(_ListwiseLoss):
+    """losses_impl.py:1036-1116; fused kernel tfr_circle_loss_f32 (the [L, L] pair matrix collapses to a
+    sort by label and two scans because the pair exponent is separable)."""
+
+    def __init__(self, name, lambda_weight=None, gamma=64, margin=0.25, ragged=False):
+        super().__init__(name, lambda_weight=lambda_weight, temperature=1.0, ragged=ragged)
+        self._margin = margin
+        self._gamma = gamma
+
+    def get_logits(self, logits):
+        return torch.clamp(torch.as_tensor(logits), 0., 1.)
+
+    def _compute_reduced(self, labels, logits, weights, reduction, mask):
+        # compute() is the one entry point that applies get_logits (:808); the clip runs in the kernel
+        losses, loss_weights = self._unreduced(labels, logits, mask, 1.0, clip=True)
+        w = self._normalize_weights_impl(labels, weights) * loss_weights
+        return compute_weighted_loss(losses, w, reduction)
+
+    def _unreduced(self, labels, logits, mask, temperature, clip=False):
+        out = {}
+
+        def runner(lg, want_grad):
+            loss, weight, d = _ops.circle_loss(lg, labels, mask, None, self._gamma, self._margin, clip, want_grad)
+            out['w'] = weight
+            return loss, d, ()
+        (loss,) = _PerListLossFn.apply(logits, runner)
+        return loss.unsqueeze(1), out['w'].unsqueeze(1)
+
+
 def neural_sort(logits, name=None, mask=None):
     """losses_impl.py:1716-1801."""
     return _mat.neural_sort(logits, mask)

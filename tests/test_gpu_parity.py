@@ -1073,3 +1073,48 @@ def test_neural_sort_reference_goldens():
     want = R.neural_sort([[3.0, 1.0, -1.0, 1000.0, 5.0, 2.0]], mask=[[True, True, True, False, False, True]])
     assert_loss_close(got, want, 1e-6)
     assert L.gumbel_neural_sort(t([[1.4, -2.8, -0.4]]), sample_size=2, temperature=0.001, seed=1).shape == (1, 2, 3, 3)
+
+
+# ------------------------------------------------------------------ Circle loss
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40)])
+@pytest.mark.parametrize('gamma,margin,lo,hi', [(64., 0.25, 0.2, 0.6), (4., 0.1, -0.3, 1.3), (16., 0.25, 0.0, 1.0)])
+def test_circle_loss_parity(B, L, gamma, margin, lo, hi):
+    labels, logits = make_batch(B, L, seed=1700 + L)
+    logits = lo + (hi - lo) * torch.sigmoid(logits)                    # similarity scores, some outside [0, 1]
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.ones_like(labels[0]), labels[0])   # no pair: weight NaN
+        labels[1] = -1.0
+    oracle = R.CircleLoss(gamma=gamma, margin=margin)
+    f = lambda lab, lg: oracle._compute_unreduced_loss_impl(lab, oracle.get_logits(lg))
+    o32, g32 = _oracle_grad(lambda lg: f(labels, lg)[0], logits)
+    truth, gt = _oracle_grad(lambda lg: f(labels.double(), lg)[0], logits.double())
+    want_w = f(labels, logits)[1].reshape(-1)
+    from ranking_amd import _ops
+    loss, w, d = _ops.circle_loss(logits.to(DEV), labels.to(DEV), None, None, gamma, margin, True)
+    _fp64_arbitrated(loss, o32, truth, 1e-5, 'circle loss')
+    _fp64_arbitrated(d, g32, gt, 2e-5, 'circle grad')
+    assert torch.equal(torch.isnan(w.cpu()), torch.isnan(want_w))
+    assert torch.equal(torch.nan_to_num(w.cpu(), nan=-1.), torch.nan_to_num(want_w, nan=-1.))
+
+
+def test_circle_loss_reference_goldens():
+    L = ra().losses_impl
+    t = lambda x: torch.tensor(x, device=DEV)
+    from tests.test_oracle_golden import _circle_py
+    scores = [[0.1, 0.3, 0.2], [0.1, 0.2, 0.3]]; labels = [[0., 0., 1.], [0., 1., 2.]]
+    l0, l1 = math.log1p(_circle_py(labels[0], scores[0])), math.log1p(_circle_py(labels[1], scores[1]))
+    red = L.Reduction.MEAN
+    assert abs(L.CircleLoss(None).compute(t(labels), t(scores), None, red).item() - (l0 + l1) / 2) < 1e-5 * (l0 + l1)   # losses_impl_test.py:1003-1014
+    got = L.CircleLoss(None).compute(t(labels), t(scores), t([[1., 1., 2.], [1., 1., 1.]]), red)                       # :1031-1044
+    assert abs(got.item() - (2 * l0 + l1) / 3) < 1e-5 * (l0 + l1)
+    want = math.log1p(_circle_py([0., 1.], [.1, .2]))
+    assert abs(L.CircleLoss(None).compute(t([[0., -1., 1.]]), t([[.1, .3, .2]]), None, red).item() - want) < 1e-5 * want  # :1059-1069
+    labels2 = [[0., 0., 1.], [0., 0., 2.]]
+    want = (math.log1p(_circle_py(labels2[0], scores[0], 4., 0.1)) + math.log1p(_circle_py(labels2[1], scores[1], 4., 0.1))) / 2
+    fn = ra().losses.make_loss_fn('circle_loss', reduction=red, params={'gamma': 4., 'margin': 0.1})                    # :1046-1057
+    lgd = t(scores).requires_grad_(True)
+    out = fn(t(labels2), lgd, {}); out.backward()
+    assert abs(out.item() - want) < 1e-5 and torch.isfinite(lgd.grad).all() and lgd.grad.abs().sum() > 0
+    # scores near 1 with gamma = 64: exp(gamma (a + b)) leaves fp32 range in the reference; the log-domain kernel stays finite
+    loss, w, d = __import__('ranking_amd')._ops.circle_loss(t([[0.0, 1.0, 0.5]]), t([[1., 0., 0.]]), None, None, 64., 0.25)
+    assert torch.isfinite(loss).all() and torch.isfinite(d).all() and loss.item() > 88.

@@ -738,3 +738,37 @@ def test_neural_sort_losses_reference_literals():
     got = nd.compute(torch.tensor([[0., 0., 1., 0., 1.]]), torch.tensor([[2., 4., 3., -5., 1000.0]]), None, red,
                      mask=torch.tensor([[True, False, True, False, False]]))
     assert abs(got.item() + 1.) < 1e-4
+
+
+# ------------------------------------------------------------------ Circle loss
+def _circle_py(labels, scores, gamma=64., margin=0.25):
+    """losses_impl_test.py:32-87 (sum over preference pairs)."""
+    tot = 0.
+    for i in range(len(labels)):
+        for j in range(len(labels)):
+            if labels[i] > labels[j]:
+                tot += math.exp(gamma * max(0., (1 + margin) - scores[i]) * ((1 - margin) - scores[i])
+                                + gamma * max(0., scores[j] + margin) * (scores[j] - margin))
+    return tot
+
+
+def test_circle_loss_reference_literals():
+    """losses_impl_test.py:1001-1083."""
+    scores = [[0.1, 0.3, 0.2], [0.1, 0.2, 0.3]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    red = R.Reduction.MEAN
+    l0, l1 = math.log1p(_circle_py(labels[0], scores[0])), math.log1p(_circle_py(labels[1], scores[1]))
+    T = torch.tensor
+    assert abs(R.CircleLoss().compute(T(labels), T(scores), None, red).item() - (l0 + l1) / 2) < 1e-5 * (l0 + l1)
+    assert abs(R.CircleLoss().compute(T(labels), T(scores), T([[1.], [2.]]), red).item() - (l0 + 2 * l1) / 3) < 1e-5 * (l0 + l1)
+    got = R.CircleLoss().compute(T(labels), T(scores), T([[1., 1., 2.], [1., 1., 1.]]), red)
+    assert abs(got.item() - (2 * l0 + l1) / 3) < 1e-5 * (l0 + l1)
+    labels2 = [[0., 0., 1.], [0., 0., 2.]]
+    want = (math.log1p(_circle_py(labels2[0], scores[0], 4., 0.1)) + math.log1p(_circle_py(labels2[1], scores[1], 4., 0.1))) / 2
+    assert abs(R.CircleLoss(gamma=4., margin=0.1).compute(T(labels2), T(scores), None, red).item() - want) < 1e-5
+    want = math.log1p(_circle_py([0., 1.], [.1, .2]))
+    assert abs(R.CircleLoss().compute(T([[0., -1., 1.]]), T([[.1, .3, .2]]), None, red).item() - want) < 1e-5 * want
+    want = (math.log1p(_circle_py([1., 0.], [.1, .2])) + math.log1p(_circle_py(labels2[1], scores[1]))) / 2
+    got = R.CircleLoss().compute(T([[1., 0., 0.], [0., 0., 2.]]), T(scores), None, red,
+                                 mask=T([[True, False, True], [True, True, True]]))
+    assert abs(got.item() - want) < 1e-5 * want
