@@ -95,6 +95,10 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
 #define TFR_METRIC_PRECISION 5
 #define TFR_METRIC_MAP 6
 #define TFR_METRIC_ARP 7
+#define TFR_METRIC_BPREF 8          /* :825-898 BPrefMetric, TREC version (denominator min(R, N)) */
+#define TFR_METRIC_BPREF_NONTREC 9  /*          use_trec_version=False (denominator R)            */
+#define TFR_METRIC_PWA 10           /* :901-965 PWAMetric (the caller supplies mean(weights) as the list weight) */
+#define TFR_METRIC_OPA 11           /* :708-743 OPAMetric: K = 1, stats_out[:, 2] = sum of pair weights     */
 int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                         int weights_per_list, const uint8_t* mask, const float* gains,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,

@@ -1144,6 +1144,73 @@ class MeanAveragePrecisionMetric(_RankingMetric):
         return per_list_map, w
 
 
+class OPAMetric(_RankingMetric):
+    """metrics_impl.py:708-743."""
+
+    def __init__(self, name=None, ragged=False):
+        super().__init__(ragged)
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        valid_pair = torch.logical_and(mask.unsqueeze(2), mask.unsqueeze(1))
+        pair_label_diff = labels.unsqueeze(2) - labels.unsqueeze(1)
+        pair_pred_diff = predictions.unsqueeze(2) - predictions.unsqueeze(1)
+        correct_pairs = (pair_label_diff > 0).to(torch.float32) * (pair_pred_diff > 0).to(torch.float32)
+        pair_weights = (pair_label_diff > 0).to(torch.float32) * weights.unsqueeze(2) * valid_pair.to(torch.float32)
+        per_list_weights = pair_weights.sum(dim=(1, 2)).unsqueeze(1)
+        per_list_opa = _safe_div((correct_pairs * pair_weights).sum(dim=(1, 2)).unsqueeze(1), per_list_weights)
+        return per_list_opa, per_list_weights
+
+
+class BPrefMetric(_RankingMetric):
+    """metrics_impl.py:825-898."""
+
+    def __init__(self, name=None, topn=None, use_trec_version=True, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+        self._use_trec_version = use_trec_version
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        relevance = (labels >= 1.0).to(torch.float32)
+        irrelevance = mask.to(torch.float32) - relevance
+        total_relevance = relevance.sum(dim=1, keepdim=True)
+        total_irrelevance = irrelevance.sum(dim=1, keepdim=True)
+        sorted_relevance, sorted_irrelevance = sort_by_scores(predictions, [relevance, irrelevance], mask=mask, topn=topn)
+        numerator = torch.minimum(torch.cumsum(sorted_irrelevance, dim=1), total_relevance)
+        denominator = torch.minimum(total_irrelevance, total_relevance) if self._use_trec_version else total_relevance
+        bpref = _safe_div(((1. - _safe_div(numerator, denominator)) * sorted_relevance).sum(dim=1, keepdim=True),
+                          total_relevance)
+        per_list_weights = _per_example_weights_to_per_list_weights(
+            weights=weights, relevance=(relevance >= 1.0).to(torch.float32))
+        return bpref, per_list_weights
+
+
+class PWAMetric(_RankingMetric):
+    """metrics_impl.py:901-965."""
+
+    def __init__(self, name=None, topn=5, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def compute(self, labels, predictions, weights=None, mask=None):
+        if weights is not None and not self._ragged:
+            w = torch.as_tensor(weights)
+            if w.dim() != 2 or w.shape[1] != 1:
+                raise ValueError('Weights should be a `Tensor` of the shape[batch_size, 1]')
+        return super().compute(labels, predictions, weights, mask)
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        sorted_labels, sorted_mask = sort_by_scores(predictions, [labels, mask], topn=topn, mask=mask)
+        sorted_list_size = sorted_labels.shape[1]
+        position_weights = 1.0 / torch.arange(1, sorted_list_size + 1).to(torch.float32)
+        masked_position_weights = sorted_mask.to(torch.float32) * position_weights
+        pwa = _safe_div((sorted_labels * masked_position_weights).sum(dim=1, keepdim=True),
+                        masked_position_weights.sum(dim=1, keepdim=True))
+        per_list_weights = weights.mean(dim=1, keepdim=True)
+        return pwa, per_list_weights
+
+
 class DCGMetric(_RankingMetric):
     """metrics_impl.py:673-705."""
 

@@ -151,6 +151,7 @@ def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns):
 
 
 METRIC_NDCG, METRIC_MRR, METRIC_DCG, METRIC_HITS, METRIC_RECALL, METRIC_PRECISION, METRIC_MAP, METRIC_ARP = range(8)
+METRIC_BPREF, METRIC_BPREF_NONTREC, METRIC_PWA, METRIC_OPA = 8, 9, 10, 11
 
 
 def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, discount=None):

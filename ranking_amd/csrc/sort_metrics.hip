@@ -345,7 +345,7 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
       m[r] = v0 && (w[r] > 0.0f);
       const float labc = m[r] ? lab : 0.0f;
       if (kind == TFR_METRIC_DCG) g[r] = gains ? gains[base + i] : gain_pow2m1(labc);
-      else if (kind == TFR_METRIC_ARP) g[r] = labc;
+      else if (kind == TFR_METRIC_ARP || kind == TFR_METRIC_PWA) g[r] = labc;
       else g[r] = (labc >= 1.0f) ? 1.0f : 0.0f;
       key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
     }
@@ -370,6 +370,40 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
     if (kind != TFR_METRIC_ARP) stats_out[(size_t)b * 3 + 2] = s_wg;
   }
   __syncthreads();
+
+  if (kind == TFR_METRIC_OPA) {
+    // OPAMetric (:708-743): sum over ordered pairs (i, j) of valid items with y_i > y_j of w_i, and of
+    // w_i [s_i > s_j].  Lanes own the items i and sweep j through LDS (label = +inf marks "not a valid j").
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int i = lane + 64 * r;
+      if (i < L) { G[i] = m[r] ? labels[base + i] : INFINITY; WG[i] = predictions[base + i]; }
+    }
+    __syncthreads();
+    float pw[IPL], cw[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int i = lane + 64 * r;
+      int np = 0, nc = 0;
+      if (m[r]) {
+        const float li = G[i], si = WG[i];
+        for (int j = 0; j < L; ++j) {
+          const bool gt = li > G[j];
+          np += gt ? 1 : 0;
+          nc += (gt && si > WG[j]) ? 1 : 0;
+        }
+      }
+      pw[r] = w[r] * (float)np;
+      cw[r] = w[r] * (float)nc;
+    }
+    const float tw = wave_tree_sum<IPL>(pw, P);
+    const float tc = wave_tree_sum<IPL>(cw, P);
+    if (lane == 0) {
+      stats_out[(size_t)b * 3 + 2] = tw;
+      metric_out[b] = (tw != 0.0f) ? tc / tw : 0.0f;
+    }
+    return;
+  }
 
   if (kind == TFR_METRIC_HITS) {
     uint64_t best = 0;
@@ -402,12 +436,13 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
     rel[r] = (p < L) ? G[idx] : 0.0f;
     wr[r] = (p < L) ? WG[idx] : 0.0f;
   }
-  float cum[IPL];                                            // inclusive prefix count of relevant items (MAP)
-  if (kind == TFR_METRIC_MAP) {
+  const bool bpref = (kind == TFR_METRIC_BPREF || kind == TFR_METRIC_BPREF_NONTREC);
+  float cum[IPL];                             // inclusive prefix count of relevant (MAP) / irrelevant (BPref) items
+  if (kind == TFR_METRIC_MAP || bpref) {
     float carry = 0.f;
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
-      float v = rel[r];
+      float v = bpref ? ((lane + 64 * r < nmask) ? 1.0f - rel[r] : 0.0f) : rel[r];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const float u = __shfl_up(v, o, 64);
@@ -434,12 +469,27 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
         if (kind == TFR_METRIC_DCG) v = wr[r] * discount[p];
         else if (kind == TFR_METRIC_MAP) v = (cum[r] / (float)(p + 1)) * wr[r];
         else if (kind == TFR_METRIC_ARP) v = (float)(p + 1) * wr[r];
+        else if (bpref) {                                    // (1 - min(#irrelevant above, R) / den) * rel   (:879-892)
+          const float num = fminf(cum[r], s_g);
+          const float den = (kind == TFR_METRIC_BPREF) ? fminf((float)nmask - s_g, s_g) : s_g;
+          v = (1.0f - ((den != 0.0f) ? num / den : 0.0f)) * rel[r];
+        } else if (kind == TFR_METRIC_PWA) v = (p < nmask) ? rel[r] * (1.0f / (float)(p + 1)) : 0.0f;   // (:946-961)
         else v = rel[r];                                     // recall / precision: count
       }
       t[r] = v;
     }
     const float total = wave_tree_sum<IPL>(t, P);
     float out = total;
+    if (bpref) out = (s_g != 0.0f) ? total / s_g : 0.0f;
+    if (kind == TFR_METRIC_PWA) {
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int p = lane + 64 * r;
+        t[r] = (p < k && p < nmask) ? 1.0f / (float)(p + 1) : 0.0f;
+      }
+      const float den = wave_tree_sum<IPL>(t, P);
+      out = (den != 0.0f) ? total / den : 0.0f;
+    }
     if (kind == TFR_METRIC_RECALL) out = (s_g != 0.0f) ? total / s_g : 0.0f;
     else if (kind == TFR_METRIC_PRECISION) { const int d = k < nmask ? k : nmask; out = d > 0 ? total / (float)d : 0.0f; }
     else if (kind == TFR_METRIC_MAP) out = (s_wg != 0.0f) ? total / s_wg : 0.0f;
@@ -597,7 +647,8 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
   if (kind == TFR_METRIC_NDCG || kind == TFR_METRIC_MRR)
     return launch_metric(kind, labels, predictions, weights, weights_per_list, mask, gains, discount, topn_host, K,
                          B, L, metric_out, stats_out, stream);
-  if (kind < TFR_METRIC_DCG || kind > TFR_METRIC_ARP) return TFR_EINVAL;
+  if (kind < TFR_METRIC_DCG || kind > TFR_METRIC_OPA) return TFR_EINVAL;
+  if (kind == TFR_METRIC_OPA && K != 1) return TFR_EINVAL;
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == TFR_METRIC_DCG && !discount) return TFR_EINVAL;

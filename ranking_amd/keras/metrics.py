@@ -37,7 +37,8 @@ def get(key: str, name: Optional[str] = None, dtype=None, topn: Optional[int] = 
     key_to_cls = {RankingMetricKey.MRR: MRRMetric, RankingMetricKey.NDCG: NDCGMetric,
                   RankingMetricKey.DCG: DCGMetric, RankingMetricKey.ARP: ARPMetric,
                   RankingMetricKey.PRECISION: PrecisionMetric, RankingMetricKey.MAP: MeanAveragePrecisionMetric,
-                  RankingMetricKey.HITS: HitsMetric, RankingMetricKey.RECALL: RecallMetric}
+                  RankingMetricKey.HITS: HitsMetric, RankingMetricKey.RECALL: RecallMetric,
+                  RankingMetricKey.ORDERED_PAIR_ACCURACY: OPAMetric}
     metric_kwargs = {'name': name, 'dtype': dtype}
     if topn:
         metric_kwargs.update({'topn': topn})
@@ -177,6 +178,15 @@ class ARPMetric(_RankingMetric):
     def __init__(self, name=None, dtype=None, ragged=False, **kwargs):
         super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
         self._metric = metrics_impl.ARPMetric(name=name, ragged=ragged)
+
+
+@utils.register_keras_serializable()
+class OPAMetric(_RankingMetric):
+    """keras/metrics.py:1013-1060."""
+
+    def __init__(self, name=None, dtype=None, ragged=False, **kwargs):
+        super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+        self._metric = metrics_impl.OPAMetric(name=name, ragged=ragged)
 
 
 @utils.register_keras_serializable()

@@ -28,6 +28,7 @@ class RankingMetricKey(object):
     ALPHA_DCG = 'alpha_dcg'
     BPREF = 'bpref'
     HITS = 'hits'
+    PWA = 'pwa'
 
 
 def _weighted_mean(values, weights):
@@ -61,7 +62,10 @@ def compute_mean(metric_key, labels, predictions, weights=None, topn=None, name=
            RankingMetricKey.PRECISION: metrics_impl.PrecisionMetric(name, topn),
            RankingMetricKey.RECALL: metrics_impl.RecallMetric(name, topn),
            RankingMetricKey.MAP: metrics_impl.MeanAveragePrecisionMetric(name, topn),
-           RankingMetricKey.HITS: metrics_impl.HitsMetric(name, topn)}
+           RankingMetricKey.HITS: metrics_impl.HitsMetric(name, topn),
+           RankingMetricKey.ORDERED_PAIR_ACCURACY: metrics_impl.OPAMetric(name),
+           RankingMetricKey.BPREF: metrics_impl.BPrefMetric(name, topn),
+           RankingMetricKey.PWA: metrics_impl.PWAMetric(metric_key, topn)}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     v, w = fns[metric_key].compute(labels, predictions, weights)
@@ -96,7 +100,11 @@ def make_ranking_metric_fn(metric_key, weights_feature_name=None, topn=None, nam
            RankingMetricKey.PRECISION: _generic(metrics_impl.PrecisionMetric(name, topn)),
            RankingMetricKey.RECALL: _generic(metrics_impl.RecallMetric(name, topn)),
            RankingMetricKey.MAP: _generic(metrics_impl.MeanAveragePrecisionMetric(name, topn)),
-           RankingMetricKey.HITS: _generic(metrics_impl.HitsMetric(name, topn))}
+           RankingMetricKey.HITS: _generic(metrics_impl.HitsMetric(name, topn)),
+           RankingMetricKey.ORDERED_PAIR_ACCURACY: _generic(metrics_impl.OPAMetric(name)),
+           RankingMetricKey.BPREF: _generic(metrics_impl.BPrefMetric(name, topn,
+                                                                     kwargs.get('use_trec_version', True))),
+           RankingMetricKey.PWA: _generic(metrics_impl.PWAMetric(name, topn))}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     return fns[metric_key]

@@ -199,6 +199,51 @@ class ARPMetric(_KindMetric):
         return out, stats[:, 2:3]
 
 
+class OPAMetric(_KindMetric):
+    """metrics_impl.py:708-743: ordered pair accuracy; the per-list weight is the sum of the pair weights."""
+    _KIND = _ops.METRIC_OPA
+
+    def __init__(self, name, ragged=False):
+        super().__init__(name, None, ragged=ragged)
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, [None])
+        return out, stats[:, 2:3]
+
+
+class BPrefMetric(_KindMetric):
+    """metrics_impl.py:825-898."""
+
+    def __init__(self, name, topn, use_trec_version=True, ragged=False):
+        super().__init__(name, topn, ragged=ragged)
+        self._use_trec_version = use_trec_version
+        self._KIND = _ops.METRIC_BPREF if use_trec_version else _ops.METRIC_BPREF_NONTREC
+
+
+class PWAMetric(_KindMetric):
+    """metrics_impl.py:901-965: weights must be per list ([batch_size, 1])."""
+    _KIND = _ops.METRIC_PWA
+
+    def __init__(self, name, topn=5, ragged=False):
+        super().__init__(name, topn, ragged=ragged)
+
+    def compute(self, labels, predictions, weights=None, mask=None):
+        if weights is not None and not utils.is_ragged(weights):
+            w = torch.as_tensor(weights)
+            if w.dim() != 2 or w.shape[1] != 1:
+                raise ValueError('Weights should be a `Tensor` of the shape[batch_size, 1]')
+        return super().compute(labels, predictions, weights, mask)
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, _ = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns)
+        b = labels.shape[0]
+        if weights is None:
+            w = torch.ones((b, 1), dtype=torch.float32, device=labels.device)
+        else:
+            w = torch.broadcast_to(weights, labels.shape).mean(dim=1, keepdim=True)
+        return out, w
+
+
 class DCGMetric(NDCGMetric):
     """metrics_impl.py:673-705."""
 

@@ -810,14 +810,34 @@ def test_more_metrics_bit_exact(B, L, weighted):
     got, got_w = mi.ARPMetric(None).compute(d(labels), d(preds), d(w))
     want, want_w = R.ARPMetric().compute(labels, preds, w)
     assert torch.equal(got.cpu(), want) and torch.equal(got_w.cpu(), want_w)
+    # BPref / PWA: same sort, scans and tree sums as the oracle -> 1e-6; OPA: integer pair counts, exact for
+    # unit weights, 1e-6 (float pair-weight sums) otherwise
+    for trec in (True, False):
+        got, got_w = mi.BPrefMetric(None, None, use_trec_version=trec).compute_multi(d(labels), d(preds), d(w), None, topns)
+        for q, k in enumerate(topns):
+            want, want_w = R.BPrefMetric(topn=k, use_trec_version=trec).compute(labels, preds, w)
+            assert_loss_close(got[q], want.reshape(-1), 1e-6, 'bpref@%s' % k)
+        assert_loss_close(got_w, want_w, 1e-6, 'bpref weights')
+    wl = None if w is None else w[:, :1].contiguous() + 0.5
+    got, got_w = mi.PWAMetric(None, None).compute_multi(d(labels), d(preds), d(wl), None, topns)
+    for q, k in enumerate(topns):
+        want, want_w = R.PWAMetric(topn=k).compute(labels, preds, wl)
+        assert_loss_close(got[q], want.reshape(-1), 1e-6, 'pwa@%s' % k)
+    assert_loss_close(got_w, want_w, 1e-6, 'pwa weights')
+    got, got_w = mi.OPAMetric(None).compute(d(labels), d(preds), d(w))
+    want, want_w = R.OPAMetric().compute(labels, preds, w)
+    if w is None:
+        assert torch.equal(got.cpu(), want) and torch.equal(got_w.cpu(), want_w)
+    else:
+        assert_loss_close(got, want, 1e-6, 'opa'); assert_loss_close(got_w / max(1., want_w.max().item()), want_w / max(1., want_w.max().item()), 1e-6, 'opa weights')
 
 
 def test_more_metrics_keras_and_factory_keys():
     km = ra().keras.metrics
     t = lambda x: torch.tensor(x, device=DEV)
     yt, yp = t([[0., 1., 0.], [1., 1., 0.]]), t([[3., 2., 1.], [3., 1., 2.]])
-    for key in ('dcg', 'arp', 'precision', 'recall', 'map', 'hits', 'ndcg', 'mrr'):
-        m = km.get(key, topn=2) if key != 'arp' else km.get(key)
+    for key in ('dcg', 'arp', 'precision', 'recall', 'map', 'hits', 'ndcg', 'mrr', 'ordered_pair_accuracy'):
+        m = km.get(key, topn=2) if key not in ('arp', 'ordered_pair_accuracy') else km.get(key)
         m.update_state(yt, yp)
         v = float(m.result())
         assert math.isfinite(v)
@@ -830,6 +850,12 @@ def test_more_metrics_keras_and_factory_keys():
     assert abs(float(m.result()) - 0.5) < 1e-6
     with pytest.raises(ValueError):
         km.get('alpha_dcg')
+    assert abs(float(km.OPAMetric()(t([[0., 1., 2.]]), t([[3., 1., 2.]]))) - 0.33333334) < 1e-6     # keras/metrics.py:1024-1028
+    assert abs(float(km.OPAMetric(ragged=True)([[0., 1.], [1., 2., 0.]], [t([2., 1.]), t([2., 5., 4.])])) - 0.5) < 1e-6
+    for key in ('bpref', 'pwa'):
+        assert math.isfinite(float(ra().metrics.make_ranking_metric_fn(key, topn=2)(yt, yp, {})))
+    with pytest.raises(ValueError):
+        ra().metrics_impl.PWAMetric(None).compute(yt, yp, t([[1., 2., 3.], [1., 1., 1.]]))       # metrics_impl_test.py:1699-1711
 
 
 # ------------------------------------------------------------------ ListMLE
