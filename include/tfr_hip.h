@@ -104,6 +104,19 @@ int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
                         float* metric_out, float* stats_out, void* stream);
 
+/* Diversity metrics on subtopic labels [B, L, S] (metrics_impl.py:313-426, :746-822).
+ *   TFR_DIV_ALPHA_DCG    AlphaDCGMetric: metric_out[q*B+b] = sum_{p<k} w gain discount, gain = sum_s y_ps (1-alpha)^{cum_s};
+ *                        discount[p] = rank_discount_fn(p + 1); the caller divides by the per-list weight
+ *   TFR_DIV_PRECISION_IA PrecisionIAMetric: the metric itself
+ * mask [B, L] or NULL (then an item is valid when any of its subtopic labels is >= 0); stats_out as above
+ * with relevance = any_s [y >= 1].  L <= 1024. */
+#define TFR_DIV_ALPHA_DCG 0
+#define TFR_DIV_PRECISION_IA 1
+int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
+                       int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
+                       const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
+                       float* stats_out, void* stream);
+
 /* metrics_impl.MRRMetric.compute (metrics_impl.py:429-459).
  *   mrr_out [K, B]; stats_out [B, 3] = (sum w, sum rel, sum w*rel), rel = 1{l>=1}. */
 int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,

@@ -1230,6 +1230,85 @@ class DCGMetric(_RankingMetric):
         return _safe_div(dcg, per_list_weights), per_list_weights
 
 
+def _alpha_dcg_gain_fn(labels, alpha):
+    """metrics_impl.py:36-60."""
+    cum_subtopics = torch.cumsum(labels, dim=1) - labels          # tf.cumsum(exclusive=True)
+    return (labels * torch.pow(torch.tensor(1 - alpha, dtype=labels.dtype), cum_subtopics)).sum(dim=-1)
+
+
+class _DivRankingMetric(_RankingMetric):
+    """metrics_impl.py:313-426."""
+
+    def __init__(self, name=None, topn=None, ragged=False):
+        super().__init__(ragged)
+        self._topn = topn
+
+    def compute(self, labels, predictions, weights=None, mask=None):
+        if self._ragged:
+            n_sub = max((len(r[0]) for r in labels if len(r)), default=1)
+            _, predictions, weights, mask = ragged_to_dense([[0.] * len(r) for r in predictions], predictions, weights)
+            dense = torch.full((len(labels), predictions.shape[1], n_sub), -1.0)
+            for i, r in enumerate(labels):
+                if len(r):
+                    dense[i, :len(r)] = torch.as_tensor(r, dtype=torch.float32)
+            labels = dense
+        labels, predictions, weights, mask = self._prepare_and_validate_params(labels, predictions, weights, mask)
+        return self._compute_impl(labels, predictions, weights, mask)
+
+    def _prepare_and_validate_params(self, labels, predictions, weights, mask):
+        labels = _t(labels)
+        predictions = _t(predictions)
+        assert labels.dim() == 3
+        if mask is None:
+            mask = is_label_valid(labels)
+        mask = _t(mask, torch.bool)
+        if mask.dim() == 3:
+            mask = mask.any(dim=2)
+        predictions = torch.where(mask, predictions,
+                                  -1e-6 * torch.ones_like(predictions) + predictions.min(dim=1, keepdim=True).values)
+        labels = torch.where(mask.unsqueeze(2), labels, torch.zeros_like(labels))
+        weights = torch.tensor(1.0) if weights is None else _t(weights)
+        example_weights = torch.ones_like(predictions) * weights
+        return labels, predictions, example_weights, mask
+
+    def _compute_per_list_weights(self, weights, labels):
+        return _per_example_weights_to_per_list_weights(weights, (labels >= 1.0).any(dim=-1).to(torch.float32),
+                                                        row_sum=tree_sum)
+
+    def _compute_impl(self, labels, predictions, weights, mask):
+        topn = predictions.shape[1] if self._topn is None else self._topn
+        per_list_metric = self._compute_per_list_metric(labels, predictions, weights, topn, mask)
+        return per_list_metric, self._compute_per_list_weights(weights, labels)
+
+
+class PrecisionIAMetric(_DivRankingMetric):
+    """metrics_impl.py:746-782."""
+
+    def _compute_per_list_metric(self, labels, predictions, weights, topn, mask):
+        sorted_labels = sort_by_scores(predictions, [labels], topn=topn, mask=mask)[0]
+        relevance = (sorted_labels >= 1.0).to(torch.float32).sum(dim=-1)
+        num_subtopics = (labels >= 1.0).any(dim=1, keepdim=True).to(torch.float32).sum(dim=-1)
+        valid_topn = torch.clamp(mask.to(torch.int32).sum(dim=1, keepdim=True), max=topn)
+        return _safe_div(relevance.sum(dim=1, keepdim=True),
+                         (valid_topn.to(torch.float32) * num_subtopics).sum(dim=1, keepdim=True))
+
+
+class AlphaDCGMetric(_DivRankingMetric):
+    """metrics_impl.py:785-822."""
+
+    def __init__(self, name=None, topn=None, alpha=0.5, rank_discount_fn=log2_inverse, seed=None, ragged=False):
+        super().__init__(name, topn, ragged)
+        self._alpha = alpha
+        self._rank_discount_fn = rank_discount_fn
+
+    def _compute_per_list_metric(self, labels, predictions, weights, topn, mask):
+        sorted_labels, sorted_weights = sort_by_scores(predictions, [labels, weights], topn=topn, mask=mask)
+        alpha_dcg = _discounted_cumulative_gain(sorted_labels, sorted_weights,
+                                                lambda l: _alpha_dcg_gain_fn(l, self._alpha), self._rank_discount_fn,
+                                                row_sum=tree_sum, full_list_size=predictions.shape[1])
+        return _safe_div(alpha_dcg, self._compute_per_list_weights(weights, labels))
+
+
 def keras_metric_mean(metric, batches):
     """keras/metrics.py:156-193: running weighted mean over update_state calls.
     ``batches`` = iterable of (y_true, y_pred, sample_weight)."""

@@ -171,6 +171,29 @@ def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, dis
     return out, stats
 
 
+DIV_ALPHA_DCG, DIV_PRECISION_IA = 0, 1
+
+
+def div_metric(kind, labels, predictions, weights, mask, topns, discount=None, alpha=0.5):
+    """tfr_div_metric_f32: ([K, B] metric, [B, 3] stats) on subtopic labels [B, L, S]."""
+    labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
+    _check2d(predictions, 'predictions')
+    if labels.dim() != 3 or tuple(labels.shape[:2]) != tuple(predictions.shape):
+        raise ValueError('labels %s must be [batch_size, list_size, subtopic_size] matching predictions %s'
+                         % (tuple(labels.shape), tuple(predictions.shape)))
+    w, per_list = _weights_arg(weights, predictions)
+    mask = _u8(mask, 'mask'); discount = _f32(discount, 'discount')
+    B, L, S = labels.shape
+    K = len(topns)
+    out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
+    stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    rc = _lib.load().tfr_div_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
+                                        _ptr(discount), float(alpha), _topn_array(topns), K, B, L, S,
+                                        _ptr(out), _ptr(stats), _stream())
+    _lib.check(rc, 'tfr_div_metric_f32')
+    return out, stats
+
+
 def mrr_metric(labels, predictions, weights, mask, topns):
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')

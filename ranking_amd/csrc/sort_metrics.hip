@@ -498,6 +498,122 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
   }
 }
 
+// Diversity metrics on [B, L, S] subtopic labels (metrics_impl.py:313-426 _DivRankingMetric, :36-59
+// _alpha_dcg_gain_fn, :785-822 AlphaDCGMetric, :746-782 PrecisionIAMetric).  One wavefront per list:
+// sort by prediction (valid first), then one exclusive scan per subtopic along the ranking.
+//   TFR_DIV_ALPHA_DCG   : metric_out = sum_{p<k} w_p * (sum_s y_ps (1 - alpha)^{#covered_s before p}) * discount[p]
+//                         (the caller divides by the per-list weight, like TFR_METRIC_DCG)
+//   TFR_DIV_PRECISION_IA: metric_out = sum_{p<k} sum_s [y_ps >= 1] / (min(k, #valid) * #subtopics with a relevant item)
+// stats_out[b] = (sum w, sum rel, sum w*rel) with rel_i = any_s [y_is >= 1]: the per-list weight statistics.
+template <int IPL>
+__global__ __launch_bounds__(64) void div_metric_wave_kernel(
+    int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
+    const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
+    const float* __restrict__ discount, float alpha, TopN topn, int B, int L, int S, int P,
+    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  float w[IPL], g[IPL];
+  bool m[IPL];
+  uint64_t key[IPL];
+  int nmask = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    w[r] = 0.f; g[r] = 0.f; m[r] = false; key[r] = 0;
+    if (i < L) {
+      const float* lab = labels + (base + i) * (size_t)S;
+      w[r] = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      bool any_valid = false, any_rel = false;
+      for (int t = 0; t < S; ++t) { const float y = lab[t]; any_valid |= (y >= 0.0f); any_rel |= (y >= 1.0f); }
+      m[r] = mask ? (mask[base + i] != 0) : any_valid;        // :354-358 (a rank-3 mask is reduced by the caller)
+      g[r] = (m[r] && any_rel) ? 1.0f : 0.0f;
+      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+    }
+    nmask += __popcll(__ballot(m[r]));
+  }
+  float t[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = w[r];
+  const float s_w = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = g[r];
+  const float s_g = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) t[r] = w[r] * g[r];
+  const float s_wg = wave_tree_sum<IPL>(t, P);
+  if (lane == 0) {
+    stats_out[(size_t)b * 3 + 0] = s_w;
+    stats_out[(size_t)b * 3 + 1] = s_g;
+    stats_out[(size_t)b * 3 + 2] = s_wg;
+  }
+
+  wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+  int idx[IPL];
+  float ws[IPL], val[IPL];
+  bool ms[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int p = lane + 64 * r;
+    idx[r] = sort_key_index(key[r]);
+    ms[r] = p < nmask;                                        // valid-first order
+    ws[r] = (p < L) ? (weights ? (weights_per_list ? wl : weights[base + idx[r]]) : 1.0f) : 0.0f;
+    val[r] = 0.f;
+  }
+  float n_sub = 0.f;
+  const float one_m_alpha = 1.0f - alpha;
+  for (int st = 0; st < S; ++st) {
+    float y[IPL];
+    bool any = false;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      y[r] = (p < L && ms[r]) ? labels[(base + idx[r]) * (size_t)S + st] : 0.0f;
+      any |= (y[r] >= 1.0f);
+    }
+    if (kind == TFR_DIV_PRECISION_IA) {
+      n_sub += (__ballot(any) != 0ull) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) val[r] += (y[r] >= 1.0f) ? 1.0f : 0.0f;
+    } else {
+      float carry = 0.f;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        float v = y[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const float u = __shfl_up(v, o, 64);
+          if (lane >= o) v += u;
+        }
+        float ex = __shfl_up(v, 1, 64);
+        if (lane == 0) ex = 0.0f;
+        const float cum = ex + carry;                          // tf.cumsum(exclusive=True) along the ranking
+        carry += __shfl(v, 63, 64);
+        val[r] += y[r] * powf(one_m_alpha, cum);
+      }
+    }
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      float v = 0.f;
+      if (p < k) v = (kind == TFR_DIV_PRECISION_IA) ? val[r] : (ws[r] * val[r]) * discount[p];
+      t[r] = v;
+    }
+    const float total = wave_tree_sum<IPL>(t, P);
+    float out = total;
+    if (kind == TFR_DIV_PRECISION_IA) {
+      const float den = (float)(k < nmask ? k : nmask) * n_sub;
+      out = (den != 0.0f) ? total / den : 0.0f;
+    }
+    if (lane == 0) metric_out[(size_t)q * B + b] = out;
+  }
+}
+
 template <int KIND, int IPL>
 void launch_metric_wave(const float* labels, const float* predictions, const float* weights, int weights_per_list,
                         const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
@@ -661,6 +777,26 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
 #define M2(I) hipLaunchKernelGGL(rank_metric2_wave_kernel<I>, dim3(B), dim3(64), (size_t)2 * 64 * I * sizeof(float), st, kind, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out)
   if (L <= 64) M2(1); else if (L <= 128) M2(2); else if (L <= 256) M2(4); else if (L <= 512) M2(8); else M2(16);
 #undef M2
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
+                                  int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
+                                  const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
+                                  float* stats_out, void* stream) {
+  if (kind != TFR_DIV_ALPHA_DCG && kind != TFR_DIV_PRECISION_IA) return TFR_EINVAL;
+  if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0 || S <= 0) return TFR_EINVAL;
+  if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
+  if (kind == TFR_DIV_ALPHA_DCG && !discount) return TFR_EINVAL;
+  if (L > 1024) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  TopN tn; tn.n = K;
+  for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
+  const int P = pow2_ceil(L < 2 ? 2 : L);
+  hipStream_t st = (hipStream_t)stream;
+#define DM(I) hipLaunchKernelGGL(div_metric_wave_kernel<I>, dim3(B), dim3(64), 0, st, kind, labels, predictions, weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out)
+  if (L <= 64) DM(1); else if (L <= 128) DM(2); else if (L <= 256) DM(4); else if (L <= 512) DM(8); else DM(16);
+#undef DM
   return (int)hipGetLastError();
 }
 

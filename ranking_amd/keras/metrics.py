@@ -26,6 +26,7 @@ class RankingMetricKey(object):
     MAP = 'map'
     ORDERED_PAIR_ACCURACY = 'ordered_pair_accuracy'
     ALPHA_DCG = 'alpha_dcg'
+    PRECISION_IA = 'precision_ia'
     HITS = 'hits'
     RECALL = 'recall'
 
@@ -38,7 +39,8 @@ def get(key: str, name: Optional[str] = None, dtype=None, topn: Optional[int] = 
                   RankingMetricKey.DCG: DCGMetric, RankingMetricKey.ARP: ARPMetric,
                   RankingMetricKey.PRECISION: PrecisionMetric, RankingMetricKey.MAP: MeanAveragePrecisionMetric,
                   RankingMetricKey.HITS: HitsMetric, RankingMetricKey.RECALL: RecallMetric,
-                  RankingMetricKey.ORDERED_PAIR_ACCURACY: OPAMetric}
+                  RankingMetricKey.ORDERED_PAIR_ACCURACY: OPAMetric, RankingMetricKey.ALPHA_DCG: AlphaDCGMetric,
+                  RankingMetricKey.PRECISION_IA: PrecisionIAMetric}
     metric_kwargs = {'name': name, 'dtype': dtype}
     if topn:
         metric_kwargs.update({'topn': topn})
@@ -178,6 +180,31 @@ class ARPMetric(_RankingMetric):
     def __init__(self, name=None, dtype=None, ragged=False, **kwargs):
         super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
         self._metric = metrics_impl.ARPMetric(name=name, ragged=ragged)
+
+
+PrecisionIAMetric = utils.register_keras_serializable()(type('PrecisionIAMetric', (_topn_metric(
+    metrics_impl.PrecisionIAMetric, 'keras/metrics.py:534-626 (y_true: [batch, list, subtopic]).'),), {}))
+
+
+@utils.register_keras_serializable()
+class AlphaDCGMetric(_RankingMetric):
+    """keras/metrics.py:886-1010 (y_true: [batch, list, subtopic])."""
+
+    def __init__(self, name='alpha_dcg_metric', topn=None, alpha=0.5, rank_discount_fn=None, seed=None, dtype=None,
+                 ragged=False, **kwargs):
+        super().__init__(name=name, dtype=dtype, ragged=ragged, **kwargs)
+        self._topn = topn
+        self._alpha = alpha
+        self._rank_discount_fn = rank_discount_fn or utils.log2_inverse
+        self._seed = seed
+        self._metric = metrics_impl.AlphaDCGMetric(name=name, topn=topn, alpha=alpha,
+                                                   rank_discount_fn=self._rank_discount_fn, seed=seed, ragged=ragged)
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'topn': self._topn, 'alpha': self._alpha, 'rank_discount_fn': self._rank_discount_fn,
+                       'seed': self._seed})
+        return config
 
 
 @utils.register_keras_serializable()

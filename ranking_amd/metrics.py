@@ -65,7 +65,9 @@ def compute_mean(metric_key, labels, predictions, weights=None, topn=None, name=
            RankingMetricKey.HITS: metrics_impl.HitsMetric(name, topn),
            RankingMetricKey.ORDERED_PAIR_ACCURACY: metrics_impl.OPAMetric(name),
            RankingMetricKey.BPREF: metrics_impl.BPrefMetric(name, topn),
-           RankingMetricKey.PWA: metrics_impl.PWAMetric(metric_key, topn)}
+           RankingMetricKey.PWA: metrics_impl.PWAMetric(metric_key, topn),
+           RankingMetricKey.PRECISION_IA: metrics_impl.PrecisionIAMetric(name, topn),
+           RankingMetricKey.ALPHA_DCG: metrics_impl.AlphaDCGMetric(name, topn)}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     v, w = fns[metric_key].compute(labels, predictions, weights)
@@ -104,7 +106,11 @@ def make_ranking_metric_fn(metric_key, weights_feature_name=None, topn=None, nam
            RankingMetricKey.ORDERED_PAIR_ACCURACY: _generic(metrics_impl.OPAMetric(name)),
            RankingMetricKey.BPREF: _generic(metrics_impl.BPrefMetric(name, topn,
                                                                      kwargs.get('use_trec_version', True))),
-           RankingMetricKey.PWA: _generic(metrics_impl.PWAMetric(name, topn))}
+           RankingMetricKey.PWA: _generic(metrics_impl.PWAMetric(name, topn)),
+           RankingMetricKey.PRECISION_IA: _generic(metrics_impl.PrecisionIAMetric(name, topn)),
+           RankingMetricKey.ALPHA_DCG: _generic(metrics_impl.AlphaDCGMetric(
+               name, topn, alpha=kwargs.get('alpha', 0.5), rank_discount_fn=rank_discount_fn,
+               seed=kwargs.get('seed')))}
     if metric_key not in fns:
         raise ValueError('Invalid metric_key: {}'.format(metric_key))
     return fns[metric_key]

@@ -244,6 +244,72 @@ class PWAMetric(_KindMetric):
         return out, w
 
 
+class _DivRankingMetric(_RankingMetric):
+    """metrics_impl.py:313-426: diversity metrics on subtopic labels [batch_size, list_size, subtopic_size],
+    served by ``tfr_div_metric_f32`` (csrc/sort_metrics.hip)."""
+    _KIND = None
+
+    def __init__(self, name, topn=None, ragged=False):
+        super().__init__(ragged=ragged)
+        self._name = name
+        self._topn = topn
+
+    @property
+    def name(self):
+        return self._name
+
+    def _prepare(self, labels, predictions, weights, mask):
+        if self._ragged and utils.is_ragged(predictions):
+            # ragged [B, (L), S]: pad the list dimension with -1 labels / -1e6 scores (utils.py:421-443)
+            n_sub = max((len(r[0]) for r in labels if len(r)), default=1)
+            dev = next((r.device for r in predictions if torch.is_tensor(r)), None)
+            _, predictions, weights, mask = utils.ragged_to_dense([[0.] * len(r) for r in predictions], predictions,
+                                                                  weights, device=dev)
+            dense = torch.full((len(labels), predictions.shape[1], n_sub), -1.0, dtype=torch.float32,
+                               device=predictions.device)
+            for i, r in enumerate(labels):
+                if len(r):
+                    dense[i, :len(r)] = torch.as_tensor(r, dtype=torch.float32, device=predictions.device)
+            labels = dense
+        predictions = _ops.require_device(torch.as_tensor(predictions), 'predictions').to(torch.float32)
+        labels = torch.as_tensor(labels, dtype=torch.float32, device=predictions.device)
+        if predictions.dim() != 2 or labels.dim() != 3 or tuple(labels.shape[:2]) != tuple(predictions.shape):
+            raise ValueError('labels must be [batch_size, list_size, subtopic_size], predictions [batch_size, '
+                             'list_size]; got %s and %s' % (tuple(labels.shape), tuple(predictions.shape)))
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float32, device=predictions.device)
+        if mask is not None:
+            mask = torch.as_tensor(mask, device=predictions.device).to(torch.bool)
+            if mask.dim() == 3:
+                mask = mask.any(dim=2)                      # :356-357
+        return labels, predictions, weights, mask
+
+
+class PrecisionIAMetric(_DivRankingMetric):
+    """metrics_impl.py:746-782."""
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        out, stats = _ops.div_metric(_ops.DIV_PRECISION_IA, labels, predictions, weights, mask, topns)
+        return out, per_list_weights_from_stats(stats)
+
+
+class AlphaDCGMetric(_DivRankingMetric):
+    """metrics_impl.py:785-822 (``seed`` only shuffles ties in the reference; ties keep index order here)."""
+
+    def __init__(self, name, topn, alpha=0.5, rank_discount_fn=_DEFAULT_RANK_DISCOUNT_FN, seed=None, ragged=False):
+        super().__init__(name, topn, ragged=ragged)
+        self._alpha = alpha
+        self._rank_discount_fn = rank_discount_fn
+        self._seed = seed
+
+    def _compute_multi(self, labels, predictions, weights, mask, topns):
+        discount = _ops.rank_table(self._rank_discount_fn, predictions.shape[1], predictions.device)
+        out, stats = _ops.div_metric(_ops.DIV_ALPHA_DCG, labels, predictions, weights, mask, topns, discount,
+                                     self._alpha)
+        plw = per_list_weights_from_stats(stats)
+        return _safe_div(out, plw.reshape(1, -1)), plw
+
+
 class DCGMetric(NDCGMetric):
     """metrics_impl.py:673-705."""
 

@@ -849,7 +849,7 @@ def test_more_metrics_keras_and_factory_keys():
     m = km.PrecisionMetric(topn=2); m.update_state(t([[0., 1., 1.]]), t([[3., 1., 2.]]))
     assert abs(float(m.result()) - 0.5) < 1e-6
     with pytest.raises(ValueError):
-        km.get('alpha_dcg')
+        km.get('no_such_metric')
     assert abs(float(km.OPAMetric()(t([[0., 1., 2.]]), t([[3., 1., 2.]]))) - 0.33333334) < 1e-6     # keras/metrics.py:1024-1028
     assert abs(float(km.OPAMetric(ragged=True)([[0., 1.], [1., 2., 0.]], [t([2., 1.]), t([2., 5., 4.])])) - 0.5) < 1e-6
     for key in ('bpref', 'pwa'):
@@ -1144,3 +1144,52 @@ def test_circle_loss_reference_goldens():
     # scores near 1 with gamma = 64: exp(gamma (a + b)) leaves fp32 range in the reference; the log-domain kernel stays finite
     loss, w, d = __import__('ranking_amd')._ops.circle_loss(t([[0.0, 1.0, 0.5]]), t([[1., 0., 0.]]), None, None, 64., 0.25)
     assert torch.isfinite(loss).all() and torch.isfinite(d).all() and loss.item() > 88.
+
+
+# ------------------------------------------------------------------ diversity metrics
+@pytest.mark.parametrize('B,L,S', [(1, 1, 1), (3, 2, 2), (5, 50, 3), (6, 65, 5), (4, 200, 4), (2, 1000, 2), (1030, 30, 3)])
+@pytest.mark.parametrize('weighted', [False, True])
+def test_diversity_metrics_parity(B, L, S, weighted):
+    g = torch.Generator().manual_seed(1900 + L)
+    preds = torch.randn(B, L, generator=g)
+    labels = (torch.rand(B, L, S, generator=g) < 0.3).float()
+    n_valid = torch.randint(1, L + 1, (B,), generator=g)
+    labels[torch.arange(L).unsqueeze(0) >= n_valid.unsqueeze(1)] = -1.0          # padded items: every subtopic -1
+    w = make_weights(B, L, seed=L + 3) if weighted else None
+    mi = ra().metrics_impl
+    d = lambda x: None if x is None else x.to(DEV)
+    topns = [1, 3, 10, None]
+    for alpha in (0.5, 0.3):
+        got, got_w = mi.AlphaDCGMetric(None, None, alpha=alpha).compute_multi(d(labels), d(preds), d(w), None, topns)
+        for q, k in enumerate(topns):
+            want, want_w = R.AlphaDCGMetric(topn=k, alpha=alpha).compute(labels, preds, w)
+            assert_loss_close(got[q], want.reshape(-1), 2e-6, 'alpha_dcg@%s' % k)
+        assert_loss_close(got_w, want_w, 1e-6, 'alpha_dcg weights')
+    got, got_w = mi.PrecisionIAMetric(None, None).compute_multi(d(labels), d(preds), d(w), None, topns)
+    for q, k in enumerate(topns):
+        want, want_w = R.PrecisionIAMetric(topn=k).compute(labels, preds, w)
+        assert_loss_close(got[q], want.reshape(-1), 1e-6, 'precision_ia@%s' % k)
+    assert_loss_close(got_w, want_w, 1e-6, 'precision_ia weights')
+
+
+def test_diversity_metrics_ragged_and_keras():
+    from tests.metric_cases import log2p1
+    mi, km = ra().metrics_impl, ra().keras.metrics
+    t = lambda x: torch.tensor(x, device=DEV)
+    scores = [t([1., 3., 4., 2.]), t([1., 3., 2.])]
+    labels = [[[0., 0.], [1., 0.], [1., 1.], [0., 1.]], [[0., 0.], [1., 0.], [0., 1.]]]
+    out, _ = mi.PrecisionIAMetric(None, None, ragged=True).compute(labels, scores)            # metrics_impl_test.py:1163-1176
+    assert_loss_close(out, torch.tensor([[1. / 2.], [2. / 6.]]), 1e-6)
+    scores = [t([1., 3., 2., 4.]), t([1., 3., 2.])]
+    labels = [[[1., 0.], [1., 1.], [0., 1.], [1., 0.]], [[0., 0.], [1., 0.], [0., 1.]]]
+    out, _ = mi.AlphaDCGMetric(None, None, ragged=True).compute(labels, scores)               # :1316-1332
+    assert_loss_close(out, torch.tensor([[1. / log2p1(1.) + 1. / log2p1(2.) + 0.5 / log2p1(2.) + 0.5 / log2p1(3.) + 0.25 / log2p1(4.)],
+                                         [1. / log2p1(1.) + 1. / log2p1(2.)]]), 1e-6)
+    yt, yp = t([[[0., 0.], [1., 0.], [0., 1.]]]), t([[1., 3., 2.]])
+    m = km.get('alpha_dcg', topn=2); m.update_state(yt, yp)
+    assert abs(float(m.result()) - (1. / log2p1(1.) + 1. / log2p1(2.))) < 1e-6
+    m = km.get('precision_ia'); m.update_state(yt, yp)
+    assert abs(float(m.result()) - 2. / 6.) < 1e-6
+    assert type(m).from_config(m.get_config()) is not None
+    for key in ('alpha_dcg', 'precision_ia'):
+        assert math.isfinite(float(ra().metrics.make_ranking_metric_fn(key, topn=2)(yt, yp, {})))

@@ -772,3 +772,17 @@ def test_circle_loss_reference_literals():
     got = R.CircleLoss().compute(T([[1., 0., 0.], [0., 0., 2.]]), T(scores), None, red,
                                  mask=T([[True, False, True], [True, True, True]]))
     assert abs(got.item() - want) < 1e-5 * want
+
+
+def test_diversity_metrics_ragged_reference_literals():
+    """metrics_impl_test.py:1163-1176, 1316-1332."""
+    from tests.metric_cases import log2p1
+    scores = [[1., 3., 4., 2.], [1., 3., 2.]]
+    labels = [[[0., 0.], [1., 0.], [1., 1.], [0., 1.]], [[0., 0.], [1., 0.], [0., 1.]]]
+    out, _ = R.PrecisionIAMetric(topn=None, ragged=True).compute(labels, scores)
+    close(out, [[1. / 2.], [2. / (2. * 3.)]], 1e-6)
+    scores = [[1., 3., 2., 4.], [1., 3., 2.]]
+    labels = [[[1., 0.], [1., 1.], [0., 1.], [1., 0.]], [[0., 0.], [1., 0.], [0., 1.]]]
+    out, _ = R.AlphaDCGMetric(topn=None, ragged=True).compute(labels, scores)
+    close(out, [[1. / log2p1(1.) + 1. / log2p1(2.) + 0.5 / log2p1(2.) + 0.5 / log2p1(3.) + 0.25 / log2p1(4.)],
+                [1. / log2p1(1.) + 1. / log2p1(2.)]], 1e-6)
