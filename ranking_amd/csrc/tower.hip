@@ -55,6 +55,13 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {     // RNE (v_
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
 }
 
+// 16-byte global -> LDS copy without VGPR staging (global_load_lds_dwordx4): the LDS destination is the
+// wave-uniform `lds_wave_base` + 16 * lane, the global source is per lane.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 // Dropout (keras/layers.py:72-73: tf.keras.layers.Dropout after every hidden activation).  The
 // keep mask is a counter-based hash of (layer seed, row, column pair) -- the same function in the
 // forward prologues and in the backward kernels, so nothing is stored.  threshold16 = rate * 65536;
@@ -129,7 +136,11 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr int WPITCH = 144;                      // bytes per row of a wave's 64 x 64 bf16 epilogue tile (128 + 16 pad)
 
 // C[M, N] = pro(A)[M, K] . B[N, K]^T (+ bias), bf16 out.
-template <int PRO, int EPI>
+// GL (K % 64 == 0): the weight tile goes global -> LDS by LDS-DMA (no VGPR staging, no ds_write_b128 pass --
+// the slowest LDS instruction, 79 B/clk/CU, was half of this kernel's LDS time); with PRO_NONE (dgrad, layer 1)
+// the activation tile does too.  The XOR swizzle is applied on the SOURCE address (the LDS image of an
+// LDS-DMA is lane-linear).
+template <int PRO, int EPI, bool GL>
 __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [buf][A tile | B tile], then the per-column prologue coefficients.
@@ -174,9 +185,8 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       R.b[i] = (kin && bn < g.N) ? *reinterpret_cast<const uint4*>(g.B + bn * g.ldb + k) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto store_tile = [&](int kt, int buf, const RegsA& RA, const RegsB& RB) {
+  auto store_a = [&](int kt, int buf, const RegsA& RA) {
     unsigned char* ta = tiles + buf * 2 * TILE_BYTES;
-    unsigned char* tb = ta + TILE_BYTES;
     const int k = kt * BK + c * 8;
     float sc[8], sh[8];
     if (PRO != PRO_NONE) {
@@ -190,7 +200,37 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
       if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
+    }
+  };
+  auto store_tile = [&](int kt, int buf, const RegsA& RA, const RegsB& RB) {
+    unsigned char* ta = tiles + buf * 2 * TILE_BYTES;
+    unsigned char* tb = ta + TILE_BYTES;
+    const int k = kt * BK + c * 8;
+    float sc[8], sh[8];
+    if (PRO != PRO_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = s_scale[k + e]; sh[e] = s_shift[k + e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 32 * i;
+      uint4 va = RA.a[i];
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
+      *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
       *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
+    }
+  };
+  // LDS-DMA of a [128][64] bf16 tile (GL): wave w copies rows [32 w + 8 i, + 8), i < 4, one KiB per instruction;
+  // lane -> (row, physical 16-byte slot); the slot holds logical chunk slot ^ ((row >> 1) & 7) (= swz()).
+  // Rows past `nrows` are clamped to the last one: they only reach output rows / columns that are never stored.
+  auto glds_tile = [&](const uint16_t* G, long ld, long row0, long nrows, int kt, unsigned char* tdst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = wave * 32 + i * 8 + (lane >> 3);
+      const int cl = (lane & 7) ^ ((rl >> 1) & 7);
+      long gr = row0 + rl;
+      gr = gr < nrows ? gr : nrows - 1;
+      glds16(G + gr * ld + kt * BK + cl * 8, tdst + (wave * 32 + i * 8) * 128);
     }
   };
 
@@ -220,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     }
   };
 
+  if constexpr (!GL) {
   // A (streamed from HBM) is requested two tiles ahead in two register sets, B (the weights,
   // L2 resident) one tile ahead: an A load has two compute phases to land.
   RegsA A0, A1;
@@ -249,6 +290,50 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     compute(1);
     if (kt + 2 < nk) store_tile(kt + 2, 0, A0, Bx);
     __syncthreads();
+  }
+  } else {
+  // LDS-DMA pipeline, two LDS buffers: the DMA of tile kt + 1 is issued right after the barrier that
+  // retired the reads of its buffer, lands during compute(kt), and is retired by the vmcnt(0) that
+  // __syncthreads() carries.  PRO != NONE keeps the activation tile on the register path (it needs the
+  // BatchNorm / ReLU / Dropout transform), two tiles ahead as before.
+  constexpr bool GLA = (PRO == PRO_NONE);
+  unsigned char* const tA0 = tiles;
+  unsigned char* const tB0 = tiles + TILE_BYTES;
+  unsigned char* const tA1 = tiles + 2 * TILE_BYTES;
+  unsigned char* const tB1 = tiles + 3 * TILE_BYTES;
+  RegsA A0, A1;
+  if (!GLA) { load_a(0, A0); if (nk > 1) load_a(1, A1); }
+  glds_tile(g.B, g.ldb, n0, g.N, 0, tB0);
+  if (GLA) glds_tile(g.A, g.lda, m0, g.M, 0, tA0);
+  if (PRO != PRO_NONE) {
+    for (int k = tid; k < nk * BK; k += 256) {
+      s_scale[k] = (k < g.K) ? g.a_scale[k] : 0.f;
+      s_shift[k] = (k < g.K) ? g.a_shift[k] : 0.f;
+    }
+    __syncthreads();
+  }
+  if (!GLA) store_a(0, 0, A0);
+  __syncthreads();
+  if (g.ablate & 16) ts1 = __builtin_amdgcn_s_memtime();
+  for (int kt = 0; kt < nk; kt += 2) {
+    if (kt + 1 < nk) {
+      glds_tile(g.B, g.ldb, n0, g.N, kt + 1, tB1);
+      if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 1, tA1);
+    }
+    if (!GLA && kt + 2 < nk) load_a(kt + 2, A0);
+    compute(0);
+    if (!GLA && kt + 1 < nk) store_a(kt + 1, 1, A1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    if (kt + 2 < nk) {
+      glds_tile(g.B, g.ldb, n0, g.N, kt + 2, tB0);
+      if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 2, tA0);
+    }
+    if (!GLA && kt + 3 < nk) load_a(kt + 3, A1);
+    compute(1);
+    if (!GLA && kt + 2 < nk) store_a(kt + 2, 0, A0);
+    __syncthreads();
+  }
   }
   if (g.ablate & 16) ts2 = __builtin_amdgcn_s_memtime();
 
@@ -776,11 +861,11 @@ int grid_for(long work_items, int block) {
   return (int)g;
 }
 
-template <int PRO, int EPI>
-int launch_gemm(const GemmArgs& g, hipStream_t st) {
+template <int PRO, int EPI, bool GL>
+int launch_gemm_v(const GemmArgs& g, hipStream_t st) {
   const int kpad = (g.K + 63) & ~63;
   const size_t lds = 4 * TILE_BYTES + 2 * (size_t)kpad * sizeof(float);
-  auto fn = tower_gemm_kernel<PRO, EPI>;
+  auto fn = tower_gemm_kernel<PRO, EPI, GL>;
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -789,6 +874,13 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
   const int groups = (g.tiles_m + 7) / 8;
   hipLaunchKernelGGL(fn, dim3(groups * 8 * g.tiles_n), dim3(256), lds, st, g);
   return (int)hipGetLastError();
+}
+
+template <int PRO, int EPI>
+int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  static const bool no_gl = [] { const char* e = getenv("TFR_TOWER_NO_LDSDMA"); return e && *e && atoi(e) != 0; }();
+  if ((g.K % BK) == 0 && !no_gl) return launch_gemm_v<PRO, EPI, true>(g, st);
+  return launch_gemm_v<PRO, EPI, false>(g, st);
 }
 
 }  // namespace
