@@ -83,7 +83,7 @@ def cast_weight(w: torch.Tensor, transpose: bool = False):
 
 
 def stats_rows(M: int) -> int:
-    return 2 * ((M + 127) // 128)
+    return (M + 63) // 64          # one row of partials per 64-row slab (tfr_tower_gemm_stats_rows)
 
 
 def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, epilogue=EPI_PLAIN,

@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       *reinterpret_cast<uint2*>(slot) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     }
   }
-  if (EPI != EPI_PLAIN && !(g.ablate & 16)) {
-    // column partials of this wave's 64 rows: stats[(2 tm + wm)][which][n]
+  if (EPI != EPI_PLAIN && !(g.ablate & 16) && mb < g.M) {
+    // column partials of this wave's 64 rows: stats[(2 tm + wm)][which][n]  (one row per 64-row slab below M)
     float* st = g.stats + ((long)(tm * 2 + wm) * 2) * g.N;
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn)
@@ -434,6 +434,221 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.stats) + (long)(tm * g.tiles_n + tn) * 5;
     dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
     dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// 256 x 256 tile variant (K % 64 == 0, N >= 256): 512 threads = 8 waves as 4 (m) x 2 (n), each wave a
+// 64 x 128 sub-tile (acc[8][4]); two LDS buffers of (32 KB activations + 32 KB weights), weights -- and
+// activations when there is no prologue -- by LDS-DMA.  Against the 128 x 128 kernel every byte that enters
+// the CU feeds twice the MFMA work (the k-loop there is bound by the L2 -> LDS path, not by MFMA issue),
+// and an A row block is fetched by N / 256 instead of N / 128 workgroups.
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2_BYTES = BM2 * BK * 2;         // 32 KB per operand tile
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* tiles = smem;                    // [buf][A tile | B tile]
+  float* s_scale = reinterpret_cast<float*>(smem + 4 * TILE2_BYTES);
+  float* s_shift = s_scale + g.K;                 // K % 64 == 0
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: LDS bases / tile offsets in SGPRs
+  const int wm = wave & 3, wn = wave >> 2;
+  const int id = blockIdx.x;
+  const int xcd = id & 7, j = id >> 3;
+  const int tn = j % g.tiles_n;
+  const int tm = (j / g.tiles_n) * 8 + xcd;
+  if (tm >= g.tiles_m) return;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+  const int nk = g.K / BK;
+  constexpr bool GLA = (PRO == PRO_NONE);
+
+  const int c = tid & 7, r0 = tid >> 3;           // staging: chunk column c of rows r0 + 64 i
+  struct RegsA { uint4 a[4]; };
+  auto load_a = [&](int kt, RegsA& R) {
+    const int k = kt * BK + c * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int ar = r0 + 64 * i;
+      asm volatile("" : "+v"(ar));
+      const long am = m0 + ar;
+      R.a[i] = (am < g.M) ? *reinterpret_cast<const uint4*>(g.A + am * g.lda + k) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_a = [&](int kt, unsigned char* ta, const RegsA& RA) {
+    const int k = kt * BK + c * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = s_scale[k + e]; sh[e] = s_shift[k + e]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 64 * i;
+      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
+      *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
+    }
+  };
+  auto glds_tile = [&](const uint16_t* G, long ld, long row0, long nrows, int kt, unsigned char* tdst) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int rl = wave * 32 + i * 8 + (lane >> 3);
+      asm volatile("" : "+v"(rl));                  // keep the address arithmetic in the loop (hoisted copies spill)
+      const int cl = (lane & 7) ^ ((rl >> 1) & 7);
+      long gr = row0 + rl;
+      gr = gr < nrows ? gr : nrows - 1;
+      glds16(G + gr * ld + kt * BK + cl * 8, tdst + (wave * 32 + i * 8) * 128);
+    }
+  };
+
+  f32x4 acc[8][4];      // [fn][fm]: D[n][m]
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  auto compute = [&](const unsigned char* ta, const unsigned char* tb) {
+#pragma unroll 1
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));    // activations
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn) {
+        bf16x8 fb[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          fb[f] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 128 + hn * 64 + f * 16 + fr, kk * 4 + fq));   // weights
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+          for (int fm = 0; fm < 4; ++fm)
+            acc[hn * 4 + fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[fn], fa[fm], acc[hn * 4 + fn][fm], 0, 0, 0);
+      }
+    }
+  };
+
+  // One code path for both LDS buffers (a second inlined copy of the MFMA block makes the register allocator
+  // carry two sets of the 128 accumulators across the loop).  The staging of tile kt + 1 is issued at the top of
+  // iteration kt and has the 64 MFMAs of compute(kt) to land: LDS-DMA for the weights (and for the activations
+  // when there is no prologue), otherwise one register set that is transformed and written behind the MFMAs.
+  RegsA R;
+  if (!GLA) load_a(0, R);
+  glds_tile(g.B, g.ldb, n0, g.N, 0, tiles + TILE2_BYTES);
+  if (GLA) glds_tile(g.A, g.lda, m0, g.M, 0, tiles);
+  if (PRO != PRO_NONE) {
+    for (int k = tid; k < g.K; k += 512) { s_scale[k] = g.a_scale[k]; s_shift[k] = g.a_shift[k]; }
+    __syncthreads();
+  }
+  if (!GLA) store_a(0, tiles, R);
+  __syncthreads();
+#pragma unroll 1
+  for (int kt = 0; kt < nk; ++kt) {
+    unsigned char* const tAc = tiles + (kt & 1) * (2 * TILE2_BYTES);
+    unsigned char* const tAn = tiles + ((kt + 1) & 1) * (2 * TILE2_BYTES);
+    const bool more = kt + 1 < nk;
+    if (more) {
+      glds_tile(g.B, g.ldb, n0, g.N, kt + 1, tAn + TILE2_BYTES);
+      if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 1, tAn);
+      else load_a(kt + 1, R);
+    }
+    compute(tAc, tAc + TILE2_BYTES);
+    if (!GLA && more) store_a(kt + 1, tAn, R);
+    __syncthreads();
+  }
+
+  // ---- epilogue: the wave's 64 x 128 result as two 64 x 64 halves through its private LDS region
+  // (same code shape as the 128 x 128 kernel; DS operations of a wave complete in order).
+  unsigned char* wl = smem + wave * (64 * WPITCH);
+  const long mb = m0 + wm * 64;
+  const bool slab_live = mb < g.M;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int nb = n0 + wn * 128 + h * 64;
+    if (EPI == EPI_RELU_BWD) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
+        uint4 zz = make_uint4(0, 0, 0, 0);
+        if (mb + row < g.M && nb + cc * 8 < g.N)
+          zz = *reinterpret_cast<const uint4*>(g.Zp + (mb + row) * g.ldz + nb + cc * 8);
+        *reinterpret_cast<uint4*>(wl + row * WPITCH + cc * 16) = zz;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    float* const st = g.stats + ((long)(tm * 4 + wm) * 2) * g.N;      // one row of partials per 64-row slab
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+      float s1[4], s2[4];
+      const int n = nb + fn * 16 + fq * 4;
+      float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (g.bias) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
+      }
+      float em[4], er[4], es[4], eh[4];
+      if (EPI == EPI_RELU_BWD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool in = n + r < g.N;
+          es[r] = in ? g.e_scale[n + r] : 0.f; eh[r] = in ? g.e_shift[n + r] : 0.f;
+          em[r] = in ? g.e_mean[n + r] : 0.f;  er[r] = in ? g.e_rstd[n + r] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm) {
+        const int row = fm * 16 + fr;
+        const bool min = mb + row < g.M;
+        unsigned char* slot = wl + row * WPITCH + (fn * 16 + fq * 4) * 2;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[h * 4 + fn][fm][r] + bias4[r];
+        if (EPI == EPI_RELU_BWD) {
+          const uint2 zz = *reinterpret_cast<const uint2*>(slot);
+          const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
+          float kf[4] = {1.f, 1.f, 1.f, 1.f};
+          if (g.epi_drop.thr) {
+            drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
+            drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float y = __builtin_fmaf(z[r], es[r], eh[r]);
+            v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
+            s1[r] += v[r];
+            s2[r] = __builtin_fmaf(v[r], (z[r] - em[r]) * er[r], s2[r]);
+          }
+        } else if (EPI == EPI_STATS) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float t = min ? v[r] : 0.f;
+            s1[r] += t;
+            s2[r] = __builtin_fmaf(t, t, s2[r]);
+          }
+        }
+        *reinterpret_cast<uint2*>(slot) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      }
+      if (EPI != EPI_PLAIN && slab_live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float a = row16_sum(s1[r]), b = row16_sum(s2[r]);
+          if (fr == 15 && n + r < g.N) { st[n + r] = a; st[g.N + n + r] = b; }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
+      if (mb + row < g.M && nb + cc * 8 < g.N)
+        *reinterpret_cast<uint4*>(g.C + (mb + row) * g.ldc + nb + cc * 8) =
+            *reinterpret_cast<const uint4*>(wl + row * WPITCH + cc * 16);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -877,8 +1092,26 @@ int launch_gemm_v(const GemmArgs& g, hipStream_t st) {
 }
 
 template <int PRO, int EPI>
+int launch_gemm256(const GemmArgs& g0, hipStream_t st) {
+  GemmArgs g = g0;
+  g.tiles_m = (g.M + BM2 - 1) / BM2; g.tiles_n = (g.N + BN2 - 1) / BN2;
+  const size_t lds = 4 * TILE2_BYTES + 2 * (size_t)g.K * sizeof(float);
+  auto fn = tower_gemm256_kernel<PRO, EPI>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int groups = (g.tiles_m + 7) / 8;
+  hipLaunchKernelGGL(fn, dim3(groups * 8 * g.tiles_n), dim3(512), lds, st, g);
+  return (int)hipGetLastError();
+}
+
+template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   static const bool no_gl = [] { const char* e = getenv("TFR_TOWER_NO_LDSDMA"); return e && *e && atoi(e) != 0; }();
+  static const int tile = [] { const char* e = getenv("TFR_TOWER_TILE"); return (e && *e) ? atoi(e) : 256; }();
+  if ((g.K % BK) == 0 && !no_gl && tile == 256 && g.N >= BN2 && g.M >= BM2 &&
+      4 * TILE2_BYTES + 2 * (size_t)g.K * sizeof(float) <= 160 * 1024)
+    return launch_gemm256<PRO, EPI>(g, st);
   if ((g.K % BK) == 0 && !no_gl) return launch_gemm_v<PRO, EPI, true>(g, st);
   return launch_gemm_v<PRO, EPI, false>(g, st);
 }
@@ -933,7 +1166,7 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   return TFR_EINVAL;
 }
 
-extern "C" int tfr_tower_gemm_stats_rows(int M) { return 2 * ((M + BM - 1) / BM); }
+extern "C" int tfr_tower_gemm_stats_rows(int M) { return (M + 63) / 64; }   // one row per 64-row slab
 
 extern "C" int tfr_tower_reduce_scratch_rows(int T) { return (T + kReduceChunk - 1) / kReduceChunk; }
 
