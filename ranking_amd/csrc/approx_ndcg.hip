@@ -33,6 +33,8 @@ using namespace tfr;
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kFastRange = 160.0f;
 
@@ -456,9 +458,11 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   }
   __syncthreads();
   const int n4 = (n + 3) >> 2;
-  const float m = 0.5f * (xmax + xmin);
+  const int iters = (n4 + C - 1) / C;                 // uniform trip count of the pair sweeps: every lane of a row
+  const int n4p = iters * C;                          // group walks `iters` float4 column groups; the padding
+  const float m = 0.5f * (xmax + xmin);               // groups hold F = +inf (sigma = 0) and A = 0
   const bool fast = (xmax - xmin) <= kFastRange;
-  for (int i = lane; i < n4 * 4; i += 64) {
+  for (int i = lane; i < n4p * 4; i += 64) {
     float e = 0.f, f = INFINITY;
     if (i < n) {
       const float xv = X[i];
@@ -487,8 +491,18 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const bool active = row < n;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (fast) {
+      // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): 2 + 2 full-rate instructions and 4 v_rcp_f32 per 4 pairs
       const float Ei = active ? E[row] : 0.f;
-      for (int gI = c; gI < n4; gI += C) pair_fwd_fast(Ei, F4[gI], a0, a1, a2, a3);
+      const f32x2 Ei2 = {Ei, Ei}, one2 = {1.0f, 1.0f};
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+        const float4 f = F4[c + it * C];
+        const f32x2 d01 = __builtin_elementwise_fma(Ei2, f32x2{f.x, f.y}, one2);
+        const f32x2 d23 = __builtin_elementwise_fma(Ei2, f32x2{f.z, f.w}, one2);
+        acc01 += f32x2{fast_rcp(d01.x), fast_rcp(d01.y)};
+        acc23 += f32x2{fast_rcp(d23.x), fast_rcp(d23.y)};
+      }
+      a0 = acc01.x; a1 = acc01.y; a2 = acc23.x; a3 = acc23.y;
     } else {
       const float xi = active ? X[row] : 0.f;
       for (int gI = c; gI < n4; gI += C) {
@@ -537,18 +551,21 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (fast) {
       const float Ek = active ? E[row] : 0.f;
-      for (int gI = c; gI < n4; gI += C) {
-        const float4 f = F4[gI];
-        const float4 aj = A4[gI];
-        const float s0 = fast_rcp(__builtin_fmaf(Ek, f.x, 1.0f));
-        const float s1 = fast_rcp(__builtin_fmaf(Ek, f.y, 1.0f));
-        const float s2 = fast_rcp(__builtin_fmaf(Ek, f.z, 1.0f));
-        const float s3 = fast_rcp(__builtin_fmaf(Ek, f.w, 1.0f));
-        a0 = __builtin_fmaf(aj.x - ak, __builtin_fmaf(-s0, s0, s0), a0);
-        a1 = __builtin_fmaf(aj.y - ak, __builtin_fmaf(-s1, s1, s1), a1);
-        a2 = __builtin_fmaf(aj.z - ak, __builtin_fmaf(-s2, s2, s2), a2);
-        a3 = __builtin_fmaf(aj.w - ak, __builtin_fmaf(-s3, s3, s3), a3);
+      const f32x2 Ek2 = {Ek, Ek}, one2 = {1.0f, 1.0f}, ak2 = {ak, ak};
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+        const float4 f = F4[c + it * C];
+        const float4 aj = A4[c + it * C];
+        const f32x2 d01 = __builtin_elementwise_fma(Ek2, f32x2{f.x, f.y}, one2);
+        const f32x2 d23 = __builtin_elementwise_fma(Ek2, f32x2{f.z, f.w}, one2);
+        const f32x2 s01 = {fast_rcp(d01.x), fast_rcp(d01.y)};
+        const f32x2 s23 = {fast_rcp(d23.x), fast_rcp(d23.y)};
+        const f32x2 w01 = __builtin_elementwise_fma(-s01, s01, s01);          // sigma' = s - s^2
+        const f32x2 w23 = __builtin_elementwise_fma(-s23, s23, s23);
+        acc01 = __builtin_elementwise_fma(f32x2{aj.x, aj.y} - ak2, w01, acc01);
+        acc23 = __builtin_elementwise_fma(f32x2{aj.z, aj.w} - ak2, w23, acc23);
       }
+      a0 = acc01.x; a1 = acc01.y; a2 = acc23.x; a3 = acc23.y;
     } else {
       const float xk = active ? X[row] : 0.f;
       for (int gI = c; gI < n4; gI += C) {
@@ -582,7 +599,7 @@ template <int IPL>
 int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
                 const float* list_scale, int B, int L, float temperature, int C, float* loss_out,
                 float* weight_out, float* dlogits_out, hipStream_t stream, int metric, const int* order) {
-  const int Lp = ((L + 3) / 4) * 4 + 4;
+  const int Lp = ((L + 3) / 4 + C) * 4;           // room for the padding column groups of the uniform sweeps
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,

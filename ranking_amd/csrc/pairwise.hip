@@ -589,6 +589,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   // ---- 4. pair sweep: row = C adjacent lanes, 64/C rows per pass, two columns per trip.
   const int rows_per_pass = 64 / C;
   const int c = lane % C, rsub = lane / C;
+  const int trips = npad / (2 * C);
   const float fL = (float)L;
   const float one_minus_s = 1.0f - a.smooth;
   const float ftopn = (float)topn;
@@ -601,7 +602,8 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
     const float2 qi = auxS[active ? row : 0];
     if (!active) ri.y = NAN;                                   // compares false: contributes nothing
     float acc_loss = 0.f, acc_w = 0.f, acc_nz = 0.f, acc_g = 0.f;
-    for (int j0 = c; j0 < npad; j0 += 2 * C) {
+    for (int it = 0; it < trips; ++it) {                      // uniform trip count: scalar loop control
+      const int j0 = c + it * 2 * C;
       const int j1 = j0 + C;
       const float4 r0 = recS[j0], r1 = recS[j1];
       float u0 = 0.f, u1 = 0.f;
