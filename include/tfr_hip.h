@@ -274,6 +274,10 @@ typedef struct tfr_tower_dropout {
  * padded; optional per-column affine (an input BatchNormalization folded in). */
 int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
                             const float* shift, void* out_bf16, void* stream);
+/* The same with a row gather: out[m] = cast(x[row_index[m]]) (row_index NULL = identity).  Fuses FlattenList's
+ * circular padding (keras/layers.py:126-182: padded slots re-use the list's valid items) into the cast. */
+int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
+                                   const float* shift, const int* row_index, void* out_bf16, void* stream);
 /* fp32 w[R, C] -> bf16 [R, pitch] or (transpose) bf16 [C, pitch]: the per-step operand copy of a
  * Dense kernel (fp32 master weights stay with the optimizer). */
 int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,

@@ -56,17 +56,25 @@ def pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
-def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None):
-    """fp32 [M, F] -> bf16 [M, pad8(F)] (zero padded), optional per-column affine."""
+def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+              row_index: Optional[torch.Tensor] = None):
+    """fp32 [R, F] -> bf16 [M, pad8(F)] (zero padded), optional per-column affine; with ``row_index`` (int32 [M])
+    row m of the result is row ``row_index[m]`` of ``x`` (FlattenList's gather fused into the cast)."""
     require_device(x, 'x')
     x = x.to(torch.float32)
     if x.stride(1) != 1:
         x = x.contiguous()
-    M, F = x.shape
+    F = x.shape[1]
+    if row_index is not None:
+        row_index = row_index.to(torch.int32).contiguous()
+        M = row_index.numel()
+    else:
+        M = x.shape[0]
     Kp = pad8(F)
     out = torch.empty((M, Kp), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().tfr_tower_cast_f32_bf16(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
-                                                   _ptr(out), _stream()), 'tfr_tower_cast_f32_bf16')
+    _lib.check(_lib.load().tfr_tower_cast_gather_f32_bf16(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
+                                                          _ptr(row_index), _ptr(out), _stream()),
+               'tfr_tower_cast_gather_f32_bf16')
     return out
 
 

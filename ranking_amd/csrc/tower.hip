@@ -656,16 +656,17 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 // fp32 [M, F] -> bf16 [M, Kp] (zero padded columns), optional per-column affine (input BN).
 __global__ void tower_cast_kernel(const float* __restrict__ x, long ldx, int M, int F, int Kp,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
-                                  uint16_t* __restrict__ out) {
+                                  const int* __restrict__ row_index, uint16_t* __restrict__ out) {
   const long chunks_per_row = Kp / 8;
   const long total = (long)M * chunks_per_row;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
     const long m = q / chunks_per_row;
+    const long ms = row_index ? (long)row_index[m] : m;        // FlattenList's circular padding: a row gather
     const int k = (int)(q % chunks_per_row) * 8;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = (k + e < F) ? x[m * ldx + k + e] : 0.f;
+      float t = (k + e < F) ? x[ms * ldx + k + e] : 0.f;
       if (scale && k + e < F) t = __builtin_fmaf(t, scale[k + e], shift[k + e]);
       v[e] = t;
     }
@@ -1118,13 +1119,19 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
-                                       const float* shift, void* out_bf16, void* stream) {
+extern "C" int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
+                                              const float* shift, const int* row_index, void* out_bf16,
+                                              void* stream) {
   if (!x || !out_bf16 || M < 0 || F <= 0 || Kp < F || (Kp & 7)) return TFR_EINVAL;
   if (M == 0) return TFR_OK;
   hipLaunchKernelGGL(tower_cast_kernel, dim3(grid_for((long)M * (Kp / 8), 256)), dim3(256), 0,
-                     (hipStream_t)stream, x, ldx, M, F, Kp, scale, shift, (uint16_t*)out_bf16);
+                     (hipStream_t)stream, x, ldx, M, F, Kp, scale, shift, row_index, (uint16_t*)out_bf16);
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
+                                       const float* shift, void* out_bf16, void* stream) {
+  return tfr_tower_cast_gather_f32_bf16(x, ldx, M, F, Kp, scale, shift, nullptr, out_bf16, stream);
 }
 
 extern "C" int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,

@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from . import layers
+from .. import utils as _tfr_utils
 
 
 class UnivariateScorer(nn.Module, metaclass=abc.ABCMeta):
@@ -38,6 +39,21 @@ class DNNScorer(UnivariateScorer):
         self._dnn_kwargs = dict(dnn_kwargs)
         self._dnn_kwargs.setdefault('output_units', 1)
         self._tower = layers.create_tower(input_dim=input_dim, **self._dnn_kwargs)
+
+    def forward(self, context_features, example_features, mask) -> torch.Tensor:
+        """keras/model.py:712-777.  With the fused tower and one dense example feature the flatten step's
+        circular-padding gather (a full copy of the [B, L, F] tensor) is folded into the tower's input cast."""
+        from ..tower import FusedTower
+        if (isinstance(self._tower, FusedTower) and not context_features and len(example_features) == 1):
+            (x,) = example_features.values()
+            if torch.is_tensor(x) and x.dim() == 3 and x.dtype == torch.float32:
+                mask = torch.as_tensor(mask, device=x.device).to(torch.bool)
+                b, l = mask.shape
+                idx, _ = _tfr_utils.padded_nd_indices(is_valid=mask)
+                rows = (idx + torch.arange(b, device=x.device).unsqueeze(1) * l).reshape(-1)
+                flat_logits = self._tower(x.reshape(b * l, x.shape[2]), row_index=rows)
+                return self._restore((flat_logits, mask))
+        return super().forward(context_features, example_features, mask)
 
     def _score_flattened(self, context_features, example_features):
         ctx = [context_features[k].reshape(context_features[k].shape[0], -1)

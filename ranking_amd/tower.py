@@ -40,7 +40,7 @@ class _TowerFn(torch.autograd.Function):
     """forward(x, training, tower, *params) -> logits [M, O] (fp32)."""
 
     @staticmethod
-    def forward(ctx, x, tower, training, *params):
+    def forward(ctx, x, tower, training, row_index, *params):
         n_h = len(tower.hidden_layer_dims)
         use_bn, relu = tower.use_batch_norm, tower.activation == 'relu'
         Ws = params[0:n_h]
@@ -48,9 +48,12 @@ class _TowerFn(torch.autograd.Function):
         gammas = params[2 * n_h:3 * n_h] if use_bn else [None] * n_h
         betas = params[3 * n_h:4 * n_h] if use_bn else [None] * n_h
         w_out, b_out = params[-2], params[-1]
-        M = x.shape[0]
         dev = x.device
-        x0 = x if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 else T.cast_rows(x)
+        if row_index is not None:
+            x0 = T.cast_rows(x, row_index=row_index)
+        else:
+            x0 = x if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 else T.cast_rows(x)
+        M = x0.shape[0]
         a_in, pro, sc, sh, drop = x0, T.PRO_NONE, None, None, None
         zs, coefs = [], []
         k_in = x0.shape[1]
@@ -152,7 +155,7 @@ class _TowerFn(torch.autograd.Function):
         if use_bn:
             grads += list(dgam) + list(dbet)
         grads += [dw_out, db_out]
-        return (None, None, None) + tuple(grads)
+        return (None, None, None, None) + tuple(grads)
 
 
 class FusedTower(nn.Module):
@@ -207,11 +210,13 @@ class FusedTower(nn.Module):
     def moving_var(self):
         return [getattr(self, 'moving_var_%d' % i) for i in range(len(self.hidden_layer_dims))]
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, row_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``row_index`` (int [M]): score row ``row_index[m]`` of ``x`` at position m -- the gather of
+        ``FlattenList``'s circular padding, fused into the input cast."""
         if x.dim() != 2 or x.shape[1] not in (self.input_dim, T.pad8(self.input_dim)):
             raise ValueError('expected [M, %d] features, got %s' % (self.input_dim, tuple(x.shape)))
         params = list(self.weights) + list(self.biases)
         if self.use_batch_norm:
             params += list(self.gammas) + list(self.betas)
         params += [self.out_weight, self.out_bias]
-        return _TowerFn.apply(x, self, self.training, *params)
+        return _TowerFn.apply(x, self, self.training, row_index, *params)

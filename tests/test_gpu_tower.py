@@ -348,3 +348,34 @@ def test_simple_pipeline_trains_on_synthetic_elwc(tmp_path):
         P.SimplePipeline(mb, db, dataclasses.replace(hp, loss={'a': 'softmax_loss'})).build_loss()
     with pytest.raises(ValueError):
         P.SimplePipeline(None, db, hp)
+
+
+def test_flatten_gather_fused_into_the_cast_matches_the_unfused_scorer():
+    """DNNScorer with the fused tower folds FlattenList's circular-padding gather (keras/layers.py:126-182) into the
+    input cast (tfr_tower_cast_gather_f32_bf16): logits and gradients equal the flatten -> tower -> restore path."""
+    from ranking_amd.keras.model import DNNScorer, UnivariateScorer
+    from ranking_amd import _tower_ops as T
+    torch.manual_seed(3)
+    B, L, F = 37, 9, 24
+    x = rnd((B, L, F), 70).to(DEV)
+    n_valid = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(1))
+    mask = (torch.arange(L).unsqueeze(0) < n_valid.unsqueeze(1)).to(DEV)
+    mask[3] = mask[3].flip(0)                       # valid items need not be a prefix
+    scorer = DNNScorer(input_dim=F, hidden_layer_dims=[64, 32], activation=torch.relu, use_batch_norm=True,
+                       dropout=0.0, compute_dtype=torch.bfloat16).to(DEV)
+    scorer.train()
+    up = rnd((B, L), 71).to(DEV)
+    got = scorer({}, {'f': x}, mask)                # fused gather
+    got.backward(up)
+    g_got = [p.grad.clone() for p in scorer.parameters()]
+    scorer.zero_grad()
+    want = UnivariateScorer.forward(scorer, {}, {'f': x}, mask)      # FlattenList (torch.gather) -> tower -> restore
+    want.backward(up)
+    g_want = [p.grad.clone() for p in scorer.parameters()]
+    assert torch.equal(got, want)
+    for a, b in zip(g_got, g_want):
+        assert torch.allclose(a, b, rtol=0, atol=1e-6 * max(1.0, b.abs().max().item()))
+    # the kernel itself
+    rows = torch.randint(0, B * L, (500,), generator=torch.Generator().manual_seed(2)).to(DEV)
+    flat = x.reshape(B * L, F)
+    assert torch.equal(T.cast_rows(flat, row_index=rows), T.cast_rows(flat[rows]))
