@@ -148,12 +148,14 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
         return value
 
+    grad_views, off = [], 0
+    for p in params:
+        grad_views.append(bucket.flat[off:off + p.numel()].view_as(p))
+        off += p.numel()
+
     def sgd():
-        with torch.no_grad():                              # SGD on the fp32 master weights
-            off = 0
-            for p in params:
-                p.add_(bucket.flat[off:off + p.numel()].view_as(p), alpha=-lr)
-                off += p.numel()
+        with torch.no_grad():                              # SGD on the fp32 master weights: one multi-tensor launch
+            torch._foreach_add_(params, grad_views, alpha=-lr)
 
     def eager_step():
         value = fwd_bwd()

@@ -298,6 +298,10 @@ int tfr_tower_bn_finalize(const float* partial, int T, int N, long M, const floa
                           const float* beta, float eps, float momentum, float* moving_mean,
                           float* moving_var, float* scale, float* shift, float* mean_out,
                           float* rstd_out, float* scratch, void* stream);
+/* BatchNormalization backward coefficients: pqr[3][N] with dz = p * dy + q * z + r, from c[2][N] = (sum dy,
+ * sum dy * zhat) = (d beta, d gamma), the forward's mean / rstd and gamma; M = rows of the batch. */
+int tfr_tower_bn_bwd_coeffs(const float* gamma, const float* rstd, const float* mean, const float* c,
+                            int N, long M, float* pqr, void* stream);
 /* out[i] = sum_t partial[t][i], i < W.  scratch: [scratch_rows(T)][W] or NULL. */
 int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, float* scratch,
                               void* stream);

@@ -173,6 +173,16 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
     return dy, reduce_partials(partial)
 
 
+def bn_bwd_coeffs(gamma, rstd, mean, c, M):
+    """pqr [3, N] of dz = p dy + q z + r from c = [sum dy; sum dy zhat] ([2, N], contiguous)."""
+    N = gamma.shape[0]
+    c = c.to(torch.float32).contiguous()
+    pqr = torch.empty((3, N), dtype=torch.float32, device=c.device)
+    _lib.check(_lib.load().tfr_tower_bn_bwd_coeffs(_ptr(gamma.detach()), _ptr(rstd), _ptr(mean), _ptr(c), N, M,
+                                                   _ptr(pqr), _stream()), 'tfr_tower_bn_bwd_coeffs')
+    return pqr
+
+
 def bn_bwd_apply_(dy, z, K, pqr):
     """In place: dy <- p * dy + q * z + r (per column); pqr is fp32 [3, K]."""
     _bf16(dy, 'dy'); _bf16(z, 'z')

@@ -1065,6 +1065,21 @@ __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, 
   }
 }
 
+// BatchNorm backward coefficients (one launch instead of a dozen elementwise ops): with s = gamma * rstd,
+//   dz = p * dy + q * z + r,   p = s,   q = -s * rstd * c2 / M,   r = s * (rstd * c2 * mean - c1) / M
+// c = [sum dy ; sum dy * zhat] per column (= d beta ; d gamma).
+__global__ void tower_bn_bwd_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                           const float* __restrict__ mean, const float* __restrict__ c, int N,
+                                           float inv_m, float* __restrict__ pqr) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float s = gamma[n] * rstd[n];
+  const float c1 = c[n], c2 = c[N + n];
+  pqr[n] = s;
+  pqr[N + n] = -s * rstd[n] * c2 * inv_m;
+  pqr[2 * N + n] = s * (rstd[n] * c2 * mean[n] - c1) * inv_m;
+}
+
 Drop to_drop(const tfr_tower_dropout* d) {
   if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f};
   return Drop{d->seed, d->threshold16 > 65535u ? 65535u : d->threshold16, d->scale};
@@ -1284,5 +1299,13 @@ extern "C" int tfr_tower_slab_reduce(const float* slab, int S, long n, float* ou
   if (!slab || !out || S < 1 || n <= 0) return TFR_EINVAL;
   hipLaunchKernelGGL(tower_slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, S,
                      n, out, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_bn_bwd_coeffs(const float* gamma, const float* rstd, const float* mean, const float* c,
+                                       int N, long M, float* pqr, void* stream) {
+  if (!gamma || !rstd || !mean || !c || !pqr || N <= 0 || M <= 0) return TFR_EINVAL;
+  hipLaunchKernelGGL(tower_bn_bwd_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma,
+                     rstd, mean, c, N, 1.0f / (float)M, pqr);
   return (int)hipGetLastError();
 }

@@ -116,19 +116,18 @@ class _TowerFn(torch.autograd.Function):
         dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
         dw_out = sums[2:].contiguous()
         db_out = dlogits.sum(dim=0)
-        c1, c2 = sums[0], sums[1]
+        cc = sums                                          # rows 0 / 1: sum dy, sum dy * zhat of the layer below
+        db_zero = torch.zeros(sum(z.shape[1] for z in zs), device=dev).split([z.shape[1] for z in zs]) if use_bn else None
         for l in range(n_h - 1, -1, -1):
             n_out = zs[l].shape[1]
             pro_l, sc_l, sh_l, mean_l, rstd_l, _ = coefs[l]
             if use_bn:
-                dgam[l], dbet[l] = c2.clone(), c1.clone()
-                s = gammas[l].detach() * rstd_l
-                pqr = torch.stack([s, -s * rstd_l * c2 / M, s * (rstd_l * c2 * mean_l - c1) / M])
-                dz = T.bn_bwd_apply_(dy, zs[l], n_out, pqr)
-                db[l] = torch.zeros(n_out, device=dev)
+                dgam[l], dbet[l] = cc[1], cc[0]
+                dz = T.bn_bwd_apply_(dy, zs[l], n_out, T.bn_bwd_coeffs(gammas[l], rstd_l, mean_l, cc[:2], M))
+                db[l] = db_zero[l]                         # a bias below BatchNorm has no gradient
             else:
                 dz = dy
-                db[l] = c1.clone()
+                db[l] = cc[0]
             if l > 0:
                 pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = coefs[l - 1]
                 a_prev, k_in = zs[l - 1], zs[l - 1].shape[1]
@@ -139,18 +138,16 @@ class _TowerFn(torch.autograd.Function):
             dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:
                 wt = T.cast_weight(Ws[l], transpose=True)          # [K, pad8(N)]
-                ones = torch.ones(k_in, device=dev); zeros = torch.zeros(k_in, device=dev)
                 if pro_p == T.PRO_AFFINE_RELU:
                     e_sc, e_sh = sc_p, sh_p
                 else:                                                # identity activation: mask always on
-                    e_sc, e_sh = zeros, ones
-                e_mean = mean_p if mean_p is not None else zeros
-                e_rstd = rstd_p if rstd_p is not None else ones
+                    e_sc, e_sh = torch.zeros(k_in, device=dev), torch.ones(k_in, device=dev)
+                e_mean = mean_p if mean_p is not None else torch.zeros(k_in, device=dev)
+                e_rstd = rstd_p if rstd_p is not None else torch.ones(k_in, device=dev)
                 dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD,
                                      Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd,
                                      epi_dropout=drop_p)
                 cc = T.reduce_partials(partial)
-                c1, c2 = cc[0], cc[1]
         grads = list(dW) + list(db)
         if use_bn:
             grads += list(dgam) + list(dbet)
