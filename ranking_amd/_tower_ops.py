@@ -56,8 +56,14 @@ def pad8(n: int) -> int:
     return (n + 7) // 8 * 8
 
 
+def pad_k(n: int) -> int:
+    """Width the tower stages its INPUT features at: a multiple of the GEMM's 64-wide k step once there are at
+    least two steps of it (the LDS-DMA kernels need whole k steps; the padding columns are zeros on both operands)."""
+    return ((n + 63) // 64) * 64 if n > 64 else pad8(n)
+
+
 def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
-              row_index: Optional[torch.Tensor] = None):
+              row_index: Optional[torch.Tensor] = None, width: Optional[int] = None):
     """fp32 [R, F] -> bf16 [M, pad8(F)] (zero padded), optional per-column affine; with ``row_index`` (int32 [M])
     row m of the result is row ``row_index[m]`` of ``x`` (FlattenList's gather fused into the cast)."""
     require_device(x, 'x')
@@ -70,7 +76,7 @@ def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Opti
         M = row_index.numel()
     else:
         M = x.shape[0]
-    Kp = pad8(F)
+    Kp = width if width is not None else pad8(F)
     out = torch.empty((M, Kp), dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().tfr_tower_cast_gather_f32_bf16(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
                                                           _ptr(row_index), _ptr(out), _stream()),
@@ -78,12 +84,12 @@ def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Opti
     return out
 
 
-def cast_weight(w: torch.Tensor, transpose: bool = False):
-    """fp32 [R, C] -> bf16 [R, pad8(C)], or (transpose) bf16 [C, pad8(R)]."""
+def cast_weight(w: torch.Tensor, transpose: bool = False, pitch: Optional[int] = None):
+    """fp32 [R, C] -> bf16 [R, pitch >= C] (default pad8(C)), or (transpose) bf16 [C, pad8(R)]; zero padded."""
     require_device(w, 'w')
     w = w.detach().to(torch.float32).contiguous()
     R, C = w.shape
-    pitch = pad8(R if transpose else C)
+    pitch = max(pitch or 0, pad8(R if transpose else C))
     out = torch.empty((C if transpose else R, pitch), dtype=torch.bfloat16, device=w.device)
     _lib.check(_lib.load().tfr_tower_weight_cast(_ptr(w), R, C, int(transpose), pitch, _ptr(out), _stream()),
                'tfr_tower_weight_cast')

@@ -49,10 +49,10 @@ class _TowerFn(torch.autograd.Function):
         betas = params[3 * n_h:4 * n_h] if use_bn else [None] * n_h
         w_out, b_out = params[-2], params[-1]
         dev = x.device
-        if row_index is not None:
-            x0 = T.cast_rows(x, row_index=row_index)
+        if row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
+            x0 = T.cast_rows(x, row_index=row_index, width=T.pad_k(x.shape[1]))
         else:
-            x0 = x if x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 else T.cast_rows(x)
+            x0 = x
         M = x0.shape[0]
         a_in, pro, sc, sh, drop = x0, T.PRO_NONE, None, None, None
         zs, coefs = [], []
@@ -63,7 +63,7 @@ class _TowerFn(torch.autograd.Function):
             base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
         for l in range(n_h):
             n_out = Ws[l].shape[0]
-            wb = T.cast_weight(Ws[l])                      # [N, pad8(K)]
+            wb = T.cast_weight(Ws[l], pitch=k_in)          # [N, k_in]: k_in = staged width of the layer input
             z, stats = T.gemm(a_in, wb, n_out, k_in, prologue=pro, a_scale=sc, a_shift=sh, bias=bs[l],
                               epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN, pro_dropout=drop)
             if use_bn:
