@@ -117,6 +117,11 @@ int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, 
                        const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
                        float* stats_out, void* stream);
 
+/* Per-list metric weights [B] from the stats_out [B, 3] of the metric entry points above
+ * (metrics_impl.py:63-119 _per_example_weights_to_per_list_weights): sum(w rel)/sum(rel); lists without
+ * relevance get the batch mean over the lists that have it (1 if none has); lists with all-zero weights get 0. */
+int tfr_metric_list_weights_f32(const float* stats, int B, float* weights_out, void* stream);
+
 /* metrics_impl.MRRMetric.compute (metrics_impl.py:429-459).
  *   mrr_out [K, B]; stats_out [B, 3] = (sum w, sum rel, sum w*rel), rel = 1{l>=1}. */
 int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,

@@ -44,6 +44,7 @@ _SIGNATURES = {
                          + [ctypes.c_void_p] * 3),
     'tfr_unique_softmax_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                + [ctypes.c_void_p] * 3),
+    'tfr_metric_list_weights_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_div_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int]
                            + [ctypes.c_void_p] * 2 + [ctypes.c_float] + [ctypes.c_void_p] + [ctypes.c_int] * 4
                            + [ctypes.c_void_p] * 3),

@@ -171,6 +171,16 @@ def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, dis
     return out, stats
 
 
+def metric_list_weights(stats):
+    """tfr_metric_list_weights_f32: [B, 3] per-list statistics -> [B, 1] per-list metric weights."""
+    stats = _f32(stats, 'stats')
+    B = stats.shape[0]
+    out = torch.empty((B, 1), dtype=torch.float32, device=stats.device)
+    _lib.check(_lib.load().tfr_metric_list_weights_f32(_ptr(stats), B, _ptr(out), _stream()),
+               'tfr_metric_list_weights_f32')
+    return out
+
+
 DIV_ALPHA_DCG, DIV_PRECISION_IA = 0, 1
 
 

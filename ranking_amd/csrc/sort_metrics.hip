@@ -614,6 +614,32 @@ __global__ __launch_bounds__(64) void div_metric_wave_kernel(
   }
 }
 
+// Per-list metric weights from the per-list statistics (metrics_impl.py:63-119
+// _per_example_weights_to_per_list_weights): w_b = sum(w rel) / sum(rel) for a list with relevance, the batch mean
+// of those for a list without, 0 for a list whose weights are all 0.  One workgroup; two passes over [B, 3].
+__global__ __launch_bounds__(1024) void metric_list_weights_kernel(const float* __restrict__ stats, int B,
+                                                                    float* __restrict__ out) {
+  __shared__ float red[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float cnt = 0.f, sum = 0.f;
+  for (int b = tid; b < B; b += 1024) {
+    const float sw = stats[(size_t)b * 3], sr = stats[(size_t)b * 3 + 1], swr = stats[(size_t)b * 3 + 2];
+    cnt += (sw > 0.0f && sr > 0.0f) ? 1.0f : 0.0f;
+    sum += (sr != 0.0f) ? swr / sr : 0.0f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cnt += __shfl_xor(cnt, o, 64); sum += __shfl_xor(sum, o, 64); }
+  if (lane == 0) { red[0][wid] = cnt; red[1][wid] = sum; }
+  __syncthreads();
+  float tc = 0.f, ts = 0.f;
+  for (int w = 0; w < 16; ++w) { tc += red[0][w]; ts += red[1][w]; }
+  const float avg = (tc > 0.0f) ? ts / tc : 1.0f;
+  for (int b = tid; b < B; b += 1024) {
+    const float sw = stats[(size_t)b * 3], sr = stats[(size_t)b * 3 + 1], swr = stats[(size_t)b * 3 + 2];
+    out[b] = (sw > 0.0f) ? ((sr > 0.0f) ? swr / sr : avg) : 0.0f;
+  }
+}
+
 template <int KIND, int IPL>
 void launch_metric_wave(const float* labels, const float* predictions, const float* weights, int weights_per_list,
                         const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
@@ -797,6 +823,13 @@ extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* pr
 #define DM(I) hipLaunchKernelGGL(div_metric_wave_kernel<I>, dim3(B), dim3(64), 0, st, kind, labels, predictions, weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out)
   if (L <= 64) DM(1); else if (L <= 128) DM(2); else if (L <= 256) DM(4); else if (L <= 512) DM(8); else DM(16);
 #undef DM
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_metric_list_weights_f32(const float* stats, int B, float* weights_out, void* stream) {
+  if (!stats || !weights_out || B < 0) return TFR_EINVAL;
+  if (B == 0) return TFR_OK;
+  hipLaunchKernelGGL(metric_list_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, B, weights_out);
   return (int)hipGetLastError();
 }
 

@@ -167,6 +167,22 @@ class PrecisionLambdaWeight(losses_impl.PrecisionLambdaWeight):
 
 
 # ------------------------------------------------------------------- helpers
+_CONST_CACHE: Dict[Any, torch.Tensor] = {}
+
+
+def _const_vector(n: int, value: float, device) -> torch.Tensor:
+    """A cached, read-only [n] fp32 tensor filled with `value` (the per-list scale of an unweighted batch):
+    saves a fill launch in every loss_and_grad call."""
+    key = (int(n), float(value), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 64:
+            _CONST_CACHE.clear()
+        t = torch.full((n,), float(value), dtype=torch.float32, device=device)
+        _CONST_CACHE[key] = t
+    return t
+
+
 def _keras_reduce(weighted, reduction):
     """tf.keras losses_utils.reduce_weighted_loss."""
     if reduction == Reduction.NONE:
@@ -302,7 +318,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
         if lam is None or self._loss._fused_kind is None:
             raise NotImplementedError('no fused kernel for this loss / lambda weight')
         item_w = None
-        list_w = torch.full((b,), scale, dtype=torch.float32, device=y_pred.device)
+        list_w = _const_vector(b, scale, y_pred.device)
         if sample_weight is not None:
             if sample_weight.dim() == 2 and sample_weight.shape == (b, l):
                 item_w = sample_weight
@@ -402,8 +418,7 @@ class SoftmaxLoss(_ListwiseLoss):
         y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
         b, l = y_pred.shape
         scale = self._scale(b)
-        w = torch.full((b,), scale, dtype=torch.float32, device=y_pred.device) \
-            if sample_weight is None else sample_weight * scale
+        w = _const_vector(b, scale, y_pred.device) if sample_weight is None else sample_weight * scale
         lam = losses_impl._lambda_kernel_args(self._lambda_weight, y_true, l, y_pred.device)
         if lam is None or lam['lambda_kind'] == _ops.LAMBDA_LABELDIFF:
             lam = dict(lambda_kind=_ops.LAMBDA_NONE)
@@ -440,10 +455,11 @@ class ApproxNDCGLoss(_ListwiseLoss):
         if torch.is_tensor(sw):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
-            list_scale = torch.full((b,), scale * float(sw), dtype=torch.float32, device=y_pred.device)
+            list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         loss, weight, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
                                                  self._temperature, 0, True)
-        return torch.dot(loss * weight, list_scale), dlogits
+        # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`
+        return torch.dot(loss, list_scale), dlogits
 
 
 @utils.register_keras_serializable()
@@ -466,7 +482,7 @@ class UniqueSoftmaxLoss(ApproxNDCGLoss):
         if torch.is_tensor(sw):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
-            list_scale = torch.full((b,), scale * float(sw), dtype=torch.float32, device=y_pred.device)
+            list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
         return torch.dot(loss, list_scale), dlogits
 
@@ -490,7 +506,7 @@ class ListMLELoss(ApproxNDCGLoss):
         if torch.is_tensor(sw):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
-            list_scale = torch.full((b,), scale * float(sw), dtype=torch.float32, device=y_pred.device)
+            list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         pw = self._loss._pos_weight(y_pred.shape[1], y_pred.device)
         loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
         return torch.dot(loss, list_scale), dlogits
@@ -517,7 +533,7 @@ class ApproxMRRLoss(ApproxNDCGLoss):
         if torch.is_tensor(sw):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
-            list_scale = torch.full((b,), scale * float(sw), dtype=torch.float32, device=y_pred.device)
+            list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         loss, weight, dlogits = _ops.approx_mrr(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
         return torch.dot(loss * weight, list_scale), dlogits
 

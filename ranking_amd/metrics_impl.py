@@ -48,17 +48,8 @@ def _safe_div(num, den):
 
 
 def per_list_weights_from_stats(stats):
-    """metrics_impl.py:63-119 given per-list (sum w, sum rel, sum w*rel)."""
-    sw, sr, swr = stats[:, 0:1], stats[:, 1:2], stats[:, 2:3]
-    nonzero_weights = sw > 0.0
-    nonzero_relevance = torch.where(nonzero_weights, (sr > 0.0).to(torch.float32), torch.zeros_like(sr))
-    count = nonzero_relevance.sum(dim=0, keepdim=True)
-    per_list = _safe_div(swr, sr)
-    sum_weights = per_list.sum(dim=0, keepdim=True)
-    avg = torch.where(count > 0.0, _safe_div(sum_weights, count), torch.ones_like(count))
-    return torch.where(nonzero_weights,
-                       torch.where(sr > 0.0, per_list, torch.ones_like(per_list) * avg),
-                       torch.zeros_like(per_list))
+    """metrics_impl.py:63-119 given per-list (sum w, sum rel, sum w*rel): one finishing launch."""
+    return _ops.metric_list_weights(stats)
 
 
 class _RankingMetric(object, metaclass=abc.ABCMeta):
