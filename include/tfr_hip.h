@@ -194,6 +194,17 @@ int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t*
                         const float* list_scale, int B, int L, float gamma, float margin, int clip,
                         float* loss_out, float* weight_out, float* dlogits_out, void* stream);
 
+/* Pointwise losses (losses_impl.py:1284-1321 _PointwiseLoss, :1425-1446 SigmoidCrossEntropyLoss, :1449-1469
+ * MeanSquaredLoss), forward + backward in one pass: per list sum(w l), sum(w), #(w != 0) and
+ * dlogits = d sum(w l) / d logits, with w = (label >= 0 ? item_weight * list_weight : 0) * [mask].
+ * item_weights [B, L] / list_weights [B] / mask / the last three outputs are nullable.  Any list size. */
+#define TFR_POINT_SIGMOID_CE 0
+#define TFR_POINT_MSE 1
+int tfr_pointwise_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                           const float* item_weights, const float* list_weights, int B, int L,
+                           float temperature, float* list_loss_out, float* list_weight_out,
+                           float* list_nnz_out, float* dlogits_out, void* stream);
+
 /* losses_impl.PairwiseLogisticLoss (+ optional DCGLambdaWeight pair weights)
  * fused with its backward (losses_impl.py:255-369, 483-537, 863-940).
  *   item_weights nullable [B, L] (w_i multiplies row i, losses_impl.py:917-930)

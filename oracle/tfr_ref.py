@@ -881,6 +881,20 @@ class SigmoidCrossEntropyLoss(_PointwiseLoss):
         return losses, mask.to(logits.dtype)
 
 
+class MeanSquaredLoss(_PointwiseLoss):
+    """losses_impl.py:1449-1469."""
+
+    def __init__(self, name=None, ragged=False):
+        super().__init__(name, None, 1.0, ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        return torch.square(labels - logits), mask.to(logits.dtype)
+
+
 # ----------------------------------------------------------------------------
 # Keras-level wrappers (keras/losses.py:247-335, 824-832, 1332-1341).
 # ----------------------------------------------------------------------------

@@ -17,7 +17,7 @@ INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
 PROF_LIB_PATH = os.path.join(CSRC, 'libtfr_hip_prof.so')     # developer aid: -DTFR_PROFILE_STAMPS build
 SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip', 'listwise.hip',
-           'neural_sort.hip']
+           'neural_sort.hip', 'pointwise.hip']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                '-fvisibility=default']
 
@@ -48,6 +48,8 @@ _SIGNATURES = {
     'tfr_div_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int]
                            + [ctypes.c_void_p] * 2 + [ctypes.c_float] + [ctypes.c_void_p] + [ctypes.c_int] * 4
                            + [ctypes.c_void_p] * 3),
+    'tfr_pointwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
+                               + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_circle_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float] * 2
                             + [ctypes.c_int] + [ctypes.c_void_p] * 4),
     'tfr_neural_sort_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2

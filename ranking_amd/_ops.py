@@ -307,6 +307,29 @@ def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, 
     return loss, dlogits
 
 
+POINT_SIGMOID_CE, POINT_MSE = 0, 1
+
+
+def pointwise_loss(kind, logits, labels, mask=None, item_weights=None, list_weights=None, temperature=1.0,
+                   want_grad=True):
+    """tfr_pointwise_loss_f32 -> (list_loss [B], list_weight [B], list_nnz [B], dlogits [B, L])."""
+    logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
+    _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
+    mask = _u8(mask, 'mask'); item_weights = _f32(item_weights, 'item_weights')
+    list_weights = _f32(list_weights, 'list_weights')
+    B, L = logits.shape
+    dev = logits.device
+    loss = torch.empty((B,), dtype=torch.float32, device=dev)
+    weight = torch.empty((B,), dtype=torch.float32, device=dev)
+    nnz = torch.empty((B,), dtype=torch.float32, device=dev)
+    dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
+    rc = _lib.load().tfr_pointwise_loss_f32(int(kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights),
+                                            _ptr(list_weights), B, L, float(temperature), _ptr(loss), _ptr(weight),
+                                            _ptr(nnz), _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_pointwise_loss_f32')
+    return loss, weight, nnz, dlogits
+
+
 def circle_loss(logits, labels, mask=None, list_scale=None, gamma=64.0, margin=0.25, clip=True, want_grad=True):
     """tfr_circle_loss_f32 -> (loss [B], weight [B] (NaN where a list has no pair), dlogits [B, L])."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')

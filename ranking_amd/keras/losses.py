@@ -73,6 +73,7 @@ def get(loss: str, reduction: str = Reduction.AUTO, lambda_weight=None, name: Op
     with_lambda.update(loss_kwargs)
     key_to_cls = {
         RankingLossKey.SIGMOID_CROSS_ENTROPY_LOSS: SigmoidCrossEntropyLoss,
+        RankingLossKey.MEAN_SQUARED_LOSS: MeanSquaredLoss,
         RankingLossKey.APPROX_NDCG_LOSS: ApproxNDCGLoss,
         RankingLossKey.APPROX_MRR_LOSS: ApproxMRRLoss,
         RankingLossKey.GUMBEL_APPROX_NDCG_LOSS: GumbelApproxNDCGLoss,
@@ -595,11 +596,68 @@ class GumbelApproxNDCGLoss(ApproxNDCGLoss):
         return loss, dlogits
 
 
+class _PointwiseLoss(_RankingLoss):
+    """Keras pointwise losses on the fused kernel tfr_pointwise_loss_f32 (scalar reductions)."""
+
+    def _weights_args(self, sample_weight, b, l, device):
+        item_w = list_w = None
+        if sample_weight is not None:
+            w = torch.as_tensor(sample_weight, dtype=torch.float32, device=device)
+            if w.dim() == 2 and w.shape == (b, l):
+                item_w = w
+            elif w.numel() == b:
+                list_w = w.reshape(b)
+            elif w.numel() == 1:
+                list_w = torch.broadcast_to(w.reshape(()), (b,)).contiguous()
+            else:
+                raise ValueError('sample_weight shape %s incompatible with [%d, %d]' % (tuple(w.shape), b, l))
+        return item_w, list_w
+
+    def _call_impl(self, y_true, y_pred, sample_weight):
+        if self.reduction == Reduction.NONE:
+            saved_ragged = self._loss._ragged
+            y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
+            self._loss._ragged = False
+            try:
+                sw = self._loss.normalize_weights(y_true, sample_weight)
+                losses, weights = self._loss.compute_unreduced_loss(labels=y_true, logits=self._loss.get_logits(y_pred),
+                                                                    mask=mask)
+            finally:
+                self._loss._ragged = saved_ragged
+            return _apply_sample_weight(losses * weights, sw)
+        y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
+        b, l = y_pred.shape
+        list_loss, _, _ = self._loss._fused(y_true, y_pred, sample_weight, mask, self._loss._temperature)
+        return list_loss.sum() * self._scale(b * l)
+
+    def loss_and_grad(self, y_true, y_pred, sample_weight=None):
+        """Single-launch training path: (scalar loss, dloss/dy_pred [B, L])."""
+        if self.reduction == Reduction.NONE:
+            raise ValueError('loss_and_grad needs a scalar reduction')
+        y_true, y_pred, sample_weight, mask = _densify(self, y_true, y_pred, sample_weight)
+        b, l = y_pred.shape
+        scale = self._scale(b * l)
+        item_w, list_w = self._weights_args(sample_weight, b, l, y_pred.device)
+        list_w = _const_vector(b, scale, y_pred.device) if list_w is None else list_w * scale
+        loss, _, _, dlogits = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w, list_w,
+                                                  self._loss._temperature, True)
+        return loss.sum(), dlogits
+
+
 @utils.register_keras_serializable()
-class SigmoidCrossEntropyLoss(_RankingLoss):
-    """keras/losses.py:1493-1556 (config 1; elementwise torch ops)."""
+class SigmoidCrossEntropyLoss(_PointwiseLoss):
+    """keras/losses.py:1493-1556."""
 
     def __init__(self, reduction=Reduction.AUTO, name=None, ragged=False):
         super().__init__(reduction, name, ragged)
         self._loss = losses_impl.SigmoidCrossEntropyLoss(
             name='{}_impl'.format(name) if name else None, ragged=ragged)
+
+
+@utils.register_keras_serializable()
+class MeanSquaredLoss(_PointwiseLoss):
+    """keras/losses.py:1550-1601."""
+
+    def __init__(self, reduction=Reduction.AUTO, name=None, ragged=False):
+        super().__init__(reduction, name, ragged)
+        self._loss = losses_impl.MeanSquaredLoss(name='{}_impl'.format(name) if name else None, ragged=ragged)

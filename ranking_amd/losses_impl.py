@@ -786,7 +786,8 @@ class _AttachFn(torch.autograd.Function):
 
 
 class _PointwiseLoss(_RankingLoss):
-    """losses_impl.py:1284-1321 (config 1, elementwise; torch device ops suffice)."""
+    """losses_impl.py:1284-1321; reduced entry points on the fused kernel tfr_pointwise_loss_f32."""
+    _fused_kind = None
 
     def _normalize_weights_impl(self, labels, weights):
         if weights is None:
@@ -794,21 +795,58 @@ class _PointwiseLoss(_RankingLoss):
         return torch.where(utils.is_label_valid(labels), torch.ones_like(labels) * weights,
                            torch.zeros_like(labels))
 
+    def _fused(self, labels, logits, weights, mask, temperature):
+        """(list_loss [B] differentiable, list_weight [B], list_nnz [B])."""
+        b, l = logits.shape
+        item_w = list_w = None
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float32, device=logits.device)
+            if weights.dim() == 2 and weights.shape == (b, l):
+                item_w = weights
+            elif weights.numel() == b:
+                list_w = weights.reshape(b)
+            elif weights.numel() == 1:
+                list_w = torch.broadcast_to(weights.reshape(()), (b,)).contiguous()
+            else:
+                raise ValueError('weights shape %s incompatible with [%d, %d]' % (tuple(weights.shape), b, l))
+
+        def runner(lg, want_grad):
+            loss, weight, nnz, d = _ops.pointwise_loss(self._fused_kind, lg, labels, mask, item_w, list_w,
+                                                       temperature, want_grad)
+            return loss, d, (weight, nnz)
+        return _PerListLossFn.apply(logits, runner)
+
     def _compute_reduced(self, labels, logits, weights, reduction, mask):
-        losses, loss_weights = self._compute_unreduced_loss_impl(labels, self.get_logits(logits), mask)
-        return compute_weighted_loss(losses, self._normalize_weights_impl(labels, weights) * loss_weights,
-                                     reduction)
+        if self._fused_kind is None:
+            losses, loss_weights = self._compute_unreduced_loss_impl(labels, self.get_logits(logits), mask)
+            return compute_weighted_loss(losses, self._normalize_weights_impl(labels, weights) * loss_weights,
+                                         reduction)
+        list_loss, list_weight, nnz = self._fused(labels, logits, weights, mask, self._temperature)
+        total = list_loss.sum()
+        if reduction == Reduction.SUM:
+            return total
+        if reduction == Reduction.MEAN:
+            return _safe_div(total, list_weight.sum())
+        if reduction == Reduction.SUM_BY_NONZERO_WEIGHTS:
+            return _safe_div(total, nnz.sum())
+        if reduction == Reduction.SUM_OVER_BATCH_SIZE:
+            return total / float(logits.numel())
+        raise ValueError('Invalid reduction: {}'.format(reduction))
 
     def compute_per_list(self, labels, logits, weights, mask=None):
         labels, logits, weights, mask = self._prepare_and_validate_params(labels, logits, weights, mask)
-        losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
-        w = self._normalize_weights_impl(labels, weights) * loss_weights
-        per_list_weights = w.sum(dim=1)
-        return _safe_div((losses * w).sum(dim=1), per_list_weights), per_list_weights
+        if self._fused_kind is None:
+            losses, loss_weights = self._compute_unreduced_loss_impl(labels, logits, mask)
+            w = self._normalize_weights_impl(labels, weights) * loss_weights
+            per_list_weights = w.sum(dim=1)
+            return _safe_div((losses * w).sum(dim=1), per_list_weights), per_list_weights
+        list_loss, list_weight, _ = self._fused(labels, logits, weights, mask, 1.0)   # no temperature (:1300-1321)
+        return _safe_div(list_loss, list_weight), list_weight
 
 
 class SigmoidCrossEntropyLoss(_PointwiseLoss):
     """losses_impl.py:1425-1446."""
+    _fused_kind = _ops.POINT_SIGMOID_CE
 
     def __init__(self, name, temperature=1.0, ragged=False):
         super().__init__(name, None, temperature, ragged)
@@ -820,3 +858,18 @@ class SigmoidCrossEntropyLoss(_PointwiseLoss):
         logits = torch.where(mask, logits, torch.zeros_like(logits))
         losses = torch.relu(logits) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
         return losses, mask.to(torch.float32)
+
+
+class MeanSquaredLoss(_PointwiseLoss):
+    """losses_impl.py:1449-1469 (temperature is not used by this loss)."""
+    _fused_kind = _ops.POINT_MSE
+
+    def __init__(self, name, ragged=False):
+        super().__init__(name, None, temperature=1.0, ragged=ragged)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = utils.is_label_valid(labels)
+        labels = torch.where(mask, labels, torch.zeros_like(labels))
+        logits = torch.where(mask, logits, torch.zeros_like(logits))
+        return torch.square(labels - logits), mask.to(torch.float32)

@@ -1193,3 +1193,61 @@ def test_diversity_metrics_ragged_and_keras():
     assert type(m).from_config(m.get_config()) is not None
     for key in ('alpha_dcg', 'precision_ia'):
         assert math.isfinite(float(ra().metrics.make_ranking_metric_fn(key, topn=2)(yt, yp, {})))
+
+
+# ------------------------------------------------------------------ pointwise losses (config 1)
+@pytest.mark.parametrize('B,L', SHAPES + [(64, 3000)])
+@pytest.mark.parametrize('kind', ['sigmoid_ce', 'mse'])
+@pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
+def test_pointwise_loss_parity(B, L, kind, wkind):
+    labels, logits = make_batch(B, L, seed=2100 + L)
+    weights = make_weights(B, L, seed=L) if wkind == 'item' else (make_weights(B, 1, seed=L) if wkind == 'list' else None)
+    T_ = 0.7 if kind == 'sigmoid_ce' else 1.0
+    oracle = R.SigmoidCrossEntropyLoss(temperature=T_) if kind == 'sigmoid_ce' else R.MeanSquaredLoss()
+    mine = (ra().losses_impl.SigmoidCrossEntropyLoss(None, temperature=T_) if kind == 'sigmoid_ce'
+            else ra().losses_impl.MeanSquaredLoss(None))
+    d = lambda x: None if x is None else x.to(DEV)
+    for red_mine, red_or in [('weighted_sum', R.Reduction.SUM), ('weighted_mean', R.Reduction.MEAN),
+                             ('weighted_sum_by_nonzero_weights', R.Reduction.SUM_BY_NONZERO_WEIGHTS),
+                             ('weighted_sum_over_batch_size', R.Reduction.SUM_OVER_BATCH_SIZE)]:
+        lg = logits.clone().requires_grad_(True)
+        want = oracle.compute(labels, lg, weights, red_or); want.backward()
+        lgd = logits.to(DEV).requires_grad_(True)
+        got = mine.compute(d(labels), lgd, d(weights), red_mine); got.backward()
+        assert_loss_close(got, want, what='%s %s' % (kind, red_mine))
+        assert_grad_close(lgd.grad, lg.grad, what='%s grad %s' % (kind, red_mine))
+    pl, pw = mine.compute_per_list(d(labels), d(logits), d(weights))
+    ol, ow = oracle.compute_per_list(labels, logits, weights)
+    assert_loss_close(pl / max(1., ol.abs().max().item()), ol / max(1., ol.abs().max().item()), what='per list')
+    assert_loss_close(pw / max(1., ow.max().item()), ow / max(1., ow.max().item()), 1e-6, what='per list weights')
+
+
+def test_pointwise_reference_goldens_and_keras():
+    L, K = ra().losses_impl, ra().keras.losses
+    t = lambda x: torch.tensor(x, device=DEV)
+    mse = lambda lab, sc: sum((a - b) ** 2 for a, b in zip(lab, sc))
+    scores = [[0.2, 0.5, 0.3], [0.2, 0.3, 0.5], [0.2, 0.3, 0.5]]
+    labels = [[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]
+    red = L.Reduction.SUM_BY_NONZERO_WEIGHTS
+    want = (mse(labels[0], scores[0]) * 2. + mse(labels[1], scores[1]) + mse(labels[2], scores[2])) / 9.
+    assert abs(L.MeanSquaredLoss(None).compute(t(labels), t(scores), t([[2.], [1.], [1.]]), red).item() - want) < 1e-5   # losses_impl_test.py:1345-1350
+    assert abs(L.MeanSquaredLoss(None).compute(t([[0., 1., 1.]]), t([[1., 3., 2.]]), None, red,
+                                               mask=t([[True, False, True]])).item() - 1.) < 1e-5               # :1362-1371
+    losses, w = L.SigmoidCrossEntropyLoss(None, ragged=True).compute_per_list(
+        [[0., 0., 1.], [0., 2.]], [t([1., 3., 2.]), t([1., 3.])], [[2., 3., 4.], [1., 1.]])
+    assert_loss_close(losses, torch.tensor([1.3644443, -0.8190755]), 1e-5); assert w.tolist() == [9., 2.]           # :557
+    losses, w = L.MeanSquaredLoss(None, ragged=True).compute_per_list(
+        [[0., 0., 1.], [0., 2.]], [t([1., 3., 2.]), t([1., 3.])], [[2., 3., 4.], [1., 1.]])
+    assert_loss_close(losses, torch.tensor([3.6666667, 1.]), 1e-5); assert w.tolist() == [9., 2.]                   # :558
+    assert abs(K.get('mean_squared_loss')(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.4) < 1e-6                      # keras/losses.py:1559-1563
+    assert abs(K.MeanSquaredLoss(ragged=True)([[1., 0.], [0., 1., 0.]], [t([0.6, 0.8]), t([0.5, 0.8, 0.4])]).item() - 0.20833336) < 1e-6  # :1565-1570
+    assert abs(K.get('sigmoid_cross_entropy_loss')(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.8042943) < 1e-6       # :1502-1506
+    for k in (K.MeanSquaredLoss(), K.SigmoidCrossEntropyLoss()):
+        lb, lg = make_batch(6, 30, seed=5)
+        sw = make_weights(6, 1, seed=3)
+        v, dd = k.loss_and_grad(lb.to(DEV), lg.to(DEV), sw.to(DEV))
+        lgd = lg.to(DEV).requires_grad_(True)
+        out = k(lb.to(DEV), lgd, sw.to(DEV)); out.backward()
+        assert abs(v.item() - out.item()) < 1e-5 * max(1.0, abs(out.item())) and torch.allclose(dd, lgd.grad, atol=1e-6)
+        none = type(k)(reduction='none')(lb.to(DEV), lg.to(DEV))
+        assert none.shape == (6, 30)

@@ -171,6 +171,7 @@ RAGGED_W = [[2., 3., 4.], [1., 1.]]
 
 @pytest.mark.parametrize('ctor,exp_l,exp_w', [   # losses_impl_test.py:556-580
     (R.SigmoidCrossEntropyLoss, [1.3644443, -0.8190755], [9., 2.]),
+    (R.MeanSquaredLoss, [3.6666667, 1.], [9., 2.]),
     (R.PairwiseHingeLoss, [1., 0.], [8., 1.]),
     (R.PairwiseLogisticLoss, [0.813262, 0.126928], [8., 1.]),
     (R.SoftmaxLoss, [1.407606, 0.126928], [4., 2.]),
@@ -189,6 +190,7 @@ def test_compute_per_list_ragged(ctor, exp_l, exp_w):
 
 @pytest.mark.parametrize('ctor,expected', [   # losses_impl_test.py:582-611
     (R.SigmoidCrossEntropyLoss, [[1.313262, 3.048587, 0.126928], [1.313262, -2.951413, 0.]]),
+    (R.MeanSquaredLoss, [[1., 9., 1.], [1., 1., 0.]]),
     (R.PairwiseHingeLoss, [[[0., 0., 0.], [0., 0., 0.], [0., 2., 0.]],
                            [[0., 0., 0.], [0., 0., 0.], [0., 0., 0.]]]),
     (R.PairwiseLogisticLoss, [[[0., 0., 0.], [0., 0., 0.], [0.313262, 1.313262, 0.]],
@@ -786,3 +788,20 @@ def test_diversity_metrics_ragged_reference_literals():
     out, _ = R.AlphaDCGMetric(topn=None, ragged=True).compute(labels, scores)
     close(out, [[1. / log2p1(1.) + 1. / log2p1(2.) + 0.5 / log2p1(2.) + 0.5 / log2p1(3.) + 0.25 / log2p1(4.)],
                 [1. / log2p1(1.) + 1. / log2p1(2.)]], 1e-6)
+
+
+def test_mean_squared_loss_reference_literals():
+    """losses_impl_test.py:1331-1371, keras/losses.py:1559-1570."""
+    mse = lambda lab, sc: sum((a - b) ** 2 for a, b in zip(lab, sc))
+    scores = [[0.2, 0.5, 0.3], [0.2, 0.3, 0.5], [0.2, 0.3, 0.5]]
+    labels = [[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    T = torch.tensor
+    want = sum(mse(l, s) for l, s in zip(labels, scores)) / 9.
+    assert abs(R.MeanSquaredLoss().compute(T(labels), T(scores), None, red).item() - want) < 1e-5
+    want = (mse(labels[0], scores[0]) * 2. + mse(labels[1], scores[1]) + mse(labels[2], scores[2])) / 9.
+    assert abs(R.MeanSquaredLoss().compute(T(labels), T(scores), T([[2.], [1.], [1.]]), red).item() - want) < 1e-5
+    assert abs(R.MeanSquaredLoss().compute(T([[0., -1., 1.]]), T([[1., 3., 2.]]), None, red).item() - 1.) < 1e-5
+    got = R.MeanSquaredLoss().compute(T([[0., 1., 1.]]), T([[1., 3., 2.]]), None, red, mask=T([[True, False, True]]))
+    assert abs(got.item() - 1.) < 1e-5
+    assert abs(R.keras_loss_call(R.MeanSquaredLoss(), T([[1., 0.]]), T([[0.6, 0.8]])).item() - 0.4) < 1e-6
