@@ -250,6 +250,12 @@ int tfr_softmax_loss_f32(const float* logits, const float* labels, const uint8_t
                          const float* gains, const float* discount, int B, int L,
                          float temperature, float* loss_out, float* weight_out,
                          float* dlogits_out, void* stream);
+/* PolyOneSoftmaxLoss (losses_impl.py:1200-1247): the same with loss += epsilon * (1 - sum_i p_i softmax_i). */
+int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                               const float* item_weights, int weights_per_list, int lambda_kind,
+                               int topn, int normalized, int gain_kind, const float* gains,
+                               const float* discount, int B, int L, float temperature, float epsilon,
+                               float* loss_out, float* weight_out, float* dlogits_out, void* stream);
 
 /* losses_impl.GumbelSampler.sample (losses_impl.py:556-649), dense path.
  *   uniform      nullable [B, S, L] injected U(0,1) noise; NULL -> in-kernel

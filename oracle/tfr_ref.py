@@ -847,6 +847,28 @@ class ApproxMRRLoss(_ListwiseLoss):
         return -mrr, nonzero_mask.to(logits.dtype).reshape(-1, 1)
 
 
+class PolyOneSoftmaxLoss(SoftmaxLoss):
+    """losses_impl.py:1200-1247."""
+
+    def __init__(self, name=None, lambda_weight=None, epsilon=1.0, temperature=1.0, ragged=False):
+        super().__init__(name, lambda_weight=lambda_weight, temperature=temperature, ragged=ragged)
+        self._epsilon = epsilon
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        if mask is None:
+            mask = is_label_valid(labels)
+        label_sum = labels.sum(dim=1, keepdim=True)
+        nonzero_mask = label_sum.reshape(-1) > 0.0
+        padded_labels = torch.where(nonzero_mask.unsqueeze(1), labels, _EPSILON * torch.ones_like(labels))
+        padded_labels = torch.where(mask, padded_labels, torch.zeros_like(padded_labels))
+        padded_label_sum = padded_labels.sum(dim=1, keepdim=True)
+        labels_for_softmax = _safe_div(padded_labels, padded_label_sum)
+        weights_for_softmax = label_sum.reshape(-1)
+        pt = (labels_for_softmax * torch.softmax(logits, dim=-1)).sum(dim=-1)
+        ce = -(labels_for_softmax * torch.log_softmax(logits, dim=1)).sum(dim=1)
+        return ce + self._epsilon * (1 - pt), weights_for_softmax
+
+
 class _PointwiseLoss(_RankingLoss):
     """losses_impl.py:1284-1321."""
 

@@ -62,6 +62,8 @@ _SIGNATURES = {
                               + [ctypes.c_float] + [ctypes.c_void_p] * 6),
     'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                              + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
+    'tfr_poly1_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
+                                   + [ctypes.c_int] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 4),
     'tfr_gumbel_sample_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_uint64] * 2 + [ctypes.c_int] * 3
                               + [ctypes.c_float] + [ctypes.c_void_p] * 2),
     'tfr_gumbel_sample_bwd_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float]

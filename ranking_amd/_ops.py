@@ -394,7 +394,8 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
 
 def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NONE, topn=0,
                  normalized=False, gain_kind=GAIN_IDENTITY, gains=None, discount=None,
-                 temperature=1.0, want_grad=True):
+                 temperature=1.0, want_grad=True, poly_epsilon=0.0):
+    """poly_epsilon != 0: PolyOneSoftmaxLoss (loss += epsilon * (1 - sum p softmax))."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
@@ -404,11 +405,11 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     weight = torch.empty((B,), dtype=torch.float32, device=dev)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
-    rc = _lib.load().tfr_softmax_loss_f32(
+    rc = _lib.load().tfr_poly1_softmax_loss_f32(
         _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),
         int(bool(normalized)), int(gain_kind), _ptr(gains), _ptr(discount), B, L, float(temperature),
-        _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
-    _lib.check(rc, 'tfr_softmax_loss_f32')
+        float(poly_epsilon), _ptr(loss), _ptr(weight), _ptr(dlogits), _stream())
+    _lib.check(rc, 'tfr_poly1_softmax_loss_f32')
     return loss, weight, dlogits
 
 

@@ -21,6 +21,7 @@ struct SmArgs {
   int weights_per_list; int lambda_kind; int topn; int normalized; int gain_kind;
   const float* gains; const float* discount; int L; int Lp; int P; float temperature;
   float* loss; float* weight; float* dlogits;
+  float poly_eps;                 // PolyOneSoftmaxLoss (losses_impl.py:1200-1247): loss += eps * (1 - sum_i p_i softmax_i)
 };
 
 __global__ void softmax_loss_kernel(const SmArgs a) {
@@ -112,23 +113,31 @@ __global__ void softmax_loss_kernel(const SmArgs a) {
   psum = block_sum(psum, red);
   esum = block_sum(esum, red);
   const float lse = logf(esum);
-  float loss = 0.f, ptot = 0.f;
+  float loss = 0.f, ptot = 0.f, pt = 0.f;
   for (int i = tid; i < L; i += T) {
     const float p = (psum != 0.0f) ? (Y[i] / psum) : 0.0f;   // divide_no_nan
     loss += p * (lse - (Z[i] - zmax));
     ptot += p;
+    if (a.poly_eps != 0.0f) pt += p * (expf(Z[i] - zmax) / esum);
     Y[i] = p;
   }
   loss = block_sum(loss, red);
   ptot = block_sum(ptot, red);
+  if (a.poly_eps != 0.0f) {                                    // wave-uniform
+    pt = block_sum(pt, red);
+    loss += a.poly_eps * (1.0f - pt);
+  }
   if (tid == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
   if (!a.dlogits) return;
-  // ---- backward: d(weight * loss)/d logits_k = (w/T) (sum_p * softmax_k - p_k), valid k.
+  // ---- backward: d(weight * loss)/d logits_k = (w/T) (sum_p * softmax_k - p_k), valid k;
+  // poly-1 adds  -eps * softmax_k * (p_k - pt).
   for (int i = tid; i < L; i += T) {
     float g = 0.f;
     if (MV[i]) {
       const float sm = expf(Z[i] - zmax) / esum;
-      g = lsum * ((ptot * sm - Y[i]) / a.temperature);
+      float d = ptot * sm - Y[i];
+      if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (Y[i] - pt);
+      g = lsum * (d / a.temperature);
     }
     a.dlogits[base + i] = g;
   }
@@ -226,12 +235,28 @@ inline int threads_for(int L) {
 
 }  // namespace
 
+extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* item_weights, int weights_per_list, int lambda_kind,
+                                          int topn, int normalized, int gain_kind, const float* gains,
+                                          const float* discount, int B, int L, float temperature, float epsilon,
+                                          float* loss_out, float* weight_out, float* dlogits_out, void* stream);
+
 extern "C" int tfr_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                                     const float* item_weights, int weights_per_list, int lambda_kind,
                                     int topn, int normalized, int gain_kind, const float* gains,
                                     const float* discount, int B, int L, float temperature,
                                     float* loss_out, float* weight_out, float* dlogits_out,
                                     void* stream) {
+  return tfr_poly1_softmax_loss_f32(logits, labels, mask, item_weights, weights_per_list, lambda_kind, topn,
+                                    normalized, gain_kind, gains, discount, B, L, temperature, 0.0f, loss_out,
+                                    weight_out, dlogits_out, stream);
+}
+
+extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* item_weights, int weights_per_list, int lambda_kind,
+                                          int topn, int normalized, int gain_kind, const float* gains,
+                                          const float* discount, int B, int L, float temperature, float epsilon,
+                                          float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || !weight_out || B < 0 || L <= 0 || !(temperature > 0.0f))
     return TFR_EINVAL;
   if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG) return TFR_EINVAL;
@@ -244,7 +269,7 @@ extern "C" int tfr_softmax_loss_f32(const float* logits, const float* labels, co
   a.weights_per_list = weights_per_list; a.lambda_kind = lambda_kind; a.topn = topn;
   a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains; a.discount = discount;
   a.L = L; a.Lp = ((L + 3) / 4) * 4; a.P = pow2_ceil(L < 2 ? 2 : L); a.temperature = temperature;
-  a.loss = loss_out; a.weight = weight_out; a.dlogits = dlogits_out;
+  a.loss = loss_out; a.weight = weight_out; a.dlogits = dlogits_out; a.poly_eps = epsilon;
   const size_t lds = 128 + (lambda_kind == TFR_LAMBDA_DCG ? (size_t)a.P * 8 : 0) +
                      (size_t)a.Lp * 17 + 16;
   if (lds > 160 * 1024) return TFR_ETOOLARGE;

@@ -48,6 +48,7 @@ _SUPPORTED = {
     RankingLossKey.PAIRWISE_HINGE_LOSS: (losses_impl.PairwiseHingeLoss, True, False),
     RankingLossKey.PAIRWISE_SOFT_ZERO_ONE_LOSS: (losses_impl.PairwiseSoftZeroOneLoss, True, False),
     RankingLossKey.SOFTMAX_LOSS: (losses_impl.SoftmaxLoss, True, False),
+    RankingLossKey.POLY_ONE_SOFTMAX_LOSS: (losses_impl.PolyOneSoftmaxLoss, True, False),
     RankingLossKey.SIGMOID_CROSS_ENTROPY_LOSS: (losses_impl.SigmoidCrossEntropyLoss, False, False),
     RankingLossKey.MEAN_SQUARED_LOSS: (losses_impl.MeanSquaredLoss, False, False),
     RankingLossKey.APPROX_NDCG_LOSS: (losses_impl.ApproxNDCGLoss, False, False),

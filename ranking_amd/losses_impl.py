@@ -701,6 +701,7 @@ class ApproxMRRLoss(_ListwiseLoss):
 
 class SoftmaxLoss(_ListwiseLoss):
     """losses_impl.py:1119-1197; fused kernel tfr_softmax_loss_f32."""
+    _poly_epsilon = 0.0
 
     def _run(self, labels, logits, weights, mask, temperature):
         lam = (self._lambda_weight._kernel_args(labels, logits.shape[1], logits.device)
@@ -715,7 +716,7 @@ class SoftmaxLoss(_ListwiseLoss):
 
         def runner(lg, want_grad):
             loss, weight, d = _ops.softmax_loss(lg, labels, mask, weights, temperature=temperature,
-                                                want_grad=want_grad, **lam)
+                                                want_grad=want_grad, poly_epsilon=self._poly_epsilon, **lam)
             # kernel's dlogits = weight * dloss/dlogits; per_list output is weight*loss.
             return loss * weight, d, (loss, weight)
         weighted, loss, weight = _PerListLossFn.apply(logits, runner)
@@ -873,3 +874,23 @@ class MeanSquaredLoss(_PointwiseLoss):
         labels = torch.where(mask, labels, torch.zeros_like(labels))
         logits = torch.where(mask, logits, torch.zeros_like(logits))
         return torch.square(labels - logits), mask.to(torch.float32)
+
+
+class PolyOneSoftmaxLoss(SoftmaxLoss):
+    """losses_impl.py:1200-1247; fused kernel tfr_poly1_softmax_loss_f32."""
+
+    def __init__(self, name, lambda_weight=None, epsilon=1.0, temperature=1.0, ragged=False):
+        super().__init__(name, lambda_weight=lambda_weight, temperature=temperature, ragged=ragged)
+        self._epsilon = epsilon
+        self._poly_epsilon = float(epsilon)
+
+    def _compute_unreduced_loss_impl(self, labels, logits, mask=None):
+        losses, weights = _mat.softmax_unreduced(labels, logits, mask)
+        if mask is None:
+            mask = utils.is_label_valid(labels)
+        label_sum = labels.sum(dim=1, keepdim=True)
+        padded = torch.where(label_sum > 0.0, labels, 1e-10 * torch.ones_like(labels))
+        padded = torch.where(mask, padded, torch.zeros_like(padded))
+        p = _safe_div(padded, padded.sum(dim=1, keepdim=True))
+        pt = (p * torch.softmax(logits, dim=-1)).sum(dim=-1)
+        return losses + self._epsilon * (1 - pt).reshape(losses.shape), weights

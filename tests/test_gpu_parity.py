@@ -1251,3 +1251,32 @@ def test_pointwise_reference_goldens_and_keras():
         assert abs(v.item() - out.item()) < 1e-5 * max(1.0, abs(out.item())) and torch.allclose(dd, lgd.grad, atol=1e-6)
         none = type(k)(reduction='none')(lb.to(DEV), lg.to(DEV))
         assert none.shape == (6, 30)
+
+
+# ------------------------------------------------------------------ PolyOneSoftmax
+@pytest.mark.parametrize('B,L', SHAPES)
+@pytest.mark.parametrize('eps', [1.0, 3.0])
+def test_poly_one_softmax_parity(B, L, eps):
+    labels, logits = make_batch(B, L, seed=2300 + L)
+    if B >= 3:
+        labels[0] = torch.where(labels[0] >= 0, torch.zeros_like(labels[0]), labels[0])
+        labels[1] = -1.0
+    weights = make_weights(B, L, seed=L)
+    T_ = 0.8
+    oracle = R.PolyOneSoftmaxLoss(epsilon=eps, temperature=T_)
+    mine = ra().losses_impl.PolyOneSoftmaxLoss(None, epsilon=eps, temperature=T_)
+    for red_mine, red_or in [('weighted_sum', R.Reduction.SUM), ('weighted_sum_by_nonzero_weights', R.Reduction.SUM_BY_NONZERO_WEIGHTS)]:
+        lg = logits.clone().requires_grad_(True)
+        want = oracle.compute(labels, lg, weights, red_or); want.backward()
+        lgd = logits.to(DEV).requires_grad_(True)
+        got = mine.compute(labels.to(DEV), lgd, weights.to(DEV), red_mine); got.backward()
+        sc = max(1.0, abs(want.item()))
+        assert_loss_close(got / sc, want / sc, what='poly1 %s' % red_mine)
+        assert_grad_close(lgd.grad, lg.grad, what='poly1 grad')
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    lb = torch.tensor([[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]], device=DEV)
+    fn = ra().losses.make_loss_fn('poly_one_softmax_loss', params={'epsilon': 3})
+    sm = lambda v: [math.exp(x) / sum(math.exp(y) for y in v) for x in v]
+    s0, s1 = sm(scores[0])[2], sm(scores[1])[2]
+    want = -((math.log(s0) - 3 * (1 - s0)) + (math.log(s1) - 3 * (1 - s1)) * 2.) / 2.          # losses_impl_test.py:1208-1226
+    assert abs(fn(lb, torch.tensor(scores, device=DEV), {}).item() - want) < 1e-5

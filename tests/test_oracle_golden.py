@@ -805,3 +805,13 @@ def test_mean_squared_loss_reference_literals():
     got = R.MeanSquaredLoss().compute(T([[0., 1., 1.]]), T([[1., 3., 2.]]), None, red, mask=T([[True, False, True]]))
     assert abs(got.item() - 1.) < 1e-5
     assert abs(R.keras_loss_call(R.MeanSquaredLoss(), T([[1., 0.]]), T([[0.6, 0.8]])).item() - 0.4) < 1e-6
+
+
+def test_poly_one_softmax_reference_literal():
+    """losses_impl_test.py:1208-1226."""
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = torch.tensor([[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]])
+    got = R.PolyOneSoftmaxLoss(epsilon=3).compute(labels, torch.tensor(scores), None, R.Reduction.SUM_BY_NONZERO_WEIGHTS)
+    s0, s1 = _softmax_py(scores[0])[2], _softmax_py(scores[1])[2]
+    want = -((math.log(s0) - 3 * (1 - s0)) + (math.log(s1) - 3 * (1 - s1)) * 2.) / 2.
+    assert abs(got.item() - want) < 1e-5
