@@ -238,8 +238,9 @@ def list_order(labels, mask=None):
 def _auto_order(labels, mask, balance, min_list_size):
     """balance: None = automatic, False = index order, True = compute the order, or a ready int32 [B] order.
     Automatic: the two ordering launches cost ~20 us; they pay for themselves when the tail they remove
-    (about one long list's wave time, ~ list_size^2) is longer -- measured break-even: ApproxNDCG around
-    list_size 300, the (4x heavier per pair) pairwise losses around 128."""
+    (about one long list's wave time, ~ list_size^2) is longer -- measured break-even (B = 16384, valid length
+    U{L/2..L}): ApproxNDCG between list_size 100 (0.063 -> 0.074 ms, a loss) and 200 (0.166 -> 0.149 ms with the
+    ordering launches included, 0.137 with a ready order); the (4x heavier per pair) pairwise losses around 128."""
     if torch.is_tensor(balance):
         return balance
     B, L = labels.shape
@@ -261,7 +262,7 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
     rc = _lib.load().tfr_approx_ndcg_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                          _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
                                          _ptr(loss), _ptr(weight), _ptr(dlogits),
-                                         _ptr(_auto_order(labels, mask, balance, 320)), _stream())
+                                         _ptr(_auto_order(labels, mask, balance, 192)), _stream())
     _lib.check(rc, 'tfr_approx_ndcg_f32')
     return loss, weight, dlogits
 
@@ -276,7 +277,7 @@ def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
     rc = _lib.load().tfr_approx_mrr_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
                                         float(temperature), _ptr(loss), _ptr(weight), _ptr(dlogits),
-                                        _ptr(_auto_order(labels, mask, balance, 320)), _stream())
+                                        _ptr(_auto_order(labels, mask, balance, 192)), _stream())
     _lib.check(rc, 'tfr_approx_mrr_f32')
     return loss, weight, dlogits
 
