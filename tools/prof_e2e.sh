@@ -1,4 +1,6 @@
 #!/bin/bash
+# rocprofv3 --kernel-trace --stats of the config-2 end-to-end step (eager launches) + the graph-captured bench line.
+# usage (through gpurun): bash tools/prof_e2e.sh ; summary in gpurun_out/e2e_now/stats.txt
 export TMPDIR=/tmp
 OUT=gpurun_out/e2e_now; mkdir -p $OUT
 python bench.py --workload e2e_softmax --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -n 1 | cut -c1-300
