@@ -394,7 +394,7 @@ def main():
         result['roofline'] = {
             'bound': 'mfma', 'achieved': tflops / world, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': tflops / world / MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(args.workload, B, L),
-            'kernel': 'whole training step (tower_gemm_kernel / tower_wgrad_kernel dominate; profiles/)',
+            'kernel': 'whole training step (tower_gemm256_kernel / tower_wgrad_kernel dominate; profiles/)',
             'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / step time, per GPU; the [M,512] layers '
                     'are HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
     if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample, ~15 s)
