@@ -18,40 +18,78 @@ namespace {
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kLn2 = 0.69314718055994530942f;
 
+// IPL > 0: list_size <= 64 * IPL, the loads of a list are all issued before the first use (memory-level
+// parallelism is what an HBM-bound kernel of four-iteration waves lacks); IPL == 0: chunked loop, any list size.
+// Four lists per 256-thread workgroup.
 template <int KIND>
-__global__ __launch_bounds__(64) void pointwise_wave_kernel(
+__device__ __forceinline__ void point_item(const float lab, const float logit, const bool m, float w, const float lw,
+                                           const float temperature, float& sl, float& sw, float& nz, float& dout) {
+  const bool lv = lab >= 0.0f;
+  const float y = m ? lab : 0.0f;
+  const float x = m ? logit / temperature : 0.0f;
+  w = (lv && m) ? w * lw : 0.0f;
+  float l, d;
+  if (KIND == TFR_POINT_SIGMOID_CE) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * kLog2e);          // exp(-|x|)
+    l = fmaxf(x, 0.0f) - x * y + log1pf(e);
+    const float q = 1.0f / (1.0f + e);                                    // sigma(|x|)
+    d = ((x >= 0.0f) ? q : e * q) - y;
+  } else {
+    const float t = y - x;
+    l = t * t;
+    d = -2.0f * t;
+  }
+  sl = __builtin_fmaf(w, l, sl);
+  sw += w;
+  nz += (w != 0.0f) ? 1.0f : 0.0f;
+  dout = m ? (w * d) / temperature : 0.0f;
+}
+
+template <int KIND, int IPL>
+__global__ __launch_bounds__(256) void pointwise_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
-    const float* __restrict__ item_weights, const float* __restrict__ list_weights, int L, float temperature,
+    const float* __restrict__ item_weights, const float* __restrict__ list_weights, int B, int L, float temperature,
     float* __restrict__ list_loss, float* __restrict__ list_weight, float* __restrict__ list_nnz,
     float* __restrict__ dlogits) {
-  const int lane = threadIdx.x, b = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
   const size_t base = (size_t)b * L;
   const float lw = list_weights ? list_weights[b] : 1.0f;
-  const float inv_t = 1.0f / temperature;
   float sl = 0.f, sw = 0.f, nz = 0.f;
-  for (int i = lane; i < L; i += 64) {
-    const float lab = labels[base + i];
-    const bool lv = lab >= 0.0f;
-    const bool m = mask ? (mask[base + i] != 0) : lv;
-    const float y = m ? lab : 0.0f;
-    const float x = m ? logits[base + i] / temperature : 0.0f;
-    float w = item_weights ? item_weights[base + i] : 1.0f;
-    w = (lv && m) ? w * lw : 0.0f;
-    float l, d;
-    if (KIND == TFR_POINT_SIGMOID_CE) {
-      const float e = __builtin_amdgcn_exp2f(-fabsf(x) * kLog2e);          // exp(-|x|)
-      l = fmaxf(x, 0.0f) - x * y + log1pf(e);
-      const float q = 1.0f / (1.0f + e);                                    // sigma(|x|)
-      d = ((x >= 0.0f) ? q : e * q) - y;
-    } else {
-      const float t = y - x;
-      l = t * t;
-      d = -2.0f * t;
+  if (IPL > 0) {
+    constexpr int N = IPL > 0 ? IPL : 1;
+    float lab[N], lg[N], w[N];
+    bool m[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const int i = lane + 64 * r;
+      lab[r] = -1.0f; lg[r] = 0.f; w[r] = 1.0f; m[r] = false;
+      if (i < L) {
+        lab[r] = labels[base + i];
+        lg[r] = logits[base + i];
+        if (item_weights) w[r] = item_weights[base + i];
+        m[r] = mask ? (mask[base + i] != 0) : (lab[r] >= 0.0f);
+      }
     }
-    sl = __builtin_fmaf(w, l, sl);
-    sw += w;
-    nz += (w != 0.0f) ? 1.0f : 0.0f;
-    if (dlogits) dlogits[base + i] = m ? (w * d) * inv_t : 0.0f;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+      const int i = lane + 64 * r;
+      if (i < L) {
+        float d;
+        point_item<KIND>(lab[r], lg[r], m[r], w[r], lw, temperature, sl, sw, nz, d);
+        if (dlogits) dlogits[base + i] = d;
+      }
+    }
+  } else {
+    for (int i = lane; i < L; i += 64) {
+      const float lab = labels[base + i];
+      const bool m = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      float d;
+      point_item<KIND>(lab, logits[base + i], m, item_weights ? item_weights[base + i] : 1.0f, lw, temperature,
+                       sl, sw, nz, d);
+      if (dlogits) dlogits[base + i] = d;
+    }
   }
   sl = wave_sum_u(sl); sw = wave_sum_u(sw); nz = wave_sum_u(nz);
   if (lane == 0) {
@@ -71,13 +109,10 @@ extern "C" int tfr_pointwise_loss_f32(int kind, const float* logits, const float
   if (kind != TFR_POINT_SIGMOID_CE && kind != TFR_POINT_MSE) return TFR_EINVAL;
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (kind == TFR_POINT_SIGMOID_CE)
-    hipLaunchKernelGGL(pointwise_wave_kernel<TFR_POINT_SIGMOID_CE>, dim3(B), dim3(64), 0, st, logits, labels, mask,
-                       item_weights, list_weights, L, temperature, list_loss_out, list_weight_out, list_nnz_out,
-                       dlogits_out);
-  else
-    hipLaunchKernelGGL(pointwise_wave_kernel<TFR_POINT_MSE>, dim3(B), dim3(64), 0, st, logits, labels, mask,
-                       item_weights, list_weights, L, temperature, list_loss_out, list_weight_out, list_nnz_out,
-                       dlogits_out);
+#define PW(K, I) hipLaunchKernelGGL((pointwise_wave_kernel<K, I>), dim3((B + 3) / 4), dim3(256), 0, st, logits, labels, mask, item_weights, list_weights, B, L, temperature, list_loss_out, list_weight_out, list_nnz_out, dlogits_out)
+#define PW_K(K) do { if (L <= 64) PW(K, 1); else if (L <= 128) PW(K, 2); else if (L <= 256) PW(K, 4); else if (L <= 512) PW(K, 8); else if (L <= 1024) PW(K, 16); else PW(K, 0); } while (0)
+  if (kind == TFR_POINT_SIGMOID_CE) PW_K(TFR_POINT_SIGMOID_CE); else PW_K(TFR_POINT_MSE);
+#undef PW_K
+#undef PW
   return (int)hipGetLastError();
 }

@@ -7,6 +7,7 @@
 // .individual_weights :281-296, _compute_ranks :483-500, inverse_max_dcg
 // :109-134, GumbelSampler.sample :556-644, _sample_gumbel :647-649.
 #include "common.h"
+#include <stdlib.h>
 #include "../../include/tfr_hip.h"
 
 using namespace tfr;
@@ -233,6 +234,91 @@ inline int threads_for(int L) {
   return t;
 }
 
+// Wave-per-list softmax loss for the plain case (no lambda weight, list_size <= 64 * IPL): everything of a list
+// lives in the registers of one wavefront -- no LDS, no workgroup barrier, four lists per 256-thread workgroup.
+// Same arithmetic as softmax_loss_kernel (which stays for DCGLambdaWeight.individual_weights and long lists):
+// masked logits = ln(1e-10), labels (x weights), all-zero lists -> 1e-10 on the valid entries, log-sum-exp,
+// gradient w (ptot * softmax - p) / T;  + poly-1 term.  12 B read + 4 B written per item: HBM-bound.
+template <int IPL>
+__global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int L = a.L;
+  const size_t base = (size_t)b * L;
+  const float wl = (a.item_weights && a.weights_per_list) ? a.item_weights[b] : 1.0f;
+  float z[IPL], y[IPL];
+  bool mv[IPL];
+  float lsum = 0.f, zmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {                        // all loads of the list are issued before the first use
+    const int i = lane + 64 * r;
+    z[r] = -INFINITY; y[r] = 0.f; mv[r] = false;
+    if (i < L) {
+      const float lab = a.labels[base + i];
+      const float x = a.logits[base + i];
+      mv[r] = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
+      float w = 1.0f;
+      if (a.item_weights) w = a.weights_per_list ? wl : a.item_weights[base + i];
+      z[r] = mv[r] ? x / a.temperature : kLogEps10;
+      y[r] = (mv[r] ? lab : 0.0f) * (a.item_weights ? w : 1.0f);
+      lsum += y[r];
+      zmax = fmaxf(zmax, z[r]);
+    }
+  }
+  lsum = wave_sum_u(lsum);
+  zmax = wave_max_u(zmax);
+  const bool nonzero = lsum > 0.0f;
+  float psum = 0.f, esum = 0.f, e[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const bool in = lane + 64 * r < L;
+    float yy = nonzero ? y[r] : 1e-10f;
+    yy = (in && mv[r]) ? yy : 0.0f;
+    y[r] = yy;
+    psum += yy;
+    e[r] = in ? expf(z[r] - zmax) : 0.0f;
+    esum += e[r];
+  }
+  psum = wave_sum_u(psum);
+  esum = wave_sum_u(esum);
+  const float lse = logf(esum);
+  float loss = 0.f, ptot = 0.f, pt = 0.f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const bool in = lane + 64 * r < L;
+    const float p = (psum != 0.0f) ? (y[r] / psum) : 0.0f;            // divide_no_nan
+    if (in) {
+      loss += p * (lse - (z[r] - zmax));
+      ptot += p;
+      pt += p * (e[r] / esum);
+    }
+    y[r] = p;
+  }
+  loss = wave_sum_u(loss);
+  ptot = wave_sum_u(ptot);
+  if (a.poly_eps != 0.0f) {
+    pt = wave_sum_u(pt);
+    loss += a.poly_eps * (1.0f - pt);
+  }
+  if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
+  if (!a.dlogits) return;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    if (i < L) {
+      float g = 0.f;
+      if (mv[r]) {
+        const float sm = e[r] / esum;
+        float d = ptot * sm - y[r];
+        if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[r] - pt);
+        g = lsum * (d / a.temperature);
+      }
+      a.dlogits[base + i] = g;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
@@ -270,6 +356,14 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
   a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains; a.discount = discount;
   a.L = L; a.Lp = ((L + 3) / 4) * 4; a.P = pow2_ceil(L < 2 ? 2 : L); a.temperature = temperature;
   a.loss = loss_out; a.weight = weight_out; a.dlogits = dlogits_out; a.poly_eps = epsilon;
+  static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
+  if (env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 1024) {
+    hipStream_t st = (hipStream_t)stream;
+#define SMW(I) hipLaunchKernelGGL(softmax_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, a, B)
+    if (L <= 64) SMW(1); else if (L <= 128) SMW(2); else if (L <= 256) SMW(4); else if (L <= 512) SMW(8); else SMW(16);
+#undef SMW
+    return (int)hipGetLastError();
+  }
   const size_t lds = 128 + (lambda_kind == TFR_LAMBDA_DCG ? (size_t)a.P * 8 : 0) +
                      (size_t)a.Lp * 17 + 16;
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
