@@ -98,7 +98,6 @@ struct GemmArgs {
   Drop pro_drop;                     // dropout of the layer below, applied in the A prologue (thr = 0: off)
   Drop epi_drop;                     // ... and in the EPI_RELU_BWD epilogue (the layer whose Zp is given)
   int M, N, K, tiles_m, tiles_n;
-  int ablate;                        // diagnostics only (TFR_TOWER_ABLATE): 1 no MFMA, 2 no global loads, 4 no LDS stores, 8 no C stores
 };
 
 enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2 };
@@ -160,8 +159,6 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   if (tm >= g.tiles_m) return;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = (g.K + BK - 1) / BK;
-  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-  if (g.ablate & 16) ts0 = __builtin_amdgcn_s_memtime();
 
   // staging: thread owns chunk column c = tid & 7 of rows (tid >> 3) + 32 * i.
   const int c = tid & 7, r0 = tid >> 3;
@@ -277,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   }
   store_tile(0, 0, A0, Bx);
   __syncthreads();
-  if (g.ablate & 16) ts1 = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < nk; kt += 2) {
     if (kt + 1 < nk) load_b(kt + 1, Bx);
     if (kt + 2 < nk) load_a(kt + 2, A0);
@@ -314,7 +310,6 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   }
   if (!GLA) store_a(0, 0, A0);
   __syncthreads();
-  if (g.ablate & 16) ts1 = __builtin_amdgcn_s_memtime();
   for (int kt = 0; kt < nk; kt += 2) {
     if (kt + 1 < nk) {
       glds_tile(g.B, g.ldb, n0, g.N, kt + 1, tB1);
@@ -335,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     __syncthreads();
   }
   }
-  if (g.ablate & 16) ts2 = __builtin_amdgcn_s_memtime();
 
   // ---- epilogue.  Lane holds D[n = nb + 4*fq + r][m = mb + fr], r = 0..3.  The staging
   // buffers are dead: every wave transposes its 64 x 64 bf16 result through a private LDS
@@ -410,7 +404,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       *reinterpret_cast<uint2*>(slot) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     }
   }
-  if (EPI != EPI_PLAIN && !(g.ablate & 16) && mb < g.M) {
+  if (EPI != EPI_PLAIN && mb < g.M) {
     // column partials of this wave's 64 rows: stats[(2 tm + wm)][which][n]  (one row per 64-row slab below M)
     float* st = g.stats + ((long)(tm * 2 + wm) * 2) * g.N;
 #pragma unroll
@@ -429,11 +423,6 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     if (mb + row < g.M && nb + cc * 8 < g.N)      // N % 8 == 0 is checked on the host
       *reinterpret_cast<uint4*>(g.C + (mb + row) * g.ldc + nb + cc * 8) =
           *reinterpret_cast<const uint4*>(wl + row * WPITCH + cc * 16);
-  }
-  if ((g.ablate & 16) && tid == 0) {
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(g.stats) + (long)(tm * g.tiles_n + tn) * 5;
-    dbg[0] = ts0; dbg[1] = ts1; dbg[2] = ts2; dbg[3] = __builtin_amdgcn_s_memtime();
-    dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID
   }
 }
 
@@ -1180,7 +1169,6 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
-  { const char* e = getenv("TFR_TOWER_ABLATE"); g.ablate = (e && *e) ? atoi(e) : 0; }
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
   TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);

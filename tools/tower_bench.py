@@ -43,30 +43,6 @@ def main():
             ms = timeit(fn)
             print('M=%d N=%d K=%d %-26s %8.3f ms  %7.1f TFLOP/s  %6.0f GB/s' % (
                 M, N, K, name, ms, flops / ms / 1e9, byts / ms / 1e6))
-    if int(os.environ.get('TFR_TOWER_ABLATE', '0')) & 16:
-        C, stats = t.gemm(A, W, N, K, prologue=2, a_scale=sc, a_shift=sh, bias=bias, epilogue=t.EPI_STATS, out=out)
-        torch.cuda.synchronize()
-        torch.cuda.synchronize()
-        nb = ((M + 127) // 128) * ((N + 127) // 128)
-        d = stats.view(torch.int64).flatten()[:nb * 5].view(nb, 5).cpu()
-        t0, t1, t2, t3, hw = d[:, 0], d[:, 1], d[:, 2], d[:, 3], d[:, 4]
-        print('blocks %d: prologue %.0f  kloop %.0f  epilogue %.0f  total %.0f ticks (mean); span %.0f ticks' % (
-            nb, (t1 - t0).float().mean(), (t2 - t1).float().mean(), (t3 - t2).float().mean(),
-            (t3 - t0).float().mean(), float(t3.max() - t0.min())))
-        cu = (hw >> 8) & 0xf; se = (hw >> 13) & 0x7; xcc = (hw >> 20) & 0xf   # best-effort decode
-        import collections
-        key = (hw & 0xfffffff0).tolist()
-        print('distinct hw ids (sans wave slot):', len(set(key)))
-        # concurrency: for a sample of blocks, how many other blocks on the same hw id overlap in time
-        by = collections.defaultdict(list)
-        for i, k_ in enumerate(key):
-            by[k_].append((int(t0[i]), int(t3[i])))
-        ov = []
-        for k_, lst in list(by.items())[:64]:
-            lst.sort()
-            for i, (a, b) in enumerate(lst[:20]):
-                ov.append(sum(1 for (c, e) in lst if c < b and e > a))
-        print('mean concurrent blocks per hw id: %.2f' % (sum(ov) / max(1, len(ov))))
     z = torch.randn((M, 512), device=dev).to(torch.bfloat16)
     w = torch.randn((1, 512), device=dev) * 0.05
     b = torch.zeros(1, device=dev)
