@@ -228,6 +228,90 @@ __global__ void gumbel_sample_bwd_kernel(const float* __restrict__ sampled, cons
   }
 }
 
+// Wave-per-row forms of the Gumbel sampler (list_size <= 64 * IPL): one wavefront per sampled row (b, s) forward,
+// per list b backward; values in registers, wave reductions, four rows per workgroup.  Same arithmetic and the same
+// Philox counters (one per output element) as the workgroup kernels above, which stay for longer lists.
+template <int IPL>
+__global__ __launch_bounds__(256) void gumbel_sample_wave_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ uniform, uint64_t seed, uint64_t offset, int BS, int S, int L,
+    float gumbel_temperature, float* __restrict__ sampled_out) {
+  const int lane = threadIdx.x & 63;
+  const int bs = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bs >= BS) return;
+  const int b = bs / S;
+  const size_t ibase = (size_t)b * L, obase = (size_t)bs * L;
+  float z[IPL];
+  float zmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    z[r] = -INFINITY;
+    if (i < L) {
+      const float lab = labels[ibase + i];
+      const bool v = mask ? (mask[ibase + i] != 0) : (lab >= 0.0f);
+      float u;
+      if (uniform) u = uniform[obase + i];
+      else u = (float)(philox_first(obase + i, offset, seed) >> 8) * (1.0f / 16777216.0f);
+      const float g = -logf(-logf(u + 1e-20f) + 1e-20f);            // :647-649
+      z[r] = v ? ((logits[ibase + i] + g) / gumbel_temperature) : kLogEps20;
+      zmax = fmaxf(zmax, z[r]);
+    }
+  }
+  zmax = wave_max_u(zmax);
+  float esum = 0.f, e[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { e[r] = (lane + 64 * r < L) ? expf(z[r] - zmax) : 0.0f; esum += e[r]; }
+  esum = wave_sum_u(esum);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    if (i < L) sampled_out[obase + i] = logf(e[r] / esum + 1e-20f);   // :605
+  }
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) void gumbel_sample_bwd_wave_kernel(
+    const float* __restrict__ sampled, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ upstream, int B, int S, int L, float gumbel_temperature,
+    float* __restrict__ dlogits_out) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const size_t ibase = (size_t)b * L;
+  float acc[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) acc[r] = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const size_t obase = ((size_t)b * S + s) * L;
+    // out_k = log(p_k + eps): d out_k / d z_j = c_k (delta_kj - p_j), c_k = p_k / (p_k + eps)
+    float p[IPL], t[IPL], dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int i = lane + 64 * r;
+      p[r] = 0.f; t[r] = 0.f;
+      if (i < L) {
+        const float e = expf(sampled[obase + i]);           // p + eps
+        p[r] = fmaxf(e - 1e-20f, 0.0f);
+        t[r] = upstream[obase + i] * (p[r] / e);
+        dot += t[r];
+      }
+    }
+    dot = wave_sum_u(dot);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) acc[r] += t[r] - p[r] * dot;
+  }
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    if (i < L) {
+      const float lab = labels[ibase + i];
+      const bool v = mask ? (mask[ibase + i] != 0) : (lab >= 0.0f);
+      dlogits_out[ibase + i] = v ? (acc[r] / gumbel_temperature) : 0.0f;
+    }
+  }
+}
+
 inline int threads_for(int L) {
   int t = ((L + 63) / 64) * 64;
   if (t > 256) t = 256;
@@ -386,6 +470,14 @@ extern "C" int tfr_gumbel_sample_f32(const float* logits, const float* labels, c
     return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
+  if (L <= 1024) {
+    hipStream_t st = (hipStream_t)stream;
+    const int BS = B * S;
+#define GW(I) hipLaunchKernelGGL(gumbel_sample_wave_kernel<I>, dim3((BS + 3) / 4), dim3(256), 0, st, logits, labels, mask, uniform, seed, offset, BS, S, L, gumbel_temperature, sampled_out)
+    if (L <= 64) GW(1); else if (L <= 128) GW(2); else if (L <= 256) GW(4); else if (L <= 512) GW(8); else GW(16);
+#undef GW
+    return (int)hipGetLastError();
+  }
   const int Lp = ((L + 3) / 4) * 4;
   hipLaunchKernelGGL(gumbel_sample_kernel, dim3(B * S), dim3(threads_for(L)), 128 + (size_t)Lp * 4,
                      (hipStream_t)stream, logits, labels, mask, uniform, seed, offset, S, L, Lp,
@@ -401,6 +493,13 @@ extern "C" int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labe
     return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
+  if (L <= 1024) {
+    hipStream_t st = (hipStream_t)stream;
+#define GB(I) hipLaunchKernelGGL(gumbel_sample_bwd_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, sampled, labels, mask, upstream, B, S, L, gumbel_temperature, dlogits_out)
+    if (L <= 64) GB(1); else if (L <= 128) GB(2); else if (L <= 256) GB(4); else if (L <= 512) GB(8); else GB(16);
+#undef GB
+    return (int)hipGetLastError();
+  }
   const int Lp = ((L + 3) / 4) * 4;
   hipLaunchKernelGGL(gumbel_sample_bwd_kernel, dim3(B), dim3(threads_for(L)), 128 + (size_t)Lp * 4,
                      (hipStream_t)stream, sampled, labels, mask, upstream, S, L, gumbel_temperature,
