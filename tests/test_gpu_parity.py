@@ -1280,3 +1280,57 @@ def test_poly_one_softmax_parity(B, L, eps):
     s0, s1 = sm(scores[0])[2], sm(scores[1])[2]
     want = -((math.log(s0) - 3 * (1 - s0)) + (math.log(s1) - 3 * (1 - s1)) * 2.) / 2.          # losses_impl_test.py:1208-1226
     assert abs(fn(lb, torch.tensor(scores, device=DEV), {}).item() - want) < 1e-5
+
+
+# ---------------------------------------------- full-size properties of the widened kernels (B=16384, L=200)
+def test_widened_kernels_at_headline_size():
+    """Every fused loss of SURVEY 8f at the headline batch: finite everywhere, no gradient on padding, shift
+    invariance (sum_k grad_k = 0) where the loss only sees score differences, list-permutation equivariance,
+    and oracle parity on a 48-list slice (the oracle materialises [B, L, L] tensors: seconds per 48 lists)."""
+    from ranking_amd import _ops
+    B, L, n = 16384, 200, 48
+    labels, logits = make_batch(B, L, seed=6)
+    g = torch.Generator().manual_seed(2)
+    labels = torch.where(labels >= 0, labels + torch.rand(labels.shape, generator=g) * 0.25, labels)   # tie-free labels
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    sim = 0.25 + 0.3 * torch.sigmoid(logits)        # similarity scores; over the whole of [0, 1] the reference's exp(64 (a + b)) is inf
+    K = ra().keras.losses
+    cases = [
+        ('pairwise+lambda', lambda s, y: _ops.pairwise_logistic(s, y, want_aux=False, **ra().losses_impl._lambda_kernel_args(K.NDCGLambdaWeight(), y, L, torch.device(DEV)))[::3],
+         lambda: R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight()), True, logits, 'rows'),
+        ('pairwise mse', lambda s, y: _ops.pairwise_logistic(s, y, loss_kind=_ops.PAIR_MSE)[::3], lambda: R.PairwiseMSELoss(), True, logits, 'rows'),
+        ('list_mle', lambda s, y: _ops.list_mle(s, y), lambda: R.ListMLELoss(), True, logits, 'list'),
+        ('unique_softmax', lambda s, y: _ops.unique_softmax(s, y), lambda: R.UniqueSoftmaxLoss(), True, logits, 'list'),
+        ('softmax', lambda s, y: _ops.softmax_loss(s, y)[::2], lambda: R.SoftmaxLoss(), True, logits, 'softmax'),
+        ('neural_sort_ndcg', lambda s, y: _ops.neural_sort_loss(_ops.NEURAL_SORT_NDCG, s, y), lambda: R.NeuralSortNDCGLoss(), True, logits, 'list'),
+        ('neural_sort_ce', lambda s, y: _ops.neural_sort_loss(_ops.NEURAL_SORT_CE, s, y), lambda: R.NeuralSortCrossEntropyLoss(), True, logits, 'list'),
+        ('circle', lambda s, y: _ops.circle_loss(s, y)[::2], lambda: R.CircleLoss(), False, sim, 'circle'),
+        ('sigmoid_ce', lambda s, y: _ops.pointwise_loss(_ops.POINT_SIGMOID_CE, s, y)[::3], lambda: R.SigmoidCrossEntropyLoss(), False, logits, 'point'),
+    ]
+    perm_b = torch.randperm(B, device=DEV)
+    for name, fn, octor, shift_inv, scores, kind in cases:
+        sc = scores.to(DEV)
+        out, d = fn(sc, lb)
+        assert torch.isfinite(out).all() and torch.isfinite(d).all(), name
+        assert (d[lb < 0] == 0).all(), name
+        if shift_inv:
+            assert d.sum(dim=1).abs().max().item() <= 2e-4 * max(1.0, d.abs().max().item()), name
+        out2, d2 = fn(sc[perm_b], lb[perm_b])                       # lists are independent: permuting them permutes the results
+        assert torch.equal(out2, out[perm_b]) and torch.equal(d2, d[perm_b]), name
+        # oracle slice
+        oracle = octor()
+        y, x = labels[:n], scores[:n].clone().requires_grad_(True)
+        if kind == 'softmax':
+            lo, w = oracle.compute_per_list(y, x, None); (lo * w).sum().backward(); want = lo
+        elif kind == 'circle':
+            lo, w = oracle._compute_unreduced_loss_impl(y, oracle.get_logits(x)); lo.sum().backward(); want = lo.reshape(-1)
+        elif kind == 'point':
+            lo, w = oracle._compute_unreduced_loss_impl(y, x); (lo * w).sum().backward(); want = (lo * w).sum(dim=1)
+        elif kind == 'rows':
+            lo, w = oracle._compute_unreduced_loss_impl(y, x, y >= 0); (lo * w).sum().backward(); want = (lo * w).sum(dim=2)
+        else:
+            lo, w = oracle._compute_unreduced_loss_impl(y, x); lo.sum().backward(); want = lo.reshape(-1)
+        scale = max(1.0, want.abs().max().item())
+        tol = 2e-4 if name.startswith('neural') else 1e-5          # NeuralSort: exp(c_t s_k - A_k) conditioned by L |s| (fp64-arbitrated elsewhere)
+        assert_loss_close(out[:n].reshape(want.shape) / scale, want.detach() / scale, tol, name)
+        assert_grad_close(d[:n], x.grad, 10 * tol, name + ' grad')
