@@ -59,7 +59,9 @@ def test_cast_weight():
 
 
 @pytest.mark.parametrize('M,N,K', [(1, 8, 8), (128, 128, 64), (300, 136, 136), (257, 512, 512), (1000, 128, 200),
-                                   (129, 520, 72)])
+                                   (129, 520, 72),
+                                   # the 256 x 256 LDS-DMA kernel: ragged M / N edges, one k step, many k steps
+                                   (700, 320, 320), (1000, 264, 128), (256, 256, 64), (511, 1024, 1024)])
 @pytest.mark.parametrize('pro', [0, 1, 2])
 def test_gemm_forward_modes(M, N, K, pro):
     t = T()
