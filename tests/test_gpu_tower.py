@@ -381,3 +381,26 @@ def test_flatten_gather_fused_into_the_cast_matches_the_unfused_scorer():
     rows = torch.randint(0, B * L, (500,), generator=torch.Generator().manual_seed(2)).to(DEV)
     flat = x.reshape(B * L, F)
     assert torch.equal(T.cast_rows(flat, row_index=rows), T.cast_rows(flat[rows]))
+
+
+@pytest.mark.parametrize('M,N,K', [(300, 136, 72), (257, 512, 512), (700, 320, 320), (1000, 264, 128), (511, 256, 1024)])
+def test_gemm_relu_bwd_epilogue(M, N, K):
+    """dgrad form: C = (A . B^T) * 1[Zp * e_scale + e_shift > 0], stats = per-slab (sum C, sum C * zhat),
+    zhat = (Zp - e_mean) * e_rstd -- both GEMM kernels (K % 64 decides), ragged edges."""
+    t = T()
+    A = (rnd((M, K), 40 + M).to(DEV) + torch.arange(M, device=DEV).unsqueeze(1) % 7 * 0.125).to(torch.bfloat16)
+    W = (rnd((N, K), 41 + N, 0.1).to(DEV) + torch.arange(N, device=DEV).unsqueeze(1) % 5 * 0.0625).to(torch.bfloat16)
+    Zp = rnd((M, N), 42).to(DEV).to(torch.bfloat16)
+    es = (rnd((N,), 43) * 0.5 + 1.0).to(DEV); eh = rnd((N,), 44, 0.3).to(DEV)
+    em = rnd((N,), 45, 0.2).to(DEV); er = (rnd((N,), 46).abs() + 0.5).to(DEV)
+    C, stats = t.gemm(A, W, N, K, prologue=t.PRO_NONE, epilogue=t.EPI_RELU_BWD, Zp=Zp, e_scale=es, e_shift=eh,
+                      e_mean=em, e_rstd=er)
+    z = Zp.float()
+    want = (A.float() @ W.float().t()) * ((z * es + eh) > 0).float()
+    bf16_close(C, want, 'dy')
+    assert stats.shape == (t.stats_rows(M), 2, N)
+    s = stats.sum(dim=0)
+    zhat = (z - em) * er
+    lim = 4e-3 * max(1.0, want.abs().max().item()) * M ** 0.5 + 1e-2
+    assert (s[0] - want.sum(dim=0)).abs().max().item() <= lim
+    assert (s[1] - (want * zhat).sum(dim=0)).abs().max().item() <= lim * max(1.0, zhat.abs().max().item())
