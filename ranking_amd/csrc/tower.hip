@@ -533,6 +533,20 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   }
   if (!GLA) store_a(0, tiles, R);
   __syncthreads();
+  // EPI_RELU_BWD: the epilogue needs the wave's 64 x 128 piece of Zp.  With one workgroup per CU nothing else
+  // would cover those loads, so they are software-pipelined: half 0 is requested during the last k step (its
+  // 64 MFMAs hide the HBM round trip), half 1 while half 0 is being processed.
+  const long mb = m0 + wm * 64;
+  uint4 zq[8];
+  auto zp_load = [&](int h) {
+    const int nbz = n0 + wn * 128 + h * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
+      zq[i] = (mb + row < g.M && nbz + cc * 8 < g.N)
+                  ? *reinterpret_cast<const uint4*>(g.Zp + (mb + row) * g.ldz + nbz + cc * 8) : make_uint4(0, 0, 0, 0);
+    }
+  };
 #pragma unroll 1
   for (int kt = 0; kt < nk; ++kt) {
     unsigned char* const tAc = tiles + (kt & 1) * (2 * TILE2_BYTES);
@@ -543,6 +557,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
       if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 1, tAn);
       else load_a(kt + 1, R);
     }
+    if (EPI == EPI_RELU_BWD && !more) zp_load(0);
     compute(tAc, tAc + TILE2_BYTES);
     if (!GLA && more) store_a(kt + 1, tAn, R);
     __syncthreads();
@@ -551,7 +566,6 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   // ---- epilogue: the wave's 64 x 128 result as two 64 x 64 halves through its private LDS region
   // (same code shape as the 128 x 128 kernel; DS operations of a wave complete in order).
   unsigned char* wl = smem + wave * (64 * WPITCH);
-  const long mb = m0 + wm * 64;
   const bool slab_live = mb < g.M;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -560,11 +574,9 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
-        uint4 zz = make_uint4(0, 0, 0, 0);
-        if (mb + row < g.M && nb + cc * 8 < g.N)
-          zz = *reinterpret_cast<const uint4*>(g.Zp + (mb + row) * g.ldz + nb + cc * 8);
-        *reinterpret_cast<uint4*>(wl + row * WPITCH + cc * 16) = zz;
+        *reinterpret_cast<uint4*>(wl + row * WPITCH + cc * 16) = zq[i];
       }
+      if (h == 0) zp_load(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     float* const st = g.stats + ((long)(tm * 4 + wm) * 2) * g.N;      // one row of partials per 64-row slab
