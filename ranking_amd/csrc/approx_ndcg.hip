@@ -331,7 +331,7 @@ __device__ __forceinline__ void wave_sort_desc(uint32_t (&a)[IPL], int lane) {
       } else {
 #pragma unroll
         for (int r = 0; r < IPL; ++r) {
-          const uint32_t p = (uint32_t)__shfl_xor((int)a[r], j, 64);
+          const uint32_t p = wave_xor_exchange(a[r], j);
           const int e = lane | (r << 6);
           const bool desc = ((e & kk) == 0);
           const bool lower = ((lane & j) == 0);

@@ -149,6 +149,28 @@ __device__ __forceinline__ float exp_df(float t_hi, float t_lo) {
 }
 
 
+// value of lane (lane ^ j), j a power of two < 64.  j = 1, 2, 4, 8 stay inside a 16-lane DPP row: one or two
+// v_mov_b32_dpp per dword (quad_perm for 1 and 2, row_ror:8 for 8, row_shr:4 + row_shl:4 on complementary banks for
+// 4) instead of a ds_bpermute round trip through the LDS crossbar -- 26 of the 33 cross-lane stages of a 256-key
+// bitonic sort.  j = 16, 32 cross rows: ds_bpermute.  (j is a literal after unrolling: the switch folds.)
+__device__ __forceinline__ uint32_t wave_xor_exchange(uint32_t v, int j) {
+  const int x = (int)v;
+  switch (j) {
+    case 1: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);      // quad_perm:[1,0,3,2]
+    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);      // quad_perm:[2,3,0,1]
+    case 4: {
+      const int t = __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xa, false);              // row_shr:4 -> banks 1, 3
+      return (uint32_t)__builtin_amdgcn_update_dpp(t, x, 0x104, 0xf, 0x5, false);           // row_shl:4 -> banks 0, 2
+    }
+    case 8: return (uint32_t)__builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);     // row_ror:8
+    default: return (uint32_t)__shfl_xor(x, j, 64);
+  }
+}
+__device__ __forceinline__ uint64_t wave_xor_exchange(uint64_t v, int j) {
+  const uint32_t lo = wave_xor_exchange((uint32_t)v, j), hi = wave_xor_exchange((uint32_t)(v >> 32), j);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 // ---------------------------------------------------------------- wave-per-list helpers
 // Bitonic sort, DESCENDING, of 64*IPL keys held in registers: element e = lane + 64*r
 // lives in a[r] of `lane`.  No LDS, no barriers (cross-lane exchanges are wave shuffles).
@@ -175,7 +197,7 @@ __device__ __forceinline__ void wave_bitonic_sort_desc(K (&a)[IPL], int lane) {
       } else {
 #pragma unroll
         for (int r = 0; r < IPL; ++r) {
-          const K p = __shfl_xor(a[r], j, 64);
+          const K p = wave_xor_exchange(a[r], j);
           const int e = lane | (r << 6);
           const bool desc = ((e & kk) == 0);
           const bool lower = ((lane & j) == 0);
