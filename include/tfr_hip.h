@@ -337,6 +337,14 @@ int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const
                       const float* shift, const float* mean, const float* rstd, const float* w,
                       const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
                       int n_blocks, const tfr_tower_dropout* dropout, void* stream);
+/* The same in two passes around the BatchNorm-backward coefficients, so that the [M, K] gradient is written once:
+ *   pass 1: dy_bf16 = NULL           -> only `partial` (sum dy, sum dy * zhat, dW_out) ;
+ *   pass 2: partial = NULL, pqr[3][K] -> dy_bf16 receives dz = p * bf16(dy) + q * z + r (tfr_tower_bn_bwd_apply fused in).
+ * pqr = NULL and both outputs given = tfr_tower_out_bwd. */
+int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                       const float* shift, const float* mean, const float* rstd, const float* w,
+                       const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
+                       int n_blocks, const tfr_tower_dropout* dropout, const float* pqr, void* stream);
 /* BatchNormalization backward, in place: dy <- p[k]*dy + q[k]*z + r[k]; pqr is fp32 [3][K]. */
 int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, long ldz, int M, int K,
                            const float* pqr, void* stream);

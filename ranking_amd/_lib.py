@@ -89,6 +89,9 @@ _SIGNATURES = {
     'tfr_tower_out_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                           + [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long]
                           + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'tfr_tower_out_bwd2': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
+                           + [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long]
+                           + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_bn_bwd_apply': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 2
                                + [ctypes.c_void_p] * 2),
     'tfr_tower_wgrad_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 2 + [ctypes.c_int] * 4

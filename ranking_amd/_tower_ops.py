@@ -161,7 +161,7 @@ def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
     return out
 
 
-def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=512, dropout=None):
+def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=1024, dropout=None):
     """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
     sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]."""
     _bf16(z, 'z')
@@ -177,6 +177,32 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
                                              dy.stride(0), _ptr(partial), n_blocks, _dp(dropout), _stream()),
                'tfr_tower_out_bwd')
     return dy, reduce_partials(partial)
+
+
+def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits, n_blocks=1024, dropout=None):
+    """Output-layer backward when the last hidden layer is BatchNorm'd, in two passes over z so the
+    [M, K] gradient is written once: pass 1 = column sums only, pass 2 recomputes dy and writes
+    dz = p * bf16(dy) + q * z + r.  Returns (dz bf16 [M, K], sums [2 + O, K]) -- bit-identical to
+    out_layer_bwd + bn_bwd_coeffs + bn_bwd_apply_."""
+    _bf16(z, 'z')
+    M = z.shape[0]
+    w = w.detach().to(torch.float32).contiguous()
+    O = w.shape[0]
+    dlogits = dlogits.to(torch.float32).contiguous()
+    n_blocks = max(1, min(n_blocks, (M + 15) // 16))
+    lib = _lib.load()
+    partial = torch.empty((n_blocks, 2 + O, K), dtype=torch.float32, device=z.device)
+    _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
+                                      _ptr(rstd), _ptr(w), _ptr(dlogits), O, None, K, _ptr(partial), n_blocks,
+                                      _dp(dropout), None, _stream()), 'tfr_tower_out_bwd2')
+    sums = reduce_partials(partial)
+    pqr = bn_bwd_coeffs(gamma, rstd, mean, sums[:2], M)
+    dz = torch.empty((M, K), dtype=torch.bfloat16, device=z.device)
+    n2 = max(1, min(4096, (M + 15) // 16))
+    _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
+                                      _ptr(rstd), _ptr(w), _ptr(dlogits), O, _ptr(dz), dz.stride(0), None, n2,
+                                      _dp(dropout), _ptr(pqr), _stream()), 'tfr_tower_out_bwd2')
+    return dz, sums
 
 
 def bn_bwd_coeffs(gamma, rstd, mean, c, M):

@@ -822,77 +822,119 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
 // Output layer backward.  logits[m, o] = sum_k a[m, k] w[o, k] + b[o], a = act(z):
 //   dy[m, k] = (sum_o dlogits[m, o] w[o, k]) * 1[y > 0]   -> bf16 [M, K]
 //   partial[blk][0][k] = sum_m dy, [1][k] = sum_m dy * zhat, [2 + o][k] = sum_m dlogits[m, o] a[m, k]
-template <int PRO>
+// MODE 0: dy and partial (the plain backward).  MODE 1: partial only -- first pass of the BatchNorm backward,
+// nothing of size [M, K] is written.  MODE 2: second pass, d is recomputed and dz = p * bf16(d) + q * z + r
+// goes straight out (instead of: write dy, read dy + z, write dz).
+// LPR lanes share one row (8 columns each): 64 = a wave reads 1 KB of a row (K >= 512), 16 for narrower layers.
+// OT = O when 1 (the usual single logit), else 4 (loops run to O).
+template <int PRO, int OT, int LPR, int MODE>
 __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
-    float* __restrict__ partial, int rows_per_block, const Drop drop) {
+    float* __restrict__ partial, int rows_per_block, const Drop drop, const float* __restrict__ pqr) {
+  constexpr int G = 256 / LPR, CW = LPR * 8;                   // row groups per block, columns per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* red = reinterpret_cast<float*>(smem);                 // [16][(2 + O) * 128]
-  const int lane16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  float* red = reinterpret_cast<float*>(smem);                 // [G][(2 + O) * CW]
+  const int lane = threadIdx.x % LPR;
+  const int grp = (LPR == 64) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : (int)(threadIdx.x / LPR);
   const long mb = (long)blockIdx.x * rows_per_block;
   const long me = (mb + rows_per_block < M) ? mb + rows_per_block : M;
   const int J = 2 + O;
-  for (int kp = 0; kp < K; kp += 128) {
-    const int k = kp + lane16 * 8;
+  for (int kp = 0; kp < K; kp += CW) {
+    const int k = kp + lane * 8;
     const bool kin = k < K;
-    float sc[8], sh[8], mu[8], rs[8], ww[4][8];
+    float sc[8], sh[8], mu[8], rs[8], ww[OT][8], cp[8], cq[8], cr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+      cp[e] = (kin && MODE == 2) ? pqr[k + e] : 1.f;
+      cq[e] = (kin && MODE == 2) ? pqr[K + k + e] : 0.f;
+      cr[e] = (kin && MODE == 2) ? pqr[2 * K + k + e] : 0.f;
       sc[e] = (kin && PRO != PRO_NONE) ? scale[k + e] : 1.f;
       sh[e] = (kin && PRO != PRO_NONE) ? shift[k + e] : 0.f;
-      mu[e] = (kin && mean) ? mean[k + e] : 0.f;
-      rs[e] = (kin && rstd) ? rstd[k + e] : 1.f;
+      mu[e] = (kin && mean && MODE != 2) ? mean[k + e] : 0.f;
+      rs[e] = (kin && rstd && MODE != 2) ? rstd[k + e] : 1.f;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) ww[o][e] = (kin && o < O) ? w[(long)o * K + k + e] : 0.f;
+      for (int o = 0; o < OT; ++o) ww[o][e] = (kin && o < O) ? w[(long)o * K + k + e] : 0.f;
     }
-    float s1[8], s2[8], dw[4][8];
+    float s1[8], s2[8], dw[OT][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; dw[0][e] = dw[1][e] = dw[2][e] = dw[3][e] = 0.f; }
-    if (kin) {
-      for (long m = mb + grp; m < me; m += 16) {
-        const uint4 v = *reinterpret_cast<const uint4*>(z + m * ldz + k);
-        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-        float dl[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int o = 0; o < O; ++o) dl[o] = dlogits[m * O + o];
-        float out[8], kf[8];
+    for (int e = 0; e < 8; ++e) {
+      s1[e] = 0.f; s2[e] = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          kf[2 * i] = 1.f; kf[2 * i + 1] = 1.f;
-          if (PRO != PRO_NONE && drop.thr) drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), kf[2 * i], kf[2 * i + 1]);
+      for (int o = 0; o < OT; ++o) dw[o][e] = 0.f;
+    }
+    auto row = [&](long m, const uint4 v, const float (&dl)[OT]) {
+      const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+      float out[8], kf[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        kf[2 * i] = 1.f; kf[2 * i + 1] = 1.f;
+        if (PRO != PRO_NONE && drop.thr) drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), kf[2 * i], kf[2 * i + 1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
+        const float y = __builtin_fmaf(zz, sc[e], sh[e]);
+        const float a = ((PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y) * kf[e];
+        float da = 0.f;
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          da = __builtin_fmaf(dl[o], ww[o][e], da);
+          if (MODE != 2) dw[o][e] = __builtin_fmaf(dl[o], a, dw[o][e]);
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
-          const float y = __builtin_fmaf(zz, sc[e], sh[e]);
-          const float a = ((PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y) * kf[e];
-          float da = 0.f;
-#pragma unroll
-          for (int o = 0; o < 4; ++o) { da = __builtin_fmaf(dl[o], ww[o][e], da); dw[o][e] = __builtin_fmaf(dl[o], a, dw[o][e]); }
-          const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da * kf[e];
+        const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da * kf[e];
+        if (MODE != 2) {
           s1[e] += d;
           s2[e] = __builtin_fmaf(d, (zz - mu[e]) * rs[e], s2[e]);
           out[e] = d;
+        } else {                                               // the value the two-kernel path produces, bit for bit
+          const float db = bf16_lo(pack_bf16(d, 0.f));
+          out[e] = __builtin_fmaf(cp[e], db, __builtin_fmaf(cq[e], zz, cr[e]));
         }
+      }
+      if (MODE != 1)
         *reinterpret_cast<uint4*>(dy + m * lddy + k) =
             make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]), pack_bf16(out[6], out[7]));
+    };
+    if (kin) {
+      long m = mb + grp;
+      for (; m + G < me; m += 2 * G) {                         // two rows in flight
+        const uint4 v0 = *reinterpret_cast<const uint4*>(z + m * ldz + k);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(z + (m + G) * ldz + k);
+        float d0[OT], d1[OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) {
+          d0[o] = (o < O) ? dlogits[m * O + o] : 0.f;
+          d1[o] = (o < O) ? dlogits[(m + G) * O + o] : 0.f;
+        }
+        row(m, v0, d0);
+        row(m + G, v1, d1);
+      }
+      if (m < me) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(z + m * ldz + k);
+        float d0[OT];
+#pragma unroll
+        for (int o = 0; o < OT; ++o) d0[o] = (o < O) ? dlogits[m * O + o] : 0.f;
+        row(m, v0, d0);
       }
     }
+    if (MODE == 2) continue;
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float* rr = red + grp * (J * 128) + lane16 * 8 + e;
-      rr[0] = s1[e]; rr[128] = s2[e];
-      for (int o = 0; o < O; ++o) rr[(2 + o) * 128] = dw[o][e];
+      float* rr = red + grp * (J * CW) + lane * 8 + e;
+      rr[0] = s1[e]; rr[CW] = s2[e];
+#pragma unroll
+      for (int o = 0; o < OT; ++o) if (o < O) rr[(2 + o) * CW] = dw[o][e];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < J * 128; i += 256) {
-      const int jj = i / 128, kk = kp + (i & 127);
+    for (int i = threadIdx.x; i < J * CW; i += 256) {
+      const int jj = i / CW, kk = kp + (i % CW);
       if (kk < K) {
         float t = 0.f;
 #pragma unroll
-        for (int gq = 0; gq < 16; ++gq) t += red[gq * (J * 128) + i];
+        for (int gq = 0; gq < G; ++gq) t += red[gq * (J * CW) + i];
         partial[((long)blockIdx.x * J + jj) * K + kk] = t;
       }
     }
@@ -1245,22 +1287,42 @@ extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prol
   return (int)hipGetLastError();
 }
 
+extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* w,
+                                  const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
+                                  int n_blocks, const tfr_tower_dropout* dropout, const float* pqr, void* stream);
+
 extern "C" int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                                  const float* shift, const float* mean, const float* rstd, const float* w,
                                  const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
                                  int n_blocks, const tfr_tower_dropout* dropout, void* stream) {
-  if (!z || !w || !dlogits || !dy_bf16 || !partial || M <= 0 || K <= 0 || (K & 7) || (ldz & 7) || (lddy & 7) ||
+  return tfr_tower_out_bwd2(z, ldz, M, K, prologue, scale, shift, mean, rstd, w, dlogits, O, dy_bf16, lddy, partial,
+                            n_blocks, dropout, nullptr, stream);
+}
+
+extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int prologue, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, const float* w,
+                                  const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
+                                  int n_blocks, const tfr_tower_dropout* dropout, const float* pqr, void* stream) {
+  if (!z || !w || !dlogits || (!dy_bf16 && !partial) || M <= 0 || K <= 0 || (K & 7) || (ldz & 7) || (lddy & 7) ||
       O < 1 || O > 4 || n_blocks < 1) return TFR_EINVAL;
+  if (pqr && (!dy_bf16 || partial)) return TFR_EINVAL;       // the apply pass writes dz and nothing else
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
   int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
   rows = (rows + 15) / 16 * 16;
-  const size_t lds = (size_t)16 * (2 + O) * 128 * sizeof(float);
+  const size_t lds = (size_t)2048 * (2 + O) * sizeof(float);   // G * CW = 2048 either way
   hipStream_t st = (hipStream_t)stream;
   const Drop dr = to_drop(dropout);
-#define OB(P) hipLaunchKernelGGL(tower_out_bwd_kernel<P>, dim3(n_blocks), dim3(256), lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr)
+  const int mode = pqr ? 2 : (dy_bf16 ? 0 : 1);
+  const bool wide = K >= 512;
+#define OB4(P, OT, LPR, MD) hipLaunchKernelGGL((tower_out_bwd_kernel<P, OT, LPR, MD>), dim3(n_blocks), dim3(256), MD == 2 ? 0 : lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr, pqr)
+#define OB3(P, OT, LPR) do { if (mode == 0) OB4(P, OT, LPR, 0); else if (mode == 1) OB4(P, OT, LPR, 1); else OB4(P, OT, LPR, 2); } while (0)
+#define OB(P) do { if (O == 1) { if (wide) OB3(P, 1, 64); else OB3(P, 1, 16); } else { if (wide) OB3(P, 4, 64); else OB3(P, 4, 16); } } while (0)
   if (prologue == PRO_NONE) OB(PRO_NONE); else if (prologue == PRO_AFFINE) OB(PRO_AFFINE);
   else if (prologue == PRO_AFFINE_RELU) OB(PRO_AFFINE_RELU); else return TFR_EINVAL;
 #undef OB
+#undef OB3
+#undef OB4
   return (int)hipGetLastError();
 }
 

@@ -20,6 +20,7 @@ from __future__ import annotations
 import math
 from typing import List, Optional
 
+import os
 import torch
 from torch import nn
 
@@ -113,7 +114,12 @@ class _TowerFn(torch.autograd.Function):
         # output layer
         pro, sc, sh, mean, rstd, drop = coefs[-1]
         n_last = zs[-1].shape[1]
-        dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
+        fused_last = use_bn and n_h > 0 and not os.environ.get('TFR_TOWER_NO_FUSED_LAST')
+        if fused_last:                                     # dz of the last hidden layer directly (two passes over z)
+            dy, sums = T.out_layer_bwd_bn(zs[-1], n_last, pro, sc, sh, mean, rstd, gammas[-1], w_out, dlogits,
+                                          dropout=drop)
+        else:
+            dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
         dw_out = sums[2:].contiguous()
         db_out = dlogits.sum(dim=0)
         cc = sums                                          # rows 0 / 1: sum dy, sum dy * zhat of the layer below
@@ -123,7 +129,8 @@ class _TowerFn(torch.autograd.Function):
             pro_l, sc_l, sh_l, mean_l, rstd_l, _ = coefs[l]
             if use_bn:
                 dgam[l], dbet[l] = cc[1], cc[0]
-                dz = T.bn_bwd_apply_(dy, zs[l], n_out, T.bn_bwd_coeffs(gammas[l], rstd_l, mean_l, cc[:2], M))
+                dz = dy if (fused_last and l == n_h - 1) else \
+                    T.bn_bwd_apply_(dy, zs[l], n_out, T.bn_bwd_coeffs(gammas[l], rstd_l, mean_l, cc[:2], M))
                 db[l] = db_zero[l]                         # a bias below BatchNorm has no gradient
             else:
                 dz = dy

@@ -168,6 +168,24 @@ def test_out_layer_bwd_and_bn_apply():
     bf16_close(got, want, 'dz')
 
 
+@pytest.mark.parametrize('M,K,O', [(1000, 264, 2), (37, 8, 1), (4099, 512, 1), (513, 136, 4)])
+@pytest.mark.parametrize('pro', [1, 2])
+def test_out_layer_bwd_bn_two_pass_is_bit_identical_to_three_kernels(M, K, O, pro):
+    """tfr_tower_out_bwd2: (sums only) + coefficients + (recompute dy, write dz) == out_bwd + coeffs + bn_bwd_apply."""
+    t = T()
+    z = (rnd((M, K), 50 + M) * 1.5 + 0.2).to(DEV).to(torch.bfloat16)
+    zf = z.float()
+    gamma = (rnd((K,), 51) * 0.3 + 1.0).to(DEV); beta = rnd((K,), 52, 0.4).to(DEV)
+    mean = zf.mean(0); rstd = torch.rsqrt(zf.var(0, unbiased=False) + 1e-3)
+    sc = gamma * rstd; sh = beta - mean * sc
+    w = rnd((O, K), 53, 0.2).to(DEV); dl = rnd((M, O), 54).to(DEV)
+    dy, sums = t.out_layer_bwd(z, K, pro, sc, sh, mean, rstd, w, dl)
+    want = t.bn_bwd_apply_(dy, z, K, t.bn_bwd_coeffs(gamma, rstd, mean, sums[:2], M))
+    got, sums2 = t.out_layer_bwd_bn(z, K, pro, sc, sh, mean, rstd, gamma, w, dl)
+    assert torch.equal(sums, sums2)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 def _ste(x):
     return x + (x.to(torch.bfloat16).float() - x).detach()
 
