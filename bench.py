@@ -140,6 +140,8 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
     scorer.train()
     bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
+    if not os.environ.get('TFR_NO_INPLACE_GRADS'):
+        bucket.attach(scorer)
     lr = 0.01
     _, world = D.world()
     params = [p for p in scorer.parameters() if p.requires_grad]

@@ -296,6 +296,15 @@ typedef struct tfr_tower_dropout {
  * padded; optional per-column affine (an input BatchNormalization folded in). */
 int tfr_tower_cast_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
                             const float* shift, void* out_bf16, void* stream);
+/* dst[j][0..n[j]) += src[j][0..n[j]) for j < count (host arrays of device pointers): gradient accumulation of the
+ * tower's small vectors (biases, gamma, beta, output weights) in one launch per 16 vectors. */
+int tfr_tower_multi_add(float* const* dst, const float* const* src, const int* n, int count, void* stream);
+
+/* FlattenList's gather index (keras/layers.py:122-183; utils.py:203-230, :308-356 with shuffle=False) in one
+ * launch: rows[b * L + p] = b * L + v_b[p mod max(n_b, 1)], v_b = valid positions of list b in index order
+ * (0 when the list has none).  mask uint8 [B, L]; rows int32 [B * L]; L <= 4096. */
+int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream);
+
 /* The same with a row gather: out[m] = cast(x[row_index[m]]) (row_index NULL = identity).  Fuses FlattenList's
  * circular padding (keras/layers.py:126-182: padded slots re-use the list's valid items) into the cast. */
 int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,

@@ -6,6 +6,7 @@ from __future__ import annotations
 import ctypes
 from typing import Optional
 
+import os
 import torch
 
 from . import _lib
@@ -60,6 +61,32 @@ def pad_k(n: int) -> int:
     """Width the tower stages its INPUT features at: a multiple of the GEMM's 64-wide k step once there are at
     least two steps of it (the LDS-DMA kernels need whole k steps; the padding columns are zeros on both operands)."""
     return ((n + 63) // 64) * 64 if n > 64 else pad8(n)
+
+
+def multi_add_(dsts, srcs):
+    """dst += src for lists of small contiguous fp32 tensors, one launch per 16 pairs."""
+    if not dsts:
+        return
+    n = len(dsts)
+    srcs = [s.to(torch.float32).contiguous() for s in srcs]
+    for d, s in zip(dsts, srcs):
+        if d.dtype != torch.float32 or not d.is_contiguous() or d.numel() != s.numel():
+            raise ValueError('multi_add_: contiguous fp32 tensors of equal size')
+    dp = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dsts])
+    sp = (ctypes.c_void_p * n)(*[s.data_ptr() for s in srcs])
+    nn = (ctypes.c_int * n)(*[d.numel() for d in dsts])
+    _lib.check(_lib.load().tfr_tower_multi_add(dp, sp, nn, n, _stream()), 'tfr_tower_multi_add')
+
+
+def flatten_row_index(mask: torch.Tensor) -> torch.Tensor:
+    """int32 [B * L] row index of FlattenList's circular-padding gather (utils.py:308-356, shuffle=False):
+    position p of list b reads flat row b * L + (p mod n_b)-th valid position of the list."""
+    require_device(mask, 'mask')
+    B, L = mask.shape
+    m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else (mask != 0).view(torch.uint8).contiguous()
+    rows = torch.empty((B * L,), dtype=torch.int32, device=mask.device)
+    _lib.check(_lib.load().tfr_flatten_row_index(_ptr(m8), B, L, _ptr(rows), _stream()), 'tfr_flatten_row_index')
+    return rows
 
 
 def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
@@ -161,6 +188,9 @@ def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
     return out
 
 
+_OUT_BWD_ROWS = int(os.environ.get('TFR_OUT_BWD_ROWS', '128'))   # rows per workgroup below which fewer blocks are launched
+
+
 def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=1024, dropout=None):
     """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
     sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]."""
@@ -169,7 +199,7 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
     w = w.detach().to(torch.float32).contiguous()
     O = w.shape[0]
     dlogits = dlogits.to(torch.float32).contiguous()
-    n_blocks = max(1, min(n_blocks, (M + 15) // 16))
+    n_blocks = max(1, min(n_blocks, (M + 15) // 16, max(256, M // _OUT_BWD_ROWS)))
     dy = torch.empty((M, K), dtype=torch.bfloat16, device=z.device)
     partial = torch.empty((n_blocks, 2 + O, K), dtype=torch.float32, device=z.device)
     _lib.check(_lib.load().tfr_tower_out_bwd(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift),
@@ -189,7 +219,7 @@ def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits
     w = w.detach().to(torch.float32).contiguous()
     O = w.shape[0]
     dlogits = dlogits.to(torch.float32).contiguous()
-    n_blocks = max(1, min(n_blocks, (M + 15) // 16))
+    n_blocks = max(1, min(n_blocks, (M + 15) // 16, max(256, M // _OUT_BWD_ROWS)))
     lib = _lib.load()
     partial = torch.empty((n_blocks, 2 + O, K), dtype=torch.float32, device=z.device)
     _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
@@ -224,19 +254,28 @@ def bn_bwd_apply_(dy, z, K, pqr):
     return dy
 
 
-def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, dropout=None):
-    """dW[N, K] = dz[M, :N]^T . pro(A)[M, :K] (fp32)."""
+_WGRAD_BLOCKS = int(os.environ.get('TFR_WGRAD_BLOCKS', '512'))   # split-M target: workgroups per launch
+
+
+def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, dropout=None, accumulate_into=None):
+    """dW[N, K] = dz[M, :N]^T . pro(A)[M, :K] (fp32).  ``accumulate_into`` (contiguous fp32 [N, K]): the split
+    reduction adds into it instead of returning a fresh tensor (gradient accumulation without another launch)."""
     _bf16(dz, 'dz'); _bf16(A, 'A')
     M = dz.shape[0]
     if splits <= 0:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
-        splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))
+        splits = max(1, min((M + 255) // 256, (_WGRAD_BLOCKS + tiles - 1) // tiles))
     slab = torch.empty((splits, N, K), dtype=torch.float32, device=dz.device)
     lib = _lib.load()
     _lib.check(lib.tfr_tower_wgrad_bf16(_ptr(dz), dz.stride(0), _ptr(A), A.stride(0), M, N, K, prologue,
                                         _ptr(a_scale), _ptr(a_shift), _ptr(slab), K, splits, _dp(dropout), _stream()),
                'tfr_tower_wgrad_bf16')
-    out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
-    _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 0, _stream()),
-               'tfr_tower_slab_reduce')
+    if accumulate_into is not None:
+        out = accumulate_into
+        if out.shape != (N, K) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError('accumulate_into must be a contiguous fp32 [%d, %d] tensor' % (N, K))
+    else:
+        out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
+    _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 1 if accumulate_into is not None else 0,
+                                         _stream()), 'tfr_tower_slab_reduce')
     return out

@@ -700,6 +700,13 @@ __global__ void tower_reduce_rows_kernel(const float* __restrict__ partial, int 
   const int t1 = (t0 + kReduceChunk < T) ? t0 + kReduceChunk : T;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int t = t0;
+  for (; t + 15 < t1; t += 16) {                               // 16 loads in flight (the walk is latency-bound)
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partial[(long)(t + u) * W + i];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+  }
   for (; t + 3 < t1; t += 4) {
     s0 += partial[(long)t * W + i];       s1 += partial[(long)(t + 1) * W + i];
     s2 += partial[(long)(t + 2) * W + i]; s3 += partial[(long)(t + 3) * W + i];
@@ -720,7 +727,18 @@ __global__ void tower_bn_finalize_kernel(const float* __restrict__ partial, int 
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   double s = 0.0, ss = 0.0;
-  for (int t = 0; t < T; ++t) {
+  int t = 0;
+  for (; t + 7 < T; t += 8) {                                  // 16 loads in flight, same summation order
+    float a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = partial[((long)(t + u) * 2 + 0) * N + n];
+      b[u] = partial[((long)(t + u) * 2 + 1) * N + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += (double)a[u]; ss += (double)b[u]; }
+  }
+  for (; t < T; ++t) {
     s += (double)partial[((long)t * 2 + 0) * N + n];
     ss += (double)partial[((long)t * 2 + 1) * N + n];
   }
@@ -744,7 +762,15 @@ __global__ void tower_reduce_partials_kernel(const float* __restrict__ partial, 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= W) return;
   double s = 0.0;
-  for (int t = 0; t < T; ++t) s += (double)partial[(long)t * W + i];
+  int t = 0;
+  for (; t + 15 < T; t += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partial[(long)(t + u) * W + i];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += (double)v[u];
+  }
+  for (; t < T; ++t) s += (double)partial[(long)t * W + i];
   out[i] = (float)s;
 }
 
@@ -1103,7 +1129,15 @@ __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, 
                                          int accumulate) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float t = 0.f;
-    for (int s = 0; s < S; ++s) t += slab[(long)s * n + i];
+    int s = 0;
+    for (; s + 15 < S; s += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = slab[(long)(s + u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    for (; s < S; ++s) t += slab[(long)s * n + i];
     out[i] = accumulate ? out[i] + t : t;
   }
 }
@@ -1175,7 +1209,68 @@ int launch_gemm(const GemmArgs& g, hipStream_t st) {
   return launch_gemm_v<PRO, EPI, false>(g, st);
 }
 
+// FlattenList's gather index in one launch (utils.py:203-230 organize_valid_indices(shuffle=False) + :308-356
+// padded_nd_indices): position p of list b reads row b * L + v[p mod max(n, 1)], v = the valid positions of the
+// list in index order (then the invalid ones -- reachable only when n = 0, where v[0] = 0).  One wave per list,
+// ballot + popcount compaction into LDS; replaces a stable sort and a dozen elementwise launches.
+__global__ __launch_bounds__(256) void flatten_row_index_kernel(const uint8_t* __restrict__ mask, int B, int L,
+                                                                int* __restrict__ rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  int* v = reinterpret_cast<int*>(smem) + (long)wave * L;
+  const uint8_t* mk = mask + (long)b * L;
+  int n = 0;
+  for (int p0 = 0; p0 < L; p0 += 64) {
+    const int p = p0 + lane;
+    const bool ok = p < L && mk[p] != 0;
+    const unsigned long long bal = __ballot(ok);
+    if (ok) v[n + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+    n += __popcll(bal);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);                          // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  const long base = (long)b * L;
+  for (int p = lane; p < L; p += 64) rows[base + p] = (int)base + (n > 0 ? v[p % n] : 0);
+}
+
+// dst[j][i] += src[j][i] for up to 16 small vectors in one launch (blockIdx.y = j); the pointers travel in
+// the kernel arguments.
+struct MultiAdd { float* dst[16]; const float* src[16]; int n[16]; };
+__global__ void tower_multi_add_kernel(const MultiAdd a) {
+  const int j = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n[j]; i += gridDim.x * blockDim.x) a.dst[j][i] += a.src[j][i];
+}
+
 }  // namespace
+
+extern "C" int tfr_tower_multi_add(float* const* dst, const float* const* src, const int* n, int count, void* stream) {
+  if (count < 0 || (count > 0 && (!dst || !src || !n))) return TFR_EINVAL;
+  for (int c0 = 0; c0 < count; c0 += 16) {
+    MultiAdd a;
+    const int c = (count - c0 < 16) ? count - c0 : 16;
+    int nmax = 1;
+    for (int j = 0; j < 16; ++j) {
+      a.dst[j] = j < c ? dst[c0 + j] : nullptr; a.src[j] = j < c ? src[c0 + j] : nullptr; a.n[j] = j < c ? n[c0 + j] : 0;
+      if (j < c && (!a.dst[j] || !a.src[j] || a.n[j] < 0)) return TFR_EINVAL;
+      if (a.n[j] > nmax) nmax = a.n[j];
+    }
+    const int gx = (nmax + 255) / 256 > 64 ? 64 : (nmax + 255) / 256;
+    hipLaunchKernelGGL(tower_multi_add_kernel, dim3(gx, c), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
+// rows[b * L + p] for tfr_tower_cast_gather_f32_bf16 (keras/layers.py:122-183 FlattenList, utils.py:308-356).
+extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream) {
+  if (!mask || !rows || B < 0 || L <= 0 || (long)B * L > 0x7fffffffL) return TFR_EINVAL;
+  if ((size_t)L * 16 > 64 * 1024) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  hipLaunchKernelGGL(flatten_row_index_kernel, dim3((B + 3) / 4), dim3(256), (size_t)L * 16, (hipStream_t)stream,
+                     mask, B, L, rows);
+  return (int)hipGetLastError();
+}
 
 extern "C" int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
                                               const float* shift, const int* row_index, void* out_bf16,

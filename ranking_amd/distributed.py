@@ -61,6 +61,16 @@ class FlatGradBucket:
             off += p.numel()
         self.group = group
 
+    def attach(self, module: torch.nn.Module) -> 'FlatGradBucket':
+        """Lets the fused towers of ``module`` accumulate straight into this bucket's views (one multi-tensor
+        launch + the weight-gradient split reductions) instead of one autograd ``grad += g`` launch per
+        parameter.  Valid because the bucket keeps every ``.grad`` allocated; parameter hooks do not fire."""
+        from .tower import FusedTower
+        for m in module.modules():
+            if isinstance(m, FusedTower):
+                m.accumulate_grads_in_place = True
+        return self
+
     @property
     def scalars(self) -> torch.Tensor:
         return self.flat[self.numel:]

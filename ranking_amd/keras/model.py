@@ -10,6 +10,7 @@ from torch import nn
 
 from . import layers
 from .. import utils as _tfr_utils
+from .. import _tower_ops
 
 
 class UnivariateScorer(nn.Module, metaclass=abc.ABCMeta):
@@ -49,8 +50,11 @@ class DNNScorer(UnivariateScorer):
             if torch.is_tensor(x) and x.dim() == 3 and x.dtype == torch.float32:
                 mask = torch.as_tensor(mask, device=x.device).to(torch.bool)
                 b, l = mask.shape
-                idx, _ = _tfr_utils.padded_nd_indices(is_valid=mask)
-                rows = (idx + torch.arange(b, device=x.device).unsqueeze(1) * l).reshape(-1)
+                if l <= 4096 and b * l < 2 ** 31:
+                    rows = _tower_ops.flatten_row_index(mask)        # one launch (utils.py:308-356)
+                else:
+                    idx, _ = _tfr_utils.padded_nd_indices(is_valid=mask)
+                    rows = (idx + torch.arange(b, device=x.device).unsqueeze(1) * l).reshape(-1)
                 flat_logits = self._tower(x.reshape(b * l, x.shape[2]), row_index=rows)
                 return self._restore((flat_logits, mask))
         return super().forward(context_features, example_features, mask)

@@ -233,7 +233,7 @@ class ModelFitPipeline(AbstractPipeline):
             opt, mode='max' if h.best_exporter_metric_higher_better else 'min', factor=0.1,
             patience=max(1, h.early_stopping_patience // 2 or 1)) if h.automatic_reduce_lr else None)
         rank, world = dist_lib.world()
-        bucket = dist_lib.FlatGradBucket(model.parameters(), n_scalars=2) if world > 1 else None
+        bucket = dist_lib.FlatGradBucket(model.parameters(), n_scalars=2).attach(model) if world > 1 else None
         train_it = iter(self._dataset_builder.build_train_dataset())
         history: Dict[str, List[float]] = {}
         best, since_best = None, 0

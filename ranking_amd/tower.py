@@ -37,6 +37,9 @@ def _act_code(activation) -> Optional[str]:
     raise ValueError('FusedTower supports activation None or relu, got %r' % (activation,))
 
 
+_FUSED_LAST_MIN_ELEMS = 1 << 25
+
+
 class _TowerFn(torch.autograd.Function):
     """forward(x, training, tower, *params) -> logits [M, O] (fp32)."""
 
@@ -109,12 +112,19 @@ class _TowerFn(torch.autograd.Function):
         M = x0.shape[0]
         dev = x0.device
         dlogits = dlogits.to(torch.float32).contiguous()
+        # Opt-in (FusedTower.accumulate_grads_in_place): add into the existing .grad buffers here -- the weight
+        # gradients inside the split reduction, the vectors in ONE multi-tensor launch -- and hand autograd None,
+        # instead of ~14 separate "grad += g" launches.  Parameter hooks do not fire in this mode.
+        direct = bool(getattr(tower, 'accumulate_grads_in_place', False)) and all(
+            p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params)
         dW, db = [None] * n_h, [None] * n_h
         dgam, dbet = [None] * n_h, [None] * n_h
         # output layer
         pro, sc, sh, mean, rstd, drop = coefs[-1]
         n_last = zs[-1].shape[1]
-        fused_last = use_bn and n_h > 0 and not os.environ.get('TFR_TOWER_NO_FUSED_LAST')
+        # two passes over z pay once the [M, K] gradient is HBM-sized; below that the extra launch costs more
+        fused_last = (use_bn and n_h > 0 and M * n_last >= _FUSED_LAST_MIN_ELEMS
+                      and not os.environ.get('TFR_TOWER_NO_FUSED_LAST'))
         if fused_last:                                     # dz of the last hidden layer directly (two passes over z)
             dy, sums = T.out_layer_bwd_bn(zs[-1], n_last, pro, sc, sh, mean, rstd, gammas[-1], w_out, dlogits,
                                           dropout=drop)
@@ -141,8 +151,11 @@ class _TowerFn(torch.autograd.Function):
             else:
                 pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = T.PRO_NONE, None, None, None, None, None
                 a_prev, k_in = x0, x0.shape[1]
-            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p)
-            dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
+            into = Ws[l].grad if (direct and k_in == Ws[l].shape[1] and Ws[l].grad.is_contiguous()) else None
+            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p,
+                        accumulate_into=into)
+            if into is None:
+                dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:
                 wt = T.cast_weight(Ws[l], transpose=True)          # [K, pad8(N)]
                 if pro_p == T.PRO_AFFINE_RELU:
@@ -159,6 +172,11 @@ class _TowerFn(torch.autograd.Function):
         if use_bn:
             grads += list(dgam) + list(dbet)
         grads += [dw_out, db_out]
+        if direct:
+            todo = [(p.grad, g) for p, g in zip(params, grads)
+                    if g is not None and not (use_bn and any(g is z for z in db_zero))]   # zero bias grads: no-op
+            T.multi_add_([a for a, _ in todo], [g for _, g in todo])
+            grads = [None] * len(grads)
         return (None, None, None, None) + tuple(grads)
 
 
@@ -184,6 +202,9 @@ class FusedTower(nn.Module):
             raise ValueError('dropout rate must be in [0, 1)')
         self.dropout = float(dropout or 0.0)
         self._drop_step = 0
+        # True: backward adds into the existing .grad buffers itself (see _TowerFn.backward); set by
+        # distributed.FlatGradBucket.attach(), whose flat buffer owns every .grad for the life of the model.
+        self.accumulate_grads_in_place = False
         self.weights = nn.ParameterList()
         self.biases = nn.ParameterList()
         self.gammas = nn.ParameterList()

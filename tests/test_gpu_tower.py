@@ -422,3 +422,74 @@ def test_gemm_relu_bwd_epilogue(M, N, K):
     lim = 4e-3 * max(1.0, want.abs().max().item()) * M ** 0.5 + 1e-2
     assert (s[0] - want.sum(dim=0)).abs().max().item() <= lim
     assert (s[1] - (want * zhat).sum(dim=0)).abs().max().item() <= lim * max(1.0, zhat.abs().max().item())
+
+
+@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (37, 64), (130, 65), (64, 200), (9, 1000), (3, 4096)])
+def test_flatten_row_index_is_bit_exact_against_padded_nd_indices(B, L):
+    """tfr_flatten_row_index == utils.padded_nd_indices(shuffle=False) (utils.py:308-356) + the batch offset:
+    scattered masks, all-valid, single-valid and EMPTY lists (which read position 0)."""
+    from ranking_amd import _tower_ops as T
+    from ranking_amd import utils as U
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    mask = torch.rand((B, L), generator=g) < 0.6
+    mask[0] = True
+    if B > 1:
+        mask[1] = False                              # empty list
+    if B > 2:
+        mask[2] = False; mask[2, L - 1] = True       # a single valid item, last
+    mask = mask.to(DEV)
+    idx, _ = U.padded_nd_indices(is_valid=mask)
+    want = (idx + torch.arange(B, device=DEV).unsqueeze(1) * L).reshape(-1).to(torch.int32)
+    got = T.flatten_row_index(mask)
+    assert got.dtype == torch.int32 and torch.equal(got, want)
+    from oracle import tfr_ref as R                  # the CPU restatement, as the checker
+    ref = (R.padded_nd_indices(mask.cpu()) + torch.arange(B).unsqueeze(1) * L).reshape(-1)
+    assert torch.equal(got.cpu().long(), ref.long())
+
+
+@pytest.mark.parametrize('F,hidden,bn', [(136, [512, 512], True), (24, [64, 32], True), (50, [64, 64], False)])
+def test_in_place_gradient_accumulation_equals_autograd_accumulation(F, hidden, bn):
+    """FlatGradBucket.attach(): the tower adds into the bucket's .grad views itself (weight gradients inside the
+    split reduction, vectors in one multi-tensor add) -- same numbers as autograd's per-parameter grad += g,
+    over two accumulated backward passes."""
+    from ranking_amd.tower import FusedTower
+    from ranking_amd import distributed as D
+    M = 1100
+    x = rnd((M, F), 90).to(DEV)
+    ups = [rnd((M, 1), 91).to(DEV), rnd((M, 1), 92).to(DEV)]
+
+    def run(attach):
+        torch.manual_seed(5)
+        tower = FusedTower(F, hidden, 1, activation='relu', use_batch_norm=bn).to(DEV)
+        tower.train()
+        bucket = D.FlatGradBucket(tower.parameters(), n_scalars=2)
+        if attach:
+            bucket.attach(tower)
+            assert tower.accumulate_grads_in_place
+        bucket.zero()
+        for up in ups:
+            tower(x).backward(up)
+        return bucket.flat.clone()
+    a, b = run(True), run(False)
+    assert bool((b != 0).any())
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * b.abs().max().item())
+
+
+def test_tower_backward_with_the_two_pass_last_layer_equals_the_three_kernel_path(monkeypatch):
+    """_TowerFn.backward switches to out_layer_bwd_bn above _FUSED_LAST_MIN_ELEMS; forced on at a small size it
+    must give the very same gradients."""
+    from ranking_amd import tower as tw
+    x = rnd((900, 40), 95).to(DEV)
+    up = rnd((900, 1), 96).to(DEV)
+
+    def grads():
+        torch.manual_seed(7)
+        t = tw.FusedTower(40, [128, 64], 1, activation='relu', use_batch_norm=True).to(DEV)
+        t.train()
+        t(x).backward(up)
+        return [p.grad.clone() for p in t.parameters()]
+    base = grads()
+    monkeypatch.setattr(tw, '_FUSED_LAST_MIN_ELEMS', 0)
+    fused = grads()
+    for a, b in zip(fused, base):
+        assert torch.equal(a, b)
