@@ -1247,6 +1247,7 @@ __global__ void tower_multi_add_kernel(const MultiAdd a) {
 
 extern "C" int tfr_tower_multi_add(float* const* dst, const float* const* src, const int* n, int count, void* stream) {
   if (count < 0 || (count > 0 && (!dst || !src || !n))) return TFR_EINVAL;
+  if (count == 0) return TFR_OK;
   for (int c0 = 0; c0 < count; c0 += 16) {
     MultiAdd a;
     const int c = (count - c0 < 16) ? count - c0 : 16;
@@ -1402,6 +1403,7 @@ extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int pro
   if (!z || !w || !dlogits || (!dy_bf16 && !partial) || M <= 0 || K <= 0 || (K & 7) || (ldz & 7) || (lddy & 7) ||
       O < 1 || O > 4 || n_blocks < 1) return TFR_EINVAL;
   if (pqr && (!dy_bf16 || partial)) return TFR_EINVAL;       // the apply pass writes dz and nothing else
+  if (!pqr && !partial) return TFR_EINVAL;                   // without coefficients the column sums are the point
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
   int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
   rows = (rows + 15) / 16 * 16;

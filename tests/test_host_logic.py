@@ -54,6 +54,16 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     topn = (ctypes.c_int32 * 1)(10)
     assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
     assert lib.tfr_gumbel_sample_f32(one, one, None, None, 0, 0, 1, 0, 8, 1.0, one, None) == -1
+    # tower: the two-pass output-layer backward accepts exactly (dy, partial), (NULL, partial), (dy, NULL, pqr)
+    ob = lambda dy, partial, pqr: lib.tfr_tower_out_bwd2(one, 8, 4, 8, 0, None, None, None, None, one, one, 1, dy, 8,
+                                                         partial, 1, None, pqr, None)
+    assert ob(None, None, None) == -1 and ob(one, None, None) == -1
+    assert ob(None, one, one) == -1 and ob(one, one, one) == -1
+    assert lib.tfr_flatten_row_index(None, 1, 8, one, None) == -1
+    assert lib.tfr_flatten_row_index(one, 1, 5000, one, None) == -2         # L > 4096: LDS compaction buffer
+    assert lib.tfr_flatten_row_index(one, 0, 8, one, None) == 0
+    assert lib.tfr_tower_multi_add(None, None, None, 0, None) == 0
+    assert lib.tfr_tower_multi_add(None, None, None, 2, None) == -1
     # B == 0 is a no-op
     assert lib.tfr_softmax_loss_f32(one, one, None, None, 0, 0, 0, 0, 0, None, None, 0, 8, 1.0, one, one,
                                     None, None) == 0
