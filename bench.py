@@ -49,6 +49,9 @@ WORKLOADS = {
     # ONE all-reduce of the flat gradient bucket + optimizer.
     'e2e_softmax': (4096, 100, 'config 2: DNNScorer 136-512-512-512-1 bf16 + SoftmaxLoss, 4096 lists/GPU, '
                                'L=100, SGD, 1 all-reduce/step', lambda L: 0),
+    'e2e_pairwise_lambda': (4096, 200, 'config 3 end-to-end: DNNScorer 136-512-512-512-1 bf16 + '
+                                       'PairwiseLogisticLoss(NDCGLambdaWeight), 4096 lists/GPU, L=200, SGD, '
+                                       '1 all-reduce/step', lambda L: 0),
     'e2e_approx_ndcg_l1000': (512, 1000, 'config 4: DNNScorer 136-512-512-512-1 bf16 + ApproxNDCGLoss, '
                                          '512 lists/GPU, L=1000, 1 all-reduce/step', lambda L: 0),
     'e2e_groupwise_gumbel': (512, 50, 'config 5: groupwise scorer (group_size=2) 272-512-512-512-2 bf16 + '
@@ -137,7 +140,12 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
                                           activation=torch.relu, use_batch_norm=True, dropout=dropout,
                                           compute_dtype=torch.bfloat16).to(dev)
         run_scorer = lambda: scorer({}, {'x': feats}, mask)
-        loss = ra.keras.losses.SoftmaxLoss() if workload == 'e2e_softmax' else ra.keras.losses.ApproxNDCGLoss()
+        if workload == 'e2e_softmax':
+            loss = ra.keras.losses.SoftmaxLoss()
+        elif workload == 'e2e_pairwise_lambda':
+            loss = ra.keras.losses.PairwiseLogisticLoss(lambda_weight=ra.keras.losses.NDCGLambdaWeight())
+        else:
+            loss = ra.keras.losses.ApproxNDCGLoss()
     scorer.train()
     bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
     if not os.environ.get('TFR_NO_INPLACE_GRADS'):

@@ -313,6 +313,10 @@ int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int K
  * Dense kernel (fp32 master weights stay with the optimizer). */
 int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,
                           void* stream);
+/* `count` such casts in one launch per 8 matrices (host arrays of device pointers / shapes): all the weight casts
+ * of a training step -- forward operands and transposed dgrad operands -- together. */
+int tfr_tower_weight_cast_batch(const float* const* w, const int* R, const int* C, const int* transpose,
+                                const int* pitch, void* const* out_bf16, int count, void* stream);
 /* Dense (+ fused neighbours): C[M, N] = prologue(A)[M, K] . B[N, K]^T + bias, bf16 out. */
 int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         int M, int N, int K, int prologue, const float* a_scale, const float* a_shift,

@@ -123,6 +123,25 @@ def cast_weight(w: torch.Tensor, transpose: bool = False, pitch: Optional[int] =
     return out
 
 
+def cast_weights(specs):
+    """[(w fp32 [R, C], transpose, pitch | None), ...] -> the bf16 operands of cast_weight, one launch per 8."""
+    ws, outs, Rs, Cs, trs, ps = [], [], [], [], [], []
+    for w, transpose, pitch in specs:
+        require_device(w, 'w')
+        w = w.detach().to(torch.float32).contiguous()
+        R, C = w.shape
+        pitch = max(pitch or 0, pad8(R if transpose else C))
+        ws.append(w); Rs.append(R); Cs.append(C); trs.append(int(bool(transpose))); ps.append(pitch)
+        outs.append(torch.empty((C if transpose else R, pitch), dtype=torch.bfloat16, device=w.device))
+    n = len(ws)
+    if n:
+        arr = lambda xs: (ctypes.c_int * n)(*xs)
+        _lib.check(_lib.load().tfr_tower_weight_cast_batch(
+            (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws]), arr(Rs), arr(Cs), arr(trs), arr(ps),
+            (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n, _stream()), 'tfr_tower_weight_cast_batch')
+    return outs
+
+
 def stats_rows(M: int) -> int:
     return (M + 63) // 64          # one row of partials per 64-row slab (tfr_tower_gemm_stats_rows)
 

@@ -689,6 +689,24 @@ __global__ void tower_weight_cast_kernel(const float* __restrict__ w, int R, int
   }
 }
 
+// The same for up to 8 matrices in one launch (blockIdx.y = matrix): every weight cast of a training step
+// (forward operands and the transposed dgrad operands) together.
+struct WCastBatch { const float* w[8]; uint16_t* out[8]; int R[8], C[8], transpose[8], pitch[8]; };
+__global__ void tower_weight_cast_batch_kernel(const WCastBatch a) {
+  const int j = blockIdx.y;
+  const float* __restrict__ w = a.w[j];
+  uint16_t* __restrict__ out = a.out[j];
+  const int R = a.R[j], C = a.C[j], transpose = a.transpose[j], pitch = a.pitch[j];
+  const int total = transpose ? C * pitch : R * pitch;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    const int orow = q / pitch, ocol = q % pitch;
+    float v = 0.f;
+    if (!transpose) { if (ocol < C) v = w[(long)orow * C + ocol]; }
+    else            { if (ocol < R) v = w[(long)ocol * C + orow]; }
+    out[q] = (uint16_t)(pack_bf16(v, 0.f) & 0xffffu);
+  }
+}
+
 // Column sums of per-workgroup partials, stage 1: out[c][i] = sum_{t in chunk c} partial[t][i].
 // Grid (ceil(W / 256), ceil(T / 64)); fully coalesced, deterministic (fixed order), so that the
 // finishing kernels below only walk ceil(T / 64) rows.
@@ -1295,6 +1313,28 @@ extern "C" int tfr_tower_weight_cast(const float* w, int R, int C, int transpose
   hipLaunchKernelGGL(tower_weight_cast_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      w, R, C, transpose, pitch, (uint16_t*)out_bf16);
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_weight_cast_batch(const float* const* w, const int* R, const int* C, const int* transpose,
+                                           const int* pitch, void* const* out_bf16, int count, void* stream) {
+  if (count < 0 || (count > 0 && (!w || !R || !C || !transpose || !pitch || !out_bf16))) return TFR_EINVAL;
+  for (int j = 0; j < count; ++j)
+    if (!w[j] || !out_bf16[j] || R[j] <= 0 || C[j] <= 0 || pitch[j] < (transpose[j] ? R[j] : C[j])) return TFR_EINVAL;
+  for (int c0 = 0; c0 < count; c0 += 8) {
+    WCastBatch a;
+    const int c = (count - c0 < 8) ? count - c0 : 8;
+    int tmax = 1;
+    for (int j = 0; j < 8; ++j) {
+      const int s = c0 + (j < c ? j : 0);                      // unused slots repeat a valid one (never launched)
+      a.w[j] = w[s]; a.out[j] = (uint16_t*)out_bf16[s]; a.R[j] = R[s]; a.C[j] = C[s];
+      a.transpose[j] = transpose[s]; a.pitch[j] = pitch[s];
+      const int total = (transpose[s] ? C[s] : R[s]) * pitch[s];
+      if (j < c && total > tmax) tmax = total;
+    }
+    hipLaunchKernelGGL(tower_weight_cast_batch_kernel, dim3(grid_for(tmax, 256), c), dim3(256), 0,
+                       (hipStream_t)stream, a);
+  }
+  return count == 0 ? TFR_OK : (int)hipGetLastError();
 }
 
 extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,

@@ -65,9 +65,16 @@ class _TowerFn(torch.autograd.Function):
         if rate > 0.0:
             tower._drop_step += 1
             base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
+        # every weight cast of the step in one launch: [N, k_in] forward operands (k_in = staged width of the layer
+        # input) and, when a backward will follow, the transposed [K, pad8(N)] dgrad operands of layers >= 1
+        specs = [(Ws[l], False, k_in if l == 0 else Ws[l - 1].shape[0]) for l in range(n_h)]
+        if any(ctx.needs_input_grad[4:]):
+            specs += [(Ws[l], True, None) for l in range(1, n_h)]
+        cast = T.cast_weights(specs)
+        wbs, ctx.wts = cast[:n_h], [None] + cast[n_h:]
         for l in range(n_h):
             n_out = Ws[l].shape[0]
-            wb = T.cast_weight(Ws[l], pitch=k_in)          # [N, k_in]: k_in = staged width of the layer input
+            wb = wbs[l]
             z, stats = T.gemm(a_in, wb, n_out, k_in, prologue=pro, a_scale=sc, a_shift=sh, bias=bs[l],
                               epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN, pro_dropout=drop)
             if use_bn:
@@ -157,7 +164,7 @@ class _TowerFn(torch.autograd.Function):
             if into is None:
                 dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:
-                wt = T.cast_weight(Ws[l], transpose=True)          # [K, pad8(N)]
+                wt = ctx.wts[l] if len(ctx.wts) > l else T.cast_weight(Ws[l], transpose=True)   # [K, pad8(N)]
                 if pro_p == T.PRO_AFFINE_RELU:
                     e_sc, e_sh = sc_p, sh_p
                 else:                                                # identity activation: mask always on

@@ -493,3 +493,16 @@ def test_tower_backward_with_the_two_pass_last_layer_equals_the_three_kernel_pat
     fused = grads()
     for a, b in zip(fused, base):
         assert torch.equal(a, b)
+
+
+def test_batched_weight_cast_equals_the_single_casts():
+    t = T()
+    ws = [rnd((512, 136), 100).to(DEV), rnd((64, 512), 101).to(DEV), rnd((8, 24), 102).to(DEV)] + \
+         [rnd((16 + 8 * i, 40), 103 + i).to(DEV) for i in range(8)]          # 11 matrices: two launches
+    specs = [(ws[0], False, 192), (ws[1], True, None), (ws[2], False, None)] + [(w, i % 2 == 0, None) for i, w in enumerate(ws[3:])]
+    got = t.cast_weights(specs)
+    assert len(got) == len(specs)
+    for g, (w, tr, pitch) in zip(got, specs):
+        want = t.cast_weight(w, transpose=tr, pitch=pitch)
+        assert g.shape == want.shape and torch.equal(g.view(torch.int16), want.view(torch.int16))
+    assert t.cast_weights([]) == []

@@ -11,7 +11,7 @@ python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=
 tail -n 3 $OUT/pytest_gpu.log
 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log
 python bench.py > $OUT/bench_headline.json 2> $OUT/bench_headline.err; tail -n 1 $OUT/bench_headline.json
-for w in pairwise_lambda softmax gumbel_approx_ndcg ndcg_metric approx_ndcg_l1000 e2e_softmax e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+for w in pairwise_lambda softmax gumbel_approx_ndcg ndcg_metric approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
   timeout 300 python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_$w.json 2> $OUT/bench_$w.err
   tail -n 1 $OUT/bench_$w.json | cut -c1-400
 done
