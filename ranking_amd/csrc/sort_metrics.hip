@@ -668,7 +668,9 @@ void dispatch_metric_wave(int L, const float* labels, const float* predictions, 
 //     (longest first) with LDS atomics: class histogram, prefix, then cursor fetch-adds.  Within a
 //     class the order is whatever the LDS atomics gave -- the loss kernels write each list to its
 //     own rows, so their results do not depend on it.  (A histogram by GLOBAL atomics cost 50 us
-//     here: ~100 hot addresses; ballot counting on one CU 30 us.)
+//     here: ~100 hot addresses; ballot counting on one CU 31 us -- measured twice, the second time
+//     atomic-free with 16 loads in flight; issuing the 16 loads of a thread before its LDS atomics: 16.5 us
+//     against 12 us for this plain loop.)
 constexpr int kOrderClasses = 16;
 
 __global__ __launch_bounds__(256) void list_count_kernel(const float* __restrict__ labels,

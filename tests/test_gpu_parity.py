@@ -904,7 +904,7 @@ def test_list_mle_reference_goldens_and_keras():
 
 
 # ------------------------------------------------------------------ longest-first launch order
-@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (300, 50), (2048, 200), (4100, 33)])
+@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (300, 50), (2048, 200), (4100, 33), (16384, 200), (20001, 40)])
 def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_it(B, L):
     from ranking_amd import _ops
     labels, logits = make_batch(B, L, seed=1200 + L)
