@@ -143,7 +143,7 @@ int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t*
                         float* dlogits_out, const int32_t* list_order, void* stream);
 
 /* Longest-first launch order for the O(n^2) loss kernels (their `list_order` argument, nullable):
- * order_out[B] = list indices by decreasing number of valid items (16 length classes; arbitrary
+ * order_out[B] = list indices by decreasing number of valid items (64 length classes; arbitrary
  * order inside a class).  Results of the loss kernels
  * do not depend on it (each list is written to its own rows); it shortens the end-of-kernel tail.
  *   workspace  int32[B] scratch owned by the caller. */

@@ -664,14 +664,14 @@ void dispatch_metric_wave(int L, const float* labels, const float* predictions, 
 // start can be the longest ones and the kernel ends on a long low-occupancy tail (measured:
 // -10 % ApproxNDCG kernel time).  Two small launches:
 // (1) list_count_kernel: one wave per list counts its valid items (fully parallel);
-// (2) list_scatter_kernel: ONE workgroup buckets the lists into kOrderClasses length classes
+// (2) list_scatter_kernel: ONE workgroup buckets the lists into kOrderClasses (64) length classes
 //     (longest first) with LDS atomics: class histogram, prefix, then cursor fetch-adds.  Within a
 //     class the order is whatever the LDS atomics gave -- the loss kernels write each list to its
 //     own rows, so their results do not depend on it.  (A histogram by GLOBAL atomics cost 50 us
 //     here: ~100 hot addresses; ballot counting on one CU 31 us -- measured twice, the second time
 //     atomic-free with 16 loads in flight; issuing the 16 loads of a thread before its LDS atomics: 16.5 us
 //     against 12 us for this plain loop.)
-constexpr int kOrderClasses = 16;
+constexpr int kOrderClasses = 64;   // one per lane of the scanning wave; valid lengths U{L/2..L} touch half of them
 
 __global__ __launch_bounds__(256) void list_count_kernel(const float* __restrict__ labels,
                                                          const uint8_t* __restrict__ mask, int B, int L,
@@ -697,9 +697,12 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
   __syncthreads();
   for (int i = threadIdx.x; i < B; i += 1024) atomicAdd(&s_hist[cls_of(nvalid[i])], 1);
   __syncthreads();
-  if (threadIdx.x == 0) {                                   // exclusive prefix over the classes
-    int run = 0;
-    for (int c = 0; c < kOrderClasses; ++c) { const int v = s_hist[c]; s_hist[c] = run; run += v; }
+  if (threadIdx.x < 64) {                                   // exclusive prefix over the classes: one wave scan
+    const int v = s_hist[threadIdx.x];
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(inc, d); if ((int)threadIdx.x >= d) inc += t; }
+    s_hist[threadIdx.x] = inc - v;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < B; i += 1024) order_out[atomicAdd(&s_hist[cls_of(nvalid[i])], 1)] = i;
