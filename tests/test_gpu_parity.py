@@ -1334,3 +1334,89 @@ def test_widened_kernels_at_headline_size():
         tol = 2e-4 if name.startswith('neural') else 1e-5          # NeuralSort: exp(c_t s_k - A_k) conditioned by L |s| (fp64-arbitrated elsewhere)
         assert_loss_close(out[:n].reshape(want.shape) / scale, want.detach() / scale, tol, name)
         assert_grad_close(d[:n], x.grad, 10 * tol, name + ' grad')
+
+
+# ------------------------------------------------------------------ Keras-level known answers on the HIP path
+# (keras/losses_test.py:146-243, 284-308, 576-602, 650-741; keras/metrics_test.py:296-396, 856-992: the same closed
+#  forms tests/test_oracle_keras_golden.py pins the oracle with)
+@pytest.mark.parametrize('form', ['hinge', 'logistic', 'soft_zero_one'])
+def test_keras_pairwise_known_answers_on_the_hip_path(form):
+    from tests.test_oracle_keras_golden import _FORMS, _pair_sum, near
+    k = ra().keras.losses
+    ctor = {'hinge': k.PairwiseHingeLoss, 'logistic': k.PairwiseLogisticLoss, 'soft_zero_one': k.PairwiseSoftZeroOneLoss}[form]
+    phi = _FORMS[form][1]
+    t = lambda x: torch.tensor(x, device=DEV)
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 0., 2.]]
+    list_w, item_w = [[2.], [1.]], [[2., 3., 4.], [1., 1., 1.]]
+    agg = lambda parts: sum(p[0] for p in parts) / sum(p[1] for p in parts)
+    for b in (0, 1):
+        near(ctor()(t([labels[b]]), t([scores[b]])).cpu(), agg([_pair_sum(labels[b], scores[b], [1.] * 3, phi)]))
+        near(ctor()(t([labels[b]]), t([scores[b]]), t([item_w[b]])).cpu(), agg([_pair_sum(labels[b], scores[b], item_w[b], phi)]))
+    near(ctor()(t(labels), t(scores), t(list_w)).cpu(),
+         agg([_pair_sum(labels[b], scores[b], [list_w[b][0]] * 3, phi) for b in (0, 1)]))
+    lam = k.DCGLambdaWeight(rank_discount_fn=lambda r: 1. / torch.log1p(r), smooth_fraction=1.)
+    near(ctor(lambda_weight=lam)(t(labels), t(scores), t(list_w)).cpu(),
+         agg([_pair_sum(labels[b], scores[b], [list_w[b][0]] * 3, phi, log_discount=True) for b in (0, 1)]) * 3.)
+
+
+def test_keras_listwise_and_metric_known_answers_on_the_hip_path():
+    from tests.test_oracle_keras_golden import _pick, _norm_weight, _dcg, _ndcg_list_weights, near, ln
+    k, km = ra().keras.losses, ra().keras.metrics
+    t = lambda x: torch.tensor(x, device=DEV)
+    # PairwiseLogistic with an invalid label, SUM, temperature (keras/losses_test.py:710-733)
+    yt, yp = t([[0., -1., 1.]]), t([[1., 3., 2.]])
+    near(k.PairwiseLogisticLoss()(yt, yp).cpu(), ln(1 + math.exp(-1.)) / 3.)
+    near(k.PairwiseLogisticLoss(reduction=k.Reduction.SUM)(yt, yp).cpu(), ln(1 + math.exp(-1.)))
+    near(k.PairwiseLogisticLoss(reduction=k.Reduction.SUM, temperature=0.1)(yt, yp).cpu(), ln(1 + math.exp(-10.)))
+    # Softmax (keras/losses_test.py:284-308, 735-741)
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]
+    near(k.SoftmaxLoss()(t(labels), t(scores)).cpu(), -(ln(_pick(scores[0], 2)) + ln(_pick(scores[1], 2)) * 2.) / 3.)
+    near(k.SoftmaxLoss()(t(labels), t(scores), t([[2.], [1.], [1.]])).cpu(),
+         -(ln(_pick(scores[0], 2)) * 2. + ln(_pick(scores[1], 2)) * 2.) / 3.)
+    lam = k.DCGLambdaWeight(rank_discount_fn=lambda r: 1. / torch.log1p(r))
+    near(k.SoftmaxLoss(lambda_weight=lam)(t(labels), t(scores)).cpu(),
+         -(ln(_pick(scores[0], 2)) / ln(3.) + ln(_pick(scores[1], 2)) * 2. / ln(2.)) / 3.)
+    near(k.SoftmaxLoss()(yt, yp).cpu(), -ln(_pick([1., 2.], 1)))
+    # ApproxNDCG, three reductions (keras/losses_test.py:576-602, 650-693)
+    scores = [[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]]
+    labels = [[0., 2., 1.], [1., 0., 3.], [0., 0., 0.]]
+    item_w = [[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]]
+    n0 = (1 / (3 / ln(2) + 1 / ln(3))) * (3 / ln(4) + 1 / ln(3))
+    n1 = (1 / (7 / ln(2) + 1 / ln(3))) * (7 / ln(2) + 1 / ln(4))
+    nw = [_norm_weight(w, l) for w, l in zip(item_w, labels)]
+    for red, div in ((k.Reduction.AUTO, 3.), (k.Reduction.SUM, 1.), (k.Reduction.SUM_OVER_BATCH_SIZE, 3.)):
+        loss = k.ApproxNDCGLoss(reduction=red)
+        near(loss(t(labels), t(scores)).cpu(), -(n0 + n1) / div)
+        near(loss(t(labels), t(scores), t([[2.], [1.], [1.]])).cpu(), -(2 * n0 + n1) / div)
+        near(loss(t(labels), t(scores), t(item_w)).cpu(), -(nw[0] * n0 + nw[1] * n1) / div)
+    # NDCG metric with item / list / zero weights (keras/metrics_test.py:856-992)
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    weights = [[1., 2., 3.], [4., 5., 6.]]
+
+    def m(metric, yt_, yp_, w=None):
+        metric.update_state(t(yt_), t(yp_), None if w is None else t(w))
+        return metric.result().cpu()
+    n1_ = (_dcg(0., 1) + _dcg(1., 2) + _dcg(0., 3)) / (_dcg(1., 1) + _dcg(0., 2) + _dcg(0., 3))
+    near(m(km.NDCGMetric(), labels, scores), (n1_ + 1.0) / 2.0)
+    near(m(km.NDCGMetric(), [[0., 0., 0.], [0., 1., 2.]], scores), 0.5)
+    w1 = (_dcg(0., 1, 2.) + _dcg(1., 2, 3.) + _dcg(0., 3, 1.)) / (_dcg(1., 1, 3.) + _dcg(0., 2, 1.) + _dcg(0., 3, 2.))
+    lw = _ndcg_list_weights(weights, labels)
+    near(m(km.NDCGMetric(), labels, scores, weights), (w1 * lw[0] + 1.0 * lw[1]) / sum(lw))
+    near(m(km.NDCGMetric(topn=1), labels, scores, weights),
+         (_dcg(0., 1, 2.) / _dcg(1., 1, 3.) * lw[0] + 1.0 * lw[1]) / sum(lw))
+    near(m(km.NDCGMetric(), labels, scores, [[1.], [2.]]), (n1_ + 2.0) / 3.0)
+    near(m(km.NDCGMetric(), labels, scores, [[0.], [0.]]), 0.0)
+    z = [[0., 0., 0.], [0., 1., 2.]]
+    near(m(km.NDCGMetric(), z, scores, weights), 0.5)                   # both lists weigh 5.75
+    # MRR (keras/metrics_test.py:296-396)
+    scores = [[1., 3., 2.], [1., 2., 3.], [3., 1., 2.]]
+    labels = [[0., 0., 1.], [0., 1., 2.], [0., 1., 0.]]
+    weights = [[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]]
+    rel_rank, mw = [2, 1, 3], [3., 5.5, 8.]
+    near(m(km.MRRMetric(), labels, scores), sum(1. / r for r in rel_rank) / 3.)
+    near(m(km.MRRMetric(topn=2), labels, scores), (0.5 + 1.0) / 3.)
+    near(m(km.MRRMetric(), labels, scores, weights), sum(w / r for w, r in zip(mw, rel_rank)) / sum(mw))
+    near(m(km.MRRMetric(topn=1), labels, scores, weights), (mw[1] / rel_rank[1]) / sum(mw))
