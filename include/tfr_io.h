@@ -38,6 +38,9 @@ int tfr_io_abi_version(void);
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */
 uint32_t tfr_io_crc32c(const uint8_t* data, size_t n);
 uint32_t tfr_io_masked_crc32c(const uint8_t* data, size_t n);
+/* tfr_io_crc32c takes the SSE4.2 crc32 instruction when the host has it; this is the table (slice-by-8) path it
+ * falls back to, exported for the cross-check. */
+uint32_t tfr_io_crc32c_portable(const uint8_t* data, size_t n);
 
 /* TFRecord framing: [u64 length][u32 masked crc of length][data][u32 masked crc of data].
  * Fills offsets[i] / lengths[i] (payload position and size inside `buf`) for up to max_records

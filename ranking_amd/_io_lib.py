@@ -27,6 +27,7 @@ _SIGNATURES = {
     'tfr_io_abi_version': (ctypes.c_int, []),
     'tfr_io_crc32c': (ctypes.c_uint32, [_P, ctypes.c_size_t]),
     'tfr_io_masked_crc32c': (ctypes.c_uint32, [_P, ctypes.c_size_t]),
+    'tfr_io_crc32c_portable': (ctypes.c_uint32, [_P, ctypes.c_size_t]),
     'tfr_io_tfrecord_index': (ctypes.c_int64, [_P, ctypes.c_size_t, ctypes.c_int, _P, _P, ctypes.c_int64]),
     'tfr_io_elwc_max_list_size': (ctypes.c_int64, [_P, _P, ctypes.c_int32]),
     'tfr_io_parse_elwc_batch': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _P,

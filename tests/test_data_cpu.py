@@ -37,9 +37,11 @@ def test_crc32c_known_answers():
     assert data.crc32c(bytes(32)) == 0x8A9136AA               # RFC 3720 B.4: 32 zero bytes
     assert data.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43      # RFC 3720 B.4: 32 0xff bytes
     rng = np.random.RandomState(0)
-    for n in (1, 7, 8, 9, 63, 64, 1000):
+    lib = _io_lib.load()
+    for n in (1, 7, 8, 9, 31, 32, 33, 63, 64, 1000, 4099):
         b = rng.bytes(n)
         assert data.crc32c(b) == D.crc32c(b)
+        assert lib.tfr_io_crc32c_portable(b, n) == D.crc32c(b)      # the table path behind the SSE4.2 one
         assert data.masked_crc32c(b) == D.masked_crc32c(b)
 
 
@@ -243,3 +245,43 @@ def test_synthetic_bench_batch_survives_the_elwc_round_trip(tmp_path):
     assert torch.equal(got['mask'], labels >= 0)
     valid = (labels >= 0).unsqueeze(-1)
     assert torch.equal(torch.where(valid, got['x'], torch.zeros(())), torch.where(valid, feats, torch.zeros(())))
+
+
+def test_feature_order_hints_and_fast_paths_never_change_the_result():
+    """The parser predicts the spec of the i-th map entry from the previous example and pattern-matches the usual
+    byte images (tfr_io.cpp: SpecTable::lookup, decode_feature / map-entry fast paths).  Examples whose features are
+    permuted, missing, unknown to the spec, duplicated (last one wins) or written unpacked must decode exactly like
+    the pure-Python oracle."""
+    rng = np.random.RandomState(7)
+    names = ['a', 'bb', 'ccc', '17', '18', 'wide']
+    widths = {'a': 1, 'bb': 1, 'ccc': 2, '17': 1, '18': 1, 'wide': 40}        # 'wide': 160-byte payload, 2-byte varints
+    records = []
+    for b in range(24):
+        exs = []
+        for i in range(int(rng.randint(1, 7))):
+            order = list(names) + ['unknown%d' % rng.randint(3)]
+            if rng.rand() < 0.6:
+                rng.shuffle(order)
+            e = {}
+            for k in order:
+                if rng.rand() < 0.2:
+                    continue                                  # absent -> default
+                w = widths.get(k, 1)
+                e[k] = ('float', [float(np.float32(rng.randn())) for _ in range(w)])
+            exs.append(e)
+        rec = D.encode_elwc(None, exs, packed=(b % 2 == 0))
+        if b % 5 == 0 and exs and 'a' in exs[0]:              # a duplicated key: the later entry wins
+            dup = D._ld(1, D._ld(1, b'a') + D._ld(2, D.encode_feature('float', [123.5])))
+            inner = b''.join(D._ld(1, D._ld(1, k.encode()) + D._ld(2, D.encode_feature(kind, vals, b % 2 == 0)))
+                             for k, (kind, vals) in exs[0].items()) + dup
+            rec = D._ld(1, D._ld(1, inner)) + b''.join(D._ld(1, D.encode_example(e, b % 2 == 0)) for e in exs[1:])
+        records.append(rec)
+    spec = {k: data.FixedLenFeature([widths[k]], F32, -3.0 + i) for i, k in enumerate(names)}
+    ospec = {k: (widths[k], -3.0 + i) for i, k in enumerate(names)}
+    feats, _, sizes, mask = D.parse_from_example_list(records, 5, ospec)
+    for threads in (1, 3):
+        got = data.parse_from_example_list(records, list_size=5, example_feature_spec=spec, size_feature_name='n',
+                                           mask_feature_name='m', num_threads=threads)
+        for k in names:
+            assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), k
+        assert got['n'].tolist() == sizes and got['m'].tolist() == mask
