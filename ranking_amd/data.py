@@ -18,6 +18,8 @@ import ctypes
 import glob as _glob
 import mmap
 import os
+import queue
+import threading
 from typing import Dict, Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -173,13 +175,119 @@ def make_parsing_fn(data_format, list_size=None, context_feature_spec=None, exam
     return _fn
 
 
+class Prefetcher:
+    """``dataset.prefetch(buffer_size)`` (data.py:1015) for this runtime: a background thread runs the wrapped
+    iterator ``buffer_size`` batches ahead -- reading and parsing happen inside ``libtfr_io.so``, which runs
+    without the GIL -- and, when ``device`` is a HIP device, stages each batch there on a dedicated copy stream
+    (pinned host buffer -> ``non_blocking`` copy -> event).  The consumer's stream waits on the event only, so the
+    host-to-device copy of batch n+1 overlaps the training step of batch n.  Nested dicts / tuples / lists of
+    tensors are handled; anything else passes through."""
+
+    _END = object()
+
+    def __init__(self, iterable: Iterable, buffer_size: int = 2, device=None):
+        self._it = iter(iterable)
+        self._queue: 'queue.Queue' = queue.Queue(maxsize=max(1, int(buffer_size)))
+        self._device = torch.device(device) if device is not None else None
+        self._cuda = self._device is not None and self._device.type == 'cuda'
+        if self._cuda and self._device.index is None:
+            self._device = torch.device('cuda', torch.cuda.current_device())
+        self._stream = torch.cuda.Stream(self._device) if self._cuda else None
+        self._stop = threading.Event()
+        self._done = False
+        self._thread = threading.Thread(target=self._run, name='tfr-prefetch', daemon=True)
+        self._thread.start()
+
+    def _map(self, obj, fn):
+        if torch.is_tensor(obj):
+            return fn(obj)
+        if isinstance(obj, dict):
+            return {k: self._map(v, fn) for k, v in obj.items()}
+        if isinstance(obj, tuple):
+            return tuple(self._map(v, fn) for v in obj)
+        if isinstance(obj, list):
+            return [self._map(v, fn) for v in obj]
+        return obj
+
+    def _put(self, item) -> bool:
+        while not self._stop.is_set():
+            try:
+                self._queue.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self):
+        try:
+            if self._cuda:
+                torch.cuda.set_device(self._device)
+            for batch in self._it:
+                event = None
+                if self._cuda:
+                    with torch.cuda.stream(self._stream):
+                        batch = self._map(batch, lambda t: (t if t.is_cuda else t.pin_memory()).to(
+                            self._device, non_blocking=True))
+                        event = torch.cuda.Event()
+                        event.record(self._stream)
+                elif self._device is not None:
+                    batch = self._map(batch, lambda t: t.to(self._device))
+                if not self._put((batch, event)):
+                    return
+            self._put(self._END)
+        except BaseException as e:                              # handed to the consumer, raised there
+            self._put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._done:
+            raise StopIteration
+        item = self._queue.get()
+        if item is self._END:
+            self._done = True
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._done = True
+            raise item
+        batch, event = item
+        if event is not None:
+            current = torch.cuda.current_stream(self._device)
+            current.wait_event(event)
+            self._map(batch, lambda t: (t.record_stream(current), t)[1])     # allocator: in use on `current` now
+        return batch
+
+    def close(self):
+        """Stops the background thread (needed for endless iterators: ``num_epochs=None``)."""
+        self._stop.set()
+        self._done = True
+        try:
+            while True:
+                self._queue.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=5.0)
+
+    def __del__(self):
+        self._stop.set()
+
+
 def build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, reader=None, reader_args=None,
                                           num_epochs=None, shuffle=True, shuffle_buffer_size=10000,
                                           shuffle_seed=None, prefetch_buffer_size=None, reader_num_threads=None,
                                           sloppy_ordering=False, drop_final_batch=False,
                                           num_parser_threads=None) -> Iterator[Dict[str, torch.Tensor]]:
-    """data.py:914-1017 as a Python generator of parsed batches (file and record shuffling with a
-    ``torch.Generator``; the reference's interleave / prefetch knobs are accepted and ignored)."""
+    """data.py:914-1017 as an iterator of parsed batches (file and record shuffling with a ``torch.Generator``).
+    ``prefetch_buffer_size`` > 0 reads and parses that many batches ahead on a background thread (``Prefetcher``;
+    the reference's AUTOTUNE default is None here = no thread); the interleave knobs are accepted and ignored."""
+    gen = _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch)
+    if prefetch_buffer_size is not None and int(prefetch_buffer_size) > 0:
+        return Prefetcher(gen, buffer_size=int(prefetch_buffer_size))
+    return gen
+
+
+def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch):
     files = sorted(sum((_glob.glob(p) for p in ([file_pattern] if isinstance(file_pattern, str) else file_pattern)), []))
     if not files:
         raise ValueError('no files match %r' % (file_pattern,))

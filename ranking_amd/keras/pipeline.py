@@ -234,7 +234,9 @@ class ModelFitPipeline(AbstractPipeline):
             patience=max(1, h.early_stopping_patience // 2 or 1)) if h.automatic_reduce_lr else None)
         rank, world = dist_lib.world()
         bucket = dist_lib.FlatGradBucket(model.parameters(), n_scalars=2).attach(model) if world > 1 else None
-        train_it = iter(self._dataset_builder.build_train_dataset())
+        # batches are staged on the GPU two ahead, on a copy stream (pinned buffer -> async copy -> event): the
+        # host-to-device copy of the next batch overlaps this step (data.Prefetcher)
+        train_it = data_lib.Prefetcher(self._dataset_builder.build_train_dataset(), buffer_size=2, device=self._device)
         history: Dict[str, List[float]] = {}
         best, since_best = None, 0
         os.makedirs(h.model_dir, exist_ok=True)
@@ -243,7 +245,7 @@ class ModelFitPipeline(AbstractPipeline):
             model.train()
             total = torch.zeros((), device=self._device)
             for _ in range(h.steps_per_epoch):
-                batch = self._to_device(next(train_it))
+                batch = next(train_it)
                 features, labels = batch[0], batch[1]
                 weights = batch[2] if len(batch) > 2 else None
                 opt.zero_grad(set_to_none=bucket is None)
@@ -302,6 +304,7 @@ class ModelFitPipeline(AbstractPipeline):
                 sched.step(monitor)
             if h.early_stopping_patience and since_best >= h.early_stopping_patience:
                 break
+        train_it.close()
         if rank == 0:
             os.makedirs(os.path.join(h.model_dir, 'export', 'latest_model'), exist_ok=True)
             torch.save(model.state_dict(), os.path.join(h.model_dir, 'export', 'latest_model', 'model.pt'))

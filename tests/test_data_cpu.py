@@ -285,3 +285,56 @@ def test_feature_order_hints_and_fast_paths_never_change_the_result():
         for k in names:
             assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), k
         assert got['n'].tolist() == sizes and got['m'].tolist() == mask
+
+
+def test_prefetcher_semantics_on_the_host(tmp_path):
+    """data.Prefetcher = dataset.prefetch(buffer_size) (data.py:1015): same batches in the same order, exceptions of
+    the producer surface in the consumer, endless iterators stop on close(); build_ranking_dataset honours
+    prefetch_buffer_size."""
+    import time
+
+    def gen(n):
+        for i in range(n):
+            time.sleep(0.002)
+            yield ({'x': torch.full((2, 3), float(i)), 'meta': 'kept'}, [torch.tensor([i])])
+    got = list(data.Prefetcher(gen(7), buffer_size=3))
+    assert [b[1][0].item() for b in got] == list(range(7)) and got[3][0]['meta'] == 'kept'
+    assert torch.equal(got[5][0]['x'], torch.full((2, 3), 5.0))
+
+    def bad():
+        yield torch.zeros(1)
+        raise RuntimeError('producer failed')
+    p = data.Prefetcher(bad(), 2)
+    next(p)
+    with pytest.raises(RuntimeError, match='producer failed'):
+        next(p)
+    with pytest.raises(StopIteration):
+        next(p)
+
+    def endless():
+        i = 0
+        while True:
+            yield torch.tensor([i])
+            i += 1
+    p = data.Prefetcher(endless(), 4)
+    assert [next(p).item() for _ in range(3)] == [0, 1, 2]
+    p.close()
+    assert not p._thread.is_alive()
+    # the dataset builder: identical batches with and without the background thread
+    rng = np.random.RandomState(3)
+    recs = [D.encode_elwc(None, [{'f': ('float', [float(np.float32(rng.randn()))]), 'label': ('float', [1.0])}
+                                 for _ in range(int(rng.randint(1, 4)))]) for _ in range(10)]
+    path = str(tmp_path / 'p.tfrecord')
+    data.write_tfrecord(path, recs)
+    spec = {'f': data.FixedLenFeature([1], F32, 0.0), 'label': data.FixedLenFeature([1], F32, -1.0)}
+    kw = dict(data_format=data.ELWC, batch_size=4, context_feature_spec=None, example_feature_spec=spec, list_size=3,
+              num_epochs=1, shuffle=True, shuffle_seed=5)
+    plain = list(data.build_ranking_dataset(path, **kw))
+    ahead = data.build_ranking_dataset(path, prefetch_buffer_size=2, **kw)
+    assert isinstance(ahead, data.Prefetcher)
+    ahead = list(ahead)
+    assert len(plain) == len(ahead) == 3
+    for a, b in zip(plain, ahead):
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(ValueError):
+        next(iter(data.build_ranking_dataset(str(tmp_path / 'none*.tfrecord'), prefetch_buffer_size=2, **kw)))

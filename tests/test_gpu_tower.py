@@ -506,3 +506,21 @@ def test_batched_weight_cast_equals_the_single_casts():
         want = t.cast_weight(w, transpose=tr, pitch=pitch)
         assert g.shape == want.shape and torch.equal(g.view(torch.int16), want.view(torch.int16))
     assert t.cast_weights([]) == []
+
+
+def test_prefetcher_stages_batches_on_the_gpu_through_a_copy_stream():
+    """data.Prefetcher(device=...): pinned buffer -> non_blocking copy on its own stream -> event the consumer's
+    stream waits on; values and order are those of the wrapped iterator."""
+    from ranking_amd import data
+
+    def gen():
+        for i in range(6):
+            yield ({'x': torch.full((64, 100, 8), float(i))}, torch.arange(4) + i)
+    p = data.Prefetcher(gen(), buffer_size=2, device=DEV)
+    seen = 0
+    for i, (f, y) in enumerate(p):
+        assert f['x'].is_cuda and y.is_cuda
+        assert float((f['x'] * 2).sum()) == 2.0 * i * 64 * 100 * 8        # consumed on the current stream
+        assert y.tolist() == [i, i + 1, i + 2, i + 3]
+        seen += 1
+    assert seen == 6
