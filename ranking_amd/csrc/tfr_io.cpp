@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <charconv>
 #include <string>
 #include <string_view>
 #include <thread>
@@ -412,7 +413,20 @@ extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t l
                                       float* features_out, float* labels_out, int64_t* stats_out) {
   if ((!text && nbytes) || list_size <= 0 || num_features <= 0) return TFR_IO_EINVAL;
   if ((features_out == nullptr) != (labels_out == nullptr)) return TFR_IO_EINVAL;
-  std::unordered_map<std::string, int64_t> qid_index;
+  // Python's float(token) then a float32 store (tf_ranking_libsvm.py:160-181): decimal -> double -> float, which
+  // from_chars<double> + a cast reproduces bit for bit; tokens it does not take whole ("+1", "1_0", " inf") go to
+  // strtod like before.
+  auto to_float = [](const char* b, const char* e, bool& ok) -> float {
+    double v = 0.0;
+    const auto r = std::from_chars(b, e, v);
+    if (r.ec == std::errc() && r.ptr == e) { ok = true; return (float)v; }
+    const std::string tmp(b, e);
+    char* endp = nullptr;
+    v = strtod(tmp.c_str(), &endp);
+    ok = endp != tmp.c_str();
+    return (float)v;
+  };
+  std::unordered_map<std::string_view, int64_t> qid_index;   // keys point into `text`
   std::vector<int32_t> ndoc;
   int64_t total = 0, discarded = 0;
   const char* p = text; const char* end = text + nbytes;
@@ -427,14 +441,13 @@ extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t l
     const char* s = skip_ws(p);
     if (s < le) {
       const char* e = tok_end(s);
-      const std::string label_tok(s, e);
-      char* endp = nullptr;
-      const float label = strtof(label_tok.c_str(), &endp);
-      if (endp == label_tok.c_str()) return TFR_IO_ECORRUPT;
+      bool ok = false;
+      const float label = to_float(s, e, ok);
+      if (!ok) return TFR_IO_ECORRUPT;
       s = skip_ws(e);
       if (s >= le) return TFR_IO_ECORRUPT;                  // "Ill-formatted line" (:143)
       e = tok_end(s);
-      const std::string qid(s, e);                          // the whole token, like the reference (:145)
+      const std::string_view qid(s, (size_t)(e - s));       // the whole token, like the reference (:145)
       auto it = qid_index.find(qid);
       int64_t q;
       if (it == qid_index.end()) {
@@ -456,9 +469,13 @@ extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t l
           e = tok_end(s);
           const char* colon = static_cast<const char*>(memchr(s, ':', (size_t)(e - s)));
           if (!colon) return TFR_IO_ECORRUPT;
-          const long fid = strtol(std::string(s, colon).c_str(), nullptr, 10);
+          long fid = 0;
+          const auto fr = std::from_chars(s, colon, fid);
+          if (fr.ec != std::errc() || fr.ptr != colon) fid = strtol(std::string(s, colon).c_str(), nullptr, 10);
           if (fid < 1 || fid > num_features) return TFR_IO_ESHAPE;   // "Key not found in features" (:181)
-          row[fid - 1] = strtof(std::string(colon + 1, e).c_str(), nullptr);
+          bool vok = false;
+          row[fid - 1] = to_float(colon + 1, e, vok);
+          if (!vok) return TFR_IO_ECORRUPT;                 // float('abc') raises in the reference too
           s = skip_ws(e);
         }
       }

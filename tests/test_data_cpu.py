@@ -338,3 +338,23 @@ def test_prefetcher_semantics_on_the_host(tmp_path):
         assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
     with pytest.raises(ValueError):
         next(iter(data.build_ranking_dataset(str(tmp_path / 'none*.tfrecord'), prefetch_buffer_size=2, **kw)))
+
+
+def test_libsvm_decimal_conversion_is_pythons_float_then_float32(tmp_path):
+    """tf_ranking_libsvm.py:160-181 stores float(token) (a double) into a float32 array: decimal -> double -> float.
+    The loader reproduces that double rounding (std::from_chars<double> + cast), '+1.5' / '1E5' / '.5' / '5.' forms,
+    overflow to inf and denormals; a token float() would reject is an error, as in the reference."""
+    pairs = [('0.1', '1e-45'), ('16777217', '0.30000001192092896'), ('+1.5', '1E5'),
+             ('7.038531e-26', '3.4028235677973366e38'), ('.5', '5.'), ('-0.0', '1.00000005960464477539')]
+    text = '\n'.join('1 qid:1 1:%s 2:%s' % p for p in pairs) + '\n'
+    path = str(tmp_path / 't.txt')
+    open(path, 'w').write(text)
+    f, l = data.load_libsvm_data(path, 8, 2)
+    of, ol = D.load_libsvm_data(text, 8, 2)[:2]
+    with np.errstate(over='ignore'):
+        want = np.asarray(of, dtype=np.float32)
+    assert np.array_equal(f.numpy().view(np.uint32), want.view(np.uint32))       # bit for bit, signed zero included
+    assert np.array_equal(l.numpy(), np.asarray(ol, dtype=np.float32))
+    open(path, 'w').write('1 qid:1 1:abc\n')
+    with pytest.raises(_io_lib.TfrIoError):
+        data.load_libsvm_data(path, 8, 2)
