@@ -96,3 +96,40 @@ def test_flat_bucket_single_process():
     assert s.tolist() == [1., 2., 3.]
     with pytest.raises(ValueError):
         D.FlatGradBucket([])
+
+
+def _avg_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(8, 4, 5, generator=g)
+    labels = torch.rand(8, 4, generator=g)
+    model = _toy_model()
+    bucket = D.FlatGradBucket(model.parameters(), n_scalars=2)
+    f, l = D.shard_lists([feats, labels])
+    value = -(torch.log_softmax(model(f).squeeze(-1), dim=1) * l).sum(dim=1).mean()    # Keras AUTO on the shard
+    bucket.zero()
+    value.backward()
+    s = bucket.all_reduce(torch.stack([value.detach(), value.new_tensor(1.0)]), average=True)   # bench.py / pipeline.py
+    out[rank] = ((s[0] / world).item(), s[1].item(), bucket.flat[:bucket.numel].clone())
+    dist.destroy_process_group()
+
+
+def test_averaged_all_reduce_of_the_training_step_world2():
+    """The step of bench.py (e2e workloads) and keras/pipeline.py: every rank back-propagates the AUTO (mean) loss
+    of its equal shard, ONE all_reduce(average=True) of the flat bucket carries the gradients and (loss, 1): the
+    gradients are those of the global-batch mean, the scalars come back summed."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_avg_worker, args=(world, port, out), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(3)
+    feats = torch.randn(8, 4, 5, generator=g)
+    labels = torch.rand(8, 4, generator=g)
+    model = _toy_model()
+    value = -(torch.log_softmax(model(feats).squeeze(-1), dim=1) * labels).sum(dim=1).mean()
+    value.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    for r in range(world):
+        assert abs(out[r][0] - value.item()) < 1e-6 and out[r][1] == float(world)
+        assert torch.allclose(out[r][2], want, atol=1e-6)
