@@ -45,11 +45,26 @@ class TfrIoError(RuntimeError):
     pass
 
 
+def _fingerprint() -> str:
+    import hashlib
+    h = hashlib.sha256(' '.join(CXX_FLAGS).encode())
+    for d in (SOURCE, os.path.join(INCLUDE, 'tfr_io.h')):
+        if os.path.exists(d):
+            with open(d, 'rb') as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
+    """Content decides (see _lib._stale); mtimes only when there is no stamp."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in (SOURCE, os.path.join(INCLUDE, 'tfr_io.h')) if os.path.exists(d))
+    try:
+        with open(LIB_PATH + '.stamp') as f:
+            return f.read().strip() != _fingerprint()
+    except OSError:
+        t = os.path.getmtime(LIB_PATH)
+        return any(os.path.getmtime(d) > t for d in (SOURCE, os.path.join(INCLUDE, 'tfr_io.h')) if os.path.exists(d))
 
 
 def build(force: bool = False) -> str:
@@ -64,6 +79,8 @@ def build(force: bool = False) -> str:
         if res.returncode != 0:
             raise TfrIoError('g++ failed:\n%s\n%s' % (res.stdout, res.stderr))
         os.replace(LIB_PATH + '.tmp', LIB_PATH)
+        with open(LIB_PATH + '.stamp', 'w') as f:
+            f.write(_fingerprint() + '\n')
         return LIB_PATH
 
 

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 INCLUDE = os.path.join(os.path.dirname(_HERE), 'include')
 LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
+STAMP_PATH = LIB_PATH + '.stamp'                           # fingerprint of what LIB_PATH was built from
 PROF_LIB_PATH = os.path.join(CSRC, 'libtfr_hip_prof.so')     # developer aid: -DTFR_PROFILE_STAMPS build
 SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip', 'listwise.hip',
            'neural_sort.hip', 'pointwise.hip']
@@ -114,13 +115,34 @@ def sources_present():
     return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def _deps():
+    deps = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    deps.append(os.path.join(INCLUDE, 'tfr_hip.h'))
+    return [d for d in deps if os.path.exists(d)]
+
+
+def _fingerprint() -> str:
+    """sha256 over the sources, the public header and the compiler flags: what the in-tree .so was built from."""
+    import hashlib
+    h = hashlib.sha256(' '.join(HIPCC_FLAGS).encode())
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale():
+    """Content, not timestamps, decides (a snapshot copied to a GPU box keeps no useful mtimes): the stamp file next
+    to the library holds the fingerprint it was built from.  Without a stamp (an older build) mtimes decide."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(('.hip', '.h'))]
-    deps.append(os.path.join(INCLUDE, 'tfr_hip.h'))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    try:
+        with open(STAMP_PATH) as f:
+            return f.read().strip() != _fingerprint()
+    except OSError:
+        t = os.path.getmtime(LIB_PATH)
+        return any(os.path.getmtime(d) > t for d in _deps())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -139,6 +161,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if res.returncode != 0:
             raise TfrHipError('hipcc failed:\n%s\n%s' % (res.stdout, res.stderr))
         os.replace(LIB_PATH + '.tmp', LIB_PATH)
+        with open(STAMP_PATH, 'w') as f:
+            f.write(_fingerprint() + '\n')
         return LIB_PATH
 
 
