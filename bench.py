@@ -267,6 +267,33 @@ def cpu_baseline(workload, L, budget_s=12.0):
                       % (Bc, L, iters, best_threads, avail)}
 
 
+def cpu_fused_c_baseline(workload, B, L):
+    """The stricter CPU number: the plain-C restatement of the same fwd+bwd (oracle/approx_ndcg_c.c, float,
+    -Ofast -march=native, OpenMP over lists) on the WHOLE batch, all host cores -- what a fused, vectorised CPU loop
+    does, next to the op-graph port above (which is how the reference itself executes).  None when gcc / the
+    library is unavailable on this host."""
+    if not workload.startswith('approx_ndcg'):
+        return None
+    try:
+        from oracle import c_ref
+        from tests.common import make_batch
+        labels, logits = make_batch(B, L, seed=4)
+        lb, lg = labels.numpy(), logits.numpy()
+        n = max(256, B // 16)
+        c_ref.approx_ndcg(lg[:n], lb[:n], temperature=0.1, variant='f32_fast')       # warm-up (threads, pages)
+        times = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            c_ref.approx_ndcg(lg, lb, temperature=0.1, variant='f32_fast')
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return {'value': B / times[len(times) // 2], 'unit': 'lists/s', 'cores': c_ref.threads(), 'kind': 'port',
+                'sample': 'plain-C restatement (oracle/approx_ndcg_c.c, fp32, -Ofast -march=native, OpenMP), '
+                          'ApproxNDCG fwd+bwd, the full %d x L=%d batch, median of 5' % (B, L)}
+    except Exception as e:                                 # the checker's build must never take the bench down
+        return {'value': None, 'unit': 'lists/s', 'error': '%s: %s' % (type(e).__name__, e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -412,6 +439,11 @@ def main():
         if cb is not None:
             result['cpu_baseline'] = cb
             result['gpu_over_cpu'] = value / cb['value']
+            fc = cpu_fused_c_baseline(args.workload, B, L)
+            if fc is not None:
+                cb['fused_c'] = fc                          # second, stricter CPU baseline (same unit)
+                if fc.get('value'):
+                    result['gpu_over_fused_c_cpu'] = value / fc['value']
     print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,102 @@
+"""Loader of the plain-C restatement of the headline path (oracle/approx_ndcg_c.c).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__ and bench.py's cpu_baseline leg, never by ranking_amd/.
+
+build() compiles the one source twice with gcc into oracle/_build/ (git-ignored, travels with gpurun):
+  libapprox_ndcg_f64.so   strict fp64 arbiter            tfr_c_approx_ndcg_f64
+  libapprox_ndcg_f32.so   -Ofast -march=native float     tfr_c_approx_ndcg_f32_fast
+"""
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, 'approx_ndcg_c.c')
+OUT = os.path.join(HERE, '_build')
+_VARIANTS = {
+    'f64': ('libapprox_ndcg_f64.so', 'tfr_c_approx_ndcg_f64', ['-O2', '-fno-fast-math']),
+    'f32_fast': ('libapprox_ndcg_f32.so', 'tfr_c_approx_ndcg_f32_fast', ['-DTFR_C_FLOAT', '-Ofast', '-march=native']),
+}
+_handles = {}
+
+
+def _host_isa():
+    """-march=native output is only valid on the CPU it was built on: the ISA flag set is part of the fingerprint, so
+    a snapshot that travels to another host (the GPU box) rebuilds there instead of dying on an illegal instruction."""
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith(('flags', 'Features')):
+                    return hashlib.sha256(line.encode()).hexdigest()[:16]
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _fingerprint(flags):
+    with open(SRC, 'rb') as f:
+        body = f.read()
+    isa = _host_isa() if '-march=native' in flags else ''
+    return hashlib.sha256(body + ' '.join(flags).encode() + isa.encode()).hexdigest()
+
+
+def build(force=False):
+    """gcc -shared -fPIC -fopenmp, once per variant; rebuilt when the source or the flags change."""
+    os.makedirs(OUT, exist_ok=True)
+    gcc = shutil.which('gcc')
+    paths = {}
+    for key, (lib, _sym, flags) in _VARIANTS.items():
+        path, stamp = os.path.join(OUT, lib), os.path.join(OUT, lib + '.stamp')
+        fp = _fingerprint(flags)
+        fresh = os.path.exists(path) and os.path.exists(stamp) and open(stamp).read().strip() == fp
+        if force or not fresh:
+            if gcc is None:
+                raise RuntimeError('gcc not found: cannot build %s' % path)
+            cmd = [gcc, '-std=c11', '-shared', '-fPIC', '-fopenmp'] + flags + [SRC, '-o', path + '.tmp', '-lm']
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError('gcc failed:\n%s\n%s' % (res.stdout, res.stderr))
+            os.replace(path + '.tmp', path)
+            with open(stamp, 'w') as f:
+                f.write(fp + '\n')
+        paths[key] = path
+    return paths
+
+
+def _fn(variant):
+    if variant not in _handles:
+        path = build()[variant]
+        lib = ctypes.CDLL(path)
+        fn = getattr(lib, _VARIANTS[variant][1])
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 3
+        _handles[variant] = fn
+    return _handles[variant]
+
+
+def approx_ndcg(logits, labels, mask=None, temperature=0.1, want_grad=True, variant='f64'):
+    """(loss [B], weight [B], dlogits [B, L] | None) as numpy fp32; per-list loss = -ApproxNDCG, weight = 1{sum
+    label > 0}, dlogits = d(sum_b loss_b) / d logits (losses_impl.py:1579-1603 with :77-167)."""
+    logits = np.ascontiguousarray(np.asarray(logits, dtype=np.float32))
+    labels = np.ascontiguousarray(np.asarray(labels, dtype=np.float32))
+    B, L = logits.shape
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+    loss = np.empty(B, dtype=np.float32)
+    weight = np.empty(B, dtype=np.float32)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    rc = _fn(variant)(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L,
+                      float(temperature), loss.ctypes.data, weight.ctypes.data,
+                      None if grad is None else grad.ctypes.data)
+    if rc != 0:
+        raise ValueError('approx_ndcg_c: invalid argument')
+    return loss, weight, grad
+
+
+def threads():
+    """omp_get_max_threads() of the C loops (what `cores` means for a timing of them)."""
+    lib = ctypes.CDLL(build()['f64'])
+    lib.tfr_c_threads.restype = ctypes.c_int
+    return int(lib.tfr_c_threads())
