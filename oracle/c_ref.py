@@ -1,9 +1,10 @@
 """Loader of the plain-C restatement of the headline path (oracle/approx_ndcg_c.c).  TEST INFRASTRUCTURE ONLY:
 imported by tests/, __graft_entry__ and bench.py's cpu_baseline leg, never by ranking_amd/.
 
-build() compiles the one source twice with gcc into oracle/_build/ (git-ignored, travels with gpurun):
-  libapprox_ndcg_f64.so   strict fp64 arbiter            tfr_c_approx_ndcg_f64
-  libapprox_ndcg_f32.so   -Ofast -march=native float     tfr_c_approx_ndcg_f32_fast
+build() compiles with gcc into oracle/_build/ (git-ignored, travels with gpurun):
+  libapprox_ndcg_f64.so        strict fp64 arbiter            tfr_c_approx_ndcg_f64
+  libapprox_ndcg_f32.so        -Ofast -march=native float     tfr_c_approx_ndcg_f32_fast
+  libpairwise_softmax_f64.so   pairwise_softmax_c.c (fp64)    tfr_c_pairwise_logistic_ndcg_f64, tfr_c_softmax_f64
 """
 import ctypes
 import hashlib
@@ -15,10 +16,12 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'approx_ndcg_c.c')
+SRC_PS = os.path.join(HERE, 'pairwise_softmax_c.c')
 OUT = os.path.join(HERE, '_build')
-_VARIANTS = {
-    'f64': ('libapprox_ndcg_f64.so', 'tfr_c_approx_ndcg_f64', ['-O2', '-fno-fast-math']),
-    'f32_fast': ('libapprox_ndcg_f32.so', 'tfr_c_approx_ndcg_f32_fast', ['-DTFR_C_FLOAT', '-Ofast', '-march=native']),
+_VARIANTS = {   # key: (library, entry point, flags, source)
+    'f64': ('libapprox_ndcg_f64.so', 'tfr_c_approx_ndcg_f64', ['-O2', '-fno-fast-math'], SRC),
+    'f32_fast': ('libapprox_ndcg_f32.so', 'tfr_c_approx_ndcg_f32_fast', ['-DTFR_C_FLOAT', '-Ofast', '-march=native'], SRC),
+    'ps_f64': ('libpairwise_softmax_f64.so', 'tfr_c_softmax_f64', ['-O2', '-fno-fast-math'], SRC_PS),
 }
 _handles = {}
 
@@ -36,8 +39,8 @@ def _host_isa():
     return 'unknown'
 
 
-def _fingerprint(flags):
-    with open(SRC, 'rb') as f:
+def _fingerprint(flags, src=SRC):
+    with open(src, 'rb') as f:
         body = f.read()
     isa = _host_isa() if '-march=native' in flags else ''
     return hashlib.sha256(body + ' '.join(flags).encode() + isa.encode()).hexdigest()
@@ -48,14 +51,14 @@ def build(force=False):
     os.makedirs(OUT, exist_ok=True)
     gcc = shutil.which('gcc')
     paths = {}
-    for key, (lib, _sym, flags) in _VARIANTS.items():
+    for key, (lib, _sym, flags, src) in _VARIANTS.items():
         path, stamp = os.path.join(OUT, lib), os.path.join(OUT, lib + '.stamp')
-        fp = _fingerprint(flags)
+        fp = _fingerprint(flags, src)
         fresh = os.path.exists(path) and os.path.exists(stamp) and open(stamp).read().strip() == fp
         if force or not fresh:
             if gcc is None:
                 raise RuntimeError('gcc not found: cannot build %s' % path)
-            cmd = [gcc, '-std=c11', '-shared', '-fPIC', '-fopenmp'] + flags + [SRC, '-o', path + '.tmp', '-lm']
+            cmd = [gcc, '-std=c11', '-shared', '-fPIC', '-fopenmp'] + flags + [src, '-o', path + '.tmp', '-lm']
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError('gcc failed:\n%s\n%s' % (res.stdout, res.stderr))
@@ -100,3 +103,44 @@ def threads():
     lib = ctypes.CDLL(build()['f64'])
     lib.tfr_c_threads.restype = ctypes.c_int
     return int(lib.tfr_c_threads())
+
+
+def _prep(logits, labels, mask):
+    logits = np.ascontiguousarray(np.asarray(logits, dtype=np.float32))
+    labels = np.ascontiguousarray(np.asarray(labels, dtype=np.float32))
+    m = None if mask is None else np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+    return logits, labels, m
+
+
+def pairwise_logistic_ndcg(logits, labels, mask=None, temperature=1.0, want_grad=True):
+    """(out [B], dlogits [B, L] | None): out[b] = sum_ij w_ij * logistic(s_i - s_j) with the Keras NDCGLambdaWeight()
+    pair weights (losses_impl.py:255-369, 483-537, 863-940); fp64 inside.  mask None, or equal to labels >= 0."""
+    logits, labels, m = _prep(logits, labels, mask)
+    B, L = logits.shape
+    lib = ctypes.CDLL(build()['ps_f64'])
+    fn = lib.tfr_c_pairwise_logistic_ndcg_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 2
+    out = np.empty(B, dtype=np.float32)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    if fn(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L, float(temperature),
+          out.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
+        raise ValueError('pairwise_logistic_ndcg_c: invalid argument')
+    return out, grad
+
+
+def softmax(logits, labels, mask=None, temperature=1.0, want_grad=True):
+    """(loss [B], weight [B], dlogits | None) of SoftmaxLoss without lambda weight (losses_impl.py:1119-1197)."""
+    logits, labels, m = _prep(logits, labels, mask)
+    B, L = logits.shape
+    lib = ctypes.CDLL(build()['ps_f64'])
+    fn = lib.tfr_c_softmax_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 3
+    loss = np.empty(B, dtype=np.float32)
+    weight = np.empty(B, dtype=np.float32)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    if fn(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L, float(temperature),
+          loss.ctypes.data, weight.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
+        raise ValueError('softmax_c: invalid argument')
+    return loss, weight, grad

@@ -56,3 +56,64 @@ def test_c_and_torch_restatements_agree(B, L):
     assert c_ref.threads() >= 1
     with pytest.raises(ValueError):
         c_ref.approx_ndcg(logits.numpy(), labels.numpy(), temperature=0.0)
+
+
+def test_softmax_c_known_answers_and_agreement():
+    # keras/losses_test.py:284-308, 735-741: Keras AUTO = sum_b loss_b * weight_b / B
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]
+    pick = lambda s, k: math.exp(s[k]) / sum(math.exp(x) for x in s)
+    loss, weight, _ = c_ref.softmax(scores, labels)
+    assert abs(float((loss * weight).sum()) / 3. + (ln(pick(scores[0], 2)) + ln(pick(scores[1], 2)) * 2.) / 3.) < 1e-6
+    loss, weight, _ = c_ref.softmax([[1., 3., 2.]], [[0., -1., 1.]])
+    assert abs(loss[0] + ln(pick([1., 2.], 1))) < 1e-6 and weight[0] == 1.0
+    for B, L, T in ((9, 7, 1.0), (33, 100, 0.5), (4, 1000, 2.0)):
+        lb, lg = make_batch(B, L, seed=700 + L)
+        lb[1] = -1.0
+        lb[2] = torch.where(lb[2] >= 0, torch.zeros_like(lb[2]), lb[2])
+        x = lg.clone().requires_grad_(True)
+        l_t, w_t = R.SoftmaxLoss(temperature=T).compute_unreduced_loss(lb, x)
+        l_t.sum().backward()
+        loss, weight, grad = c_ref.softmax(lg.numpy(), lb.numpy(), temperature=T)
+        assert np.abs(loss - l_t.detach().numpy()).max() < 2e-5 * max(1.0, float(l_t.detach().abs().max()))
+        assert np.array_equal(weight, w_t.numpy())
+        assert np.abs(grad - x.grad.numpy()).max() < 2e-6
+
+
+def _py_pairwise_ndcg(labels, scores):
+    """sum over pairs of the Keras NDCGLambdaWeight() weight times the logistic loss, in plain Python."""
+    L = len(labels)
+    order = sorted(range(L), key=lambda i: (-scores[i], i))
+    rank = {i: p + 1 for p, i in enumerate(order)}
+    gain = [2.0 ** l - 1.0 for l in labels]
+    D = lambda r: math.log(2.0) / math.log1p(r)
+    ideal = sum(g * D(p + 1) for p, g in enumerate(sorted(gain, reverse=True)))
+    total = 0.0
+    for i in range(L):
+        for j in range(L):
+            if labels[i] > labels[j]:
+                rd = abs(rank[i] - rank[j])
+                w = abs(gain[i] - gain[j]) / ideal * abs(D(rd) - D(rd + 1)) * L
+                total += w * math.log1p(math.exp(-(scores[i] - scores[j])))
+    return total
+
+
+def test_pairwise_logistic_ndcg_c_against_plain_python_and_torch():
+    scores = [[1., 3., 2., 0.5], [0.2, -0.4, 1.1, 2.0]]
+    labels = [[0., 0., 1., 2.], [3., 0., 1., 1.]]
+    out, _ = c_ref.pairwise_logistic_ndcg(scores, labels)
+    for b in range(2):
+        assert abs(out[b] - _py_pairwise_ndcg(labels[b], scores[b])) < 1e-5
+    for B, L, T in ((9, 7, 1.0), (17, 50, 1.0), (5, 200, 0.5)):
+        lb, lg = make_batch(B, L, seed=800 + L)
+        lb[1] = -1.0
+        lb[2] = torch.where(lb[2] >= 0, torch.ones_like(lb[2]), lb[2])                # all labels equal: no pair
+        x = lg.clone().requires_grad_(True)
+        o = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight(), temperature=T)
+        l_t, w_t = o.compute_unreduced_loss(lb, o.get_logits(x))        # the Keras __call__ order (keras/losses.py:277)
+        tot = (l_t * w_t).sum(dim=(1, 2))
+        tot.sum().backward()
+        out, grad = c_ref.pairwise_logistic_ndcg(lg.numpy(), lb.numpy(), temperature=T)
+        assert np.abs(out - tot.detach().numpy()).max() < 2e-5 * max(1.0, float(tot.detach().abs().max()))
+        assert np.abs(grad - x.grad.numpy()).max() < 2e-5 * max(1.0, float(x.grad.abs().max()))
+        assert out[1] == 0.0 and out[2] == 0.0
