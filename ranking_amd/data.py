@@ -16,7 +16,6 @@ from __future__ import annotations
 import collections
 import ctypes
 import glob as _glob
-import mmap
 import os
 import queue
 import threading

@@ -17,7 +17,6 @@ torch tower for it (same GPU, fp32, unfused).
 """
 from __future__ import annotations
 
-import math
 from typing import List, Optional
 
 import os
