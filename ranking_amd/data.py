@@ -280,13 +280,33 @@ def build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, 
     """data.py:914-1017 as an iterator of parsed batches (file and record shuffling with a ``torch.Generator``).
     ``prefetch_buffer_size`` > 0 reads and parses that many batches ahead on a background thread (``Prefetcher``;
     the reference's AUTOTUNE default is None here = no thread); the interleave knobs are accepted and ignored."""
-    gen = _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch)
+    gen = _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch,
+                           shuffle_buffer_size)
     if prefetch_buffer_size is not None and int(prefetch_buffer_size) > 0:
         return Prefetcher(gen, buffer_size=int(prefetch_buffer_size))
     return gen
 
 
-def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch):
+def _shuffle_stream(records: Iterable[bytes], buffer_size: int, g: torch.Generator) -> Iterator[bytes]:
+    """``dataset.shuffle(buffer_size)``: keep ``buffer_size`` records, emit a uniformly chosen one for every record
+    read and refill its slot; drain in random order at the end.  A buffer at least as large as the data gives a
+    uniform permutation; memory is the buffer, not the dataset."""
+    buf: List[bytes] = []
+    for r in records:
+        if len(buf) < buffer_size:
+            buf.append(r)
+            continue
+        k = int(torch.randint(len(buf), (1,), generator=g))
+        out, buf[k] = buf[k], r
+        yield out
+    for k in torch.randperm(len(buf), generator=g).tolist():
+        yield buf[k]
+
+
+def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch,
+                     shuffle_buffer_size=10000):
+    """Streams: one file in memory at a time (files in a fresh random order per epoch when ``shuffle``), records
+    through a ``shuffle_buffer_size`` shuffle buffer, ``batch_size`` records per parsed batch (data.py:975-1013)."""
     files = sorted(sum((_glob.glob(p) for p in ([file_pattern] if isinstance(file_pattern, str) else file_pattern)), []))
     if not files:
         raise ValueError('no files match %r' % (file_pattern,))
@@ -294,16 +314,16 @@ def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, 
     epoch = 0
     while num_epochs is None or epoch < num_epochs:
         order = torch.randperm(len(files), generator=g).tolist() if shuffle else range(len(files))
-        records: List[bytes] = []
-        for fi in order:
-            records.extend(read_tfrecord(files[fi]))
+        stream: Iterable[bytes] = (r for fi in order for r in read_tfrecord(files[fi]))
         if shuffle:
-            perm = torch.randperm(len(records), generator=g).tolist()
-            records = [records[i] for i in perm]
-        for lo in range(0, len(records), batch_size):
-            chunk = records[lo:lo + batch_size]
-            if len(chunk) < batch_size and drop_final_batch:
-                break
+            stream = _shuffle_stream(stream, max(1, int(shuffle_buffer_size or 1)), g)
+        chunk: List[bytes] = []
+        for r in stream:
+            chunk.append(r)
+            if len(chunk) == batch_size:
+                yield parsing_fn(chunk)
+                chunk = []
+        if chunk and not drop_final_batch:
             yield parsing_fn(chunk)
         epoch += 1
 

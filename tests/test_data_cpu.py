@@ -358,3 +358,32 @@ def test_libsvm_decimal_conversion_is_pythons_float_then_float32(tmp_path):
     open(path, 'w').write('1 qid:1 1:abc\n')
     with pytest.raises(_io_lib.TfrIoError):
         data.load_libsvm_data(path, 8, 2)
+
+
+def test_dataset_streams_through_a_shuffle_buffer(tmp_path):
+    """data.py:975-1013: files are read one at a time and records pass a `shuffle_buffer_size` buffer -- every record
+    appears exactly once per epoch, a buffer of 1 keeps the order inside a file, a large one mixes files."""
+    recs = [D.encode_elwc(None, [{'x': ('float', [float(q)])}]) for q in range(40)]
+    for k in range(4):
+        data.write_tfrecord(str(tmp_path / ('s%d.tfrecord' % k)), recs[k * 10:(k + 1) * 10])
+    spec = {'x': data.FixedLenFeature([1], F32, -1.0)}
+
+    def epoch(**kw):
+        ds = data.build_ranking_dataset(str(tmp_path / 's*.tfrecord'), data.ELWC, 8, None, spec, list_size=1,
+                                        num_epochs=1, **kw)
+        return torch.cat([b['x'] for b in ds])[:, 0, 0].tolist()
+    assert epoch(shuffle=False) == [float(q) for q in range(40)]
+    big = epoch(shuffle=True, shuffle_seed=1, shuffle_buffer_size=1000)
+    assert sorted(big) == [float(q) for q in range(40)] and big != sorted(big)
+    assert big == epoch(shuffle=True, shuffle_seed=1, shuffle_buffer_size=1000)          # seeded: reproducible
+    assert big != epoch(shuffle=True, shuffle_seed=2, shuffle_buffer_size=1000)
+    one = epoch(shuffle=True, shuffle_seed=3, shuffle_buffer_size=1)                        # only the FILE order moves
+    assert sorted(one) == [float(q) for q in range(40)]
+    for k in range(4):
+        block = one[k * 10:(k + 1) * 10]
+        assert block == sorted(block) and block[-1] - block[0] == 9.0
+    small = epoch(shuffle=True, shuffle_seed=4, shuffle_buffer_size=5)
+    assert sorted(small) == [float(q) for q in range(40)]
+    # a small buffer cannot move a record far: the i-th output was read no later than position i + buffer
+    files_first = [int(v) // 10 for v in small]
+    assert len(set(files_first[:10])) <= 2
