@@ -144,3 +144,19 @@ def softmax(logits, labels, mask=None, temperature=1.0, want_grad=True):
           loss.ctypes.data, weight.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
         raise ValueError('softmax_c: invalid argument')
     return loss, weight, grad
+
+
+def ndcg_mrr(predictions, labels, mask=None, topn=None):
+    """(ndcg [B], mrr [B]) per list, unweighted (metrics_impl.py:429-459, 631-670); fp64 inside."""
+    predictions, labels, m = _prep(predictions, labels, mask)
+    B, L = predictions.shape
+    lib = ctypes.CDLL(build()['ps_f64'])
+    fn = lib.tfr_c_ndcg_mrr_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+    ndcg = np.empty(B, dtype=np.float32)
+    mrr = np.empty(B, dtype=np.float32)
+    if fn(predictions.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L,
+          0 if topn is None else int(topn), ndcg.ctypes.data, mrr.ctypes.data) != 0:
+        raise ValueError('ndcg_mrr_c: invalid argument')
+    return ndcg, mrr

@@ -1,4 +1,4 @@
-/* TEST INFRASTRUCTURE ONLY -- plain-C (fp64 inside) restatements of two more rows of the hot path, independent of
+/* TEST INFRASTRUCTURE ONLY -- plain-C (fp64 inside) restatements of three more rows of the hot path, independent of
  * the torch restatement in tfr_ref.py; loaded by tests/ only (oracle/c_ref.py), never by the product.
  *
  * (1) PairwiseLogisticLoss with the Keras NDCGLambdaWeight defaults (config 3).  tensorflow_ranking/python:
@@ -133,6 +133,50 @@ int tfr_c_softmax_f64(const float* logits, const float* labels, const unsigned c
     }
     loss_out[b] = (float)loss;
     weight_out[b] = (float)label_sum;
+  }
+  return 0;
+}
+
+/* (3) NDCG@topn and MRR@topn per list, unweighted (metrics_impl.py:210-291 preparation, :429-459 MRR, :631-670 NDCG,
+ *     :589-628 _discounted_cumulative_gain; utils.py:115-164 sort_by_scores with the deterministic tie rule: descending
+ *     score, ties -> lower index first, invalid items after every valid one).  gain = 2^l - 1, discount = 1 / log2(1 + rank);
+ *     NDCG = DCG / ideal DCG (0 when the ideal is 0); MRR = 1 / rank of the first item with label >= 1 (0 if none).
+ *     topn <= 0 means the whole list.  fp64 inside: the torch restatement and the HIP kernel agree with each other bit
+ *     for bit through a shared fp32 summation order; this one pins the value itself. */
+int tfr_c_ndcg_mrr_f64(const float* predictions, const float* labels, const unsigned char* mask, int B, int L, int topn,
+                       float* ndcg_out, float* mrr_out) {
+  if (!predictions || !labels || !ndcg_out || !mrr_out || B < 0 || L <= 0) return -1;
+  const int K = (topn <= 0 || topn > L) ? L : topn;
+#pragma omp parallel
+  {
+    Item* items = (Item*)malloc((size_t)L * sizeof(Item));
+    double* ideal = (double*)malloc((size_t)L * sizeof(double));
+#pragma omp for schedule(dynamic, 16)
+    for (int b = 0; b < B; ++b) {
+      const float* pr = predictions + (size_t)b * L;
+      const float* lb = labels + (size_t)b * L;
+      int n = 0;
+      for (int i = 0; i < L; ++i) {
+        const int v = mask ? mask[(size_t)b * L + i] != 0 : lb[i] >= 0.0f;
+        if (!v) continue;
+        items[n].score = pr[i]; items[n].index = i;
+        ideal[n] = pow(2.0, (double)lb[i]) - 1.0;
+        ++n;
+      }
+      qsort(items, (size_t)n, sizeof(Item), by_score_desc);
+      qsort(ideal, (size_t)n, sizeof(double), dbl_desc);
+      double dcg = 0.0, idcg = 0.0, mrr = 0.0;
+      for (int p = 0; p < n && p < K; ++p) {
+        const double d = log(2.0) / log1p((double)(p + 1));
+        const double l = (double)lb[items[p].index];
+        dcg += (pow(2.0, l) - 1.0) * d;
+        idcg += ideal[p] * d;
+        if (mrr == 0.0 && l >= 1.0) mrr = 1.0 / (double)(p + 1);
+      }
+      ndcg_out[b] = idcg > 0.0 ? (float)(dcg / idcg) : 0.0f;
+      mrr_out[b] = (float)mrr;
+    }
+    free(items); free(ideal);
   }
   return 0;
 }

@@ -117,3 +117,27 @@ def test_pairwise_logistic_ndcg_c_against_plain_python_and_torch():
         assert np.abs(out - tot.detach().numpy()).max() < 2e-5 * max(1.0, float(tot.detach().abs().max()))
         assert np.abs(grad - x.grad.numpy()).max() < 2e-5 * max(1.0, float(x.grad.abs().max()))
         assert out[1] == 0.0 and out[2] == 0.0
+
+
+def test_ndcg_mrr_c_known_answers_and_agreement():
+    # keras/metrics.py:218-229, 729-740 doc values; keras/metrics_test.py:296-396, 856-992
+    ndcg, mrr = c_ref.ndcg_mrr([[3., 1., 2.]], [[0., 1., 1.]])
+    assert abs(ndcg[0] - 0.6934264) < 1e-6 and abs(mrr[0] - 0.5) < 1e-7
+    scores = [[1., 3., 2.], [1., 2., 3.], [3., 1., 2.]]
+    labels = [[0., 0., 1.], [0., 1., 2.], [0., 1., 0.]]
+    ndcg, mrr = c_ref.ndcg_mrr(scores, labels)
+    assert np.allclose(mrr, [1 / 2., 1., 1 / 3.], atol=1e-7)
+    dcg = lambda l, r: (2.0 ** l - 1.0) / math.log2(1.0 + r)
+    assert abs(ndcg[0] - (dcg(0., 1) + dcg(1., 2) + dcg(0., 3)) / (dcg(1., 1) + dcg(0., 2) + dcg(0., 3))) < 1e-6
+    assert abs(ndcg[1] - 1.0) < 1e-7
+    _, mrr1 = c_ref.ndcg_mrr(scores, labels, topn=1)
+    assert mrr1.tolist() == [0.0, 1.0, 0.0]
+    for B, L, topn in ((9, 7, None), (33, 100, 10), (64, 200, 5), (4, 1000, 1)):
+        lb, lg = make_batch(B, L, seed=600 + L)
+        lb[1] = -1.0
+        lb[2] = torch.where(lb[2] >= 0, torch.zeros_like(lb[2]), lb[2])
+        want_n, _ = R.NDCGMetric(topn=topn).compute(lb, lg)
+        want_m, _ = R.MRRMetric(topn=topn).compute(lb, lg)
+        ndcg, mrr = c_ref.ndcg_mrr(lg.numpy(), lb.numpy(), topn=topn)
+        assert np.abs(ndcg - want_n.reshape(-1).numpy()).max() < 2e-6
+        assert np.abs(mrr - want_m.reshape(-1).numpy()).max() < 1e-7
