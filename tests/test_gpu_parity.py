@@ -1420,3 +1420,54 @@ def test_keras_listwise_and_metric_known_answers_on_the_hip_path():
     near(m(km.MRRMetric(topn=2), labels, scores), (0.5 + 1.0) / 3.)
     near(m(km.MRRMetric(), labels, scores, weights), sum(w / r for w, r in zip(mw, rel_rank)) / sum(mw))
     near(m(km.MRRMetric(topn=1), labels, scores, weights), (mw[1] / rel_rank[1]) / sum(mw))
+
+
+# ------------------------------------------------------------------ the second, plain-C oracle (oracle/*_c.c)
+def _c_ref_or_skip():
+    try:
+        from oracle import c_ref
+        c_ref.build()
+        return c_ref
+    except Exception as e:                                   # no gcc on this host: the torch oracle tests still run
+        pytest.skip('plain-C oracle not buildable here: %s' % e)
+
+
+@pytest.mark.parametrize('B,L', [(5, 50), (64, 200), (3, 1000)])
+def test_hip_path_against_the_plain_c_arbiters(B, L):
+    """ApproxNDCG, PairwiseLogistic + NDCGLambdaWeight, Softmax and NDCG / MRR through the C ABI against the fp64
+    plain-C restatements (oracle/approx_ndcg_c.c, oracle/pairwise_softmax_c.c) -- an oracle that shares no code with
+    the torch one."""
+    c = _c_ref_or_skip()
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=1500 + L)
+    labels[1] = -1.0
+    labels[2] = torch.where(labels[2] >= 0, torch.zeros_like(labels[2]), labels[2])
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    t = lambda a: torch.from_numpy(a)
+    # ApproxNDCG (temperature 0.1)
+    loss, weight, d = _ops.approx_ndcg(lg, lb, None, None, 0.1)
+    w_loss, w_weight, w_grad = c.approx_ndcg(logits.numpy(), labels.numpy(), temperature=0.1)
+    assert_loss_close(loss, t(w_loss), 2e-5, what='approx_ndcg vs C')
+    assert torch.equal(weight.cpu(), t(w_weight))
+    assert_grad_close(d, t(w_grad), 3e-5, what='approx_ndcg grad vs C')
+    # Softmax
+    ones = torch.ones(B, device=DEV)
+    s_loss, s_weight, s_d = _ops.softmax_loss(lg, lb, None, ones, temperature=1.0, want_grad=True)
+    w_loss, w_weight, w_grad = c.softmax(logits.numpy(), labels.numpy())
+    assert_loss_close(s_loss, t(w_loss), 2e-5, what='softmax vs C')
+    assert_loss_close(s_weight, t(w_weight), 1e-6, what='softmax weight vs C')
+    # NDCG@10 / MRR@10
+    k = ra().metrics_impl
+    ndcg, _ = k.NDCGMetric(None, 10).compute(lb, lg)
+    mrr, _ = k.MRRMetric(None, 10).compute(lb, lg)
+    w_ndcg, w_mrr = c.ndcg_mrr(logits.numpy(), labels.numpy(), topn=10)
+    assert_loss_close(ndcg, t(w_ndcg), 5e-6, what='ndcg vs C')
+    assert_loss_close(mrr, t(w_mrr), 1e-6, what='mrr vs C')
+    # PairwiseLogistic + NDCGLambdaWeight: per-list sum of w_ij * loss_ij and its gradient
+    kl = ra().keras.losses
+    lam = ra().losses_impl._lambda_kernel_args(kl.NDCGLambdaWeight(), lb, L, torch.device(DEV))
+    row, _, _, dl = _ops.pairwise_logistic(lg, lb, None, None, ones, temperature=1.0, want_grad=True, want_aux=False,
+                                           loss_kind=kl.PairwiseLogisticLoss()._loss._fused_kind, **lam)
+    w_out, w_grad = c.pairwise_logistic_ndcg(logits.numpy(), labels.numpy())
+    assert_loss_close(row.sum(dim=1), t(w_out), 3e-5, what='pairwise vs C')
+    assert_grad_close(dl, t(w_grad), 5e-5, what='pairwise grad vs C')
