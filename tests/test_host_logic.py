@@ -208,3 +208,12 @@ def test_flatten_restore_and_tower_shapes():   # keras/layers.py:87-108,195-216
                                       activation=torch.relu, use_batch_norm=False, dropout=0.)
     logits = scorer(ctx, ex, mask)
     assert logits.shape == (2, 3) and logits[0, 2].item() == pytest.approx(e)
+
+
+def test_integration_doc_names_every_exported_symbol():
+    """INTEGRATION.md is the map from C entry points to the reference interfaces they replace: nothing exported
+    may be missing from it."""
+    from ranking_amd import _io_lib
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    missing = [s for s in list(_lib.EXPORTED_SYMBOLS) + list(_io_lib.EXPORTED_SYMBOLS) if s not in text]
+    assert not missing, missing
