@@ -276,12 +276,17 @@ def build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, 
                                           num_epochs=None, shuffle=True, shuffle_buffer_size=10000,
                                           shuffle_seed=None, prefetch_buffer_size=None, reader_num_threads=None,
                                           sloppy_ordering=False, drop_final_batch=False,
-                                          num_parser_threads=None) -> Iterator[Dict[str, torch.Tensor]]:
+                                          num_parser_threads=None, shard=None) -> Iterator[Dict[str, torch.Tensor]]:
     """data.py:914-1017 as an iterator of parsed batches (file and record shuffling with a ``torch.Generator``).
     ``prefetch_buffer_size`` > 0 reads and parses that many batches ahead on a background thread (``Prefetcher``;
-    the reference's AUTOTUNE default is None here = no thread); the interleave knobs are accepted and ignored."""
+    the reference's AUTOTUNE default is None here = no thread); the interleave knobs are accepted and ignored.
+    ``shard=(rank, world)``: data-parallel input -- every rank keeps its ``1 / world`` of the identically shuffled
+    record stream (what ``tf.distribute`` does to a dataset under ``AutoShardPolicy.DATA``); ``batch_size`` is then
+    the per-rank batch.  All ranks must pass the same ``shuffle_seed``."""
+    if shard is not None and not (0 <= int(shard[0]) < int(shard[1])):
+        raise ValueError('shard must be (rank, world) with 0 <= rank < world, got %r' % (shard,))
     gen = _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch,
-                           shuffle_buffer_size)
+                           shuffle_buffer_size, shard)
     if prefetch_buffer_size is not None and int(prefetch_buffer_size) > 0:
         return Prefetcher(gen, buffer_size=int(prefetch_buffer_size))
     return gen
@@ -303,8 +308,20 @@ def _shuffle_stream(records: Iterable[bytes], buffer_size: int, g: torch.Generat
         yield buf[k]
 
 
+def _shard_stream(records: Iterable[bytes], rank: int, world: int) -> Iterator[bytes]:
+    """tf.data's AutoShardPolicy.DATA: every rank walks the same (identically seeded) stream and keeps record
+    ``k * world + rank`` of it.  Only complete groups of ``world`` records are handed out, so all ranks see the same
+    number of records per epoch (a collective never waits for a rank that ran out of data)."""
+    group: List[bytes] = []
+    for r in records:
+        group.append(r)
+        if len(group) == world:
+            yield group[rank]
+            group = []
+
+
 def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, shuffle_seed, drop_final_batch,
-                     shuffle_buffer_size=10000):
+                     shuffle_buffer_size=10000, shard=None):
     """Streams: one file in memory at a time (files in a fresh random order per epoch when ``shuffle``), records
     through a ``shuffle_buffer_size`` shuffle buffer, ``batch_size`` records per parsed batch (data.py:975-1013)."""
     files = sorted(sum((_glob.glob(p) for p in ([file_pattern] if isinstance(file_pattern, str) else file_pattern)), []))
@@ -317,6 +334,8 @@ def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, 
         stream: Iterable[bytes] = (r for fi in order for r in read_tfrecord(files[fi]))
         if shuffle:
             stream = _shuffle_stream(stream, max(1, int(shuffle_buffer_size or 1)), g)
+        if shard is not None and shard[1] > 1:
+            stream = _shard_stream(stream, int(shard[0]), int(shard[1]))
         chunk: List[bytes] = []
         for r in stream:
             chunk.append(r)

@@ -122,7 +122,7 @@ class SimpleDatasetBuilder(AbstractDatasetBuilder):
             return features, label, weight
         return features, label
 
-    def _build_dataset(self, file_pattern, batch_size, list_size, randomize_input, num_epochs):
+    def _build_dataset(self, file_pattern, batch_size, list_size, randomize_input, num_epochs, shard=None):
         spec = dict(self._example_feature_spec)
         spec[self._label_spec[0]] = self._label_spec[1]
         if self._sample_weight_spec:
@@ -130,12 +130,16 @@ class SimpleDatasetBuilder(AbstractDatasetBuilder):
         ds = data_lib.build_ranking_dataset(
             file_pattern, data_lib.ELWC, batch_size, self._context_feature_spec, spec, list_size=list_size,
             mask_feature_name=self._mask_feature_name, shuffle=randomize_input, num_epochs=num_epochs,
-            drop_final_batch=randomize_input)
+            drop_final_batch=randomize_input, shard=shard)
         return (self._features_and_labels(f) for f in ds)
 
     def build_train_dataset(self):
+        # data parallel: `train_batch_size` is the GLOBAL batch (as under tf.distribute); rank r trains on its
+        # 1 / world of the identically shuffled stream -- the validation set stays whole on every rank
         h = self._hparams
-        return self._build_dataset(h.train_input_pattern, h.train_batch_size, h.list_size, True, None)
+        rank, world = dist_lib.world()
+        return self._build_dataset(h.train_input_pattern, max(1, h.train_batch_size // world), h.list_size, True, None,
+                                   shard=(rank, world) if world > 1 else None)
 
     def build_valid_dataset(self):
         h = self._hparams

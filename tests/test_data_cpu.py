@@ -387,3 +387,25 @@ def test_dataset_streams_through_a_shuffle_buffer(tmp_path):
     # a small buffer cannot move a record far: the i-th output was read no later than position i + buffer
     files_first = [int(v) // 10 for v in small]
     assert len(set(files_first[:10])) <= 2
+
+
+def test_data_parallel_sharding_of_the_record_stream(tmp_path):
+    """shard=(rank, world): the ranks' epochs are disjoint, together they cover the (group-complete part of the)
+    data, and every rank gets the same number of records -- tf.distribute's AutoShardPolicy.DATA."""
+    recs = [D.encode_elwc(None, [{'x': ('float', [float(q)])}]) for q in range(43)]       # 43 = 3 * 14 + 1
+    for k in range(3):
+        data.write_tfrecord(str(tmp_path / ('d%d.tfrecord' % k)), recs[k::3])
+    spec = {'x': data.FixedLenFeature([1], F32, -1.0)}
+
+    def epoch(shard, **kw):
+        ds = data.build_ranking_dataset(str(tmp_path / 'd*.tfrecord'), data.ELWC, 4, None, spec, list_size=1,
+                                        num_epochs=1, shard=shard, **kw)
+        return torch.cat([b['x'] for b in ds])[:, 0, 0].tolist()
+    for kw in (dict(shuffle=False), dict(shuffle=True, shuffle_seed=9, shuffle_buffer_size=16)):
+        whole = epoch(None, **kw)
+        parts = [epoch((r, 3), **kw) for r in range(3)]
+        assert [len(p) for p in parts] == [14, 14, 14]
+        assert sorted(sum(parts, [])) == sorted(whole[:42])              # the incomplete last group is dropped
+        assert all(parts[r] == whole[r:42:3] for r in range(3))
+    with pytest.raises(ValueError):
+        epoch((3, 3), shuffle=False)
