@@ -141,3 +141,26 @@ def test_ndcg_mrr_c_known_answers_and_agreement():
         ndcg, mrr = c_ref.ndcg_mrr(lg.numpy(), lb.numpy(), topn=topn)
         assert np.abs(ndcg - want_n.reshape(-1).numpy()).max() < 2e-6
         assert np.abs(mrr - want_m.reshape(-1).numpy()).max() < 1e-7
+
+
+def test_tie_rule_is_the_same_in_both_restatements():
+    """Tied scores: descending score, ties -> lower index first, invalid items last (the deterministic rule of
+    utils_test.py:108-109; the reference shuffles ties randomly otherwise).  Heavily tied integer scores must give the
+    same pairwise lambda weights (through the ranks) and the same NDCG / MRR in the C and the torch restatement."""
+    g = torch.Generator().manual_seed(11)
+    B, L = 40, 30
+    logits = torch.randint(-2, 3, (B, L), generator=g).float()           # 5 distinct values: ties everywhere
+    labels = torch.randint(0, 4, (B, L), generator=g).float()
+    n = torch.randint(L // 2, L + 1, (B,), generator=g)
+    labels[torch.arange(L).unsqueeze(0) >= n.unsqueeze(1)] = -1.0
+    o = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight())
+    l_t, w_t = o.compute_unreduced_loss(labels, logits)
+    out, _ = c_ref.pairwise_logistic_ndcg(logits.numpy(), labels.numpy())
+    tot = (l_t * w_t).sum(dim=(1, 2)).numpy()
+    assert np.abs(out - tot).max() < 2e-5 * max(1.0, np.abs(tot).max())
+    for topn in (None, 5):
+        want_n, _ = R.NDCGMetric(topn=topn).compute(labels, logits)
+        want_m, _ = R.MRRMetric(topn=topn).compute(labels, logits)
+        ndcg, mrr = c_ref.ndcg_mrr(logits.numpy(), labels.numpy(), topn=topn)
+        assert np.abs(ndcg - want_n.reshape(-1).numpy()).max() < 2e-6
+        assert np.abs(mrr - want_m.reshape(-1).numpy()).max() < 1e-7
