@@ -115,9 +115,16 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
     serialized = list(serialized)
     B = len(serialized)
     ptrs, lens = _record_arrays(serialized)
-    if list_size is None or list_size <= 0:
-        list_size = max(1, int(_io_lib.check(lib.tfr_io_elwc_max_list_size(ptrs, lens.ctypes.data, B),
-                                             'tfr_io_elwc_max_list_size')))
+    out_list_size = list_size
+    if list_size is None or list_size <= 0 or shuffle_examples:
+        cur = max(1, int(_io_lib.check(lib.tfr_io_elwc_max_list_size(ptrs, lens.ctypes.data, B),
+                                       'tfr_io_elwc_max_list_size')))
+        if list_size is None or list_size <= 0:
+            list_size = out_list_size = cur
+        else:
+            # data.py:164-182: the shuffle runs over ALL examples of the batch's longest list and the truncation to
+            # list_size comes after it (a truncated list is a random sample, not the first list_size examples)
+            list_size = max(cur, list_size)
     ex_names, ex_arr, _k1 = _spec_array(example_feature_spec)
     cx_names, cx_arr, _k2 = _spec_array(context_feature_spec or {})
     ex_w = [_spec_width(example_feature_spec[n]) for n in ex_names]
@@ -136,8 +143,9 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
     if shuffle_examples:
         from . import utils
         is_valid = torch.from_numpy(mask.astype(bool))
-        idx = utils.shuffle_valid_indices(is_valid, seed=seed)
+        idx = utils.shuffle_valid_indices(is_valid, seed=seed)[:, :out_list_size]
         ex_t = torch.gather(ex_t, 1, idx.unsqueeze(-1).expand(-1, -1, ex_t.shape[2]))
+        mask = mask[:, :out_list_size]                     # = sequence_mask(sizes, list_size), data.py:206
     features: Dict[str, torch.Tensor] = {}
     off = 0
     for name, w in zip(ex_names, ex_w):

@@ -31,14 +31,40 @@ def gather_per_row(inputs, indices):
     return torch.gather(inputs, 1, idx)
 
 
+# Op-level seeds behave like TensorFlow's (`tf.random.uniform(seed=s)`, utils.py:101): a seeded op owns a
+# random STREAM that is fixed by (global seed, op seed) and ADVANCES on every call -- two calls with the same
+# seed draw different numbers, a re-run of the program after `set_random_seed` draws the same sequence.  One
+# persistent torch.Generator per (device, seed) gives exactly that; a fresh `manual_seed(seed)` per call would
+# freeze "shuffled" orders to one permutation for the whole run.
+_GLOBAL_SEED = 0
+_STREAMS: Dict[tuple, torch.Generator] = {}
+
+
+def set_random_seed(seed: int = 0) -> None:
+    """`tf.random.set_seed`: restarts every seeded op stream (and re-keys them with ``seed``)."""
+    global _GLOBAL_SEED
+    _GLOBAL_SEED = int(seed)
+    _STREAMS.clear()
+
+
+def random_stream(seed: Optional[int], device) -> Optional[torch.Generator]:
+    """The persistent generator of the op seed ``seed`` on ``device`` (None -> torch's global stream)."""
+    if seed is None:
+        return None
+    device = torch.device(device)
+    key = (device.type, device.index, int(seed))
+    gen = _STREAMS.get(key)
+    if gen is None:
+        gen = torch.Generator(device=device)
+        gen.manual_seed((_GLOBAL_SEED * 0x9E3779B1 + int(seed)) & 0x7FFFFFFFFFFFFFFF)
+        _STREAMS[key] = gen
+    return gen
+
+
 def _tiebreak(shape, device, shuffle_ties, seed):
     if not shuffle_ties:
         return None
-    gen = None
-    if seed is not None:
-        gen = torch.Generator(device=device)
-        gen.manual_seed(int(seed))
-    return torch.randint(0, 32768, shape, dtype=torch.int32, device=device, generator=gen)
+    return torch.randint(0, 32768, shape, dtype=torch.int32, device=device, generator=random_stream(seed, device))
 
 
 def sort_by_scores(scores, features_list, topn=None, shuffle_ties=True, seed=None, mask=None):
@@ -131,11 +157,7 @@ def organize_valid_indices(is_valid, shuffle=True, seed=None):
     is_valid = torch.as_tensor(is_valid, dtype=torch.bool)
     b, l = is_valid.shape
     if shuffle:
-        gen = None
-        if seed is not None:
-            gen = torch.Generator(device=is_valid.device)
-            gen.manual_seed(int(seed))
-        values = torch.rand((b, l), device=is_valid.device, generator=gen)
+        values = torch.rand((b, l), device=is_valid.device, generator=random_stream(seed, is_valid.device))
     else:
         values = torch.arange(l - 1, -1, -1, dtype=torch.float32, device=is_valid.device).expand(b, l)
     rand = torch.where(is_valid, values, torch.full_like(values, -1e-6))
