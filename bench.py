@@ -71,7 +71,7 @@ def e2e_flops_per_list(workload, L):
 
 
 def make_inputs(B, L, seed, device):
-    from tests.common import make_batch
+    from ranking_amd.synthetic import make_batch
     labels, logits = make_batch(B, L, seed)
     return labels.to(device), logits.to(device)
 
@@ -224,7 +224,7 @@ def cpu_baseline(workload, L, budget_s=12.0):
     The thread count is calibrated (best of a few candidates up to the cores this
     process may run on) so that the baseline is not handicapped by oversubscription."""
     from oracle import tfr_ref as R
-    from tests.common import make_batch
+    from ranking_amd.synthetic import make_batch
     if not workload.startswith('approx_ndcg'):
         return None
     try:
@@ -275,7 +275,7 @@ def cpu_fused_c_baseline(workload, B, L):
         return None
     try:
         from oracle import c_ref
-        from tests.common import make_batch
+        from ranking_amd.synthetic import make_batch
         labels, logits = make_batch(B, L, seed=4)
         lb, lg = labels.numpy(), logits.numpy()
         n = max(256, B // 16)

@@ -948,6 +948,22 @@ def keras_loss_call(loss, y_true, y_pred, sample_weight=None, reduction=Reductio
     return keras_compute_weighted_loss(out, sw, reduction)
 
 
+def keras_calibrated_softmax_call(y_true, y_pred, sample_weight=None, reduction=Reduction.AUTO, lambda_weight=None,
+                                  temperature=1.0, virtual_label=0.0):
+    """Restates ``tfr.keras.losses.CalibratedSoftmaxLoss.__call__`` (keras/losses.py:899-936): a virtual item with
+    label ``virtual_label`` and score 0 (weight 1 under per-item weights) is appended, then SoftmaxLoss.__call__."""
+    y_true, y_pred = _t(y_true), _t(y_pred)
+    b = y_true.shape[0]
+    y_true = torch.cat([y_true, torch.ones((b, 1), dtype=y_true.dtype) * virtual_label], dim=1)       # :915-918
+    y_pred = torch.cat([y_pred, torch.zeros((b, 1), dtype=y_pred.dtype)], dim=1)                      # :921-922
+    if sample_weight is not None:
+        sample_weight = _t(sample_weight)
+        if sample_weight.dim() == 2 and sample_weight.shape[1] > 1:                                   # :924-928
+            sample_weight = torch.cat([sample_weight, torch.ones((b, 1), dtype=sample_weight.dtype)], dim=1)
+    loss = SoftmaxLoss(lambda_weight=lambda_weight, temperature=temperature)
+    return keras_loss_call(loss, y_true, y_pred, sample_weight, reduction)
+
+
 # ----------------------------------------------------------------------------
 # metrics_impl.py
 # ----------------------------------------------------------------------------

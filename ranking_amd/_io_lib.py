@@ -68,17 +68,18 @@ def _stale():
 
 
 def build(force: bool = False) -> str:
-    with _lock:
+    from ._lib import _BuildLock
+    with _lock, _BuildLock(LIB_PATH + '.lock'):              # ranks of one torchrun job build once, not concurrently
         if not force and not _stale():
             return LIB_PATH
         cxx = shutil.which('g++') or shutil.which('c++')
         if cxx is None:
             raise TfrIoError('g++ not found: cannot build %s' % LIB_PATH)
-        res = subprocess.run([cxx] + CXX_FLAGS + ['-I', INCLUDE, SOURCE, '-o', LIB_PATH + '.tmp'],
-                             capture_output=True, text=True)
+        tmp = '%s.%d.tmp' % (LIB_PATH, os.getpid())
+        res = subprocess.run([cxx] + CXX_FLAGS + ['-I', INCLUDE, SOURCE, '-o', tmp], capture_output=True, text=True)
         if res.returncode != 0:
             raise TfrIoError('g++ failed:\n%s\n%s' % (res.stdout, res.stderr))
-        os.replace(LIB_PATH + '.tmp', LIB_PATH)
+        os.replace(tmp, LIB_PATH)
         with open(LIB_PATH + '.stamp', 'w') as f:
             f.write(_fingerprint() + '\n')
         return LIB_PATH

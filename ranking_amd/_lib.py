@@ -145,25 +145,94 @@ def _stale():
         return any(os.path.getmtime(d) > t for d in _deps())
 
 
+OBJ_DIR = os.path.join(CSRC, '_obj')                     # per-source objects + their fingerprints (git-ignored)
+COMPILE_FLAGS = [f for f in HIPCC_FLAGS if f != '-shared']
+
+
+class _BuildLock:
+    """Inter-process lock around stale-check + build: under torchrun every rank may find the library stale at the
+    same moment; one compiles, the others wait and then see a fresh stamp."""
+
+    def __init__(self, path):
+        self._path, self._fd = path, None
+
+    def __enter__(self):
+        import fcntl
+        self._fd = os.open(self._path, os.O_CREAT | os.O_RDWR, 0o644)
+        fcntl.flock(self._fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self._fd, fcntl.LOCK_UN)
+        os.close(self._fd)
+
+
+def _source_fingerprint(src: str) -> str:
+    """What one object file depends on: its source, the shared headers and the compile flags."""
+    import hashlib
+    h = hashlib.sha256(' '.join(COMPILE_FLAGS).encode())
+    deps = [os.path.join(CSRC, src)] + [d for d in _deps() if d.endswith('.h')]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _compile_one(hipcc: str, src: str, verbose: bool) -> str:
+    obj = os.path.join(OBJ_DIR, src + '.o')
+    stamp = obj + '.stamp'
+    fp = _source_fingerprint(src)
+    try:
+        with open(stamp) as f:
+            if f.read().strip() == fp and os.path.exists(obj):
+                return obj
+    except OSError:
+        pass
+    tmp = '%s.%d.tmp' % (obj, os.getpid())
+    cmd = [hipcc] + COMPILE_FLAGS + ['-I', INCLUDE, '-c', os.path.join(CSRC, src), '-o', tmp]
+    if verbose:
+        print(' '.join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise TfrHipError('hipcc failed on %s:\n%s\n%s' % (src, res.stdout, res.stderr))
+    os.replace(tmp, obj)
+    with open(stamp, 'w') as f:
+        f.write(fp + '\n')
+    return obj
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compiles every HIP translation unit for gfx950 into libtfr_hip.so (in-tree)."""
+    """Compiles every HIP translation unit for gfx950 (one object per source, in parallel, re-using the objects
+    whose source / headers / flags did not change) and links them into the in-tree libtfr_hip.so."""
     with _lock:
-        if not force and not _stale():
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        with _BuildLock(os.path.join(OBJ_DIR, '.lock')):
+            if not force and not _stale():
+                return LIB_PATH
+            hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+            if not os.path.exists(hipcc):
+                raise TfrHipError('hipcc not found: cannot build %s' % LIB_PATH)
+            if force:
+                for f in os.listdir(OBJ_DIR):
+                    if f.endswith('.stamp'):
+                        os.remove(os.path.join(OBJ_DIR, f))
+            from concurrent.futures import ThreadPoolExecutor
+            srcs = sources_present()
+            with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+                objs = list(pool.map(lambda s_: _compile_one(hipcc, s_, verbose), srcs))
+            tmp = '%s.%d.tmp' % (LIB_PATH, os.getpid())
+            cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-fvisibility=default'] + objs + ['-o', tmp]
+            if verbose:
+                print(' '.join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise TfrHipError('hipcc link failed:\n%s\n%s' % (res.stdout, res.stderr))
+            os.replace(tmp, LIB_PATH)
+            with open(STAMP_PATH, 'w') as f:
+                f.write(_fingerprint() + '\n')
             return LIB_PATH
-        hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
-        if not os.path.exists(hipcc):
-            raise TfrHipError('hipcc not found: cannot build %s' % LIB_PATH)
-        srcs = [os.path.join(CSRC, s) for s in sources_present()]
-        cmd = [hipcc] + HIPCC_FLAGS + ['-I', INCLUDE] + srcs + ['-o', LIB_PATH + '.tmp']
-        if verbose:
-            print(' '.join(cmd))
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise TfrHipError('hipcc failed:\n%s\n%s' % (res.stdout, res.stderr))
-        os.replace(LIB_PATH + '.tmp', LIB_PATH)
-        with open(STAMP_PATH, 'w') as f:
-            f.write(_fingerprint() + '\n')
-        return LIB_PATH
 
 
 def build_profiling(verbose: bool = False) -> str:

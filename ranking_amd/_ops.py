@@ -7,6 +7,7 @@ current stream and returns freshly allocated outputs.  No CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import functools
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
@@ -441,3 +442,33 @@ def gumbel_sample_bwd(sampled, labels, mask, upstream, sample_size, gumbel_tempe
                                                B, S, L, float(gumbel_temperature), _ptr(out), _stream())
     _lib.check(rc, 'tfr_gumbel_sample_bwd_f32')
     return out
+
+
+def device_guarded(fn):
+    """Runs ``fn`` with the HIP device of its first device-tensor argument current, so that ``_stream()`` and every
+    allocation inside land on the device the tensors live on (a caller holding cuda:1 tensors while cuda:0 is current
+    would otherwise launch on the wrong device's stream)."""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        dev = None
+        for a in args:
+            if isinstance(a, (list, tuple)) and a:
+                a = a[0]
+            if torch.is_tensor(a) and a.is_cuda:
+                dev = a.device
+                break
+        if dev is None or dev.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(dev):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
+def _guard_module(namespace, module_name, skip=()):
+    for name, obj in list(namespace.items()):
+        if (callable(obj) and not name.startswith('_') and getattr(obj, '__module__', None) == module_name
+                and isinstance(obj, type(_guard_module)) and name not in skip):
+            namespace[name] = device_guarded(obj)
+
+
+_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded'))

@@ -10,6 +10,7 @@ import os
 import torch
 
 from . import _lib
+from . import _ops
 from ._ops import _ptr, _stream, require_device
 
 class Dropout(ctypes.Structure):
@@ -298,3 +299,6 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
     _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 1 if accumulate_into is not None else 0,
                                          _stream()), 'tfr_tower_slab_reduce')
     return out
+
+
+_ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask'))

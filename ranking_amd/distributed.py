@@ -41,6 +41,37 @@ def shard_lists(tensors: Sequence[torch.Tensor], rank: Optional[int] = None,
     return [t[lo:hi] for t in tensors]
 
 
+def broadcast_module(module: torch.nn.Module, src: int = 0, group=None) -> None:
+    """Makes every replica start from rank ``src``'s parameters and buffers (what `tf.distribute` mirrored variables
+    do from a single initialisation): ONE broadcast of one flat fp32 buffer, then a scatter back.  Without it the
+    ranks would average gradients of differently initialised models."""
+    _, w = world()
+    if w <= 1:
+        return
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    tensors = [t for t in tensors if t.numel()]
+    if not tensors:
+        return
+    flat = torch.cat([t.reshape(-1).to(torch.float32) for t in tensors])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for t in tensors:
+        t.copy_(flat[off:off + t.numel()].view_as(t).to(t.dtype))
+        off += t.numel()
+
+
+def all_reduce_scalars(values: Sequence, device, average: bool = False, group=None) -> List[float]:
+    """Sums (or averages) a few python / tensor scalars over the ranks with one collective -- the validation
+    loss, early-stopping monitors: every rank must take the same decision or the next all-reduce hangs."""
+    _, w = world()
+    buf = torch.stack([torch.as_tensor(v, dtype=torch.float64, device=device).reshape(()) for v in values])
+    if w > 1:
+        dist.all_reduce(buf, group=group)
+        if average:
+            buf /= w
+    return [float(x) for x in buf.tolist()]
+
+
 class FlatGradBucket:
     """Re-homes every parameter's ``.grad`` into one contiguous fp32 buffer with
     ``n_scalars`` extra slots at its end, so a step needs exactly one all-reduce."""

@@ -85,6 +85,7 @@ def get(loss: str, reduction: str = Reduction.AUTO, lambda_weight=None, name: Op
         RankingLossKey.PAIRWISE_MSE_LOSS: PairwiseMSELoss,
         RankingLossKey.YETI_LOGISTIC_LOSS: YetiLogisticLoss,
         RankingLossKey.SOFTMAX_LOSS: SoftmaxLoss,
+        RankingLossKey.CALIBRATED_SOFTMAX_LOSS: CalibratedSoftmaxLoss,
         RankingLossKey.LIST_MLE_LOSS: ListMLELoss,
         RankingLossKey.UNIQUE_SOFTMAX_LOSS: UniqueSoftmaxLoss,
     }
@@ -165,6 +166,17 @@ class PrecisionLambdaWeight(losses_impl.PrecisionLambdaWeight):
 
     def get_config(self) -> Dict[str, Any]:
         return {'topn': self._topn, 'positive_fn': self._positive_fn}
+
+
+@utils.register_keras_serializable()
+class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
+    """keras/losses.py:233-244: the serialisable form of the position weights of ListMLELoss."""
+
+    def __init__(self, rank_discount_fn=None, **kwargs):
+        super().__init__(rank_discount_fn)
+
+    def get_config(self) -> Dict[str, Any]:
+        return {'rank_discount_fn': self._rank_discount_fn}
 
 
 # ------------------------------------------------------------------- helpers
@@ -420,13 +432,51 @@ class SoftmaxLoss(_ListwiseLoss):
         b, l = y_pred.shape
         scale = self._scale(b)
         w = _const_vector(b, scale, y_pred.device) if sample_weight is None else sample_weight * scale
-        lam = losses_impl._lambda_kernel_args(self._lambda_weight, y_true, l, y_pred.device)
-        if lam is None or lam['lambda_kind'] == _ops.LAMBDA_LABELDIFF:
-            lam = dict(lambda_kind=_ops.LAMBDA_NONE)
-        lam.pop('smooth_fraction', None)
+        lam = self._loss._lambda_args(y_true, y_pred, mask)      # only a DCGLambdaWeight is active, like __call__
         loss, weight, dlogits = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
-                                                  temperature=self._temperature, want_grad=True, **lam)
+                                                  temperature=self._temperature, want_grad=True,
+                                                  poly_epsilon=self._loss._poly_epsilon, **lam)
         return torch.dot(loss, weight), dlogits
+
+
+@utils.register_keras_serializable()
+class CalibratedSoftmaxLoss(SoftmaxLoss):
+    """keras/losses.py:835-936: softmax over the list PLUS one virtual item with score 0 and label
+    ``virtual_label`` (item weight 1 when per-item weights are given):
+    ``loss = -sum_i y_i log(e^{s_i} / (1 + sum_j e^{s_j})) - y_0 log(1 / (1 + sum_j e^{s_j}))``.
+    It is the softmax kernel on a list of L + 1 items; the virtual item's gradient column is dropped."""
+
+    def __init__(self, reduction=Reduction.AUTO, name=None, lambda_weight=None, temperature=1.0,
+                 virtual_label=0.0):
+        super().__init__(reduction, name, lambda_weight, temperature, False)
+        assert virtual_label >= 0, 'Virtual label must be non-negative.'
+        self._virtual_label = virtual_label
+
+    def get_config(self) -> Dict[str, Any]:
+        config = super().get_config()
+        config.pop('ragged', None)                      # not a constructor argument of this class (:876-883)
+        config.update({'virtual_label': self._virtual_label})
+        return config
+
+    def _with_virtual_item(self, y_true, y_pred, sample_weight):
+        y_pred = _ops.require_device(torch.as_tensor(y_pred), 'y_pred').to(torch.float32)
+        y_true = torch.as_tensor(y_true, dtype=torch.float32, device=y_pred.device)
+        losses_impl._check_tensor_shapes([y_true, y_pred])
+        b = y_true.shape[0]
+        y_true = torch.cat([y_true, y_true.new_full((b, 1), float(self._virtual_label))], dim=1)
+        y_pred = torch.cat([y_pred, y_pred.new_zeros((b, 1))], dim=1)
+        if sample_weight is not None:
+            sample_weight = torch.as_tensor(sample_weight, dtype=torch.float32, device=y_pred.device)
+            if sample_weight.dim() == 2 and sample_weight.shape[1] > 1:
+                sample_weight = torch.cat([sample_weight, sample_weight.new_ones((b, 1))], dim=1)
+        return y_true, y_pred, sample_weight
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        return super().__call__(*self._with_virtual_item(y_true, y_pred, sample_weight))
+
+    def loss_and_grad(self, y_true, y_pred, sample_weight=None):
+        loss, dlogits = super().loss_and_grad(*self._with_virtual_item(y_true, y_pred, sample_weight))
+        return loss, dlogits[:, :-1].contiguous()
 
 
 @utils.register_keras_serializable()

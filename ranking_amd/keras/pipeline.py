@@ -230,6 +230,7 @@ class ModelFitPipeline(AbstractPipeline):
         """keras/pipeline.py:561-650.  Returns the history (per-epoch loss / val_loss / val metrics)."""
         h = self._hparams
         model = self._model_builder.build().to(self._device)
+        dist_lib.broadcast_module(model)        # replicas start from rank 0's initialisation (mirrored variables)
         loss = self.build_loss()
         metrics = self.build_weighted_metrics() if h.use_weighted_metrics else self.build_metrics()
         opt = _OPTIMIZERS[h.optimizer](model.parameters(), lr=h.learning_rate)
@@ -257,9 +258,13 @@ class ModelFitPipeline(AbstractPipeline):
                     bucket.zero()
                 logits = model(features)
                 if fused:                       # one launch: loss AND d loss / d logits
-                    value, dlogits = loss.loss_and_grad(labels, logits.detach(), weights)
-                    logits.backward(dlogits)
-                else:
+                    try:
+                        value, dlogits = loss.loss_and_grad(labels, logits.detach(), weights)
+                    except NotImplementedError:  # e.g. YetiLogisticLoss, a pairwise loss with a non-fusable
+                        fused = False            # lambda weight: the autograd path serves them
+                    else:
+                        logits.backward(dlogits)
+                if not fused:
                     value = loss(labels, logits, weights)
                     value.backward()
                 if bucket is not None:          # ONE all-reduce of the flat gradient bucket per step
@@ -287,6 +292,9 @@ class ModelFitPipeline(AbstractPipeline):
                     vcount += 1
                     for m in metrics:
                         m.update_state(labels, logits, weights if h.use_weighted_metrics else None)
+            if world > 1:                       # every rank must see the same numbers: the early-stopping and
+                vsum, vcount = dist_lib.all_reduce_scalars([vloss, vcount], self._device)   # LR decisions below
+                vloss = vsum                    # decide whether this rank enters the next all-reduce
             history.setdefault('val_loss', []).append(float(vloss) / max(1, vcount))
             for m in metrics:
                 history.setdefault('val_' + m.name, []).append(float(m.result()))

@@ -703,16 +703,22 @@ class SoftmaxLoss(_ListwiseLoss):
     """losses_impl.py:1119-1197; fused kernel tfr_softmax_loss_f32."""
     _poly_epsilon = 0.0
 
-    def _run(self, labels, logits, weights, mask, temperature):
+    def _lambda_args(self, labels, logits, mask):
+        """Kernel arguments of `individual_weights`: only a DCGLambdaWeight is active in SoftmaxLoss.precompute
+        (losses_impl.py:1132-1134); any other lambda weight (V2, Precision, LabelDiff, ...) is ignored there."""
         lam = (self._lambda_weight._kernel_args(labels, logits.shape[1], logits.device)
                if isinstance(self._lambda_weight, DCGLambdaWeight)
-               else dict(lambda_kind=_ops.LAMBDA_NONE))  # only DCGLambdaWeight applies (:1132)
+               else dict(lambda_kind=_ops.LAMBDA_NONE))
         lam.pop('smooth_fraction', None)
         if lam.get('gain_kind') == _ops.GAIN_CUSTOM:
             m = mask if mask is not None else labels >= 0
             clean = torch.where(m, labels, torch.zeros_like(labels))
             clean = torch.where(clean >= 0, clean, torch.zeros_like(clean))
             lam['gains'] = self._lambda_weight._gain_fn(clean).to(torch.float32).contiguous()
+        return lam
+
+    def _run(self, labels, logits, weights, mask, temperature):
+        lam = self._lambda_args(labels, logits, mask)
 
         def runner(lg, want_grad):
             loss, weight, d = _ops.softmax_loss(lg, labels, mask, weights, temperature=temperature,

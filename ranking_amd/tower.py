@@ -52,6 +52,11 @@ class _TowerFn(torch.autograd.Function):
         betas = params[3 * n_h:4 * n_h] if use_bn else [None] * n_h
         w_out, b_out = params[-2], params[-1]
         dev = x.device
+        if ctx.needs_input_grad[0]:
+            # the layer-0 dgrad (d loss / d features) is not implemented: anything upstream of the tower
+            # (an embedding, a projection) would silently train on no gradient -- refuse instead
+            raise NotImplementedError('FusedTower does not propagate a gradient to its input; detach the features '
+                                      'or use the torch-op tower (compute_dtype=torch.float32) below trainable layers')
         if row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
             x0 = T.cast_rows(x, row_index=row_index, width=T.pad_k(x.shape[1]))
         else:

@@ -133,3 +133,89 @@ def test_averaged_all_reduce_of_the_training_step_world2():
     for r in range(world):
         assert abs(out[r][0] - value.item()) < 1e-6 and out[r][1] == float(world)
         assert torch.allclose(out[r][2], want, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- keras/pipeline.py DP branch, 2 ranks
+class _ToyLoss:
+    """Torch-only stand-in with the Keras loss protocol (the product losses need a HIP device): softmax
+    cross-entropy per list, AUTO (mean over lists) reduction.  No `loss_and_grad` -> the autograd branch."""
+
+    def __call__(self, y_true, y_pred, sample_weight=None):
+        return -(torch.log_softmax(y_pred, dim=1) * y_true).sum(dim=1).mean()
+
+
+class _ToyModelBuilder:
+    def __init__(self, seed):
+        self._seed = seed
+
+    def build(self):
+        torch.manual_seed(self._seed)                          # a DIFFERENT initialisation on every rank
+
+        class _M(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.net = torch.nn.Sequential(torch.nn.Linear(5, 8), torch.nn.ReLU(), torch.nn.Linear(8, 1))
+                self.register_buffer('steps_seen', torch.full((1,), float(torch.initial_seed())))
+
+            def forward(self, features):
+                return self.net(features['x']).squeeze(-1)
+        return _M()
+
+
+def _toy_batches(n_steps, batch, lo, hi):
+    g = torch.Generator().manual_seed(11)
+    feats = torch.randn(n_steps, batch, 4, 5, generator=g)
+    labels = torch.rand(n_steps, batch, 4, generator=g)
+    return [({'x': feats[s, lo:hi]}, labels[s, lo:hi]) for s in range(n_steps)]
+
+
+def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8):
+    from ranking_amd.keras import pipeline as P
+    lo, hi = D.shard_bounds(batch, rank, world)
+
+    class _Pipe(P.ModelFitPipeline):
+        def build_loss(self):
+            return _ToyLoss()
+
+        def build_metrics(self):
+            return []
+
+        def build_weighted_metrics(self):
+            return []
+    # rank-dependent validation data: the early-stopping / best-checkpoint decisions must still agree
+    valid = _toy_batches(2, batch, 0, batch) if rank == 0 else _toy_batches(2, batch, 0, batch // 2)
+    hp = P.PipelineHparams(model_dir=os.path.join(tmp, 'rank%d' % rank), num_epochs=3, steps_per_epoch=2,
+                           validation_steps=2, learning_rate=0.05, loss='toy', optimizer='sgd',
+                           early_stopping_patience=2, automatic_reduce_lr=True)
+    pipe = _Pipe(_ToyModelBuilder(seed), P.NullDatasetBuilder(iter(_toy_batches(n_steps, batch, lo, hi)), valid), hp,
+                 device=torch.device('cpu'))
+    history = pipe.train_and_validate()
+    flat = torch.cat([p.detach().reshape(-1) for p in pipe.model.parameters()])
+    return history, flat, float(pipe.model.steps_seen)
+
+
+def _pipeline_worker(rank, world, port, tmp, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    history, flat, buf = _run_toy_pipeline(tmp, rank, world, seed=100 + rank)
+    out[rank] = (history, flat, buf)
+    dist.destroy_process_group()
+
+
+def test_model_fit_pipeline_data_parallel_world2(tmp_path):
+    """`ModelFitPipeline.train_and_validate` with 2 ranks (keras/pipeline.py:605-632 under a tf.distribute strategy):
+    replicas are initialised differently, rank 0's parameters AND buffers are broadcast, each rank trains on its half
+    of every batch, one all-reduce per step; the result equals the single-process run on the whole batches from rank
+    0's initialisation, and both ranks record the same (globally reduced) validation history."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path), out), nprocs=world, join=True)
+    want_hist, want_flat, want_buf = _run_toy_pipeline(str(tmp_path / 'single'), 0, 1, seed=100)
+    for r in range(world):
+        hist, flat, buf = out[r]
+        assert torch.allclose(flat, want_flat, atol=1e-6), (flat - want_flat).abs().max()
+        assert buf == want_buf                                   # buffers are broadcast too
+        assert hist['loss'] == pytest.approx(want_hist['loss'], abs=1e-6)
+    assert out[0][0]['val_loss'] == out[1][0]['val_loss']       # the same decisions on every rank
+    assert len(out[0][0]['val_loss']) == len(out[1][0]['val_loss'])

@@ -1379,6 +1379,23 @@ def test_keras_listwise_and_metric_known_answers_on_the_hip_path():
     near(k.SoftmaxLoss(lambda_weight=lam)(t(labels), t(scores)).cpu(),
          -(ln(_pick(scores[0], 2)) / ln(3.) + ln(_pick(scores[1], 2)) * 2. / ln(2.)) / 3.)
     near(k.SoftmaxLoss()(yt, yp).cpu(), -ln(_pick([1., 2.], 1)))
+    # CalibratedSoftmax (keras/losses_test.py:936-970, doc value keras/losses.py:850-854) + ListMLELambdaWeight (:562-575)
+    from tests.test_oracle_keras_golden import _calibrated_expected
+    cal = k.get('calibrated_softmax_loss', virtual_label=0.5)
+    near(cal(t(labels), t(scores)).cpu(), _calibrated_expected(scores, labels, [1., 1., 1.], 0.5))
+    near(cal(t(labels), t(scores), t([[2.], [1.], [1.]])).cpu(), _calibrated_expected(scores, labels, [2., 1., 1.], 0.5))
+    near(k.CalibratedSoftmaxLoss(virtual_label=0.1)(t([[1., 0.]]), t([[0.6, 0.8]])).cpu(), 1.1808171)
+    cv, cg = cal.loss_and_grad(t(labels), t(scores))
+    xs = t(scores).requires_grad_(True)
+    cal(t(labels), xs).backward()
+    near(cv.cpu(), _calibrated_expected(scores, labels, [1., 1., 1.], 0.5))
+    assert cg.shape == xs.shape and (cg - xs.grad).abs().max().item() <= 1e-6
+    assert k.CalibratedSoftmaxLoss.from_config(cal.get_config())._virtual_label == 0.5
+    mle_scores, mle_labels = [[0., ln(3), ln(2)], [0., ln(2), ln(3)]], [[0., 2., 1.], [1., 0., 2.]]
+    lw = k.ListMLELambdaWeight(rank_discount_fn=lambda rank: torch.pow(torch.tensor(2.), 3 - rank) - 1.)
+    near(k.get('list_mle_loss', lambda_weight=lw)(t(mle_labels), t(mle_scores)).cpu(),
+         -((3 * ln(3. / 6) + 1 * ln(2. / 3)) + (3 * ln(3. / 6) + 1 * ln(1. / 3))) / 2)
+    assert 'rank_discount_fn' in lw.get_config()
     # ApproxNDCG, three reductions (keras/losses_test.py:576-602, 650-693)
     scores = [[1.4, -2.8, -0.4], [0., 1.8, 10.2], [1., 1.2, -3.2]]
     labels = [[0., 2., 1.], [1., 0., 3.], [0., 0., 0.]]
@@ -1471,3 +1488,22 @@ def test_hip_path_against_the_plain_c_arbiters(B, L):
     w_out, w_grad = c.pairwise_logistic_ndcg(logits.numpy(), labels.numpy())
     assert_loss_close(row.sum(dim=1), t(w_out), 3e-5, what='pairwise vs C')
     assert_grad_close(dl, t(w_grad), 5e-5, what='pairwise grad vs C')
+
+
+@pytest.mark.gpu
+def test_integration_stub_runs():
+    """The ctypes stub documented in INTEGRATION.md (section 2), executed as written, on device buffers: loss and
+    gradient equal the in-repo binding's."""
+    from tests.test_host_logic import integration_stub_namespace
+    ns = integration_stub_namespace()
+    B, L = 16, 40
+    labels, logits = make_batch(B, L, seed=21)
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    inv = ra()._ops.rank_table(ra()._ops._inv_log1p, L, torch.device(DEV))       # [L] fp32 1/log1p(r), host computed
+    loss = torch.empty(B, device=DEV); weight = torch.empty(B, device=DEV); d = torch.empty((B, L), device=DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    ns['approx_ndcg'](lg.data_ptr(), lb.data_ptr(), inv.data_ptr(), B, L, 0.1, loss.data_ptr(), weight.data_ptr(),
+                      d.data_ptr(), stream)
+    torch.cuda.synchronize()
+    want_loss, want_w, want_d = ra()._ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
+    assert torch.equal(loss, want_loss) and torch.equal(weight, want_w) and torch.equal(d, want_d)

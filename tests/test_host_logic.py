@@ -217,3 +217,40 @@ def test_integration_doc_names_every_exported_symbol():
     text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
     missing = [s for s in list(_lib.EXPORTED_SYMBOLS) + list(_io_lib.EXPORTED_SYMBOLS) if s not in text]
     assert not missing, missing
+
+
+def integration_stub_namespace():
+    """Executes the ctypes stub documented in INTEGRATION.md section 2 (the binding a reference maintainer would
+    add) against the in-tree library and returns its namespace."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    stub = [b for b in blocks if 'ctypes.CDLL(' in b]
+    assert len(stub) == 1, 'INTEGRATION.md must hold exactly one ctypes stub'
+    code = stub[0].replace("'ranking_amd/csrc/libtfr_hip.so'", repr(_lib.LIB_PATH))
+    _lib.load()                                               # builds the library when it is stale
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    return ns
+
+
+def header_arity(name):
+    src = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
+    m = re.search(r'^int\s+%s\s*\((.*?)\)\s*;' % re.escape(name), src, flags=re.M | re.S)
+    assert m, name
+    return len([a for a in m.group(1).split(',') if a.strip()])
+
+
+def test_integration_stub_matches_the_header():
+    """The documented stub must bind the entry point with the header's arity and the argtypes this repository's own
+    binding uses (round 1 shipped a 13-argument stub for a 14-argument function)."""
+    ns = integration_stub_namespace()
+    fn = ns['lib'].tfr_approx_ndcg_f32
+    assert len(fn.argtypes) == header_arity('tfr_approx_ndcg_f32')
+    assert list(fn.argtypes) == list(_lib._SIGNATURES['tfr_approx_ndcg_f32'][1])
+    # the call inside the stub passes exactly that many arguments
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    call_args = doc.split('rc = lib.tfr_approx_ndcg_f32(')[1].split(')\n')[0]
+    assert len([a for a in call_args.split(',') if a.strip()]) == header_arity('tfr_approx_ndcg_f32')
+    # every header entry point has the arity the in-repo binding declares
+    for name, (_, argtypes) in _lib._SIGNATURES.items():
+        assert len(argtypes) == header_arity(name) or name == 'tfr_hip_abi_version', name

@@ -93,6 +93,29 @@ def test_keras_softmax_loss():
     near(R.keras_loss_call(R.SoftmaxLoss(), T([[0., -1., 1.]]), T([[1., 3., 2.]])), -ln(_pick([1., 2.], 1)))
 
 
+def _calibrated_expected(scores, labels, list_w, virtual_label):
+    """keras/losses_test.py:936-970 closed form: softmax with the denominator shifted by e^0 = 1 plus the virtual term."""
+    den = lambda v: sum(math.exp(x) for x in v)
+    tot = 0.0
+    for sc, lb, w in zip(scores, labels, list_w):
+        for k, y in enumerate(lb):
+            if y:
+                tot += w * y * ln(math.exp(sc[k]) / (den(sc) + 1.0))
+        tot -= w * virtual_label * ln(1.0 + den(sc))
+    return -tot / len(scores)
+
+
+def test_keras_calibrated_softmax_loss():                                # keras/losses_test.py:936-970
+    scores = [[1.0, 3.0, 2.0], [1.0, 2.0, 3.0], [1.0, 2.0, 3.0]]
+    labels = [[0.0, 0.0, 1.0], [0.0, 0.0, 2.0], [0.0, 0.0, 0.0]]
+    near(R.keras_calibrated_softmax_call(T(labels), T(scores), virtual_label=0.5),
+         _calibrated_expected(scores, labels, [1., 1., 1.], 0.5))
+    near(R.keras_calibrated_softmax_call(T(labels), T(scores), T([[2.0], [1.0], [1.0]]), virtual_label=0.5),
+         _calibrated_expected(scores, labels, [2., 1., 1.], 0.5))
+    # docstring value, keras/losses.py:850-854
+    near(R.keras_calibrated_softmax_call(T([[1., 0.]]), T([[0.6, 0.8]]), virtual_label=0.1), 1.1808171)
+
+
 # ---------------------------------------------------------------------------- ApproxNDCG (keras/losses_test.py:576-602, 650-693)
 def _norm_weight(w, l):
     return sum(wi * li for wi, li in zip(w, l)) / sum(l) if sum(l) > 0 else 0.0

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import ranking_amd as ra
-from tests.common import make_batch
+from ranking_amd.synthetic import make_batch
 
 B, L, steps = 16384, 200, 50
 labels, logits = make_batch(B, L, 4)

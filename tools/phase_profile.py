@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ranking_amd import _lib  # noqa: E402
-from tests.common import make_batch  # noqa: E402
+from ranking_amd.synthetic import make_batch  # noqa: E402
 
 
 def main():
