@@ -4,21 +4,31 @@
 Headline (BASELINE.json `metric`): ranked lists/sec, loss forward+backward,
 ApproxNDCG (temperature 0.1) at list_size=200, 16384 lists per GPU per step
 (SURVEY.md 8d row H), synthetic inputs already resident in HBM.  A "step" is one
-pass of the hot path over one batch: one fused kernel launch that produces the
-per-list loss AND d loss / d logits, plus the [B]-vector dot that reduces the
-loss to a scalar.
+pass of the hot path over one batch: the fused kernel launch that produces the
+per-list loss AND d loss / d logits (plus the launch-order helper and the scalar
+reduction the Keras call returns).
 
     python bench.py --gpus N --steps K --warmup W [--workload NAME]
 
-For N > 1 the driver launches one rank per GPU with torch.distributed.run; lists
-shard across ranks with no data-path collective (the loss path has no exchange
-step: SURVEY.md 8e) -> "scaling": "weak".  Rank 0 prints ONE JSON line.
+`--gpus N` with N > 1 from a bare shell re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, backend
+"nccl" = RCCL over xGMI); when the driver has already launched the ranks
+(WORLD_SIZE set) it just joins them.  The loss kernels shard the lists across
+ranks with no data-path collective -> "scaling": "weak"; the
+end-to-end workloads (`e2e_*`) run ONE all-reduce of the flat gradient bucket per
+step and report its time separately.  Rank 0 prints ONE JSON line; with `--also`
+(the default set is the BASELINE multi-GPU configs 4 and 5 plus the pairwise
+kernel north_star names) the same line carries those workloads under "also".
+Every workload entry has `roofline` (dominant kernel, HIP events) and, at N = 1,
+`cpu_baseline` (the oracle on a bounded sample on the host cores).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,9 +39,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
+TRAFFIC_FILES = ('profiles/r02_traffic.json', 'profiles/r01_traffic.json')     # newest first
 
 WORKLOADS = {
-    # name: (B per GPU, L, description, algorithmic HBM bytes per list)
+    # name: (B per GPU, L, description, algorithmic HBM bytes per list -- SURVEY.md 8d)
     'approx_ndcg': (16384, 200, 'ApproxNDCGLoss(T=0.1) loss fwd+bwd, B=16384/GPU, L=200 (SURVEY 8d row H)',
                     lambda L: 12 * L + 12),
     'approx_ndcg_l1000': (512, 1000, 'ApproxNDCGLoss(T=0.1) loss fwd+bwd, B=512/GPU, L=1000 (config 4 shard)',
@@ -57,8 +69,13 @@ WORKLOADS = {
                                       'GumbelApproxNDCGLoss(S=8), 512 lists/GPU, L=50, 1 all-reduce/step',
                              lambda L: 0),
 }
+DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel')
 
-MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
+# VALU issue cost of the O(L^2) pair sweeps, SIMD cycles per 64 pair evaluations, measured on MI355X with
+# tools/ubench.hip (profiles/): ApproxNDCG forward + backward sweep; pairwise = the lean logistic+lambda pair body
+# (18 plain VALU at 2.4 + 3 transcendentals at 8.5 cycles).  Used for `roofline.valu_frac` (the bound that applies).
+VALU_CYCLES_PER_64_PAIRS = {'approx_ndcg': 15.3 + 20.5, 'pairwise': 18 * 2.4 + 3 * 8.5}
+SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
 
 
 def e2e_flops_per_list(workload, L):
@@ -70,6 +87,49 @@ def e2e_flops_per_list(workload, L):
     return 6.0 * macs * L
 
 
+# ------------------------------------------------------------------------------------------ launching N ranks
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n_gpus: int, argv, port: int):
+    """The command `python bench.py --gpus N ...` re-executes itself as (the driver's own launch line)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def respawn_under_torchrun(args, argv) -> int:
+    if not args.plumbing_check:
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            raise SystemExit('bench.py --gpus %d needs %d MI355X GPUs, %d visible (no CPU fallback)'
+                             % (args.gpus, args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC only on this host driver (RCCL needs it)
+    return subprocess.call(launch_command(args.gpus, argv, free_port()), env=env)
+
+
+def plumbing_check(rank, world):
+    """`--plumbing-check`: rendezvous + ONE real all-reduce per rank on the `gloo` backend and nothing else -- the
+    part of the N > 1 path a GPU-less host can exercise (tests/test_bench_contract_cpu.py).  It measures nothing
+    and prints no metric."""
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({'plumbing_check': True, 'n_gpus': world, 'rccl_ranks': ranks, 'backend': 'gloo',
+                          'all_reduce_sum': float(t.item())}))
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ the steps
 def make_inputs(B, L, seed, device):
     from ranking_amd.synthetic import make_batch
     labels, logits = make_batch(B, L, seed)
@@ -77,34 +137,58 @@ def make_inputs(B, L, seed, device):
 
 
 def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
-    """Returns (step_fn, kernel_fn) -- kernel_fn launches only the dominant kernel."""
-    from ranking_amd import _ops
+    """Returns a dict: step (callable), kernel (callable launching only the dominant kernel, or None),
+    kernel_name, and for the e2e workloads `all_reduce` (callable: the step's collective alone)."""
+    from ranking_amd import _ops, losses_impl
     from ranking_amd.keras import losses as K
     from ranking_amd import metrics_impl
+    B, L = labels.shape
+    dev = labels.device
     if workload.startswith('approx_ndcg'):
         loss = K.ApproxNDCGLoss()
-        B = labels.shape[0]
-        scale = torch.full((B,), 1.0 / B, dtype=torch.float32, device=labels.device)
+        scale = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
         # the dominant kernel alone, in the configuration the step runs it: with the longest-first launch order
         # when the step computes one (two small launches that the step pays for and this timing leaves out)
         order = _ops._auto_order(labels, None, None, 192)
-        return (lambda: loss.loss_and_grad(labels, logits),
-                lambda: _ops.approx_ndcg(logits, labels, None, scale, 0.1, 0, True,
-                                         balance=order if order is not None else False))
+        return dict(step=lambda: loss.loss_and_grad(labels, logits),
+                    kernel=lambda: _ops.approx_ndcg(logits, labels, None, scale, 0.1, 0, True,
+                                                    balance=order if order is not None else False),
+                    kernel_name='approx_ndcg_wave_kernel' if L <= 256 else 'approx_ndcg_kernel')
     if workload == 'pairwise_lambda':
         loss = K.PairwiseLogisticLoss(lambda_weight=K.NDCGLambdaWeight())
-        return (lambda: loss.loss_and_grad(labels, logits)), None
+        lam = losses_impl._lambda_kernel_args(loss._lambda_weight, labels, L, dev)
+        list_w = torch.full((B,), 1.0 / (B * L), dtype=torch.float32, device=dev)
+        order = _ops._auto_order(labels, None, None, 128)
+        return dict(step=lambda: loss.loss_and_grad(labels, logits),
+                    kernel=lambda: _ops.pairwise_logistic(
+                        logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_aux=False,
+                        loss_kind=_ops.PAIR_LOGISTIC, balance=order if order is not None else False, **lam),
+                    kernel_name='pairwise_wave_kernel' if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()
-        return (lambda: loss.loss_and_grad(labels, logits)), None
+        w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
+        return dict(step=lambda: loss.loss_and_grad(labels, logits),
+                    kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True),
+                    kernel_name='softmax_wave_kernel')
     if workload == 'gumbel_approx_ndcg':
         loss = K.GumbelApproxNDCGLoss(seed=1)
-        return (lambda: loss.loss_and_grad(labels, logits)), None
+        S = 8
+        sampled = _ops.gumbel_sample(logits, labels, None, None, 1, 0, S, 1.0)
+        gl = labels.unsqueeze(1).expand(B, S, L).reshape(B * S, L).contiguous()
+        scale = torch.full((B * S,), 1.0 / (B * S), dtype=torch.float32, device=dev)
+        return dict(step=lambda: loss.loss_and_grad(labels, logits),
+                    kernel=lambda: _ops.approx_ndcg(sampled, gl, None, scale, 0.1, 0, True, balance=False),
+                    kernel_name='approx_ndcg_wave_kernel on the B*S sampled lists (the sampler and its backward are '
+                                'two more launches of the step)')
     if workload == 'ndcg_metric':
         m = metrics_impl.NDCGMetric(None, None)
-        return (lambda: m.compute_multi(labels, logits, None, None, [1, 3, 5, 10, None])), None
+        topns = [1, 3, 5, 10, None]
+        discount = _ops.rank_table(m._rank_discount_fn, L, dev)
+        return dict(step=lambda: m.compute_multi(labels, logits, None, None, topns),
+                    kernel=lambda: _ops.ndcg_metric(labels, logits, None, None, None, discount, topns),
+                    kernel_name='rank_metric_wave_kernel<NDCG>')
     if workload.startswith('e2e_'):
-        return build_e2e_step(workload, labels, dropout, use_graph), None
+        return build_e2e_step(workload, labels, dropout, use_graph)
     raise ValueError(workload)
 
 
@@ -117,22 +201,20 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     g = torch.Generator(device=dev).manual_seed(1234 + int(os.environ.get('RANK', '0')))
     feats = torch.rand((B, L, 136), generator=g, device=dev) * 2 - 1
     mask = labels >= 0
-    torch.manual_seed(0)                                  # identical replicas on every rank
+    torch.manual_seed(0)                                  # identical replicas on every rank ...
+    graph_generators = []
     if workload == 'e2e_groupwise_gumbel':
         from ranking_amd import model as gmodel
         tower = ra.keras.layers.create_tower([512, 512, 512], 2, activation=torch.relu, use_batch_norm=True,
                                              dropout=dropout, input_dim=272, compute_dtype=torch.bfloat16)
 
-        def group_score_fn(ctx, group_features):
-            x = group_features['x']
-            return tower(x.reshape(x.shape[0], -1))
-        gw = gmodel.GroupwiseScorer(group_score_fn, group_size=2).to(dev)
-        gw.add_module('tower', tower)
-        gw.to(dev)
+        gw = gmodel.GroupwiseScorer(gmodel.FusedGroupScoreFn(tower), group_size=2).to(dev)
         scorer = gw
         gw.train()
-        gidx = gw.group_indices(mask)                         # index plumbing: once per batch, outside the graph
-        run_scorer = lambda: gw({}, {'x': feats}, mask, group_indices=gidx)
+        # TRAIN mode: the valid items are re-shuffled every step (model.py:313-339, op seed 77); the index kernel and
+        # its torch.rand draw are part of the step (and of the captured graph: the stream's generator is registered)
+        graph_generators = [ra.utils.random_stream(77, dev)]
+        run_scorer = lambda: gw({}, {'x': feats}, mask)
         loss = ra.keras.losses.GumbelApproxNDCGLoss(seed=1)
     else:
         scorer = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1,
@@ -146,13 +228,13 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         else:
             loss = ra.keras.losses.ApproxNDCGLoss()
     scorer.train()
+    D.broadcast_module(scorer)                             # ... and made so explicitly, like the pipeline does
     bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
     if not os.environ.get('TFR_NO_INPLACE_GRADS'):
         bucket.attach(scorer)
     lr = 0.01
     _, world = D.world()
     params = [p for p in scorer.parameters() if p.requires_grad]
-    flat_params = None
 
     def fwd_bwd():
         bucket.zero()
@@ -176,8 +258,12 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         sgd()
         return s[0] / max(world, 1)
 
+    info = dict(kernel=None, kernel_name='whole training step (tower_gemm256_kernel / tower_wgrad_kernel dominate)',
+                all_reduce_bytes=int(bucket.flat.numel() * 4), params=int(bucket.numel))
     if not use_graph:
-        return eager_step
+        scal = torch.zeros(2, device=dev)
+        info.update(step=eager_step, all_reduce=lambda: bucket.all_reduce(scal, average=True))
+        return info
 
     # hipGraph capture of the launch-bound parts: [zero, scorer fwd, loss, scorer bwd] and [SGD];
     # the ONE all-reduce of the flat bucket stays between the two replays (RCCL, eager).
@@ -189,6 +275,8 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g_fb, g_sgd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    for gen in graph_generators:                            # philox offsets advance per replay, like eager calls
+        g_fb.register_generator_state(gen)
     one = torch.ones((), device=dev)
     with torch.cuda.graph(g_fb):
         static_value = fwd_bwd()
@@ -201,46 +289,151 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         s = bucket.all_reduce(static_scalars, average=True)
         g_sgd.replay()
         return s[0] / max(world, 1)
-    return graph_step
+    info.update(step=graph_step, all_reduce=lambda: bucket.all_reduce(static_scalars, average=True))
+    return info
+
+
+# ------------------------------------------------------------------------------------------ committed PMC traffic
+def _traffic_entry(workload, B, L):
+    for rel in TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                t = json.load(f).get(workload)
+        except (OSError, ValueError):
+            continue
+        if t and t.get('B') == B and t.get('L') == L:
+            return t, rel
+    return None, None
 
 
 def measured_traffic(workload, B, L):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01_traffic.json), when the workload and batch match what was profiled."""
-    path = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_traffic.json),
+    when the workload and batch match what was profiled."""
+    t, _ = _traffic_entry(workload, B, L)
+    return None if t is None else t['traffic_bytes']
+
+
+def traffic_source(workload, B, L):
+    t, rel = _traffic_entry(workload, B, L)
+    if t is None:
+        return 'not profiled for this workload / batch'
+    return ('committed rocprofv3 --pmc figure from %s (FETCH_SIZE x 2 + WRITE_SIZE per dispatch, separate passes, '
+            'gfx950 correction of MI355X_MICROARCH.md); NOT measured in this run' % rel)
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines
+def _avail_cores():
     try:
-        with open(path) as f:
-            t = json.load(f).get(workload)
-    except (OSError, ValueError):
-        return None
-    if not t or t.get('B') != B or t.get('L') != L:
-        return None
-    return t['traffic_bytes']
+        return len(os.sched_getaffinity(0))
+    except AttributeError:   # pragma: no cover
+        return os.cpu_count() or 1
+
+
+def _oracle_runner(workload, L):
+    """(run(labels, logits) -> None, lists-per-iteration cap, description) on the torch-CPU restatement of the
+    TF-Ranking op graph (oracle/tfr_ref.py): forward + autograd backward, the [B, L, L] tensors materialised."""
+    from oracle import tfr_ref as R
+    if workload.startswith('approx_ndcg'):
+        loss = R.ApproxNDCGLoss()
+
+        def run(labels, logits):
+            lg = logits.clone().requires_grad_(True)
+            R.keras_loss_call(loss, labels, lg).backward()
+        return run, int(2.0e7 // (L * L)), 'ApproxNDCG fwd+autograd bwd'
+    if workload == 'pairwise_lambda':
+        loss = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight())
+
+        def run(labels, logits):
+            lg = logits.clone().requires_grad_(True)
+            R.keras_loss_call(loss, labels, lg).backward()
+        return run, int(4.0e6 // (L * L)), 'PairwiseLogistic + NDCGLambdaWeight fwd+autograd bwd (~35 [B,L,L] tensors)'
+    if workload == 'softmax':
+        loss = R.SoftmaxLoss()
+
+        def run(labels, logits):
+            lg = logits.clone().requires_grad_(True)
+            R.keras_loss_call(loss, labels, lg).backward()
+        return run, 4096, 'Softmax fwd+autograd bwd'
+    if workload == 'gumbel_approx_ndcg':
+        loss = R.ApproxNDCGLoss()
+        sampler = R.GumbelSampler(sample_size=8, temperature=1.0)
+        g = torch.Generator().manual_seed(9)
+
+        def run(labels, logits):
+            lg = logits.clone().requires_grad_(True)
+            u = torch.rand((labels.shape[0], 8, labels.shape[1]), generator=g)
+            R.keras_loss_call(loss, labels, lg, gumbel_sampler=sampler, uniform=u).backward()
+        return run, int(2.0e7 // (8 * L * L)), 'GumbelApproxNDCG (S=8) fwd+autograd bwd'
+    if workload == 'ndcg_metric':
+        metrics = [R.NDCGMetric(topn=k) for k in (1, 3, 5, 10, None)]
+
+        def run(labels, logits):
+            for m in metrics:
+                m.compute(labels, logits)
+        return run, 4096, 'NDCG@{1,3,5,10,all}, five metric objects like keras default metrics'
+    return None, 0, ''
+
+
+def _e2e_cpu_runner(workload, L):
+    """Scorer + loss training step on the host: the reference's create_tower op graph in fp32 torch ops
+    (oracle.create_tower_train: Dense / BatchNormalization / ReLU as separate ops, autograd backward) + the oracle
+    loss + SGD; groupwise = oracle.groupwise_logits around the same tower."""
+    from oracle import tfr_ref as R
+    gs = 2 if workload == 'e2e_groupwise_gumbel' else 1
+    dims = [136 * gs, 512, 512, 512, gs]
+    g = torch.Generator().manual_seed(0)
+    Ws = [(torch.randn(dims[i], dims[i + 1], generator=g) * (2.0 / (dims[i] + dims[i + 1])) ** 0.5).requires_grad_(True)
+          for i in range(4)]
+    bs = [torch.zeros(dims[i + 1], requires_grad=True) for i in range(4)]
+    gam = [torch.ones(512, requires_grad=True) for _ in range(3)]
+    bet = [torch.zeros(512, requires_grad=True) for _ in range(3)]
+    params = Ws + bs + gam + bet
+    if workload == 'e2e_softmax':
+        loss, sampler = R.SoftmaxLoss(), None
+    elif workload == 'e2e_pairwise_lambda':
+        loss, sampler = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight()), None
+    elif workload == 'e2e_groupwise_gumbel':
+        loss, sampler = R.ApproxNDCGLoss(), R.GumbelSampler(sample_size=8, temperature=1.0)
+    else:
+        loss, sampler = R.ApproxNDCGLoss(), None
+
+    def run(labels, feats):
+        b, l, f = feats.shape
+        mask = labels >= 0
+        if gs == 1:
+            logits = R.create_tower_train(feats.reshape(b * l, f), Ws, bs, gam, bet).reshape(b, l)
+            logits = R.restore_list(logits, mask)
+        else:
+            logits = R.groupwise_logits(lambda x: R.create_tower_train(x.reshape(x.shape[0], -1), Ws, bs, gam, bet),
+                                        feats, mask, gs)
+        u = torch.rand((b, 8, l), generator=g) if sampler is not None else None
+        value = R.keras_loss_call(loss, labels, logits, gumbel_sampler=sampler, uniform=u)
+        grads = torch.autograd.grad(value, params)
+        with torch.no_grad():
+            for p, gr in zip(params, grads):
+                p.add_(gr, alpha=-0.01)
+    return run
 
 
 def cpu_baseline(workload, L, budget_s=12.0):
-    """Times the torch-CPU restatement of the reference op graph (oracle/) on a
-    bounded sample of the same workload: fwd + autograd bwd on the host cores.
-    The thread count is calibrated (best of a few candidates up to the cores this
+    """Times the oracle (kind "port": torch-CPU restatement of the TF-Ranking op graph) on a bounded sample of the
+    same workload on the host cores.  The thread count is calibrated (best of a few candidates up to the cores this
     process may run on) so that the baseline is not handicapped by oversubscription."""
-    from oracle import tfr_ref as R
     from ranking_amd.synthetic import make_batch
-    if not workload.startswith('approx_ndcg'):
-        return None
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:   # pragma: no cover
-        avail = os.cpu_count() or 1
-    loss = R.ApproxNDCGLoss()
-
-    def run(labels, logits):
-        lg = logits.clone().requires_grad_(True)
-        out = R.keras_loss_call(loss, labels, lg)
-        out.backward()
-        return lg.grad
-
-    Bc = max(8, min(1024, int(2.0e7 // (L * L))))       # [Bc, L, L] fp32 tensors of <= 80 MB
-    labels, logits = make_batch(Bc, L, seed=4)
+    avail = _avail_cores()
+    if workload.startswith('e2e_'):
+        run_e2e = _e2e_cpu_runner(workload, L)
+        Bc = max(2, min(64, int(6400 // L)))
+        labels, _ = make_batch(Bc, L, seed=4)
+        feats = torch.rand((Bc, L, 136), generator=torch.Generator().manual_seed(5)) * 2 - 1
+        run = lambda lb, _lg: run_e2e(lb, feats)
+        logits, what = None, 'scorer (fp32 torch ops: Dense/BatchNorm/ReLU) fwd+bwd + oracle loss + SGD'
+    else:
+        run, cap, what = _oracle_runner(workload, L)
+        if run is None:
+            return None
+        Bc = max(8, min(1024, cap))
+        labels, logits = make_batch(Bc, L, seed=4)
     best_t, best_threads = None, 1
     for threads in sorted({t for t in (avail, 128, 64, 32, 16, 8) if 1 <= t <= avail}, reverse=True):
         torch.set_num_threads(threads)
@@ -260,79 +453,96 @@ def cpu_baseline(workload, L, budget_s=12.0):
     times.sort()
     med = times[len(times) // 2]
     return {'value': Bc / med, 'unit': 'lists/s', 'cores': best_threads, 'kind': 'port',
-            'sample': 'torch-CPU restatement of the TF-Ranking op graph (oracle/tfr_ref.py), '
-                      'ApproxNDCG fwd+autograd bwd, %d lists x L=%d per iteration, median of %d '
-                      'iterations, fp32, %d threads (best of a sweep; %d cores available)'
-                      % (Bc, L, iters, best_threads, avail)}
+            'sample': 'torch-CPU restatement of the TF-Ranking op graph (oracle/tfr_ref.py), %s, %d lists x L=%d '
+                      'per iteration, median of %d iterations, fp32, %d threads (best of a sweep; %d cores available)'
+                      % (what, Bc, L, iters, best_threads, avail)}
 
 
 def cpu_fused_c_baseline(workload, B, L):
-    """The stricter CPU number: the plain-C restatement of the same fwd+bwd (oracle/approx_ndcg_c.c, float,
-    -Ofast -march=native, OpenMP over lists) on the WHOLE batch, all host cores -- what a fused, vectorised CPU loop
-    does, next to the op-graph port above (which is how the reference itself executes).  None when gcc / the
-    library is unavailable on this host."""
-    if not workload.startswith('approx_ndcg'):
-        return None
+    """The stricter CPU number: the plain-C restatements (oracle/*.c, OpenMP over lists) on the WHOLE batch, all
+    host cores -- what a fused CPU loop does, next to the op-graph port above (which is how the reference itself
+    executes).  None when there is no C restatement of the workload; an error string when gcc is unavailable."""
     try:
         from oracle import c_ref
         from ranking_amd.synthetic import make_batch
+        if workload.startswith('approx_ndcg'):
+            fn = lambda lg, lb: c_ref.approx_ndcg(lg, lb, temperature=0.1, variant='f32_fast')
+            what = 'oracle/approx_ndcg_c.c, fp32, -Ofast -march=native, ApproxNDCG fwd+bwd'
+        elif workload == 'pairwise_lambda':
+            fn = lambda lg, lb: c_ref.pairwise_logistic_ndcg(lg, lb, temperature=1.0)
+            what = 'oracle/pairwise_softmax_c.c, fp64 inside, PairwiseLogistic+NDCGLambdaWeight fwd+bwd'
+        elif workload == 'softmax':
+            fn = lambda lg, lb: c_ref.softmax(lg, lb, temperature=1.0)
+            what = 'oracle/pairwise_softmax_c.c, fp64 inside, Softmax fwd+bwd'
+        elif workload == 'ndcg_metric':
+            fn = lambda lg, lb: [c_ref.ndcg_mrr(lg, lb, topn=k) for k in (1, 3, 5, 10, None)]
+            what = 'oracle/pairwise_softmax_c.c, fp64 inside, NDCG@{1,3,5,10,all} (five passes)'
+        else:
+            return None
         labels, logits = make_batch(B, L, seed=4)
         lb, lg = labels.numpy(), logits.numpy()
         n = max(256, B // 16)
-        c_ref.approx_ndcg(lg[:n], lb[:n], temperature=0.1, variant='f32_fast')       # warm-up (threads, pages)
+        fn(lg[:n], lb[:n])                                     # warm-up (threads, pages)
         times = []
         for _ in range(5):
             t0 = time.perf_counter()
-            c_ref.approx_ndcg(lg, lb, temperature=0.1, variant='f32_fast')
+            fn(lg, lb)
             times.append(time.perf_counter() - t0)
         times.sort()
         return {'value': B / times[len(times) // 2], 'unit': 'lists/s', 'cores': c_ref.threads(), 'kind': 'port',
-                'sample': 'plain-C restatement (oracle/approx_ndcg_c.c, fp32, -Ofast -march=native, OpenMP), '
-                          'ApproxNDCG fwd+bwd, the full %d x L=%d batch, median of 5' % (B, L)}
+                'sample': 'plain-C restatement (%s, OpenMP over lists), the full %d x L=%d batch, median of 5'
+                          % (what, B, L)}
     except Exception as e:                                 # the checker's build must never take the bench down
         return {'value': None, 'unit': 'lists/s', 'error': '%s: %s' % (type(e).__name__, e)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
-    ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
-                    help='launch eagerly instead of replaying the step from hipGraphs')
-    ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
-    ap.add_argument('--traffic-bytes', type=float, default=None,
-                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
-    args = ap.parse_args()
-
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
+# ------------------------------------------------------------------------------------------ measuring one workload
+def _timed_loop(fn, n, dist):
+    torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
 
-    B, L, desc, bytes_per_list = WORKLOADS[args.workload]
-    if args.batch > 0:
+
+def _kernel_ms(kernel, n):
+    """Average duration of the dominant kernel: HIP events on the launch stream, kernel launches only."""
+    stream = torch.cuda.current_stream()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for _ in range(3):
+        kernel()
+    torch.cuda.synchronize()
+    for a, b in evs:
+        a.record(stream)
+        kernel()
+        b.record(stream)
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs]
+    return sum(ts) / len(ts)
+
+
+def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s):
+    """All ranks call this collectively; the returned dict is complete on rank 0."""
+    B, L, desc, bytes_per_list = WORKLOADS[name]
+    if args.batch > 0 and name == args.workload:
         B = args.batch
     labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
-    step, kernel_only = build_step(args.workload, labels, logits, args.dropout, args.graph)
-    if args.graph and not args.workload.startswith('e2e_'):
+    info = build_step(name, labels, logits, args.dropout, args.graph)
+    step = info['step']
+    is_e2e = name.startswith('e2e_')
+    if args.graph and not is_e2e:
         # The loss step is a handful of short launches (order, loss kernel, reduction): replay it from a
         # hipGraph so that the measured rate is the GPU's, not the Python launch path's.
         eager = step
@@ -351,99 +561,160 @@ def main():
             graph.replay()
             return static_out
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # dominant-kernel duration: HIP events on the launch stream, kernel launches only.
-    kernel_ms = None
-    if kernel_only is not None:
-        stream = torch.cuda.current_stream()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-               for _ in range(args.steps)]
-        torch.cuda.synchronize()
-        for a, b in evs:
-            a.record(stream)
-            kernel_only()
-            b.record(stream)
-        torch.cuda.synchronize()
-        ts = sorted(a.elapsed_time(b) for a, b in evs)
-        kernel_ms = sum(ts) / len(ts)
-
+    for _ in range(warmup):
+        step()
+    elapsed = _timed_loop(step, steps, dist)
+    kernel_ms = _kernel_ms(info['kernel'], steps) if info.get('kernel') is not None else None
+    all_reduce_ms = None
+    if is_e2e:
+        all_reduce_ms = 1e3 * _timed_loop(info['all_reduce'], steps, dist) / steps if world > 1 else 0.0
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
-    lists = B * world * args.steps
-    value = lists / elapsed
+    value = B * world * steps / elapsed
+    ms_per_step = 1e3 * elapsed / steps
     result = {
-        'metric': 'ranked lists/sec (fwd+bwd), ApproxNDCG list_size=200' if args.workload == 'approx_ndcg'
-                  else 'ranked lists/sec, %s' % args.workload,
-        'value': value, 'unit': 'lists/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'metric': 'ranked lists/sec (fwd+bwd), ApproxNDCG list_size=200' if name == 'approx_ndcg'
+                  else 'ranked lists/sec, %s' % name,
+        'value': value, 'unit': 'lists/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'bf16' if is_e2e else 'f32', 'data': 'synthetic',
         'config': {'workload': desc, 'lists_per_gpu_per_step': B, 'list_size': L,
                    'valid_length': 'U{ceil(L/2)..L}', 'labels': 'randint{0..4}, -1 padding',
-                   'logits': 'N(0,1) tie-free', 'parallelism': 'dp%d (lists sharded, no collective)' % world},
+                   'logits': 'N(0,1) tie-free',
+                   'parallelism': ('dp%d (lists sharded, ONE all-reduce of the flat gradient bucket per step)' % world)
+                   if is_e2e else 'dp%d (lists sharded, no collective)' % world},
     }
     if kernel_ms is not None:
         algo_bytes = bytes_per_list(L) * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        result['roofline'] = {
+        roof = {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS,
-            'traffic': args.traffic_bytes if args.traffic_bytes is not None else measured_traffic(args.workload, B, L),
-            'kernel': 'approx_ndcg_wave_kernel<4>' if L <= 256 else 'approx_ndcg_kernel', 'kernel_ms': kernel_ms,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': args.traffic_bytes if (
+                args.traffic_bytes is not None and name == args.workload) else measured_traffic(name, B, L),
+            'traffic_source': traffic_source(name, B, L), 'kernel': info['kernel_name'], 'kernel_ms': kernel_ms,
             'algorithmic_bytes_per_launch': algo_bytes,
-            'note': 'O(L^2) pair work is on-chip: the kernel is VALU/transcendental bound, the HBM '
-                    'fraction is reported as the contract asks; see DESIGN.md for the VALU roofline',
-            'pairs_per_s': None,
         }
-        n_valid_sq = float(((labels >= 0).sum(dim=1).double() ** 2).sum().item())
-        result['roofline']['pairs_per_s'] = 2.0 * n_valid_sq / (kernel_ms * 1e-3)   # fwd + bwd evaluations
-        # VALU issue floor of the two pair sweeps alone (tools/ubench.hip on MI355X: 15.3 + 20.5 cycles per 64
-        # pair evaluations per SIMD; 1024 SIMDs at the 2.4 GHz peak clock) -- the bound that actually applies.
-        valu_floor_ms = n_valid_sq / 64.0 * (15.3 + 20.5) / (1024 * 2.4e9) * 1e3
-        result['roofline']['valu_floor_ms'] = valu_floor_ms
-        result['roofline']['valu_frac'] = valu_floor_ms / kernel_ms
-    if args.workload.startswith('e2e_'):
-        tflops = e2e_flops_per_list(args.workload, L) * B * world / (elapsed / args.steps) / 1e12
-        result['dtype'] = 'bf16'
+        valid = (labels >= 0)
+        if name.startswith('approx_ndcg') or name == 'gumbel_approx_ndcg':
+            mult = 8.0 if name == 'gumbel_approx_ndcg' else 1.0
+            n_valid_sq = mult * float((valid.sum(dim=1).double() ** 2).sum().item())
+            floor_ms = n_valid_sq / 64.0 * VALU_CYCLES_PER_64_PAIRS['approx_ndcg'] / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            roof.update(pairs_per_s=2.0 * n_valid_sq / (kernel_ms * 1e-3), valu_floor_ms=floor_ms,
+                        valu_frac=floor_ms / kernel_ms,
+                        note='O(L^2) pair work is on-chip: the kernel is VALU/transcendental bound, the HBM fraction '
+                             'is reported as the contract asks; valu_frac = issue floor of the two pair sweeps '
+                             '(tools/ubench.hip cycle costs, 1024 SIMDs at 2.4 GHz) / kernel time (DESIGN.md)')
+        elif name == 'pairwise_lambda':
+            lab = torch.where(valid, labels, torch.full_like(labels, -1.0))
+            # ordered pairs with l_i > l_j among valid items = the pairs the loss sums over
+            cnt = torch.stack([(lab == g).sum(dim=1).double() for g in range(5)], dim=1)          # [B, 5]
+            higher = torch.flip(torch.cumsum(torch.flip(cnt, [1]), 1), [1]) - cnt                # items with a larger grade
+            active = float((cnt * higher).sum().item())
+            floor_ms = active / 64.0 * VALU_CYCLES_PER_64_PAIRS['pairwise'] / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            roof.update(pairs_per_s=active / (kernel_ms * 1e-3), active_pairs_per_launch=active,
+                        valu_floor_ms=floor_ms, valu_frac=floor_ms / kernel_ms,
+                        note='active pairs = ordered (i, j) with l_i > l_j (about 20 % of n^2 for 5 uniform grades); '
+                             'valu_frac = issue floor of the lean logistic+lambda pair body over the ACTIVE pairs '
+                             'only / kernel time: a kernel that sweeps inactive pairs scores low here')
+        else:
+            roof['note'] = 'O(L) / sort kernel: HBM-bound by design; the batch (%.1f MB) fits the 256 MB Infinity ' \
+                           'Cache under graph replay, so achieved GB/s is a cache-resident rate' % (algo_bytes / 1e6)
+        result['roofline'] = roof
+    if is_e2e:
+        tflops = e2e_flops_per_list(name, L) * B / (ms_per_step * 1e-3) / 1e12
         result['roofline'] = {
-            'bound': 'mfma', 'achieved': tflops / world, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': tflops / world / MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(args.workload, B, L),
-            'kernel': 'whole training step (tower_gemm256_kernel / tower_wgrad_kernel dominate; profiles/)',
+            'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tflops / MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(name, B, L),
+            'traffic_source': traffic_source(name, B, L), 'kernel': info['kernel_name'],
             'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / step time, per GPU; the [M,512] layers '
                     'are HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
-    if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample, ~15 s)
-        cb = cpu_baseline(args.workload, L)
+        result['all_reduce'] = {'ms': all_reduce_ms, 'bytes': info['all_reduce_bytes'], 'params': info['params'],
+                                'frac_of_step': (all_reduce_ms / ms_per_step) if ms_per_step else None,
+                                'compute_ms': ms_per_step - all_reduce_ms,
+                                'note': 'the step\'s ONE collective (flat fp32 gradient bucket + 2 scalars) timed '
+                                        'alone over the same number of iterations; 0 at N = 1 (no collective issued)'}
+    if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample)
+        cb = cpu_baseline(name, L, cpu_budget_s)
         if cb is not None:
             result['cpu_baseline'] = cb
             result['gpu_over_cpu'] = value / cb['value']
-            fc = cpu_fused_c_baseline(args.workload, B, L)
+            fc = cpu_fused_c_baseline(name, B, L)
             if fc is not None:
                 cb['fused_c'] = fc                          # second, stricter CPU baseline (same unit)
                 if fc.get('value'):
                     result['gpu_over_fused_c_cpu'] = value / fc['value']
-    print(json.dumps(result))
+    return result
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
+    ap.add_argument('--also', default=None,
+                    help='comma-separated extra workloads measured after the main one and reported under "also" '
+                         '(default: %s when --workload is the headline; "none" to disable)' % ','.join(DEFAULT_ALSO))
+    ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
+                    help='launch eagerly instead of replaying the step from hipGraphs')
+    ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
+    ap.add_argument('--traffic-bytes', type=float, default=None,
+                    help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
+    ap.add_argument('--plumbing-check', action='store_true',
+                    help='rendezvous + one all-reduce on gloo, no measurement (exercises the N > 1 launch on a GPU-less host)')
+    args = ap.parse_args(argv)
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:     # bare shell: become N ranks
+        raise SystemExit(respawn_under_torchrun(args, argv))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.plumbing_check:
+        return plumbing_check(rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    rccl_ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                               # a real RCCL collective before anything is timed
+        rccl_ranks = int(round(probe.item()))
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if dist is not None:
+        dist.barrier()
+
+    result = run_workload(args.workload, args, dist, rank, world, dev, args.steps, args.warmup, 12.0)
+    also = DEFAULT_ALSO if (args.also is None and args.workload == 'approx_ndcg') else tuple(
+        w for w in (args.also or '').split(',') if w and w != 'none')
+    extra = {}
+    for w in also:
+        if w not in WORKLOADS:
+            raise SystemExit('unknown workload in --also: %s' % w)
+        try:
+            r = run_workload(w, args, dist, rank, world, dev, max(10, min(args.steps, 50)),
+                             max(3, min(args.warmup, 10)), 4.0)
+        except Exception as e:                              # an extra line must never take the headline down
+            if world > 1:
+                raise                                       # ... but ranks must not diverge inside collectives
+            r = {'error': '%s: %s' % (type(e).__name__, e)}
+        extra[w] = r
+    if rank == 0:
+        result['rccl_ranks'] = rccl_ranks
+        if extra:
+            result['also'] = extra
+        print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -368,6 +368,31 @@ int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int
                          long ldw, int splits, const tfr_tower_dropout* dropout, void* stream);
 int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream);
 
+/* ---- groupwise multi-item scoring (model.py:164-244, 313-421; csrc/groupwise.hip) -------------------------------
+ * Group indices of _form_group_indices_nd (model.py:205-244) for one shuffle: the valid items of every list in
+ * organize_valid_indices order (utils.py:203-230: index order when `keys` is NULL, else by DESCENDING key, ties by
+ * index -- the caller draws keys ~ U[0,1)), then the rolling windows of _rolling_window_indices (model.py:164-202).
+ *   is_valid   [B, L] uint8;  keys nullable [B, L] fp32
+ *   idx_out    [B, L, group_size] int32: item index (inside its list) of member k of group g
+ *   gmask_out  [B, L] uint8: group g is valid (its first member is one of the n valid items) */
+int tfr_group_indices_i32(const uint8_t* is_valid, const float* keys, int B, int L, int group_size,
+                          int32_t* idx_out, uint8_t* gmask_out, void* stream);
+/* tf.gather_nd(example_features, feature_gather_indices) + reshape + the tower's bf16 input cast (model.py:374-381):
+ *   x   fp32 [B, L, F] with row pitch ldx (elements);  idx [B, G, group_size] int32
+ *   out bf16 [B * G, Kp], Kp >= group_size * F a multiple of 8; out[(b, g), k * F + f] = x[b, idx[b, g, k], f],
+ *   padding columns are zero. */
+int tfr_group_gather_cast_f32_bf16(const float* x, long ldx, const int32_t* idx, int B, int L, int G,
+                                   int group_size, int F, int Kp, void* out_bf16, void* stream);
+/* The two tf.scatter_nd + div_no_nan of model.py:389-409: logits[b, i] = (sum of scores[b, g, k] over valid groups
+ * with idx[b, g, k] == i) / (their number), 0 where none lands.  Contributions are added in (g, k) order.
+ *   scores [B * G, group_size] fp32;  gmask [B, G] uint8;  logits_out [B, L];  counts_out nullable [B, L]. */
+int tfr_group_scatter_avg_f32(const float* scores, const int32_t* idx, const uint8_t* gmask, int B, int L,
+                              int G, int group_size, float* logits_out, float* counts_out, void* stream);
+/* Its backward: dscores[b, g, k] = gmask[b, g] ? dlogits[b, idx] / counts[b, idx] : 0  (0 where count is 0). */
+int tfr_group_scatter_avg_bwd_f32(const float* dlogits, const float* counts, const int32_t* idx,
+                                  const uint8_t* gmask, int B, int L, int G, int group_size,
+                                  float* dscores_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

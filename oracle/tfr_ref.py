@@ -1421,6 +1421,25 @@ def dnn_tower(x, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor]
     return x
 
 
+def create_tower_train(x, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
+                       gammas: Sequence[torch.Tensor], betas: Sequence[torch.Tensor], activation=torch.relu,
+                       epsilon=1e-3, keep_masks: Optional[Sequence[torch.Tensor]] = None, rate=0.0):
+    """keras/layers.py:26-77 in TRAINING mode, as separate ops like the reference graph: per hidden layer
+    Dense -> BatchNormalization (batch mean, biased batch variance, tf.keras epsilon 1e-3) -> activation
+    (-> Dropout with the given keep masks, scaled by 1/(1-rate)), then the output Dense.  ``weights[i]`` is
+    ``[in, out]``; the last weight / bias pair is the output layer."""
+    n_h = len(weights) - 1
+    for i in range(n_h):
+        z = x @ weights[i] + biases[i]
+        mean = z.mean(dim=0, keepdim=True)
+        var = ((z - mean) ** 2).mean(dim=0, keepdim=True)
+        z = (z - mean) * torch.rsqrt(var + epsilon) * gammas[i] + betas[i]
+        x = activation(z) if activation is not None else z
+        if keep_masks is not None and rate > 0.0:
+            x = x * keep_masks[i] / (1.0 - rate)
+    return x @ weights[-1] + biases[-1]
+
+
 def rolling_window_indices(size, rw_size, num_valid_entries):
     """model.py:164-202."""
     num_valid_entries = torch.as_tensor(num_valid_entries).reshape(-1, 1, 1)
@@ -1444,11 +1463,13 @@ def form_group_indices(is_valid, group_size):
     return idx, mask
 
 
-def groupwise_logits(score_fn, example_features, is_valid, group_size):
-    """model.py:341-421 (single example feature tensor [B, L, F]; shuffle off):
-    gather groups -> score [B*G, gs] -> masked scatter-add -> divide by counts."""
+def groupwise_logits(score_fn, example_features, is_valid, group_size, indices=None):
+    """model.py:341-421 (single example feature tensor [B, L, F]): gather groups -> score [B*G, gs] -> masked
+    scatter-add -> divide by counts.  ``indices`` = (idx [B, G, gs], mask [B, G]) of a shuffled / multi-shuffle run
+    (model.py:313-339); default: the no-shuffle indices."""
     b, l, f = example_features.shape
-    idx, mask = form_group_indices(is_valid, group_size)
+    idx, mask = form_group_indices(is_valid, group_size) if indices is None else indices
+    idx = idx.to(torch.int64)
     g = idx.shape[1]
     gathered = torch.gather(example_features.unsqueeze(1).expand(b, g, l, f), 2,
                             idx.unsqueeze(-1).expand(b, g, group_size, f))
@@ -1458,3 +1479,18 @@ def groupwise_logits(score_fn, example_features, is_valid, group_size):
     scores = torch.where(scores_mask, scores, torch.zeros_like(scores))
     logits = torch.zeros(b, l).scatter_add(1, idx.reshape(b, -1), scores.reshape(b, -1))
     return _safe_div(logits, counts)
+
+
+def form_group_indices_with_keys(is_valid, group_size, keys):
+    """model.py:205-244 with shuffle=True for GIVEN uniform draws ``keys`` [B, L] (utils.py:219-227: valid entries
+    keep their draw, invalid entries get -1e-6, stable descending argsort), then the rolling windows."""
+    is_valid = _t(is_valid, torch.bool)
+    b, l = is_valid.shape
+    n_valid = is_valid.sum(dim=1)
+    rw = rolling_window_indices(l, group_size, n_valid)
+    rw_raw = torch.arange(group_size).unsqueeze(0) + torch.arange(l).unsqueeze(1)
+    mask = rw_raw.min(dim=1).values.unsqueeze(0) < n_valid.reshape(-1, 1)
+    rand = torch.where(is_valid, _t(keys), torch.full((b, l), -1e-6))
+    organized = torch.sort(rand, dim=1, descending=True, stable=True).indices
+    idx = torch.gather(organized.unsqueeze(1).expand(b, l, l), 2, rw)
+    return idx, mask

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
 STAMP_PATH = LIB_PATH + '.stamp'                           # fingerprint of what LIB_PATH was built from
 PROF_LIB_PATH = os.path.join(CSRC, 'libtfr_hip_prof.so')     # developer aid: -DTFR_PROFILE_STAMPS build
 SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip', 'listwise.hip',
-           'neural_sort.hip', 'pointwise.hip']
+           'neural_sort.hip', 'pointwise.hip', 'groupwise.hip']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                '-fvisibility=default']
 
@@ -102,6 +102,13 @@ _SIGNATURES = {
                              + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    # groupwise scoring (groupwise.hip)
+    'tfr_group_indices_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+    'tfr_group_gather_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+                                       + [ctypes.c_int] * 6 + [ctypes.c_void_p] * 2),
+    'tfr_group_scatter_avg_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3),
+    'tfr_group_scatter_avg_bwd_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4
+                                      + [ctypes.c_void_p] * 2),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -249,7 +249,7 @@ class FusedTower(nn.Module):
     def forward(self, x: torch.Tensor, row_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``row_index`` (int [M]): score row ``row_index[m]`` of ``x`` at position m -- the gather of
         ``FlattenList``'s circular padding, fused into the input cast."""
-        if x.dim() != 2 or x.shape[1] not in (self.input_dim, T.pad8(self.input_dim)):
+        if x.dim() != 2 or x.shape[1] not in (self.input_dim, T.pad8(self.input_dim), T.pad_k(self.input_dim)):
             raise ValueError('expected [M, %d] features, got %s' % (self.input_dim, tuple(x.shape)))
         params = list(self.weights) + list(self.biases)
         if self.use_batch_norm:
