@@ -71,10 +71,11 @@ WORKLOADS = {
 }
 DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel')
 
-# VALU issue cost of the O(L^2) pair sweeps, SIMD cycles per 64 pair evaluations, measured on MI355X with
-# tools/ubench.hip (profiles/): ApproxNDCG forward + backward sweep; pairwise = the lean logistic+lambda pair body
-# (18 plain VALU at 2.4 + 3 transcendentals at 8.5 cycles).  Used for `roofline.valu_frac` (the bound that applies).
-VALU_CYCLES_PER_64_PAIRS = {'approx_ndcg': 15.3 + 20.5, 'pairwise': 18 * 2.4 + 3 * 8.5}
+# VALU issue cost of the O(L^2) pair sweeps, SIMD cycles per 64 pair evaluations, from the per-instruction costs
+# measured on MI355X with tools/ubench.hip (profiles/: plain VALU 2.4, v_rcp / v_log / v_exp 8.5 cycles per
+# wave-instruction): ApproxNDCG forward + backward sweep; pairwise = the LambdaRank fast path per ACTIVE ordered pair
+# (l_i > l_j): "hi" sweep 8 plain + rcp + log, "lo" sweep 7 plain + rcp.  Used for `roofline.valu_frac`.
+VALU_CYCLES_PER_64_PAIRS = {'approx_ndcg': 15.3 + 20.5, 'pairwise': (8 + 7) * 2.4 + 3 * 8.5}
 SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
 
 
@@ -163,7 +164,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
                     kernel=lambda: _ops.pairwise_logistic(
                         logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_aux=False,
                         loss_kind=_ops.PAIR_LOGISTIC, balance=order if order is not None else False, **lam),
-                    kernel_name='pairwise_wave_kernel' if L <= 256 else 'pairwise_logistic_kernel')
+                    kernel_name='pairwise_lean_kernel' if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()
         w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
@@ -615,8 +616,8 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
             roof.update(pairs_per_s=active / (kernel_ms * 1e-3), active_pairs_per_launch=active,
                         valu_floor_ms=floor_ms, valu_frac=floor_ms / kernel_ms,
                         note='active pairs = ordered (i, j) with l_i > l_j (about 20 % of n^2 for 5 uniform grades); '
-                             'valu_frac = issue floor of the lean logistic+lambda pair body over the ACTIVE pairs '
-                             'only / kernel time: a kernel that sweeps inactive pairs scores low here')
+                             'valu_frac = issue floor of the two LambdaRank sweeps over the ACTIVE pairs only / kernel '
+                             'time (rank counting, grade ordering and range rounding are overhead against it)')
         else:
             roof['note'] = 'O(L) / sort kernel: HBM-bound by design; the batch (%.1f MB) fits the 256 MB Infinity ' \
                            'Cache under graph replay, so achieved GB/s is a cache-resident rate' % (algo_bytes / 1e6)

@@ -149,6 +149,20 @@ __device__ __forceinline__ float exp_df(float t_hi, float t_lo) {
 }
 
 
+// The same with the single-instruction transcendentals (v_exp_f32 / v_ldexp_f32, 1 ulp): per-item set-up of the
+// factorised pair kernels.
+__device__ __forceinline__ float exp_df_hw(float t_hi, float t_lo) {
+  const float LOG2E_HI = 1.44269502162933349609375f;
+  const float LOG2E_LO = 1.92596299112661746e-08f;
+  const float y_hi = t_hi * LOG2E_HI;
+  float y_lo = __builtin_fmaf(t_hi, LOG2E_HI, -y_hi);
+  y_lo = __builtin_fmaf(t_hi, LOG2E_LO, y_lo);
+  y_lo = __builtin_fmaf(t_lo, LOG2E_HI, y_lo);
+  const float n = rintf(y_hi);
+  const float f = (y_hi - n) + y_lo;
+  return __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // value of lane (lane ^ j), j a power of two < 64.  j = 1, 2, 4, 8 stay inside a 16-lane DPP row: one or two
 // v_mov_b32_dpp per dword (quad_perm for 1 and 2, row_ror:8 for 8, row_shr:4 + row_shl:4 on complementary banks for
 // 4) instead of a ds_bpermute round trip through the LDS crossbar -- 26 of the 33 cross-lane stages of a 256-key

@@ -653,6 +653,321 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   }
 }
 
+// ===========================================================================
+// LambdaRank fast path: PairwiseLogisticLoss x DCGLambdaWeight (smooth_fraction 0, no topn, built-in
+// monotone gain, no separate mask) -- the configuration of BASELINE config 3 / keras NDCGLambdaWeight().
+//
+// Only ordered pairs with l_i > l_j carry a weight (losses_impl.py:503-537): ~40 % of the n^2 pairs of a
+// list with 5 uniform grades.  The general kernel above sweeps all n^2 and pays exp + log + rcp on each;
+// this one
+//   * re-homes the items in GRADE order (label descending; a handful of distinct values -> a few ballot /
+//     popcount rounds, no sort), so that the pairs a row needs are two contiguous column ranges:
+//     lower grades behind its own segment ("hi" sweep: the row is the preferred item -> loss and its own
+//     gradient share) and higher grades in front of it ("lo" sweep: the gradient share it receives as
+//     the non-preferred item; no log needed);
+//   * factorises the exponential: with A = e^{-(x - m)}, B = e^{x - m} per ITEM (double-float argument, 1 ulp),
+//     1 + e^{-(x_i - x_j)} = fma(A_i, B_j, 1): a pair costs fma, rcp, log (hi) or fma, rcp (lo) instead of
+//     sub, mul, exp, add, rcp, log, max, fma, mul, cmp, select;
+//   * needs no per-pair predicate: for a monotone gain max(G_i - G_j, 0) is already 0 on equal or inverted
+//     grades and on the padding records (gain +1e30 / -1e30), so ranges may be rounded outwards freely.
+// The rank-difference discount |D(m) - D(m+1)| is an LDS gather on |rank_i - rank_j| (v_sad + ds_read_b32).
+// Lists whose score range exceeds kLeanRange (e^{range} would leave fp32) take the per-pair exp form.
+// ===========================================================================
+constexpr float kLeanRange = 80.0f;
+constexpr float kBigGain = 1e30f;
+constexpr int kMaxRuns = 8;
+
+__host__ __device__ inline size_t pw_lean_wave_lds(int Lp, bool itemw) {
+  return (size_t)Lp * (16 + 4 + 4 + 4 + 4 + (itemw ? 4 : 0)) + 16;
+}
+
+template <int IPL, bool AUX, bool ITEMW>
+__global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  const int wave = threadIdx.x >> 6, S = blockDim.x >> 6;
+  const int Lp = a.Lp;
+  unsigned char* smem_raw = smem_all + (size_t)wave * pw_lean_wave_lds(Lp, ITEMW);
+  float* nz_slot = reinterpret_cast<float*>(smem_all + (size_t)S * pw_lean_wave_lds(Lp, ITEMW));   // [S]
+  float4* rec = reinterpret_cast<float4*>(smem_raw);          // [Lp] grade order: (B, A, gain, 4 * rank as bits)
+  float* U = reinterpret_cast<float*>(rec + Lp);              // [Lp] |D(m) - D(m+1)| * list_size
+  float* XS = U + Lp;                                         // [Lp] compact x (rank count) / x in grade order (slow path)
+  int* CIS = reinterpret_cast<int*>(XS + Lp);                 // [Lp] grade position -> original index
+  int* SEG = CIS + Lp;                                        // [Lp] (lo-sweep end | hi-sweep start << 16)
+  float* WS = reinterpret_cast<float*>(SEG + Lp);             // [Lp] item weight, grade order (ITEMW only)
+  const int lane = threadIdx.x & 63, b = a.order ? a.order[blockIdx.x] : blockIdx.x, L = a.L;
+  const size_t base = (size_t)b * L;
+  const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
+
+  // ---- 1. load, gains, compaction of the valid items (mask == NULL: valid = label >= 0).
+  float g[IPL], xr[IPL], labr[IPL], wr[IPL];
+  int posr[IPL];
+  bool lv[IPL];
+  int n = 0;
+  float xmin = INFINITY, xmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = lane + 64 * r;
+    g[r] = 0.f; lv[r] = false;
+    float x = 0.f, lab = -1.f, w = 0.f;
+    if (e < L) {
+      lab = a.labels[base + e];
+      x = a.logits[base + e] / a.temperature;
+      lv[r] = lab >= 0.0f;
+      if (lv[r]) {
+        g[r] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(lab) : lab;
+        w = ITEMW ? a.item_weights[base + e] * lw : lw;
+        xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+      } else {
+        if (a.row_loss) a.row_loss[base + e] = 0.f;
+        if (AUX && a.row_weight) a.row_weight[base + e] = 0.f;
+        if (a.dlogits) a.dlogits[base + e] = 0.f;
+      }
+    }
+    const unsigned long long bal = __ballot(lv[r]);
+    xr[r] = x; labr[r] = lv[r] ? lab : -1.0f; wr[r] = w;
+    posr[r] = n + __popcll(bal & ((1ull << lane) - 1ull));
+    if (lv[r]) XS[posr[r]] = x;
+    n += __popcll(bal);
+  }
+  xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
+  const bool fast = (xmax - xmin) <= kLeanRange;             // wave-uniform
+  const float m = 0.5f * (xmax + xmin);
+  for (int q = lane; q < Lp; q += 64) {
+    const float um = (q >= 1 && q < L) ? fabsf(a.discount[q - 1] - a.discount[q]) : 0.0f;
+    U[q] = um * (float)L;                                    // the final x list_size (:278) folded in
+  }
+  const int n4 = (n + 3) >> 2;
+  for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
+  WAVE_LDS_SYNC();
+
+  // ---- 2. ranks by counting (score descending, ties by index) (:483-500).
+  int rk[IPL];
+  {
+    const float4* X4 = reinterpret_cast<const float4*>(XS);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      rk[r] = 0;
+      if (!lv[r]) continue;
+      const float xi = xr[r];
+      const int p = posr[r];
+      int cnt = 0;
+      for (int gq = 0; gq < n4; ++gq) {
+        const float4 xx = X4[gq];
+        const int j = gq * 4;
+        cnt += (xx.x > xi || (xx.x == xi && j < p)) ? 1 : 0;
+        cnt += (xx.y > xi || (xx.y == xi && j + 1 < p)) ? 1 : 0;
+        cnt += (xx.z > xi || (xx.z == xi && j + 2 < p)) ? 1 : 0;
+        cnt += (xx.w > xi || (xx.w == xi && j + 3 < p)) ? 1 : 0;
+      }
+      rk[r] = cnt;
+    }
+  }
+
+  // ---- 3. grade order: repeatedly take the largest remaining label value; its items (in element order)
+  // become the next segment.  After kMaxRuns distinct values the rest forms one unsorted tail segment whose
+  // rows sweep conservatively (every column is a candidate; the gain difference decides).
+  int sp[IPL], seg[IPL];
+  float rem[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { rem[r] = labr[r]; sp[r] = 0; seg[r] = 0; }
+  int pos = 0;
+  bool tail = false;
+  for (int it = 0; it <= kMaxRuns; ++it) {
+    float mx = rem[0];
+#pragma unroll
+    for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+    const float v = wave_max_u(mx);
+    if (v < 0.0f) break;
+    const bool last = it == kMaxRuns;                        // everything that is left
+    int c = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const bool hit = last ? (rem[r] >= 0.0f) : (rem[r] == v);
+      const unsigned long long bal = __ballot(hit);
+      if (hit) { sp[r] = pos + c + __popcll(bal & ((1ull << lane) - 1ull)); rem[r] = -2.0f; }
+      c += __popcll(bal);
+      seg[r] = hit ? -1 : seg[r];                            // marks "assigned in this round"
+    }
+#pragma unroll
+    for (int r = 0; r < IPL; ++r)
+      if (seg[r] == -1) seg[r] = last ? (n | (pos << 16)) : (pos | ((pos + c) << 16));
+    pos += c;
+    tail = last;
+  }
+
+  // ---- 4. ideal DCG of the labels (:109-134): the grade position IS the sorted position (equal labels have
+  // equal gains); with an unsorted tail segment the gains are sorted (register bitonic network) instead.
+  float inv_max_dcg = 1.0f;
+  if (a.normalized) {
+    float idcg = 0.f;
+    if (!tail) {
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) if (lv[r]) idcg += g[r] * a.discount[sp[r]];
+    } else {
+      uint32_t sk[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) sk[r] = lv[r] ? float_to_ordered(g[r]) : 0u;
+      wave_sort_desc_u32<IPL>(sk, lane);
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int e = lane + 64 * r;
+        if (e < n) {
+          const uint32_t o = sk[r];
+          idcg += __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o) * a.discount[e];
+        }
+      }
+    }
+    idcg = wave_sum_u(idcg);
+    inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+  }
+  WAVE_LDS_SYNC();                                           // every lane is done reading XS (rank count)
+
+  // ---- 5. records in grade order.
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    if (!lv[r]) continue;
+    const float xv = xr[r];
+    float Bv, Av;
+    if (fast) {
+      const float t_hi = xv - m;
+      const float bb = t_hi - xv;
+      const float t_lo = (xv - (t_hi - bb)) + (-m - bb);
+      Bv = exp_df_hw(t_hi, t_lo);
+      Av = exp_df_hw(-t_hi, -t_lo);
+    } else {
+      Bv = xv; Av = xv;                                      // the slow path works on the scores themselves
+    }
+    rec[sp[r]] = make_float4(Bv, Av, g[r] * inv_max_dcg, __int_as_float(rk[r] * 4));
+    CIS[sp[r]] = lane + 64 * r;
+    SEG[sp[r]] = seg[r];
+    if (ITEMW) WS[sp[r]] = wr[r];
+  }
+  const int C = a.C;
+  const int npad = ((n + 2 * C - 1) / (2 * C)) * (2 * C);    // two columns per trip per lane
+  for (int p = n + lane; p < npad && p < Lp; p += 64) {      // neutral padding: B = A = 0 -> w1 = 1; gain decides
+    rec[p] = make_float4(0.f, 0.f, kBigGain, __int_as_float(0));
+    if (ITEMW) WS[p] = 0.f;
+  }
+  WAVE_LDS_SYNC();
+
+  // ---- 6. pair sweeps: row = C adjacent lanes, 64 / C rows per pass, two columns per trip.
+  const int rows_per_pass = 64 / C;
+  const int c = lane % C, rsub = lane / C;
+  const int trips = npad / (2 * C);
+  typedef const __attribute__((address_space(3))) float lds_cf;
+  const uint32_t ubase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)U;
+  float nnz_local = 0.f;
+  for (int row0 = wave * rows_per_pass; row0 < n; row0 += S * rows_per_pass) {
+    const int row = row0 + rsub;
+    const bool active = row < n;
+    const float4 ri = rec[active ? row : 0];
+    const float Ghi = active ? ri.z : -kBigGain;             // inactive rows: no positive gain difference either way
+    const float Glo = active ? ri.z : kBigGain;
+    const uint32_t r4i = (uint32_t)__float_as_int(ri.w);
+    const int last_row = (row0 + rows_per_pass < n ? row0 + rows_per_pass : n) - 1;
+    const int it_h0 = (SEG[row0] >> 16) / (2 * C);           // hi sweep: columns behind the first row's segment
+    const int it_l1 = ((SEG[last_row] & 0xffff) + 2 * C - 1) / (2 * C);   // lo sweep: columns before the last row's
+    float acc_l = 0.f, acc_g = 0.f, acc_w = 0.f, acc_nz = 0.f, acc_g2 = 0.f;
+    if (fast) {
+      for (int it = it_h0; it < trips; ++it) {               // row preferred: 1 + e^{-(x_i - x_j)} = fma(A_i, B_j, 1)
+        const int j0 = c + it * 2 * C, j1 = j0 + C;
+        const float4 r0 = rec[j0], r1 = rec[j1];
+        const float u0 = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(r0.w), ubase);
+        const float u1 = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(r1.w), ubase);
+        const float w10 = __builtin_fmaf(ri.y, r0.x, 1.0f), w11 = __builtin_fmaf(ri.y, r1.x, 1.0f);
+        const float q0 = __builtin_amdgcn_rcpf(w10), q1 = __builtin_amdgcn_rcpf(w11);
+        const float lg0 = __builtin_amdgcn_logf(w10), lg1 = __builtin_amdgcn_logf(w11);
+        const float W0 = fmaxf(Ghi - r0.z, 0.0f) * u0, W1 = fmaxf(Ghi - r1.z, 0.0f) * u1;
+        acc_l = __builtin_fmaf(W0, lg0, acc_l); acc_l = __builtin_fmaf(W1, lg1, acc_l);
+        acc_g = __builtin_fmaf(W0, 1.0f - q0, acc_g); acc_g = __builtin_fmaf(W1, 1.0f - q1, acc_g);
+        if (AUX) {
+          acc_w += W0; acc_w += W1;
+          acc_nz += (W0 != 0.0f) ? 1.0f : 0.0f; acc_nz += (W1 != 0.0f) ? 1.0f : 0.0f;
+        }
+      }
+      for (int it = 0; it < it_l1; ++it) {                   // column preferred: 1 + e^{-(x_j - x_i)} = fma(B_i, A_j, 1)
+        const int j0 = c + it * 2 * C, j1 = j0 + C;
+        const float4 r0 = rec[j0], r1 = rec[j1];
+        const float u0 = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(r0.w), ubase);
+        const float u1 = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(r1.w), ubase);
+        const float q0 = __builtin_amdgcn_rcpf(__builtin_fmaf(ri.x, r0.y, 1.0f));
+        const float q1 = __builtin_amdgcn_rcpf(__builtin_fmaf(ri.x, r1.y, 1.0f));
+        float W0 = fmaxf(r0.z - Glo, 0.0f) * u0, W1 = fmaxf(r1.z - Glo, 0.0f) * u1;
+        if (ITEMW) { W0 *= WS[j0]; W1 *= WS[j1]; }          // the weight of the PREFERRED item (:917-930)
+        acc_g2 = __builtin_fmaf(W0, 1.0f - q0, acc_g2); acc_g2 = __builtin_fmaf(W1, 1.0f - q1, acc_g2);
+      }
+    } else {
+      // per-pair exponential, numerically safe for any score range (same algebra as pair_loss above);
+      // rec.x = rec.y = x.  The loss accumulates in log2 units like the fast path.
+      for (int it = it_h0; it < trips; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = c + it * 2 * C + h * C;
+          const float4 rj = rec[j];
+          const float u = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(rj.w), ubase);
+          const bool padded = j >= n;
+          const float d0 = padded ? 0.0f : ri.x - rj.x;
+          const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);
+          const float w1 = 1.0f + e;
+          const float q = __builtin_amdgcn_rcpf(w1);
+          const float lg = __builtin_amdgcn_logf(w1) + fmaxf(-d0, 0.0f) * kLog2e;
+          const float sel = (d0 >= 0.0f) ? e * q : q;         // sigma(-d0)
+          const float W = fmaxf(Ghi - rj.z, 0.0f) * u;
+          acc_l = __builtin_fmaf(W, lg, acc_l);
+          acc_g = __builtin_fmaf(W, sel, acc_g);
+          if (AUX) { acc_w += W; acc_nz += (W != 0.0f) ? 1.0f : 0.0f; }
+        }
+      }
+      for (int it = 0; it < it_l1; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = c + it * 2 * C + h * C;
+          const float4 rj = rec[j];
+          const float u = *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(r4i, (uint32_t)__float_as_int(rj.w), ubase);
+          const bool padded = j >= n;
+          const float d0 = padded ? 0.0f : rj.x - ri.x;        // preferred (column) minus row
+          const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);
+          const float q = __builtin_amdgcn_rcpf(1.0f + e);
+          const float sel = (d0 >= 0.0f) ? e * q : q;
+          float W = fmaxf(rj.z - Glo, 0.0f) * u;
+          if (padded) W = 0.0f;
+          if (ITEMW) W *= WS[j];
+          acc_g2 = __builtin_fmaf(W, sel, acc_g2);
+        }
+      }
+    }
+    for (int o = 1; o < C; o <<= 1) {
+      acc_l += __shfl_xor(acc_l, o, 64);
+      acc_g += __shfl_xor(acc_g, o, 64);
+      acc_g2 += __shfl_xor(acc_g2, o, 64);
+      if (AUX) { acc_w += __shfl_xor(acc_w, o, 64); acc_nz += __shfl_xor(acc_nz, o, 64); }
+    }
+    if (active && c == 0) {
+      const int oi = CIS[row];
+      const float wi = ITEMW ? WS[row] : lw;                 // weight of the row item (preferred in the hi sweep)
+      if (a.row_loss) a.row_loss[base + oi] = acc_l * kLn2 * wi;
+      if (AUX && a.row_weight) a.row_weight[base + oi] = acc_w * wi;
+      const float g2 = ITEMW ? acc_g2 : acc_g2 * lw;
+      if (a.dlogits) a.dlogits[base + oi] = (g2 - acc_g * wi) / a.temperature;
+      if (AUX) nnz_local += (wi != 0.0f) ? acc_nz : 0.0f;
+    }
+  }
+  if (!AUX) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
+  if (S == 1) {
+    if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
+  } else {
+    if (lane == 0) nz_slot[wave] = nnz_local;
+    __syncthreads();
+    if (threadIdx.x == 0 && a.nnz) {
+      float t = 0.f;
+      for (int w2 = 0; w2 < S; ++w2) t += nz_slot[w2];
+      a.nnz[b] = t;
+    }
+  }
+}
+
 int env_int(const char* name, int dflt);
 
 template <int IPL>
@@ -669,6 +984,25 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
                         a.mask != nullptr);
   const bool aux = a.row_weight != nullptr || a.nnz != nullptr;
   const bool itemw = generic || a.item_weights != nullptr || a.mask != nullptr;
+  static const int env_lean = env_int("TFR_PAIRWISE_LEAN", 1);
+  if (env_lean && a.kind == TFR_PAIR_LOGISTIC && a.lambda_kind == TFR_LAMBDA_DCG && !generic &&
+      a.gain_kind != TFR_GAIN_CUSTOM) {
+    // LambdaRank fast path (grade-segmented, factorised exponential); S waves per list when the batch is small
+    const bool iw = a.item_weights != nullptr;
+    static const int env_ls = env_int("TFR_PAIRWISE_LEAN_WAVES", 0);
+    int Sl = env_ls > 0 ? env_ls : (B >= 8192 ? 1 : (B >= 2048 ? 2 : 4));
+    if (a.L <= 64) Sl = 1;
+    if (Sl > 4) Sl = 4;
+    while (Sl > 1 && (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 16 > 60 * 1024) Sl >>= 1;
+    const size_t ll = (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 16;
+    if (ll <= 64 * 1024) {
+#define PW_LEAN(AUX, IW) hipLaunchKernelGGL((pairwise_lean_kernel<IPL, AUX, IW>), dim3(B), dim3(64 * Sl), ll, stream, a)
+      if (aux) { if (iw) PW_LEAN(true, true); else PW_LEAN(true, false); }
+      else { if (iw) PW_LEAN(false, true); else PW_LEAN(false, false); }
+#undef PW_LEAN
+      return (int)hipGetLastError();
+    }
+  }
 #define PW_L2(LAM, GEN, AUX, IW) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, AUX, IW, TFR_PAIR_LOGISTIC>), dim3(B), dim3(64 * S), lds, stream, a)
 #define PW_RT(LAM, GEN) hipLaunchKernelGGL((pairwise_wave_kernel<IPL, LAM, GEN, true, true, -1>), dim3(B), dim3(64 * S), lds, stream, a)
 #define PW_LAUNCH(LAM, GEN) do { if (a.kind != TFR_PAIR_LOGISTIC) PW_RT(LAM, GEN);                              \

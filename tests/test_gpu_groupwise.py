@@ -228,17 +228,32 @@ def test_groupwise_scorer_fused_tower_against_the_oracle(shuffle, use_bn):
     assert (got2 - got).abs().max().item() < 2e-2 * scale
     # backward: d loss / d parameters through scatter-average backward + the fused tower backward
     up = torch.randn(B, L, generator=torch.Generator().manual_seed(8))
-    for p in tower.parameters():
-        p.grad = None
-    (got * up.to(DEV)).sum().backward()
+    params = list(tower.weights) + [tower.out_weight]
+
+    def grads_of(out):
+        for p in tower.parameters():
+            p.grad = None
+        (out * up.to(DEV)).sum().backward()
+        return [p.grad.detach().cpu().clone() for p in params]
+    g_fused = grads_of(got)
+    g_general = grads_of(got2)
+    # (a) the fused input (gather inside the bf16 cast) feeds the tower the same bf16 matrix as the op-by-op gather:
+    #     the gradients of the two paths agree far inside bf16 noise
+    for i, (a_, b_) in enumerate(zip(g_fused, g_general)):
+        rel = (a_ - b_).norm().item() / (b_.norm().item() + 1e-12)
+        assert rel <= 2e-3, ('fused vs general', i, rel)
+    # (b) against the fp32 oracle (autograd through oracle.groupwise_logits around the fp32 replica): the direction of
+    #     every weight gradient is the oracle's (bf16 operands and bf16 dz between the layers leave a few per cent of
+    #     noise on a randomly signed upstream; tests/test_gpu_tower.py holds the tower itself to a bf16-aware replica)
     Ws, bs, gam, bet = rep
     leaves = [w.clone().requires_grad_(True) for w in Ws]
     fn = _replica_score_fn((leaves, bs, gam, bet), use_bn)
     (R.groupwise_logits(fn, x, v, gs, indices=cpu_idx) * up).sum().backward()
-    for i, w in enumerate(list(tower.weights) + [tower.out_weight]):
-        want_g = leaves[i].grad.t()
-        err = (w.grad.cpu() - want_g).abs().max().item()
-        assert err < 4e-2 * max(1e-3, want_g.abs().max().item()), (i, err, want_g.abs().max().item())
+    for i, a_ in enumerate(g_fused):
+        b_ = leaves[i].grad.t()
+        cos = (a_ * b_).sum().item() / (a_.norm().item() * b_.norm().item() + 1e-12)
+        ratio = a_.norm().item() / (b_.norm().item() + 1e-12)
+        assert cos >= 0.99 and 0.9 <= ratio <= 1.1, ('vs oracle', i, cos, ratio)
 
 
 def test_groupwise_rejects_bad_arguments():

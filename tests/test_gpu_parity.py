@@ -1507,3 +1507,100 @@ def test_integration_stub_runs():
     torch.cuda.synchronize()
     want_loss, want_w, want_d = ra()._ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
     assert torch.equal(loss, want_loss) and torch.equal(weight, want_w) and torch.equal(d, want_d)
+
+
+# ------------------------------------------------------------------ LambdaRank fast path (pairwise_lean_kernel) edge cases
+def _lean_case(labels, logits, weights=None, T=1.0, lam=None, tol=1e-5):
+    """PairwiseLogisticLoss x (N)DCGLambdaWeight through the fused entry point against the oracle: per-row losses,
+    row weights, pair counts and gradients."""
+    K = ra().keras.losses
+    mine = K.NDCGLambdaWeight() if lam is None else lam[0]
+    theirs = R.NDCGLambdaWeight() if lam is None else lam[1]
+    oracle = R.PairwiseLogisticLoss(lambda_weight=theirs, temperature=T)
+    lg = logits.clone().requires_grad_(True)
+    losses, w = oracle._compute_unreduced_loss_impl(labels, lg / T, labels >= 0)
+    nw = oracle._normalize_weights_impl(labels, weights)
+    want_rows, want_w = (losses * w * nw).sum(dim=2), w * nw
+    want_rows.sum().backward()
+    loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=mine, temperature=T)
+    lgd = logits.to(DEV).requires_grad_(True)
+    list_loss, row_loss, row_weight, nnz = loss._fused(labels.to(DEV), lgd, None if weights is None else weights.to(DEV), None)
+    scale = max(1.0, want_rows.abs().max().item())
+    assert_loss_close(row_loss / scale, want_rows.detach() / scale, tol, what='lean rows')
+    ws = max(1., want_w.sum(2).max().item())
+    assert_loss_close(row_weight / ws, want_w.sum(dim=2) / ws, tol, what='lean row weights')
+    assert torch.equal(nnz.cpu(), (want_w != 0).sum(dim=(1, 2)).float())
+    list_loss.sum().backward()
+    assert_grad_close(lgd.grad, lg.grad, 2 * tol, what='lean grad')
+    # the gradient-only variant (no aux outputs: what loss_and_grad launches)
+    k = K.PairwiseLogisticLoss(lambda_weight=mine, temperature=T, reduction=K.Reduction.SUM)
+    v, d = k.loss_and_grad(labels.to(DEV), logits.to(DEV), None if weights is None else weights.to(DEV))
+    assert_loss_close(v / scale, want_rows.detach().sum() / scale, tol, what='lean loss_and_grad')
+    assert_grad_close(d, lg.grad, 2 * tol, what='lean loss_and_grad grad')
+
+
+@pytest.mark.parametrize('L', [1, 2, 3, 17, 64, 65, 128, 129, 200, 256])
+@pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
+def test_lambdarank_fast_path_shapes(L, wkind):
+    B = 7
+    labels, logits = make_batch(B, L, seed=900 + L)
+    labels[0] = -1.0                                           # no valid item
+    if L > 1:
+        labels[1, 1:] = -1.0; labels[1, 0] = 3.0               # one valid item
+        labels[2] = torch.where(labels[2] >= 0, torch.full_like(labels[2], 2.0), labels[2])     # one grade only
+    w = make_weights(B, L, seed=L) if wkind == 'item' else (make_weights(B, 1, seed=L) if wkind == 'list' else None)
+    if w is not None and wkind == 'item':
+        w[3, : max(1, L // 3)] = 0.0                           # zero item weights change the non-zero pair count
+    _lean_case(labels, logits, w, T=0.7)
+
+
+def test_lambdarank_fast_path_many_distinct_labels_and_real_valued_grades():
+    """More distinct label values than the grade-run budget (the unsorted tail segment), real-valued and
+    fractional grades, identity and 2^l - 1 gains, un-normalised DCG weights."""
+    B, L = 6, 150
+    g = torch.Generator().manual_seed(5)
+    _, logits = make_batch(B, L, seed=41)
+    labels = torch.rand(B, L, generator=g) * 3.0                       # ~all distinct
+    labels[0] = torch.randint(0, 12, (L,), generator=g).float()       # 12 grades > 8 runs
+    labels[1] = (torch.randint(0, 5, (L,), generator=g).float() * 0.5)  # fractional grades
+    labels[:, 140:] = -1.0
+    L_ = ra().losses_impl
+    for lam in [None,
+                (L_.DCGLambdaWeight(), R.DCGLambdaWeight()),
+                (L_.DCGLambdaWeight(normalized=True), R.DCGLambdaWeight(normalized=True)),
+                (ra().losses.create_ndcg_lambda_weight(), R.create_ndcg_lambda_weight())]:
+        _lean_case(labels, logits, None, T=1.0, lam=lam)
+    _lean_case(labels, logits, make_weights(B, L, seed=3), T=1.3)
+
+
+def test_lambdarank_fast_path_wide_score_ranges():
+    """Score ranges beyond what the factorised exponential holds (the per-pair exp branch), right at the switch, and
+    large but factorisable ranges: the loss of a badly inverted pair is ~ its score difference, not inf."""
+    B, L = 8, 90
+    labels, logits = make_batch(B, L, seed=77)
+    scale = torch.tensor([1.0, 10.0, 25.0, 39.0, 41.0, 60.0, 200.0, 1000.0]).reshape(B, 1)
+    lg = logits * scale / 3.0
+    _lean_case(labels, lg, None, T=1.0, tol=2e-5)
+    _lean_case(labels, lg, make_weights(B, L, seed=9), T=0.5, tol=2e-5)
+
+
+def test_lambdarank_fast_path_ties_in_scores():
+    """Tied scores: ranks break ties by index on both sides (oracle: stable sort)."""
+    B, L = 5, 40
+    labels, logits = make_batch(B, L, seed=13)
+    logits = torch.round(logits * 2.0) / 2.0                           # many exact ties
+    _lean_case(labels, logits, None)
+
+
+def test_lambdarank_fast_path_env_switch_matches_general_kernel():
+    """The fast path and the general pair kernel agree (same inputs, TFR_PAIRWISE_LEAN read once per process: the
+    general kernel is reached here through a configuration the fast path does not take -- an explicit mask)."""
+    B, L = 16, 200
+    labels, logits = make_batch(B, L, seed=4)
+    K = ra().keras.losses
+    loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
+    a = loss._fused(labels.to(DEV), logits.to(DEV), None, None)
+    b = loss._fused(labels.to(DEV), logits.to(DEV), None, (labels >= 0).to(DEV))          # mask given: general kernel
+    scale = max(1.0, b[1].abs().max().item())
+    assert_loss_close(a[1] / scale, b[1] / scale, 2e-6, what='lean vs general rows')
+    assert torch.equal(a[3], b[3])
