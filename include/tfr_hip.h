@@ -228,14 +228,19 @@ int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const ui
  *   loss_kind  TFR_PAIR_LOGISTIC (PairwiseLogisticLoss), TFR_PAIR_HINGE (PairwiseHingeLoss :943-948,
  *              relu(1 - d)), TFR_PAIR_SOFT_ZERO_ONE (PairwiseSoftZeroOneLoss :951-958, sigma(-d)),
  *              TFR_PAIR_MSE (PairwiseMSELoss :961-998: all ordered pairs of distinct valid items).
- *   lambda_kind additionally accepts TFR_LAMBDA_DCG_V2 / TFR_LAMBDA_YETI_DCG / TFR_LAMBDA_PRECISION. */
+ *   lambda_kind additionally accepts TFR_LAMBDA_DCG_V2 / TFR_LAMBDA_YETI_DCG / TFR_LAMBDA_PRECISION.
+ *   list_order     nullable [B] launch order (tfr_list_order_i32)
+ *   list_loss_out  nullable [B]: sum over the rows of a list of row_loss (what every scalar reduction consumes;
+ *                  with row_loss_out = NULL nothing [B, L]-sized is written for the loss).
+ * PairwiseLogisticLoss with a DCGLambdaWeight (smooth_fraction 0, no topn, identity / 2^l - 1 gain, no mask) and
+ * list_size <= 256 runs the LambdaRank fast path: items re-homed by grade, only the pairs with l_i > l_j visited. */
 int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                           const float* item_weights, const float* list_weights,
                           int lambda_kind, int topn, float smooth_fraction, int normalized,
                           int gain_kind, const float* gains, const float* discount,
                           int B, int L, float temperature,
                           float* row_loss_out, float* row_weight_out, float* nnz_out,
-                          float* dlogits_out, const int32_t* list_order, void* stream);
+                          float* dlogits_out, const int32_t* list_order, float* list_loss_out, void* stream);
 
 /* losses_impl.SoftmaxLoss.precompute + _compute_unreduced_loss_impl fused with
  * the backward (losses_impl.py:1119-1197, 281-296).

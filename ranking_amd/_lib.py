@@ -60,7 +60,7 @@ _SIGNATURES = {
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_pairwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                               + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
-                              + [ctypes.c_float] + [ctypes.c_void_p] * 6),
+                              + [ctypes.c_float] + [ctypes.c_void_p] * 7),
     'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                              + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
     'tfr_poly1_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2

@@ -37,6 +37,7 @@ struct PwArgs {
   const float* gains; const float* discount;
   int L; int Lp; int P; float temperature; int C; int kind;
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
+  float* list_loss;                      // nullable [B]: sum of the row losses of a list
   const int* order;                      // longest-first launch order (nullable)
 };
 
@@ -311,7 +312,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
   const int c = tid % C, rsub = tid / C;
   const float fL = (float)L;
   const float one_minus_s = 1.0f - a.smooth;
-  float nnz_local = 0.f;
+  float nnz_local = 0.f, list_local = 0.f;
   for (int i = tid; i < L; i += T) {
     if (!MV[i]) {
       if (a.row_loss) a.row_loss[base + i] = 0.f;
@@ -349,10 +350,15 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       if (a.row_weight) a.row_weight[base + oi] = acc_w;
       if (a.dlogits) a.dlogits[base + oi] = acc_g / a.temperature;
       nnz_local += acc_nz;
+      list_local += acc_loss;
     }
   }
   nnz_local = block_sum(nnz_local, red);
   if (tid == 0 && a.nnz) a.nnz[b] = nnz_local;
+  if (a.list_loss) {
+    list_local = block_sum(list_local, red);
+    if (tid == 0) a.list_loss[b] = list_local;
+  }
 }
 
 
@@ -407,6 +413,32 @@ __device__ unsigned long long* g_prof_buf_pw = nullptr;
 #else
 #define PW_STAMP(i) do { } while (0)
 #endif
+
+// End of a wave kernel: per-list pair count (AUX) and loss sum over the S waves that shared the list.  The only
+// workgroup-level exchange: 2 * S floats through LDS, summed in wave order (deterministic).
+template <bool AUX>
+__device__ __forceinline__ void pw_finish(const PwArgs& a, int b, int lane, int wave, int S, float nnz_local,
+                                          float list_local, float* slots) {
+  const bool want_list = a.list_loss != nullptr;              // kernel argument: wave-uniform
+  if (!AUX && !want_list) return;
+  const float nz = AUX ? wave_sum_u(nnz_local) : 0.f;
+  const float ls = want_list ? wave_sum_u(list_local) : 0.f;
+  if (S == 1) {
+    if (lane == 0) {
+      if (AUX && a.nnz) a.nnz[b] = nz;
+      if (want_list) a.list_loss[b] = ls;
+    }
+    return;
+  }
+  if (lane == 0) { slots[wave] = nz; slots[S + wave] = ls; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f, u = 0.f;
+    for (int w2 = 0; w2 < S; ++w2) { t += slots[w2]; u += slots[S + w2]; }
+    if (AUX && a.nnz) a.nnz[b] = t;
+    if (want_list) a.list_loss[b] = u;
+  }
+}
 
 // KIND: TFR_PAIR_LOGISTIC at compile time (the hot configuration), or -1 = a.kind at run time.
 template <int IPL, int LAMBDA, bool GENERIC, bool AUX, bool ITEMW, int KIND>
@@ -594,7 +626,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   const float one_minus_s = 1.0f - a.smooth;
   const float ftopn = (float)topn;
   const int kind = (KIND >= 0) ? KIND : a.kind;
-  float nnz_local = 0.f;
+  float nnz_local = 0.f, list_local = 0.f;
   for (int row0 = wave * rows_per_pass; row0 < n; row0 += S * rows_per_pass) {
     const int row = row0 + rsub;
     const bool active = row < n;
@@ -628,6 +660,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
       if (AUX && a.row_weight) a.row_weight[base + oi] = acc_w;
       if (a.dlogits) a.dlogits[base + oi] = acc_g / a.temperature;
       nnz_local += acc_nz;
+      list_local += acc_loss;
     }
   }
   PW_STAMP(4);
@@ -637,20 +670,7 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
     for (int i = 0; i < 8; ++i) g_prof_buf_pw[(size_t)b * 8 + i] = prof_t[i];
   }
 #endif
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
-  if (!AUX) return;
-  if (S == 1) {
-    if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
-  } else {                                    // the only workgroup-level exchange: S pair counts
-    if (lane == 0) nz_slot[wave] = nnz_local;
-    __syncthreads();
-    if (threadIdx.x == 0 && a.nnz) {
-      float t = 0.f;
-      for (int w2 = 0; w2 < S; ++w2) t += nz_slot[w2];
-      a.nnz[b] = t;
-    }
-  }
+  pw_finish<AUX>(a, b, lane, wave, S, nnz_local, list_local, nz_slot);
 }
 
 // ===========================================================================
@@ -697,6 +717,10 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   const int lane = threadIdx.x & 63, b = a.order ? a.order[blockIdx.x] : blockIdx.x, L = a.L;
   const size_t base = (size_t)b * L;
   const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
+#ifdef TFR_PROFILE_STAMPS
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PW_STAMP(0);
 
   // ---- 1. load, gains, compaction of the valid items (mask == NULL: valid = label >= 0).
   float g[IPL], xr[IPL], labr[IPL], wr[IPL];
@@ -740,6 +764,7 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
   WAVE_LDS_SYNC();
 
+  PW_STAMP(1);
   // ---- 2. ranks by counting (score descending, ties by index) (:483-500).
   int rk[IPL];
   {
@@ -763,6 +788,7 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
     }
   }
 
+  PW_STAMP(2);
   // ---- 3. grade order: repeatedly take the largest remaining label value; its items (in element order)
   // become the next segment.  After kMaxRuns distinct values the rest forms one unsorted tail segment whose
   // rows sweep conservatively (every column is a candidate; the gain difference decides).
@@ -850,13 +876,14 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   }
   WAVE_LDS_SYNC();
 
+  PW_STAMP(3);
   // ---- 6. pair sweeps: row = C adjacent lanes, 64 / C rows per pass, two columns per trip.
   const int rows_per_pass = 64 / C;
   const int c = lane % C, rsub = lane / C;
   const int trips = npad / (2 * C);
   typedef const __attribute__((address_space(3))) float lds_cf;
   const uint32_t ubase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)U;
-  float nnz_local = 0.f;
+  float nnz_local = 0.f, list_local = 0.f;
   for (int row0 = wave * rows_per_pass; row0 < n; row0 += S * rows_per_pass) {
     const int row = row0 + rsub;
     const bool active = row < n;
@@ -945,27 +972,23 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
     if (active && c == 0) {
       const int oi = CIS[row];
       const float wi = ITEMW ? WS[row] : lw;                 // weight of the row item (preferred in the hi sweep)
-      if (a.row_loss) a.row_loss[base + oi] = acc_l * kLn2 * wi;
+      const float row_l = acc_l * kLn2 * wi;
+      list_local += row_l;
+      if (a.row_loss) a.row_loss[base + oi] = row_l;
       if (AUX && a.row_weight) a.row_weight[base + oi] = acc_w * wi;
       const float g2 = ITEMW ? acc_g2 : acc_g2 * lw;
       if (a.dlogits) a.dlogits[base + oi] = (g2 - acc_g * wi) / a.temperature;
       if (AUX) nnz_local += (wi != 0.0f) ? acc_nz : 0.0f;
     }
   }
-  if (!AUX) return;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) nnz_local += __shfl_xor(nnz_local, o, 64);
-  if (S == 1) {
-    if (lane == 0 && a.nnz) a.nnz[b] = nnz_local;
-  } else {
-    if (lane == 0) nz_slot[wave] = nnz_local;
-    __syncthreads();
-    if (threadIdx.x == 0 && a.nnz) {
-      float t = 0.f;
-      for (int w2 = 0; w2 < S; ++w2) t += nz_slot[w2];
-      a.nnz[b] = t;
-    }
+  PW_STAMP(4);
+#ifdef TFR_PROFILE_STAMPS
+  if (lane == 0 && wave == 0 && g_prof_buf_pw) {
+    prof_t[7] = (unsigned long long)n;
+    for (int i = 0; i < 8; ++i) g_prof_buf_pw[(size_t)b * 8 + i] = prof_t[i];
   }
+#endif
+  pw_finish<AUX>(a, b, lane, wave, S, nnz_local, list_local, nz_slot);
 }
 
 int env_int(const char* name, int dflt);
@@ -976,8 +999,8 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   int S = env_s > 0 ? env_s : 1;     // (S > 1 measured slower at every batch size tried)
   if (S > 4) S = 4;
   if (a.L <= 64) S = 1;
-  while (S > 1 && (size_t)S * pw_wave_lds(a.Lp) + 16 > 60 * 1024) S >>= 1;
-  const size_t lds = (size_t)S * pw_wave_lds(a.Lp) + 16;
+  while (S > 1 && (size_t)S * pw_wave_lds(a.Lp) + 32 > 60 * 1024) S >>= 1;
+  const size_t lds = (size_t)S * pw_wave_lds(a.Lp) + 32;
   if (lds > 64 * 1024) return -3;          // (caller falls back to the workgroup kernel)
   const bool generic = (a.lambda_kind == TFR_LAMBDA_DCG) &&
                        (a.lambda_sub != TFR_SUB_DCG || a.smooth != 0.0f || (a.topn > 0 && a.topn < a.L) ||
@@ -990,11 +1013,11 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
     // LambdaRank fast path (grade-segmented, factorised exponential); S waves per list when the batch is small
     const bool iw = a.item_weights != nullptr;
     static const int env_ls = env_int("TFR_PAIRWISE_LEAN_WAVES", 0);
-    int Sl = env_ls > 0 ? env_ls : (B >= 8192 ? 1 : (B >= 2048 ? 2 : 4));
+    int Sl = env_ls > 0 ? env_ls : 1;     // (more waves per list measured slower at B = 4096 and 16384)
     if (a.L <= 64) Sl = 1;
     if (Sl > 4) Sl = 4;
-    while (Sl > 1 && (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 16 > 60 * 1024) Sl >>= 1;
-    const size_t ll = (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 16;
+    while (Sl > 1 && (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 32 > 60 * 1024) Sl >>= 1;
+    const size_t ll = (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 32;
     if (ll <= 64 * 1024) {
 #define PW_LEAN(AUX, IW) hipLaunchKernelGGL((pairwise_lean_kernel<IPL, AUX, IW>), dim3(B), dim3(64 * Sl), ll, stream, a)
       if (aux) { if (iw) PW_LEAN(true, true); else PW_LEAN(true, false); }
@@ -1030,7 +1053,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          int normalized, int gain_kind, const float* gains,
                                          const float* discount, int B, int L, float temperature,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
-                                         float* dlogits_out, const int* order, void* stream) {
+                                         float* dlogits_out, const int* order, float* list_loss_out, void* stream) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_MSE) return TFR_EINVAL;
   if (lambda_kind < TFR_LAMBDA_NONE || lambda_kind > TFR_LAMBDA_PRECISION) return TFR_EINVAL;
@@ -1062,7 +1085,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
     const int c2 = (2 * C > 4) ? 2 * C : 4;
     w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
     w.temperature = temperature; w.C = C; w.kind = kind; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
-    w.nnz = nnz_out; w.dlogits = dlogits_out; w.order = order;
+    w.nnz = nnz_out; w.dlogits = dlogits_out; w.order = order; w.list_loss = list_loss_out;
     hipStream_t st = (hipStream_t)stream;
     if (L <= 64) return launch_pw_wave<1>(w, B, st);
     if (L <= 128) return launch_pw_wave<2>(w, B, st);
@@ -1076,7 +1099,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   a.smooth = smooth_fraction; a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains;
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
   a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
-  a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order;
+  a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order; a.list_loss = list_loss_out;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
   const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
@@ -1109,7 +1132,7 @@ extern "C" int tfr_pairwise_logistic_f32(const float* logits, const float* label
                                          float* dlogits_out, void* stream) {
   return pairwise_dispatch(TFR_PAIR_LOGISTIC, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
-                           row_loss_out, row_weight_out, nnz_out, dlogits_out, nullptr, stream);
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, nullptr, nullptr, stream);
 }
 
 extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
@@ -1118,10 +1141,11 @@ extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const f
                                      int normalized, int gain_kind, const float* gains,
                                      const float* discount, int B, int L, float temperature,
                                      float* row_loss_out, float* row_weight_out, float* nnz_out,
-                                     float* dlogits_out, const int32_t* list_order, void* stream) {
+                                     float* dlogits_out, const int32_t* list_order, float* list_loss_out,
+                                     void* stream) {
   return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
-                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, stream);
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream);
 }
 
 #ifdef TFR_PROFILE_STAMPS

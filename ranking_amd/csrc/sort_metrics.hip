@@ -708,6 +708,71 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
   for (int i = threadIdx.x; i < B; i += 1024) order_out[atomicAdd(&s_hist[cls_of(nvalid[i])], 1)] = i;
 }
 
+// The same order from two FULLY PARALLEL launches (B >= kOrderParallelMin): the one-workgroup scatter above spends
+// 12 us in two dependent sweeps of conflicting LDS atomics over all B lists.  Here every workgroup owns 256 lists:
+// (1) list_class_kernel: its 4 waves count the valid items of their lists, the class of every list goes to
+//     `cls` (one byte per list) and the workgroup's class histogram (LDS atomics on 256 values only) to
+//     `partial[blk][64]`;
+// (2) list_place_kernel: a workgroup derives its base offset per class from the partial histograms (class prefix
+//     over the column sums + the column sums of the workgroups before it: lane = class, coalesced 256-byte rows) and
+//     places its 256 lists with LDS cursors.  Workspace: cls (B bytes) + partial (64 ints per workgroup) <= B ints.
+constexpr int kOrderParallelMin = 512;
+constexpr int kOrderLists = 256;    // lists per workgroup
+
+__global__ __launch_bounds__(256) void list_class_kernel(const float* __restrict__ labels,
+                                                         const uint8_t* __restrict__ mask, int B, int L,
+                                                         uint8_t* __restrict__ cls, int* __restrict__ partial) {
+  __shared__ int s_hist[kOrderClasses];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < kOrderClasses) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int b0 = blockIdx.x * kOrderLists + wave * (kOrderLists / 4);
+  for (int q = 0; q < kOrderLists / 4; ++q) {               // 64 lists per wave, one after the other (loads pipeline)
+    const int b = b0 + q;
+    if (b >= B) break;                                       // wave-uniform
+    const size_t base = (size_t)b * L;
+    int n = 0;
+    for (int c = 0; c < L; c += 64) {
+      const int i = c + lane;
+      const bool v = (i < L) && (mask ? (mask[base + i] != 0) : (labels[base + i] >= 0.0f));
+      n += __popcll(__ballot(v));
+    }
+    if (lane == 0) {
+      const int c = kOrderClasses - 1 - (n * kOrderClasses) / (L + 1);                 // 0 = longest
+      cls[b] = (uint8_t)c;
+      atomicAdd(&s_hist[c], 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kOrderClasses) partial[blockIdx.x * kOrderClasses + threadIdx.x] = s_hist[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const uint8_t* __restrict__ cls,
+                                                         const int* __restrict__ partial, int* __restrict__ order_out) {
+  __shared__ int s_cur[kOrderClasses];
+  __shared__ int s_part[4][2][kOrderClasses];               // per wave: (total, before-me) partial column sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int tot = 0, before = 0;
+  for (int r = wave; r < nblk; r += 4) {                    // lane = class: coalesced rows of the histogram matrix
+    const int v = partial[r * kOrderClasses + lane];
+    tot += v;
+    before += (r < (int)blockIdx.x) ? v : 0;
+  }
+  s_part[wave][0][lane] = tot; s_part[wave][1][lane] = before;
+  __syncthreads();
+  if (wave == 0) {
+    const int t = s_part[0][0][lane] + s_part[1][0][lane] + s_part[2][0][lane] + s_part[3][0][lane];
+    const int bf = s_part[0][1][lane] + s_part[1][1][lane] + s_part[2][1][lane] + s_part[3][1][lane];
+    int inc = t;                                             // exclusive prefix over the classes: one wave scan
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (lane >= d) inc += u; }
+    s_cur[lane] = inc - t + bf;
+  }
+  __syncthreads();
+  const int b = blockIdx.x * kOrderLists + threadIdx.x;
+  if (b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
+}
+
 inline int block_threads_for(int P) {
   int t = P / 2;
   if (t < 64) t = 64;
@@ -844,6 +909,15 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (B >= kOrderParallelMin) {
+    const int nblk = (B + kOrderLists - 1) / kOrderLists;
+    uint8_t* cls = reinterpret_cast<uint8_t*>(workspace);                    // B bytes
+    int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 4 + 64 <= B - B/4)
+    hipLaunchKernelGGL(list_class_kernel, dim3(nblk), dim3(256), 0, st, labels, mask, B, L, cls, partial);
+    hipLaunchKernelGGL(list_place_kernel, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
+                       (const int*)partial, (int*)order_out);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(list_count_kernel, dim3((B + 3) / 4), dim3(256), 0, st, labels, mask, B, L, (int*)workspace);
   hipLaunchKernelGGL(list_scatter_kernel, dim3(1), dim3(1024), 0, st, B, L, (const int*)workspace, (int*)order_out);
   return (int)hipGetLastError();

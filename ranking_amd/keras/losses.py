@@ -337,10 +337,10 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
                 item_w = sample_weight
             else:
                 list_w = list_w * torch.broadcast_to(sample_weight.reshape(-1), (b,))
-        row_loss, _, _, dlogits = _ops.pairwise_logistic(
+        _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-            want_grad=True, want_aux=False, loss_kind=self._loss._fused_kind, **lam)
-        return row_loss.sum(), dlogits
+            want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind, **lam)
+        return list_loss.sum(), dlogits                    # [B] per-list sums: nothing [B, L]-sized for the loss
 
 
 @utils.register_keras_serializable()

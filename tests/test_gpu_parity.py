@@ -1585,11 +1585,19 @@ def test_lambdarank_fast_path_wide_score_ranges():
 
 
 def test_lambdarank_fast_path_ties_in_scores():
-    """Tied scores: ranks break ties by index on both sides (oracle: stable sort)."""
+    """Tied scores: ranks break ties by index on both sides (oracle: stable sort).  The reference writes the logistic
+    loss as relu(-d) + log1p(exp(-|d|)) (losses_impl.py:936-940), whose AUTODIFF at d == 0 exactly is 0 (relu'(0) = 0,
+    sign(0) = 0) although the function is smooth there with derivative -1/2: for the gradient the oracle is given the
+    same function as softplus(-d), whose autodiff is the true derivative -- what the kernels compute."""
     B, L = 5, 40
     labels, logits = make_batch(B, L, seed=13)
     logits = torch.round(logits * 2.0) / 2.0                           # many exact ties
-    _lean_case(labels, logits, None)
+    saved = R.PairwiseLogisticLoss._pairwise_loss
+    R.PairwiseLogisticLoss._pairwise_loss = lambda self, d: torch.nn.functional.softplus(-d)
+    try:
+        _lean_case(labels, logits, None)
+    finally:
+        R.PairwiseLogisticLoss._pairwise_loss = saved
 
 
 def test_lambdarank_fast_path_env_switch_matches_general_kernel():
@@ -1604,3 +1612,22 @@ def test_lambdarank_fast_path_env_switch_matches_general_kernel():
     scale = max(1.0, b[1].abs().max().item())
     assert_loss_close(a[1] / scale, b[1] / scale, 2e-6, what='lean vs general rows')
     assert torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize('L,masked,kind', [(200, False, 0), (200, True, 0), (60, False, 1), (300, False, 0), (300, True, 2)])
+def test_pairwise_list_loss_output_is_the_row_sum(L, masked, kind):
+    """`list_loss_out` of tfr_pairwise_loss_f32 (what loss_and_grad consumes) on the LambdaRank fast path, the general
+    wave kernel (mask given / other loss kinds) and the workgroup kernel (L > 256): equal to the sum of the rows."""
+    B = 9
+    labels, logits = make_batch(B, L, seed=55 + L)
+    K = ra().keras.losses
+    lam = ra().losses_impl._lambda_kernel_args(K.NDCGLambdaWeight(), labels.to(DEV), L, torch.device(DEV))
+    lw = make_weights(B, 1, seed=2).reshape(B).to(DEV)
+    mask = (labels >= 0).to(DEV) if masked else None
+    rows, _, _, d1 = ra()._ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), mask, None, lw, want_aux=False,
+                                                 loss_kind=kind, **lam)
+    _, _, _, d2, lst = ra()._ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), mask, None, lw, want_rows=False,
+                                                   want_aux=False, want_list=True, loss_kind=kind, **lam)
+    assert torch.equal(d1, d2)
+    want = rows.double().sum(dim=1)
+    assert ((lst.double() - want).abs() <= 1e-6 * want.abs().clamp(min=1e-3)).all()

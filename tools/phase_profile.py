@@ -75,7 +75,7 @@ def main_pairwise():
     if not os.path.exists(_lib.PROF_LIB_PATH):
         _lib.build_profiling()
     lib = ctypes.CDLL(_lib.PROF_LIB_PATH)
-    B, L = 4096, 200
+    B, L = int(os.environ.get('B', '4096')), 200
     labels, logits = make_batch(B, L, seed=4)
     dev = 'cuda'
     labels, logits = labels.to(dev), logits.to(dev)
@@ -102,12 +102,19 @@ def main_pairwise():
     e1.record(); torch.cuda.synchronize()
     print('pairwise (NDCG lambda) kernel %.4f ms' % (e0.elapsed_time(e1) / 20))
     t = buf.cpu()[:, :5].double()
-    names = ['load+compact', 'ideal DCG', 'rank count + re-home', 'pair sweep']
+    names = (['load+compact', 'rank count', 'grade order + ideal DCG + records', 'pair sweeps'] if os.environ.get('TFR_PAIRWISE_LEAN', '1') != '0'
+             else ['load+compact', 'ideal DCG', 'rank count + re-home', 'pair sweep'])
     tot = (t[:, 4] - t[:, 0]).mean().item()
     print('mean ticks per list-wave: total %.0f' % tot)
     for i, nme in enumerate(names):
         dt = (t[:, i + 1] - t[:, i]).mean().item()
-        print('  %-22s %8.0f  %5.1f %%' % (nme, dt, 100 * dt / tot))
+        print('  %-36s %8.0f  %5.1f %%' % (nme, dt, 100 * dt / tot))
+    n = buf.cpu()[:, 7].double()
+    lab = labels.cpu()
+    cnt = torch.stack([(lab == g).sum(dim=1).double() for g in range(5)], dim=1)
+    higher = torch.flip(torch.cumsum(torch.flip(cnt, [1]), 1), [1]) - cnt
+    print('mean n_valid %.1f, mean n^2 %.0f, mean active ordered pairs %.0f' % (
+        n.mean().item(), (n * n).mean().item(), (cnt * higher).sum(dim=1).mean().item()))
 
 
 if __name__ == '__main__':
