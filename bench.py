@@ -230,12 +230,11 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
             loss = ra.keras.losses.ApproxNDCGLoss()
     scorer.train()
     D.broadcast_module(scorer)                             # ... and made so explicitly, like the pipeline does
-    bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2)
+    bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2, flatten_params=True)
     if not os.environ.get('TFR_NO_INPLACE_GRADS'):
         bucket.attach(scorer)
     lr = 0.01
     _, world = D.world()
-    params = [p for p in scorer.parameters() if p.requires_grad]
 
     def fwd_bwd():
         bucket.zero()
@@ -244,14 +243,8 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
         return value
 
-    grad_views, off = [], 0
-    for p in params:
-        grad_views.append(bucket.flat[off:off + p.numel()].view_as(p))
-        off += p.numel()
-
     def sgd():
-        with torch.no_grad():                              # SGD on the fp32 master weights: one multi-tensor launch
-            torch._foreach_add_(params, grad_views, alpha=-lr)
+        bucket.sgd_step(lr)                                # SGD on the flat fp32 master weights: one launch
 
     def eager_step():
         value = fwd_bwd()

@@ -765,27 +765,40 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   WAVE_LDS_SYNC();
 
   PW_STAMP(1);
-  // ---- 2. ranks by counting (score descending, ties by index) (:483-500).
+  // ---- 2. ranks by counting (score descending, ties by index) (:483-500).  Compact item p = lane + 64 q
+  // counts the scores above its own: one v_cmp + one add-with-carry per compare, columns as float4 LDS broadcasts.
+  // Tied scores would share a count: a second pass (wave-uniform branch, rare) adds the earlier equals.
   int rk[IPL];
   {
     const float4* X4 = reinterpret_cast<const float4*>(XS);
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      rk[r] = 0;
-      if (!lv[r]) continue;
-      const float xi = xr[r];
-      const int p = posr[r];
-      int cnt = 0;
+    int* RKS = CIS;                                          // scratch: rank by compact position (CIS is filled in step 5)
+    bool any_tie = false;
+    for (int q0 = 0; q0 < n; q0 += 64) {
+      const int p = q0 + lane;
+      const bool on = p < n;
+      const float xi = on ? XS[p] : INFINITY;
+      int cnt = 0, ceq = 0;
       for (int gq = 0; gq < n4; ++gq) {
         const float4 xx = X4[gq];
-        const int j = gq * 4;
-        cnt += (xx.x > xi || (xx.x == xi && j < p)) ? 1 : 0;
-        cnt += (xx.y > xi || (xx.y == xi && j + 1 < p)) ? 1 : 0;
-        cnt += (xx.z > xi || (xx.z == xi && j + 2 < p)) ? 1 : 0;
-        cnt += (xx.w > xi || (xx.w == xi && j + 3 < p)) ? 1 : 0;
+        cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
+        cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
+        ceq += (xx.x == xi) ? 1 : 0; ceq += (xx.y == xi) ? 1 : 0;
+        ceq += (xx.z == xi) ? 1 : 0; ceq += (xx.w == xi) ? 1 : 0;
       }
-      rk[r] = cnt;
+      const bool tie = on && ceq > 1;
+      if (__ballot(tie)) {                                   // some item of this pass shares its score
+        any_tie = true;
+        if (tie) {
+          for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;      // equals with a lower (compact) index first
+        }
+      }
+      if (on) RKS[p] = cnt;
     }
+    (void)any_tie;
+    WAVE_LDS_SYNC();
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
+    WAVE_LDS_SYNC();                                         // RKS (= CIS) is rewritten below
   }
 
   PW_STAMP(2);

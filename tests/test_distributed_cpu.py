@@ -219,3 +219,23 @@ def test_model_fit_pipeline_data_parallel_world2(tmp_path):
         assert hist['loss'] == pytest.approx(want_hist['loss'], abs=1e-6)
     assert out[0][0]['val_loss'] == out[1][0]['val_loss']       # the same decisions on every rank
     assert len(out[0][0]['val_loss']) == len(out[1][0]['val_loss'])
+
+
+def test_flat_params_sgd_equals_per_tensor_sgd():
+    """FlatGradBucket(flatten_params=True): the parameters become views of one buffer (values kept, module still
+    works) and `sgd_step` equals torch.optim.SGD on the separate tensors."""
+    ref = _toy_model()
+    flat = _toy_model()
+    opt = torch.optim.SGD(ref.parameters(), lr=0.1)
+    bucket = D.FlatGradBucket(flat.parameters(), n_scalars=2, flatten_params=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref.parameters(), flat.parameters()))
+    x = torch.randn(6, 5, generator=torch.Generator().manual_seed(2))
+    for _ in range(3):
+        opt.zero_grad(); bucket.zero()
+        ref(x).pow(2).sum().backward(); flat(x).pow(2).sum().backward()
+        opt.step(); bucket.sgd_step(0.1)
+    for a, b in zip(ref.parameters(), flat.parameters()):
+        assert torch.allclose(a, b, atol=1e-7)
+    assert all(p.data_ptr() >= bucket.flat_params.data_ptr() for p in flat.parameters())
+    with pytest.raises(ValueError):
+        D.FlatGradBucket(_toy_model().parameters()).sgd_step(0.1)
