@@ -766,39 +766,45 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
 
   PW_STAMP(1);
   // ---- 2. ranks by counting (score descending, ties by index) (:483-500).  Compact item p = lane + 64 q
-  // counts the scores above its own: one v_cmp + one add-with-carry per compare, columns as float4 LDS broadcasts.
-  // Tied scores would share a count: a second pass (wave-uniform branch, rare) adds the earlier equals.
+  // counts the scores above its own: one v_cmp + half a carry-add per compare, columns as float4 LDS broadcasts.
+  // Items with tied scores end up with the SAME count: an occupancy table over the counts finds them (rare), and
+  // only those add their earlier equals.
   int rk[IPL];
   {
     const float4* X4 = reinterpret_cast<const float4*>(XS);
-    int* RKS = CIS;                                          // scratch: rank by compact position (CIS is filled in step 5)
-    bool any_tie = false;
+    int* RKS = CIS;                                          // scratch: count by compact position (CIS is filled in step 5)
+    int* OCC = SEG;                                          // scratch: how many items share a count (SEG: step 5)
+    for (int p = lane; p < n; p += 64) OCC[p] = 0;
+    WAVE_LDS_SYNC();
     for (int q0 = 0; q0 < n; q0 += 64) {
       const int p = q0 + lane;
       const bool on = p < n;
       const float xi = on ? XS[p] : INFINITY;
-      int cnt = 0, ceq = 0;
+      int cnt = 0;
       for (int gq = 0; gq < n4; ++gq) {
         const float4 xx = X4[gq];
         cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
         cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
-        ceq += (xx.x == xi) ? 1 : 0; ceq += (xx.y == xi) ? 1 : 0;
-        ceq += (xx.z == xi) ? 1 : 0; ceq += (xx.w == xi) ? 1 : 0;
       }
-      const bool tie = on && ceq > 1;
-      if (__ballot(tie)) {                                   // some item of this pass shares its score
-        any_tie = true;
+      if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
+    }
+    WAVE_LDS_SYNC();
+    for (int q0 = 0; q0 < n; q0 += 64) {
+      const int p = q0 + lane;
+      const bool tie = p < n && OCC[RKS[p]] > 1;
+      if (__ballot(tie)) {                                   // wave-uniform: some item of this pass shares its score
         if (tie) {
+          const float xi = XS[p];
+          int cnt = RKS[p];
           for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;      // equals with a lower (compact) index first
+          RKS[p] = cnt;                                      // (OCC is not read for this count again: own slot only)
         }
       }
-      if (on) RKS[p] = cnt;
     }
-    (void)any_tie;
     WAVE_LDS_SYNC();
 #pragma unroll
     for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
-    WAVE_LDS_SYNC();                                         // RKS (= CIS) is rewritten below
+    WAVE_LDS_SYNC();                                         // RKS (= CIS) and OCC (= SEG) are rewritten below
   }
 
   PW_STAMP(2);

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
 
 // The same order from two FULLY PARALLEL launches (B >= kOrderParallelMin): the one-workgroup scatter above spends
 // 12 us in two dependent sweeps of conflicting LDS atomics over all B lists.  Here every workgroup owns 256 lists:
-// (1) list_class_kernel: one thread per list counts its valid items, the class of every list goes to
+// (1) list_class_kernel: four threads per list count its valid items, the class of every list goes to
 //     `cls` (one byte per list) and the workgroup's class histogram (LDS atomics on 256 values only) to
 //     `partial[blk][64]`;
 // (2) list_place_kernel: a workgroup derives its base offset per class from the partial histograms (class prefix
@@ -719,43 +719,36 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
 constexpr int kOrderParallelMin = 512;
 constexpr int kOrderLists = 256;    // lists per workgroup
 
-__global__ __launch_bounds__(256) void list_class_kernel(const float* __restrict__ labels,
-                                                         const uint8_t* __restrict__ mask, int B, int L,
-                                                         uint8_t* __restrict__ cls, int* __restrict__ partial) {
+__global__ __launch_bounds__(1024) void list_class_kernel(const float* __restrict__ labels,
+                                                          const uint8_t* __restrict__ mask, int B, int L,
+                                                          uint8_t* __restrict__ cls, int* __restrict__ partial) {
   __shared__ int s_hist[kOrderClasses];
   if (threadIdx.x < kOrderClasses) s_hist[threadIdx.x] = 0;
   __syncthreads();
-  // ONE THREAD per list: its loads are independent (16 in flight), a 128-byte line serves 8 consecutive float4
-  // steps of the same thread, nothing waits on a wave-wide ballot.  (A wave per list, 64 lists one after the other,
-  // measured 90 us here: every ballot waits for its own load.)
-  const int b = blockIdx.x * kOrderLists + threadIdx.x;
+  // FOUR THREADS per list (a DPP quad), interleaved over the row: independent loads (many in
+  // flight per thread), no wave-wide ballot to wait for.  (A wave per list, 64 lists one after the other, measured
+  // 90 us here -- every ballot waits for its own load; one thread per list 11 us.)
+  const int t = threadIdx.x & 3;
+  const int b = blockIdx.x * kOrderLists + (threadIdx.x >> 2);
+  int n = 0;
   if (b < B) {
     const size_t base = (size_t)b * L;
-    int n = 0;
-    if (mask) {
-      const uint8_t* m = mask + base;
-      if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0)) {
-        const uint32_t* m4 = reinterpret_cast<const uint32_t*>(m);
-#pragma unroll 8
-        for (int i = 0; i < L / 4; ++i) {
-          const uint32_t v = m4[i];
-          n += ((v & 0xffu) != 0) + ((v & 0xff00u) != 0) + ((v & 0xff0000u) != 0) + ((v & 0xff000000u) != 0);
-        }
-      } else {
-#pragma unroll 8
-        for (int i = 0; i < L; ++i) n += m[i] != 0;
-      }
-    } else if ((L & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0)) {
-      const float4* p = reinterpret_cast<const float4*>(labels + base);
-#pragma unroll 8
-      for (int i = 0; i < L / 4; ++i) {
+    if (!mask && (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0)) {
+      const float4* p = reinterpret_cast<const float4*>(labels + base);     // the quad reads 64 contiguous bytes a step
+#pragma unroll 4
+      for (int i = t; i < L / 4; i += 4) {
         const float4 v = p[i];
         n += (v.x >= 0.0f) + (v.y >= 0.0f) + (v.z >= 0.0f) + (v.w >= 0.0f);
       }
     } else {
-#pragma unroll 8
-      for (int i = 0; i < L; ++i) n += labels[base + i] >= 0.0f;
+      const int per = (L + 3) / 4, lo = t * per, hi = (lo + per < L) ? lo + per : L;
+      if (mask) { for (int i = lo; i < hi; ++i) n += mask[base + i] != 0; }
+      else { for (int i = lo; i < hi; ++i) n += labels[base + i] >= 0.0f; }
     }
+  }
+  n += __shfl_xor(n, 1, 64);
+  n += __shfl_xor(n, 2, 64);
+  if (b < B && t == 0) {
     const int c = kOrderClasses - 1 - (n * kOrderClasses) / (L + 1);                   // 0 = longest
     cls[b] = (uint8_t)c;
     atomicAdd(&s_hist[c], 1);
@@ -930,7 +923,7 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
     const int nblk = (B + kOrderLists - 1) / kOrderLists;
     uint8_t* cls = reinterpret_cast<uint8_t*>(workspace);                    // B bytes
     int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 4 + 64 <= B - B/4)
-    hipLaunchKernelGGL(list_class_kernel, dim3(nblk), dim3(256), 0, st, labels, mask, B, L, cls, partial);
+    hipLaunchKernelGGL(list_class_kernel, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
     hipLaunchKernelGGL(list_place_kernel, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
                        (const int*)partial, (int*)order_out);
     return (int)hipGetLastError();

@@ -1631,3 +1631,44 @@ def test_pairwise_list_loss_output_is_the_row_sum(L, masked, kind):
     assert torch.equal(d1, d2)
     want = rows.double().sum(dim=1)
     assert ((lst.double() - want).abs() <= 1e-6 * want.abs().clamp(min=1e-3)).all()
+
+
+@pytest.mark.gpu
+def test_headline_batch_in_the_bench_configuration_against_the_fp64_c_arbiter():
+    """The BASELINE headline batch itself (16384 lists x 200, seed 4 -- what bench.py times), in the configuration
+    bench.py runs it: Keras `loss_and_grad`, longest-first launch order, the whole step replayed from a hipGraph.
+    Every per-list loss and every gradient entry against the strict-fp64 plain-C restatement
+    (oracle/approx_ndcg_c.c), plus the PairwiseLogistic + NDCGLambdaWeight step of config 3 on its batch (4096 x 200)."""
+    c = _c_ref_or_skip()
+    from ranking_amd import _ops
+    K = ra().keras.losses
+    for name, B, L in (('approx_ndcg', 16384, 200), ('pairwise_lambda', 4096, 200)):
+        labels, logits = make_batch(B, L, seed=4)
+        lb, lg = labels.to(DEV), logits.to(DEV)
+        loss = K.ApproxNDCGLoss() if name == 'approx_ndcg' else K.PairwiseLogisticLoss(lambda_weight=K.NDCGLambdaWeight())
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                loss.loss_and_grad(lb, lg)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            value, dlogits = loss.loss_and_grad(lb, lg)
+        dlogits.zero_()
+        graph.replay(); graph.replay()
+        torch.cuda.synchronize()
+        if name == 'approx_ndcg':
+            w_loss, w_weight, w_grad = c.approx_ndcg(logits.numpy(), labels.numpy(), temperature=0.1)
+            want_value = float(torch.from_numpy(w_loss).double().sum() / B)                 # Keras AUTO: mean over lists
+            want_grad = torch.from_numpy(w_grad) / B
+            per_list, _, _ = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, False)             # the per-list losses
+            assert_loss_close(per_list, torch.from_numpy(w_loss), 2e-5, what='headline per-list loss vs C fp64')
+        else:
+            w_out, w_grad = c.pairwise_logistic_ndcg(logits.numpy(), labels.numpy())
+            want_value = float(torch.from_numpy(w_out).double().sum() / (B * L))            # keras/losses.py:324-335
+            want_grad = torch.from_numpy(w_grad) / (B * L)
+        assert abs(value.item() - want_value) <= 1e-5 * max(1.0, abs(want_value)), (name, value.item(), want_value)
+        assert_grad_close(dlogits, want_grad, 5e-5, what='%s full-batch gradient vs C fp64' % name)
+        assert bool((dlogits[lb < 0] == 0).all())
