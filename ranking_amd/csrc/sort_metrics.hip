@@ -919,7 +919,8 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (B >= kOrderParallelMin) {
+  static const int env_par = [] { const char* e = getenv("TFR_ORDER_PARALLEL"); return (e && *e) ? atoi(e) : 1; }();
+  if (env_par && B >= kOrderParallelMin) {
     const int nblk = (B + kOrderLists - 1) / kOrderLists;
     uint8_t* cls = reinterpret_cast<uint8_t*>(workspace);                    // B bytes
     int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 4 + 64 <= B - B/4)
