@@ -512,19 +512,35 @@ def _timed_loop(fn, n, dist):
 
 
 def _kernel_ms(kernel, n):
-    """Average duration of the dominant kernel: HIP events on the launch stream, kernel launches only."""
+    """Average duration of the dominant kernel, kernel launches only, HIP events on the launch stream.  The launches
+    are replayed from a hipGraph of `reps` back-to-back launches (events around every replay): an eager launch from
+    Python costs ~10 us of host time, which would be the measurement for the 5-20 us kernels (softmax, metrics)."""
+    reps = 8
     stream = torch.cuda.current_stream()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for _ in range(3):
         kernel()
     torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(stream)
+    with torch.cuda.stream(side):
+        kernel()
+    stream.wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for _ in range(reps):
+            kernel()
+    graph.replay()
+    torch.cuda.synchronize()
+    n = max(4, n // reps)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
     for a, b in evs:
         a.record(stream)
-        kernel()
+        graph.replay()
         b.record(stream)
     torch.cuda.synchronize()
     ts = [a.elapsed_time(b) for a, b in evs]
-    return sum(ts) / len(ts)
+    return sum(ts) / len(ts) / reps
 
 
 def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s):

@@ -323,6 +323,9 @@ inline int threads_for(int L) {
 // Same arithmetic as softmax_loss_kernel (which stays for DCGLambdaWeight.individual_weights and long lists):
 // masked logits = ln(1e-10), labels (x weights), all-zero lists -> 1e-10 on the valid entries, log-sum-exp,
 // gradient w (ptot * softmax - p) / T;  + poly-1 term.  12 B read + 4 B written per item: HBM-bound.
+// (A 16-byte-access form -- 4 consecutive items per lane, one dwordx4 load per array for a 200-item list -- measured
+// SLOWER on MI355X: 25.1 vs 20.1 us per step at B = 16384, L = 200; only 50 of 64 lanes carry data and the four
+// items of a lane serialise the exp / divide chain.  Dropped.)
 template <int IPL>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B) {
   const int lane = threadIdx.x & 63;
@@ -403,104 +406,6 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
   }
 }
 
-// The same kernel with 16-byte accesses (list_size % 4 == 0, no separate mask): lane t owns the 4 consecutive items
-// 4 (t + 64 v) .. + 3, so a 200-item list is ONE global_load_dwordx4 per array and one global_store_dwordx4 instead
-// of four dword accesses each (the dword form sat at 2.3 TB/s: instruction-issue / request bound, not bandwidth).
-// Sums run over a different item order than the dword form (fp32, within the 1e-5 bar; nothing here is bit-pinned).
-template <int V>
-__global__ __launch_bounds__(256) void softmax_wave4_kernel(const SmArgs a, int B) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
-  const int L4 = a.L >> 2;
-  const size_t base = (size_t)b * a.L;
-  const float4* lab4 = reinterpret_cast<const float4*>(a.labels + base);
-  const float4* x4 = reinterpret_cast<const float4*>(a.logits + base);
-  const float4* w4 = (a.item_weights && !a.weights_per_list) ? reinterpret_cast<const float4*>(a.item_weights + base) : nullptr;
-  const float wl = (a.item_weights && a.weights_per_list) ? a.item_weights[b] : 1.0f;
-  float z[V][4], y[V][4];
-  bool mvv[V][4];
-  float lsum = 0.f, zmax = -INFINITY;
-#pragma unroll
-  for (int v = 0; v < V; ++v) {                         // every load of the list is issued before the first use
-    const int q = lane + 64 * v;
-    const bool in = q < L4;
-    float4 lb = make_float4(-1.f, -1.f, -1.f, -1.f), xx = make_float4(0.f, 0.f, 0.f, 0.f), ww = make_float4(wl, wl, wl, wl);
-    if (in) { lb = lab4[q]; xx = x4[q]; if (w4) ww = w4[q]; }
-    const float l_[4] = {lb.x, lb.y, lb.z, lb.w}, x_[4] = {xx.x, xx.y, xx.z, xx.w}, w_[4] = {ww.x, ww.y, ww.z, ww.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      mvv[v][c] = in && l_[c] >= 0.0f;
-      z[v][c] = in ? (mvv[v][c] ? x_[c] / a.temperature : kLogEps10) : -INFINITY;
-      y[v][c] = mvv[v][c] ? l_[c] * (a.item_weights ? w_[c] : 1.0f) : 0.0f;
-      lsum += y[v][c];
-      zmax = fmaxf(zmax, z[v][c]);
-    }
-  }
-  lsum = wave_sum_u(lsum);
-  zmax = wave_max_u(zmax);
-  const bool nonzero = lsum > 0.0f;
-  float psum = 0.f, esum = 0.f, e[V][4];
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const bool in = lane + 64 * v < L4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float yy = nonzero ? y[v][c] : 1e-10f;
-      yy = mvv[v][c] ? yy : 0.0f;
-      y[v][c] = yy;
-      psum += yy;
-      e[v][c] = in ? expf(z[v][c] - zmax) : 0.0f;
-      esum += e[v][c];
-    }
-  }
-  psum = wave_sum_u(psum);
-  esum = wave_sum_u(esum);
-  const float lse = logf(esum);
-  float loss = 0.f, ptot = 0.f, pt = 0.f;
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const bool in = lane + 64 * v < L4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float p = (psum != 0.0f) ? (y[v][c] / psum) : 0.0f;            // divide_no_nan
-      if (in) {
-        loss += p * (lse - (z[v][c] - zmax));
-        ptot += p;
-        pt += p * (e[v][c] / esum);
-      }
-      y[v][c] = p;
-    }
-  }
-  loss = wave_sum_u(loss);
-  ptot = wave_sum_u(ptot);
-  if (a.poly_eps != 0.0f) {
-    pt = wave_sum_u(pt);
-    loss += a.poly_eps * (1.0f - pt);
-  }
-  if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
-  if (!a.dlogits) return;
-  float4* d4 = reinterpret_cast<float4*>(a.dlogits + base);
-#pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const int q = lane + 64 * v;
-    if (q < L4) {
-      float g[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        g[c] = 0.f;
-        if (mvv[v][c]) {
-          const float sm = e[v][c] / esum;
-          float d = ptot * sm - y[v][c];
-          if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[v][c] - pt);
-          g[c] = lsum * (d / a.temperature);
-        }
-      }
-      d4[q] = make_float4(g[0], g[1], g[2], g[3]);
-    }
-  }
-}
-
 }  // namespace
 
 extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
@@ -541,16 +446,6 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
   static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
   if (env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
-    static const int env_v4 = [] { const char* e = getenv("TFR_SOFTMAX_VEC4"); return (e && *e) ? atoi(e) : 1; }();
-    const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(labels) |
-                           reinterpret_cast<uintptr_t>(dlogits_out) |
-                           ((item_weights && !weights_per_list) ? reinterpret_cast<uintptr_t>(item_weights) : 0)) & 15) == 0;
-    if (env_v4 && !mask && (L & 3) == 0 && aligned) {      // 16-byte accesses: 4 consecutive items per lane
-#define SMV(V) hipLaunchKernelGGL(softmax_wave4_kernel<V>, dim3((B + 3) / 4), dim3(256), 0, st, a, B)
-      if (L <= 256) SMV(1); else if (L <= 512) SMV(2); else SMV(4);
-#undef SMV
-      return (int)hipGetLastError();
-    }
 #define SMW(I) hipLaunchKernelGGL(softmax_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, a, B)
     if (L <= 64) SMW(1); else if (L <= 128) SMW(2); else if (L <= 256) SMW(4); else if (L <= 512) SMW(8); else SMW(16);
 #undef SMW
