@@ -161,9 +161,10 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         list_w = torch.full((B,), 1.0 / (B * L), dtype=torch.float32, device=dev)
         order = _ops._auto_order(labels, None, None, 128)
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
-                    kernel=lambda: _ops.pairwise_logistic(
-                        logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_aux=False,
-                        loss_kind=_ops.PAIR_LOGISTIC, balance=order if order is not None else False, **lam),
+                    kernel=lambda: _ops.pairwise_logistic(                 # exactly the launch of loss_and_grad
+                        logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_rows=False,
+                        want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC,
+                        balance=order if order is not None else False, **lam),
                     kernel_name='pairwise_lean_kernel' if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()

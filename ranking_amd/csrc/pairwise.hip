@@ -414,6 +414,45 @@ __device__ unsigned long long* g_prof_buf_pw = nullptr;
 #define PW_STAMP(i) do { } while (0)
 #endif
 
+// 0-based rank (score descending, ties by lower compact index) of the n compact scores XS[0 .. n) of ONE wavefront's
+// list, into RKS[0 .. n).  XS is padded with -inf up to a multiple of 4 (+4).  Compact item p = lane + 64 q counts the
+// scores above its own: one v_cmp + half a carry-add per compare, the columns are float4 LDS broadcasts.  Items with
+// tied scores end up with the SAME count: an occupancy table (OCC, n ints of scratch) finds them -- rare -- and only
+// those add the equal scores in front of them.  (The previous form evaluated the full tie rule in every compare and
+// walked the 4 x 64 register layout: 6 VALU per compare over 4 passes, as much issue time as the pair sweep.)
+__device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
+  const float4* X4 = reinterpret_cast<const float4*>(XS);
+  const int n4 = (n + 3) >> 2;
+  for (int p = lane; p < n; p += 64) OCC[p] = 0;
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int p = q0 + lane;
+    const bool on = p < n;
+    const float xi = on ? XS[p] : INFINITY;
+    int cnt = 0;
+    for (int gq = 0; gq < n4; ++gq) {
+      const float4 xx = X4[gq];
+      cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
+      cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
+    }
+    if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
+  }
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int p = q0 + lane;
+    const bool tie = p < n && OCC[RKS[p]] > 1;
+    if (__ballot(tie)) {                                     // wave-uniform: some item of this pass shares its score
+      if (tie) {
+        const float xi = XS[p];
+        int cnt = RKS[p];
+        for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;
+        RKS[p] = cnt;                                        // (other lanes read OCC at their OWN first count only)
+      }
+    }
+  }
+  WAVE_LDS_SYNC();
+}
+
 // End of a wave kernel: per-list pair count (AUX) and loss sum over the S waves that shared the list.  The only
 // workgroup-level exchange: 2 * S floats through LDS, summed in wave order (deterministic).
 template <bool AUX>
@@ -584,21 +623,20 @@ __global__ __launch_bounds__(256) void pairwise_wave_kernel(const PwArgs a) {
   const int n4 = (n + 3) >> 2;
   for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
   WAVE_LDS_SYNC();
-  const float4* X4 = reinterpret_cast<const float4*>(XS);
+  int cntr[IPL];
+  {
+    int* RKS = reinterpret_cast<int*>(auxS);                 // scratch (auxS / CIS are filled by the re-homing below)
+    int* OCC = CIS;
+    wave_rank_by_count(XS, n, lane, RKS, OCC);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) cntr[r] = mv[r] ? RKS[posr[r]] : 0;
+    WAVE_LDS_SYNC();
+  }
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
     if (!mv[r]) continue;
     const float xi = xr[r];
-    const int p = posr[r];
-    int cnt = 0;
-    for (int gq = 0; gq < n4; ++gq) {
-      const float4 xx = X4[gq];
-      const int j = gq * 4;
-      cnt += (xx.x > xi || (xx.x == xi && j < p)) ? 1 : 0;
-      cnt += (xx.y > xi || (xx.y == xi && j + 1 < p)) ? 1 : 0;
-      cnt += (xx.z > xi || (xx.z == xi && j + 2 < p)) ? 1 : 0;
-      cnt += (xx.w > xi || (xx.w == xi && j + 3 < p)) ? 1 : 0;
-    }
+    const int cnt = cntr[r];
     float dprime = 0.f;
     float gz = lv[r] ? g[r] : 0.0f;
     if (LAMBDA == TFR_LAMBDA_DCG) {
@@ -771,37 +809,9 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   // only those add their earlier equals.
   int rk[IPL];
   {
-    const float4* X4 = reinterpret_cast<const float4*>(XS);
     int* RKS = CIS;                                          // scratch: count by compact position (CIS is filled in step 5)
     int* OCC = SEG;                                          // scratch: how many items share a count (SEG: step 5)
-    for (int p = lane; p < n; p += 64) OCC[p] = 0;
-    WAVE_LDS_SYNC();
-    for (int q0 = 0; q0 < n; q0 += 64) {
-      const int p = q0 + lane;
-      const bool on = p < n;
-      const float xi = on ? XS[p] : INFINITY;
-      int cnt = 0;
-      for (int gq = 0; gq < n4; ++gq) {
-        const float4 xx = X4[gq];
-        cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
-        cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
-      }
-      if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
-    }
-    WAVE_LDS_SYNC();
-    for (int q0 = 0; q0 < n; q0 += 64) {
-      const int p = q0 + lane;
-      const bool tie = p < n && OCC[RKS[p]] > 1;
-      if (__ballot(tie)) {                                   // wave-uniform: some item of this pass shares its score
-        if (tie) {
-          const float xi = XS[p];
-          int cnt = RKS[p];
-          for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;      // equals with a lower (compact) index first
-          RKS[p] = cnt;                                      // (OCC is not read for this count again: own slot only)
-        }
-      }
-    }
-    WAVE_LDS_SYNC();
+    wave_rank_by_count(XS, n, lane, RKS, OCC);
 #pragma unroll
     for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
     WAVE_LDS_SYNC();                                         // RKS (= CIS) and OCC (= SEG) are rewritten below

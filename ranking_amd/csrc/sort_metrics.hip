@@ -614,6 +614,284 @@ __global__ __launch_bounds__(64) void div_metric_wave_kernel(
   }
 }
 
+// ===========================================================================
+// Workgroup-per-list forms of the two kernels above for LONG lists (list_size > 512): the register bitonic
+// network of the wave kernels does not fit the register file beyond 8 keys per lane (the 16-key forms spilled
+// 0.6 - 1.7 KB per lane).  Keys, the per-item values and the sorted-order values live in LDS (32 B per item:
+// list_size <= 4096), sorts are block_bitonic_sort_desc, sums block_tree_sum over the same zero-padded power of
+// two -- the same pairing as wave_tree_sum, so results are bit-identical to the wave kernels.
+// ===========================================================================
+// inclusive prefix sum of a[0 .. P) (Hillis-Steele ping-pong between `a` and `scratch`, P a power of two; the result
+// ends in `a`).  Values are item counts / small label sums: the wave kernels scan in a different association, equal
+// for integer-valued data.
+__device__ __forceinline__ void block_inclusive_scan(float* a, float* scratch, int P) {
+  float* src = a;
+  float* dst = scratch;
+  for (int o = 1; o < P; o <<= 1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) dst[i] = src[i] + ((i >= o) ? src[i - o] : 0.0f);
+    float* t = src; src = dst; dst = t;
+  }
+  __syncthreads();
+  if (src != a) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) a[i] = src[i];
+    __syncthreads();
+  }
+}
+
+__global__ void rank_metric2_block_kernel(
+    int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
+    const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
+    const float* __restrict__ gains, const float* __restrict__ discount, TopN topn, int B, int L, int P,
+    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* W = reinterpret_cast<float*>(keys + P);                  // [P] weight by original index
+  float* G = W + P;                                               // [P] relevance / gain by original index
+  float* REL = G + P;                                             // [P] relevance in sorted order
+  float* WR = REL + P;                                            // [P] w * rel in sorted order
+  float* CUM = WR + P;                                            // [P] prefix counts
+  float* term = CUM + P;                                          // [P] tree-sum scratch
+  const int b = blockIdx.x, T = blockDim.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  float nm = 0.f;
+  for (int i = threadIdx.x; i < P; i += T) {
+    float w = 0.f, g = 0.f;
+    bool m = false;
+    uint64_t key = 0;
+    if (i < L) {
+      const float lab = labels[base + i];
+      w = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      m = v0 && (w > 0.0f);
+      const float labc = m ? lab : 0.0f;
+      if (kind == TFR_METRIC_DCG) g = gains ? gains[base + i] : gain_pow2m1(labc);
+      else if (kind == TFR_METRIC_ARP || kind == TFR_METRIC_PWA) g = labc;
+      else g = (labc >= 1.0f) ? 1.0f : 0.0f;
+      key = make_sort_key(m, predictions[base + i], 0, i);
+    }
+    W[i] = w; G[i] = g; keys[i] = key;
+    nm += m ? 1.0f : 0.0f;
+  }
+  const int nmask = (int)block_sum(nm, red);
+  __syncthreads();
+  float s_w, s_g, s_wg;
+  for (int i = threadIdx.x; i < P; i += T) term[i] = W[i];
+  block_tree_sum(term, P); s_w = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += T) term[i] = G[i];
+  block_tree_sum(term, P); s_g = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += T) term[i] = W[i] * G[i];
+  block_tree_sum(term, P); s_wg = term[0]; __syncthreads();
+  if (threadIdx.x == 0) {
+    stats_out[(size_t)b * 3 + 0] = s_w;
+    stats_out[(size_t)b * 3 + 1] = s_g;
+    if (kind != TFR_METRIC_ARP) stats_out[(size_t)b * 3 + 2] = s_wg;
+  }
+
+  if (kind == TFR_METRIC_OPA) {
+    // (:708-743) REL = label (+inf: not a valid j), WR = prediction, by original index; CUM / term = the two sums
+    for (int i = threadIdx.x; i < P; i += T) {
+      const bool m = i < L && (keys[i] >> 63) != 0;
+      REL[i] = m ? labels[base + i] : INFINITY;
+      WR[i] = i < L ? predictions[base + i] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += T) {
+      int np = 0, nc = 0;
+      if (i < L && (keys[i] >> 63) != 0) {
+        const float li = REL[i], si = WR[i];
+        for (int j = 0; j < L; ++j) {
+          const bool gt = li > REL[j];
+          np += gt ? 1 : 0;
+          nc += (gt && si > WR[j]) ? 1 : 0;
+        }
+      }
+      CUM[i] = W[i] * (float)np;
+      term[i] = W[i] * (float)nc;
+    }
+    block_tree_sum(term, P);
+    const float tc = term[0];
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += T) term[i] = CUM[i];
+    block_tree_sum(term, P);
+    const float tw = term[0];
+    if (threadIdx.x == 0) {
+      stats_out[(size_t)b * 3 + 2] = tw;
+      metric_out[b] = (tw != 0.0f) ? tc / tw : 0.0f;
+    }
+    return;
+  }
+
+  block_bitonic_sort_desc(keys, P);                              // (Hits too: the first relevant sorted position)
+  for (int p = threadIdx.x; p < P; p += T) {
+    float r = 0.f, wr = 0.f;
+    if (p < L) { const int idx = sort_key_index(keys[p]); r = G[idx]; wr = W[idx] * G[idx]; }
+    REL[p] = r; WR[p] = wr;
+  }
+  __syncthreads();
+  if (kind == TFR_METRIC_HITS) {
+    float pmin = INFINITY;
+    for (int p = threadIdx.x; p < L; p += T) if (REL[p] > 0.0f && (keys[p] >> 63) != 0) pmin = fminf(pmin, (float)p);
+    pmin = block_min(pmin, red);
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < topn.n; ++q) {
+        const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+        metric_out[(size_t)q * B + b] = (pmin < (float)k) ? 1.0f : 0.0f;
+      }
+    }
+    return;
+  }
+  const bool bpref = (kind == TFR_METRIC_BPREF || kind == TFR_METRIC_BPREF_NONTREC);
+  if (kind == TFR_METRIC_MAP || bpref) {
+    for (int p = threadIdx.x; p < P; p += T) CUM[p] = bpref ? ((p < nmask) ? 1.0f - REL[p] : 0.0f) : REL[p];
+    block_inclusive_scan(CUM, term, P);
+  }
+  float arp_den = 0.f;
+  if (kind == TFR_METRIC_ARP) {
+    for (int p = threadIdx.x; p < P; p += T) term[p] = WR[p];
+    block_tree_sum(term, P);
+    arp_den = term[0];
+    __syncthreads();
+    if (threadIdx.x == 0) stats_out[(size_t)b * 3 + 2] = arp_den;
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    for (int p = threadIdx.x; p < P; p += T) {
+      float v = 0.f;
+      if (p < k) {
+        if (kind == TFR_METRIC_DCG) v = WR[p] * discount[p];
+        else if (kind == TFR_METRIC_MAP) v = (CUM[p] / (float)(p + 1)) * WR[p];
+        else if (kind == TFR_METRIC_ARP) v = (float)(p + 1) * WR[p];
+        else if (bpref) {
+          const float num = fminf(CUM[p], s_g);
+          const float den = (kind == TFR_METRIC_BPREF) ? fminf((float)nmask - s_g, s_g) : s_g;
+          v = (1.0f - ((den != 0.0f) ? num / den : 0.0f)) * REL[p];
+        } else if (kind == TFR_METRIC_PWA) v = (p < nmask) ? REL[p] * (1.0f / (float)(p + 1)) : 0.0f;
+        else v = REL[p];
+      }
+      term[p] = v;
+    }
+    block_tree_sum(term, P);
+    const float total = term[0];
+    __syncthreads();
+    float out = total;
+    if (bpref) out = (s_g != 0.0f) ? total / s_g : 0.0f;
+    if (kind == TFR_METRIC_PWA) {
+      for (int p = threadIdx.x; p < P; p += T) term[p] = (p < k && p < nmask) ? 1.0f / (float)(p + 1) : 0.0f;
+      block_tree_sum(term, P);
+      const float den = term[0];
+      __syncthreads();
+      out = (den != 0.0f) ? total / den : 0.0f;
+    }
+    if (kind == TFR_METRIC_RECALL) out = (s_g != 0.0f) ? total / s_g : 0.0f;
+    else if (kind == TFR_METRIC_PRECISION) { const int d = k < nmask ? k : nmask; out = d > 0 ? total / (float)d : 0.0f; }
+    else if (kind == TFR_METRIC_MAP) out = (s_wg != 0.0f) ? total / s_wg : 0.0f;
+    else if (kind == TFR_METRIC_ARP) out = (arp_den != 0.0f) ? total / arp_den : 0.0f;
+    if (threadIdx.x == 0) metric_out[(size_t)q * B + b] = out;
+  }
+}
+
+__global__ void div_metric_block_kernel(
+    int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
+    const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
+    const float* __restrict__ discount, float alpha, TopN topn, int B, int L, int S, int P,
+    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* W = reinterpret_cast<float*>(keys + P);                  // [P] weight by original index, then in sorted order
+  float* G = W + P;                                               // [P] rel by original index
+  float* VAL = G + P;                                             // [P] per-position value, sorted order
+  float* Y = VAL + P;                                             // [P] one subtopic's labels / their prefix
+  float* term = Y + P;                                            // [P]
+  const int b = blockIdx.x, T = blockDim.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+  float nm = 0.f;
+  for (int i = threadIdx.x; i < P; i += T) {
+    float w = 0.f, g = 0.f;
+    uint64_t key = 0;
+    if (i < L) {
+      const float* lab = labels + (base + i) * (size_t)S;
+      w = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      bool any_valid = false, any_rel = false;
+      for (int t = 0; t < S; ++t) { const float y = lab[t]; any_valid |= (y >= 0.0f); any_rel |= (y >= 1.0f); }
+      const bool m = mask ? (mask[base + i] != 0) : any_valid;
+      g = (m && any_rel) ? 1.0f : 0.0f;
+      key = make_sort_key(m, predictions[base + i], 0, i);
+      nm += m ? 1.0f : 0.0f;
+    }
+    W[i] = w; G[i] = g; keys[i] = key;
+  }
+  const int nmask = (int)block_sum(nm, red);
+  __syncthreads();
+  float s_w, s_g, s_wg;
+  for (int i = threadIdx.x; i < P; i += T) term[i] = W[i];
+  block_tree_sum(term, P); s_w = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += T) term[i] = G[i];
+  block_tree_sum(term, P); s_g = term[0]; __syncthreads();
+  for (int i = threadIdx.x; i < P; i += T) term[i] = W[i] * G[i];
+  block_tree_sum(term, P); s_wg = term[0]; __syncthreads();
+  if (threadIdx.x == 0) {
+    stats_out[(size_t)b * 3 + 0] = s_w;
+    stats_out[(size_t)b * 3 + 1] = s_g;
+    stats_out[(size_t)b * 3 + 2] = s_wg;
+  }
+  block_bitonic_sort_desc(keys, P);
+  for (int p = threadIdx.x; p < P; p += T) {
+    float ws = 0.f;
+    if (p < L) { const int idx = sort_key_index(keys[p]); ws = weights ? (weights_per_list ? wl : weights[base + idx]) : 1.0f; }
+    G[p] = ws;                                                   // G is free now: weight in sorted order
+    VAL[p] = 0.f;
+  }
+  __syncthreads();
+  float n_sub = 0.f;
+  const float one_m_alpha = 1.0f - alpha;
+  for (int st = 0; st < S; ++st) {
+    float anyf = 0.f;
+    for (int p = threadIdx.x; p < P; p += T) {
+      float y = 0.f;
+      if (p < L && p < nmask) y = labels[(base + sort_key_index(keys[p])) * (size_t)S + st];
+      Y[p] = y;
+      term[p] = y;
+      anyf = fmaxf(anyf, (y >= 1.0f) ? 1.0f : 0.0f);
+    }
+    if (kind == TFR_DIV_PRECISION_IA) {
+      n_sub += block_max(anyf, red);
+      __syncthreads();
+      for (int p = threadIdx.x; p < P; p += T) VAL[p] += (Y[p] >= 1.0f) ? 1.0f : 0.0f;
+      __syncthreads();
+    } else {
+      block_inclusive_scan(term, W, P);                          // inclusive (W is free: scratch); exclusive below
+      for (int p = threadIdx.x; p < P; p += T) {
+        const float cum = (p > 0) ? term[p - 1] : 0.0f;          // tf.cumsum(exclusive=True) along the ranking
+        VAL[p] += Y[p] * powf(one_m_alpha, cum);
+      }
+      __syncthreads();
+    }
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    for (int p = threadIdx.x; p < P; p += T) {
+      float v = 0.f;
+      if (p < k) v = (kind == TFR_DIV_PRECISION_IA) ? VAL[p] : (G[p] * VAL[p]) * discount[p];
+      term[p] = v;
+    }
+    block_tree_sum(term, P);
+    const float total = term[0];
+    __syncthreads();
+    float out = total;
+    if (kind == TFR_DIV_PRECISION_IA) {
+      const float den = (float)(k < nmask ? k : nmask) * n_sub;
+      out = (den != 0.0f) ? total / den : 0.0f;
+    }
+    if (threadIdx.x == 0) metric_out[(size_t)q * B + b] = out;
+  }
+}
+
 // Per-list metric weights from the per-list statistics (metrics_impl.py:63-119
 // _per_example_weights_to_per_list_weights): w_b = sum(w rel) / sum(rel) for a list with relevance, the batch mean
 // of those for a list without, 0 for a list whose weights are all 0.  One workgroup; two passes over [B, 3].
@@ -655,7 +933,7 @@ void dispatch_metric_wave(int L, const float* labels, const float* predictions, 
                           const TopN& tn, int B, int P, float* metric_out, float* stats_out, hipStream_t st) {
 #define MW(I) launch_metric_wave<KIND, I>(labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out, st)
   if (L <= 64) MW(1); else if (L <= 128) MW(2); else if (L <= 256) MW(4);
-  else if (KIND == 0) { if (L <= 512) MW(8); else MW(16); }
+  else if (KIND == 0) MW(8);                      // 256 < L <= 512 (NDCG only; longer lists: the workgroup kernel)
 #undef MW
 }
 
@@ -829,13 +1107,20 @@ static int launch_metric(int kind, const float* labels, const float* predictions
   const int P = pow2_ceil(L < 2 ? 2 : L);
   static const int env_wave = [] { const char* e = getenv("TFR_SORT_WAVE"); return (e && *e) ? atoi(e) : 1; }();
   // (the MRR wave kernel is only instantiated usefully up to IPL = 4: hipcc spills the IPL >= 8 forms)
-  if (env_wave && L <= (kind == 0 ? 1024 : 256) && (L <= 256 || B >= 1024)) {
+  if (env_wave && L <= (kind == 0 ? 512 : 256) && (L <= 256 || B >= 1024)) {
     if (kind == 0) dispatch_metric_wave<0>(L, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, P, metric_out, stats_out, (hipStream_t)stream);
     else dispatch_metric_wave<1>(L, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, P, metric_out, stats_out, (hipStream_t)stream);
     return (int)hipGetLastError();
   }
   const int T = block_threads_for(P);
   const size_t lds = 128 + (size_t)P * (sizeof(uint64_t) + 4 * sizeof(float) + 1) + 16;
+  if (lds > 160 * 1024) return TFR_ETOOLARGE;     // list_size <= 4096 (25 B of LDS per item)
+  if (lds > 64 * 1024) {
+    hipError_t e = (kind == 0)
+        ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_metric_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+        : hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_metric_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
   if (kind == 0)
     hipLaunchKernelGGL(rank_metric_kernel<0>, dim3(B), dim3(T), lds, (hipStream_t)stream, labels,
                        predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P,
@@ -874,14 +1159,25 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == TFR_METRIC_DCG && !discount) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernels only (list_size <= 1024)
+  if (L > 4096) return TFR_ETOOLARGE;            // 32 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;
+  if (L > 512) {                                  // long lists: one workgroup per list, everything in LDS
+    const size_t lds = 128 + (size_t)P * 32;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_metric2_block_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(rank_metric2_block_kernel, dim3(B), dim3(block_threads_for(P)), lds, st, kind, labels, predictions,
+                       weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
+    return (int)hipGetLastError();
+  }
 #define M2(I) hipLaunchKernelGGL(rank_metric2_wave_kernel<I>, dim3(B), dim3(64), (size_t)2 * 64 * I * sizeof(float), st, kind, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out)
-  if (L <= 64) M2(1); else if (L <= 128) M2(2); else if (L <= 256) M2(4); else if (L <= 512) M2(8); else M2(16);
+  if (L <= 64) M2(1); else if (L <= 128) M2(2); else if (L <= 256) M2(4); else M2(8);
 #undef M2
   return (int)hipGetLastError();
 }
@@ -894,14 +1190,25 @@ extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* pr
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0 || S <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == TFR_DIV_ALPHA_DCG && !discount) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;
+  if (L > 4096) return TFR_ETOOLARGE;            // 28 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;
+  if (L > 512) {                                  // long lists: one workgroup per list
+    const size_t lds = 128 + (size_t)P * 28;
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&div_metric_block_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(div_metric_block_kernel, dim3(B), dim3(block_threads_for(P)), lds, st, kind, labels, predictions,
+                       weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out);
+    return (int)hipGetLastError();
+  }
 #define DM(I) hipLaunchKernelGGL(div_metric_wave_kernel<I>, dim3(B), dim3(64), 0, st, kind, labels, predictions, weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out)
-  if (L <= 64) DM(1); else if (L <= 128) DM(2); else if (L <= 256) DM(4); else if (L <= 512) DM(8); else DM(16);
+  if (L <= 64) DM(1); else if (L <= 128) DM(2); else if (L <= 256) DM(4); else DM(8);
 #undef DM
   return (int)hipGetLastError();
 }

@@ -92,7 +92,8 @@ def test_sort_reference_goldens():
 
 
 # ---------------------------------------------------------------------- metrics
-@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (1024, 700)])   # the last two: wave kernels, IPL 8 / 16
+# (1100, 300): wave kernel with 8 keys per lane; 512 < L <= 4096: the workgroup kernels (LDS bitonic sort)
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (1024, 700), (3, 3000), (2, 4096)])
 @pytest.mark.parametrize('weighted', [False, True])
 def test_ndcg_mrr_bit_exact(B, L, weighted):
     labels, preds = make_batch(B, L, seed=100 + L)
@@ -790,7 +791,7 @@ def test_more_metrics_reference_literals(case):
         assert_loss_close(w, torch.tensor(exp_w), 1e-6, cls + ' weights')
 
 
-@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300)])
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (5, 513), (3, 700), (2, 2500), (1, 4096)])   # > 512: workgroup kernel
 @pytest.mark.parametrize('weighted', [False, True])
 def test_more_metrics_bit_exact(B, L, weighted):
     labels, preds = make_batch(B, L, seed=1000 + L)
@@ -1147,7 +1148,8 @@ def test_circle_loss_reference_goldens():
 
 
 # ------------------------------------------------------------------ diversity metrics
-@pytest.mark.parametrize('B,L,S', [(1, 1, 1), (3, 2, 2), (5, 50, 3), (6, 65, 5), (4, 200, 4), (2, 1000, 2), (1030, 30, 3)])
+@pytest.mark.parametrize('B,L,S', [(1, 1, 1), (3, 2, 2), (5, 50, 3), (6, 65, 5), (4, 200, 4), (2, 1000, 2), (1030, 30, 3),
+                                   (3, 600, 3), (1, 3000, 2)])                  # > 512: workgroup kernel
 @pytest.mark.parametrize('weighted', [False, True])
 def test_diversity_metrics_parity(B, L, S, weighted):
     g = torch.Generator().manual_seed(1900 + L)
