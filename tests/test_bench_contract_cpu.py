@@ -29,11 +29,13 @@ def test_e2e_flops_are_six_times_the_macs():
 
 
 def test_committed_traffic_is_reported_for_the_profiled_shapes_only():
-    t = json.load(open(os.path.join(ROOT, 'profiles', 'r01_traffic.json')))
+    t = json.load(open(os.path.join(ROOT, bench.TRAFFIC_FILES[0])))             # the newest committed PMC passes
     got = bench.measured_traffic('approx_ndcg', 16384, 200)
     assert got == t['approx_ndcg']['traffic_bytes'] and got >= t['approx_ndcg']['algorithmic_bytes']
     assert got < 1.25 * t['approx_ndcg']['algorithmic_bytes']                         # no wasted re-reads
     assert bench.measured_traffic('approx_ndcg', 8192, 200) is None
+    pw = bench.measured_traffic('pairwise_lambda', 4096, 200)                         # the kernel north_star names
+    assert pw and t['pairwise_lambda']['algorithmic_bytes'] <= pw < 1.5 * t['pairwise_lambda']['algorithmic_bytes']
     assert bench.measured_traffic('no_such_workload', 1, 1) is None
 
 
