@@ -373,6 +373,11 @@ int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int
                          long ldw, int splits, const tfr_tower_dropout* dropout, void* stream);
 int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream);
 
+/* out[0] = sum_i x[i] * w[i] (w NULL: sum_i x[i]), n <= 65536, 16-byte aligned inputs: the scalar reduction of a per-list
+ * loss vector (compute_weighted_loss / the Keras reduction, losses_impl.py:787-814) in one launch with a fixed
+ * summation order. */
+int tfr_list_dot_f32(const float* x, const float* w, int n, float* out, void* stream);
+
 /* ---- groupwise multi-item scoring (model.py:164-244, 313-421; csrc/groupwise.hip) -------------------------------
  * Group indices of _form_group_indices_nd (model.py:205-244) for one shuffle: the valid items of every list in
  * organize_valid_indices order (utils.py:203-230: index order when `keys` is NULL, else by DESCENDING key, ties by

@@ -102,6 +102,7 @@ _SIGNATURES = {
                              + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    'tfr_list_dot_f32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 2),
     # groupwise scoring (groupwise.hip)
     'tfr_group_indices_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_group_gather_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]

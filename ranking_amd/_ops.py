@@ -448,6 +448,19 @@ def gumbel_sample_bwd(sampled, labels, mask, upstream, sample_size, gumbel_tempe
     return out
 
 
+def list_dot(x, w=None):
+    """sum(x * w) (or sum(x)) of a per-list vector as a 0-d tensor: one launch, fixed summation order
+    (tfr_list_dot_f32); vectors beyond 65536 entries use the library reduction."""
+    x = _f32(x, 'x').reshape(-1)
+    w = None if w is None else _f32(w, 'w').reshape(-1)
+    n = x.numel()
+    if n > 65536 or (x.data_ptr() & 15) or (w is not None and (w.data_ptr() & 15)):
+        return torch.dot(x, w) if w is not None else x.sum()
+    out = torch.empty((), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tfr_list_dot_f32(_ptr(x), _ptr(w), n, _ptr(out), _stream()), 'tfr_list_dot_f32')
+    return out
+
+
 def device_guarded(fn):
     """Runs ``fn`` with the HIP device of its first device-tensor argument current, so that ``_stream()`` and every
     allocation inside land on the device the tensors live on (a caller holding cuda:1 tensors while cuda:0 is current

@@ -272,6 +272,49 @@ __device__ __forceinline__ float wave_sum_u(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// LDS hand-off inside ONE wavefront (its lanes exchange data through the wave's private LDS
+// slice): DS operations of a wave complete in order, so draining the counter is enough.
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// 0-based rank (score descending, ties by lower compact index) of the n compact scores XS[0 .. n) of ONE wavefront's
+// list, into RKS[0 .. n).  XS is padded with -inf up to a multiple of 4 (+4).  Compact item p = lane + 64 q counts the
+// scores above its own: one v_cmp + half a carry-add per compare, the columns are float4 LDS broadcasts.  Items with
+// tied scores end up with the SAME count: an occupancy table (OCC, n ints of scratch) finds them -- rare -- and only
+// those add the equal scores in front of them.  (The previous form evaluated the full tie rule in every compare and
+// walked the 4 x 64 register layout: 6 VALU per compare over 4 passes, as much issue time as the pair sweep.)
+__device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
+  const float4* X4 = reinterpret_cast<const float4*>(XS);
+  const int n4 = (n + 3) >> 2;
+  for (int p = lane; p < n; p += 64) OCC[p] = 0;
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int p = q0 + lane;
+    const bool on = p < n;
+    const float xi = on ? XS[p] : INFINITY;
+    int cnt = 0;
+    for (int gq = 0; gq < n4; ++gq) {
+      const float4 xx = X4[gq];
+      cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
+      cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
+    }
+    if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
+  }
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int p = q0 + lane;
+    const bool tie = p < n && OCC[RKS[p]] > 1;
+    if (__ballot(tie)) {                                     // wave-uniform: some item of this pass shares its score
+      if (tie) {
+        const float xi = XS[p];
+        int cnt = RKS[p];
+        for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;
+        RKS[p] = cnt;                                        // (other lanes read OCC at their OWN first count only)
+      }
+    }
+  }
+  WAVE_LDS_SYNC();
+}
+
 // sum_p sorted_desc(g)[p] * table[p] for NON-NEGATIVE g (element e = lane + 64*r, zero beyond
 // L) without sorting: the sorted sequence is a few runs of equal values, so repeatedly take the
 // largest remaining value v, its multiplicity c, and add v * sum(table[pos .. pos + c)).  Graded

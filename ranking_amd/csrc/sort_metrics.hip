@@ -308,6 +308,165 @@ __global__ __launch_bounds__(64) void rank_metric_wave_kernel(
   }
 }
 
+// NDCG without the two 64-bit register sorts (the default for list_size <= 512): the DCG needs the RANK of every
+// item, not the sorted sequence -- a counting sweep over the compact predictions (wave_rank_by_count: one compare + half
+// a carry-add per pair, ties by index exactly like the sort keys) -- and the ideal DCG needs the weighted gains in
+// descending order, which for graded labels are a handful of runs of equal values (largest remaining value + its
+// multiplicity, <= kNdcgRuns rounds; more distinct values, e.g. per-item weights: ONE register sort for that half).
+// The terms are scattered to their sorted position in LDS and summed with the same tree_sum pairing as before, so the
+// result is bit-identical to rank_metric_wave_kernel<0> (and to the oracle).
+constexpr int kNdcgRuns = 8;
+
+template <int IPL>
+__global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
+    const float* __restrict__ labels, const float* __restrict__ predictions, const float* __restrict__ weights,
+    int weights_per_list, const uint8_t* __restrict__ mask, const float* __restrict__ gains,
+    const float* __restrict__ discount, TopN topn, int B, int L, int P, float* __restrict__ metric_out,
+    float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int N = 64 * IPL;
+  float* TERM = reinterpret_cast<float*>(smem_raw);        // [N] term by sorted position
+  float* XS = TERM + N;                                    // [N + 8] compact predictions (pad -inf)
+  int* RKS = reinterpret_cast<int*>(XS + N + 8);           // [N]
+  int* OCC = RKS + N;                                      // [N]
+  float* WG = reinterpret_cast<float*>(OCC + N);           // [N] w * gain by original index (sort fallback)
+  const int lane = threadIdx.x, b = blockIdx.x;
+  const size_t base = (size_t)b * L;
+  const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+
+  float w[IPL], g[IPL], wg[IPL], pr[IPL];
+  bool m[IPL];
+  int posr[IPL];
+  int n = 0;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    w[r] = 0.f; g[r] = 0.f; m[r] = false; pr[r] = 0.f;
+    if (i < L) {
+      const float lab = labels[base + i];
+      w[r] = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
+      const bool v0 = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      m[r] = v0 && (w[r] > 0.0f);
+      const float labc = m[r] ? lab : 0.0f;
+      g[r] = gain_pow2m1(labc);                              // (custom gains: rank_metric_wave_kernel<0>, a masked
+      pr[r] = predictions[base + i];                         //  item may then carry a non-zero gain_fn(0))
+    }
+    wg[r] = w[r] * g[r];
+    WG[i] = wg[r];
+    const unsigned long long bal = __ballot(m[r]);
+    posr[r] = n + __popcll(bal & ((1ull << lane) - 1ull));
+    if (m[r]) XS[posr[r]] = pr[r] + 0.0f;                  // -0 -> +0 like float_to_ordered: tied zeros compare equal
+    n += __popcll(bal);
+  }
+  {
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = w[r];
+    const float s_w = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = g[r];
+    const float s_g = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = wg[r];
+    const float s_wg = wave_tree_sum<IPL>(t, P);
+    if (lane == 0) {
+      stats_out[(size_t)b * 3 + 0] = s_w;
+      stats_out[(size_t)b * 3 + 1] = s_g;
+      stats_out[(size_t)b * 3 + 2] = s_wg;
+    }
+  }
+  const int n4 = (n + 3) >> 2;
+  for (int p = n + lane; p < n4 * 4 + 4 && p < N + 8; p += 64) XS[p] = -INFINITY;
+  for (int p = lane; p < N; p += 64) TERM[p] = 0.0f;
+  WAVE_LDS_SYNC();
+
+  // ---- DCG: rank of every metric-valid item among them (prediction descending, ties by index); the masked items
+  // follow in the sorted order and carry w * gain = 0: their terms are the zeros TERM starts from.
+  wave_rank_by_count(XS, n, lane, RKS, OCC);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    if (m[r]) { const int rk = RKS[posr[r]]; TERM[rk] = wg[r] * discount[rk]; }
+  }
+  WAVE_LDS_SYNC();
+  float term[IPL], dcg[TFR_MAX_TOPN];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) term[r] = TERM[lane + 64 * r];
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? term[r] : 0.0f;
+    dcg[q] = wave_tree_sum<IPL>(t, P);
+  }
+
+  // ---- ideal DCG: the weighted gains of the metric-valid items in descending order = runs of equal values
+  float rv[kNdcgRuns];
+  int rs[kNdcgRuns];
+  float rem[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) rem[r] = m[r] ? wg[r] : -INFINITY;
+  int nruns = 0, pos = 0;
+  bool complete = false;
+#pragma unroll
+  for (int it = 0; it < kNdcgRuns; ++it) {
+    float mx = rem[0];
+#pragma unroll
+    for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+    const float v = wave_max_u(mx);
+    rv[it] = v; rs[it] = pos;
+    if (!complete) {
+      if (v == -INFINITY) { complete = true; }
+      else {
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool hit = rem[r] == v;
+          c += __popcll(__ballot(hit));
+          rem[r] = hit ? -INFINITY : rem[r];
+        }
+        pos += c; nruns = it + 1;
+      }
+    }
+  }
+  if (!complete) {                                           // all kNdcgRuns rounds found a value: anything left?
+    float mx = rem[0];
+#pragma unroll
+    for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+    complete = wave_max_u(mx) == -INFINITY;
+  }
+  if (complete) {
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      float val = 0.0f;
+#pragma unroll
+      for (int it = 0; it < kNdcgRuns; ++it) val = (it < nruns && p >= rs[it]) ? rv[it] : val;   // rs ascends
+      term[r] = (p < pos) ? val * discount[p] : 0.0f;        // beyond the metric-valid items: w * gain(0) = 0
+    }
+  } else {
+    uint64_t key[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int i = lane + 64 * r;
+      key[r] = (i < L) ? make_sort_key(m[r], wg[r], 0, i) : 0ull;
+    }
+    wave_bitonic_sort_desc<uint64_t, IPL>(key, lane);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int p = lane + 64 * r;
+      term[r] = (p < L) ? WG[sort_key_index(key[r])] * discount[p] : 0.0f;
+    }
+  }
+  for (int q = 0; q < topn.n; ++q) {
+    const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
+    float t[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? term[r] : 0.0f;
+    const float idcg = wave_tree_sum<IPL>(t, P);
+    if (lane == 0) metric_out[(size_t)q * B + b] = (idcg != 0.0f) ? (dcg[q] / idcg) : 0.0f;   // divide_no_nan
+  }
+}
+
 // The other sort-based metrics of metrics_impl.py on the same wave-per-list machinery
 // (kind is wave-uniform at run time):
 //   TFR_METRIC_DCG       :673-705  sum_{p<k} w gain disc(p)   (divided by the list weight by the caller)
@@ -922,6 +1081,13 @@ template <int KIND, int IPL>
 void launch_metric_wave(const float* labels, const float* predictions, const float* weights, int weights_per_list,
                         const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
                         int L, int P, float* metric_out, float* stats_out, hipStream_t st) {
+  static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
+  if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
+    constexpr size_t lds = (size_t)64 * IPL * 5 * sizeof(float) + 8 * sizeof(float);
+    hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL>), dim3(B), dim3(64), lds, st, labels, predictions, weights,
+                       weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
+    return;
+  }
   hipLaunchKernelGGL((rank_metric_wave_kernel<KIND, IPL>), dim3(B), dim3(64), (size_t)64 * IPL * sizeof(float), st,
                      labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P,
                      metric_out, stats_out);

@@ -340,7 +340,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
         _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
             want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind, **lam)
-        return list_loss.sum(), dlogits                    # [B] per-list sums: nothing [B, L]-sized for the loss
+        return _ops.list_dot(list_loss), dlogits           # [B] per-list sums: nothing [B, L]-sized for the loss
 
 
 @utils.register_keras_serializable()
@@ -436,7 +436,7 @@ class SoftmaxLoss(_ListwiseLoss):
         loss, weight, dlogits = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
                                                   temperature=self._temperature, want_grad=True,
                                                   poly_epsilon=self._loss._poly_epsilon, **lam)
-        return torch.dot(loss, weight), dlogits
+        return _ops.list_dot(loss, weight), dlogits
 
 
 @utils.register_keras_serializable()
@@ -510,7 +510,7 @@ class ApproxNDCGLoss(_ListwiseLoss):
         loss, weight, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
                                                  self._temperature, 0, True)
         # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`
-        return torch.dot(loss, list_scale), dlogits
+        return _ops.list_dot(loss, list_scale), dlogits
 
 
 @utils.register_keras_serializable()
@@ -535,7 +535,7 @@ class UniqueSoftmaxLoss(ApproxNDCGLoss):
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
-        return torch.dot(loss, list_scale), dlogits
+        return _ops.list_dot(loss, list_scale), dlogits
 
 
 @utils.register_keras_serializable()
@@ -560,7 +560,7 @@ class ListMLELoss(ApproxNDCGLoss):
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         pw = self._loss._pos_weight(y_pred.shape[1], y_pred.device)
         loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
-        return torch.dot(loss, list_scale), dlogits
+        return _ops.list_dot(loss, list_scale), dlogits
 
 
 @utils.register_keras_serializable()
@@ -691,7 +691,7 @@ class _PointwiseLoss(_RankingLoss):
         list_w = _const_vector(b, scale, y_pred.device) if list_w is None else list_w * scale
         loss, _, _, dlogits = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w, list_w,
                                                   self._loss._temperature, True)
-        return loss.sum(), dlogits
+        return _ops.list_dot(loss), dlogits
 
 
 @utils.register_keras_serializable()

@@ -1674,3 +1674,20 @@ def test_headline_batch_in_the_bench_configuration_against_the_fp64_c_arbiter():
         assert abs(value.item() - want_value) <= 1e-5 * max(1.0, abs(want_value)), (name, value.item(), want_value)
         assert_grad_close(dlogits, want_grad, 5e-5, what='%s full-batch gradient vs C fp64' % name)
         assert bool((dlogits[lb < 0] == 0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n', [1, 3, 4, 5, 1023, 1024, 4097, 16384, 65536, 70000])
+def test_list_dot_is_the_weighted_sum(n):
+    """tfr_list_dot_f32 (the scalar reduction of loss_and_grad): equal to the fp64 sum within fp32 rounding, identical
+    from run to run, and a plain sum without weights; longer vectors fall back to the library reduction."""
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g); w = torch.rand(n, generator=g)
+    a = ra()._ops.list_dot(x.to(DEV), w.to(DEV))
+    b = ra()._ops.list_dot(x.to(DEV), w.to(DEV))
+    want = float((x.double() * w.double()).sum())
+    scale = float((x.double() * w.double()).abs().sum()) + 1e-30
+    assert a.shape == () and torch.equal(a, b)
+    assert abs(a.item() - want) <= 1e-6 * scale
+    s = ra()._ops.list_dot(x.to(DEV))
+    assert abs(s.item() - float(x.double().sum())) <= 1e-6 * float(x.double().abs().sum())
