@@ -699,10 +699,14 @@ __host__ __device__ inline size_t pw_lean_wave_lds(int Lp, bool itemw) {
 template <int IPL, bool AUX, bool ITEMW>
 __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  // blockDim.x = 64 * S: S wavefronts COOPERATE on one list through ONE shared LDS image when the batch alone cannot
+  // fill the chip (B < 8192): the loads, the grade order and the ideal DCG are cheap and repeated per wave in
+  // registers; the rank count and the two pair sweeps -- 85 % of the work -- are split.  S == 1: no workgroup barrier.
   const int wave = threadIdx.x >> 6, S = blockDim.x >> 6;
   const int Lp = a.Lp;
-  unsigned char* smem_raw = smem_all + (size_t)wave * pw_lean_wave_lds(Lp, ITEMW);
-  float* nz_slot = reinterpret_cast<float*>(smem_all + (size_t)S * pw_lean_wave_lds(Lp, ITEMW));   // [S]
+  unsigned char* smem_raw = smem_all;
+  float* nz_slot = reinterpret_cast<float*>(smem_all + pw_lean_wave_lds(Lp, ITEMW));   // [2 S]
+#define LIST_SYNC() do { if (S > 1) __syncthreads(); else WAVE_LDS_SYNC(); } while (0)
   float4* rec = reinterpret_cast<float4*>(smem_raw);          // [Lp] grade order: (B, A, gain, 4 * rank as bits)
   float* U = reinterpret_cast<float*>(rec + Lp);              // [Lp] |D(m) - D(m+1)| * list_size
   float* XS = U + Lp;                                         // [Lp] compact x (rank count) / x in grade order (slow path)
@@ -736,7 +740,7 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
         g[r] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(lab) : lab;
         w = ITEMW ? a.item_weights[base + e] * lw : lw;
         xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
-      } else {
+      } else if (wave == 0) {
         if (a.row_loss) a.row_loss[base + e] = 0.f;
         if (AUX && a.row_weight) a.row_weight[base + e] = 0.f;
         if (a.dlogits) a.dlogits[base + e] = 0.f;
@@ -745,19 +749,22 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
     const unsigned long long bal = __ballot(lv[r]);
     xr[r] = x; labr[r] = lv[r] ? lab : -1.0f; wr[r] = w;
     posr[r] = n + __popcll(bal & ((1ull << lane) - 1ull));
-    if (lv[r]) XS[posr[r]] = x;
+    if (lv[r] && wave == 0) XS[posr[r]] = x;
     n += __popcll(bal);
   }
   xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
   const bool fast = (xmax - xmin) <= kLeanRange;             // wave-uniform
   const float m = 0.5f * (xmax + xmin);
-  for (int q = lane; q < Lp; q += 64) {
+  for (int q = threadIdx.x; q < Lp; q += 64 * S) {
     const float um = (q >= 1 && q < L) ? fabsf(a.discount[q - 1] - a.discount[q]) : 0.0f;
     U[q] = um * (float)L;                                    // the final x list_size (:278) folded in
   }
   const int n4 = (n + 3) >> 2;
-  for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
-  WAVE_LDS_SYNC();
+  if (wave == 0) for (int p = n + lane; p < n4 * 4 + 4 && p < Lp; p += 64) XS[p] = -INFINITY;
+  int* const RKS = CIS;                                      // scratch: count by compact position (CIS is filled in step 5)
+  int* const OCC = SEG;                                      // scratch: how many items share a count (SEG: step 5)
+  for (int p = threadIdx.x; p < n; p += 64 * S) OCC[p] = 0;
+  LIST_SYNC();
 
   PW_STAMP(1);
   // ---- 2. ranks by counting (score descending, ties by index) (:483-500).  Compact item p = lane + 64 q
@@ -766,12 +773,37 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   // only those add their earlier equals.
   int rk[IPL];
   {
-    int* RKS = CIS;                                          // scratch: count by compact position (CIS is filled in step 5)
-    int* OCC = SEG;                                          // scratch: how many items share a count (SEG: step 5)
-    wave_rank_by_count(XS, n, lane, RKS, OCC);
+    // (wave_rank_by_count of common.h with its passes dealt to the S waves)
+    const float4* X4 = reinterpret_cast<const float4*>(XS);
+    for (int q0 = 64 * wave; q0 < n; q0 += 64 * S) {
+      const int p = q0 + lane;
+      const bool on = p < n;
+      const float xi = on ? XS[p] : INFINITY;
+      int cnt = 0;
+      for (int gq = 0; gq < n4; ++gq) {
+        const float4 xx = X4[gq];
+        cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
+        cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
+      }
+      if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
+    }
+    LIST_SYNC();
+    for (int q0 = 64 * wave; q0 < n; q0 += 64 * S) {
+      const int p = q0 + lane;
+      const bool tie = p < n && OCC[RKS[p]] > 1;
+      if (__ballot(tie)) {                                   // wave-uniform: some item of this pass shares its score
+        if (tie) {
+          const float xi = XS[p];
+          int cnt = RKS[p];
+          for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;
+          RKS[p] = cnt;                                      // (others read OCC at their OWN first count only)
+        }
+      }
+    }
+    LIST_SYNC();
 #pragma unroll
     for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
-    WAVE_LDS_SYNC();                                         // RKS (= CIS) and OCC (= SEG) are rewritten below
+    LIST_SYNC();                                             // RKS (= CIS) and OCC (= SEG) are rewritten below
   }
 
   PW_STAMP(2);
@@ -832,12 +864,11 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
     idcg = wave_sum_u(idcg);
     inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
   }
-  WAVE_LDS_SYNC();                                           // every lane is done reading XS (rank count)
 
   // ---- 5. records in grade order.
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
-    if (!lv[r]) continue;
+    if (!lv[r] || (r % S) != wave) continue;                  // register r's records are written by wave r mod S
     const float xv = xr[r];
     float Bv, Av;
     if (fast) {
@@ -856,11 +887,11 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   }
   const int C = a.C;
   const int npad = ((n + 2 * C - 1) / (2 * C)) * (2 * C);    // two columns per trip per lane
-  for (int p = n + lane; p < npad && p < Lp; p += 64) {      // neutral padding: B = A = 0 -> w1 = 1; gain decides
+  for (int p = n + threadIdx.x; p < npad && p < Lp; p += 64 * S) {      // neutral padding: B = A = 0 -> w1 = 1; gain decides
     rec[p] = make_float4(0.f, 0.f, kBigGain, __int_as_float(0));
     if (ITEMW) WS[p] = 0.f;
   }
-  WAVE_LDS_SYNC();
+  LIST_SYNC();
 
   PW_STAMP(3);
   // ---- 6. pair sweeps: row = C adjacent lanes, 64 / C rows per pass, two columns per trip.
@@ -975,6 +1006,7 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
   }
 #endif
   pw_finish<AUX>(a, b, lane, wave, S, nnz_local, list_local, nz_slot);
+#undef LIST_SYNC
 }
 
 int env_int(const char* name, int dflt);
@@ -999,11 +1031,12 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
     // LambdaRank fast path (grade-segmented, factorised exponential); S waves per list when the batch is small
     const bool iw = a.item_weights != nullptr;
     static const int env_ls = env_int("TFR_PAIRWISE_LEAN_WAVES", 0);
-    int Sl = env_ls > 0 ? env_ls : 1;     // (more waves per list measured slower at B = 4096 and 16384)
+    // waves per list: 1 when the batch alone gives every SIMD its 8 list-waves; else 2 / 4 cooperate (shared LDS image)
+    int Sl = env_ls > 0 ? env_ls : (B >= 8192 ? 1 : (B >= 2048 ? 2 : 4));
     if (a.L <= 64) Sl = 1;
     if (Sl > 4) Sl = 4;
-    while (Sl > 1 && (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 32 > 60 * 1024) Sl >>= 1;
-    const size_t ll = (size_t)Sl * pw_lean_wave_lds(a.Lp, iw) + 32;
+    if (Sl == 3) Sl = 2;
+    const size_t ll = pw_lean_wave_lds(a.Lp, iw) + 32;
     if (ll <= 64 * 1024) {
 #define PW_LEAN(AUX, IW) hipLaunchKernelGGL((pairwise_lean_kernel<IPL, AUX, IW>), dim3(B), dim3(64 * Sl), ll, stream, a)
       if (aux) { if (iw) PW_LEAN(true, true); else PW_LEAN(true, false); }

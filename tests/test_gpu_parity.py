@@ -1605,15 +1605,17 @@ def test_lambdarank_fast_path_ties_in_scores():
 def test_lambdarank_fast_path_env_switch_matches_general_kernel():
     """The fast path and the general pair kernel agree (same inputs, TFR_PAIRWISE_LEAN read once per process: the
     general kernel is reached here through a configuration the fast path does not take -- an explicit mask)."""
-    B, L = 16, 200
-    labels, logits = make_batch(B, L, seed=4)
     K = ra().keras.losses
-    loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
-    a = loss._fused(labels.to(DEV), logits.to(DEV), None, None)
-    b = loss._fused(labels.to(DEV), logits.to(DEV), None, (labels >= 0).to(DEV))          # mask given: general kernel
-    scale = max(1.0, b[1].abs().max().item())
-    assert_loss_close(a[1] / scale, b[1] / scale, 2e-6, what='lean vs general rows')
-    assert torch.equal(a[3], b[3])
+    # waves per list of the fast path: 4 cooperate below 2048 lists, 2 below 8192, one wave per list from there on
+    for B, L in ((16, 200), (2100, 130), (8200, 130)):
+        labels, logits = make_batch(B, L, seed=4)
+        loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
+        a = loss._fused(labels.to(DEV), logits.to(DEV), None, None)
+        b = loss._fused(labels.to(DEV), logits.to(DEV), None, (labels >= 0).to(DEV))      # mask given: general kernel
+        scale = max(1.0, b[1].abs().max().item())
+        assert_loss_close(a[1] / scale, b[1] / scale, 2e-6, what='lean vs general rows B=%d' % B)
+        assert torch.equal(a[3], b[3])
+        a[0].sum().backward() if a[0].requires_grad else None
 
 
 @pytest.mark.parametrize('L,masked,kind', [(200, False, 0), (200, True, 0), (60, False, 1), (300, False, 0), (300, True, 2)])
