@@ -273,6 +273,18 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     for gen in graph_generators:                            # philox offsets advance per replay, like eager calls
         g_fb.register_generator_state(gen)
     one = torch.ones((), device=dev)
+    if world <= 1:
+        # one replica: no collective between backward and the optimizer -> the whole step is ONE graph
+        with torch.cuda.graph(g_fb):
+            static_value = fwd_bwd()
+            static_scalars = torch.stack([static_value, one])
+            sgd()
+
+        def graph_step():
+            g_fb.replay()
+            return static_scalars[0]
+        info.update(step=graph_step, all_reduce=lambda: None)
+        return info
     with torch.cuda.graph(g_fb):
         static_value = fwd_bwd()
         static_scalars = torch.stack([static_value, one])

@@ -345,6 +345,11 @@ int tfr_tower_bn_bwd_coeffs(const float* gamma, const float* rstd, const float* 
 /* out[i] = sum_t partial[t][i], i < W.  scratch: [scratch_rows(T)][W] or NULL. */
 int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, float* scratch,
                               void* stream);
+/* The same for partial[T][J][N] (J stacked rows) and, when gamma is given, the coefficients of tfr_tower_bn_bwd_coeffs
+ * from rows 0 / 1 of the result in the same launch (one launch for T <= 1024, J <= 6; else the two entry points in turn). */
+int tfr_tower_reduce_partials_coeffs(const float* partial, int T, int J, int N, float* out, float* scratch,
+                                     const float* gamma, const float* rstd, const float* mean, long M,
+                                     float* pqr, void* stream);
 /* Output Dense(output_units <= 4): out[M, O] = prologue(z)[M, K] . w[O, K]^T + b (fp32). */
 int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                       const float* shift, const float* w, const float* b, int O, float* out,

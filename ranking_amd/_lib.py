@@ -85,6 +85,8 @@ _SIGNATURES = {
     'tfr_tower_bn_finalize': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_long]
                               + [ctypes.c_void_p] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 8),
     'tfr_tower_reduce_partials': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
+    'tfr_tower_reduce_partials_coeffs': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+                                         + [ctypes.c_long] + [ctypes.c_void_p] * 2),
     'tfr_tower_out_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                           + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
     'tfr_tower_out_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3

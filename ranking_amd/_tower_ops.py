@@ -177,7 +177,7 @@ def bn_finalize(partial, M, gamma, beta, eps, momentum, moving_mean, moving_var)
     dev = partial.device
     scale = torch.empty(N, dtype=torch.float32, device=dev)
     shift = torch.empty_like(scale); mean = torch.empty_like(scale); rstd = torch.empty_like(scale)
-    scratch = _scratch(T, 2 * N, dev)
+    scratch = None if T <= _FUSED_ROWS else _scratch(T, 2 * N, dev)
     _lib.check(_lib.load().tfr_tower_bn_finalize(_ptr(partial), T, N, M, _ptr(gamma), _ptr(beta), eps, momentum,
                                                  _ptr(moving_mean), _ptr(moving_var), _ptr(scale), _ptr(shift),
                                                  _ptr(mean), _ptr(rstd), _ptr(scratch), _stream()),
@@ -185,14 +185,28 @@ def bn_finalize(partial, M, gamma, beta, eps, momentum, moving_mean, moving_var)
     return scale, shift, mean, rstd
 
 
-def reduce_partials(partial):
-    """[T, J, N] per-workgroup column partials -> [J, N] sums."""
+_FUSED_ROWS = 1024          # tfr_tower_reduce_partials_coeffs / tfr_tower_bn_finalize: one launch up to this many rows
+
+
+def reduce_partials(partial, bn=None):
+    """[T, J, N] per-workgroup column partials -> [J, N] sums.  ``bn = (gamma, rstd, mean, M)``: also the
+    BatchNorm-backward coefficients pqr [3, N] of the layer whose (sum dy, sum dy zhat) are rows 0 / 1, from the same
+    launch; returns (sums, pqr) then."""
     T, J, N = partial.shape
     out = torch.empty((J, N), dtype=torch.float32, device=partial.device)
-    scratch = _scratch(T, J * N, partial.device)
-    _lib.check(_lib.load().tfr_tower_reduce_partials(_ptr(partial), T, J * N, _ptr(out), _ptr(scratch), _stream()),
-               'tfr_tower_reduce_partials')
-    return out
+    fused = T <= _FUSED_ROWS and J <= 6
+    scratch = None if fused else _scratch(T, J * N, partial.device)
+    if bn is None:
+        _lib.check(_lib.load().tfr_tower_reduce_partials_coeffs(_ptr(partial), T, J, N, _ptr(out), _ptr(scratch), None,
+                                                               None, None, 0, None, _stream()),
+                   'tfr_tower_reduce_partials_coeffs')
+        return out
+    gamma, rstd, mean, M = bn
+    pqr = torch.empty((3, N), dtype=torch.float32, device=partial.device)
+    _lib.check(_lib.load().tfr_tower_reduce_partials_coeffs(_ptr(partial), T, J, N, _ptr(out), _ptr(scratch),
+                                                           _ptr(gamma.detach()), _ptr(rstd), _ptr(mean), M, _ptr(pqr),
+                                                           _stream()), 'tfr_tower_reduce_partials_coeffs')
+    return out, pqr
 
 
 def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
@@ -211,9 +225,10 @@ def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
 _OUT_BWD_ROWS = int(os.environ.get('TFR_OUT_BWD_ROWS', '128'))   # rows per workgroup below which fewer blocks are launched
 
 
-def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=1024, dropout=None):
+def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=1024, dropout=None, bn=None):
     """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
-    sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]."""
+    sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]; with ``bn = (gamma, rstd, mean, M)`` of the
+    last hidden layer a third value: its BatchNorm-backward coefficients pqr (same launch as the sums)."""
     _bf16(z, 'z')
     M = z.shape[0]
     w = w.detach().to(torch.float32).contiguous()
@@ -226,7 +241,10 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
                                              _ptr(mean), _ptr(rstd), _ptr(w), _ptr(dlogits), O, _ptr(dy),
                                              dy.stride(0), _ptr(partial), n_blocks, _dp(dropout), _stream()),
                'tfr_tower_out_bwd')
-    return dy, reduce_partials(partial)
+    if bn is None:
+        return dy, reduce_partials(partial)
+    sums, pqr = reduce_partials(partial, bn)
+    return dy, sums, pqr
 
 
 def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits, n_blocks=1024, dropout=None):
@@ -245,8 +263,7 @@ def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits
     _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
                                       _ptr(rstd), _ptr(w), _ptr(dlogits), O, None, K, _ptr(partial), n_blocks,
                                       _dp(dropout), None, _stream()), 'tfr_tower_out_bwd2')
-    sums = reduce_partials(partial)
-    pqr = bn_bwd_coeffs(gamma, rstd, mean, sums[:2], M)
+    sums, pqr = reduce_partials(partial, (gamma, rstd, mean, M))
     dz = torch.empty((M, K), dtype=torch.bfloat16, device=z.device)
     n2 = max(1, min(4096, (M + 15) // 16))
     _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),

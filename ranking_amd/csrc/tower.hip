@@ -792,6 +792,106 @@ __global__ void tower_reduce_partials_kernel(const float* __restrict__ partial, 
   out[i] = (float)s;
 }
 
+// Short partial matrices (T <= kFusedRows rows: the launch-bound steps, M = 25600 in BASELINE config 5) finish in ONE
+// launch instead of reduce_rows + the finishing kernel: a workgroup owns 64 columns, its 4 waves take the 64-row chunks
+// round-robin and reduce each exactly like tower_reduce_rows_kernel (same fp32 association), the chunk sums meet in
+// LDS and wave 0 adds them in chunk order in fp64 like the finishing kernels -- bit-identical to the two-launch path.
+constexpr int kFusedRows = 1024;                              // <= 16 chunks of 64 rows
+__device__ __forceinline__ float chunk_column_sum(const float* __restrict__ partial, long W, long col, int t0, int t1) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int t = t0;
+  for (; t + 15 < t1; t += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = partial[(long)(t + u) * W + col];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
+  }
+  for (; t + 3 < t1; t += 4) {
+    s0 += partial[(long)t * W + col];       s1 += partial[(long)(t + 1) * W + col];
+    s2 += partial[(long)(t + 2) * W + col]; s3 += partial[(long)(t + 3) * W + col];
+  }
+  for (; t < t1; ++t) s0 += partial[(long)t * W + col];
+  return (s0 + s1) + (s2 + s3);
+}
+
+// sums[j][lane] (double) of columns n = blockIdx.x * 64 + lane of the J stacked [N]-wide rows of partial [T][J][N];
+// valid in wave 0 after the call.  T <= 64: the finishing kernels' plain row walk.
+template <int JMAX>
+__device__ __forceinline__ void fused_column_sums(const float* __restrict__ partial, int T, int J, int N, int n,
+                                                  float (*chunk)[JMAX][64], double (&sums)[JMAX]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long W = (long)J * N;
+  const bool live = n < N;
+  if (T <= kReduceChunk) {
+    if (wave == 0) {
+      for (int j = 0; j < J; ++j) {
+        double s = 0.0;
+        if (live) for (int t = 0; t < T; ++t) s += (double)partial[(long)t * W + (long)j * N + n];
+        sums[j] = s;
+      }
+    }
+    return;
+  }
+  const int nchunks = (T + kReduceChunk - 1) / kReduceChunk;
+  for (int c = wave; c < nchunks; c += 4) {
+    const int t0 = c * kReduceChunk, t1 = (t0 + kReduceChunk < T) ? t0 + kReduceChunk : T;
+    for (int j = 0; j < J; ++j) chunk[c][j][lane] = live ? chunk_column_sum(partial, W, (long)j * N + n, t0, t1) : 0.f;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    for (int j = 0; j < J; ++j) {
+      double s = 0.0;
+      for (int c = 0; c < nchunks; ++c) s += (double)chunk[c][j][lane];
+      sums[j] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tower_bn_finalize_fused_kernel(
+    const float* __restrict__ partial, int T, int N, long M, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ moving_mean,
+    float* __restrict__ moving_var, float* __restrict__ scale, float* __restrict__ shift,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ float chunk[kFusedRows / kReduceChunk][2][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  double sums[2];
+  fused_column_sums<2>(partial, T, 2, N, n, chunk, sums);
+  if ((threadIdx.x >> 6) != 0 || n >= N) return;
+  const double mean = sums[0] / (double)M;
+  double var = sums[1] / (double)M - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float ga = gamma ? gamma[n] : 1.f, be = beta ? beta[n] : 0.f;
+  const float sc = ga * rstd;
+  scale[n] = sc;
+  shift[n] = be - (float)mean * sc;
+  mean_out[n] = (float)mean;
+  rstd_out[n] = rstd;
+  if (moving_mean) moving_mean[n] = moving_mean[n] * momentum + (float)mean * (1.f - momentum);
+  if (moving_var) moving_var[n] = moving_var[n] * momentum + (float)var * (1.f - momentum);
+}
+
+// out[j][n] = sum_t partial[t][j][n] for the J <= 6 stacked rows, and -- when gamma is given -- the BatchNorm-backward
+// coefficients pqr[3][N] of tower_bn_bwd_coeffs_kernel from rows 0 / 1 (sum dy, sum dy * zhat) in the same launch.
+__global__ __launch_bounds__(256) void tower_reduce_partials_fused_kernel(
+    const float* __restrict__ partial, int T, int J, int N, float* __restrict__ out, const float* __restrict__ gamma,
+    const float* __restrict__ rstd, const float* __restrict__ mean, float inv_m, float* __restrict__ pqr) {
+  __shared__ float chunk[kFusedRows / kReduceChunk][6][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  double sums[6];
+  fused_column_sums<6>(partial, T, J, N, n, chunk, sums);
+  if ((threadIdx.x >> 6) != 0 || n >= N) return;
+  for (int j = 0; j < J; ++j) out[(long)j * N + n] = (float)sums[j];
+  if (gamma) {
+    const float s = gamma[n] * rstd[n];
+    const float c1 = (float)sums[0], c2 = (float)sums[1];
+    pqr[n] = s;
+    pqr[N + n] = -s * rstd[n] * c2 * inv_m;
+    pqr[2 * N + n] = s * (rstd[n] * c2 * mean[n] - c1) * inv_m;
+  }
+}
+
 // Output layer: logits[m, o] = sum_k act(z[m, k]) * w[o, k] + b[o], O <= 4 (GEMV class:
 // one read of z).  A row is owned by 16 lanes, 8 bf16 (16 B) per lane per trip; the
 // per-column coefficients live in LDS as [K/8][(2 + O)][8] floats (one float4 pair each).
@@ -1376,6 +1476,11 @@ extern "C" int tfr_tower_bn_finalize(const float* partial, int T, int N, long M,
                                      float* rstd_out, float* scratch, void* stream) {
   if (!partial || T <= 0 || N <= 0 || M <= 0 || !scale || !shift || !mean_out || !rstd_out) return TFR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (T <= kFusedRows) {                       // short partial matrix: one launch (same arithmetic, same order)
+    hipLaunchKernelGGL(tower_bn_finalize_fused_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, T, N, M, gamma,
+                       beta, eps, momentum, moving_mean, moving_var, scale, shift, mean_out, rstd_out);
+    return (int)hipGetLastError();
+  }
   const float* src = partial;
   int rows = T;
   if (T > kReduceChunk && scratch) {          // stage 1: [T][2N] -> [ceil(T/64)][2N]
@@ -1499,6 +1604,22 @@ extern "C" int tfr_tower_slab_reduce(const float* slab, int S, long n, float* ou
   hipLaunchKernelGGL(tower_slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, S,
                      n, out, accumulate);
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_reduce_partials_coeffs(const float* partial, int T, int J, int N, float* out, float* scratch,
+                                                const float* gamma, const float* rstd, const float* mean, long M,
+                                                float* pqr, void* stream) {
+  if (!partial || T <= 0 || J <= 0 || N <= 0 || !out) return TFR_EINVAL;
+  if (gamma && (!rstd || !mean || !pqr || M <= 0 || J < 2)) return TFR_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (T <= kFusedRows && J <= 6) {
+    hipLaunchKernelGGL(tower_reduce_partials_fused_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, T, J, N, out,
+                       gamma, rstd, mean, gamma ? 1.0f / (float)M : 0.0f, pqr);
+    return (int)hipGetLastError();
+  }
+  const int rc = tfr_tower_reduce_partials(partial, T, J * N, out, scratch, stream);
+  if (rc != TFR_OK || !gamma) return rc;
+  return tfr_tower_bn_bwd_coeffs(gamma, rstd, mean, out, N, M, pqr, stream);
 }
 
 extern "C" int tfr_tower_bn_bwd_coeffs(const float* gamma, const float* rstd, const float* mean, const float* c,

@@ -132,12 +132,13 @@ class FlatGradBucket:
     def all_reduce(self, scalars: Optional[torch.Tensor] = None, average: bool = False) -> torch.Tensor:
         """Sums gradients (and the appended scalars) over ranks with one collective;
         returns the globally summed scalars.  ``average`` divides gradients by W."""
+        _, w = world()
+        if w <= 1:                                   # a single replica: nothing to exchange, nothing to launch
+            return self.scalars.clone() if scalars is None else scalars.reshape(-1)
         if scalars is not None:
             self.scalars.copy_(scalars.reshape(-1))
-        _, w = world()
-        if w > 1:
-            dist.all_reduce(self.flat, group=self.group)
-        if average and w > 1:
+        dist.all_reduce(self.flat, group=self.group)
+        if average:
             self.flat[:self.numel].div_(w)
         return self.scalars.clone()
 

@@ -136,9 +136,13 @@ class _TowerFn(torch.autograd.Function):
         # two passes over z pay once the [M, K] gradient is HBM-sized; below that the extra launch costs more
         fused_last = (use_bn and n_h > 0 and M * n_last >= _FUSED_LAST_MIN_ELEMS
                       and not os.environ.get('TFR_TOWER_NO_FUSED_LAST'))
+        pqr = None                                         # BatchNorm-backward coefficients of the layer at hand
         if fused_last:                                     # dz of the last hidden layer directly (two passes over z)
             dy, sums = T.out_layer_bwd_bn(zs[-1], n_last, pro, sc, sh, mean, rstd, gammas[-1], w_out, dlogits,
                                           dropout=drop)
+        elif use_bn:                                       # (sum dy, sum dy zhat) and the coefficients in one launch
+            dy, sums, pqr = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop,
+                                            bn=(gammas[-1], rstd, mean, M))
         else:
             dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
         dw_out = sums[2:].contiguous()
@@ -150,8 +154,7 @@ class _TowerFn(torch.autograd.Function):
             pro_l, sc_l, sh_l, mean_l, rstd_l, _ = coefs[l]
             if use_bn:
                 dgam[l], dbet[l] = cc[1], cc[0]
-                dz = dy if (fused_last and l == n_h - 1) else \
-                    T.bn_bwd_apply_(dy, zs[l], n_out, T.bn_bwd_coeffs(gammas[l], rstd_l, mean_l, cc[:2], M))
+                dz = dy if (fused_last and l == n_h - 1) else T.bn_bwd_apply_(dy, zs[l], n_out, pqr)
                 db[l] = db_zero[l]                         # a bias below BatchNorm has no gradient
             else:
                 dz = dy
@@ -178,7 +181,10 @@ class _TowerFn(torch.autograd.Function):
                 dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD,
                                      Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd,
                                      epi_dropout=drop_p)
-                cc = T.reduce_partials(partial)
+                if use_bn:                                 # the column sums of layer l - 1 and its coefficients together
+                    cc, pqr = T.reduce_partials(partial, (gammas[l - 1], rstd_p, mean_p, M))
+                else:
+                    cc = T.reduce_partials(partial)
         grads = list(dW) + list(db)
         if use_bn:
             grads += list(dgam) + list(dbet)
