@@ -644,6 +644,11 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
             roof['note'] = 'O(L) / sort kernel: HBM-bound by design; the batch (%.1f MB) fits the 256 MB Infinity ' \
                            'Cache under graph replay, so achieved GB/s is a cache-resident rate' % (algo_bytes / 1e6)
         result['roofline'] = roof
+    if name == 'ndcg_metric':
+        result['parity'] = ('NDCG@k is bit-equal to the CPU oracle BY CO-DESIGN: kernel and oracle share the fp32 summation '
+                            'order (tree_sum), the host-computed discount table and exact 2^l gains; the independent fp64 '
+                            'plain-C arbiter (oracle/pairwise_softmax_c.c) agrees to 5e-6 and the reference literals to 1e-6 '
+                            '(tests/test_gpu_parity.py)')
     if is_e2e:
         tflops = e2e_flops_per_list(name, L) * B / (ms_per_step * 1e-3) / 1e12
         result['roofline'] = {

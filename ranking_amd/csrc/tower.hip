@@ -793,70 +793,58 @@ __global__ void tower_reduce_partials_kernel(const float* __restrict__ partial, 
 }
 
 // Short partial matrices (T <= kFusedRows rows: the launch-bound steps, M = 25600 in BASELINE config 5) finish in ONE
-// launch instead of reduce_rows + the finishing kernel: a workgroup owns 64 columns, its 4 waves take the 64-row chunks
-// round-robin and reduce each exactly like tower_reduce_rows_kernel (same fp32 association), the chunk sums meet in
-// LDS and wave 0 adds them in chunk order in fp64 like the finishing kernels -- bit-identical to the two-launch path.
-constexpr int kFusedRows = 1024;                              // <= 16 chunks of 64 rows
-__device__ __forceinline__ float chunk_column_sum(const float* __restrict__ partial, long W, long col, int t0, int t1) {
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int t = t0;
-  for (; t + 15 < t1; t += 16) {
-    float v[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = partial[(long)(t + u) * W + col];
-#pragma unroll
-    for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
-  }
-  for (; t + 3 < t1; t += 4) {
-    s0 += partial[(long)t * W + col];       s1 += partial[(long)(t + 1) * W + col];
-    s2 += partial[(long)(t + 2) * W + col]; s3 += partial[(long)(t + 3) * W + col];
-  }
-  for (; t < t1; ++t) s0 += partial[(long)t * W + col];
-  return (s0 + s1) + (s2 + s3);
-}
+// launch instead of reduce_rows + the finishing kernel: a 1024-thread workgroup owns 64 columns, its 16 waves take the
+// rows round-robin (row t goes to wave t mod 16: a wave walks <= 64 rows, 16 loads in flight), the 16 partial sums of a
+// column meet in LDS and wave 0 adds them in wave order in fp64.  Fixed association, run-to-run identical; it differs
+// from the two-launch path (chunks of 64 rows) in the last bits only.  (A first version that kept the 64-row chunks
+// -- 4 waves, <= 16 chunks -- took 10.5 us per launch at T = 400: as long as the two launches it replaced.)
+constexpr int kFusedRows = 1024;
+constexpr int kFusedWaves = 16;
 
-// sums[j][lane] (double) of columns n = blockIdx.x * 64 + lane of the J stacked [N]-wide rows of partial [T][J][N];
-// valid in wave 0 after the call.  T <= 64: the finishing kernels' plain row walk.
+// sums[j] (double) of column n = blockIdx.x * 64 + lane of the J stacked [N]-wide rows of partial [T][J][N]; valid in
+// wave 0 after the call (all 1024 threads must call).
 template <int JMAX>
 __device__ __forceinline__ void fused_column_sums(const float* __restrict__ partial, int T, int J, int N, int n,
-                                                  float (*chunk)[JMAX][64], double (&sums)[JMAX]) {
+                                                  float (*part)[JMAX][64], double (&sums)[JMAX]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long W = (long)J * N;
   const bool live = n < N;
-  if (T <= kReduceChunk) {
-    if (wave == 0) {
-      for (int j = 0; j < J; ++j) {
-        double s = 0.0;
-        if (live) for (int t = 0; t < T; ++t) s += (double)partial[(long)t * W + (long)j * N + n];
-        sums[j] = s;
+  for (int j = 0; j < J; ++j) {
+    const long col = (long)j * N + n;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = wave;
+    if (live) {
+      for (; t + 15 * kFusedWaves < T; t += 16 * kFusedWaves) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = partial[(long)(t + u * kFusedWaves) * W + col];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
       }
+      for (; t < T; t += kFusedWaves) s0 += partial[(long)t * W + col];
     }
-    return;
-  }
-  const int nchunks = (T + kReduceChunk - 1) / kReduceChunk;
-  for (int c = wave; c < nchunks; c += 4) {
-    const int t0 = c * kReduceChunk, t1 = (t0 + kReduceChunk < T) ? t0 + kReduceChunk : T;
-    for (int j = 0; j < J; ++j) chunk[c][j][lane] = live ? chunk_column_sum(partial, W, (long)j * N + n, t0, t1) : 0.f;
+    part[wave][j][lane] = (s0 + s1) + (s2 + s3);
   }
   __syncthreads();
   if (wave == 0) {
     for (int j = 0; j < J; ++j) {
       double s = 0.0;
-      for (int c = 0; c < nchunks; ++c) s += (double)chunk[c][j][lane];
+#pragma unroll
+      for (int w = 0; w < kFusedWaves; ++w) s += (double)part[w][j][lane];
       sums[j] = s;
     }
   }
 }
 
-__global__ __launch_bounds__(256) void tower_bn_finalize_fused_kernel(
+__global__ __launch_bounds__(1024) void tower_bn_finalize_fused_kernel(
     const float* __restrict__ partial, int T, int N, long M, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float momentum, float* __restrict__ moving_mean,
     float* __restrict__ moving_var, float* __restrict__ scale, float* __restrict__ shift,
     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-  __shared__ float chunk[kFusedRows / kReduceChunk][2][64];
+  __shared__ float part[kFusedWaves][2][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   double sums[2];
-  fused_column_sums<2>(partial, T, 2, N, n, chunk, sums);
+  fused_column_sums<2>(partial, T, 2, N, n, part, sums);
   if ((threadIdx.x >> 6) != 0 || n >= N) return;
   const double mean = sums[0] / (double)M;
   double var = sums[1] / (double)M - mean * mean;
@@ -874,13 +862,13 @@ __global__ __launch_bounds__(256) void tower_bn_finalize_fused_kernel(
 
 // out[j][n] = sum_t partial[t][j][n] for the J <= 6 stacked rows, and -- when gamma is given -- the BatchNorm-backward
 // coefficients pqr[3][N] of tower_bn_bwd_coeffs_kernel from rows 0 / 1 (sum dy, sum dy * zhat) in the same launch.
-__global__ __launch_bounds__(256) void tower_reduce_partials_fused_kernel(
+__global__ __launch_bounds__(1024) void tower_reduce_partials_fused_kernel(
     const float* __restrict__ partial, int T, int J, int N, float* __restrict__ out, const float* __restrict__ gamma,
     const float* __restrict__ rstd, const float* __restrict__ mean, float inv_m, float* __restrict__ pqr) {
-  __shared__ float chunk[kFusedRows / kReduceChunk][6][64];
+  __shared__ float part[kFusedWaves][6][64];
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   double sums[6];
-  fused_column_sums<6>(partial, T, J, N, n, chunk, sums);
+  fused_column_sums<6>(partial, T, J, N, n, part, sums);
   if ((threadIdx.x >> 6) != 0 || n >= N) return;
   for (int j = 0; j < J; ++j) out[(long)j * N + n] = (float)sums[j];
   if (gamma) {
@@ -1477,7 +1465,7 @@ extern "C" int tfr_tower_bn_finalize(const float* partial, int T, int N, long M,
   if (!partial || T <= 0 || N <= 0 || M <= 0 || !scale || !shift || !mean_out || !rstd_out) return TFR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (T <= kFusedRows) {                       // short partial matrix: one launch (same arithmetic, same order)
-    hipLaunchKernelGGL(tower_bn_finalize_fused_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, T, N, M, gamma,
+    hipLaunchKernelGGL(tower_bn_finalize_fused_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, partial, T, N, M, gamma,
                        beta, eps, momentum, moving_mean, moving_var, scale, shift, mean_out, rstd_out);
     return (int)hipGetLastError();
   }
@@ -1613,7 +1601,7 @@ extern "C" int tfr_tower_reduce_partials_coeffs(const float* partial, int T, int
   if (gamma && (!rstd || !mean || !pqr || M <= 0 || J < 2)) return TFR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (T <= kFusedRows && J <= 6) {
-    hipLaunchKernelGGL(tower_reduce_partials_fused_kernel, dim3((N + 63) / 64), dim3(256), 0, st, partial, T, J, N, out,
+    hipLaunchKernelGGL(tower_reduce_partials_fused_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, partial, T, J, N, out,
                        gamma, rstd, mean, gamma ? 1.0f / (float)M : 0.0f, pqr);
     return (int)hipGetLastError();
   }
