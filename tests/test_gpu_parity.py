@@ -1693,3 +1693,39 @@ def test_list_dot_is_the_weighted_sum(n):
     assert abs(a.item() - want) <= 1e-6 * scale
     s = ra()._ops.list_dot(x.to(DEV))
     assert abs(s.item() - float(x.double().sum())) <= 1e-6 * float(x.double().abs().sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', range(24))
+def test_lambdarank_fast_path_randomised_against_the_general_kernel(seed):
+    """Random shapes, grade distributions, padding patterns (not only a suffix), weights, temperatures and gains: the
+    fast path (grade-segmented, factorised) against the general pair kernel (reached through an explicit mask), row by
+    row, plus pair counts and gradients."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    B = int(torch.randint(1, 40, (1,), generator=g))
+    L = int(torch.randint(1, 257, (1,), generator=g))
+    n_grades = int(torch.randint(1, 14, (1,), generator=g))
+    labels = torch.randint(0, n_grades, (B, L), generator=g).float()
+    if seed % 3 == 0:
+        labels = labels * 0.5                                          # fractional grades
+    labels[torch.rand(B, L, generator=g) < float(torch.rand(1, generator=g)) * 0.6] = -1.0    # scattered padding
+    logits = torch.randn(B, L, generator=g) * float(torch.rand(1, generator=g) * 8 + 0.1)
+    wkind = seed % 3
+    weights = None if wkind == 0 else (make_weights(B, L, seed) if wkind == 1 else make_weights(B, 1, seed))
+    T = float(torch.rand(1, generator=g) * 2 + 0.2)
+    K, L_ = ra().keras.losses, ra().losses_impl
+    lam = [K.NDCGLambdaWeight(), L_.DCGLambdaWeight(), L_.DCGLambdaWeight(normalized=True),
+           ra().losses.create_ndcg_lambda_weight()][seed % 4]
+    loss = L_.PairwiseLogisticLoss(None, lambda_weight=lam, temperature=T)
+    d = lambda x: None if x is None else x.to(DEV)
+    xa = logits.to(DEV).requires_grad_(True)
+    xb = logits.to(DEV).requires_grad_(True)
+    a = loss._fused(d(labels), xa, d(weights), None)
+    b = loss._fused(d(labels), xb, d(weights), (labels >= 0).to(DEV))
+    scale = max(1.0, b[1].abs().max().item())
+    assert_loss_close(a[1] / scale, b[1] / scale, 3e-6, what='rows')
+    ws = max(1.0, b[2].abs().max().item())
+    assert_loss_close(a[2] / ws, b[2] / ws, 3e-6, what='row weights')
+    assert torch.equal(a[3], b[3])
+    a[0].sum().backward(); b[0].sum().backward()
+    assert_grad_close(xa.grad, xb.grad, 1e-5, what='grad')
