@@ -1729,3 +1729,30 @@ def test_lambdarank_fast_path_randomised_against_the_general_kernel(seed):
     assert torch.equal(a[3], b[3])
     a[0].sum().backward(); b[0].sum().backward()
     assert_grad_close(xa.grad, xb.grad, 1e-5, what='grad')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,L', [(2100, 50), (2049, 200), (8300, 100), (8193, 256), (16384, 200)])
+@pytest.mark.parametrize('wkind', ['none', 'list', 'item'])
+def test_softmax_many_lists_per_wave_against_the_c_arbiter(B, L, wkind):
+    """From 2048 lists on a wavefront of the softmax kernel owns 2, from 8192 on 4 lists (all loads issued up front):
+    every per-list loss, weight and gradient row against the fp64 plain-C restatement (unweighted) and against the
+    one-list-per-wave result of the same kernel on the first lists (weighted); ragged tails (B not a multiple of 16)."""
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=31 + L)
+    labels[1] = -1.0
+    labels[2] = torch.where(labels[2] >= 0, torch.zeros_like(labels[2]), labels[2])
+    w = None if wkind == 'none' else (make_weights(B, 1, seed=5).reshape(B) if wkind == 'list' else make_weights(B, L, seed=5))
+    d = lambda x: None if x is None else x.to(DEV)
+    loss, weight, grad = _ops.softmax_loss(d(logits), d(labels), None, d(w), temperature=0.7, want_grad=True)
+    if w is None:
+        c = _c_ref_or_skip()
+        w_loss, w_weight, w_grad = c.softmax(logits.numpy(), labels.numpy(), temperature=0.7)
+        assert_loss_close(loss, torch.from_numpy(w_loss), 2e-5, what='softmax vs C')
+        assert_loss_close(weight, torch.from_numpy(w_weight), 1e-6, what='softmax weight vs C')
+        want = torch.from_numpy(w_grad) * torch.from_numpy(w_weight).unsqueeze(1)     # kernel: d(weight * loss) / d logits
+        assert_grad_close(grad, want, 3e-5, what='softmax grad vs C')
+    n = 1000                                                  # < 2048 lists: one list per wave, same arithmetic
+    l1, w1, g1 = _ops.softmax_loss(d(logits[:n]), d(labels[:n]), None, d(None if w is None else w[:n]), temperature=0.7,
+                                   want_grad=True)
+    assert torch.equal(loss[:n], l1) and torch.equal(weight[:n], w1) and torch.equal(grad[:n], g1)
