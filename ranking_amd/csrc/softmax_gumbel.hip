@@ -325,109 +325,85 @@ inline int threads_for(int L) {
 // gradient w (ptot * softmax - p) / T;  + poly-1 term.  12 B read + 4 B written per item: HBM-bound.
 // (A 16-byte-access form -- 4 consecutive items per lane, one dwordx4 load per array for a 200-item list -- measured
 // SLOWER on MI355X: 25.1 vs 20.1 us per step at B = 16384, L = 200; only 50 of 64 lanes carry data and the four
-// items of a lane serialise the exp / divide chain.  Dropped.)
-template <int IPL, int LPW>
+// items of a lane serialise the exp / divide chain.  Dropped.  So was a form with 2 / 4 lists per wavefront and all
+// loads issued up front: 12.5 / 13.7 us against 11.9 us per launch at B = 16384, L = 100 -- the kernel is not short of
+// bytes in flight; ~4 us of every launch are fixed cost and the rest streams at ~2.5 TB/s out of the Infinity Cache.)
+template <int IPL>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B) {
-  // LPW lists per wavefront: ALL loads of the LPW lists are issued before the first use (LPW x the bytes in flight
-  // per wave: the kernel is request-latency bound -- a wave's life is one load round trip plus ~300 instructions --
-  // and with one list per wave a 16384-list batch needed two rounds of resident waves), then the lists are finished
-  // one after the other.
   const int lane = threadIdx.x & 63;
-  const int b0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LPW;
-  if (b0 >= B) return;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
   const int L = a.L;
-  float zz[LPW][IPL], yy[LPW][IPL], wl[LPW];
-  bool mm[LPW][IPL];
+  const size_t base = (size_t)b * L;
+  const float wl = (a.item_weights && a.weights_per_list) ? a.item_weights[b] : 1.0f;
+  float z[IPL], y[IPL];
+  bool mv[IPL];
+  float lsum = 0.f, zmax = -INFINITY;
 #pragma unroll
-  for (int q = 0; q < LPW; ++q) {
-    const int b = (b0 + q < B) ? b0 + q : B - 1;             // (the tail repeats the last list; its stores are skipped)
-    const size_t base = (size_t)b * L;
-    wl[q] = (a.item_weights && a.weights_per_list) ? a.item_weights[b] : 1.0f;
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const int i = lane + 64 * r;
-      zz[q][r] = -INFINITY; yy[q][r] = 0.f; mm[q][r] = false;
-      if (i < L) {
-        const float lab = a.labels[base + i];
-        const float x = a.logits[base + i];
-        mm[q][r] = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
-        float w = 1.0f;
-        if (a.item_weights && !a.weights_per_list) w = a.item_weights[base + i];
-        zz[q][r] = x;
-        yy[q][r] = lab * w;
-      }
+  for (int r = 0; r < IPL; ++r) {                        // all loads of the list are issued before the first use
+    const int i = lane + 64 * r;
+    z[r] = -INFINITY; y[r] = 0.f; mv[r] = false;
+    if (i < L) {
+      const float lab = a.labels[base + i];
+      const float x = a.logits[base + i];
+      mv[r] = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
+      float w = 1.0f;
+      if (a.item_weights) w = a.weights_per_list ? wl : a.item_weights[base + i];
+      z[r] = mv[r] ? x / a.temperature : kLogEps10;
+      y[r] = (mv[r] ? lab : 0.0f) * (a.item_weights ? w : 1.0f);
+      lsum += y[r];
+      zmax = fmaxf(zmax, z[r]);
     }
   }
+  lsum = wave_sum_u(lsum);
+  zmax = wave_max_u(zmax);
+  const bool nonzero = lsum > 0.0f;
+  float psum = 0.f, esum = 0.f, e[IPL];
 #pragma unroll
-  for (int q = 0; q < LPW; ++q) {
-    const int b = b0 + q;
-    if (b >= B) break;                                       // wave-uniform
-    const size_t base = (size_t)b * L;
-    float z[IPL], y[IPL];
-    bool mv[IPL];
-    float lsum = 0.f, zmax = -INFINITY;
+  for (int r = 0; r < IPL; ++r) {
+    const bool in = lane + 64 * r < L;
+    float yy = nonzero ? y[r] : 1e-10f;
+    yy = (in && mv[r]) ? yy : 0.0f;
+    y[r] = yy;
+    psum += yy;
+    e[r] = in ? expf(z[r] - zmax) : 0.0f;
+    esum += e[r];
+  }
+  psum = wave_sum_u(psum);
+  esum = wave_sum_u(esum);
+  const float lse = logf(esum);
+  float loss = 0.f, ptot = 0.f, pt = 0.f;
 #pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const int i = lane + 64 * r;
-      mv[r] = mm[q][r];
-      z[r] = -INFINITY; y[r] = 0.f;
-      if (i < L) {
-        z[r] = mv[r] ? zz[q][r] / a.temperature : kLogEps10;
-        y[r] = mv[r] ? (a.item_weights ? (a.weights_per_list ? (yy[q][r] * wl[q]) : yy[q][r]) : yy[q][r]) : 0.0f;
-        lsum += y[r];
-        zmax = fmaxf(zmax, z[r]);
+  for (int r = 0; r < IPL; ++r) {
+    const bool in = lane + 64 * r < L;
+    const float p = (psum != 0.0f) ? (y[r] / psum) : 0.0f;            // divide_no_nan
+    if (in) {
+      loss += p * (lse - (z[r] - zmax));
+      ptot += p;
+      pt += p * (e[r] / esum);
+    }
+    y[r] = p;
+  }
+  loss = wave_sum_u(loss);
+  ptot = wave_sum_u(ptot);
+  if (a.poly_eps != 0.0f) {
+    pt = wave_sum_u(pt);
+    loss += a.poly_eps * (1.0f - pt);
+  }
+  if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
+  if (!a.dlogits) return;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int i = lane + 64 * r;
+    if (i < L) {
+      float g = 0.f;
+      if (mv[r]) {
+        const float sm = e[r] / esum;
+        float d = ptot * sm - y[r];
+        if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[r] - pt);
+        g = lsum * (d / a.temperature);
       }
-    }
-    lsum = wave_sum_u(lsum);
-    zmax = wave_max_u(zmax);
-    const bool nonzero = lsum > 0.0f;
-    float psum = 0.f, esum = 0.f, e[IPL];
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const bool in = lane + 64 * r < L;
-      float yv = nonzero ? y[r] : 1e-10f;
-      yv = (in && mv[r]) ? yv : 0.0f;
-      y[r] = yv;
-      psum += yv;
-      e[r] = in ? expf(z[r] - zmax) : 0.0f;
-      esum += e[r];
-    }
-    psum = wave_sum_u(psum);
-    esum = wave_sum_u(esum);
-    const float lse = logf(esum);
-    float loss = 0.f, ptot = 0.f, pt = 0.f;
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const bool in = lane + 64 * r < L;
-      const float p = (psum != 0.0f) ? (y[r] / psum) : 0.0f;            // divide_no_nan
-      if (in) {
-        loss += p * (lse - (z[r] - zmax));
-        ptot += p;
-        pt += p * (e[r] / esum);
-      }
-      y[r] = p;
-    }
-    loss = wave_sum_u(loss);
-    ptot = wave_sum_u(ptot);
-    if (a.poly_eps != 0.0f) {
-      pt = wave_sum_u(pt);
-      loss += a.poly_eps * (1.0f - pt);
-    }
-    if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
-    if (!a.dlogits) continue;
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      const int i = lane + 64 * r;
-      if (i < L) {
-        float g = 0.f;
-        if (mv[r]) {
-          const float sm = e[r] / esum;
-          float d = ptot * sm - y[r];
-          if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[r] - pt);
-          g = lsum * (d / a.temperature);
-        }
-        a.dlogits[base + i] = g;
-      }
+      a.dlogits[base + i] = g;
     }
   }
 }
@@ -472,13 +448,8 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
   static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
   if (env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
-    // lists per wave: 4 when the batch would otherwise need more than one round of resident waves and the list is short
-    static const int env_lpw = [] { const char* e = getenv("TFR_SOFTMAX_LPW"); return (e && *e) ? atoi(e) : 0; }();
-    const int lpw = env_lpw > 0 ? env_lpw : ((L <= 256 && B >= 8192) ? 4 : ((L <= 256 && B >= 2048) ? 2 : 1));
-#define SMW(I, Q) hipLaunchKernelGGL((softmax_wave_kernel<I, Q>), dim3((B + 4 * Q - 1) / (4 * Q)), dim3(256), 0, st, a, B)
-#define SMQ(I) do { if (lpw >= 4) SMW(I, 4); else if (lpw >= 2) SMW(I, 2); else SMW(I, 1); } while (0)
-    if (L <= 64) SMQ(1); else if (L <= 128) SMQ(2); else if (L <= 256) SMQ(4); else if (L <= 512) SMW(8, 1); else SMW(16, 1);
-#undef SMQ
+#define SMW(I) hipLaunchKernelGGL(softmax_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, a, B)
+    if (L <= 64) SMW(1); else if (L <= 128) SMW(2); else if (L <= 256) SMW(4); else if (L <= 512) SMW(8); else SMW(16);
 #undef SMW
     return (int)hipGetLastError();
   }
