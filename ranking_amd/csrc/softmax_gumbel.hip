@@ -336,6 +336,9 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
   const int L = a.L;
   const size_t base = (size_t)b * L;
   const float wl = (a.item_weights && a.weights_per_list) ? a.item_weights[b] : 1.0f;
+  // one reciprocal per list instead of a division per item (x / T, y / sum y, e / sum e, d / T: four IEEE divisions of
+  // ~10 instructions each on every item) and the single-instruction exponential: the kernel was issue-bound on them
+  const float inv_t = 1.0f / a.temperature;
   float z[IPL], y[IPL];
   bool mv[IPL];
   float lsum = 0.f, zmax = -INFINITY;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
       mv[r] = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
       float w = 1.0f;
       if (a.item_weights) w = a.weights_per_list ? wl : a.item_weights[base + i];
-      z[r] = mv[r] ? x / a.temperature : kLogEps10;
+      z[r] = mv[r] ? x * inv_t : kLogEps10;
       y[r] = (mv[r] ? lab : 0.0f) * (a.item_weights ? w : 1.0f);
       lsum += y[r];
       zmax = fmaxf(zmax, z[r]);
@@ -366,21 +369,23 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
     yy = (in && mv[r]) ? yy : 0.0f;
     y[r] = yy;
     psum += yy;
-    e[r] = in ? expf(z[r] - zmax) : 0.0f;
+    e[r] = in ? __builtin_amdgcn_exp2f((z[r] - zmax) * 1.44269504088896340736f) : 0.0f;
     esum += e[r];
   }
   psum = wave_sum_u(psum);
   esum = wave_sum_u(esum);
   const float lse = logf(esum);
+  const float inv_p = (psum != 0.0f) ? 1.0f / psum : 0.0f;            // divide_no_nan
+  const float inv_e = 1.0f / esum;
   float loss = 0.f, ptot = 0.f, pt = 0.f;
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
     const bool in = lane + 64 * r < L;
-    const float p = (psum != 0.0f) ? (y[r] / psum) : 0.0f;            // divide_no_nan
+    const float p = y[r] * inv_p;
     if (in) {
       loss += p * (lse - (z[r] - zmax));
       ptot += p;
-      pt += p * (e[r] / esum);
+      pt += p * (e[r] * inv_e);
     }
     y[r] = p;
   }
@@ -398,10 +403,10 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
     if (i < L) {
       float g = 0.f;
       if (mv[r]) {
-        const float sm = e[r] / esum;
+        const float sm = e[r] * inv_e;
         float d = ptot * sm - y[r];
         if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[r] - pt);
-        g = lsum * (d / a.temperature);
+        g = (lsum * inv_t) * d;
       }
       a.dlogits[base + i] = g;
     }
