@@ -33,6 +33,7 @@
 #include "common.h"
 #include "../../include/tfr_hip.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 using namespace tfr;
@@ -98,6 +99,9 @@ struct GemmArgs {
   Drop pro_drop;                     // dropout of the layer below, applied in the A prologue (thr = 0: off)
   Drop epi_drop;                     // ... and in the EPI_RELU_BWD epilogue (the layer whose Zp is given)
   int M, N, K, tiles_m, tiles_n;
+  int stagger_phases, stagger_sleeps;  // 256 x 256 kernel: first-round workgroups of phase p idle p * sleeps * s_sleep(127)
+  int flags;                           // persistent 256 x 256 kernel: PF_* bits
+  int row0;                            // global index of row 0 of A / C (dropout hash) when a launch covers a row range
 };
 
 enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2 };
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
       // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
       *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
     }
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
         const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
         float kf[4] = {1.f, 1.f, 1.f, 1.f};
         if (g.epi_drop.thr) {                           // d a / d relu = keep / (1 - rate): same hash as the forward
-          drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
-          drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+          drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
+          drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -434,6 +438,21 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
 // and an A row block is fetched by N / 256 instead of N / 128 workgroups.
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int TILE2_BYTES = BM2 * BK * 2;         // 32 KB per operand tile
+// Developer ablations (tools/gemm_ablate.py builds tower.hip with -DTFR_GEMM_ABLATE=mask; the product build has 0):
+// 1 = no MFMA block, 2 = no global -> LDS staging inside the k loop, 4 = no epilogue, 8 = MFMAs on registers (no ds_read);
+// (the persistent kernel takes stamps only: 16).
+#ifndef TFR_GEMM_ABLATE
+#define TFR_GEMM_ABLATE 0
+#endif
+constexpr int kAb = TFR_GEMM_ABLATE;
+// mask 16: thread 0 of every workgroup records s_memtime at the phase boundaries (+ HW_ID, XCC_ID) into a buffer
+// set with tfr_prof_set_buffer_gemm() -- [workgroup][8] u64.
+#if (TFR_GEMM_ABLATE & 16)
+__device__ unsigned long long* g_prof_gemm = nullptr;
+#define GEMM_STAMP(i) do { if (tid == 0) prof_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GEMM_STAMP(i) do { } while (0)
+#endif
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g) {
@@ -446,6 +465,10 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: LDS bases / tile offsets in SGPRs
   const int wm = wave & 3, wn = wave >> 2;
   const int id = blockIdx.x;
+#if (TFR_GEMM_ABLATE & 16)
+  unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  GEMM_STAMP(0);
   const int xcd = id & 7, j = id >> 3;
   const int tn = j % g.tiles_n;
   const int tm = (j / g.tiles_n) * 8 + xcd;
@@ -453,6 +476,10 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int nk = g.K / BK;
   constexpr bool GLA = (PRO == PRO_NONE);
+  if (g.stagger_phases > 1 && id < 256) {
+    const int ph = (id >> 3) % g.stagger_phases;
+    for (int i = 0; i < ph * g.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   const int c = tid & 7, r0 = tid >> 3;           // staging: chunk column c of rows r0 + 64 i
   struct RegsA { uint4 a[4]; };
@@ -474,7 +501,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 64 * i;
-      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(m0 + row), (uint32_t)k);
+      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -502,14 +529,18 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 fa[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));    // activations
+      for (int f = 0; f < 4; ++f) {
+        if (kAb & 8) asm volatile("" : "=v"(fa[f]));
+        else fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));    // activations
+      }
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
         bf16x8 fb[4];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          fb[f] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 128 + hn * 64 + f * 16 + fr, kk * 4 + fq));   // weights
+        for (int f = 0; f < 4; ++f) {
+          if (kAb & 8) asm volatile("" : "=v"(fb[f]));
+          else fb[f] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 128 + hn * 64 + f * 16 + fr, kk * 4 + fq));   // weights
+        }
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn)
 #pragma unroll
@@ -533,6 +564,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   }
   if (!GLA) store_a(0, tiles, R);
   __syncthreads();
+  GEMM_STAMP(1);
   // EPI_RELU_BWD: the epilogue needs the wave's 64 x 128 piece of Zp.  With one workgroup per CU nothing else
   // would cover those loads, so they are software-pipelined: half 0 is requested during the last k step (its
   // 64 MFMAs hide the HBM round trip), half 1 while half 0 is being processed.
@@ -552,15 +584,25 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
     unsigned char* const tAc = tiles + (kt & 1) * (2 * TILE2_BYTES);
     unsigned char* const tAn = tiles + ((kt + 1) & 1) * (2 * TILE2_BYTES);
     const bool more = kt + 1 < nk;
-    if (more) {
+    if (more && !(kAb & 2)) {
       glds_tile(g.B, g.ldb, n0, g.N, kt + 1, tAn + TILE2_BYTES);
       if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 1, tAn);
       else load_a(kt + 1, R);
     }
     if (EPI == EPI_RELU_BWD && !more) zp_load(0);
-    compute(tAc, tAc + TILE2_BYTES);
-    if (!GLA && more) store_a(kt + 1, tAn, R);
+    if (!(kAb & 1)) compute(tAc, tAc + TILE2_BYTES);
+    if (!GLA && more && !(kAb & 2)) store_a(kt + 1, tAn, R);
     __syncthreads();
+  }
+  GEMM_STAMP(2);
+  if (kAb & 4) {
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+    if (s == 12345.678f) g.C[tid] = 1;
+    return;
   }
 
   // ---- epilogue: the wave's 64 x 128 result as two 64 x 64 halves through its private LDS region
@@ -579,6 +621,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
       if (h == 0) zp_load(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    if (h == 1) GEMM_STAMP(3);
     float* const st = g.stats + ((long)(tm * 4 + wm) * 2) * g.N;      // one row of partials per 64-row slab
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
@@ -613,8 +656,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
           const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
           float kf[4] = {1.f, 1.f, 1.f, 1.f};
           if (g.epi_drop.thr) {
-            drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
-            drop_pair(g.epi_drop, (uint32_t)(mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+            drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
+            drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -650,6 +693,380 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
             *reinterpret_cast<const uint4*>(wl + row * WPITCH + cc * 16);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  GEMM_STAMP(4);
+#if (TFR_GEMM_ABLATE & 16)
+  if (kAb & 32) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ... and when the stores have been acknowledged
+  GEMM_STAMP(5);
+  if (tid == 0 && g_prof_gemm) {
+    prof_t[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    prof_t[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+    for (int i = 0; i < 8; ++i) g_prof_gemm[(size_t)id * 8 + i] = prof_t[i];
+  }
+#endif
+}
+
+#if (TFR_GEMM_ABLATE & 16)
+extern "C" int tfr_prof_set_buffer_gemm(void* device_u64_buffer) {
+  unsigned long long* p = (unsigned long long*)device_u64_buffer;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_gemm), &p, sizeof(p));
+}
+#endif
+
+// ------------------------------------------------------------------------------------
+// Persistent form of the 256 x 256 kernel: full tiles only (M % 256 == 0, N % 256 == 0, K % 64 == 0, 128 <= K <= 1024;
+// the launcher sends a ragged last M-tile through the kernel above).  Why (tools/gemm_timeline.py, config-2 hidden
+// layer, round 2): with one workgroup per tile a CU spent 26 / 34 / 40 us per tile (plain / forward / dgrad) of which
+// the MFMA block needs 8.4: 1.3-2.2 us between workgroups, 2.6-3.7 us until the first tile is staged, a k step that
+// lasts as long as an HBM round trip (2.2 us, the stage is requested at the top of the step that precedes its use),
+// and an epilogue of 4.3 / 7.3 / 16.4 us that nothing overlaps and that was instruction-bound (per-element bounds
+// checks, 64-bit address arithmetic per access, per-lane global loads of the per-column coefficients).  Here
+//  * one workgroup per CU walks its XCD's tiles (the two n-tiles of an M-tile still run side by side on one XCD);
+//  * every LDS-DMA is issued by hand (inline asm, SGPR base + a per-lane 32-bit offset computed once per kernel) and
+//    waited for by hand, so the next tile's first TWO stages are in flight before the epilogue starts (no-prologue
+//    form) and the epilogue's stores drain behind the next tile's first k steps;
+//  * waves 0-3 touch the A lines of stage kt + 2 (one dword per 128-byte line, LDS-DMA'd into a junk slot) so that the
+//    stage requested one step ahead is an L2 hit; waves 4-7 do the same for the Zp tile of the dgrad epilogue;
+//  * the epilogue works on 16-row x 64-column chunks through a 2 KB per-wave staging slot outside the stage buffers,
+//    keeps the per-column coefficients in registers per 64-column half (they come from LDS, loaded once per tile),
+//    has no bounds checks, and folds (z - mean) * rstd out of the per-element work:
+//    sum dy * zhat = rstd * sum dy * z - mean * rstd * sum dy.
+constexpr int P_SCALE = 4 * TILE2_BYTES;              // [2][K] floats (K <= 1024)
+constexpr int P_EPI = P_SCALE + 2 * 1024 * 4;         // [4][256] floats: the tile's per-column epilogue coefficients
+constexpr int P_STAGE = P_EPI + 4 * 256 * 4;          // 8 waves x 2 KB
+constexpr int P_JUNK = P_STAGE + 8 * 2048;            // 8 waves x 256 B (touch destinations, never read)
+constexpr int P_LDS = P_JUNK + 8 * 256;               // 157 696 B
+
+__device__ __forceinline__ void dma16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+  // (s_nop 4: an SGPR fresh from v_readfirstlane must not be read by a VMEM instruction within 5 states)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void touch4_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ f32x4 row16_sum4(f32x4 v) {
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = row16_sum(v[r]);
+  return o;
+}
+
+enum { PF_TOUCH_A = 1, PF_TOUCH_Z = 2 };
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// The previous layer's BatchNorm (+ ReLU, + dropout) on one MFMA operand fragment (8 consecutive k of one row) as it
+// comes out of LDS: relu on the packed bf16 pair is a signed 16-bit max with 0 (v_pk_max_i16), the affine a v_pk_fma_f32.
+template <int PRO, bool DROP>
+__device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, const f32x4 sc1, const f32x4 sh0, const f32x4 sh1,
+                                                 const Drop d, uint32_t m, uint32_t k) {
+  if (PRO == PRO_NONE) return raw;
+  const uint4 v = __builtin_bit_cast(uint4, raw);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+  const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
+    const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
+    x = x * s + h;
+    if (DROP) {                                     // relu(y) * f == relu(y * f) for f >= 0
+      float f0, f1;
+      drop_pair(d, m, (k >> 1) + i, f0, f1);
+      x = x * f32x2{f0, f1};
+    }
+    uint32_t pk = pack_bf16(x[0], x[1]);
+    if (PRO == PRO_AFFINE_RELU)
+      pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
+    o[i] = pk;
+  }
+  return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+}
+
+template <int PRO, int EPI, bool DROP>
+__global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int nk = g.K / BK;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  float* s_scale = reinterpret_cast<float*>(smem + P_SCALE);
+  float* s_shift = s_scale + g.K;
+  float* s_epi = reinterpret_cast<float*>(smem + P_EPI);
+  unsigned char* sw = smem + P_STAGE + wave * 2048;
+  const uint32_t junk = lds0 + P_JUNK + wave * 256;
+
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int nq = ((g.tiles_m - xcd + 7) >> 3) * g.tiles_n;       // this XCD's tiles: M-tiles xcd, xcd + 8, ...
+  if (slot >= nq) return;
+  const bool touch_z = EPI == EPI_RELU_BWD && (g.flags & PF_TOUCH_Z) != 0 && wave >= 4;
+
+  // per-lane byte offsets of the staging pieces (tile independent): piece i = rows wave * 32 + 8 i .. + 8
+  uint32_t offA[4], offB[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = wave * 32 + i * 8 + (lane >> 3);
+    const int cl = (lane & 7) ^ ((rl >> 1) & 7);
+    offA[i] = (uint32_t)((rl * g.lda + cl * 8) * 2);
+    offB[i] = (uint32_t)((rl * g.ldb + cl * 8) * 2);
+  }
+  const uint32_t offTZ = (uint32_t)(((wave & 3) * 64 + lane) * g.ldz * 2);
+  const int fr = lane & 15, fq = lane >> 4;
+
+  auto tile_of = [&](int q, int& tm, int& tn) __attribute__((always_inline)) { tm = (q / g.tiles_n) * 8 + xcd; tn = q % g.tiles_n; };
+  auto a_base = [&](int tm, int kt) __attribute__((always_inline)) { return reinterpret_cast<const char*>(g.A) + ((long)tm * BM2 * g.lda + kt * BK) * 2; };
+  auto b_base = [&](int tn, int kt) __attribute__((always_inline)) { return reinterpret_cast<const char*>(g.B) + ((long)tn * BN2 * g.ldb + kt * BK) * 2; };
+  auto issue_b = [&](int tn, int kt, int buf) __attribute__((always_inline)) {
+    const char* bb = b_base(tn, kt);
+    const uint32_t dst = lds0 + buf * (2 * TILE2_BYTES) + TILE2_BYTES + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16_s(offB[i], bb, dst + i * 1024);
+  };
+  auto issue_a = [&](int tm, int kt, int buf) __attribute__((always_inline)) {
+    const char* ab = a_base(tm, kt);
+    const uint32_t dst = lds0 + buf * (2 * TILE2_BYTES) + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma16_s(offA[i], ab, dst + i * 1024);
+  };
+  f32x4 acc[8][4];      // [fn][fm]: D[n][m]
+  // With a prologue the raw z tile is staged like any A tile and the BatchNorm / ReLU / dropout is applied to the
+  // operand fragments in registers (each fragment is read by the two waves of its row block: twice the arithmetic of
+  // a staged transform, but no register-staged copy of the tile, no ds_write_b128 pass and the same two-stage
+  // run-ahead at tile boundaries as the plain form).
+  // One k step = 4 blocks of 16 MFMAs; the 8 LDS-DMA pieces of the next stage go out two per block (A first).  A step
+  // that has nothing to request sends its pieces to the wave's idle epilogue slot: two inlined copies of this block
+  // -- with / without the pieces -- make the register allocator carry two sets of accumulators.
+  // What was measured on the way (tools/gemm_timeline.py, config-2 hidden layer, cycles per k step and SIMD): MFMAs
+  // alone 2360 (128 x 16 = 2048 is the floor), + fragment reads 3130, + LDS-DMA pieces 4440 -- the three add up
+  // whatever the order: all pieces at the top of the step, one or two per block, alternating between the two waves of
+  // a SIMD; fragment reads one or two half blocks ahead of their MFMAs; accumulators in VGPRs or (hand-assigned) in
+  // AGPRs; L2-warming touches two stages ahead.  None of these moved the step by more than 5 %.
+  auto compute = [&](const unsigned char* ta, const unsigned char* tb, bool issue, const char* ab, const char* bb,
+                     uint32_t dstbuf, int kt, int m0_) __attribute__((always_inline)) {
+    const uint32_t dst_a = issue ? dstbuf + wave * 4096 : lds0 + P_STAGE + wave * 2048;
+    const uint32_t dst_b = issue ? dstbuf + TILE2_BYTES + wave * 4096 : lds0 + P_STAGE + wave * 2048;
+    const uint32_t dst_step = issue ? 1024u : 0u;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));    // activations
+      if (PRO != PRO_NONE) {
+        const int k = kt * BK + kk * 32 + fq * 8;
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_scale + k), sc1 = *reinterpret_cast<const f32x4*>(s_scale + k + 4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + k), sh1 = *reinterpret_cast<const f32x4*>(s_shift + k + 4);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+          fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, g.pro_drop,
+                                            (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k);
+      }
+#pragma unroll
+      for (int hn = 0; hn < 2; ++hn) {
+        const int blk = kk * 2 + hn;
+        if (blk < 2) {
+          dma16_s(offA[2 * blk], ab, dst_a + (2 * blk) * dst_step);
+          dma16_s(offA[2 * blk + 1], ab, dst_a + (2 * blk + 1) * dst_step);
+        } else {
+          dma16_s(offB[2 * blk - 4], bb, dst_b + (2 * blk - 4) * dst_step);
+          dma16_s(offB[2 * blk - 3], bb, dst_b + (2 * blk - 3) * dst_step);
+        }
+#pragma unroll
+        for (int fp = 0; fp < 2; ++fp) {            // weight fragments two at a time (8 registers instead of 16)
+          bf16x8 fb[2];
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+            fb[f] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 128 + hn * 64 + (fp * 2 + f) * 16 + fr, kk * 4 + fq));
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+              acc[hn * 4 + fp * 2 + f][fm] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[f], fa[fm], acc[hn * 4 + fp * 2 + f][fm], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // the per-column epilogue coefficients of n-tile tn -> LDS (with tiles_n | nslots a workgroup keeps its n-tile)
+  auto fill_epi = [&](int tn_) __attribute__((always_inline)) {
+    if (tid < 256) {
+      const int n = tn_ * BN2 + tid;
+      if (EPI == EPI_RELU_BWD) {
+        const float rs = g.e_rstd[n];
+        s_epi[tid] = g.e_scale[n]; s_epi[256 + tid] = g.e_shift[n];
+        s_epi[512 + tid] = rs; s_epi[768 + tid] = -g.e_mean[n] * rs;
+      } else {
+        s_epi[tid] = g.bias ? g.bias[n] : 0.f;
+      }
+    }
+  };
+
+  // ---- first tile: stage 0 (and stage 1 when both operands go by LDS-DMA)
+  int q = slot, tm, tn;
+  tile_of(q, tm, tn);
+  bool refill = false;
+  fill_epi(tn);
+  int p = 0;                                       // the buffer that holds stage 0 of the current tile
+  issue_b(tn, 0, 0); issue_a(tm, 0, 0); issue_b(tn, 1, 1); issue_a(tm, 1, 1);
+  if (PRO != PRO_NONE)
+    for (int k = tid; k < g.K; k += 512) { s_scale[k] = g.a_scale[k]; s_shift[k] = g.a_shift[k]; }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+  while (true) {
+    const int qn = q + nslots;                     // this workgroup's next tile
+    const bool have_next = qn < nq;
+    int tmn = tm, tnn = tn;
+    if (have_next) tile_of(qn, tmn, tnn);
+    const int m0 = tm * BM2, n0 = tn * BN2;
+    const long mb = (long)m0 + wm * 64;
+#if (TFR_GEMM_ABLATE & 16)
+    unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    GEMM_STAMP(0);
+
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 zq0 = make_uint4(0, 0, 0, 0), zq1 = zq0;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = p ^ (kt & 1), oth = cur ^ 1;
+      const bool last = kt + 1 == nk;
+      // stage kt + 1, or the next tile's stage 0, goes to the other buffer during this step; the tile's stage 1 has
+      // been in flight since before the previous epilogue, so step 0 requests nothing
+      const bool issued = kt != 0 && (!last || have_next);
+      const int stm = last ? tmn : tm, stn = last ? tnn : tn, skt = last ? 0 : kt + 1;
+      if (touch_z && kt < 4)                        // the tile's Zp lines: 4 lines (256 columns) per row
+        touch4_s(offTZ, reinterpret_cast<const char*>(g.Zp) + ((long)m0 * g.ldz + n0 + kt * 64) * 2, junk);
+      if (EPI == EPI_RELU_BWD && last) {            // first Zp chunk of the epilogue
+        const char* zb = reinterpret_cast<const char*>(g.Zp) + (mb * g.ldz + n0 + wn * 128) * 2;
+        zq0 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((lane >> 3) * g.ldz + (lane & 7) * 8) * 2));
+        zq1 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((8 + (lane >> 3)) * g.ldz + (lane & 7) * 8) * 2));
+      }
+      compute(smem + cur * (2 * TILE2_BYTES), smem + cur * (2 * TILE2_BYTES) + TILE2_BYTES, issued, a_base(stm, skt),
+              b_base(stn, skt), lds0 + oth * (2 * TILE2_BYTES), kt, m0);
+      if (kt == 1 && refill) {                     // (rare: the n-tile changed) every wave is past the old epilogue here
+        asm volatile("" ::: "memory");
+        fill_epi(tn);
+      }
+      // the pieces requested in this step must have landed (every wave's) before anyone reads them
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    GEMM_STAMP(2);
+    const int freeb = p ^ ((nk - 1) & 1);           // the buffer of the last step: free now
+    const int pn = freeb ^ 1;                       // ... and the next tile's stage 0 sits in the other one
+    if (have_next) { issue_b(tnn, 1, freeb); issue_a(tmn, 1, freeb); }
+
+    // ---- epilogue: 2 halves (64 columns) x 4 chunks (16 rows) per wave through the wave's 2 KB slot
+    // (per-lane offsets recomputed per tile: they would cost ten registers through the k loop)
+    uint32_t offC[2], offZ[2], stg_rm[2], stg_acc[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                  // row-major 16-byte pieces of a [16][64] chunk, two per lane
+      const int qq = lane + 64 * i, row = qq >> 3, cc = qq & 7;
+      offC[i] = (uint32_t)((row * g.ldc + cc * 8) * 2);
+      offZ[i] = (uint32_t)((row * g.ldz + cc * 8) * 2);
+      stg_rm[i] = (uint32_t)(row * 128 + ((cc ^ (row & 7)) << 4));
+    }
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn)                 // the lane's 8-byte slot of fragment column fn in the chunk
+      stg_acc[fn] = (uint32_t)(fr * 128 + (((fn * 2 + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8);
+    bool first_store = true;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int nl = wn * 128 + h * 64;             // column of the half inside the tile
+      f32x4 pb[4], pe[4];                           // bias | BN scale, shift of the layer below (relu mask)
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) {
+        pb[fn] = *reinterpret_cast<const f32x4*>(s_epi + nl + fn * 16 + fq * 4);
+        if (EPI == EPI_RELU_BWD) pe[fn] = *reinterpret_cast<const f32x4*>(s_epi + 256 + nl + fn * 16 + fq * 4);
+      }
+      f32x4 s1[4], s2[4];
+#pragma unroll
+      for (int fn = 0; fn < 4; ++fn) { s1[fn] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[fn] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      char* cb = reinterpret_cast<char*>(g.C) + (mb * g.ldc + n0 + nl) * 2;
+      const char* zb = reinterpret_cast<const char*>(g.Zp) + (mb * g.ldz + n0 + nl) * 2;
+#pragma unroll
+      for (int fm = 0; fm < 4; ++fm) {
+        if (EPI == EPI_RELU_BWD) {
+          *reinterpret_cast<uint4*>(sw + stg_rm[0]) = zq0;
+          *reinterpret_cast<uint4*>(sw + stg_rm[1]) = zq1;
+          if (!(h == 1 && fm == 3)) {               // next chunk (next 16 rows, or the other half's first rows)
+            const char* zn = (fm < 3) ? zb + (long)(fm + 1) * 16 * g.ldz * 2 : zb + 64 * 2;
+            zq0 = *reinterpret_cast<const uint4*>(zn + offZ[0]);
+            zq1 = *reinterpret_cast<const uint4*>(zn + offZ[1]);
+          }
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          f32x4 v = acc[h * 4 + fn][fm];
+          if (EPI == EPI_RELU_BWD) {
+            const uint2 zz = *reinterpret_cast<const uint2*>(sw + stg_acc[fn]);
+            const f32x4 z = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
+            const f32x4 y = z * pb[fn] + pe[fn];
+            if (DROP) {
+              float kf[4];
+              const uint32_t row = (uint32_t)(g.row0 + mb + fm * 16 + fr), cp = (uint32_t)((n0 + nl + fn * 16 + fq * 4) >> 1);
+              drop_pair(g.epi_drop, row, cp, kf[0], kf[1]);
+              drop_pair(g.epi_drop, row, cp + 1, kf[2], kf[3]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] *= kf[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+            s1[fn] += v;
+            s2[fn] += v * z;
+          } else {
+            v += pb[fn];
+            if (EPI == EPI_STATS) { s1[fn] += v; s2[fn] += v * v; }
+          }
+          *reinterpret_cast<uint2*>(sw + stg_acc[fn]) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+        }
+        if (first_store) {                          // the next tile's two stages have had the first chunk's time
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          first_store = false;
+        }
+        const uint4 o0 = *reinterpret_cast<const uint4*>(sw + stg_rm[0]);
+        const uint4 o1 = *reinterpret_cast<const uint4*>(sw + stg_rm[1]);
+        char* cc = cb + (long)fm * 16 * g.ldc * 2;
+        *reinterpret_cast<uint4*>(cc + offC[0]) = o0;
+        *reinterpret_cast<uint4*>(cc + offC[1]) = o1;
+      }
+      if (h == 0) GEMM_STAMP(3);
+      if (h == 1) GEMM_STAMP(4);
+      if (EPI != EPI_PLAIN) {
+        float* const st = g.stats + ((long)(tm * 4 + wm) * 2) * g.N + n0 + nl;      // one row of partials per 64-row slab
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+          f32x4 a = row16_sum4(s1[fn]), b = row16_sum4(s2[fn]);
+          if (EPI == EPI_RELU_BWD) {                // sum dy * zhat = rstd * sum dy z - mean rstd * sum dy
+            const f32x4 er = *reinterpret_cast<const f32x4*>(s_epi + 512 + nl + fn * 16 + fq * 4);
+            const f32x4 c2 = *reinterpret_cast<const f32x4*>(s_epi + 768 + nl + fn * 16 + fq * 4);
+            b = b * er + a * c2;
+          }
+          if (fr == 15) {
+            *reinterpret_cast<f32x4*>(st + fn * 16 + fq * 4) = a;
+            *reinterpret_cast<f32x4*>(st + g.N + fn * 16 + fq * 4) = b;
+          }
+        }
+      }
+    }
+    GEMM_STAMP(5);
+#if (TFR_GEMM_ABLATE & 16)
+    if (tid == 0 && g_prof_gemm) {
+      prof_t[1] = prof_t[0];
+      prof_t[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+      prof_t[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);
+      for (int i = 0; i < 8; ++i) g_prof_gemm[(size_t)(tm * g.tiles_n + tn) * 8 + i] = prof_t[i];
+    }
+#endif
+    if (!have_next) break;
+    refill = tnn != tn;
+    q = qn; tm = tmn; tn = tnn; p = pn;
   }
 }
 
@@ -1294,6 +1711,11 @@ template <int PRO, int EPI>
 int launch_gemm256(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   g.tiles_m = (g.M + BM2 - 1) / BM2; g.tiles_n = (g.N + BN2 - 1) / BN2;
+  {
+    const char* e = getenv("TFR_GEMM_STAGGER");          // "phases,sleeps" (developer knob)
+    g.stagger_phases = 0; g.stagger_sleeps = 0;
+    if (e && *e) sscanf(e, "%d,%d", &g.stagger_phases, &g.stagger_sleeps);
+  }
   const size_t lds = 4 * TILE2_BYTES + 2 * (size_t)g.K * sizeof(float);
   auto fn = tower_gemm256_kernel<PRO, EPI>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1304,8 +1726,39 @@ int launch_gemm256(const GemmArgs& g0, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// Persistent kernel over the full 256-row tiles, the kernel above over a ragged rest.
+template <int PRO, int EPI>
+int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
+  static const int flags = [] { const char* e = getenv("TFR_GEMM_FLAGS"); return (e && *e) ? atoi(e) : (PF_TOUCH_A | PF_TOUCH_Z); }();
+  GemmArgs g = g0;
+  const int m_full = g0.M & ~(BM2 - 1);
+  g.M = m_full;
+  g.tiles_m = m_full / BM2; g.tiles_n = g.N / BN2;
+  g.flags = flags;
+  const bool drop = (PRO != PRO_NONE && g.pro_drop.thr) || (EPI == EPI_RELU_BWD && g.epi_drop.thr);
+  const int nq0 = ((g.tiles_m + 7) >> 3) * g.tiles_n;
+  const int nslots = nq0 < 32 ? nq0 : 32;
+  auto fn = drop ? tower_gemm256p_kernel<PRO, EPI, true> : tower_gemm256p_kernel<PRO, EPI, false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(fn, dim3(8 * nslots), dim3(512), P_LDS, st, g);
+  int rc = (int)hipGetLastError();
+  if (rc != 0 || m_full == g0.M) return rc;
+  GemmArgs t = g0;                                  // the last M - m_full (< 256) rows
+  t.A = g0.A + (long)m_full * g0.lda; t.C = g0.C + (long)m_full * g0.ldc;
+  if (g0.Zp) t.Zp = g0.Zp + (long)m_full * g0.ldz;
+  if (g0.stats) t.stats = g0.stats + (long)(m_full / 64) * 2 * g0.N;
+  t.M = g0.M - m_full; t.row0 = g0.row0 + m_full;
+  t.tiles_m = (t.M + BM - 1) / BM; t.tiles_n = (t.N + BN - 1) / BN;
+  return launch_gemm_v<PRO, EPI, true>(t, st);
+}
+
 template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  static const bool persist = [] { const char* e = getenv("TFR_TOWER_PERSIST"); return !(e && *e) || atoi(e) != 0; }();
+  if (persist && g.M >= BM2 && (g.N % BN2) == 0 && (g.K % BK) == 0 && g.K >= 2 * BK && g.K <= 1024 &&
+      !(EPI == EPI_RELU_BWD && g.bias) && g.lda < (1L << 21) && g.ldb < (1L << 21) && g.ldc < (1L << 21) && g.ldz < (1L << 21))
+    return launch_gemm256p<PRO, EPI>(g, st);
   static const bool no_gl = [] { const char* e = getenv("TFR_TOWER_NO_LDSDMA"); return e && *e && atoi(e) != 0; }();
   static const int tile = [] { const char* e = getenv("TFR_TOWER_TILE"); return (e && *e) ? atoi(e) : 256; }();
   if ((g.K % BK) == 0 && !no_gl && tile == 256 && g.N >= BN2 && g.M >= BM2 &&
@@ -1447,6 +1900,7 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
+  g.stagger_phases = 0; g.stagger_sleeps = 0; g.flags = 0; g.row0 = 0;
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
   TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);

@@ -61,7 +61,10 @@ def test_cast_weight():
 @pytest.mark.parametrize('M,N,K', [(1, 8, 8), (128, 128, 64), (300, 136, 136), (257, 512, 512), (1000, 128, 200),
                                    (129, 520, 72),
                                    # the 256 x 256 LDS-DMA kernel: ragged M / N edges, one k step, many k steps
-                                   (700, 320, 320), (1000, 264, 128), (256, 256, 64), (511, 1024, 1024)])
+                                   (700, 320, 320), (1000, 264, 128), (256, 256, 64), (511, 1024, 1024),
+                                   # the persistent kernel: several tiles per workgroup, the n-tile changes between a
+                                   # workgroup's tiles (tiles_n = 3 against 32 slots), ragged rest through the other kernel
+                                   (34816, 512, 512), (22605, 768, 128), (2048, 256, 192)])
 @pytest.mark.parametrize('pro', [0, 1, 2])
 def test_gemm_forward_modes(M, N, K, pro):
     t = T()
@@ -401,7 +404,8 @@ def test_flatten_gather_fused_into_the_cast_matches_the_unfused_scorer():
     assert torch.equal(T.cast_rows(flat, row_index=rows), T.cast_rows(flat[rows]))
 
 
-@pytest.mark.parametrize('M,N,K', [(300, 136, 72), (257, 512, 512), (700, 320, 320), (1000, 264, 128), (511, 256, 1024)])
+@pytest.mark.parametrize('M,N,K', [(300, 136, 72), (257, 512, 512), (700, 320, 320), (1000, 264, 128), (511, 256, 1024),
+                                   (34816, 512, 512), (22605, 768, 128), (2048, 256, 192)])
 def test_gemm_relu_bwd_epilogue(M, N, K):
     """dgrad form: C = (A . B^T) * 1[Zp * e_scale + e_shift > 0], stats = per-slab (sum C, sum C * zhat),
     zhat = (Zp - e_mean) * e_rstd -- both GEMM kernels (K % 64 decides), ragged edges."""
