@@ -842,7 +842,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   // alone 2360 (128 x 16 = 2048 is the floor), + fragment reads 3130, + LDS-DMA pieces 4440 -- the three add up
   // whatever the order: all pieces at the top of the step, one or two per block, alternating between the two waves of
   // a SIMD; fragment reads one or two half blocks ahead of their MFMAs; accumulators in VGPRs or (hand-assigned) in
-  // AGPRs; L2-warming touches two stages ahead.  None of these moved the step by more than 5 %.
+  // AGPRs; L2-warming touches two stages ahead; sched_group_barrier patterns (3 MFMAs : 1 LDS read).  None of these
+  // moved the step by more than 5 %.
   auto compute = [&](const unsigned char* ta, const unsigned char* tb, bool issue, const char* ab, const char* bb,
                      uint32_t dstbuf, int kt, int m0_) __attribute__((always_inline)) {
     const uint32_t dst_a = issue ? dstbuf + wave * 4096 : lds0 + P_STAGE + wave * 2048;
@@ -1647,6 +1648,151 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// 256 (n) x 256 (k) weight-gradient tile, 8 waves (4 over n x 2 over k: 64 x 128 each, acc[4][8]), both operands
+// staged by hand-issued LDS-DMA in 64-row steps, double buffered (2 x 64 KB), one workgroup per (M split, tile).
+// Needs N % 256 == 0, K % 256 == 0, M % (64 * splits) == 0 and no dropout (with the transposed fragments a lane holds
+// 8 rows of ONE column, so the keep mask would cost a hash per element); everything else takes the kernel above.
+// Against the 128 x 128 kernel: half the bytes through the CU per MAC (each dz / A row block is read by 2 instead of 4
+// workgroups), no register staging and no ds_write_b128 pass, the prologue applied to the operand fragments with the
+// column's scale / shift held in registers for the whole launch (a lane's fragments are always the same 8 columns).
+// LDS image of an operand stage: two [64][128] bf16 half tiles in the swizzle of the kernel above (swz_t / swz_t8).
+template <int PRO>
+__global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave & 3, wk = wave >> 2;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const int id = blockIdx.x, xcd = id & 7, jj = id >> 3, tiles = g.tiles_n * g.tiles_k;
+  const int split = (jj / tiles) * 8 + xcd, tile = jj % tiles;          // the tiles of one M slice on one XCD
+  if (split >= g.splits) return;
+  const int n0 = (tile % g.tiles_n) * 256, k0 = (tile / g.tiles_n) * 256;
+  const long ms = (long)split * g.rows_per_split;
+  const int steps = g.rows_per_split / 64;
+
+  // staging pieces: a half tile is 16 pieces of 4 rows x 256 B; wave w carries rows 8 w .. 8 w + 7 of all four
+  // half tiles (dz 0/1, A 0/1): 8 pieces per step
+  uint32_t offD[2], offA[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = wave * 8 + j * 4 + (lane >> 4);
+    const int cc = (lane & 15) ^ ((((r & 3) | ((r >> 1) & 4)) << 1));   // logical chunk that lands in physical slot lane & 15
+    offD[j] = (uint32_t)((r * g.lddz + cc * 8) * 2);
+    offA[j] = (uint32_t)((r * g.lda + cc * 8) * 2);
+  }
+  auto issue = [&](int st, int buf) __attribute__((always_inline)) {
+    const char* db = reinterpret_cast<const char*>(g.DZ) + ((ms + (long)st * 64) * g.lddz + n0) * 2;
+    const char* ab = reinterpret_cast<const char*>(g.A) + ((ms + (long)st * 64) * g.lda + k0) * 2;
+    const uint32_t dst = lds0 + buf * 65536 + wave * 2048;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        dma16_s(offD[j], db + h * 256, dst + h * 16384 + j * 1024);
+        dma16_s(offA[j], ab + h * 256, dst + 32768 + h * 16384 + j * 1024);
+      }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int trow = fr >> 2, tslot = fr & 3;       // this lane's piece of the [4][16] block of a transpose read
+  // byte offsets of this lane's transpose-read pieces inside a half tile, row block 0 (the swizzle term is the same for
+  // rows rb, rb + 4 and rb + 32: they are immediates on top of these)
+  const int rb0 = fq * 8 + trow;
+  uint32_t adD[4], adA[8];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) adD[f] = (uint32_t)swz_t8(rb0, ((wn & 1) * 64 + f * 16) / 4 + tslot);
+#pragma unroll
+  for (int f = 0; f < 8; ++f) adA[f] = (uint32_t)swz_t8(rb0, (f * 16) / 4 + tslot);
+  float scf[8], shf[8];                           // the prologue coefficients of this lane's 8 fragment columns
+  if (PRO != PRO_NONE) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {
+      const int k = k0 + wk * 128 + f * 16 + fr;
+      scf[f] = g.a_scale[k]; shf[f] = g.a_shift[k];
+    }
+  }
+
+  f32x4 acc[4][8];      // [fn][fk]: D[n][k]
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  issue(0, 0);
+  if (steps > 1) issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+#pragma unroll 1
+  for (int st = 0; st < steps; ++st) {
+    const int cur = st & 1;
+    const bool more = st >= 1 && st + 1 < steps;   // stage st + 1 -> the other buffer (stage 1 went out up front)
+    const unsigned char* td = smem + cur * 65536 + (wn >> 1) * 16384;            // dz half tile of this wave's 64 columns
+    const unsigned char* ta = smem + cur * 65536 + 32768 + wk * 16384;           // A half tile of its 128 columns
+    const char* db = reinterpret_cast<const char*>(g.DZ) + ((ms + (long)(st + 1) * 64) * g.lddz + n0) * 2;
+    const char* ab = reinterpret_cast<const char*>(g.A) + ((ms + (long)(st + 1) * 64) * g.lda + k0) * 2;
+    const uint32_t dst = more ? lds0 + (cur ^ 1) * 65536 + wave * 2048 : lds0 + cur * 65536 + wave * 2048;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {              // 32 rows of m per MFMA
+      bf16x8 fd[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const bf16x4 d0 = lds_tr16(td + adD[f] + kk * 8192), d1 = lds_tr16(td + adD[f] + kk * 8192 + 1024);
+        fd[f] = __builtin_shufflevector(d0, d1, 0, 1, 2, 3, 4, 5, 6, 7);
+      }
+#pragma unroll
+      for (int hk = 0; hk < 4; ++hk) {            // A fragments two at a time (register budget)
+        if (more && !(hk & 1)) {                  // 2 of the 8 pieces per two half blocks (uniform branch)
+          const int blk = kk * 2 + (hk >> 1), h = blk >> 1, j = blk & 1;
+          dma16_s(offD[j], db + h * 256, dst + h * 16384 + j * 1024);
+          dma16_s(offA[j], ab + h * 256, dst + 32768 + h * 16384 + j * 1024);
+        }
+        bf16x8 fa[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const bf16x4 a0 = lds_tr16(ta + adA[hk * 2 + f] + kk * 8192), a1 = lds_tr16(ta + adA[hk * 2 + f] + kk * 8192 + 1024);
+          bf16x8 v = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+          if (PRO != PRO_NONE) {
+            const uint4 u = __builtin_bit_cast(uint4, v);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            uint32_t o[4];
+            const float sc = scf[hk * 2 + f], sh = shf[hk * 2 + f];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x0 = __builtin_fmaf(bf16_lo(w[i]), sc, sh), x1 = __builtin_fmaf(bf16_hi(w[i]), sc, sh);
+              uint32_t pk = pack_bf16(x0, x1);
+              if (PRO == PRO_AFFINE_RELU)
+                pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
+              o[i] = pk;
+            }
+            v = __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
+          }
+          fa[f] = v;
+        }
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+            acc[fn][hk * 2 + f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[fn], fa[f], acc[fn][hk * 2 + f], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  // D[n = nb + 4 fq + r][k = kb + fr]
+  float* out = g.slab + (long)split * g.N * g.ldw;
+#pragma unroll
+  for (int fn = 0; fn < 4; ++fn)
+#pragma unroll
+    for (int fk = 0; fk < 8; ++fk) {
+      const int k = k0 + wk * 128 + fk * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + fn * 16 + fq * 4 + r;
+        out[(long)n * g.ldw + k] = acc[fn][fk][r];
+      }
+    }
+}
+
 // out[i] (+)= sum_s slab[s][i]
 __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, long n, float* __restrict__ out,
                                          int accumulate) {
@@ -2030,11 +2176,22 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
   WgradArgs g;
   g.DZ = (const uint16_t*)DZ; g.lddz = lddz; g.A = (const uint16_t*)A; g.lda = lda; g.a_scale = a_scale;
   g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.drop = to_drop(dropout);
+  hipStream_t st = (hipStream_t)stream;
+  static const bool big = [] { const char* e = getenv("TFR_WGRAD_256"); return !(e && *e) || atoi(e) != 0; }();
+  if (big && (N % 256) == 0 && (K % 256) == 0 && g.drop.thr == 0 && ((long)M % (64L * splits)) == 0 &&
+      lddz < (1L << 21) && lda < (1L << 21)) {
+    g.rows_per_split = (int)((long)M / splits);
+    g.splits = splits; g.tiles_n = N / 256; g.tiles_k = K / 256;
+    const dim3 grid256((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
+#define WG2(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad256_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad256_kernel<P>, grid256, dim3(512), 131072, st, g); } while (0)
+    if (prologue == PRO_NONE) WG2(PRO_NONE); else if (prologue == PRO_AFFINE) WG2(PRO_AFFINE); else WG2(PRO_AFFINE_RELU);
+#undef WG2
+    return (int)hipGetLastError();
+  }
   int rows = (int)(((long)M + splits - 1) / splits);
   g.rows_per_split = (rows + 63) / 64 * 64;
   g.splits = splits; g.tiles_n = (N + 127) / 128; g.tiles_k = (K + 127) / 128;
   const dim3 grid((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
-  hipStream_t st = (hipStream_t)stream;
 #define WG(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad_kernel<P>, grid, dim3(256), 65536, st, g); } while (0)
   if (prologue == PRO_NONE) WG(PRO_NONE); else if (prologue == PRO_AFFINE) WG(PRO_AFFINE); else WG(PRO_AFFINE_RELU);
 #undef WG

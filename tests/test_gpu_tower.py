@@ -126,7 +126,9 @@ def test_bn_finalize_and_out_layer():
         assert torch.allclose(got, want, atol=2e-3, rtol=1e-4), (pro, (got - want).abs().max().item())
 
 
-@pytest.mark.parametrize('M,N,K', [(64, 128, 128), (1, 8, 8), (300, 136, 512), (1000, 512, 136), (4097, 264, 200)])
+@pytest.mark.parametrize('M,N,K', [(64, 128, 128), (1, 8, 8), (300, 136, 512), (1000, 512, 136), (4097, 264, 200),
+                                   # the 256 x 256 kernel (N, K multiples of 256, M a multiple of 64 * splits)
+                                   (4096, 256, 256), (8192, 512, 512), (51200, 512, 256)])
 @pytest.mark.parametrize('pro', [0, 2])
 def test_wgrad(M, N, K, pro):
     t = T()
@@ -137,7 +139,7 @@ def test_wgrad(M, N, K, pro):
     if pro:
         a = torch.relu(a * sc + sh).to(torch.bfloat16).float()
     want = dz.float().t() @ a
-    for splits in (0, 1, 3):
+    for splits in (0, 1, 3, 4):
         got = t.wgrad(dz, A, N, K, prologue=pro, a_scale=sc if pro else None, a_shift=sh if pro else None,
                       splits=splits)
         err = (got - want).abs().max().item()
