@@ -253,7 +253,7 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         sgd()
         return s[0] / max(world, 1)
 
-    info = dict(kernel=None, kernel_name='whole training step (tower_gemm256_kernel / tower_wgrad_kernel dominate)',
+    info = dict(kernel=None, kernel_name='whole training step (tower_gemm256p_kernel / tower_wgrad256_kernel dominate)',
                 all_reduce_bytes=int(bucket.flat.numel() * 4), params=int(bucket.numel))
     if not use_graph:
         scal = torch.zeros(2, device=dev)

@@ -842,8 +842,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   // alone 2360 (128 x 16 = 2048 is the floor), + fragment reads 3130, + LDS-DMA pieces 4440 -- the three add up
   // whatever the order: all pieces at the top of the step, one or two per block, alternating between the two waves of
   // a SIMD; fragment reads one or two half blocks ahead of their MFMAs; accumulators in VGPRs or (hand-assigned) in
-  // AGPRs; L2-warming touches two stages ahead; sched_group_barrier patterns (3 MFMAs : 1 LDS read).  None of these
-  // moved the step by more than 5 %.
+  // AGPRs; L2-warming touches two stages ahead; sched_group_barrier patterns (3 MFMAs : 1 LDS read); the same flops as
+  // half as many v_mfma_f32_32x32x16_bf16.  None of these moved the step by more than 5 %.
   auto compute = [&](const unsigned char* ta, const unsigned char* tb, bool issue, const char* ab, const char* bb,
                      uint32_t dstbuf, int kt, int m0_) __attribute__((always_inline)) {
     const uint32_t dst_a = issue ? dstbuf + wave * 4096 : lds0 + P_STAGE + wave * 2048;
@@ -1875,7 +1875,7 @@ int launch_gemm256(const GemmArgs& g0, hipStream_t st) {
 // Persistent kernel over the full 256-row tiles, the kernel above over a ragged rest.
 template <int PRO, int EPI>
 int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
-  static const int flags = [] { const char* e = getenv("TFR_GEMM_FLAGS"); return (e && *e) ? atoi(e) : (PF_TOUCH_A | PF_TOUCH_Z); }();
+  static const int flags = [] { const char* e = getenv("TFR_GEMM_FLAGS"); return (e && *e) ? atoi(e) : 0; }();   // PF_TOUCH_Z: measured, no gain, +47 % fetch
   GemmArgs g = g0;
   const int m_full = g0.M & ~(BM2 - 1);
   g.M = m_full;

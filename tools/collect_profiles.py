@@ -62,16 +62,42 @@ def main(tag):
         if vals.get('fetch_kib') and vals.get('write_kib'):
             traffic[w] = dict(B=B, L=L, kernel=sub, algorithmic_bytes=(12 * L + 12) * B,
                               traffic_bytes=int(round((vals['fetch_kib'] * 2 + vals['write_kib']) * 1024)), **vals)
+    e2e = None
+    pf, pw = os.path.join(R, 'pmc_fetch_e2e_softmax.txt'), os.path.join(R, 'pmc_write_e2e_softmax.txt')
+    if os.path.exists(pf) and os.path.exists(pw):
+        for c, p in (('fetch', pf), ('write', pw)):
+            pm.append('## rocprofv3 --pmc <%s counters> -- python bench.py --workload e2e_softmax --steps 20 --warmup 2 '
+                      '--no-cpu-baseline --also none\n%s\n' % (c, open(p).read().rstrip()))
+        M, W = 4096 * 100, 512
+        unit = M * W * 2                                         # one [M, 512] bf16 matrix
+        names = {'tower_gemm256p_kernel<0, 2, false>': ('dgrad, the longest kernel of the step: reads dz and Zp, writes dy', 3 * unit),
+                 'tower_gemm256p_kernel<2, 1, false>': ('forward hidden layer: reads z, writes z', 2 * unit),
+                 'tower_wgrad256_kernel<2>': ('weight gradient: reads dz and z; writes 64 fp32 split slabs of [512, 512]', 2 * unit),
+                 'tower_bn_bwd_apply_kernel': ('dz = p dy + q z + r in place', 3 * unit),
+                 'tower_out_bwd_kernel<2, 1, 64, 1>': ('last layer backward, sums only', unit),
+                 'tower_out_bwd_kernel<2, 1, 64, 2>': ('last layer backward, recompute dy, write dz', 2 * unit)}
+        ent = {}
+        for k, (note, alg) in names.items():
+            f, w = pmc_mean(pf, k, 'FETCH_SIZE'), pmc_mean(pw, k, 'WRITE_SIZE')
+            if f is not None and w is not None:
+                ent[k] = dict(note=note, fetch_kib=f, write_kib=w, algorithmic_bytes=alg,
+                              traffic_bytes=int(round((2 * f + w) * 1024)))
+        k0 = 'tower_gemm256p_kernel<0, 2, false>'
+        if k0 in ent:
+            e2e = dict(B=4096, L=100, kernel=k0 + ' (' + ent[k0]['note'] + ')', fetch_kib=ent[k0]['fetch_kib'],
+                       write_kib=ent[k0]['write_kib'], traffic_bytes=ent[k0]['traffic_bytes'],
+                       algorithmic_bytes=ent[k0]['algorithmic_bytes'], others={k: v for k, v in ent.items() if k != k0})
     open(os.path.join(ROOT, 'profiles', 'r02_pmc.txt'), 'w').write('\n'.join(pm))
     tp = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
     old = json.load(open(tp)) if os.path.exists(tp) else {}
     old['_comment'] = ('HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per '
                        'dispatch, mean over dispatches; visit %s, tables in profiles/r02_pmc.txt), corrected as MI355X_MICROARCH.md '
                        'prescribes for gfx950 (FETCH_SIZE x 2 for wide coalesced reads).  bench.py copies the entry that matches its '
-                       'workload and batch into roofline.traffic and says so in roofline.traffic_source.  e2e_softmax: round-1 figures '
-                       '(profiles/r01_traffic.json), the tower kernels are unchanged.' % tag)
+                       'workload and batch into roofline.traffic and says so in roofline.traffic_source.' % tag)
     for w, v in traffic.items():
         old[w] = v
+    if e2e is not None:
+        old['e2e_softmax'] = e2e
     json.dump(old, open(tp, 'w'), indent=1)
     for w, v in traffic.items():
         print(w, 'traffic / algorithmic = %.3f' % (v['traffic_bytes'] / v['algorithmic_bytes']))
