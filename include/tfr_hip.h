@@ -162,14 +162,15 @@ int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* 
  *   pos_weight   nullable [L]: rank_discount_fn(p + 1) of a ListMLELambdaWeight (host table)
  *   loss_out     [B] negative log likelihood per list (the list weight is 1)
  *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
- * list_size <= 1024 (TFR_ETOOLARGE otherwise); ties between equal labels keep index order. */
+ * list_size <= 4096 (one wavefront per list up to 1024, one workgroup beyond; TFR_ETOOLARGE otherwise); ties between
+ * equal labels keep index order. */
 int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                      const float* pos_weight, const float* list_scale, int B, int L,
                      float temperature, float* loss_out, float* dlogits_out, void* stream);
 
 /* losses_impl.UniqueSoftmaxLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:1250-1281): loss_b = sum_i (2^l_i - 1) (log(e^s_i + sum_{j: l_j < l_i} e^s_j) - s_i).
- * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 1024). */
+ * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 4096). */
 int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
                            const float* list_scale, int B, int L, float temperature,
                            float* loss_out, float* dlogits_out, void* stream);
@@ -189,7 +190,7 @@ int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels,
  * clipped to [0, 1]; weight[b] = 1, or NaN for a list without any preference pair (the reference's 0 / 0);
  * dlogits = d loss / d logits (x list_scale[b]).  clip != 0 applies get_logits' clip_by_value(0, 1) in
  * the kernel (compute()); compute_per_list / compute_unreduced_loss hand the scores over as they are.
- * L <= 1024. */
+ * L <= 4096 (one wavefront per list up to 1024, one workgroup beyond). */
 int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                         const float* list_scale, int B, int L, float gamma, float margin, int clip,
                         float* loss_out, float* weight_out, float* dlogits_out, void* stream);

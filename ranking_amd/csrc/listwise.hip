@@ -418,15 +418,288 @@ __global__ __launch_bounds__(64) void circle_wave_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Workgroup forms for 1024 < list_size <= 4096 (the register sort of the wave kernels does not fit beyond 16 keys per
+// lane): keys and per-position values in LDS, block_bitonic_sort_desc, Hillis-Steele scans.  Same arithmetic as the
+// wave kernels; the scans associate differently, so results agree to rounding, not bit for bit.
+template <typename T, typename Op>
+__device__ __forceinline__ void block_scan_inclusive(T* a, T* scratch, int P, Op op) {    // result ends in `a`
+  T* src = a;
+  T* dst = scratch;
+  for (int o = 1; o < P; o <<= 1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += blockDim.x) dst[i] = (i >= o) ? op(src[i - o], src[i]) : src[i];
+    T* t = src; src = dst; dst = t;
+  }
+  __syncthreads();
+  if (src != a) {
+    for (int i = threadIdx.x; i < P; i += blockDim.x) a[i] = src[i];
+    __syncthreads();
+  }
+}
+struct ScanAdd { __device__ float operator()(float a, float b) const { return a + b; } };
+struct ScanMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+struct ScanMinI { __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
+
+__global__ __launch_bounds__(1024) void list_mle_block_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int L, int P, float temperature,
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] logits by original index, then scan scratch
+  float* XP = XS + P;                                             // [P] logit - max by sorted position
+  float* SA = XP + P;                                             // [P] reversed e -> suffix sums
+  float* CA = SA + P;                                             // [P] w / S -> prefix sums
+  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const size_t base = (size_t)b * L;
+  for (int i = tid; i < P; i += T) {
+    uint64_t k = 0;
+    float x = 0.f;
+    if (i < L) {
+      const float lab = labels[base + i];
+      const bool v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      x = v ? logits[base + i] / temperature : kLogEps;
+      k = make_sort_key(v, v ? lab : 0.0f, 0, i);                 // valid first, label desc, then index
+    }
+    keys[i] = k; XS[i] = x;
+  }
+  block_bitonic_sort_desc(keys, P);
+  float mx = -INFINITY;
+  for (int p = tid; p < L; p += T) mx = fmaxf(mx, XS[sort_key_index(keys[p])]);
+  mx = block_max(mx, red);
+  for (int p = tid; p < P; p += T) {
+    const float x = (p < L) ? XS[sort_key_index(keys[p])] - mx : -INFINITY;
+    XP[p] = x;
+    SA[P - 1 - p] = (p < L) ? expf(x) : 0.0f;
+  }
+  __syncthreads();
+  block_scan_inclusive(SA, XS, P, ScanAdd());                     // S_p = SA[P - 1 - p] = sum_{q >= p} e_q
+  float term = 0.f;
+  for (int p = tid; p < P; p += T) {
+    float c = 0.f;
+    if (p < L) {
+      const float w = pos_weight ? pos_weight[p] : 1.0f, S = SA[P - 1 - p];
+      term += w * (logf(S) - XP[p]);
+      c = w / S;
+    }
+    CA[p] = c;
+  }
+  const float loss = block_sum(term, red);
+  if (tid == 0) loss_out[b] = loss;
+  if (!dlogits_out) return;
+  __syncthreads();
+  block_scan_inclusive(CA, XS, P, ScanAdd());                     // C_p = sum_{q <= p} w_q / S_q
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) / temperature;
+  for (int p = tid; p < L; p += T) {
+    const uint64_t k = keys[p];
+    const float w = pos_weight ? pos_weight[p] : 1.0f;
+    dlogits_out[base + sort_key_index(k)] = (k >> 63) ? (expf(XP[p]) * CA[p] - w) * gscale : 0.0f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ list_scale, int L, int P, float temperature, float* __restrict__ loss_out,
+    float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] logits by original index -> suffix sums (SA)
+  float* LB = XS + P;                                             // [P] labels by original index -> scan scratch (SB)
+  float* XP = LB + P;                                             // [P] logit - max by sorted position
+  float* LP = XP + P;                                             // [P] label by sorted position
+  int* GS = reinterpret_cast<int*>(LP + P);                       // [P] first position of the label group
+  int* GE = GS + P;                                               // [P] one past its last position (reversed index)
+  float* CA = reinterpret_cast<float*>(GE + P);                   // [P] g / D -> prefix sums
+  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const size_t base = (size_t)b * L;
+  int nvl = 0;
+  for (int i = tid; i < P; i += T) {
+    uint64_t k = 0;
+    float x = 0.f, lb = 0.f;
+    if (i < L) {
+      const float lab = labels[base + i];
+      const bool v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
+      x = v ? logits[base + i] / temperature : 0.0f;
+      lb = v ? lab : 0.0f;
+      k = make_sort_key(v, lb, 0, i);
+      nvl += v ? 1 : 0;
+      if (dlogits_out && !v) dlogits_out[base + i] = 0.0f;
+    }
+    keys[i] = k; XS[i] = x; LB[i] = lb;
+  }
+  const int nv = (int)(block_sum((float)nvl, red) + 0.5f);       // < 2^24: exact
+  block_bitonic_sort_desc(keys, P);                               // valid first, label descending, then index
+  float mx = -INFINITY;
+  for (int p = tid; p < nv; p += T) mx = fmaxf(mx, XS[sort_key_index(keys[p])]);
+  mx = block_max(mx, red);
+  for (int p = tid; p < P; p += T) {
+    const int idx = sort_key_index(keys[p]);
+    XP[p] = (p < nv) ? XS[idx] - mx : -INFINITY;
+    LP[p] = (p < nv) ? LB[idx] : -INFINITY;
+  }
+  __syncthreads();
+  float* SA = XS;                                                 // (the by-index arrays are dead now)
+  float* SB = LB;
+  for (int p = tid; p < P; p += T) {
+    SA[P - 1 - p] = (p < nv) ? expf(XP[p]) : 0.0f;
+    // tie groups: position p opens a group iff its label is below the previous one; closes one iff the next is below
+    const bool first = p < nv && (p == 0 || LP[p] < LP[p - 1]);
+    const bool last = p < nv && (p + 1 >= nv || LP[p + 1] < LP[p]);
+    GS[p] = first ? p : -1;
+    GE[P - 1 - p] = last ? p + 1 : 0x7fffffff;
+  }
+  __syncthreads();
+  block_scan_inclusive(SA, SB, P, ScanAdd());                     // SUF[p] = SA[P - 1 - p] = sum_{q >= p} e_q
+  block_scan_inclusive(GS, reinterpret_cast<int*>(SB), P, ScanMaxI());      // group start
+  block_scan_inclusive(GE, reinterpret_cast<int*>(SB), P, ScanMinI());      // group end, reversed: GE[P - 1 - p]
+  float term = 0.f;
+  for (int p = tid; p < P; p += T) {
+    float c = 0.f;
+    if (p < nv) {
+      const int ge = GE[P - 1 - p];
+      const float e = expf(XP[p]), D = e + (ge < P ? SA[P - 1 - ge] : 0.0f), g = gain_pow2m1(LP[p]);
+      term += g * (logf(D) - XP[p]);
+      c = g / D;
+    }
+    CA[p] = c;
+  }
+  const float loss = block_sum(term, red);
+  if (tid == 0) loss_out[b] = loss;
+  if (!dlogits_out) return;
+  __syncthreads();
+  block_scan_inclusive(CA, SB, P, ScanAdd());                     // inclusive prefix of g / D
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) / temperature;
+  for (int p = tid; p < nv; p += T) {
+    const int ge = GE[P - 1 - p], gs = GS[p];
+    const float e = expf(XP[p]), D = e + (ge < P ? SA[P - 1 - ge] : 0.0f), g = gain_pow2m1(LP[p]);
+    const float higher = gs > 0 ? CA[gs - 1] : 0.0f;              // sum over strictly higher labels
+    dlogits_out[base + sort_key_index(keys[p])] = (-g + e * (g / D + higher)) * gscale;
+  }
+}
+
+__global__ __launch_bounds__(1024) void circle_block_kernel(
+    const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
+    const float* __restrict__ list_scale, int L, int P, float gamma, float margin, int clip,
+    float* __restrict__ loss_out, float* __restrict__ weight_out, float* __restrict__ dlogits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);               // [32]
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
+  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] raw logits by original index -> suffix sums of F
+  float* LB = XS + P;                                             // [P] labels by original index -> scan scratch
+  float* SP = LB + P;                                             // [P] raw score by sorted position
+  float* LP = SP + P;                                             // [P] label by sorted position
+  int* GS = reinterpret_cast<int*>(LP + P);                       // [P] first position of the label group
+  int* GE = GS + P;                                               // [P] one past its last position (reversed index)
+  float* EA = reinterpret_cast<float*>(GE + P);                   // [P] E -> inclusive prefix sums
+  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const size_t base = (size_t)b * L;
+  int nvl = 0;
+  for (int i = tid; i < P; i += T) {
+    uint64_t k = 0;
+    float x = 0.f, lb = 0.f;
+    if (i < L) {
+      lb = labels[base + i];
+      const bool v = mask ? (mask[base + i] != 0) : (lb >= 0.0f);
+      x = logits[base + i];
+      k = make_sort_key(v, v ? lb : 0.0f, 0, i);
+      nvl += v ? 1 : 0;
+      if (dlogits_out && !v) dlogits_out[base + i] = 0.0f;
+    }
+    keys[i] = k; XS[i] = x; LB[i] = lb;
+  }
+  const int nv = (int)(block_sum((float)nvl, red) + 0.5f);
+  block_bitonic_sort_desc(keys, P);                               // valid first, label descending, then index
+  // per position: a_p = gamma * alpha_i (1 - margin - s), b_p = gamma * alpha'_j (s - margin)
+  auto ga_of = [&](float raw) { const float sc = clip ? fminf(fmaxf(raw, 0.0f), 1.0f) : raw;
+                                return gamma * (fmaxf(1.0f - sc + margin, 0.0f) * (1.0f - sc - margin)); };
+  auto gb_of = [&](float raw) { const float sc = clip ? fminf(fmaxf(raw, 0.0f), 1.0f) : raw;
+                                return gamma * (fmaxf(sc + margin, 0.0f) * (sc - margin)); };
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int p = tid; p < P; p += T) {
+    const int idx = sort_key_index(keys[p]);
+    const float raw = (p < nv) ? XS[idx] : 0.0f;
+    SP[p] = raw;
+    LP[p] = (p < nv) ? LB[idx] : -INFINITY;
+    if (p < nv) { ma = fmaxf(ma, ga_of(raw)); mb = fmaxf(mb, gb_of(raw)); }
+  }
+  const float MA = block_max(ma, red), MB = block_max(mb, red);
+  __syncthreads();
+  float* SA = XS;
+  float* SB = LB;
+  for (int p = tid; p < P; p += T) {
+    const bool in = p < nv;
+    SA[P - 1 - p] = in ? expf(gb_of(SP[p]) - MB) : 0.0f;
+    EA[p] = in ? expf(ga_of(SP[p]) - MA) : 0.0f;
+    const bool first = in && (p == 0 || LP[p] < LP[p - 1]);
+    const bool last = in && (p + 1 >= nv || LP[p + 1] < LP[p]);
+    GS[p] = first ? p : -1;
+    GE[P - 1 - p] = last ? p + 1 : 0x7fffffff;
+  }
+  __syncthreads();
+  block_scan_inclusive(SA, SB, P, ScanAdd());                     // SUF[p] = SA[P - 1 - p] = sum_{q >= p} F_q
+  block_scan_inclusive(EA, SB, P, ScanAdd());                     // inclusive prefix of E
+  block_scan_inclusive(GS, reinterpret_cast<int*>(SB), P, ScanMaxI());
+  block_scan_inclusive(GE, reinterpret_cast<int*>(SB), P, ScanMinI());
+  // t_p = log( e^{ga_p} * sum_{y_q < y_p} e^{gb_q} );  lw = logsumexp_p t_p = log W
+  auto t_of = [&](int p) {
+    const int ge = GE[P - 1 - p];
+    const float lower = ge < P ? SA[P - 1 - ge] : 0.0f;
+    return lower > 0.0f ? ga_of(SP[p]) + (MB + logf(lower)) : -INFINITY;
+  };
+  float tm = -INFINITY;
+  for (int p = tid; p < nv; p += T) tm = fmaxf(tm, t_of(p));
+  tm = block_max(tm, red);
+  const bool any_pair = tm > -INFINITY;
+  float acc = 0.f;
+  for (int p = tid; p < nv; p += T) { const float t = t_of(p); acc += (t > -INFINITY) ? expf(t - tm) : 0.0f; }
+  acc = block_sum(acc, red);
+  const float lw = any_pair ? tm + logf(acc) : -INFINITY;
+  const float loss = any_pair ? (fmaxf(lw, 0.0f) + log1pf(expf(-fabsf(lw)))) : 0.0f;      // log1p(W)
+  if (tid == 0) {
+    loss_out[b] = loss;
+    if (weight_out) weight_out[b] = any_pair ? 1.0f : NAN;
+  }
+  if (!dlogits_out) return;
+  const float sig = any_pair ? 1.0f / (1.0f + expf(-lw)) : 0.0f;                          // W / (1 + W)
+  const float gscale = (list_scale ? list_scale[b] : 1.0f) * gamma * sig;
+  for (int p = tid; p < nv; p += T) {
+    const float raw = SP[p];
+    const float sc = clip ? fminf(fmaxf(raw, 0.0f), 1.0f) : raw;
+    const bool inside = !clip || (raw >= 0.0f && raw <= 1.0f);   // clip_by_value passes the gradient on [0, 1]
+    float gpart = 0.f;
+    if (any_pair && inside) {
+      const float t = t_of(p);
+      const float hi = (t > -INFINITY) ? expf(t - lw) : 0.0f;                             // item as the preferred one
+      const int gs = GS[p];
+      const float higher = gs > 0 ? EA[gs - 1] : 0.0f;
+      const float lo = (higher > 0.0f) ? expf(gb_of(raw) + (MA + logf(higher)) - lw) : 0.0f;   // item as the other one
+      gpart = -fmaxf(1.0f - sc + margin, 0.0f) * hi + fmaxf(sc + margin, 0.0f) * lo;
+    }
+    dlogits_out[base + sort_key_index(keys[p])] = gscale * gpart;
+  }
+}
+
 }  // namespace
 
 extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                                 const float* pos_weight, const float* list_scale, int B, int L,
                                 float temperature, float* loss_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (L > 4096) return TFR_ETOOLARGE;            // 24 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (L > 1024) {
+    const int P = pow2_ceil(L);
+    const size_t lds = 128 + (size_t)P * 24;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_mle_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(list_mle_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, pos_weight, list_scale, L, P,
+                       temperature, loss_out, dlogits_out);
+    return (int)hipGetLastError();
+  }
 #define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out)
   if (L <= 64) LM(1); else if (L <= 128) LM(2); else if (L <= 256) LM(4); else if (L <= 512) LM(8); else LM(16);
 #undef LM
@@ -437,9 +710,18 @@ extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, 
                                       const float* list_scale, int B, int L, float temperature,
                                       float* loss_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (L > 4096) return TFR_ETOOLARGE;            // 36 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (L > 1024) {
+    const int P = pow2_ceil(L);
+    const size_t lds = 128 + (size_t)P * 36;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unique_softmax_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(unique_softmax_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, list_scale, L, P,
+                       temperature, loss_out, dlogits_out);
+    return (int)hipGetLastError();
+  }
 #define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out)
   if (L <= 64) US(1); else if (L <= 128) US(2); else if (L <= 256) US(4); else if (L <= 512) US(8); else US(16);
 #undef US
@@ -450,9 +732,18 @@ extern "C" int tfr_circle_loss_f32(const float* logits, const float* labels, con
                                    const float* list_scale, int B, int L, float gamma, float margin, int clip,
                                    float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (L > 4096) return TFR_ETOOLARGE;            // 36 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
+  if (L > 1024) {
+    const int P = pow2_ceil(L);
+    const size_t lds = 128 + (size_t)P * 36;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&circle_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(circle_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, list_scale, L, P, gamma, margin,
+                       clip, loss_out, weight_out, dlogits_out);
+    return (int)hipGetLastError();
+  }
 #define CL(I) hipLaunchKernelGGL(circle_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, gamma, margin, clip, loss_out, weight_out, dlogits_out)
   if (L <= 64) CL(1); else if (L <= 128) CL(2); else if (L <= 256) CL(4); else if (L <= 512) CL(8); else CL(16);
 #undef CL

@@ -860,7 +860,7 @@ def test_more_metrics_keras_and_factory_keys():
 
 
 # ------------------------------------------------------------------ ListMLE
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300)])
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096)])       # > 1024: the workgroup kernel
 @pytest.mark.parametrize('with_lambda', [False, True])
 def test_list_mle_parity(B, L, with_lambda):
     labels, logits = make_batch(B, L, seed=1100 + L)
@@ -933,7 +933,7 @@ def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_
 
 
 # ------------------------------------------------------------------ UniqueSoftmax
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300)])
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096)])       # > 1024: the workgroup kernel
 def test_unique_softmax_parity(B, L):
     labels, logits = make_batch(B, L, seed=1300 + L)        # graded labels: plenty of tie groups
     if B >= 3:
@@ -1103,7 +1103,7 @@ def test_neural_sort_reference_goldens():
 
 
 # ------------------------------------------------------------------ Circle loss
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40)])
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40), (3, 1500), (2, 4096)])        # > 1024: the workgroup kernel
 @pytest.mark.parametrize('gamma,margin,lo,hi', [(64., 0.25, 0.2, 0.6), (4., 0.1, -0.3, 1.3), (16., 0.25, 0.0, 1.0)])
 def test_circle_loss_parity(B, L, gamma, margin, lo, hi):
     labels, logits = make_batch(B, L, seed=1700 + L)
