@@ -49,7 +49,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 7, 0, 0.0, 0, 0, None, one, 1, 8, 1.0,
                                          None, None, None, None, None) == -1       # lambda kind
     assert lib.tfr_list_order_i32(None, None, 4, 8, one, one, None) == -1
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 2000, 1.0, one, None, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, None) == -2
     assert lib.tfr_rank_metric_f32(12, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, None) == -1
     topn = (ctypes.c_int32 * 1)(10)
     assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
