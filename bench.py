@@ -727,6 +727,24 @@ def main(argv=None):
     also = DEFAULT_ALSO if (args.also is None and args.workload == 'approx_ndcg') else tuple(
         w for w in (args.also or '').split(',') if w and w != 'none')
     extra = {}
+
+    def emit_and_leave(why):
+        """N > 1 only: the extra workloads run collectives; a rank that fails or stalls inside one must not take the
+        headline line down with it.  Rank 0 prints the line with what it has, every rank leaves without the
+        process-group teardown (which would wait for the stuck peers)."""
+        if rank == 0:
+            result['rccl_ranks'] = rccl_ranks
+            extra.setdefault('error', why)
+            result['also'] = extra
+            print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+
+    if world > 1 and also:
+        import signal
+        budget = int(os.environ.get('TFR_BENCH_ALSO_BUDGET_S', '420'))
+        signal.signal(signal.SIGALRM, lambda *_: emit_and_leave('extra workloads exceeded %d s at %d ranks' % (budget, world)))
+        signal.alarm(budget)
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit('unknown workload in --also: %s' % w)
@@ -734,10 +752,12 @@ def main(argv=None):
             r = run_workload(w, args, dist, rank, world, dev, max(10, min(args.steps, 50)),
                              max(3, min(args.warmup, 10)), 4.0)
         except Exception as e:                              # an extra line must never take the headline down
-            if world > 1:
-                raise                                       # ... but ranks must not diverge inside collectives
+            if world > 1:                                   # ... and the ranks must not diverge inside collectives
+                emit_and_leave('%s: %s: %s' % (w, type(e).__name__, e))
             r = {'error': '%s: %s' % (type(e).__name__, e)}
         extra[w] = r
+    if world > 1 and also:
+        signal.alarm(0)
     if rank == 0:
         result['rccl_ranks'] = rccl_ranks
         if extra:
