@@ -286,7 +286,11 @@ int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const u
  * epilogue: 0 = plain, 1 = + per-column partial sums (sum z, sum z^2) per 64-row half tile into
  * stats[tfr_tower_gemm_stats_rows(M)][2][N] (the next BatchNormalization's batch statistics),
  * 2 = backward of relu/BN-input: C = acc * 1[Zp*e_scale + e_shift > 0], stats = partial
- * (sum dy, sum dy * zhat) with zhat = (Zp - e_mean) * e_rstd.                              */
+ * (sum dy, sum dy * zhat) with zhat = (Zp - e_mean) * e_rstd.
+ * Activations other than ReLU (keras/layers.py:66-70 takes any Keras activation): prologue 3 | act << 8 =
+ * act(A*scale[k] + shift[k]), epilogue 3 | act << 8 = C = acc * act'(Zp*e_scale + e_shift) with the same stats;
+ * act: 1 tanh, 2 sigmoid, 3 elu (alpha = 1), 4 softplus, 5 swish.  (Prologue 3 with epilogues 2 / 3, and
+ * epilogue 3 with a prologue, are TFR_EINVAL: no tower runs them.)                              */
 
 /* Dropout after a hidden activation (keras/layers.py:72-73).  HOST struct, nullable everywhere
  * (NULL or threshold16 == 0: no dropout).  Element (row m, column k) of the layer is kept iff 16

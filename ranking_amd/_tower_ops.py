@@ -41,8 +41,18 @@ def dropout_mask(d: 'Dropout', M: int, K: int, device) -> torch.Tensor:
     return keep.to(torch.float32) * float(d.scale)
 
 
-PRO_NONE, PRO_AFFINE, PRO_AFFINE_RELU = 0, 1, 2
-EPI_PLAIN, EPI_STATS, EPI_RELU_BWD = 0, 1, 2
+PRO_NONE, PRO_AFFINE, PRO_AFFINE_RELU, PRO_AFFINE_ACT = 0, 1, 2, 3
+EPI_PLAIN, EPI_STATS, EPI_RELU_BWD, EPI_ACT_BWD = 0, 1, 2, 3
+# activations other than ReLU: the code rides in bits 8.. of the `prologue` / `epilogue` arguments (include/tfr_hip.h)
+ACT_CODES = {'tanh': 1, 'sigmoid': 2, 'elu': 3, 'softplus': 4, 'swish': 5}
+
+
+def pro_act(name: str) -> int:
+    return PRO_AFFINE_ACT | (ACT_CODES[name] << 8)
+
+
+def epi_act_bwd(name: str) -> int:
+    return EPI_ACT_BWD | (ACT_CODES[name] << 8)
 
 
 def _bf16(t, name):
@@ -155,7 +165,7 @@ def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, e
     M = A.shape[0]
     C = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     stats = None
-    if epilogue != EPI_PLAIN:
+    if (epilogue & 0xff) != EPI_PLAIN:
         stats = torch.empty((stats_rows(M), 2, N), dtype=torch.float32, device=A.device)
     _lib.check(_lib.load().tfr_tower_gemm_bf16(
         _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), M, N, K, prologue,

@@ -101,15 +101,40 @@ struct GemmArgs {
   int M, N, K, tiles_m, tiles_n;
   int stagger_phases, stagger_sleeps;  // 256 x 256 kernel: first-round workgroups of phase p idle p * sleeps * s_sleep(127)
   int flags;                           // persistent 256 x 256 kernel: PF_* bits
+  int act;                             // ACT_* of PRO_AFFINE_ACT / EPI_ACT_BWD
   int row0;                            // global index of row 0 of A / C (dropout hash) when a launch covers a row range
 };
 
-enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2 };
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_RELU_BWD = 2 };
+enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2, PRO_AFFINE_ACT = 3 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_RELU_BWD = 2, EPI_ACT_BWD = 3 };
+// Activations other than ReLU (keras/layers.py:66-70: tf.keras.layers.Activation(activation) after the BatchNorm): the
+// PRO_AFFINE_ACT prologues apply act(z * scale + shift), the EPI_ACT_BWD epilogue multiplies by act'(.) of the
+// recomputed pre-activation.  The code travels in bits 8.. of the C ABI's `prologue` / `epilogue` arguments.
+enum { ACT_TANH = 1, ACT_SIGMOID = 2, ACT_ELU = 3, ACT_SOFTPLUS = 4, ACT_SWISH = 5, ACT_LAST = 5 };
+__device__ __forceinline__ float act_fwd(int act, float y) {
+  switch (act) {
+    case ACT_TANH: return tanhf(y);
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-y));
+    case ACT_ELU: return y > 0.f ? y : expm1f(y);
+    case ACT_SOFTPLUS: return fmaxf(y, 0.f) + log1pf(expf(-fabsf(y)));
+    case ACT_SWISH: return y / (1.0f + expf(-y));
+  }
+  return y;
+}
+__device__ __forceinline__ float act_grad(int act, float y) {
+  switch (act) {
+    case ACT_TANH: { const float t = tanhf(y); return 1.0f - t * t; }
+    case ACT_SIGMOID: { const float t = 1.0f / (1.0f + expf(-y)); return t * (1.0f - t); }
+    case ACT_ELU: return y > 0.f ? 1.0f : expf(y);
+    case ACT_SOFTPLUS: return 1.0f / (1.0f + expf(-y));
+    case ACT_SWISH: { const float t = 1.0f / (1.0f + expf(-y)); return t * (1.0f + y * (1.0f - t)); }
+  }
+  return 1.0f;
+}
 
 template <int PRO>
 __device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f},
-                                                 uint32_t m = 0, uint32_t k = 0) {
+                                                 uint32_t m = 0, uint32_t k = 0, int act = 0) {
   if (PRO == PRO_NONE) return v;
   uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -117,6 +142,7 @@ __device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const
     float a = __builtin_fmaf(bf16_lo(w[i]), sc[2 * i], sh[2 * i]);
     float b = __builtin_fmaf(bf16_hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
     if (PRO == PRO_AFFINE_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
+    if (PRO == PRO_AFFINE_ACT) { a = act_fwd(act, a); b = act_fwd(act, b); }
     if (drop.thr) {                                     // wave-uniform
       float f0, f1;
       drop_pair(drop, m, (k >> 1) + i, f0, f1);
@@ -199,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
       // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -216,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
       *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
     }
@@ -342,7 +368,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   unsigned char* wl = smem + wave * (64 * WPITCH);
   const long mb = m0 + wm * 64;
   const int nb = n0 + wn * 64;
-  if (EPI == EPI_RELU_BWD) {
+  if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
@@ -363,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       for (int r = 0; r < 4; ++r) bias4[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
     }
     float em[4], er[4], es[4], eh[4];
-    if (EPI == EPI_RELU_BWD) {
+    if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool in = n + r < g.N;
@@ -381,7 +407,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[fn][fm][r] + bias4[r];
-      if (EPI == EPI_RELU_BWD) {
+      if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
         // dy = da * 1[y > 0], y = z * scale + shift;  column partials: sum dy, sum dy * z_hat
         const uint2 zz = *reinterpret_cast<const uint2*>(slot);
         const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
@@ -393,7 +419,8 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float y = __builtin_fmaf(z[r], es[r], eh[r]);
-          v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
+          if (EPI == EPI_ACT_BWD) v[r] = min ? v[r] * kf[r] * act_grad(g.act, y) : 0.f;
+          else v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
           s1[fn][r] += v[r];
           s2[fn][r] = __builtin_fmaf(v[r], (z[r] - em[r]) * er[r], s2[fn][r]);
         }
@@ -501,7 +528,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 64 * i;
-      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k);
+      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -589,7 +616,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
       if (GLA) glds_tile(g.A, g.lda, m0, g.M, kt + 1, tAn);
       else load_a(kt + 1, R);
     }
-    if (EPI == EPI_RELU_BWD && !more) zp_load(0);
+    if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && !more) zp_load(0);
     if (!(kAb & 1)) compute(tAc, tAc + TILE2_BYTES);
     if (!GLA && more && !(kAb & 2)) store_a(kt + 1, tAn, R);
     __syncthreads();
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const int nb = n0 + wn * 128 + h * 64;
-    if (EPI == EPI_RELU_BWD) {
+    if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int q = lane + 64 * i, row = q >> 3, cc = q & 7;
@@ -633,7 +660,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
         for (int r = 0; r < 4; ++r) bias4[r] = (n + r < g.N) ? g.bias[n + r] : 0.f;
       }
       float em[4], er[4], es[4], eh[4];
-      if (EPI == EPI_RELU_BWD) {
+      if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const bool in = n + r < g.N;
@@ -651,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[h * 4 + fn][fm][r] + bias4[r];
-        if (EPI == EPI_RELU_BWD) {
+        if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
           const uint2 zz = *reinterpret_cast<const uint2*>(slot);
           const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
           float kf[4] = {1.f, 1.f, 1.f, 1.f};
@@ -662,7 +689,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float y = __builtin_fmaf(z[r], es[r], eh[r]);
-            v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
+            if (EPI == EPI_ACT_BWD) v[r] = min ? v[r] * kf[r] * act_grad(g.act, y) : 0.f;
+            else v[r] = (y > 0.f && min) ? v[r] * kf[r] : 0.f;
             s1[r] += v[r];
             s2[r] = __builtin_fmaf(v[r], (z[r] - em[r]) * er[r], s2[r]);
           }
@@ -759,7 +787,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // comes out of LDS: relu on the packed bf16 pair is a signed 16-bit max with 0 (v_pk_max_i16), the affine a v_pk_fma_f32.
 template <int PRO, bool DROP>
 __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, const f32x4 sc1, const f32x4 sh0, const f32x4 sh1,
-                                                 const Drop d, uint32_t m, uint32_t k) {
+                                                 const Drop d, uint32_t m, uint32_t k, int act) {
   if (PRO == PRO_NONE) return raw;
   const uint4 v = __builtin_bit_cast(uint4, raw);
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -771,6 +799,7 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
     f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
     const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
     x = x * s + h;
+    if (PRO == PRO_AFFINE_ACT) { x[0] = act_fwd(act, x[0]); x[1] = act_fwd(act, x[1]); }
     if (DROP) {                                     // relu(y) * f == relu(y * f) for f >= 0
       float f0, f1;
       drop_pair(d, m, (k >> 1) + i, f0, f1);
@@ -801,7 +830,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
   const int nq = ((g.tiles_m - xcd + 7) >> 3) * g.tiles_n;       // this XCD's tiles: M-tiles xcd, xcd + 8, ...
   if (slot >= nq) return;
-  const bool touch_z = EPI == EPI_RELU_BWD && (g.flags & PF_TOUCH_Z) != 0 && wave >= 4;
+  const bool touch_z = (EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && (g.flags & PF_TOUCH_Z) != 0 && wave >= 4;
 
   // per-lane byte offsets of the staging pieces (tile independent): piece i = rows wave * 32 + 8 i .. + 8
   uint32_t offA[4], offB[4];
@@ -862,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #pragma unroll
         for (int f = 0; f < 4; ++f)
           fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, g.pro_drop,
-                                            (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k);
+                                            (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act);
       }
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
@@ -895,7 +924,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   auto fill_epi = [&](int tn_) __attribute__((always_inline)) {
     if (tid < 256) {
       const int n = tn_ * BN2 + tid;
-      if (EPI == EPI_RELU_BWD) {
+      if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
         const float rs = g.e_rstd[n];
         s_epi[tid] = g.e_scale[n]; s_epi[256 + tid] = g.e_shift[n];
         s_epi[512 + tid] = rs; s_epi[768 + tid] = -g.e_mean[n] * rs;
@@ -944,7 +973,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
       const int stm = last ? tmn : tm, stn = last ? tnn : tn, skt = last ? 0 : kt + 1;
       if (touch_z && kt < 4)                        // the tile's Zp lines: 4 lines (256 columns) per row
         touch4_s(offTZ, reinterpret_cast<const char*>(g.Zp) + ((long)m0 * g.ldz + n0 + kt * 64) * 2, junk);
-      if (EPI == EPI_RELU_BWD && last) {            // first Zp chunk of the epilogue
+      if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && last) {            // first Zp chunk of the epilogue
         const char* zb = reinterpret_cast<const char*>(g.Zp) + (mb * g.ldz + n0 + wn * 128) * 2;
         zq0 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((lane >> 3) * g.ldz + (lane & 7) * 8) * 2));
         zq1 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((8 + (lane >> 3)) * g.ldz + (lane & 7) * 8) * 2));
@@ -977,14 +1006,14 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
     for (int fn = 0; fn < 4; ++fn)                 // the lane's 8-byte slot of fragment column fn in the chunk
       stg_acc[fn] = (uint32_t)(fr * 128 + (((fn * 2 + (fq >> 1)) ^ (fr & 7)) << 4) + (fq & 1) * 8);
     bool first_store = true;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int h = 0; h < 2; ++h) {
       const int nl = wn * 128 + h * 64;             // column of the half inside the tile
       f32x4 pb[4], pe[4];                           // bias | BN scale, shift of the layer below (relu mask)
 #pragma unroll
       for (int fn = 0; fn < 4; ++fn) {
         pb[fn] = *reinterpret_cast<const f32x4*>(s_epi + nl + fn * 16 + fq * 4);
-        if (EPI == EPI_RELU_BWD) pe[fn] = *reinterpret_cast<const f32x4*>(s_epi + 256 + nl + fn * 16 + fq * 4);
+        if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) pe[fn] = *reinterpret_cast<const f32x4*>(s_epi + 256 + nl + fn * 16 + fq * 4);
       }
       f32x4 s1[4], s2[4];
 #pragma unroll
@@ -993,7 +1022,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
       const char* zb = reinterpret_cast<const char*>(g.Zp) + (mb * g.ldz + n0 + nl) * 2;
 #pragma unroll
       for (int fm = 0; fm < 4; ++fm) {
-        if (EPI == EPI_RELU_BWD) {
+        if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
           *reinterpret_cast<uint4*>(sw + stg_rm[0]) = zq0;
           *reinterpret_cast<uint4*>(sw + stg_rm[1]) = zq1;
           if (!(h == 1 && fm == 3)) {               // next chunk (next 16 rows, or the other half's first rows)
@@ -1005,7 +1034,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           f32x4 v = acc[h * 4 + fn][fm];
-          if (EPI == EPI_RELU_BWD) {
+          if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {
             const uint2 zz = *reinterpret_cast<const uint2*>(sw + stg_acc[fn]);
             const f32x4 z = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
             const f32x4 y = z * pb[fn] + pe[fn];
@@ -1018,7 +1047,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
               for (int r = 0; r < 4; ++r) v[r] *= kf[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = y[r] > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 4; ++r) v[r] = (EPI == EPI_ACT_BWD) ? v[r] * act_grad(g.act, y[r]) : (y[r] > 0.f ? v[r] : 0.f);
             s1[fn] += v;
             s2[fn] += v * z;
           } else {
@@ -1044,7 +1073,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) {
           f32x4 a = row16_sum4(s1[fn]), b = row16_sum4(s2[fn]);
-          if (EPI == EPI_RELU_BWD) {                // sum dy * zhat = rstd * sum dy z - mean rstd * sum dy
+          if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD)) {                // sum dy * zhat = rstd * sum dy z - mean rstd * sum dy
             const f32x4 er = *reinterpret_cast<const f32x4*>(s_epi + 512 + nl + fn * 16 + fq * 4);
             const f32x4 c2 = *reinterpret_cast<const f32x4*>(s_epi + 768 + nl + fn * 16 + fq * 4);
             b = b * er + a * c2;
@@ -1306,7 +1335,7 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        int O, float* __restrict__ out, const Drop drop) {
+                                                        int O, float* __restrict__ out, const Drop drop, const int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* coef = reinterpret_cast<float*>(smem);          // [K/8][2 + O][8]
   const int stride = (2 + O) * 8;
@@ -1334,6 +1363,7 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
         float t = a[e];
         if (PRO != PRO_NONE) t = __builtin_fmaf(t, cc[e], cc[8 + e]);
         if (PRO == PRO_AFFINE_RELU) t = fmaxf(t, 0.f);
+        if (PRO == PRO_AFFINE_ACT) t = act_fwd(act, t);
         a[e] = t;
       }
       if (PRO != PRO_NONE && drop.thr) {
@@ -1382,7 +1412,7 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
-    float* __restrict__ partial, int rows_per_block, const Drop drop, const float* __restrict__ pqr) {
+    float* __restrict__ partial, int rows_per_block, const Drop drop, const float* __restrict__ pqr, const int act) {
   constexpr int G = 256 / LPR, CW = LPR * 8;                   // row groups per block, columns per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [G][(2 + O) * CW]
@@ -1426,14 +1456,14 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
       for (int e = 0; e < 8; ++e) {
         const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
         const float y = __builtin_fmaf(zz, sc[e], sh[e]);
-        const float a = ((PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : y) * kf[e];
+        const float a = ((PRO == PRO_AFFINE_RELU) ? fmaxf(y, 0.f) : (PRO == PRO_AFFINE_ACT) ? act_fwd(act, y) : y) * kf[e];
         float da = 0.f;
 #pragma unroll
         for (int o = 0; o < OT; ++o) {
           da = __builtin_fmaf(dl[o], ww[o][e], da);
           if (MODE != 2) dw[o][e] = __builtin_fmaf(dl[o], a, dw[o][e]);
         }
-        const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : da * kf[e];
+        const float d = (PRO == PRO_AFFINE_RELU && !(y > 0.f)) ? 0.f : (PRO == PRO_AFFINE_ACT) ? da * kf[e] * act_grad(act, y) : da * kf[e];
         if (MODE != 2) {
           s1[e] += d;
           s2[e] = __builtin_fmaf(d, (zz - mu[e]) * rs[e], s2[e]);
@@ -1532,6 +1562,7 @@ struct WgradArgs {
   float* slab; long ldw;             // [splits][N][ldw]
   Drop drop;                         // dropout of the layer that produced A (prologue)
   int M, N, K, rows_per_split, splits, tiles_n, tiles_k;
+  int act;                           // ACT_* of PRO_AFFINE_ACT
 };
 
 // byte offset of 16-byte chunk cc (0..15) of row r in a swizzled [64][128] bf16 tile
@@ -1587,7 +1618,7 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 16 * i;
       uint4 va = ra[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.drop, (uint32_t)(ms + (long)cur_step * 64 + row), (uint32_t)(k0 + cc * 8));
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.drop, (uint32_t)(ms + (long)cur_step * 64 + row), (uint32_t)(k0 + cc * 8), g.act);
       *reinterpret_cast<uint4*>(td + swz_t(row, cc)) = rd[i];
       *reinterpret_cast<uint4*>(ta + swz_t(row, cc)) = va;
     }
@@ -1759,7 +1790,8 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
             const float sc = scf[hk * 2 + f], sh = shf[hk * 2 + f];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float x0 = __builtin_fmaf(bf16_lo(w[i]), sc, sh), x1 = __builtin_fmaf(bf16_hi(w[i]), sc, sh);
+              float x0 = __builtin_fmaf(bf16_lo(w[i]), sc, sh), x1 = __builtin_fmaf(bf16_hi(w[i]), sc, sh);
+              if (PRO == PRO_AFFINE_ACT) { x0 = act_fwd(g.act, x0); x1 = act_fwd(g.act, x1); }
               uint32_t pk = pack_bf16(x0, x1);
               if (PRO == PRO_AFFINE_RELU)
                 pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
@@ -1826,6 +1858,14 @@ __global__ void tower_bn_bwd_coeffs_kernel(const float* __restrict__ gamma, cons
   pqr[2 * N + n] = s * (rstd[n] * c2 * mean[n] - c1) * inv_m;
 }
 
+// `prologue` / `epilogue` arguments of the C ABI: mode in bits 0-7, ACT_* code in bits 8.. (modes 3 only)
+static inline bool split_mode(int arg, int& mode, int& act) {
+  mode = arg & 0xff; act = arg >> 8;
+  if (arg < 0 || mode > 3) return false;
+  if (mode == 3) return act >= 1 && act <= ACT_LAST;
+  return act == 0;
+}
+
 Drop to_drop(const tfr_tower_dropout* d) {
   if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f};
   return Drop{d->seed, d->threshold16 > 65535u ? 65535u : d->threshold16, d->scale};
@@ -1881,7 +1921,7 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   g.M = m_full;
   g.tiles_m = m_full / BM2; g.tiles_n = g.N / BN2;
   g.flags = flags;
-  const bool drop = (PRO != PRO_NONE && g.pro_drop.thr) || (EPI == EPI_RELU_BWD && g.epi_drop.thr);
+  const bool drop = (PRO != PRO_NONE && g.pro_drop.thr) || ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.epi_drop.thr);
   const int nq0 = ((g.tiles_m + 7) >> 3) * g.tiles_n;
   const int nslots = nq0 < 32 ? nq0 : 32;
   auto fn = drop ? tower_gemm256p_kernel<PRO, EPI, true> : tower_gemm256p_kernel<PRO, EPI, false>;
@@ -1903,7 +1943,7 @@ template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   static const bool persist = [] { const char* e = getenv("TFR_TOWER_PERSIST"); return !(e && *e) || atoi(e) != 0; }();
   if (persist && g.M >= BM2 && (g.N % BN2) == 0 && (g.K % BK) == 0 && g.K >= 2 * BK && g.K <= 1024 &&
-      !(EPI == EPI_RELU_BWD && g.bias) && g.lda < (1L << 21) && g.ldb < (1L << 21) && g.ldc < (1L << 21) && g.ldz < (1L << 21))
+      !((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.bias) && g.lda < (1L << 21) && g.ldb < (1L << 21) && g.ldc < (1L << 21) && g.ldz < (1L << 21))
     return launch_gemm256p<PRO, EPI>(g, st);
   static const bool no_gl = [] { const char* e = getenv("TFR_TOWER_NO_LDSDMA"); return e && *e && atoi(e) != 0; }();
   static const int tile = [] { const char* e = getenv("TFR_TOWER_TILE"); return (e && *e) ? atoi(e) : 256; }();
@@ -2033,10 +2073,13 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
                                    void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return TFR_EINVAL;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7) || (K & 7) || lda < K || ldb < K || ldc < N) return TFR_EINVAL;
-  if (prologue < 0 || prologue > 2 || epilogue < 0 || epilogue > 2) return TFR_EINVAL;
+  int pact = 0, eact = 0;
+  if (!split_mode(prologue, prologue, pact) || !split_mode(epilogue, epilogue, eact)) return TFR_EINVAL;
+  if ((prologue == PRO_AFFINE_ACT && epilogue >= EPI_RELU_BWD) || (epilogue == EPI_ACT_BWD && prologue != PRO_NONE))
+    return TFR_EINVAL;                                                                // no model runs those pairs
   if (prologue != PRO_NONE && (!a_scale || !a_shift)) return TFR_EINVAL;
   if (epilogue != EPI_PLAIN && !stats) return TFR_EINVAL;
-  if (epilogue == EPI_RELU_BWD && (!Zp || !e_scale || !e_shift || !e_mean || !e_rstd || (ldz & 7))) return TFR_EINVAL;
+  if (epilogue >= EPI_RELU_BWD && (!Zp || !e_scale || !e_shift || !e_mean || !e_rstd || (ldz & 7))) return TFR_EINVAL;
   if (K > 4096) return TFR_ETOOLARGE;
   if (M == 0) return TFR_OK;
   GemmArgs g;
@@ -2046,10 +2089,11 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
-  g.stagger_phases = 0; g.stagger_sleeps = 0; g.flags = 0; g.row0 = 0;
+  g.stagger_phases = 0; g.stagger_sleeps = 0; g.flags = 0; g.row0 = 0; g.act = pact ? pact : eact;
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
   TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);
+  TG(3, 0); TG(3, 1); TG(0, 3);
 #undef TG
   return TFR_EINVAL;
 }
@@ -2101,6 +2145,8 @@ extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prol
                                  const float* shift, const float* w, const float* b, int O, float* out,
                                  const tfr_tower_dropout* dropout, void* stream) {
   if (!z || !w || !out || M < 0 || K <= 0 || (K & 7) || (ldz & 7) || O < 1 || O > 4) return TFR_EINVAL;
+  int act = 0;
+  if (!split_mode(prologue, prologue, act)) return TFR_EINVAL;
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
   if (M == 0) return TFR_OK;
   const int grid = grid_for((long)M * 16, 256) > 2048 ? 2048 : grid_for((long)M * 16, 256);
@@ -2109,9 +2155,10 @@ extern "C" int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prol
   hipStream_t st = (hipStream_t)stream;
   const uint16_t* zz = (const uint16_t*)z;
   const Drop dr = to_drop(dropout);
-  if (prologue == PRO_NONE) hipLaunchKernelGGL(tower_out_kernel<PRO_NONE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
-  else if (prologue == PRO_AFFINE) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
-  else if (prologue == PRO_AFFINE_RELU) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_RELU>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr);
+  if (prologue == PRO_NONE) hipLaunchKernelGGL(tower_out_kernel<PRO_NONE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr, act);
+  else if (prologue == PRO_AFFINE) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr, act);
+  else if (prologue == PRO_AFFINE_RELU) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_RELU>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr, act);
+  else if (prologue == PRO_AFFINE_ACT) hipLaunchKernelGGL(tower_out_kernel<PRO_AFFINE_ACT>, dim3(grid), dim3(256), lds, st, zz, ldz, M, K, scale, shift, w, b, O, out, dr, act);
   else return TFR_EINVAL;
   return (int)hipGetLastError();
 }
@@ -2137,6 +2184,8 @@ extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int pro
       O < 1 || O > 4 || n_blocks < 1) return TFR_EINVAL;
   if (pqr && (!dy_bf16 || partial)) return TFR_EINVAL;       // the apply pass writes dz and nothing else
   if (!pqr && !partial) return TFR_EINVAL;                   // without coefficients the column sums are the point
+  int act = 0;
+  if (!split_mode(prologue, prologue, act)) return TFR_EINVAL;
   if (prologue != PRO_NONE && (!scale || !shift)) return TFR_EINVAL;
   int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
   rows = (rows + 15) / 16 * 16;
@@ -2145,11 +2194,12 @@ extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int pro
   const Drop dr = to_drop(dropout);
   const int mode = pqr ? 2 : (dy_bf16 ? 0 : 1);
   const bool wide = K >= 512;
-#define OB4(P, OT, LPR, MD) hipLaunchKernelGGL((tower_out_bwd_kernel<P, OT, LPR, MD>), dim3(n_blocks), dim3(256), MD == 2 ? 0 : lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr, pqr)
+#define OB4(P, OT, LPR, MD) hipLaunchKernelGGL((tower_out_bwd_kernel<P, OT, LPR, MD>), dim3(n_blocks), dim3(256), MD == 2 ? 0 : lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr, pqr, act)
 #define OB3(P, OT, LPR) do { if (mode == 0) OB4(P, OT, LPR, 0); else if (mode == 1) OB4(P, OT, LPR, 1); else OB4(P, OT, LPR, 2); } while (0)
 #define OB(P) do { if (O == 1) { if (wide) OB3(P, 1, 64); else OB3(P, 1, 16); } else { if (wide) OB3(P, 4, 64); else OB3(P, 4, 16); } } while (0)
   if (prologue == PRO_NONE) OB(PRO_NONE); else if (prologue == PRO_AFFINE) OB(PRO_AFFINE);
-  else if (prologue == PRO_AFFINE_RELU) OB(PRO_AFFINE_RELU); else return TFR_EINVAL;
+  else if (prologue == PRO_AFFINE_RELU) OB(PRO_AFFINE_RELU); else if (prologue == PRO_AFFINE_ACT) OB(PRO_AFFINE_ACT);
+  else return TFR_EINVAL;
 #undef OB
 #undef OB3
 #undef OB4
@@ -2172,8 +2222,10 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
                                     long ldw, int splits, const tfr_tower_dropout* dropout, void* stream) {
   if (!DZ || !A || !slab || M <= 0 || N <= 0 || K <= 0 || (lddz & 7) || (lda & 7) || (N & 7) || (K & 7) ||
       ldw < K || splits < 1 || splits > 65535) return TFR_EINVAL;
-  if (prologue < 0 || prologue > 2 || (prologue != PRO_NONE && (!a_scale || !a_shift))) return TFR_EINVAL;
+  int act = 0;
+  if (!split_mode(prologue, prologue, act) || (prologue != PRO_NONE && (!a_scale || !a_shift))) return TFR_EINVAL;
   WgradArgs g;
+  g.act = act;
   g.DZ = (const uint16_t*)DZ; g.lddz = lddz; g.A = (const uint16_t*)A; g.lda = lda; g.a_scale = a_scale;
   g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.drop = to_drop(dropout);
   hipStream_t st = (hipStream_t)stream;
@@ -2184,7 +2236,8 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
     g.splits = splits; g.tiles_n = N / 256; g.tiles_k = K / 256;
     const dim3 grid256((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
 #define WG2(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad256_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad256_kernel<P>, grid256, dim3(512), 131072, st, g); } while (0)
-    if (prologue == PRO_NONE) WG2(PRO_NONE); else if (prologue == PRO_AFFINE) WG2(PRO_AFFINE); else WG2(PRO_AFFINE_RELU);
+    if (prologue == PRO_NONE) WG2(PRO_NONE); else if (prologue == PRO_AFFINE) WG2(PRO_AFFINE);
+    else if (prologue == PRO_AFFINE_RELU) WG2(PRO_AFFINE_RELU); else WG2(PRO_AFFINE_ACT);
 #undef WG2
     return (int)hipGetLastError();
   }
@@ -2193,7 +2246,8 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
   g.splits = splits; g.tiles_n = (N + 127) / 128; g.tiles_k = (K + 127) / 128;
   const dim3 grid((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
 #define WG(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad_kernel<P>, grid, dim3(256), 65536, st, g); } while (0)
-  if (prologue == PRO_NONE) WG(PRO_NONE); else if (prologue == PRO_AFFINE) WG(PRO_AFFINE); else WG(PRO_AFFINE_RELU);
+  if (prologue == PRO_NONE) WG(PRO_NONE); else if (prologue == PRO_AFFINE) WG(PRO_AFFINE);
+  else if (prologue == PRO_AFFINE_RELU) WG(PRO_AFFINE_RELU); else WG(PRO_AFFINE_ACT);
 #undef WG
   return (int)hipGetLastError();
 }

@@ -9,7 +9,7 @@ load and bias / bf16 cast / BatchNorm statistics fused into its epilogue
 (``csrc/tower.hip``), forward and backward.  Parameters stay fp32 (master copy); the
 bf16 operand copies are rebuilt per call.
 
-What the fused path covers: ``activation`` in {None, relu}, ``use_batch_norm`` on or
+What the fused path covers: ``activation`` in {None, relu, tanh, sigmoid, elu, softplus, swish}, ``use_batch_norm`` on or
 off, training (batch statistics, moving averages updated; Dropout as a counter-based keep mask
 shared by forward and backward -- the TF random stream itself is not reproducible) and inference
 (moving averages, no dropout).  ``input_batch_norm`` is not fused: ``create_tower`` builds the plain
@@ -28,12 +28,38 @@ from . import _tower_ops as T
 _BN_EPS = 1e-3          # tf.keras.layers.BatchNormalization default epsilon
 
 
+_ACT_ALIASES = {
+    'relu': ('relu', torch.relu, torch.nn.functional.relu),
+    'tanh': ('tanh', torch.tanh, torch.nn.functional.tanh),
+    'sigmoid': ('sigmoid', torch.sigmoid, torch.nn.functional.sigmoid),
+    'elu': ('elu', torch.nn.functional.elu),
+    'softplus': ('softplus', torch.nn.functional.softplus),
+    'swish': ('swish', 'silu', torch.nn.functional.silu),
+}
+_ACT_MODULES = {nn.ReLU: 'relu', nn.Tanh: 'tanh', nn.Sigmoid: 'sigmoid', nn.SiLU: 'swish'}
+
+
 def _act_code(activation) -> Optional[str]:
+    """keras/layers.py:66-70 takes any Keras activation; the fused kernels know None, relu, tanh, sigmoid, elu
+    (alpha = 1), softplus and swish (= silu)."""
     if activation is None:
         return None
-    if activation in ('relu', torch.relu, torch.nn.functional.relu) or isinstance(activation, nn.ReLU):
-        return 'relu'
-    raise ValueError('FusedTower supports activation None or relu, got %r' % (activation,))
+    for name, aliases in _ACT_ALIASES.items():
+        if any(activation is a or (isinstance(activation, str) and activation == a) for a in aliases):
+            return name
+    for cls, name in _ACT_MODULES.items():
+        if isinstance(activation, cls):
+            return name
+    if isinstance(activation, nn.ELU) and activation.alpha == 1.0:
+        return 'elu'
+    if isinstance(activation, nn.Softplus) and activation.beta == 1.0:
+        return 'softplus'
+    raise ValueError('FusedTower supports activation None, relu, tanh, sigmoid, elu, softplus or swish, got %r'
+                     % (activation,))
+
+
+def _pro_of(act: Optional[str]) -> int:
+    return T.PRO_AFFINE if act is None else (T.PRO_AFFINE_RELU if act == 'relu' else T.pro_act(act))
 
 
 _FUSED_LAST_MIN_ELEMS = 1 << 25
@@ -45,7 +71,7 @@ class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, tower, training, row_index, *params):
         n_h = len(tower.hidden_layer_dims)
-        use_bn, relu = tower.use_batch_norm, tower.activation == 'relu'
+        use_bn, act = tower.use_batch_norm, tower.activation
         Ws = params[0:n_h]
         bs = params[n_h:2 * n_h]
         gammas = params[2 * n_h:3 * n_h] if use_bn else [None] * n_h
@@ -90,12 +116,12 @@ class _TowerFn(torch.autograd.Function):
                     mean = tower.moving_mean[l]
                     sc = gammas[l].detach() * rstd
                     sh = betas[l].detach() - mean * sc
-                pro = T.PRO_AFFINE_RELU if relu else T.PRO_AFFINE
+                pro = _pro_of(act)
             else:
                 mean = rstd = None
-                if relu or rate > 0.0:
+                if act is not None or rate > 0.0:
                     sc = torch.ones(n_out, device=dev); sh = torch.zeros(n_out, device=dev)
-                    pro = T.PRO_AFFINE_RELU if relu else T.PRO_AFFINE
+                    pro = _pro_of(act)
                 else:
                     sc = sh = None
                     pro = T.PRO_NONE
@@ -172,13 +198,16 @@ class _TowerFn(torch.autograd.Function):
                 dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:
                 wt = ctx.wts[l] if len(ctx.wts) > l else T.cast_weight(Ws[l], transpose=True)   # [K, pad8(N)]
+                epi = T.EPI_RELU_BWD
                 if pro_p == T.PRO_AFFINE_RELU:
                     e_sc, e_sh = sc_p, sh_p
+                elif (pro_p & 0xff) == T.PRO_AFFINE_ACT:             # act'(z * scale + shift)
+                    e_sc, e_sh, epi = sc_p, sh_p, T.epi_act_bwd(tower.activation)
                 else:                                                # identity activation: mask always on
                     e_sc, e_sh = torch.zeros(k_in, device=dev), torch.ones(k_in, device=dev)
                 e_mean = mean_p if mean_p is not None else torch.zeros(k_in, device=dev)
                 e_rstd = rstd_p if rstd_p is not None else torch.ones(k_in, device=dev)
-                dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD,
+                dy, partial = T.gemm(dz, wt, k_in, n_out, prologue=T.PRO_NONE, epilogue=epi,
                                      Zp=zs[l - 1], e_scale=e_sc, e_shift=e_sh, e_mean=e_mean, e_rstd=e_rstd,
                                      epi_dropout=drop_p)
                 if use_bn:                                 # the column sums of layer l - 1 and its coefficients together

@@ -208,10 +208,14 @@ def ref_tower(x, tower, training=True):
             y = (z - mean) * torch.rsqrt(var + 1e-3) * tower.gammas[l] + tower.betas[l]
         else:
             y = z
-        a = torch.relu(y) if tower.activation == 'relu' else y
+        a = _ACT[tower.activation](y)
         if l < n_h - 1:
             a = _ste(a)
     return a @ tower.out_weight.t() + tower.out_bias
+
+
+_ACT = {None: lambda y: y, 'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': torch.sigmoid,
+        'elu': torch.nn.functional.elu, 'softplus': torch.nn.functional.softplus, 'swish': torch.nn.functional.silu}
 
 
 @pytest.mark.parametrize('M,F,hidden,O,act,bn', [
@@ -220,11 +224,20 @@ def ref_tower(x, tower, training=True):
     (700, 20, [128, 64], 2, None, True),
     (900, 50, [64, 64], 1, 'relu', False),
     (513, 16, [32], 1, None, False),
+    # activations other than ReLU (keras/layers.py:66-70) in the fused prologues / the dgrad epilogue: the 128 x 128
+    # kernels, and the persistent 256 x 256 ones with a ragged rest (2100 = 8 x 256 + 52 rows)
+    (1500, 136, [128, 64], 1, 'tanh', True),
+    (2100, 40, [512, 512], 1, 'tanh', True),
+    (2100, 40, [512, 256], 2, 'sigmoid', True),
+    (1300, 24, [256, 256], 1, 'elu', True),
+    (1300, 24, [256, 256], 1, 'softplus', False),
+    (2100, 40, [512, 512], 1, 'swish', True),
 ])
 def test_fused_tower_forward_backward(M, F, hidden, O, act, bn):
     from ranking_amd.tower import FusedTower
     torch.manual_seed(0)
     tower = FusedTower(F, hidden, O, activation=act, use_batch_norm=bn).to(DEV)
+    assert tower.activation == act
     with torch.no_grad():
         for p in list(tower.biases) + [tower.out_bias]:
             p.normal_(0, 0.1)
