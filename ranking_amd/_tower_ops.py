@@ -122,6 +122,26 @@ def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Opti
     return out
 
 
+def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blocks: int = 512):
+    """Per-column partial sums [T, 2, F] (sum x, sum x^2) of the fp32 features (rows gathered through
+    ``row_index``): the batch statistics of create_tower's input BatchNormalization, in bn_finalize's format."""
+    require_device(x, 'x')
+    x = x.to(torch.float32)
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    if row_index is not None:
+        row_index = row_index.to(torch.int32).contiguous()
+        M = row_index.numel()
+    else:
+        M = x.shape[0]
+    F = x.shape[1]
+    T = max(1, min(n_blocks, (M + 63) // 64))
+    partial = torch.empty((T, 2, F), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tfr_tower_input_stats_f32(_ptr(x), x.stride(0), M, F, _ptr(row_index), _ptr(partial), T,
+                                                     _stream()), 'tfr_tower_input_stats_f32')
+    return partial, M
+
+
 def cast_weight(w: torch.Tensor, transpose: bool = False, pitch: Optional[int] = None):
     """fp32 [R, C] -> bf16 [R, pitch >= C] (default pad8(C)), or (transpose) bf16 [C, pad8(R)]; zero padded."""
     require_device(w, 'w')

@@ -2018,6 +2018,35 @@ extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, in
   return (int)hipGetLastError();
 }
 
+// input_batch_norm (keras/layers.py:57-60: BatchNormalization on the raw features): per-column partial sums
+// (sum x, sum x^2) of the fp32 input, rows gathered like the cast does; partial[T][2][F] feeds tfr_tower_bn_finalize,
+// whose scale / shift the cast kernel then applies.
+__global__ __launch_bounds__(256) void tower_input_stats_kernel(const float* __restrict__ x, long ldx, int M, int F,
+                                                                const int* __restrict__ row_index,
+                                                                float* __restrict__ partial, int rows_per_block) {
+  const long mb = (long)blockIdx.x * rows_per_block;
+  const long me = (mb + rows_per_block < M) ? mb + rows_per_block : M;
+  for (int c = threadIdx.x; c < F; c += blockDim.x) {
+    float s1 = 0.f, s2 = 0.f;
+    for (long m = mb; m < me; ++m) {
+      const long ms = row_index ? (long)row_index[m] : m;
+      const float v = x[ms * ldx + c];
+      s1 += v; s2 = __builtin_fmaf(v, v, s2);
+    }
+    partial[((long)blockIdx.x * 2) * F + c] = s1;
+    partial[((long)blockIdx.x * 2 + 1) * F + c] = s2;
+  }
+}
+
+extern "C" int tfr_tower_input_stats_f32(const float* x, long ldx, int M, int F, const int* row_index, float* partial,
+                                         int n_blocks, void* stream) {
+  if (!x || !partial || M <= 0 || F <= 0 || n_blocks < 1 || ldx < F) return TFR_EINVAL;
+  const int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
+  hipLaunchKernelGGL(tower_input_stats_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, F, row_index,
+                     partial, rows);
+  return (int)hipGetLastError();
+}
+
 extern "C" int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int Kp, const float* scale,
                                               const float* shift, const int* row_index, void* out_bf16,
                                               void* stream) {

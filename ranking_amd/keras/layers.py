@@ -40,7 +40,7 @@ def create_tower(hidden_layer_dims: List[int], output_units: int, activation: Op
     from ..scorer import make_dense
     if input_dim is None:
         raise ValueError('input_dim is required')
-    if compute_dtype == torch.bfloat16 and hidden_layer_dims and not input_batch_norm:
+    if compute_dtype == torch.bfloat16 and hidden_layer_dims:
         # MI355X fast path: one fused MFMA launch per layer, forward and backward (ranking_amd/tower.py).
         from ..tower import FusedTower, _act_code
         try:
@@ -51,7 +51,7 @@ def create_tower(hidden_layer_dims: List[int], output_units: int, activation: Op
         if fusable:
             return FusedTower(input_dim, list(hidden_layer_dims), output_units, activation=act,
                               use_batch_norm=use_batch_norm, batch_norm_moment=batch_norm_moment,
-                              dropout=dropout or 0.0)
+                              dropout=dropout or 0.0, input_batch_norm=input_batch_norm)
     layers: List[nn.Module] = []
     if input_batch_norm:
         layers.append(nn.BatchNorm1d(input_dim, momentum=1.0 - batch_norm_moment, eps=1e-3))

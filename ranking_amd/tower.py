@@ -12,8 +12,9 @@ bf16 operand copies are rebuilt per call.
 What the fused path covers: ``activation`` in {None, relu, tanh, sigmoid, elu, softplus, swish}, ``use_batch_norm`` on or
 off, training (batch statistics, moving averages updated; Dropout as a counter-based keep mask
 shared by forward and backward -- the TF random stream itself is not reproducible) and inference
-(moving averages, no dropout).  ``input_batch_norm`` is not fused: ``create_tower`` builds the plain
-torch tower for it (same GPU, fp32, unfused).
+(moving averages, no dropout).  ``input_batch_norm``: batch statistics of the raw features by
+``tfr_tower_input_stats_f32``, the normalisation inside the input cast, its two parameter gradients from
+the layer-0 dgrad's column partials.
 """
 from __future__ import annotations
 
@@ -83,7 +84,19 @@ class _TowerFn(torch.autograd.Function):
             # (an embedding, a projection) would silently train on no gradient -- refuse instead
             raise NotImplementedError('FusedTower does not propagate a gradient to its input; detach the features '
                                       'or use the torch-op tower (compute_dtype=torch.float32) below trainable layers')
-        if row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
+        in_bn = None                                       # (scale, shift) of create_tower's input BatchNormalization
+        if tower.input_batch_norm:
+            g_in, b_in = params[-4], params[-3]
+            if training:                                   # batch statistics of the raw fp32 features
+                part, rows = T.input_stats(x, row_index=row_index)
+                in_sc, in_sh, _, _ = T.bn_finalize(part, rows, g_in, b_in, _BN_EPS, tower.momentum,
+                                                   tower.moving_mean_in, tower.moving_var_in)
+            else:
+                in_sc = g_in.detach() * torch.rsqrt(tower.moving_var_in + _BN_EPS)
+                in_sh = b_in.detach() - tower.moving_mean_in * in_sc
+            in_bn = (in_sc, in_sh)
+            x0 = T.cast_rows(x, scale=in_sc, shift=in_sh, row_index=row_index, width=T.pad_k(x.shape[1]))
+        elif row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
             x0 = T.cast_rows(x, row_index=row_index, width=T.pad_k(x.shape[1]))
         else:
             x0 = x
@@ -98,7 +111,8 @@ class _TowerFn(torch.autograd.Function):
         # every weight cast of the step in one launch: [N, k_in] forward operands (k_in = staged width of the layer
         # input) and, when a backward will follow, the transposed [K, pad8(N)] dgrad operands of layers >= 1
         specs = [(Ws[l], False, k_in if l == 0 else Ws[l - 1].shape[0]) for l in range(n_h)]
-        if any(ctx.needs_input_grad[4:]):
+        want_bwd = any(ctx.needs_input_grad[4:])
+        if want_bwd:
             specs += [(Ws[l], True, None) for l in range(1, n_h)]
         cast = T.cast_weights(specs)
         wbs, ctx.wts = cast[:n_h], [None] + cast[n_h:]
@@ -131,7 +145,7 @@ class _TowerFn(torch.autograd.Function):
             a_in, k_in = z, n_out
         logits = T.out_layer(a_in, k_in, pro, sc, sh, w_out, b_out, dropout=drop)
         ctx.tower, ctx.training = tower, training
-        ctx.x0, ctx.zs, ctx.coefs = x0, zs, coefs
+        ctx.x0, ctx.zs, ctx.coefs, ctx.in_bn = x0, zs, coefs, in_bn
         ctx.params = params
         return logits
 
@@ -192,6 +206,8 @@ class _TowerFn(torch.autograd.Function):
                 pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = T.PRO_NONE, None, None, None, None, None
                 a_prev, k_in = x0, x0.shape[1]
             into = Ws[l].grad if (direct and k_in == Ws[l].shape[1] and Ws[l].grad.is_contiguous()) else None
+            if l == 0:
+                dz0 = dz
             g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p,
                         accumulate_into=into)
             if into is None:
@@ -217,6 +233,23 @@ class _TowerFn(torch.autograd.Function):
         grads = list(dW) + list(db)
         if use_bn:
             grads += list(dgam) + list(dbet)
+        if tower.input_batch_norm:
+            # d gamma_in = sum_m dxbn * xhat, d beta_in = sum_m dxbn with dxbn = dz_1 . W_1 (the layer-0 dgrad, run for
+            # these two vectors only: the features themselves take no gradient); xhat = (x0 - beta_in) / gamma_in is
+            # recovered from the staged bf16 input by the epilogue's (Zp - e_mean) * e_rstd
+            g_in, b_in = params[-4], params[-3]
+            F = Ws[0].shape[1]
+            k0 = x0.shape[1]
+            wt0 = T.cast_weight(Ws[0], transpose=True, pitch=T.pad8(Ws[0].shape[0]))      # [F, pad8(N)]
+            if wt0.shape[0] != k0:                                                       # rows up to the staged width
+                wt0 = torch.cat([wt0, torch.zeros((k0 - wt0.shape[0], wt0.shape[1]), dtype=wt0.dtype, device=dev)])
+            e_mean = torch.zeros(k0, device=dev); e_mean[:F] = b_in.detach()
+            e_rstd = torch.ones(k0, device=dev); e_rstd[:F] = 1.0 / g_in.detach()
+            _, partial = T.gemm(dz0, wt0, k0, Ws[0].shape[0], prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD, Zp=x0,
+                                e_scale=torch.zeros(k0, device=dev), e_shift=torch.ones(k0, device=dev),
+                                e_mean=e_mean, e_rstd=e_rstd)
+            cin = T.reduce_partials(partial)
+            grads += [cin[1][:F].contiguous(), cin[0][:F].contiguous()]
         grads += [dw_out, db_out]
         if direct:
             todo = [(p.grad, g) for p, g in zip(params, grads)
@@ -230,7 +263,8 @@ class FusedTower(nn.Module):
     """create_tower(...) as one fused module; call with the flattened ``[M, F]`` features."""
 
     def __init__(self, input_dim: int, hidden_layer_dims: List[int], output_units: int = 1, activation=None,
-                 use_batch_norm: bool = True, batch_norm_moment: float = 0.999, dropout: float = 0.0):
+                 use_batch_norm: bool = True, batch_norm_moment: float = 0.999, dropout: float = 0.0,
+                 input_batch_norm: bool = False):
         super().__init__()
         if not hidden_layer_dims:
             raise ValueError('FusedTower needs at least one hidden layer')
@@ -243,6 +277,7 @@ class FusedTower(nn.Module):
         self.output_units = int(output_units)
         self.activation = _act_code(activation)
         self.use_batch_norm = bool(use_batch_norm)
+        self.input_batch_norm = bool(input_batch_norm)
         self.momentum = float(batch_norm_moment)
         if not 0.0 <= float(dropout or 0.0) < 1.0:
             raise ValueError('dropout rate must be in [0, 1)')
@@ -268,6 +303,11 @@ class FusedTower(nn.Module):
                 self.register_buffer('moving_mean_%d' % i, torch.zeros(h))
                 self.register_buffer('moving_var_%d' % i, torch.ones(h))
             width = h
+        if self.input_batch_norm:                           # keras/layers.py:57-60
+            self.gamma_in = nn.Parameter(torch.ones(self.input_dim))
+            self.beta_in = nn.Parameter(torch.zeros(self.input_dim))
+            self.register_buffer('moving_mean_in', torch.zeros(self.input_dim))
+            self.register_buffer('moving_var_in', torch.ones(self.input_dim))
         w = torch.empty(self.output_units, width)
         nn.init.xavier_uniform_(w)
         self.out_weight = nn.Parameter(w)
@@ -289,5 +329,9 @@ class FusedTower(nn.Module):
         params = list(self.weights) + list(self.biases)
         if self.use_batch_norm:
             params += list(self.gammas) + list(self.betas)
+        if self.input_batch_norm:
+            if x.dtype != torch.float32 or x.shape[1] != self.input_dim:
+                raise ValueError('input_batch_norm needs the raw fp32 [M, %d] features' % self.input_dim)
+            params += [self.gamma_in, self.beta_in]
         params += [self.out_weight, self.out_bias]
         return _TowerFn.apply(x, self, self.training, row_index, *params)

@@ -198,6 +198,9 @@ def _ste(x):
 def ref_tower(x, tower, training=True):
     """fp32 torch restatement of create_tower with the kernel's bf16 rounding points
     (straight-through), differentiable by autograd."""
+    if getattr(tower, 'input_batch_norm', False):        # keras/layers.py:57-60: BatchNormalization on the raw features
+        mean = x.mean(0); var = x.var(0, unbiased=False)
+        x = (x - mean) * torch.rsqrt(var + 1e-3) * tower.gamma_in + tower.beta_in
     a = _ste(x)
     n_h = len(tower.hidden_layer_dims)
     for l in range(n_h):
@@ -232,13 +235,21 @@ _ACT = {None: lambda y: y, 'relu': torch.relu, 'tanh': torch.tanh, 'sigmoid': to
     (1300, 24, [256, 256], 1, 'elu', True),
     (1300, 24, [256, 256], 1, 'softplus', False),
     (2100, 40, [512, 512], 1, 'swish', True),
+    # input_batch_norm (statistics of the raw features, normalisation inside the cast, two more parameter gradients)
+    (2000, 136, [64, 32], 1, 'relu', 'in'),
+    (2100, 40, [512, 512], 1, 'relu', 'in'),
+    (900, 50, [64, 64], 2, 'tanh', 'in-only'),
 ])
 def test_fused_tower_forward_backward(M, F, hidden, O, act, bn):
     from ranking_amd.tower import FusedTower
     torch.manual_seed(0)
-    tower = FusedTower(F, hidden, O, activation=act, use_batch_norm=bn).to(DEV)
+    in_bn = isinstance(bn, str)
+    bn = bn is True or bn == 'in'
+    tower = FusedTower(F, hidden, O, activation=act, use_batch_norm=bn, input_batch_norm=in_bn).to(DEV)
     assert tower.activation == act
     with torch.no_grad():
+        if in_bn:
+            tower.gamma_in.uniform_(0.5, 1.5); tower.beta_in.normal_(0, 0.2)
         for p in list(tower.biases) + [tower.out_bias]:
             p.normal_(0, 0.1)
         for g in tower.gammas:
@@ -246,6 +257,8 @@ def test_fused_tower_forward_backward(M, F, hidden, O, act, bn):
         for b in tower.betas:
             b.normal_(0, 0.2)
     x = rnd((M, F), 50).to(DEV)
+    if in_bn:                                            # columns of different location and scale
+        x = x * (torch.arange(F, device=DEV) % 5 + 1) * 0.5 + (torch.arange(F, device=DEV) % 3 - 1.0)
     up = rnd((M, O), 51).to(DEV)
     tower.train()
     got = tower(x)
