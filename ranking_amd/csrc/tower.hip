@@ -99,7 +99,6 @@ struct GemmArgs {
   Drop pro_drop;                     // dropout of the layer below, applied in the A prologue (thr = 0: off)
   Drop epi_drop;                     // ... and in the EPI_RELU_BWD epilogue (the layer whose Zp is given)
   int M, N, K, tiles_m, tiles_n;
-  int stagger_phases, stagger_sleeps;  // 256 x 256 kernel: first-round workgroups of phase p idle p * sleeps * s_sleep(127)
   int flags;                           // persistent 256 x 256 kernel: PF_* bits
   int act;                             // ACT_* of PRO_AFFINE_ACT / EPI_ACT_BWD
   int row0;                            // global index of row 0 of A / C (dropout hash) when a launch covers a row range
@@ -503,10 +502,6 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
   const int m0 = tm * BM2, n0 = tn * BN2;
   const int nk = g.K / BK;
   constexpr bool GLA = (PRO == PRO_NONE);
-  if (g.stagger_phases > 1 && id < 256) {
-    const int ph = (id >> 3) % g.stagger_phases;
-    for (int i = 0; i < ph * g.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   const int c = tid & 7, r0 = tid >> 3;           // staging: chunk column c of rows r0 + 64 i
   struct RegsA { uint4 a[4]; };
@@ -1897,11 +1892,6 @@ template <int PRO, int EPI>
 int launch_gemm256(const GemmArgs& g0, hipStream_t st) {
   GemmArgs g = g0;
   g.tiles_m = (g.M + BM2 - 1) / BM2; g.tiles_n = (g.N + BN2 - 1) / BN2;
-  {
-    const char* e = getenv("TFR_GEMM_STAGGER");          // "phases,sleeps" (developer knob)
-    g.stagger_phases = 0; g.stagger_sleeps = 0;
-    if (e && *e) sscanf(e, "%d,%d", &g.stagger_phases, &g.stagger_sleeps);
-  }
   const size_t lds = 4 * TILE2_BYTES + 2 * (size_t)g.K * sizeof(float);
   auto fn = tower_gemm256_kernel<PRO, EPI>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2118,7 +2108,7 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.e_mean = e_mean; g.e_rstd = e_rstd; g.M = M; g.N = N; g.K = K;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
-  g.stagger_phases = 0; g.stagger_sleeps = 0; g.flags = 0; g.row0 = 0; g.act = pact ? pact : eact;
+  g.flags = 0; g.row0 = 0; g.act = pact ? pact : eact;
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
   TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);

@@ -120,3 +120,28 @@ def test_scorer_on_device_bf16_close_to_fp32():
     out = loss(labels, bb)
     out.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in s16.parameters())
+
+
+def test_create_tower_routes_the_keras_options_to_the_fused_tower():
+    """keras/layers.py:26-77: activation (any Keras activation), input_batch_norm, use_batch_norm, dropout.  The bf16
+    tower takes the options its kernels know (module construction needs no GPU); everything else gets the torch-op
+    tower."""
+    from ranking_amd.keras.layers import create_tower
+    from ranking_amd.tower import FusedTower, _act_code
+    for act, want in ((torch.relu, 'relu'), ('tanh', 'tanh'), (torch.sigmoid, 'sigmoid'), (torch.nn.functional.elu, 'elu'),
+                      (torch.nn.Softplus(), 'softplus'), (torch.nn.SiLU(), 'swish'), ('swish', 'swish'), (None, None)):
+        assert _act_code(act) == want
+        t = create_tower([64, 32], 1, activation=act, input_dim=24, compute_dtype=torch.bfloat16)
+        assert isinstance(t, FusedTower) and t.activation == want
+    with pytest.raises(ValueError):
+        _act_code(torch.nn.functional.gelu)
+    t = create_tower([64, 32], 1, activation=torch.nn.functional.gelu, input_dim=24, compute_dtype=torch.bfloat16)
+    assert not isinstance(t, FusedTower)                       # an activation the kernels do not know
+    t = create_tower([64, 32], 1, activation=torch.relu, input_batch_norm=True, input_dim=24, compute_dtype=torch.bfloat16)
+    assert isinstance(t, FusedTower) and t.input_batch_norm
+    names = [n for n, _ in t.named_parameters()]
+    assert 'gamma_in' in names and 'beta_in' in names and t.moving_var_in.shape == (24,)
+    assert not isinstance(create_tower([60, 32], 1, activation=torch.relu, input_dim=24, compute_dtype=torch.bfloat16),
+                          FusedTower)                        # hidden width not a multiple of 8
+    assert not isinstance(create_tower([64, 32], 1, activation=torch.relu, input_dim=24, compute_dtype=torch.float32),
+                          FusedTower)                        # fp32 compute
