@@ -131,6 +131,15 @@ def plumbing_check(rank, world):
 
 
 # ------------------------------------------------------------------------------------------ the steps
+def capture(graph):
+    """torch.cuda.graph(...) for this process.  With a process group alive its watchdog thread polls events while the
+    capture runs; in the default 'global' capture mode that invalidates the capture, 'thread_local' confines the check
+    to the capturing thread."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return torch.cuda.graph(graph, capture_error_mode='thread_local' if multi else 'global')
+
+
 def make_inputs(B, L, seed, device):
     from ranking_amd.synthetic import make_batch
     labels, logits = make_batch(B, L, seed)
@@ -275,7 +284,7 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     one = torch.ones((), device=dev)
     if world <= 1:
         # one replica: no collective between backward and the optimizer -> the whole step is ONE graph
-        with torch.cuda.graph(g_fb):
+        with capture(g_fb):
             static_value = fwd_bwd()
             static_scalars = torch.stack([static_value, one])
             sgd()
@@ -285,10 +294,10 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
             return static_scalars[0]
         info.update(step=graph_step, all_reduce=lambda: None)
         return info
-    with torch.cuda.graph(g_fb):
+    with capture(g_fb):
         static_value = fwd_bwd()
         static_scalars = torch.stack([static_value, one])
-    with torch.cuda.graph(g_sgd):
+    with capture(g_sgd):
         sgd()
 
     def graph_step():
@@ -540,7 +549,7 @@ def _kernel_ms(kernel, n):
     stream.wait_stream(side)
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
+    with capture(graph):
         for _ in range(reps):
             kernel()
     graph.replay()
@@ -577,7 +586,7 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with capture(graph):
             static_out = eager()
 
         def step():
