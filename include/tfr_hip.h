@@ -178,7 +178,7 @@ int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8
 /* NeuralSort losses (losses_impl.py:1635-1673 NeuralSortCrossEntropyLoss, :1676-1713 NeuralSortNDCGLoss,
  * :1716-1801 neural_sort): per-list loss [B] and d loss / d logits [B, L] (x list_scale[b] when given),
  * one wavefront per list, no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG
- * kind only).  L <= 1024 (TFR_ETOOLARGE beyond).  The Gumbel variants are this kernel on the sampler's
+ * kind only).  L <= 2048 (TFR_ETOOLARGE beyond: 40 / 60 B of LDS per item).  The Gumbel variants are this kernel on the sampler's
  * expanded batch. */
 #define TFR_NEURAL_SORT_NDCG 0
 #define TFR_NEURAL_SORT_CE 1

@@ -323,14 +323,14 @@ extern "C" int tfr_neural_sort_loss_f32(int kind, const float* logits, const flo
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind != TFR_NEURAL_SORT_NDCG && kind != TFR_NEURAL_SORT_CE) return TFR_EINVAL;
   if (kind == TFR_NEURAL_SORT_NDCG && !inv_log1p) return TFR_EINVAL;
-  if (L > 1024) return TFR_ETOOLARGE;            // wave-per-list kernel only
+  if (L > 2048) return TFR_ETOOLARGE;            // 40 / 60 B of LDS per item, one wavefront per list (32 items per lane)
   if (B == 0) return TFR_OK;
   static const int max_runs = env_int_ns("TFR_APPROX_MAX_RUNS", 8);
   hipStream_t st = (hipStream_t)stream;
   const int Lp = ((L + 3) / 4) * 4 + 4;
   const size_t lds = ns_lds_bytes(Lp, kind);
-#define NS(I, K) hipLaunchKernelGGL((neural_sort_wave_kernel<I, K>), dim3(B), dim3(64), lds, st, logits, labels, mask, inv_log1p, list_scale, L, Lp, temperature, loss_out, dlogits_out, max_runs)
-#define NS_K(K) do { if (L <= 64) NS(1, K); else if (L <= 128) NS(2, K); else if (L <= 256) NS(4, K); else if (L <= 512) NS(8, K); else NS(16, K); } while (0)
+#define NS(I, K) if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&neural_sort_wave_kernel<I, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return (int)e; } hipLaunchKernelGGL((neural_sort_wave_kernel<I, K>), dim3(B), dim3(64), lds, st, logits, labels, mask, inv_log1p, list_scale, L, Lp, temperature, loss_out, dlogits_out, max_runs)
+#define NS_K(K) do { if (L <= 64) { NS(1, K); } else if (L <= 128) { NS(2, K); } else if (L <= 256) { NS(4, K); } else if (L <= 512) { NS(8, K); } else if (L <= 1024) { NS(16, K); } else { NS(32, K); } } while (0)
   if (kind == TFR_NEURAL_SORT_NDCG) NS_K(TFR_NEURAL_SORT_NDCG); else NS_K(TFR_NEURAL_SORT_CE);
 #undef NS_K
 #undef NS

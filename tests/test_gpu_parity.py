@@ -1043,7 +1043,7 @@ def _fp64_arbitrated(got, o32, truth, tol, what):
     assert err <= max(tol * scale, 3.0 * ref_err), '%s: err %.3e (oracle-fp32 err %.3e, scale %.3e)' % (what, err, ref_err, scale)
 
 
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40)])
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40), (2, 1500), (1, 2048)])      # > 1024: 32 items per lane
 @pytest.mark.parametrize('kind', ['ndcg', 'ce'])
 @pytest.mark.parametrize('temperature', [1.0, 0.1])
 def test_neural_sort_loss_parity(B, L, kind, temperature):
