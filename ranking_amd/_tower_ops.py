@@ -332,9 +332,9 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
     if splits <= 0:
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         splits = max(1, min((M + 255) // 256, (_WGRAD_BLOCKS + tiles - 1) // tiles))
-        if N % 256 == 0 and K % 256 == 0 and (dropout is None or not dropout.threshold16):
+        if N % 256 == 0 and K % 64 == 0 and K >= 128 and (dropout is None or not dropout.threshold16):
             # the 256 x 256 kernel: one workgroup per CU, M split into equal runs of 64-row steps
-            want = max(1, 256 // ((N // 256) * (K // 256)))
+            want = max(1, 256 // ((N // 256) * ((K + 255) // 256)))
             fit = [s for s in range(want, 0, -1) if M % (64 * s) == 0]
             if fit and fit[0] * 2 > want:
                 splits = fit[0]

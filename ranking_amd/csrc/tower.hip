@@ -1677,7 +1677,7 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
 // ------------------------------------------------------------------------------------
 // 256 (n) x 256 (k) weight-gradient tile, 8 waves (4 over n x 2 over k: 64 x 128 each, acc[4][8]), both operands
 // staged by hand-issued LDS-DMA in 64-row steps, double buffered (2 x 64 KB), one workgroup per (M split, tile).
-// Needs N % 256 == 0, K % 256 == 0, M % (64 * splits) == 0 and no dropout (with the transposed fragments a lane holds
+// Needs N % 256 == 0, K % 64 == 0 (K >= 128), M % (64 * splits) == 0 and no dropout (with the transposed fragments a lane holds
 // 8 rows of ONE column, so the keep mask would cost a hash per element); everything else takes the kernel above.
 // Against the 128 x 128 kernel: half the bytes through the CU per MAC (each dz / A row block is read by 2 instead of 4
 // workgroups), no register staging and no ds_write_b128 pass, the prologue applied to the operand fragments with the
@@ -1699,13 +1699,20 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
 
   // staging pieces: a half tile is 16 pieces of 4 rows x 256 B; wave w carries rows 8 w .. 8 w + 7 of all four
   // half tiles (dz 0/1, A 0/1): 8 pieces per step
-  uint32_t offD[2], offA[2];
+  // (K may end inside the tile -- layer 1 stages 136 features as 192 columns: the pieces beyond column K re-read the
+  // row's last 8 columns, their products land in output columns >= K that are never stored)
+  uint32_t offD[2], offA[2][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int r = wave * 8 + j * 4 + (lane >> 4);
     const int cc = (lane & 15) ^ ((((r & 3) | ((r >> 1) & 4)) << 1));   // logical chunk that lands in physical slot lane & 15
     offD[j] = (uint32_t)((r * g.lddz + cc * 8) * 2);
-    offA[j] = (uint32_t)((r * g.lda + cc * 8) * 2);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int col = h * 128 + cc * 8;
+      if (k0 + col >= g.K) col = g.K - 8 - k0;
+      offA[j][h] = (uint32_t)((r * g.lda + col) * 2);
+    }
   }
   auto issue = [&](int st, int buf) __attribute__((always_inline)) {
     const char* db = reinterpret_cast<const char*>(g.DZ) + ((ms + (long)st * 64) * g.lddz + n0) * 2;
@@ -1716,7 +1723,7 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         dma16_s(offD[j], db + h * 256, dst + h * 16384 + j * 1024);
-        dma16_s(offA[j], ab + h * 256, dst + 32768 + h * 16384 + j * 1024);
+        dma16_s(offA[j][h], ab, dst + 32768 + h * 16384 + j * 1024);
       }
   };
 
@@ -1735,7 +1742,7 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
 #pragma unroll
     for (int f = 0; f < 8; ++f) {
       const int k = k0 + wk * 128 + f * 16 + fr;
-      scf[f] = g.a_scale[k]; shf[f] = g.a_shift[k];
+      scf[f] = k < g.K ? g.a_scale[k] : 0.f; shf[f] = k < g.K ? g.a_shift[k] : 0.f;
     }
   }
 
@@ -1771,7 +1778,7 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
         if (more && !(hk & 1)) {                  // 2 of the 8 pieces per two half blocks (uniform branch)
           const int blk = kk * 2 + (hk >> 1), h = blk >> 1, j = blk & 1;
           dma16_s(offD[j], db + h * 256, dst + h * 16384 + j * 1024);
-          dma16_s(offA[j], ab + h * 256, dst + 32768 + h * 16384 + j * 1024);
+          dma16_s(h ? offA[j][1] : offA[j][0], ab, dst + 32768 + h * 16384 + j * 1024);
         }
         bf16x8 fa[2];
 #pragma unroll
@@ -1815,7 +1822,7 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + fn * 16 + fq * 4 + r;
-        out[(long)n * g.ldw + k] = acc[fn][fk][r];
+        if (k < g.K) out[(long)n * g.ldw + k] = acc[fn][fk][r];
       }
     }
 }
@@ -2249,10 +2256,10 @@ extern "C" int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, lo
   g.a_shift = a_shift; g.slab = slab; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.drop = to_drop(dropout);
   hipStream_t st = (hipStream_t)stream;
   static const bool big = [] { const char* e = getenv("TFR_WGRAD_256"); return !(e && *e) || atoi(e) != 0; }();
-  if (big && (N % 256) == 0 && (K % 256) == 0 && g.drop.thr == 0 && ((long)M % (64L * splits)) == 0 &&
+  if (big && (N % 256) == 0 && (K % 64) == 0 && K >= 128 && g.drop.thr == 0 && ((long)M % (64L * splits)) == 0 &&
       lddz < (1L << 21) && lda < (1L << 21)) {
     g.rows_per_split = (int)((long)M / splits);
-    g.splits = splits; g.tiles_n = N / 256; g.tiles_k = K / 256;
+    g.splits = splits; g.tiles_n = N / 256; g.tiles_k = (K + 255) / 256;
     const dim3 grid256((splits + 7) / 8 * 8 * g.tiles_n * g.tiles_k);
 #define WG2(P) do { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tower_wgrad256_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); if (e != hipSuccess) return (int)e; hipLaunchKernelGGL(tower_wgrad256_kernel<P>, grid256, dim3(512), 131072, st, g); } while (0)
     if (prologue == PRO_NONE) WG2(PRO_NONE); else if (prologue == PRO_AFFINE) WG2(PRO_AFFINE);

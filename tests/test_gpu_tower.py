@@ -128,7 +128,9 @@ def test_bn_finalize_and_out_layer():
 
 @pytest.mark.parametrize('M,N,K', [(64, 128, 128), (1, 8, 8), (300, 136, 512), (1000, 512, 136), (4097, 264, 200),
                                    # the 256 x 256 kernel (N, K multiples of 256, M a multiple of 64 * splits)
-                                   (4096, 256, 256), (8192, 512, 512), (51200, 512, 256)])
+                                   (4096, 256, 256), (8192, 512, 512), (51200, 512, 256),
+                                   # ... with K ending inside the k tile (layer 1: 136 features staged as 192)
+                                   (8192, 512, 192), (4096, 256, 320), (2048, 256, 128)])
 @pytest.mark.parametrize('pro', [0, 2])
 def test_wgrad(M, N, K, pro):
     t = T()
