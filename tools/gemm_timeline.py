@@ -67,48 +67,40 @@ def run():
 
 
 def analyse(d, us, mask):
+    """Per-CU timeline (the s_memtime counters are not synchronised across XCDs / shader engines, so everything is
+    computed per CU: HW_ID + XCC_ID identify it): ticks per microsecond from the CU's busy span against the launch
+    duration, phase means, idle gap between consecutive workgroups (round-1 kernel) or tiles (persistent kernel)."""
     import numpy as np
     d = d[d[:, 0] > 0]
     t = d[:, :6].astype(np.float64)
     hw, xcc = d[:, 6], d[:, 7] & 0xf
-    # the s_memtime counters of the XCDs are not synchronised: everything per XCD
-    spans = [t[xcc == x, 5].max() - t[xcc == x, 0].min() for x in np.unique(xcc)]
-    tk = np.mean(spans) / us
-    print('   %d workgroups, %d XCDs, per-XCD stamp span %.0f..%.0f ticks -> %.1f ticks/us' % (
-        len(d), len(spans), min(spans), max(spans), tk))
-    names = ['prologue (first tile staged)', 'k loop', 'epilogue half 0', 'epilogue half 1',
-             'stores acknowledged' if mask & 32 else '(end)']
-    for i, nm in enumerate(names):
-        dt = t[:, i + 1] - t[:, i]
-        print('   %-30s mean %7.2f us   p10 %7.2f   p90 %7.2f' % (nm, dt.mean() / tk, np.quantile(dt, 0.1) / tk,
-                                                                     np.quantile(dt, 0.9) / tk))
-    print('   %-30s mean %7.2f us' % ('workgroup lifetime', (t[:, 5] - t[:, 0]).mean() / tk))
-    cu_key = (xcc << 16) | (hw & 0xff00) | ((hw >> 13) & 7)
-    gaps, per_cu = [], []
-    for key in np.unique(cu_key):
-        tt = t[cu_key == key]
+    key = (xcc << 16) | (hw & 0xff00) | ((hw >> 13) & 7)
+    spans, gaps = [], []
+    for k in np.unique(key):
+        tt = t[key == k]
         tt = tt[np.argsort(tt[:, 0])]
-        per_cu.append(len(tt))
+        spans.append(tt[-1, 5] - tt[0, 0])
         if len(tt) > 1:
             gaps.append(tt[1:, 0] - tt[:-1, 5])
-    g = np.concatenate(gaps)
-    print('   distinct CU keys %d, workgroups per CU %.1f; gap end -> next start on one CU: mean %.2f us, p10 %.2f, '
-          'p90 %.2f' % (len(per_cu), np.mean(per_cu), g.mean() / tk, np.quantile(g, 0.1) / tk, np.quantile(g, 0.9) / tk))
-    fr = []
-    for x in np.unique(xcc):
-        tx = t[xcc == x]
-        t0 = tx[:, 0].min()
-        grid = np.linspace(0.1, 0.9, 200) * (tx[:, 5].max() - t0)
-        inep = np.array([(((tx[:, 2] - t0) <= v) & ((tx[:, 5] - t0) > v)).sum() for v in grid])
-        live = np.array([(((tx[:, 0] - t0) <= v) & ((tx[:, 5] - t0) > v)).sum() for v in grid])
-        fr.append(inep / np.maximum(live, 1))
-    fr = np.concatenate(fr)
-    print('   share of an XCD\'s live workgroups that are in their epilogue: mean %.2f, p10 %.2f, p90 %.2f '
-          '(lockstep -> bimodal)' % (fr.mean(), np.quantile(fr, 0.1), np.quantile(fr, 0.9)))
+    tk = np.median(spans) / us
+    g = np.concatenate(gaps) if gaps else np.zeros(1)
+    print('   %d tiles on %d CUs, %.0f ticks/us' % (len(d), len(spans), tk))
+    persistent = bool((t[:, 1] == t[:, 0]).all())           # the persistent kernel stamps 0, 2, 3, 4, 5 only
+    phases = ([(0, 2, 'k loop'), (2, 3, 'epilogue half 0'), (3, 4, 'epilogue half 1'), (4, 5, 'stats / end')] if persistent else
+              [(0, 1, 'first tile staged'), (1, 2, 'k loop'), (2, 3, 'epilogue half 0'), (3, 4, 'epilogue half 1'),
+               (4, 5, 'stores acknowledged' if mask & 32 else 'end')])
+    for i0, i1, nm in phases:
+        dt = t[:, i1] - t[:, i0]
+        print('   %-22s mean %6.2f us   p10 %6.2f   p90 %6.2f' % (nm, dt.mean() / tk, np.quantile(dt, .1) / tk,
+                                                                  np.quantile(dt, .9) / tk))
+    print('   tile %.2f us, gap to the next one on the same CU %.2f us' % ((t[:, 5] - t[:, 0]).mean() / tk, g.mean() / tk))
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'build':
         build()
+    elif len(sys.argv) > 4 and sys.argv[1] == 'analyse':      # analyse <file.npy> <launch us> <mask>: offline
+        import numpy as np
+        analyse(np.load(sys.argv[2]), float(sys.argv[3]), int(sys.argv[4]))
     else:
         run()
