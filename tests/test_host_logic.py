@@ -254,3 +254,21 @@ def test_integration_stub_matches_the_header():
     # every header entry point has the arity the in-repo binding declares
     for name, (_, argtypes) in _lib._SIGNATURES.items():
         assert len(argtypes) == header_arity(name) or name == 'tfr_hip_abi_version', name
+
+
+def test_every_environment_switch_is_documented():
+    """DESIGN.md section 8 lists the A/B switches; a switch read by the sources but missing there is undocumented
+    behaviour."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for path in (glob.glob(os.path.join(root, 'ranking_amd', '**', '*.py'), recursive=True) +
+                 glob.glob(os.path.join(root, 'ranking_amd', 'csrc', '*.hip')) +
+                 glob.glob(os.path.join(root, 'ranking_amd', 'csrc', '*.cpp')) + [os.path.join(root, 'bench.py')]):
+        text = open(path).read()
+        used |= set(re.findall(r'(?:getenv|env_int\w*|environ\.get)\(\s*[\'"](TFR_[A-Z0-9_]+)[\'"]', text))
+    design = open(os.path.join(root, 'DESIGN.md')).read()
+    section = design[design.index('## 8. Developer switches'):]
+    missing = sorted(v for v in used if v not in section)
+    assert not missing, missing
