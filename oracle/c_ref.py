@@ -5,6 +5,7 @@ build() compiles with gcc into oracle/_build/ (git-ignored, travels with gpurun)
   libapprox_ndcg_f64.so        strict fp64 arbiter            tfr_c_approx_ndcg_f64
   libapprox_ndcg_f32.so        -Ofast -march=native float     tfr_c_approx_ndcg_f32_fast
   libpairwise_softmax_f64.so   pairwise_softmax_c.c (fp64)    tfr_c_pairwise_logistic_ndcg_f64, tfr_c_softmax_f64
+  liblistwise_f64.so           listwise_c.c (fp64)            tfr_c_list_mle_f64, tfr_c_unique_softmax_f64
 """
 import ctypes
 import hashlib
@@ -17,11 +18,13 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, 'approx_ndcg_c.c')
 SRC_PS = os.path.join(HERE, 'pairwise_softmax_c.c')
+SRC_LW = os.path.join(HERE, 'listwise_c.c')
 OUT = os.path.join(HERE, '_build')
 _VARIANTS = {   # key: (library, entry point, flags, source)
     'f64': ('libapprox_ndcg_f64.so', 'tfr_c_approx_ndcg_f64', ['-O2', '-fno-fast-math'], SRC),
     'f32_fast': ('libapprox_ndcg_f32.so', 'tfr_c_approx_ndcg_f32_fast', ['-DTFR_C_FLOAT', '-Ofast', '-march=native'], SRC),
     'ps_f64': ('libpairwise_softmax_f64.so', 'tfr_c_softmax_f64', ['-O2', '-fno-fast-math'], SRC_PS),
+    'lw_f64': ('liblistwise_f64.so', 'tfr_c_list_mle_f64', ['-O2', '-fno-fast-math'], SRC_LW),
 }
 _handles = {}
 
@@ -160,3 +163,38 @@ def ndcg_mrr(predictions, labels, mask=None, topn=None):
           0 if topn is None else int(topn), ndcg.ctypes.data, mrr.ctypes.data) != 0:
         raise ValueError('ndcg_mrr_c: invalid argument')
     return ndcg, mrr
+
+
+def list_mle(logits, labels, mask=None, pos_weight=None, temperature=1.0, want_grad=True):
+    """(loss [B], dlogits [B, L] | None) of ListMLELoss (losses_impl.py:1541-1576; pos_weight[p] = the
+    ListMLELambdaWeight rank discount of position p + 1, :457-480); fp64 inside, O(L^2) loops."""
+    logits, labels, m = _prep(logits, labels, mask)
+    B, L = logits.shape
+    pw = None if pos_weight is None else np.ascontiguousarray(np.asarray(pos_weight, dtype=np.float32))
+    lib = ctypes.CDLL(build()['lw_f64'])
+    fn = lib.tfr_c_list_mle_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 2
+    loss = np.empty(B, dtype=np.float32)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    if fn(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data,
+          None if pw is None else pw.ctypes.data, B, L, float(temperature), loss.ctypes.data,
+          None if grad is None else grad.ctypes.data) != 0:
+        raise ValueError('list_mle_c: invalid argument')
+    return loss, grad
+
+
+def unique_softmax(logits, labels, mask=None, temperature=1.0, want_grad=True):
+    """(loss [B], dlogits [B, L] | None) of UniqueSoftmaxLoss (losses_impl.py:1250-1281); fp64 inside."""
+    logits, labels, m = _prep(logits, labels, mask)
+    B, L = logits.shape
+    lib = ctypes.CDLL(build()['lw_f64'])
+    fn = lib.tfr_c_unique_softmax_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float] + [ctypes.c_void_p] * 2
+    loss = np.empty(B, dtype=np.float32)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    if fn(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L, float(temperature),
+          loss.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
+        raise ValueError('unique_softmax_c: invalid argument')
+    return loss, grad

@@ -1451,6 +1451,32 @@ def _c_ref_or_skip():
         pytest.skip('plain-C oracle not buildable here: %s' % e)
 
 
+@pytest.mark.parametrize('B,L', [(5, 50), (16, 200), (3, 1000), (2, 1500)])          # 1500: the workgroup kernels
+def test_listwise_kernels_against_the_plain_c_arbiters(B, L):
+    """ListMLE (+ lambda weight) and UniqueSoftmax through the C ABI against oracle/listwise_c.c: fp64 double loops
+    over the definitions, no sort + scan formulation in common with the kernels."""
+    c = _c_ref_or_skip()
+    from ranking_amd import _ops
+    t = lambda a: torch.from_numpy(a)
+    labels, logits = make_batch(B, L, seed=1700 + L)
+    labels[1] = -1.0
+    g = torch.Generator().manual_seed(L)                   # distinct labels for ListMLE (ties: unpinned in the reference)
+    distinct = torch.where(labels >= 0, labels + torch.rand(labels.shape, generator=g) * 0.5, labels)
+    T_ = 0.7
+    for pw in (None, (1.0 / torch.log1p(torch.arange(1, L + 1, dtype=torch.float32)))):
+        loss, d = _ops.list_mle(logits.to(DEV), distinct.to(DEV), None, None if pw is None else pw.to(DEV), None, T_)
+        w_loss, w_grad = c.list_mle(logits.numpy(), distinct.numpy(), pos_weight=None if pw is None else pw.numpy(),
+                                    temperature=T_)
+        scale = max(1.0, float(abs(w_loss).max()))
+        assert_loss_close(loss / scale, t(w_loss) / scale, 2e-5, what='list_mle vs C')
+        assert_grad_close(d, t(w_grad), 5e-5, what='list_mle grad vs C')
+    loss, d = _ops.unique_softmax(logits.to(DEV), labels.to(DEV), None, None, 0.8)
+    w_loss, w_grad = c.unique_softmax(logits.numpy(), labels.numpy(), temperature=0.8)
+    scale = max(1.0, float(abs(w_loss).max()))
+    assert_loss_close(loss / scale, t(w_loss) / scale, 2e-5, what='unique_softmax vs C')
+    assert_grad_close(d, t(w_grad), 5e-5, what='unique_softmax grad vs C')
+
+
 @pytest.mark.parametrize('B,L', [(5, 50), (64, 200), (3, 1000)])
 def test_hip_path_against_the_plain_c_arbiters(B, L):
     """ApproxNDCG, PairwiseLogistic + NDCGLambdaWeight, Softmax and NDCG / MRR through the C ABI against the fp64

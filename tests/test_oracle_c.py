@@ -164,3 +164,77 @@ def test_tie_rule_is_the_same_in_both_restatements():
         ndcg, mrr = c_ref.ndcg_mrr(logits.numpy(), labels.numpy(), topn=topn)
         assert np.abs(ndcg - want_n.reshape(-1).numpy()).max() < 2e-6
         assert np.abs(mrr - want_m.reshape(-1).numpy()).max() < 1e-7
+
+
+@pytest.mark.parametrize('B,L', [(5, 1), (6, 7), (9, 50), (4, 300)])
+@pytest.mark.parametrize('with_lambda', [False, True])
+def test_list_mle_c_against_the_torch_restatement(B, L, with_lambda):
+    """oracle/listwise_c.c (fp64 double loops over the definition, losses_impl.py:1541-1576) vs oracle/tfr_ref.py
+    (op-for-op torch + autograd): two independent restatements of ListMLE (+ ListMLELambdaWeight, :457-480)."""
+    labels, logits = make_batch(B, L, seed=4100 + L)
+    g = torch.Generator().manual_seed(L)                   # distinct labels: the reference shuffles ties at random
+    labels = torch.where(labels >= 0, labels + torch.rand(labels.shape, generator=g) * 0.5, labels)
+    if B >= 3:
+        labels[1] = -1.0
+    T_ = 0.7
+    disc = (lambda rank: 1. / torch.log1p(rank)) if with_lambda else None
+    oracle = R.ListMLELoss(lambda_weight=R.ListMLELambdaWeight(disc) if with_lambda else None, temperature=T_)
+    lg = logits.clone().requires_grad_(True)
+    want = oracle._compute_unreduced_loss_impl(labels, lg / T_)[0]
+    want.sum().backward()
+    pw = disc(torch.arange(1, L + 1, dtype=torch.float32)).numpy() if with_lambda else None
+    loss, grad = c_ref.list_mle(logits.numpy(), labels.numpy(), pos_weight=pw, temperature=T_)
+    scale = max(1.0, float(want.detach().abs().max()))
+    assert np.abs(loss - want.detach().reshape(-1).numpy()).max() <= 2e-6 * scale * max(1, L) ** 0.5
+    assert np.abs(grad - lg.grad.numpy()).max() <= 5e-6 * max(1.0, float(lg.grad.abs().max()))
+    assert not grad[labels.numpy() < 0].any()
+    with pytest.raises(ValueError):
+        c_ref.list_mle(logits.numpy(), labels.numpy(), temperature=0.0)
+
+
+@pytest.mark.parametrize('B,L', [(5, 1), (6, 7), (9, 50), (4, 300)])
+def test_unique_softmax_c_against_the_torch_restatement(B, L):
+    """UniqueSoftmaxLoss (losses_impl.py:1250-1281): the C double loop over `l_j < l_i` vs the torch restatement's
+    [B, L, L + 1] tensor."""
+    labels, logits = make_batch(B, L, seed=4300 + L)       # graded labels: plenty of tie groups
+    if B >= 3:
+        labels[1] = -1.0
+        labels[0] = torch.where(labels[0] >= 0, torch.ones_like(labels[0]) * 2, labels[0])   # one single group
+    T_ = 0.8
+    oracle = R.UniqueSoftmaxLoss(temperature=T_)
+    lg = logits.clone().requires_grad_(True)
+    want = oracle._compute_unreduced_loss_impl(labels, lg / T_)[0]
+    want.sum().backward()
+    loss, grad = c_ref.unique_softmax(logits.numpy(), labels.numpy(), temperature=T_)
+    scale = max(1.0, float(want.detach().abs().max()))
+    assert np.abs(loss - want.detach().reshape(-1).numpy()).max() <= 5e-6 * scale
+    assert np.abs(grad - lg.grad.numpy()).max() <= 2e-5 * max(1.0, float(lg.grad.abs().max()))
+    assert not grad[labels.numpy() < 0].any()
+
+
+def test_listwise_c_reference_known_answers():
+    """The reference's own literals: ListMLE losses_impl_test.py:1276-1328, UniqueSoftmax :1231-1271 (per-list sums of
+    the closed forms the tests average)."""
+    ln = math.log
+    scores = [[0., ln(3), ln(2)], [0., ln(2), ln(3)]]
+    labels = [[0., 2., 1.], [1., 0., 2.]]
+    loss, _ = c_ref.list_mle(scores, labels)
+    want = [-(ln(3. / 6) + ln(2. / 3) + ln(1. / 1)), -(ln(3. / 6) + ln(1. / 3) + ln(2. / 2))]
+    assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-6
+    pw = [2. ** (3 - r) - 1. for r in (1, 2, 3)]             # ListMLELambdaWeight(rank_discount_fn = 2^(3 - rank) - 1)
+    loss, _ = c_ref.list_mle(scores, labels, pos_weight=pw)
+    want = [-(3 * ln(3. / 6) + 1 * ln(2. / 3)), -(3 * ln(3. / 6) + 1 * ln(1. / 3))]
+    assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-6
+    # (the masked case :1318-1328 is not a per-item identity: the reference leaves the masked item in the denominators
+    #  with exp(log 1e-10); both restatements agree on it in test_list_mle_c_against_the_torch_restatement)
+
+    def softmax(v):
+        e = [math.exp(x) for x in v]
+        return [x / sum(e) for x in e]
+    scores = [[1., 3., 2.], [1., 2., 3.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 1., 2.], [0., 0., 0.]]
+    loss, _ = c_ref.unique_softmax(scores, labels)
+    want = [-ln(softmax(scores[0])[2]), -(ln(softmax(scores[1][:2])[1]) + 3. * ln(softmax(scores[1])[2])), 0.0]
+    assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-6
+    loss, _ = c_ref.unique_softmax([[1., 2., 3., 2.]], [[0., 1., 1., 0.]], mask=[[True, False, True, True]])
+    assert abs(loss[0] + ln(softmax([1, 3, 2])[1])) < 1e-6
