@@ -5,7 +5,7 @@ build() compiles with gcc into oracle/_build/ (git-ignored, travels with gpurun)
   libapprox_ndcg_f64.so        strict fp64 arbiter            tfr_c_approx_ndcg_f64
   libapprox_ndcg_f32.so        -Ofast -march=native float     tfr_c_approx_ndcg_f32_fast
   libpairwise_softmax_f64.so   pairwise_softmax_c.c (fp64)    tfr_c_pairwise_logistic_ndcg_f64, tfr_c_softmax_f64
-  liblistwise_f64.so           listwise_c.c (fp64)            tfr_c_list_mle_f64, tfr_c_unique_softmax_f64
+  liblistwise_f64.so           listwise_c.c (fp64)            tfr_c_list_mle_f64, tfr_c_unique_softmax_f64, tfr_c_circle_f64
 """
 import ctypes
 import hashlib
@@ -198,3 +198,22 @@ def unique_softmax(logits, labels, mask=None, temperature=1.0, want_grad=True):
           loss.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
         raise ValueError('unique_softmax_c: invalid argument')
     return loss, grad
+
+
+def circle(logits, labels, mask=None, gamma=64.0, margin=0.25, clip=True, want_grad=True):
+    """(loss [B], has_pair [B] bool, dlogits [B, L] | None) of CircleLoss (losses_impl.py:1036-1116) on raw logits
+    (clip = get_logits' clip_by_value(0, 1)); fp64 inside, the pair sum with its maximum pulled out."""
+    logits, labels, m = _prep(logits, labels, mask)
+    B, L = logits.shape
+    lib = ctypes.CDLL(build()['lw_f64'])
+    fn = lib.tfr_c_circle_f64
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int] + \
+        [ctypes.c_void_p] * 3
+    loss = np.empty(B, dtype=np.float32)
+    has = np.empty(B, dtype=np.uint8)
+    grad = np.empty((B, L), dtype=np.float32) if want_grad else None
+    if fn(logits.ctypes.data, labels.ctypes.data, None if m is None else m.ctypes.data, B, L, float(gamma), float(margin),
+          1 if clip else 0, loss.ctypes.data, has.ctypes.data, None if grad is None else grad.ctypes.data) != 0:
+        raise ValueError('circle_c: invalid argument')
+    return loss, has.astype(bool), grad

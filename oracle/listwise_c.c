@@ -116,3 +116,64 @@ int tfr_c_unique_softmax_f64(const float* logits, const float* labels, const uns
   }
   return 0;
 }
+
+/* CircleLoss (tensorflow_ranking/python/losses_impl.py:1036-1116): scores s (already clipped to [0, 1] by get_logits when
+ * `clip` != 0, :1082-1085), alpha_i = relu(1 + margin - s_i), alpha'_j = relu(s_j + margin) held constant,
+ *   loss[b] = log1p( sum_{valid i, j: y_i > y_j} exp(gamma (alpha_i (1 - margin - s_i) + alpha'_j (s_j - margin))) ).
+ * dlogits = d loss / d raw logits (the clip passes the gradient on [0, 1]).  The double sum runs in fp64 with the exponent's
+ * maximum pulled out, so gamma = 64 does not overflow (the fp32 reference overflows to inf near s = 1; the kernel and
+ * this arbiter do not).  has_pair[b] = 1 when the list has a preference pair (the reference's weight is 0 / 0 = NaN
+ * without one, :1109-1111). */
+int tfr_c_circle_f64(const float* logits, const float* labels, const unsigned char* mask, int B, int L, float gamma,
+                     float margin, int clip, float* loss_out, unsigned char* has_pair_out, float* dlogits_out) {
+  if (!logits || !labels || !loss_out || B < 0 || L <= 0) return -1;
+#pragma omp parallel for schedule(dynamic)
+  for (int b = 0; b < B; ++b) {
+    const float* lg = logits + (size_t)b * L;
+    const float* lb = labels + (size_t)b * L;
+    double* a = (double*)malloc(sizeof(double) * (size_t)L);   /* gamma * alpha_i (1 - margin - s_i) */
+    double* c = (double*)malloc(sizeof(double) * (size_t)L);   /* gamma * alpha'_j (s_j - margin)   */
+    double* s = (double*)malloc(sizeof(double) * (size_t)L);
+    int* v = (int*)malloc(sizeof(int) * (size_t)L);
+    for (int i = 0; i < L; ++i) {
+      v[i] = mask ? (mask[(size_t)b * L + i] != 0) : (lb[i] >= 0.0f);
+      double x = (double)lg[i];
+      if (clip) x = x < 0.0 ? 0.0 : (x > 1.0 ? 1.0 : x);
+      s[i] = x;
+      const double ai = fmax(1.0 - x + (double)margin, 0.0), aj = fmax(x + (double)margin, 0.0);
+      a[i] = (double)gamma * ai * (1.0 - x - (double)margin);
+      c[i] = (double)gamma * aj * (x - (double)margin);
+    }
+    double mx = -INFINITY;
+    for (int i = 0; i < L; ++i)
+      for (int j = 0; j < L; ++j)
+        if (v[i] && v[j] && lb[i] > lb[j] && a[i] + c[j] > mx) mx = a[i] + c[j];
+    const int any = mx > -INFINITY;
+    double W = 0.0;                                             /* sum of exp(. - mx) */
+    if (any)
+      for (int i = 0; i < L; ++i)
+        for (int j = 0; j < L; ++j)
+          if (v[i] && v[j] && lb[i] > lb[j]) W += exp(a[i] + c[j] - mx);
+    /* log1p(W e^mx) = mx + log(W) + log1p(e^{-(mx + log W)}) for large arguments, direct otherwise */
+    const double lw = any ? mx + log(W) : -INFINITY;
+    loss_out[b] = (float)(any ? (fmax(lw, 0.0) + log1p(exp(-fabs(lw)))) : 0.0);
+    if (has_pair_out) has_pair_out[b] = (unsigned char)any;
+    if (dlogits_out) {
+      const double sig = any ? 1.0 / (1.0 + exp(-lw)) : 0.0;     /* W' / (1 + W'), W' = the un-shifted sum */
+      for (int k = 0; k < L; ++k) {
+        double g = 0.0;
+        const int inside = !clip || ((double)lg[k] >= 0.0 && (double)lg[k] <= 1.0);
+        if (any && v[k] && inside) {
+          double hi = 0.0, lo = 0.0;                           /* k as the preferred item / as the other one */
+          for (int j = 0; j < L; ++j) if (v[j] && lb[k] > lb[j]) hi += exp(a[k] + c[j] - lw);
+          for (int i = 0; i < L; ++i) if (v[i] && lb[i] > lb[k]) lo += exp(a[i] + c[k] - lw);
+          const double ai = fmax(1.0 - s[k] + (double)margin, 0.0), aj = fmax(s[k] + (double)margin, 0.0);
+          g = (double)gamma * sig * (-ai * hi + aj * lo);
+        }
+        dlogits_out[(size_t)b * L + k] = (float)g;
+      }
+    }
+    free(a); free(c); free(s); free(v);
+  }
+  return 0;
+}

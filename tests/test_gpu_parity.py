@@ -1453,8 +1453,8 @@ def _c_ref_or_skip():
 
 @pytest.mark.parametrize('B,L', [(5, 50), (16, 200), (3, 1000), (2, 1500)])          # 1500: the workgroup kernels
 def test_listwise_kernels_against_the_plain_c_arbiters(B, L):
-    """ListMLE (+ lambda weight) and UniqueSoftmax through the C ABI against oracle/listwise_c.c: fp64 double loops
-    over the definitions, no sort + scan formulation in common with the kernels."""
+    """ListMLE (+ lambda weight), UniqueSoftmax and CircleLoss through the C ABI against oracle/listwise_c.c: fp64
+    double loops over the definitions, no sort + scan formulation in common with the kernels."""
     c = _c_ref_or_skip()
     from ranking_amd import _ops
     t = lambda a: torch.from_numpy(a)
@@ -1475,6 +1475,15 @@ def test_listwise_kernels_against_the_plain_c_arbiters(B, L):
     scale = max(1.0, float(abs(w_loss).max()))
     assert_loss_close(loss / scale, t(w_loss) / scale, 2e-5, what='unique_softmax vs C')
     assert_grad_close(d, t(w_grad), 5e-5, what='unique_softmax grad vs C')
+    # CircleLoss on similarity scores, some outside [0, 1] (clip on)
+    sim = -0.3 + 1.6 * torch.sigmoid(logits)
+    for gamma, margin in ((64., 0.25), (4., 0.1)):
+        loss, w, d = _ops.circle_loss(sim.to(DEV), labels.to(DEV), None, None, gamma, margin, True)
+        w_loss, w_has, w_grad = c.circle(sim.numpy(), labels.numpy(), gamma=gamma, margin=margin)
+        scale = max(1.0, float(abs(w_loss).max()))
+        assert_loss_close(loss / scale, t(w_loss) / scale, 2e-5, what='circle vs C')
+        assert_grad_close(d, t(w_grad), 5e-5, what='circle grad vs C')
+        assert torch.equal(~torch.isnan(w.cpu()), t(w_has))
 
 
 @pytest.mark.parametrize('B,L', [(5, 50), (64, 200), (3, 1000)])

@@ -238,3 +238,44 @@ def test_listwise_c_reference_known_answers():
     assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-6
     loss, _ = c_ref.unique_softmax([[1., 2., 3., 2.]], [[0., 1., 1., 0.]], mask=[[True, False, True, True]])
     assert abs(loss[0] + ln(softmax([1, 3, 2])[1])) < 1e-6
+
+
+def _circle_py(labels, scores, gamma=64., margin=0.25):
+    """losses_impl_test.py:32-87: the reference test suite's own helper (sum over preference pairs)."""
+    tot = 0.
+    for i in range(len(labels)):
+        for j in range(len(labels)):
+            if labels[i] > labels[j]:
+                tot += math.exp(gamma * max(0., (1 + margin) - scores[i]) * ((1 - margin) - scores[i])
+                                + gamma * max(0., scores[j] + margin) * (scores[j] - margin))
+    return tot
+
+
+def test_circle_c_known_answers_and_agreement():
+    """oracle/listwise_c.c tfr_c_circle_f64: the reference's literals (losses_impl_test.py:1001-1083) and agreement
+    with the torch restatement (fp64 run of it) on random batches, gradient included."""
+    scores = [[0.1, 0.3, 0.2], [0.1, 0.2, 0.3]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    loss, has, _ = c_ref.circle(scores, labels)
+    want = [math.log1p(_circle_py(labels[0], scores[0])), math.log1p(_circle_py(labels[1], scores[1]))]
+    assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-5 * max(want) and has.all()
+    loss, has, _ = c_ref.circle(scores, [[0., 0., 1.], [0., 1., 2.]], gamma=4., margin=0.1)
+    want = [math.log1p(_circle_py(labels[0], scores[0], 4., 0.1)), math.log1p(_circle_py(labels[1], scores[1], 4., 0.1))]
+    assert np.abs(loss - np.array(want, dtype=np.float32)).max() < 1e-6
+    loss, has, _ = c_ref.circle([[.1, .3, .2]], [[0., -1., 1.]])                      # an invalid item
+    assert abs(loss[0] - math.log1p(_circle_py([0., 1.], [.1, .2]))) < 1e-5 * loss[0]
+    loss, has, grad = c_ref.circle([[.1, .3, .2]], [[1., 1., 1.]])                    # no preference pair
+    assert loss[0] == 0.0 and not has[0] and not grad.any()
+    for (B, L, gamma, margin, lo, hi) in ((6, 7, 64., 0.25, 0.2, 0.6), (9, 50, 4., 0.1, -0.3, 1.3), (4, 300, 16., 0.25, 0.0, 1.0)):
+        lab, lg = make_batch(B, L, seed=4700 + L)
+        lg = lo + (hi - lo) * torch.sigmoid(lg)                        # similarity scores, some outside [0, 1]
+        lab[1] = -1.0
+        oracle = R.CircleLoss(gamma=gamma, margin=margin)
+        x = lg.double().clone().requires_grad_(True)
+        want = oracle._compute_unreduced_loss_impl(lab.double(), oracle.get_logits(x))[0]
+        want.sum().backward()
+        loss, has, grad = c_ref.circle(lg.numpy(), lab.numpy(), gamma=gamma, margin=margin)
+        w = want.detach().reshape(-1).numpy()
+        assert np.abs(loss - w).max() <= 1e-6 * max(1.0, np.abs(w).max())
+        assert np.abs(grad - x.grad.numpy()).max() <= 1e-5 * max(1.0, float(x.grad.abs().max()))
+        assert not has[1] and has[0]
