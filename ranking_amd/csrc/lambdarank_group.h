@@ -1,0 +1,477 @@
+// LambdaRank "group" kernel (round 3): PairwiseLogisticLoss x (N)DCGLambdaWeight with smooth_fraction 0, no topn, a
+// built-in monotone gain and no separate mask -- BASELINE config 3, the kernel north_star names.  Included by
+// pairwise.hip inside its anonymous namespace (shares PwArgs and the pair-loss helpers).
+//
+// Reference behaviour restated (losses_impl.py): _compute_ranks :483-500, _pairwise_comparison :503-537,
+// DCGLambdaWeight.pair_weights :255-279 / _pair_rank_discount :334-369 (smooth_fraction 0: |D(|r_i-r_j|) - D(|r_i-r_j|+1)|),
+// inverse_max_dcg :109-134, _PairwiseLoss._compute_unreduced_loss_impl :871-884, _normalize_weights_impl :917-930,
+// PairwiseLogisticLoss._pairwise_loss :936-940; backward = SURVEY.md Appendix B.
+//
+// What round 2's pairwise_lean_kernel left on the table (profiles/r02_pairwise_phases.txt):
+//   (1) the rank-difference discount U[|r_i - r_j|] is a data-dependent LDS gather: 32 lanes with arbitrary ranks hit
+//       the 32 banks ~3.3 deep, and together with the 16-byte column records the sweeps asked the CU's one LDS for
+//       ~21 cycles per trip and wave against 50-72 cycles of VALU work, four SIMDs sharing it: LDS-bound;
+//   (2) one list per wavefront and four such waves per SIMD at B = 4096: the kernel lasted 2.1x the mean wave's
+//       lifetime (n^2 varies 4x between lists), i.e. half of the launch was a tail;
+//   (3) every pair paid `sub, max, mul` for a weight (G_i - G_j)+ * u whose gain difference is constant over a whole
+//       (row, grade segment) rectangle.
+// This kernel:
+//   * ONE workgroup = W wavefronts = W lists.  Wave w builds list w's LDS image alone (load, compaction, ranks by
+//     counting, grade order, ideal DCG, records: no cross-wave traffic), ONE barrier, then the (list, 32-row pass)
+//     work items of ALL W lists are dealt round-robin to the W waves: every SIMD of the CU gets an equal share of
+//     every list, and the lists of a workgroup are drawn serpentine-wise from the longest-first order (long lists
+//     are paired with short ones), so neither SIMDs nor CUs are left with the long lists.
+//   * the table U[m] * list_size is replicated once per LDS bank (address = (m * R + lane % R) * 4, R = 32): the
+//     gather is conflict-free by construction (2 LDS cycles per wave instruction), `v_sad_u16` on the pre-scaled
+//     ranks still forms the address in one instruction.  The table is list independent: one copy per workgroup.
+//   * records are split by use: the "hi" sweep reads (B_j, rank_j), the "lo" sweep (A_j, rank_j) -- 8 bytes per
+//     column, two columns per ds_read_b128.
+//   * grade segments start on 4-column boundaries (padding records with A = B = 0 contribute exactly nothing:
+//     w = fma(A_i, 0, 1) = 1 -> log2 = 0, 1 - 1/w = 0), so a row pass sweeps one column SEGMENT at a time and the
+//     gain difference is applied once per (row, segment): a hi pair is `sad, fma, rcp, log, fma, sub, fma`
+//     (5 plain + 2 transcendental, was 8 + 2), a lo pair `sad, fma, rcp, sub, fma` (4 + 1, was 7 + 1).
+//   * more than kMaxRuns distinct label values: the rest forms one unsorted tail segment whose column loops take the
+//     gain difference per pair (PG variants).  Lists whose score range exceeds kLeanRange take a per-pair exp body.
+#pragma once
+
+constexpr int kGrpMaxSeg = kMaxRuns + 1;        // pure segments + the unsorted tail
+constexpr int kGrpSegSlots = 10;
+constexpr int kGrpPassRows = 32;                // rows per pass: two lanes per row
+constexpr int kGrpMaxPass = 12;
+constexpr int kGrpSlack = 8;                    // readable zero records behind every column array (prefetch overrun)
+
+struct GrpHdr {                                 // per list, in LDS (256 bytes)
+  int n, np, nseg, flags;                       // valid items; padded grade-order length (multiple of 4); segments; 1 = fast, 2 = tail
+  int b, npass;                                 // list index (-1: empty slot), 32-row passes
+  float lw, pad0;
+  int seg_start[kGrpSegSlots];                  // padded grade positions
+  int seg_end[kGrpSegSlots];                    // start + count rounded up to 4
+  float seg_gain[kGrpSegSlots];                 // gain * 1 / max DCG of the segment's label value (pure segments)
+  float pass_loss[kGrpMaxPass];
+  float pass_nnz[kGrpMaxPass];
+};
+static_assert(sizeof(GrpHdr) <= 256, "GrpHdr");
+constexpr int kGrpHdrBytes = 256;
+
+__host__ __device__ inline int grp_lp(int L) { return ((L + 3 * kGrpMaxSeg + 4 + 31) / 32) * 32; }
+__host__ __device__ inline size_t grp_list_bytes(int Lp, bool itemw) {
+  // recH float2 [Lp + slack], recL float2 [Lp + slack], GS float [Lp + slack], CIS int [Lp], (WS float [Lp + slack])
+  return kGrpHdrBytes + (size_t)(Lp + kGrpSlack) * (8 + 8 + 4 + (itemw ? 4 : 0)) + (size_t)Lp * 4;
+}
+__host__ __device__ inline size_t grp_table_bytes(int L, int R) { return (((size_t)L * R * 4) + 127) & ~(size_t)127; }
+
+typedef const __attribute__((address_space(3))) float grp_lds_cf;
+
+// u = Urep[(|r_i - r_j| * R + lane % R)]: ranks are stored pre-multiplied by 4 R, `ubase` = LDS address of the table
+// + 4 (lane % R).  One v_sad_u16 forms the byte address (|a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c).
+__device__ __forceinline__ float grp_u(uint32_t ri, float rj_bits, uint32_t ubase) {
+  return *(grp_lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(ri, (uint32_t)__float_as_int(rj_bits), ubase);
+}
+
+struct GrpAcc { float l, g, w, nz; };
+
+// "hi" sweep of one column segment [s, s + 4 trips): the row item is the preferred one.  Accumulates
+// sum u * log2(1 + e^-(x_i - x_j)) and sum u * sigma(-(x_i - x_j)); PG: the gain difference is taken per pair
+// (unsorted tail segment) and is part of u.  Lane c of a row takes columns s + 4 t + 2 c, + 1.
+template <bool PG, bool AUX>
+__device__ __forceinline__ void grp_hi_loop(const float2* recH, const float* GS, int s, int trips, int c, float Ai,
+                                            float Gi, uint32_t ri, uint32_t ubase, GrpAcc& acc) {
+  float al = 0.f, ag = 0.f, aw = 0.f, anz = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(recH + s + 2 * c);      // a trip = 4 records = 2 float4
+  const float2* gp = reinterpret_cast<const float2*>(GS + s + 2 * c);
+  float4 cr = p[0];
+  float u0 = grp_u(ri, cr.y, ubase), u1 = grp_u(ri, cr.w, ubase);
+  float4 cn = p[2];
+#pragma unroll 2
+  for (int t = 0; t < trips; ++t) {                           // uniform trip count: scalar loop control
+    const float un0 = grp_u(ri, cn.y, ubase), un1 = grp_u(ri, cn.w, ubase);
+    const float4 cnn = p[2 * t + 4];
+    if (PG) {
+      const float2 gj = gp[2 * t];
+      u0 *= fmaxf(Gi - gj.x, 0.0f); u1 *= fmaxf(Gi - gj.y, 0.0f);
+    }
+    const float w0 = __builtin_fmaf(Ai, cr.x, 1.0f), w1 = __builtin_fmaf(Ai, cr.z, 1.0f);
+    const float q0 = __builtin_amdgcn_rcpf(w0), q1 = __builtin_amdgcn_rcpf(w1);
+    const float l0 = __builtin_amdgcn_logf(w0), l1 = __builtin_amdgcn_logf(w1);
+    al = __builtin_fmaf(u0, l0, al); al = __builtin_fmaf(u1, l1, al);
+    ag = __builtin_fmaf(u0, 1.0f - q0, ag); ag = __builtin_fmaf(u1, 1.0f - q1, ag);
+    if (AUX) {                                                // padding columns (B = 0) carry a non-zero u: mask them
+      const float v0 = (cr.x != 0.0f) ? u0 : 0.0f, v1 = (cr.z != 0.0f) ? u1 : 0.0f;
+      aw += v0; aw += v1;
+      anz += (v0 != 0.0f) ? 1.0f : 0.0f; anz += (v1 != 0.0f) ? 1.0f : 0.0f;
+    }
+    cr = cn; cn = cnn; u0 = un0; u1 = un1;
+  }
+  acc.l = al; acc.g = ag; acc.w = aw; acc.nz = anz;
+}
+
+// "lo" sweep of one column segment: the COLUMN item is the preferred one; the row receives sum u * sigma(-(x_j - x_i))
+// (times the column's item weight, ITEMW).
+template <bool PG, bool ITEMW>
+__device__ __forceinline__ float grp_lo_loop(const float2* recL, const float* GS, const float* WS, int s, int trips, int c,
+                                             float Bi, float Gi, uint32_t ri, uint32_t ubase) {
+  float ag = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(recL + s + 2 * c);
+  const float2* gp = reinterpret_cast<const float2*>(GS + s + 2 * c);
+  const float2* wp = reinterpret_cast<const float2*>(WS + s + 2 * c);
+  float4 cr = p[0];
+  float u0 = grp_u(ri, cr.y, ubase), u1 = grp_u(ri, cr.w, ubase);
+  float4 cn = p[2];
+#pragma unroll 2
+  for (int t = 0; t < trips; ++t) {
+    const float un0 = grp_u(ri, cn.y, ubase), un1 = grp_u(ri, cn.w, ubase);
+    const float4 cnn = p[2 * t + 4];
+    if (PG) {
+      const float2 gj = gp[2 * t];
+      u0 *= fmaxf(gj.x - Gi, 0.0f); u1 *= fmaxf(gj.y - Gi, 0.0f);
+    }
+    if (ITEMW) {
+      const float2 wj = wp[2 * t];
+      u0 *= wj.x; u1 *= wj.y;                                // the weight of the PREFERRED item (:917-930)
+    }
+    const float q0 = __builtin_amdgcn_rcpf(__builtin_fmaf(Bi, cr.x, 1.0f));
+    const float q1 = __builtin_amdgcn_rcpf(__builtin_fmaf(Bi, cr.z, 1.0f));
+    ag = __builtin_fmaf(u0, 1.0f - q0, ag); ag = __builtin_fmaf(u1, 1.0f - q1, ag);
+    cr = cn; cn = cnn; u0 = un0; u1 = un1;
+  }
+  return ag;
+}
+
+template <int IPL, bool AUX, bool ITEMW>
+__global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp) {
+  extern __shared__ __attribute__((aligned(128))) unsigned char grp_smem[];
+  const int W = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int L = a.L;
+  float* Urep = reinterpret_cast<float*>(grp_smem);                         // [L * R]
+  const size_t tab_bytes = grp_table_bytes(L, R);
+  const size_t per_list = grp_list_bytes(Lp, ITEMW);
+  const int LpS = Lp + kGrpSlack;
+#define GRP_HDR(l) reinterpret_cast<GrpHdr*>(grp_smem + tab_bytes + (size_t)(l) * per_list)
+#define GRP_RECH(l) reinterpret_cast<float2*>(grp_smem + tab_bytes + (size_t)(l) * per_list + kGrpHdrBytes)
+
+  // ---- 0. the replicated rank-difference table (list independent), all waves.
+  {
+    const int shift = 31 - __builtin_clz(R);
+    const float fL = (float)L;
+    for (int k = threadIdx.x; k < L * R; k += blockDim.x) {
+      const int m = k >> shift;
+      Urep[k] = (m >= 1) ? fabsf(a.discount[m - 1] - a.discount[m]) * fL : 0.0f;   // the final x list_size (:278) folded in
+    }
+  }
+
+  // ---- 1. wave w builds the LDS image of its list.  Lists are drawn serpentine-wise from the launch order.
+  {
+    const int N = gridDim.x;
+    const int posn = (wave & 1) ? (wave + 1) * N - 1 - (int)blockIdx.x : wave * N + (int)blockIdx.x;
+    const int b = (posn < B) ? (a.order ? a.order[posn] : posn) : -1;
+    GrpHdr* H = GRP_HDR(wave);
+    float2* recH = GRP_RECH(wave);
+    float2* recL = recH + LpS;
+    float* GS = reinterpret_cast<float*>(recL + LpS);
+    float* WS = GS + LpS;                                                   // ITEMW only
+    int* CIS = reinterpret_cast<int*>(GS + LpS + (ITEMW ? LpS : 0));
+    if (b < 0) {
+      if (lane == 0) { H->b = -1; H->npass = 0; H->n = 0; }
+    } else {
+      const size_t base = (size_t)b * L;
+      const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
+      float* XS = reinterpret_cast<float*>(recH);                           // scratch: compact scores (rank count)
+      int* RKS = reinterpret_cast<int*>(recL);                              // scratch: count by compact position
+      int* OCC = RKS + Lp;                                                  // scratch: how many items share a count
+      // 1a. load, gains, compaction of the valid items (mask == NULL: valid = label >= 0).
+      float g[IPL], xr[IPL], labr[IPL], wr[IPL];
+      int posr[IPL];
+      bool lv[IPL];
+      int n = 0;
+      float xmin = INFINITY, xmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int e = lane + 64 * r;
+        g[r] = 0.f; lv[r] = false;
+        float x = 0.f, lab = -1.f, w = 0.f;
+        if (e < L) {
+          lab = a.labels[base + e];
+          x = a.logits[base + e] / a.temperature;
+          lv[r] = lab >= 0.0f;
+          if (lv[r]) {
+            g[r] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(lab) : lab;
+            w = ITEMW ? a.item_weights[base + e] * lw : lw;
+            xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
+          } else {
+            if (a.row_loss) a.row_loss[base + e] = 0.f;
+            if (AUX && a.row_weight) a.row_weight[base + e] = 0.f;
+            if (a.dlogits) a.dlogits[base + e] = 0.f;
+          }
+        }
+        const unsigned long long bal = __ballot(lv[r]);
+        xr[r] = x; labr[r] = lv[r] ? lab : -1.0f; wr[r] = w;
+        posr[r] = n + __popcll(bal & ((1ull << lane) - 1ull));
+        if (lv[r]) XS[posr[r]] = x;
+        n += __popcll(bal);
+      }
+      xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
+      const bool fast = (xmax - xmin) <= kLeanRange;                        // wave-uniform
+      const float m = 0.5f * (xmax + xmin);
+      const int n4 = (n + 3) >> 2;
+      for (int p = n + lane; p < n4 * 4 + 4; p += 64) XS[p] = -INFINITY;
+      WAVE_LDS_SYNC();
+
+      // 1b. ranks by counting (score descending, ties by index) (:483-500).
+      int rk[IPL];
+      wave_rank_by_count(XS, n, lane, RKS, OCC);
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
+      WAVE_LDS_SYNC();                                                       // the scratch is rewritten below
+
+      // 1c. grade order: repeatedly take the largest remaining label value; its items (in element order) become the
+      // next segment, which starts on a 4-column boundary.  After kMaxRuns distinct values the rest forms one
+      // unsorted tail segment.  sp = position in the sorted label sequence (ideal DCG), gp = padded grade position.
+      int sp[IPL], gp[IPL];
+      float rem[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) { rem[r] = labr[r]; sp[r] = 0; gp[r] = 0; }
+      int pos = 0, ppos = 0, nseg = 0;
+      bool tail = false;
+      for (int it = 0; it <= kMaxRuns; ++it) {
+        float mx = rem[0];
+#pragma unroll
+        for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+        const float v = wave_max_u(mx);
+        if (v < 0.0f) break;
+        const bool last = it == kMaxRuns;                                    // everything that is left
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool hit = last ? (rem[r] >= 0.0f) : (rem[r] == v);
+          const unsigned long long bal = __ballot(hit);
+          if (hit) {
+            const int o = c + __popcll(bal & ((1ull << lane) - 1ull));
+            sp[r] = pos + o; gp[r] = ppos + o; rem[r] = -2.0f;
+          }
+          c += __popcll(bal);
+        }
+        const int pend = (ppos + c + 3) & ~3;
+        if (lane == 0) {
+          H->seg_start[nseg] = ppos; H->seg_end[nseg] = pend;
+          H->seg_gain[nseg] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(v) : v;
+        }
+        pos += c; ppos = pend; ++nseg;
+        tail = last;
+      }
+
+      // 1d. ideal DCG of the labels (:109-134): the sorted position of a pure-segment item is its grade position;
+      // with an unsorted tail the gains are sorted (register bitonic network) instead.
+      float inv_max_dcg = 1.0f;
+      if (a.normalized) {
+        float idcg = 0.f;
+        if (!tail) {
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) if (lv[r]) idcg += g[r] * a.discount[sp[r]];
+        } else {
+          uint32_t sk[IPL];
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) sk[r] = lv[r] ? float_to_ordered(g[r]) : 0u;
+          wave_sort_desc_u32<IPL>(sk, lane);
+#pragma unroll
+          for (int r = 0; r < IPL; ++r) {
+            const int e = lane + 64 * r;
+            if (e < n) {
+              const uint32_t o = sk[r];
+              idcg += __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o) * a.discount[e];
+            }
+          }
+        }
+        idcg = wave_sum_u(idcg);
+        inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+      }
+
+      // 1e. the image: everything is padding first (A = B = 0, no original index), then the records in grade order.
+      for (int p = lane; p < LpS; p += 64) {
+        recH[p] = make_float2(0.f, 0.f); recL[p] = make_float2(0.f, 0.f); GS[p] = 0.f;
+        if (ITEMW) WS[p] = 0.f;
+        if (p < Lp) CIS[p] = -1;
+      }
+      const int rscale = 4 * R;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        if (!lv[r]) continue;
+        const float xv = xr[r];
+        float Bv, Av;
+        if (fast) {
+          const float t_hi = xv - m;
+          const float bb = t_hi - xv;
+          const float t_lo = (xv - (t_hi - bb)) + (-m - bb);
+          Bv = exp_df_hw(t_hi, t_lo);
+          Av = exp_df_hw(-t_hi, -t_lo);
+        } else {
+          Bv = xv; Av = 1.0f;                                                // slow path: the score itself / a validity flag
+        }
+        const float rb = __int_as_float(rk[r] * rscale);
+        recH[gp[r]] = make_float2(Bv, rb);
+        recL[gp[r]] = make_float2(Av, rb);
+        GS[gp[r]] = g[r] * inv_max_dcg;
+        if (ITEMW) WS[gp[r]] = wr[r];
+        CIS[gp[r]] = lane + 64 * r;
+      }
+      if (lane < nseg) H->seg_gain[lane] *= inv_max_dcg;
+      if (lane == 0) {
+        H->n = n; H->np = ppos; H->nseg = nseg; H->flags = (fast ? 1 : 0) | (tail ? 2 : 0);
+        H->b = b; H->npass = (ppos + kGrpPassRows - 1) / kGrpPassRows; H->lw = lw;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. the (list, 32-row pass) work items of all W lists, dealt round-robin to the W waves.
+  const int c = lane & 1;
+  const uint32_t ubase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)Urep + 4u * (uint32_t)(lane & (R - 1));
+  int q = wave;
+  for (int l = 0; l < W; ++l) {
+    GrpHdr* H = GRP_HDR(l);
+    const int npass = __builtin_amdgcn_readfirstlane(H->npass);
+    if (q >= npass) { q -= npass; continue; }
+    const float2* recH = GRP_RECH(l);
+    const float2* recL = recH + LpS;
+    const float* GS = reinterpret_cast<const float*>(recL + LpS);
+    const float* WS = GS + LpS;
+    const int* CIS = reinterpret_cast<const int*>(GS + LpS + (ITEMW ? LpS : 0));
+    const int b = __builtin_amdgcn_readfirstlane(H->b);
+    const int np = __builtin_amdgcn_readfirstlane(H->np);
+    const int nseg = __builtin_amdgcn_readfirstlane(H->nseg);
+    const int flags = __builtin_amdgcn_readfirstlane(H->flags);
+    const float lw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, H->lw)));
+    const bool fast = (flags & 1) != 0, tail = (flags & 2) != 0;
+    const size_t base = (size_t)b * L;
+    // the segment table, one segment per lane (read back with v_readlane: no LDS round trip per rectangle)
+    const int sl = lane < kGrpSegSlots ? lane : 0;
+    const int seg_s = H->seg_start[sl], seg_e = H->seg_end[sl];
+    const float seg_g = H->seg_gain[sl];
+    for (; q < npass; q += W) {
+      const int row0 = q * kGrpPassRows;
+      const int row = row0 + (lane >> 1);
+      const float2 rh = recH[row], rl = recL[row];
+      const float Gi = GS[row];
+      const int ci = CIS[row];
+      const float wi = ITEMW ? WS[row] : lw;                  // weight of the row item (preferred in the hi sweep)
+      const uint32_t ri = (uint32_t)__float_as_int(rh.y);
+      const int last_row = (row0 + kGrpPassRows < np ? row0 + kGrpPassRows : np) - 1;
+      const int s_first = __popcll(__ballot(lane < nseg && seg_e <= row0));
+      const int s_last = __popcll(__ballot(lane < nseg && seg_e <= last_row));
+      float accL = 0.f, accG = 0.f, accG2 = 0.f, accW = 0.f, accNZ = 0.f;
+      if (fast) {
+        const float Ai = rl.x, Bi = rh.x;
+        const bool in_tail = tail && s_last == nseg - 1;      // some row of this pass lies in the unsorted tail segment
+        const int hi0 = in_tail ? (s_first + 1 < nseg - 1 ? s_first + 1 : nseg - 1) : s_first + 1;
+        for (int h = hi0; h < nseg; ++h) {                    // row preferred: the lower grades behind it
+          const int s = __builtin_amdgcn_readlane(seg_s, h), e = __builtin_amdgcn_readlane(seg_e, h);
+          GrpAcc r;
+          if (tail && h == nseg - 1) {
+            grp_hi_loop<true, AUX>(recH, GS, s, (e - s) >> 2, c, Ai, Gi, ri, ubase, r);
+            accL += r.l; accG += r.g;
+            if (AUX) { accW += r.w; accNZ += r.nz; }
+          } else {
+            const float Gh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h));
+            const float dG = fmaxf(Gi - Gh, 0.0f);
+            grp_hi_loop<false, AUX>(recH, GS, s, (e - s) >> 2, c, Ai, Gi, ri, ubase, r);
+            accL = __builtin_fmaf(dG, r.l, accL); accG = __builtin_fmaf(dG, r.g, accG);
+            if (AUX) { accW = __builtin_fmaf(dG, r.w, accW); accNZ += (dG != 0.0f) ? r.nz : 0.0f; }
+          }
+        }
+        const int lo1 = in_tail ? nseg : s_last;
+        for (int h = 0; h < lo1; ++h) {                       // column preferred: the higher grades in front of it
+          const int s = __builtin_amdgcn_readlane(seg_s, h), e = __builtin_amdgcn_readlane(seg_e, h);
+          if (tail && h == nseg - 1) {
+            accG2 += grp_lo_loop<true, ITEMW>(recL, GS, WS, s, (e - s) >> 2, c, Bi, Gi, ri, ubase);
+          } else {
+            const float Gh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h));
+            const float dG = fmaxf(Gh - Gi, 0.0f);
+            accG2 = __builtin_fmaf(dG, grp_lo_loop<false, ITEMW>(recL, GS, WS, s, (e - s) >> 2, c, Bi, Gi, ri, ubase), accG2);
+          }
+        }
+      } else {
+        // per-pair exponential, numerically safe for any score range (same algebra as pair_loss above): recH.x = x,
+        // recL.x = validity flag.  The loss accumulates in log2 units like the fast path.
+        const float xi = rh.x;
+        for (int j = 2 * c; j < np; j += 4) {
+          const float4 ch = *reinterpret_cast<const float4*>(&recH[j]);
+          const float4 cl = *reinterpret_cast<const float4*>(&recL[j]);
+          const float2 gj = *reinterpret_cast<const float2*>(&GS[j]);
+          float2 wj = make_float2(1.f, 1.f);
+          if (ITEMW) wj = *reinterpret_cast<const float2*>(&WS[j]);
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const float xj = hh ? ch.z : ch.x, rj = hh ? ch.w : ch.y, vj = hh ? cl.z : cl.x;
+            const float Gj = hh ? gj.y : gj.x, wjj = hh ? wj.y : wj.x;
+            const float u = grp_u(ri, rj, ubase) * vj;
+            const float d0 = xi - xj;
+            const float ex = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);
+            const float w1 = 1.0f + ex;
+            const float qq = __builtin_amdgcn_rcpf(w1);
+            const float lg = __builtin_amdgcn_logf(w1) + fmaxf(-d0, 0.0f) * kLog2e;
+            const float s_neg = (d0 >= 0.0f) ? ex * qq : qq;   // sigma(-d0)
+            const float s_pos = (d0 >= 0.0f) ? qq : ex * qq;   // sigma(+d0)
+            const float Whi = fmaxf(Gi - Gj, 0.0f) * u;
+            float Wlo = fmaxf(Gj - Gi, 0.0f) * u;
+            if (ITEMW) Wlo *= wjj;
+            accL = __builtin_fmaf(Whi, lg, accL);
+            accG = __builtin_fmaf(Whi, s_neg, accG);
+            accG2 = __builtin_fmaf(Wlo, s_pos, accG2);
+            if (AUX) { accW += Whi; accNZ += (Whi != 0.0f) ? 1.0f : 0.0f; }
+          }
+        }
+      }
+      // the two lanes of a row
+      accL += TFR_DPP_F(0.f, accL, 0xB1, 0xf, 0xf, false);
+      accG += TFR_DPP_F(0.f, accG, 0xB1, 0xf, 0xf, false);
+      accG2 += TFR_DPP_F(0.f, accG2, 0xB1, 0xf, 0xf, false);
+      if (AUX) { accW += TFR_DPP_F(0.f, accW, 0xB1, 0xf, 0xf, false); accNZ += TFR_DPP_F(0.f, accNZ, 0xB1, 0xf, 0xf, false); }
+      float row_l = 0.f, row_nz = 0.f;
+      if (c == 0 && ci >= 0) {
+        row_l = accL * kLn2 * wi;
+        if (a.row_loss) a.row_loss[base + ci] = row_l;
+        if (AUX && a.row_weight) a.row_weight[base + ci] = accW * wi;
+        const float g2 = ITEMW ? accG2 : accG2 * lw;
+        if (a.dlogits) a.dlogits[base + ci] = (g2 - accG * wi) / a.temperature;
+        if (AUX) row_nz = (wi != 0.0f) ? accNZ : 0.0f;
+      }
+      const bool want_list = a.list_loss != nullptr;
+      if (want_list) { const float s = wave_sum_u(row_l); if (lane == 0) H->pass_loss[q] = s; }
+      if (AUX && a.nnz) { const float s = wave_sum_u(row_nz); if (lane == 0) H->pass_nnz[q] = s; }
+    }
+    q -= npass;
+  }
+  if (a.list_loss == nullptr && !(AUX && a.nnz)) return;
+  __syncthreads();
+
+  // ---- 3. per-list sums over the passes, in pass order (deterministic).
+  {
+    const GrpHdr* H = GRP_HDR(wave);
+    const int b = H->b;
+    if (lane == 0 && b >= 0) {
+      const int npass = H->npass;
+      if (a.list_loss) { float t = 0.f; for (int p = 0; p < npass; ++p) t += H->pass_loss[p]; a.list_loss[b] = t; }
+      if (AUX && a.nnz) { float t = 0.f; for (int p = 0; p < npass; ++p) t += H->pass_nnz[p]; a.nnz[b] = t; }
+    }
+  }
+#undef GRP_HDR
+#undef GRP_RECH
+}
+
+// Host side: geometry of the group kernel for a batch.  Returns 0 and fills (W, R, lds) when the kernel applies.
+inline bool grp_geometry(int B, int L, bool itemw, int& W, int& R, size_t& lds) {
+  const int Lp = grp_lp(L);
+  if ((Lp + kGrpPassRows - 1) / kGrpPassRows > kGrpMaxPass) return false;
+  static const int env_w = env_int("TFR_LAMBDARANK_WAVES", 0);
+  static const int env_r = env_int("TFR_LAMBDARANK_REP", 0);
+  W = env_w > 0 ? env_w : (B >= 2048 ? 8 : (B >= 1024 ? 4 : (B >= 512 ? 2 : 1)));
+  if (W > 8) W = 8;
+  R = (env_r == 16 || env_r == 32 || env_r == 8) ? env_r : 32;
+  // two workgroups per CU (160 KiB of LDS) when the full replication allows it, else the half table
+  auto need = [&](int r) { return grp_table_bytes(L, r) + (size_t)W * grp_list_bytes(Lp, itemw); };
+  if (env_r == 0 && W == 8 && need(32) > 80 * 1024 && need(16) <= 80 * 1024) R = 16;
+  if (L * 4 * R > 65535) R = 16;                              // v_sad_u16 works on 16-bit ranks * 4 R
+  if (L * 4 * R > 65535) return false;
+  lds = need(R);
+  return lds <= 160 * 1024;
+}

@@ -1011,6 +1011,23 @@ __global__ __launch_bounds__(256) void pairwise_lean_kernel(const PwArgs a) {
 
 int env_int(const char* name, int dflt);
 
+#include "lambdarank_group.h"
+
+// One launch of the group kernel (dynamic LDS beyond 64 KiB needs the attribute once per instantiation).
+template <int IPL, bool AUX, bool IW>
+int launch_grp(const PwArgs& a, int B, int W, int R, size_t lds, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lambdarank_group_kernel<IPL, AUX, IW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int N = (B + W - 1) / W;
+  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * W), lds, stream, a, B, R, grp_lp(a.L));
+  return (int)hipGetLastError();
+}
+
 template <int IPL>
 int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   static const int env_s = env_int("TFR_PAIRWISE_WAVES_PER_LIST", 0);
@@ -1028,8 +1045,20 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   static const int env_lean = env_int("TFR_PAIRWISE_LEAN", 1);
   if (env_lean && a.kind == TFR_PAIR_LOGISTIC && a.lambda_kind == TFR_LAMBDA_DCG && !generic &&
       a.gain_kind != TFR_GAIN_CUSTOM) {
-    // LambdaRank fast path (grade-segmented, factorised exponential); S waves per list when the batch is small
+    // LambdaRank fast path (grade-segmented, factorised exponential)
     const bool iw = a.item_weights != nullptr;
+    static const int env_grp = env_int("TFR_LAMBDARANK_GROUP", 1);
+    static const int env_grp_min = env_int("TFR_LAMBDARANK_GROUP_MIN_B", 512);
+    int gW = 0, gR = 0;
+    size_t glds = 0;
+    if (env_grp && B >= env_grp_min && grp_geometry(B, a.L, iw, gW, gR, glds)) {
+      // W lists per workgroup, shared pair sweeps, conflict-free rank-difference gather (lambdarank_group.h)
+      if (aux) return iw ? launch_grp<IPL, true, true>(a, B, gW, gR, glds, stream)
+                         : launch_grp<IPL, true, false>(a, B, gW, gR, glds, stream);
+      return iw ? launch_grp<IPL, false, true>(a, B, gW, gR, glds, stream)
+                : launch_grp<IPL, false, false>(a, B, gW, gR, glds, stream);
+    }
+    // smaller batches: S waves cooperate on one list (round-2 kernel)
     static const int env_ls = env_int("TFR_PAIRWISE_LEAN_WAVES", 0);
     // waves per list: 1 when the batch alone gives every SIMD its 8 list-waves; else 2 / 4 cooperate (shared LDS image)
     int Sl = env_ls > 0 ? env_ls : (B >= 8192 ? 1 : (B >= 2048 ? 2 : 4));

@@ -24,3 +24,34 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Parity margins: every tolerance check of the GPU suites reports (what, achieved max error, bar) here, and the
+# session prints the worst margin per check and writes them to gpurun_out/parity_margins.json, so that pytest.log
+# records HOW MUCH of each bar is used, not only that it held ("Next round" #2).
+MARGINS = {}
+
+
+def record_margin(what, err, bar):
+    test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+    key = what or test
+    frac = float(err) / float(bar) if bar else 0.0
+    cur = MARGINS.get(key)
+    if cur is None or frac > cur['used']:
+        MARGINS[key] = {'max_err': float(err), 'bar': float(bar), 'used': frac, 'test': test}
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if not MARGINS:
+        return
+    tr = terminalreporter
+    tr.section('parity margins (max error / bar; worst case per check)')
+    rows = sorted(MARGINS.items(), key=lambda kv: -kv[1]['used'])
+    for what, m in rows[:60]:
+        tr.write_line('%-72s max_err %.3e  bar %.1e  used %5.1f %%' % (what[:72], m['max_err'], m['bar'], 100 * m['used']))
+    out = os.path.join(ROOT, 'gpurun_out')
+    if os.path.isdir(out):
+        import json
+        with open(os.path.join(out, 'parity_margins.json'), 'w') as f:
+            json.dump(dict(rows), f, indent=1)

@@ -14,6 +14,7 @@ import torch
 
 from oracle import tfr_ref as R
 from tests.common import make_batch, make_weights
+from tests.conftest import record_margin
 
 pytestmark = pytest.mark.gpu
 
@@ -33,6 +34,8 @@ def assert_loss_close(got, want, tol=LOSS_TOL, what=''):
     assert got.shape == want.shape, (what, got.shape, want.shape)
     err = (got - want).abs()
     lim = tol * torch.clamp(want.abs(), min=1.0)
+    if err.numel():
+        record_margin(what, (err / torch.clamp(want.abs(), min=1.0)).max().item(), tol)
     assert bool((err <= lim).all()), '%s: max err %.3e (tol %.1e) at %d: got %r want %r' % (
         what, err.max().item(), tol, int(err.argmax()), got[err.argmax()].item(), want[err.argmax()].item())
 
@@ -41,8 +44,11 @@ def assert_grad_close(got, want, rtol=GRAD_RTOL, what=''):
     got = got.detach().cpu().double()
     want = want.detach().cpu().double()
     assert got.shape == want.shape
+    if not want.numel():
+        return
     scale = want.abs().max().item()
     err = (got - want).abs().max().item()
+    record_margin(what + ' [grad]', err, rtol * scale + 1e-7)
     assert err <= rtol * scale + 1e-7, '%s: max grad err %.3e vs scale %.3e (rel %.2e)' % (
         what, err, scale, err / max(scale, 1e-30))
 
@@ -1651,6 +1657,86 @@ def test_lambdarank_fast_path_env_switch_matches_general_kernel():
         assert_loss_close(a[1] / scale, b[1] / scale, 2e-6, what='lean vs general rows B=%d' % B)
         assert torch.equal(a[3], b[3])
         a[0].sum().backward() if a[0].requires_grad else None
+
+
+def _edge_case_batch(B, L, seed):
+    """A batch of B lists made of the LambdaRank edge cases in rotation: plain graded lists of every valid length, no
+    valid item, one valid item, one grade only, 12 grades (> the 8 grade runs: unsorted tail segment), real-valued
+    labels, fractional grades, scattered (non-suffix) padding, a score range beyond the factorised exponential, ties."""
+    g = torch.Generator().manual_seed(seed)
+    labels, logits = make_batch(B, L, seed=seed)
+    for b in range(B):
+        k = b % 16
+        if k == 1:
+            labels[b] = -1.0
+        elif k == 2 and L > 1:
+            labels[b, 1:] = -1.0; labels[b, 0] = 3.0
+        elif k == 3:
+            labels[b] = torch.where(labels[b] >= 0, torch.full_like(labels[b], 2.0), labels[b])
+        elif k == 4:
+            labels[b] = torch.where(labels[b] >= 0, torch.randint(0, 12, (L,), generator=g).float(), labels[b])
+        elif k == 5:
+            labels[b] = torch.where(labels[b] >= 0, torch.rand(L, generator=g) * 3.0, labels[b])
+        elif k == 6:
+            labels[b] = torch.where(labels[b] >= 0, labels[b] * 0.5, labels[b])
+        elif k == 7:
+            labels[b] = torch.randint(0, 5, (L,), generator=g).float()
+            labels[b][torch.rand(L, generator=g) < 0.4] = -1.0
+        elif k == 8:
+            logits[b] = logits[b] * 60.0
+        elif k == 9:
+            logits[b] = torch.round(logits[b] * 2.0) / 2.0
+        elif k == 10:
+            labels[b] = torch.randint(0, 5, (L,), generator=g).float()          # completely full list
+    return labels, logits
+
+
+@pytest.mark.parametrize('B,L', [(520, 17), (1100, 64), (1029, 130), (2051, 200), (2048, 256), (700, 1), (600, 3)])
+@pytest.mark.parametrize('wkind', ['none', 'item', 'list'])
+def test_lambdarank_group_kernel_against_the_general_kernel(B, L, wkind):
+    """Batches of 512 lists and more run the group kernel (lambdarank_group.h: W lists per workgroup, shared pair sweeps,
+    replicated rank-difference table; B not a multiple of W leaves empty slots): every row, pair count and gradient
+    against the general pair kernel (reached through an explicit mask), with and without the launch order."""
+    labels, logits = _edge_case_batch(B, L, seed=300 + L)
+    w = make_weights(B, L, seed=L) if wkind == 'item' else (make_weights(B, 1, seed=L) if wkind == 'list' else None)
+    if w is not None and wkind == 'item':
+        w[3, : max(1, L // 3)] = 0.0
+    K, L_ = ra().keras.losses, ra().losses_impl
+    d = lambda x: None if x is None else x.to(DEV)
+    for lam in (K.NDCGLambdaWeight(), L_.DCGLambdaWeight()):
+        loss = L_.PairwiseLogisticLoss(None, lambda_weight=lam, temperature=0.8)
+        xa = logits.to(DEV).requires_grad_(True)
+        xb = logits.to(DEV).requires_grad_(True)
+        a = loss._fused(d(labels), xa, d(w), None)
+        b = loss._fused(d(labels), xb, d(w), (labels >= 0).to(DEV))
+        scale = max(1.0, b[1].abs().max().item())
+        assert_loss_close(a[1] / scale, b[1] / scale, 3e-6, what='group vs general rows')
+        ws = max(1.0, b[2].abs().max().item())
+        assert_loss_close(a[2] / ws, b[2] / ws, 3e-6, what='group vs general row weights')
+        assert torch.equal(a[3], b[3])
+        a[0].sum().backward(); b[0].sum().backward()
+        assert_grad_close(xa.grad, xb.grad, 1e-5, what='group vs general grad')
+    # what loss_and_grad launches (no aux outputs, per-list sums, launch order): equal to the row sums above
+    lamk = L_._lambda_kernel_args(K.NDCGLambdaWeight(), d(labels), L, torch.device(DEV))
+    lw = None if wkind != 'list' else d(w).reshape(B)
+    iw = d(w) if wkind == 'item' else None
+    rows, _, _, d1 = ra()._ops.pairwise_logistic(d(logits), d(labels), None, iw, lw, want_aux=False, balance=False, **lamk)
+    for balance in (False, True):
+        _, _, _, d2, lst = ra()._ops.pairwise_logistic(d(logits), d(labels), None, iw, lw, want_rows=False, want_aux=False,
+                                                       want_list=True, balance=balance, **lamk)
+        assert torch.equal(d1, d2)
+        want = rows.double().sum(dim=1)
+        assert ((lst.double() - want).abs() <= 1e-6 * want.abs().clamp(min=1e-3)).all()
+
+
+@pytest.mark.parametrize('L', [23, 70])
+@pytest.mark.parametrize('wkind', ['none', 'item'])
+def test_lambdarank_group_kernel_against_the_oracle(L, wkind):
+    B = 520
+    labels, logits = _edge_case_batch(B, L, seed=77 + L)
+    logits[8::16] = logits[8::16] / 6.0                        # (the oracle comparison of wide ranges is a test of its own)
+    w = make_weights(B, L, seed=L) if wkind == 'item' else None
+    _lean_case(labels, logits, w, T=0.9, tol=2e-5)
 
 
 @pytest.mark.parametrize('L,masked,kind', [(200, False, 0), (200, True, 0), (60, False, 1), (300, False, 0), (300, True, 2)])
