@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void group_indices_kernel(const uint8_t* __res
                                                             int* __restrict__ idx_out, uint8_t* __restrict__ gmask_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + wave;
+  const int b = blockIdx.x * (blockDim.x >> 6) + wave;          // 4 list-waves per workgroup, fewer for long lists
   if (b >= B) return;
   float* key = reinterpret_cast<float*>(smem) + (long)wave * 2 * L;
   int* organized = reinterpret_cast<int*>(key + L);
@@ -236,9 +236,11 @@ extern "C" int tfr_group_indices_i32(const uint8_t* is_valid, const float* keys,
                                      int32_t* idx_out, uint8_t* gmask_out, void* stream) {
   if (!is_valid || !idx_out || !gmask_out || B < 0 || L <= 0 || group_size <= 0) return TFR_EINVAL;
   if ((long)B * L * group_size > 0x7fffffffL) return TFR_EINVAL;
-  if ((size_t)L * 32 > 64 * 1024) return TFR_ETOOLARGE;            // 4 waves x 8 bytes x L of LDS
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;                      // 8 bytes x L of LDS per list-wave, <= 64 KiB
   if (B == 0) return TFR_OK;
-  hipLaunchKernelGGL(group_indices_kernel, dim3((B + 3) / 4), dim3(256), (size_t)L * 8 * 4, (hipStream_t)stream,
+  int W = 4;                                                        // list-waves per workgroup
+  while (W > 1 && (size_t)L * 8 * W > 64 * 1024) W >>= 1;
+  hipLaunchKernelGGL(group_indices_kernel, dim3((B + W - 1) / W), dim3(64 * W), (size_t)L * 8 * W, (hipStream_t)stream,
                      is_valid, keys, B, L, group_size, idx_out, gmask_out);
   return (int)hipGetLastError();
 }

@@ -37,13 +37,14 @@
 constexpr int kGrpMaxSeg = kMaxRuns + 1;        // pure segments + the unsorted tail
 constexpr int kGrpSegSlots = 10;
 constexpr int kGrpPassRows = 32;                // rows per pass: two lanes per row
-constexpr int kGrpMaxPass = 12;
-constexpr int kGrpSlack = 8;                    // readable zero records behind every column array (prefetch overrun)
+constexpr int kGrpMaxPass = 10;
+constexpr int kGrpSlack = 16;                   // readable zero records behind every column array (prefetch overrun)
 
 struct GrpHdr {                                 // per list, in LDS (256 bytes)
   int n, np, nseg, flags;                       // valid items; padded grade-order length (multiple of 4); segments; 1 = fast, 2 = tail
   int b, npass;                                 // list index (-1: empty slot), 32-row passes
-  float lw, pad0;
+  float lw;
+  int state, next_pass, done_pass;              // 2 = image published; pass tickets handed out / passes completed
   int seg_start[kGrpSegSlots];                  // padded grade positions
   int seg_end[kGrpSegSlots];                    // start + count rounded up to 4
   float seg_gain[kGrpSegSlots];                 // gain * 1 / max DCG of the segment's label value (pure segments)
@@ -66,6 +67,28 @@ typedef const __attribute__((address_space(3))) float grp_lds_cf;
 // + 4 (lane % R).  One v_sad_u16 forms the byte address (|a.lo16 - b.lo16| + |a.hi16 - b.hi16| + c).
 __device__ __forceinline__ float grp_u(uint32_t ri, float rj_bits, uint32_t ubase) {
   return *(grp_lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(ri, (uint32_t)__float_as_int(rj_bits), ubase);
+}
+
+// 2^l - 1 (keras/utils.py:79-92), exact for integer grades like common.h's gain_pow2m1; the general exp2f (a libm
+// expansion) is only executed when some lane of the wavefront holds a non-integer or huge label.
+__device__ __forceinline__ float grp_gain_pow2m1(float l) {
+  const float r = rintf(l);
+  const bool exact = (r == l) && fabsf(l) < 120.0f;
+  float p = __builtin_amdgcn_ldexpf(1.0f, (int)r);
+  if (__ballot(!exact)) p = exact ? p : exp2f(l);
+  return p - 1.0f;
+}
+
+// wave-wide OR on the DPP network (result wave-uniform, read from lane 63)
+__device__ __forceinline__ unsigned grp_wave_or(unsigned v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
 
 struct GrpAcc { float l, g, w, nz; };
@@ -137,66 +160,288 @@ __device__ __forceinline__ float grp_lo_loop(const float2* recL, const float* GS
   return ag;
 }
 
+// The pure segments a row pass needs are CONTIGUOUS columns (a segment ends where the next one starts), so the hi sweep
+// is ONE software-pipelined loop over [seg_start[h0], seg_end[h1 - 1]) and the per-segment partial sums are folded into the
+// row totals with the segment's gain difference whenever a trip crosses a segment end (a scalar compare per trip):
+// no per-rectangle loop start-up (address set-up, two dependent LDS round trips) -- 43 rectangles per list on average.
+template <bool AUX>
+__device__ __forceinline__ void grp_hi_sweep(const float2* recH, int h0, int h1, int seg_s, int seg_e, float seg_g, int c,
+                                             float Ai, float Gi, uint32_t ri, uint32_t ubase, float& accL, float& accG,
+                                             float& accW, float& accNZ) {
+  if (h0 >= h1) return;
+  const int j0 = __builtin_amdgcn_readlane(seg_s, h0), j1 = __builtin_amdgcn_readlane(seg_e, h1 - 1);
+  const int trips = (j1 - j0) >> 2;
+  int h = h0;
+  int tb = (__builtin_amdgcn_readlane(seg_e, h) - j0) >> 2;                   // trip at which segment h ends
+  float dG = fmaxf(Gi - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h)), 0.0f);
+  float al = 0.f, ag = 0.f, aw = 0.f, anz = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(recH + j0 + 2 * c);        // a trip = 4 records = 2 float4
+  // pipeline state: CR = records of this trip, U = their rank-difference discounts, CN = records of the next trip.
+  // The loop body is written out for two trips with the register roles swapped, so nothing is moved between trips.
+#define GRP_HI_TRIP(CR, U0, U1, CN, NU0, NU1, NEWC, T)                                                             \
+  do {                                                                                                              \
+    if ((T) == tb) {                /* (uniform) the columns of the next segment start here */                      \
+      accL = __builtin_fmaf(dG, al, accL); accG = __builtin_fmaf(dG, ag, accG);                                    \
+      if (AUX) { accW = __builtin_fmaf(dG, aw, accW); accNZ += (dG != 0.0f) ? anz : 0.0f; aw = 0.f; anz = 0.f; }    \
+      al = 0.f; ag = 0.f;                                                                                           \
+      ++h;                                                                                                          \
+      tb = (__builtin_amdgcn_readlane(seg_e, h) - j0) >> 2;                                                         \
+      dG = fmaxf(Gi - __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h)), 0.0f); \
+    }                                                                                                               \
+    NU0 = grp_u(ri, CN.y, ubase); NU1 = grp_u(ri, CN.w, ubase);                                                     \
+    NEWC = p[2 * (T) + 6];                                                                                          \
+    const float w0_ = __builtin_fmaf(Ai, CR.x, 1.0f), w1_ = __builtin_fmaf(Ai, CR.z, 1.0f);                         \
+    const float q0_ = __builtin_amdgcn_rcpf(w0_), q1_ = __builtin_amdgcn_rcpf(w1_);                                 \
+    const float l0_ = __builtin_amdgcn_logf(w0_), l1_ = __builtin_amdgcn_logf(w1_);                                 \
+    al = __builtin_fmaf(U0, l0_, al); al = __builtin_fmaf(U1, l1_, al);                                             \
+    ag = __builtin_fmaf(U0, 1.0f - q0_, ag); ag = __builtin_fmaf(U1, 1.0f - q1_, ag);                               \
+    if (AUX) {                      /* padding columns (B = 0) carry a non-zero u: mask them */                     \
+      const float v0_ = (CR.x != 0.0f) ? U0 : 0.0f, v1_ = (CR.z != 0.0f) ? U1 : 0.0f;                               \
+      aw += v0_; aw += v1_;                                                                                         \
+      anz += (v0_ != 0.0f) ? 1.0f : 0.0f; anz += (v1_ != 0.0f) ? 1.0f : 0.0f;                                       \
+    }                                                                                                               \
+  } while (0)
+  // three trips in flight: records two trips ahead, discounts one trip ahead (an LDS round trip is ~100+ cycles under
+  // load, a trip ~50 of VALU work: with the discounts fetched only one trip ahead every trip waited on them)
+  float4 ca = p[0], cb = p[2], cc = p[4];
+  float ua0 = grp_u(ri, ca.y, ubase), ua1 = grp_u(ri, ca.w, ubase);
+  float ub0 = grp_u(ri, cb.y, ubase), ub1 = grp_u(ri, cb.w, ubase);
+  int t = 0;
+  for (; t + 3 <= trips; t += 3) {                            // uniform trip count: scalar loop control
+    float4 cd, ce, cf;
+    float uc0, uc1, ud0, ud1, ue0, ue1;
+    GRP_HI_TRIP(ca, ua0, ua1, cc, uc0, uc1, cd, t);           // computes trip t, gathers for t + 2, loads records t + 3
+    GRP_HI_TRIP(cb, ub0, ub1, cd, ud0, ud1, ce, t + 1);
+    GRP_HI_TRIP(cc, uc0, uc1, ce, ue0, ue1, cf, t + 2);
+    ca = cd; ua0 = ud0; ua1 = ud1; cb = ce; ub0 = ue0; ub1 = ue1; cc = cf;
+  }
+  if (t < trips) {
+    float4 cd; float uc0, uc1;
+    GRP_HI_TRIP(ca, ua0, ua1, cc, uc0, uc1, cd, t);
+    if (t + 1 < trips) { float4 ce; float ud0, ud1; GRP_HI_TRIP(cb, ub0, ub1, cd, ud0, ud1, ce, t + 1); (void)ce; (void)ud0; (void)ud1; }
+    (void)uc0; (void)uc1;
+  }
+#undef GRP_HI_TRIP
+  accL = __builtin_fmaf(dG, al, accL); accG = __builtin_fmaf(dG, ag, accG);
+  if (AUX) { accW = __builtin_fmaf(dG, aw, accW); accNZ += (dG != 0.0f) ? anz : 0.0f; }
+}
+
+// The lo sweep over the pure segments [0, h1): one loop over the columns [0, seg_end[h1 - 1]).
+template <bool ITEMW>
+__device__ __forceinline__ void grp_lo_sweep(const float2* recL, const float* WS, int h1, int seg_e, float seg_g, int c,
+                                             float Bi, float Gi, uint32_t ri, uint32_t ubase, float& accG2) {
+  if (h1 <= 0) return;
+  const int j1 = __builtin_amdgcn_readlane(seg_e, h1 - 1);
+  const int trips = j1 >> 2;
+  int h = 0;
+  int tb = __builtin_amdgcn_readlane(seg_e, 0) >> 2;
+  float dG = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), 0)) - Gi, 0.0f);
+  float ag = 0.f;
+  const float4* p = reinterpret_cast<const float4*>(recL + 2 * c);
+  const float2* wp = reinterpret_cast<const float2*>(WS + 2 * c);
+#define GRP_LO_TRIP(CR, U0, U1, CN, NU0, NU1, NEWC, T)                                                             \
+  do {                                                                                                              \
+    if ((T) == tb) {                                                                                                \
+      accG2 = __builtin_fmaf(dG, ag, accG2);                                                                        \
+      ag = 0.f;                                                                                                     \
+      ++h;                                                                                                          \
+      tb = __builtin_amdgcn_readlane(seg_e, h) >> 2;                                                                \
+      dG = fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h)) - Gi, 0.0f); \
+    }                                                                                                               \
+    NU0 = grp_u(ri, CN.y, ubase); NU1 = grp_u(ri, CN.w, ubase);                                                     \
+    NEWC = p[2 * (T) + 6];                                                                                          \
+    float x0_ = U0, x1_ = U1;                                                                                       \
+    if (ITEMW) { const float2 wj_ = wp[2 * (T)]; x0_ *= wj_.x; x1_ *= wj_.y; }  /* weight of the PREFERRED item */  \
+    const float q0_ = __builtin_amdgcn_rcpf(__builtin_fmaf(Bi, CR.x, 1.0f));                                        \
+    const float q1_ = __builtin_amdgcn_rcpf(__builtin_fmaf(Bi, CR.z, 1.0f));                                        \
+    ag = __builtin_fmaf(x0_, 1.0f - q0_, ag); ag = __builtin_fmaf(x1_, 1.0f - q1_, ag);                             \
+  } while (0)
+  float4 ca = p[0], cb = p[2], cc = p[4];                     // three trips in flight (see grp_hi_sweep)
+  float ua0 = grp_u(ri, ca.y, ubase), ua1 = grp_u(ri, ca.w, ubase);
+  float ub0 = grp_u(ri, cb.y, ubase), ub1 = grp_u(ri, cb.w, ubase);
+  int t = 0;
+  for (; t + 3 <= trips; t += 3) {
+    float4 cd, ce, cf;
+    float uc0, uc1, ud0, ud1, ue0, ue1;
+    GRP_LO_TRIP(ca, ua0, ua1, cc, uc0, uc1, cd, t);
+    GRP_LO_TRIP(cb, ub0, ub1, cd, ud0, ud1, ce, t + 1);
+    GRP_LO_TRIP(cc, uc0, uc1, ce, ue0, ue1, cf, t + 2);
+    ca = cd; ua0 = ud0; ua1 = ud1; cb = ce; ub0 = ue0; ub1 = ue1; cc = cf;
+  }
+  if (t < trips) {
+    float4 cd; float uc0, uc1;
+    GRP_LO_TRIP(ca, ua0, ua1, cc, uc0, uc1, cd, t);
+    if (t + 1 < trips) { float4 ce; float ud0, ud1; GRP_LO_TRIP(cb, ub0, ub1, cd, ud0, ud1, ce, t + 1); (void)ce; (void)ud0; (void)ud1; }
+    (void)uc0; (void)uc1;
+  }
+#undef GRP_LO_TRIP
+  accG2 = __builtin_fmaf(dG, ag, accG2);
+}
+
+// 0-based rank (score descending, ties by lower compact index) of the n compact scores XS[0 .. n) of ONE wavefront's
+// list, for up to IPL row chunks of 64 compact items AT ONCE: every float4 of column scores is read once (not once per
+// chunk) and compared against the NC chunk registers, two column groups per trip with both loads issued first -- the
+// one-chunk-at-a-time form (common.h) waited one LDS round trip per 8 VALU instructions and took 17 % of the kernel.
+// Ties as in wave_rank_by_count: items with equal scores get the same count, an occupancy table finds them (rare).
+template <int NC>
+__device__ __forceinline__ void grp_rank_chunks(const float* XS, int n, int lane, int* RKS, int* OCC) {
+  const float4* X4 = reinterpret_cast<const float4*>(XS);
+  const int n4 = (n + 3) >> 2;
+  float xi[NC];
+  int cnt[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { const int p = lane + 64 * k; xi[k] = p < n ? XS[p] : INFINITY; cnt[k] = 0; }
+  int gq = 0;
+  for (; gq + 2 <= n4; gq += 2) {
+    const float4 xa = X4[gq], xb = X4[gq + 1];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
+      cnt[k] += (xb.x > xi[k]) ? 1 : 0; cnt[k] += (xb.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xb.z > xi[k]) ? 1 : 0; cnt[k] += (xb.w > xi[k]) ? 1 : 0;
+    }
+  }
+  if (gq < n4) {
+    const float4 xa = X4[gq];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int p = lane + 64 * k;
+    if (p < n) { RKS[p] = cnt[k]; atomicAdd(&OCC[cnt[k]], 1); }
+  }
+}
+
+__device__ __forceinline__ void grp_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
+  for (int p = lane; p < n; p += 64) OCC[p] = 0;
+  WAVE_LDS_SYNC();
+  if (n <= 64) grp_rank_chunks<1>(XS, n, lane, RKS, OCC);
+  else if (n <= 128) grp_rank_chunks<2>(XS, n, lane, RKS, OCC);
+  else if (n <= 192) grp_rank_chunks<3>(XS, n, lane, RKS, OCC);
+  else grp_rank_chunks<4>(XS, n, lane, RKS, OCC);
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {
+    const int p = q0 + lane;
+    const bool tie = p < n && OCC[RKS[p]] > 1;
+    if (__ballot(tie)) {                                     // wave-uniform: some item of this chunk shares its score
+      if (tie) {
+        const float xi = XS[p];
+        int cnt = RKS[p];
+        for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;
+        RKS[p] = cnt;                                        // (other lanes read OCC at their OWN first count only)
+      }
+    }
+  }
+  WAVE_LDS_SYNC();
+}
+
 template <int IPL, bool AUX, bool ITEMW>
-__global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp) {
+__global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp,
+                                                                const int G) {
+  // G lists per workgroup, blockDim.x / 64 >= G wavefronts: waves 0 .. G-1 each BUILD one list's LDS image, then every
+  // wave SWEEPS (list, 32-row pass) work items of whichever lists are ready, taken from per-list LDS tickets -- no
+  // barrier between the two phases: a wave that has built its (short) list sweeps while a long list is still being
+  // ranked, and the latency-bound build of one wave overlaps the VALU-bound sweeps of the others on its SIMD.
   extern __shared__ __attribute__((aligned(128))) unsigned char grp_smem[];
-  const int W = blockDim.x >> 6;
+  const int Wt = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int L = a.L;
   float* Urep = reinterpret_cast<float*>(grp_smem);                         // [L * R]
   const size_t tab_bytes = grp_table_bytes(L, R);
   const size_t per_list = grp_list_bytes(Lp, ITEMW);
   const int LpS = Lp + kGrpSlack;
+#ifdef TFR_PROFILE_STAMPS
+  unsigned long long grp_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int grp_passes = 0, grp_polls = 0;
+#define GRP_STAMP(i) do { grp_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GRP_STAMP(i) do { } while (0)
+#endif
+  GRP_STAMP(0);
 #define GRP_HDR(l) reinterpret_cast<GrpHdr*>(grp_smem + tab_bytes + (size_t)(l) * per_list)
 #define GRP_RECH(l) reinterpret_cast<float2*>(grp_smem + tab_bytes + (size_t)(l) * per_list + kGrpHdrBytes)
+  const bool builder = wave < G;
 
-  // ---- 0. the replicated rank-difference table (list independent), all waves.
-  {
-    const int shift = 31 - __builtin_clz(R);
-    const float fL = (float)L;
-    for (int k = threadIdx.x; k < L * R; k += blockDim.x) {
-      const int m = k >> shift;
-      Urep[k] = (m >= 1) ? fabsf(a.discount[m - 1] - a.discount[m]) * fL : 0.0f;   // the final x list_size (:278) folded in
-    }
-  }
-
-  // ---- 1. wave w builds the LDS image of its list.  Lists are drawn serpentine-wise from the launch order.
-  {
+  // ---- 0a. the builder's list (drawn serpentine-wise from the launch order) and its raw loads, issued first.
+  int b = -1;
+  float lw = 1.0f;
+  float lab_raw[IPL], x_raw[IPL], w_raw[IPL];
+  if (builder) {
     const int N = gridDim.x;
     const int posn = (wave & 1) ? (wave + 1) * N - 1 - (int)blockIdx.x : wave * N + (int)blockIdx.x;
-    const int b = (posn < B) ? (a.order ? a.order[posn] : posn) : -1;
+    b = (posn < B) ? (a.order ? a.order[posn] : posn) : -1;
+    if (lane == 0) {                                          // (LDS is not initialised: tickets and state before anyone polls)
+      GrpHdr* H = GRP_HDR(wave);
+      H->state = 0; H->next_pass = 0; H->done_pass = 0; H->npass = 0; H->b = b; H->n = 0;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    lab_raw[r] = -1.0f; x_raw[r] = 0.0f; w_raw[r] = 1.0f;
+    const int e = lane + 64 * r;
+    if (b >= 0 && e < L) {
+      lab_raw[r] = a.labels[(size_t)b * L + e];
+      x_raw[r] = a.logits[(size_t)b * L + e];
+      if (ITEMW) w_raw[r] = a.item_weights[(size_t)b * L + e];
+    }
+  }
+  if (b >= 0 && a.list_weights) lw = a.list_weights[b];
+
+  // ---- 0b. the replicated rank-difference table (list independent).  Thread (part, m) loads D(m), D(m + 1) once and
+  // stores its R / P copies of U[m] * list_size, rotated by the lane inside its own slot range so that the lanes of a store
+  // spread over the banks.  (P = how many times the L table rows fit into the workgroup, a power of two <= R.)
+  {
+    int P = 1;
+    while (2 * P * L <= (int)blockDim.x && 2 * P <= R) P *= 2;
+    const int per = R / P;
+    for (int idx = threadIdx.x; idx < L * P; idx += blockDim.x) {            // (one trip unless the workgroup is smaller than L)
+      int part = 0, m = idx;
+      while (m >= L) { m -= L; ++part; }
+      const float v = (m >= 1) ? fabsf(a.discount[m - 1] - a.discount[m]) * (float)L : 0.0f;   // x list_size (:278) folded in
+      // (the rotation by the lane stays inside the thread's own `per` slots: per = 16 -> 2-way store conflicts, free)
+      for (int k = 0; k < per; ++k) Urep[m * R + part * per + ((k + lane) & (per - 1))] = v;
+    }
+  }
+  __syncthreads();                                            // the table and the tickets are in place
+  GRP_STAMP(1);
+
+  // ---- 1. wave w < G builds the LDS image of its list.
+  if (builder) {
     GrpHdr* H = GRP_HDR(wave);
     float2* recH = GRP_RECH(wave);
     float2* recL = recH + LpS;
     float* GS = reinterpret_cast<float*>(recL + LpS);
     float* WS = GS + LpS;                                                   // ITEMW only
     int* CIS = reinterpret_cast<int*>(GS + LpS + (ITEMW ? LpS : 0));
-    if (b < 0) {
-      if (lane == 0) { H->b = -1; H->npass = 0; H->n = 0; }
-    } else {
+    if (b >= 0) {
       const size_t base = (size_t)b * L;
-      const float lw = a.list_weights ? a.list_weights[b] : 1.0f;
       float* XS = reinterpret_cast<float*>(recH);                           // scratch: compact scores (rank count)
       int* RKS = reinterpret_cast<int*>(recL);                              // scratch: count by compact position
       int* OCC = RKS + Lp;                                                  // scratch: how many items share a count
-      // 1a. load, gains, compaction of the valid items (mask == NULL: valid = label >= 0).
+      // 1a. gains, compaction of the valid items (mask == NULL: valid = label >= 0).
       float g[IPL], xr[IPL], labr[IPL], wr[IPL];
       int posr[IPL];
       bool lv[IPL];
       int n = 0;
       float xmin = INFINITY, xmax = -INFINITY;
+      const bool unit_t = a.temperature == 1.0f, pow2 = a.gain_kind == TFR_GAIN_POW2M1;
 #pragma unroll
       for (int r = 0; r < IPL; ++r) {
         const int e = lane + 64 * r;
         g[r] = 0.f; lv[r] = false;
         float x = 0.f, lab = -1.f, w = 0.f;
         if (e < L) {
-          lab = a.labels[base + e];
-          x = a.logits[base + e] / a.temperature;
+          lab = lab_raw[r];
+          x = unit_t ? x_raw[r] : x_raw[r] / a.temperature;   // (the division is ~10 instructions; T = 1 is the common case)
           lv[r] = lab >= 0.0f;
           if (lv[r]) {
-            g[r] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(lab) : lab;
-            w = ITEMW ? a.item_weights[base + e] * lw : lw;
+            g[r] = pow2 ? grp_gain_pow2m1(lab) : lab;
+            w = ITEMW ? w_raw[r] * lw : lw;
             xmin = fminf(xmin, x); xmax = fmaxf(xmax, x);
           } else {
             if (a.row_loss) a.row_loss[base + e] = 0.f;
@@ -216,13 +461,15 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
       const int n4 = (n + 3) >> 2;
       for (int p = n + lane; p < n4 * 4 + 4; p += 64) XS[p] = -INFINITY;
       WAVE_LDS_SYNC();
+      GRP_STAMP(2);
 
       // 1b. ranks by counting (score descending, ties by index) (:483-500).
       int rk[IPL];
-      wave_rank_by_count(XS, n, lane, RKS, OCC);
+      grp_rank_by_count(XS, n, lane, RKS, OCC);
 #pragma unroll
       for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
       WAVE_LDS_SYNC();                                                       // the scratch is rewritten below
+      GRP_STAMP(3);
 
       // 1c. grade order: repeatedly take the largest remaining label value; its items (in element order) become the
       // next segment, which starts on a 4-column boundary.  After kMaxRuns distinct values the rest forms one
@@ -233,12 +480,33 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
       for (int r = 0; r < IPL; ++r) { rem[r] = labr[r]; sp[r] = 0; gp[r] = 0; }
       int pos = 0, ppos = 0, nseg = 0;
       bool tail = false;
-      for (int it = 0; it <= kMaxRuns; ++it) {
-        float mx = rem[0];
+      // graded relevance = small non-negative integers: the set of label values present comes from ONE wave-wide OR of
+      // (1 << label) and the rounds below walk its bits from the top -- no wave maximum (a chain of seven dependent
+      // DPP steps) per round.  Any other label set keeps the maximum search.
+      bool small_int = true;
+      unsigned present = 0u;
 #pragma unroll
-        for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
-        const float v = wave_max_u(mx);
-        if (v < 0.0f) break;
+      for (int r = 0; r < IPL; ++r) {
+        const bool ok = !lv[r] || (labr[r] < 32.0f && labr[r] == rintf(labr[r]));
+        small_int = small_int && ok;
+        if (lv[r] && ok) present |= 1u << (int)labr[r];
+      }
+      small_int = __ballot(!small_int) == 0ull;
+      if (small_int) present = grp_wave_or(present);
+      for (int it = 0; it <= kMaxRuns; ++it) {
+        float v;
+        if (small_int && it < kMaxRuns) {
+          if (present == 0u) break;
+          const int gb = 31 - __builtin_clz(present);
+          present &= ~(1u << gb);
+          v = (float)gb;
+        } else {
+          float mx = rem[0];
+#pragma unroll
+          for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+          v = wave_max_u(mx);
+          if (v < 0.0f) break;
+        }
         const bool last = it == kMaxRuns;                                    // everything that is left
         int c = 0;
 #pragma unroll
@@ -254,7 +522,7 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
         const int pend = (ppos + c + 3) & ~3;
         if (lane == 0) {
           H->seg_start[nseg] = ppos; H->seg_end[nseg] = pend;
-          H->seg_gain[nseg] = (a.gain_kind == TFR_GAIN_POW2M1) ? gain_pow2m1(v) : v;
+          H->seg_gain[nseg] = pow2 ? grp_gain_pow2m1(v) : v;
         }
         pos += c; ppos = pend; ++nseg;
         tail = last;
@@ -285,6 +553,7 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
         idcg = wave_sum_u(idcg);
         inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
       }
+      GRP_STAMP(4);
 
       // 1e. the image: everything is padding first (A = B = 0, no original index), then the records in grade order.
       for (int p = lane; p < LpS; p += 64) {
@@ -302,8 +571,8 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
           const float t_hi = xv - m;
           const float bb = t_hi - xv;
           const float t_lo = (xv - (t_hi - bb)) + (-m - bb);
-          Bv = exp_df_hw(t_hi, t_lo);
-          Av = exp_df_hw(-t_hi, -t_lo);
+          Bv = exp_df_hw(t_hi, t_lo);                           // e^(x - m), 1 ulp
+          Av = __builtin_amdgcn_rcpf(Bv);                      // e^-(x - m): one more ulp, far inside the 1e-5 budget
         } else {
           Bv = xv; Av = 1.0f;                                                // slow path: the score itself / a validity flag
         }
@@ -315,45 +584,84 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
         CIS[gp[r]] = lane + 64 * r;
       }
       if (lane < nseg) H->seg_gain[lane] *= inv_max_dcg;
+      const int npass = (ppos + kGrpPassRows - 1) / kGrpPassRows;
       if (lane == 0) {
         H->n = n; H->np = ppos; H->nseg = nseg; H->flags = (fast ? 1 : 0) | (tail ? 2 : 0);
-        H->b = b; H->npass = (ppos + kGrpPassRows - 1) / kGrpPassRows; H->lw = lw;
+        H->npass = npass; H->lw = lw;
+        if (npass == 0) {                                     // no valid item: nothing to sweep, the sums are zero
+          if (a.list_loss) a.list_loss[b] = 0.f;
+          if (AUX && a.nnz) a.nnz[b] = 0.f;
+        }
       }
     }
+    // publish: the wave's DS operations complete in order, so the state lands behind everything written above
+    WAVE_LDS_SYNC();
+    if (lane == 0) *reinterpret_cast<volatile int*>(&H->state) = 2;
   }
-  __syncthreads();
+  GRP_STAMP(5);
 
-  // ---- 2. the (list, 32-row pass) work items of all W lists, dealt round-robin to the W waves.
+  // ---- 2. sweeps: (list, 32-row pass) work items from the per-list tickets of the lists that are ready.
   const int c = lane & 1;
   const uint32_t ubase = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)Urep + 4u * (uint32_t)(lane & (R - 1));
-  int q = wave;
-  for (int l = 0; l < W; ++l) {
+  unsigned pending = (G >= 32) ? 0xffffffffu : ((1u << G) - 1u);            // lists this wave has not seen exhausted yet
+  int l = wave < G ? wave : wave % G;                                        // start at the own list / spread the helpers
+  int misses = 0;
+  long spins = 0;
+  while (pending) {
+    if (!((pending >> l) & 1u)) { l = (l + 1 == G) ? 0 : l + 1; continue; }
     GrpHdr* H = GRP_HDR(l);
-    const int npass = __builtin_amdgcn_readfirstlane(H->npass);
-    if (q >= npass) { q -= npass; continue; }
+    int q = -1, npass = 0;
+    {
+      int st = 0;
+      if (lane == 0) st = *reinterpret_cast<volatile int*>(&H->state);
+      st = __builtin_amdgcn_readfirstlane(st);
+      if (st == 2) {
+        npass = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&H->npass));
+        int t = 0;
+        if (lane == 0) t = (npass > 0) ? atomicAdd(&H->next_pass, 1) : 0;
+        q = __builtin_amdgcn_readfirstlane(t);
+        if (q >= npass) { pending &= ~(1u << l); l = (l + 1 == G) ? 0 : l + 1; misses = 0; continue; }
+      }
+    }
+    if (q < 0) {                                              // list l is still being built: look at the others first
+      l = (l + 1 == G) ? 0 : l + 1;
+      if (++misses >= G) {
+        misses = 0;
+        __builtin_amdgcn_s_sleep(8);
+#ifdef TFR_PROFILE_STAMPS
+        ++grp_polls;
+#endif
+        if (++spins > (1l << 22)) break;                      // (a builder always finishes; never spin forever on a bug)
+      }
+      continue;
+    }
+    misses = 0;
     const float2* recH = GRP_RECH(l);
     const float2* recL = recH + LpS;
     const float* GS = reinterpret_cast<const float*>(recL + LpS);
     const float* WS = GS + LpS;
     const int* CIS = reinterpret_cast<const int*>(GS + LpS + (ITEMW ? LpS : 0));
-    const int b = __builtin_amdgcn_readfirstlane(H->b);
+    const int lb = __builtin_amdgcn_readfirstlane(H->b);
     const int np = __builtin_amdgcn_readfirstlane(H->np);
     const int nseg = __builtin_amdgcn_readfirstlane(H->nseg);
     const int flags = __builtin_amdgcn_readfirstlane(H->flags);
-    const float lw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, H->lw)));
+    const float llw = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, H->lw)));
     const bool fast = (flags & 1) != 0, tail = (flags & 2) != 0;
-    const size_t base = (size_t)b * L;
-    // the segment table, one segment per lane (read back with v_readlane: no LDS round trip per rectangle)
+    const size_t base = (size_t)lb * L;
+    // the segment table, one segment per lane (read back with v_readlane: no LDS round trip per segment)
     const int sl = lane < kGrpSegSlots ? lane : 0;
     const int seg_s = H->seg_start[sl], seg_e = H->seg_end[sl];
     const float seg_g = H->seg_gain[sl];
-    for (; q < npass; q += W) {
+    {
+#ifdef TFR_PROFILE_STAMPS
+      ++grp_passes;
+#endif
       const int row0 = q * kGrpPassRows;
       const int row = row0 + (lane >> 1);
       const float2 rh = recH[row], rl = recL[row];
       const float Gi = GS[row];
       const int ci = CIS[row];
-      const float wi = ITEMW ? WS[row] : lw;                  // weight of the row item (preferred in the hi sweep)
+      const float wi = ITEMW ? WS[row] : llw;                 // weight of the row item (preferred in the hi sweep)
       const uint32_t ri = (uint32_t)__float_as_int(rh.y);
       const int last_row = (row0 + kGrpPassRows < np ? row0 + kGrpPassRows : np) - 1;
       const int s_first = __popcll(__ballot(lane < nseg && seg_e <= row0));
@@ -361,33 +669,19 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
       float accL = 0.f, accG = 0.f, accG2 = 0.f, accW = 0.f, accNZ = 0.f;
       if (fast) {
         const float Ai = rl.x, Bi = rh.x;
-        const bool in_tail = tail && s_last == nseg - 1;      // some row of this pass lies in the unsorted tail segment
-        const int hi0 = in_tail ? (s_first + 1 < nseg - 1 ? s_first + 1 : nseg - 1) : s_first + 1;
-        for (int h = hi0; h < nseg; ++h) {                    // row preferred: the lower grades behind it
-          const int s = __builtin_amdgcn_readlane(seg_s, h), e = __builtin_amdgcn_readlane(seg_e, h);
+        const int npure = tail ? nseg - 1 : nseg;             // pure grade segments; the unsorted tail (if any) is segment nseg - 1
+        const bool in_tail = tail && s_last == nseg - 1;      // some row of this pass lies in the tail segment
+        // row preferred: the lower grades behind it (pure segments s_first + 1 .. npure - 1 in ONE loop)
+        grp_hi_sweep<AUX>(recH, s_first + 1, npure, seg_s, seg_e, seg_g, c, Ai, Gi, ri, ubase, accL, accG, accW, accNZ);
+        // column preferred: the higher grades in front of it (pure segments 0 .. s_last - 1)
+        grp_lo_sweep<ITEMW>(recL, WS, s_last < npure ? s_last : npure, seg_e, seg_g, c, Bi, Gi, ri, ubase, accG2);
+        if (tail) {                                           // the tail segment: gain difference per pair
+          const int s = __builtin_amdgcn_readlane(seg_s, nseg - 1), e = __builtin_amdgcn_readlane(seg_e, nseg - 1);
           GrpAcc r;
-          if (tail && h == nseg - 1) {
-            grp_hi_loop<true, AUX>(recH, GS, s, (e - s) >> 2, c, Ai, Gi, ri, ubase, r);
-            accL += r.l; accG += r.g;
-            if (AUX) { accW += r.w; accNZ += r.nz; }
-          } else {
-            const float Gh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h));
-            const float dG = fmaxf(Gi - Gh, 0.0f);
-            grp_hi_loop<false, AUX>(recH, GS, s, (e - s) >> 2, c, Ai, Gi, ri, ubase, r);
-            accL = __builtin_fmaf(dG, r.l, accL); accG = __builtin_fmaf(dG, r.g, accG);
-            if (AUX) { accW = __builtin_fmaf(dG, r.w, accW); accNZ += (dG != 0.0f) ? r.nz : 0.0f; }
-          }
-        }
-        const int lo1 = in_tail ? nseg : s_last;
-        for (int h = 0; h < lo1; ++h) {                       // column preferred: the higher grades in front of it
-          const int s = __builtin_amdgcn_readlane(seg_s, h), e = __builtin_amdgcn_readlane(seg_e, h);
-          if (tail && h == nseg - 1) {
-            accG2 += grp_lo_loop<true, ITEMW>(recL, GS, WS, s, (e - s) >> 2, c, Bi, Gi, ri, ubase);
-          } else {
-            const float Gh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, seg_g), h));
-            const float dG = fmaxf(Gh - Gi, 0.0f);
-            accG2 = __builtin_fmaf(dG, grp_lo_loop<false, ITEMW>(recL, GS, WS, s, (e - s) >> 2, c, Bi, Gi, ri, ubase), accG2);
-          }
+          grp_hi_loop<true, AUX>(recH, GS, s, (e - s) >> 2, c, Ai, Gi, ri, ubase, r);
+          accL += r.l; accG += r.g;
+          if (AUX) { accW += r.w; accNZ += r.nz; }
+          if (in_tail) accG2 += grp_lo_loop<true, ITEMW>(recL, GS, WS, s, (e - s) >> 2, c, Bi, Gi, ri, ubase);
         }
       } else {
         // per-pair exponential, numerically safe for any score range (same algebra as pair_loss above): recH.x = x,
@@ -431,45 +725,54 @@ __global__ __launch_bounds__(512) void lambdarank_group_kernel(const PwArgs a, c
         row_l = accL * kLn2 * wi;
         if (a.row_loss) a.row_loss[base + ci] = row_l;
         if (AUX && a.row_weight) a.row_weight[base + ci] = accW * wi;
-        const float g2 = ITEMW ? accG2 : accG2 * lw;
+        const float g2 = ITEMW ? accG2 : accG2 * llw;
         if (a.dlogits) a.dlogits[base + ci] = (g2 - accG * wi) / a.temperature;
         if (AUX) row_nz = (wi != 0.0f) ? accNZ : 0.0f;
       }
-      const bool want_list = a.list_loss != nullptr;
-      if (want_list) { const float s = wave_sum_u(row_l); if (lane == 0) H->pass_loss[q] = s; }
-      if (AUX && a.nnz) { const float s = wave_sum_u(row_nz); if (lane == 0) H->pass_nnz[q] = s; }
-    }
-    q -= npass;
-  }
-  if (a.list_loss == nullptr && !(AUX && a.nnz)) return;
-  __syncthreads();
-
-  // ---- 3. per-list sums over the passes, in pass order (deterministic).
-  {
-    const GrpHdr* H = GRP_HDR(wave);
-    const int b = H->b;
-    if (lane == 0 && b >= 0) {
-      const int npass = H->npass;
-      if (a.list_loss) { float t = 0.f; for (int p = 0; p < npass; ++p) t += H->pass_loss[p]; a.list_loss[b] = t; }
-      if (AUX && a.nnz) { float t = 0.f; for (int p = 0; p < npass; ++p) t += H->pass_nnz[p]; a.nnz[b] = t; }
+      const bool want_list = a.list_loss != nullptr, want_nnz = AUX && a.nnz != nullptr;
+      if (want_list) { const float sm = wave_sum_u(row_l); if (lane == 0) H->pass_loss[q] = sm; }
+      if (want_nnz) { const float sm = wave_sum_u(row_nz); if (lane == 0) H->pass_nnz[q] = sm; }
+      if (want_list || want_nnz) {
+        // the wave that completes the LAST pass of a list sums the pass partials, in pass order (deterministic):
+        // every wave wrote its partial before its own ticket return below, and LDS serves the requests in order
+        int done = 0;
+        if (lane == 0) done = atomicAdd(&H->done_pass, 1);
+        done = __builtin_amdgcn_readfirstlane(done);
+        if (done + 1 == npass && lane == 0) {
+          if (want_list) { float t = 0.f; for (int p2 = 0; p2 < npass; ++p2) t += H->pass_loss[p2]; a.list_loss[lb] = t; }
+          if (want_nnz) { float t = 0.f; for (int p2 = 0; p2 < npass; ++p2) t += H->pass_nnz[p2]; a.nnz[lb] = t; }
+        }
+      }
     }
   }
+  GRP_STAMP(7);
+#ifdef TFR_PROFILE_STAMPS
+  if (lane == 0 && g_prof_buf_pw) {
+    grp_t[8] = (unsigned long long)(builder ? GRP_HDR(wave)->n : 0);
+    grp_t[9] = (unsigned long long)grp_passes;
+    grp_t[10] = (unsigned long long)grp_polls;
+    for (int i = 0; i < 12; ++i) g_prof_buf_pw[((size_t)blockIdx.x * Wt + wave) * 12 + i] = grp_t[i];
+  }
+#endif
 #undef GRP_HDR
 #undef GRP_RECH
 }
 
 // Host side: geometry of the group kernel for a batch.  Returns 0 and fills (W, R, lds) when the kernel applies.
-inline bool grp_geometry(int B, int L, bool itemw, int& W, int& R, size_t& lds) {
+inline bool grp_geometry(int B, int L, bool itemw, int& G, int& Wt, int& R, size_t& lds) {
   const int Lp = grp_lp(L);
   if ((Lp + kGrpPassRows - 1) / kGrpPassRows > kGrpMaxPass) return false;
-  static const int env_w = env_int("TFR_LAMBDARANK_WAVES", 0);
+  static const int env_w = env_int("TFR_LAMBDARANK_WAVES", 0);          // lists (= builder waves) per workgroup
+  static const int env_h = env_int("TFR_LAMBDARANK_HELPERS", -1);       // extra sweep-only waves per workgroup
   static const int env_r = env_int("TFR_LAMBDARANK_REP", 0);
-  W = env_w > 0 ? env_w : (B >= 2048 ? 8 : (B >= 1024 ? 4 : (B >= 512 ? 2 : 1)));
-  if (W > 8) W = 8;
+  G = env_w > 0 ? env_w : (B >= 2048 ? 8 : (B >= 1024 ? 4 : (B >= 512 ? 2 : 1)));
+  if (G > 8) G = 8;
+  Wt = G + (env_h >= 0 ? env_h : G / 2);                      // (measured: 8 + 4 waves beat 8 + 0, 8 + 2 and 8 + 8 at B = 4096 and 16384)
+  if (Wt > 16) Wt = 16;
   R = (env_r == 16 || env_r == 32 || env_r == 8) ? env_r : 32;
   // two workgroups per CU (160 KiB of LDS) when the full replication allows it, else the half table
-  auto need = [&](int r) { return grp_table_bytes(L, r) + (size_t)W * grp_list_bytes(Lp, itemw); };
-  if (env_r == 0 && W == 8 && need(32) > 80 * 1024 && need(16) <= 80 * 1024) R = 16;
+  auto need = [&](int r) { return grp_table_bytes(L, r) + (size_t)G * grp_list_bytes(Lp, itemw); };
+  if (env_r == 0 && G == 8 && need(32) > 80 * 1024 && need(16) <= 80 * 1024) R = 16;
   if (L * 4 * R > 65535) R = 16;                              // v_sad_u16 works on 16-bit ranks * 4 R
   if (L * 4 * R > 65535) return false;
   lds = need(R);

@@ -1015,7 +1015,7 @@ int env_int(const char* name, int dflt);
 
 // One launch of the group kernel (dynamic LDS beyond 64 KiB needs the attribute once per instantiation).
 template <int IPL, bool AUX, bool IW>
-int launch_grp(const PwArgs& a, int B, int W, int R, size_t lds, hipStream_t stream) {
+int launch_grp(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lambdarank_group_kernel<IPL, AUX, IW>),
@@ -1023,8 +1023,8 @@ int launch_grp(const PwArgs& a, int B, int W, int R, size_t lds, hipStream_t str
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  const int N = (B + W - 1) / W;
-  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * W), lds, stream, a, B, R, grp_lp(a.L));
+  const int N = (B + G - 1) / G;
+  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R, grp_lp(a.L), G);
   return (int)hipGetLastError();
 }
 
@@ -1049,14 +1049,14 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
     const bool iw = a.item_weights != nullptr;
     static const int env_grp = env_int("TFR_LAMBDARANK_GROUP", 1);
     static const int env_grp_min = env_int("TFR_LAMBDARANK_GROUP_MIN_B", 512);
-    int gW = 0, gR = 0;
+    int gG = 0, gWt = 0, gR = 0;
     size_t glds = 0;
-    if (env_grp && B >= env_grp_min && grp_geometry(B, a.L, iw, gW, gR, glds)) {
-      // W lists per workgroup, shared pair sweeps, conflict-free rank-difference gather (lambdarank_group.h)
-      if (aux) return iw ? launch_grp<IPL, true, true>(a, B, gW, gR, glds, stream)
-                         : launch_grp<IPL, true, false>(a, B, gW, gR, glds, stream);
-      return iw ? launch_grp<IPL, false, true>(a, B, gW, gR, glds, stream)
-                : launch_grp<IPL, false, false>(a, B, gW, gR, glds, stream);
+    if (env_grp && B >= env_grp_min && grp_geometry(B, a.L, iw, gG, gWt, gR, glds)) {
+      // G lists per workgroup, barrier-free build / sweep, conflict-free rank-difference gather (lambdarank_group.h)
+      if (aux) return iw ? launch_grp<IPL, true, true>(a, B, gG, gWt, gR, glds, stream)
+                         : launch_grp<IPL, true, false>(a, B, gG, gWt, gR, glds, stream);
+      return iw ? launch_grp<IPL, false, true>(a, B, gG, gWt, gR, glds, stream)
+                : launch_grp<IPL, false, false>(a, B, gG, gWt, gR, glds, stream);
     }
     // smaller batches: S waves cooperate on one list (round-2 kernel)
     static const int env_ls = env_int("TFR_PAIRWISE_LEAN_WAVES", 0);

@@ -292,12 +292,20 @@ class ModelFitPipeline(AbstractPipeline):
                     vcount += 1
                     for m in metrics:
                         m.update_state(labels, logits, weights if h.use_weighted_metrics else None)
-            if world > 1:                       # every rank must see the same numbers: the early-stopping and
-                vsum, vcount = dist_lib.all_reduce_scalars([vloss, vcount], self._device)   # LR decisions below
-                vloss = vsum                    # decide whether this rank enters the next all-reduce
-            history.setdefault('val_loss', []).append(float(vloss) / max(1, vcount))
+            # Every rank must see the same numbers: the early-stopping / ReduceLROnPlateau / best-checkpoint decisions
+            # below decide whether this rank enters the next all-reduce.  ONE collective carries the validation loss
+            # and every metric's Mean sums (a metric without a batch on this rank contributes zeros); BatchNorm moving
+            # statistics differ between ranks after the initial broadcast, so per-rank metric values would too.
+            sums = [vloss, vcount]
             for m in metrics:
-                history.setdefault('val_' + m.name, []).append(float(m.result()))
+                sums += [m.total if m.total is not None else 0.0, m.count if m.count is not None else 0.0]
+            if world > 1:
+                sums = dist_lib.all_reduce_scalars(sums, self._device)
+            sums = [float(x) for x in sums]
+            history.setdefault('val_loss', []).append(sums[0] / max(1.0, sums[1]))
+            for i, m in enumerate(metrics):
+                t, c = sums[2 + 2 * i], sums[3 + 2 * i]
+                history.setdefault('val_' + m.name, []).append(t / c if c != 0 else 0.0)
             monitor = history['val_' + h.best_exporter_metric][-1] if h.best_exporter_metric != 'loss' \
                 else history['val_loss'][-1]
             if verbose and rank == 0:

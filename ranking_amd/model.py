@@ -120,8 +120,8 @@ class GroupwiseScorer(torch.nn.Module):
         if not isinstance(fn, FusedGroupScoreFn) or context_features:
             return None
         from .tower import FusedTower
-        if not isinstance(fn.tower, FusedTower):
-            return None
+        if not isinstance(fn.tower, FusedTower) or fn.tower.input_batch_norm:
+            return None      # input BatchNorm needs the raw fp32 group features (batch statistics): op-by-op gather
         names = fn.names(example_features)
         parts = [example_features[n] for n in names]
         b, l = parts[0].shape[0], parts[0].shape[1]

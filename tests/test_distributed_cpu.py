@@ -144,6 +144,27 @@ class _ToyLoss:
         return -(torch.log_softmax(y_pred, dim=1) * y_true).sum(dim=1).mean()
 
 
+class _ToyMetric:
+    """Torch-only stand-in with the Keras metric protocol (name, total / count Mean sums, update_state, reset_state):
+    the mean top-1 label of the lists.  Per-rank values differ when the ranks validate on different data."""
+    name = 'toy_metric'
+
+    def __init__(self):
+        self.total = self.count = None
+
+    def reset_state(self):
+        self.total = self.count = None
+
+    def update_state(self, y_true, y_pred, sample_weight=None):
+        top = y_true.gather(1, y_pred.argmax(dim=1, keepdim=True)).sum()
+        self.total = top if self.total is None else self.total + top
+        n = torch.tensor(float(y_true.shape[0]))
+        self.count = n if self.count is None else self.count + n
+
+    def result(self):
+        raise AssertionError('the pipeline reduces the sums itself (one collective), result() is not its path')
+
+
 class _ToyModelBuilder:
     def __init__(self, seed):
         self._seed = seed
@@ -169,7 +190,7 @@ def _toy_batches(n_steps, batch, lo, hi):
     return [({'x': feats[s, lo:hi]}, labels[s, lo:hi]) for s in range(n_steps)]
 
 
-def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8):
+def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8, with_metric=False):
     from ranking_amd.keras import pipeline as P
     lo, hi = D.shard_bounds(batch, rank, world)
 
@@ -178,7 +199,7 @@ def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8):
             return _ToyLoss()
 
         def build_metrics(self):
-            return []
+            return [_ToyMetric()] if with_metric else []
 
         def build_weighted_metrics(self):
             return []
@@ -186,7 +207,9 @@ def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8):
     valid = _toy_batches(2, batch, 0, batch) if rank == 0 else _toy_batches(2, batch, 0, batch // 2)
     hp = P.PipelineHparams(model_dir=os.path.join(tmp, 'rank%d' % rank), num_epochs=3, steps_per_epoch=2,
                            validation_steps=2, learning_rate=0.05, loss='toy', optimizer='sgd',
-                           early_stopping_patience=2, automatic_reduce_lr=True)
+                           early_stopping_patience=2, automatic_reduce_lr=True,
+                           **(dict(best_exporter_metric='toy_metric', best_exporter_metric_higher_better=True)
+                              if with_metric else {}))
     pipe = _Pipe(_ToyModelBuilder(seed), P.NullDatasetBuilder(iter(_toy_batches(n_steps, batch, lo, hi)), valid), hp,
                  device=torch.device('cpu'))
     history = pipe.train_and_validate()
@@ -194,11 +217,11 @@ def _run_toy_pipeline(tmp, rank, world, seed, n_steps=6, batch=8):
     return history, flat, float(pipe.model.steps_seen)
 
 
-def _pipeline_worker(rank, world, port, tmp, out):
+def _pipeline_worker(rank, world, port, tmp, out, with_metric=False):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    history, flat, buf = _run_toy_pipeline(tmp, rank, world, seed=100 + rank)
+    history, flat, buf = _run_toy_pipeline(tmp, rank, world, seed=100 + rank, with_metric=with_metric)
     out[rank] = (history, flat, buf)
     dist.destroy_process_group()
 
@@ -219,6 +242,23 @@ def test_model_fit_pipeline_data_parallel_world2(tmp_path):
         assert hist['loss'] == pytest.approx(want_hist['loss'], abs=1e-6)
     assert out[0][0]['val_loss'] == out[1][0]['val_loss']       # the same decisions on every rank
     assert len(out[0][0]['val_loss']) == len(out[1][0]['val_loss'])
+
+
+def test_model_fit_pipeline_monitors_a_metric_identically_on_every_rank(tmp_path):
+    """with `best_exporter_metric` set to a metric, the monitor that drives early stopping, ReduceLROnPlateau
+    and the best checkpoint must be the SAME number on every rank although the ranks validate on different data: the
+    pipeline reduces the metric's Mean sums in the collective that carries the validation loss."""
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path), out, True), nprocs=world, join=True)
+    h0, h1 = out[0][0], out[1][0]
+    assert 'val_toy_metric' in h0 and len(h0['val_toy_metric']) >= 1
+    assert h0['val_toy_metric'] == h1['val_toy_metric'] and h0['val_loss'] == h1['val_loss']
+    assert len(h0['loss']) == len(h1['loss'])                    # both ranks stopped after the same epoch
+    assert torch.equal(out[0][1], out[1][1])                     # ... with identical parameters
+    # rank 0 validated 8 lists per batch, rank 1 the first 4 of them: the reduced value is the mean over all 12
+    single = _run_toy_pipeline(str(tmp_path / 'single'), 0, 1, seed=100, with_metric=True)[0]
+    assert h0['val_toy_metric'] != single['val_toy_metric']
 
 
 def test_flat_params_sgd_equals_per_tensor_sgd():

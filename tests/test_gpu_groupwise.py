@@ -38,7 +38,7 @@ def _valid(B, L, seed, p=0.7):
     return v
 
 
-@pytest.mark.parametrize('B,L', [(1, 1), (5, 3), (9, 50), (7, 64), (6, 65), (5, 200), (3, 1000)])
+@pytest.mark.parametrize('B,L', [(1, 1), (5, 3), (9, 50), (7, 64), (6, 65), (5, 200), (3, 1000), (3, 2049), (2, 4100)])   # > 2048: fewer list-waves per workgroup
 @pytest.mark.parametrize('gs', [1, 2, 3, 5])
 def test_group_indices_no_shuffle(B, L, gs):
     """model_test.py:52-73, 96-112 semantics at scale: valid-first index order, rolling windows mod n_valid."""
@@ -61,7 +61,7 @@ def test_group_indices_reference_literals():
     assert idx.cpu().tolist() == [[[0, 1], [1, 2], [2, 0]], [[0, 1], [1, 0], [0, 1]]]
 
 
-@pytest.mark.parametrize('B,L,gs', [(9, 50, 2), (6, 65, 3), (4, 200, 2), (3, 777, 4)])
+@pytest.mark.parametrize('B,L,gs', [(9, 50, 2), (6, 65, 3), (4, 200, 2), (3, 777, 4), (2, 3000, 2)])
 def test_group_indices_with_shuffle_keys(B, L, gs):
     """utils.py:203-230 with shuffle: stable descending order of the draws, invalid entries last; tied draws keep
     index order."""

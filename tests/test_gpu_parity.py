@@ -1735,6 +1735,8 @@ def test_lambdarank_group_kernel_against_the_oracle(L, wkind):
     B = 520
     labels, logits = _edge_case_batch(B, L, seed=77 + L)
     logits[8::16] = logits[8::16] / 6.0                        # (the oracle comparison of wide ranges is a test of its own)
+    g = torch.Generator().manual_seed(5)                       # ... and so are exact ties (relu'(0) of the reference's
+    logits[9::16] = torch.randn(logits[9::16].shape, generator=g)     # formula: test_lambdarank_fast_path_ties_in_scores)
     w = make_weights(B, L, seed=L) if wkind == 'item' else None
     _lean_case(labels, logits, w, T=0.9, tol=2e-5)
 

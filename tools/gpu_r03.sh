@@ -32,6 +32,20 @@ PY
       for w in 4 8; do for r in 16 32; do
         TFR_LAMBDARANK_WAVES=$w TFR_LAMBDARANK_REP=$r timeout 300 python bench.py --workload pairwise_lambda --batch 4096 --steps 100 --warmup 10 --no-cpu-baseline --also none 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  W=$w R=$r B=4096 kernel_ms %.4f step %.4f' % (d['roofline']['kernel_ms'], d['ms_per_step']))"
       done; done ;;
+    pw_quick)
+      TFR_LAMBDARANK_GROUP_MIN_B=1 TFR_LAMBDARANK_WAVES=8 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lambdarank" > $OUT/pw_forced8.log 2>&1; echo "forced W=8 rc=$?"; tail -n 4 $OUT/pw_forced8.log
+      for b in 4096 16384; do
+          timeout 300 python bench.py --workload pairwise_lambda --batch $b --steps 100 --warmup 10 --no-cpu-baseline --also none 2>/dev/null | tail -n 1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('  B=$b kernel_ms %.4f step %.4f valu_frac %.3f' % (d['roofline']['kernel_ms'], d['ms_per_step'], d['roofline']['valu_frac']))"
+      done ;;
+    pw_prof)
+      for b in 4096 16384; do B=$b timeout 200 python tools/phase_profile.py group > $OUT/phase_group_B$b.txt 2>&1; cat $OUT/phase_group_B$b.txt; done
+      B=4096 TFR_LAMBDARANK_WAVES=4 TFR_LAMBDARANK_REP=16 timeout 200 python tools/phase_profile.py group > $OUT/phase_group_B4096_W4.txt 2>&1; cat $OUT/phase_group_B4096_W4.txt
+      for b in 4096 16384; do
+        timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_sq_pw$b.log 2>&1
+        python tools/rocpd_summary.py pmc $OUT/pmc_sq_pw$b/r_results.db lambdarank > $OUT/pmc_sq_pw$b.txt 2>&1; cat $OUT/pmc_sq_pw$b.txt
+        timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_sq2_pw$b.log 2>&1
+        python tools/rocpd_summary.py pmc $OUT/pmc_sq2_pw$b/r_results.db lambdarank > $OUT/pmc_sq2_pw$b.txt 2>&1; cat $OUT/pmc_sq2_pw$b.txt
+      done ;;
     tests)
       timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
       tail -n 70 $OUT/pytest_gpu.log

@@ -117,8 +117,72 @@ def main_pairwise():
         n.mean().item(), (n * n).mean().item(), (cnt * higher).sum(dim=1).mean().item()))
 
 
+def main_group():
+    """LambdaRank group kernel (lambdarank_group.h): per-wave stamps [table, load+compact, rank count, grade order +
+    ideal DCG, records, (barrier wait), sweeps]."""
+    if not os.path.exists(_lib.PROF_LIB_PATH):
+        _lib.build_profiling()
+    lib = ctypes.CDLL(_lib.PROF_LIB_PATH)
+    B, L = int(os.environ.get('B', '4096')), 200
+    W = int(os.environ.get('TFR_LAMBDARANK_WAVES', '8'))
+    labels, logits = make_batch(B, L, seed=4)
+    dev = 'cuda'
+    labels, logits = labels.to(dev), logits.to(dev)
+    import math
+    r = torch.arange(1, L + 2, dtype=torch.float32)
+    disc = (math.log(2.) / torch.log1p(r)).to(dev)
+    dl = torch.empty((B, L), device=dev); lst = torch.empty((B,), device=dev)
+    lw = torch.full((B,), 1.0 / (B * L), device=dev)
+    Wt_ = W + max(0, int(os.environ.get('TFR_LAMBDARANK_HELPERS', '0')))
+    nwaves = ((B + W - 1) // W) * Wt_
+    buf = torch.zeros((nwaves, 12), dtype=torch.int64, device=dev)
+    lib.tfr_prof_set_buffer_pw(ctypes.c_void_p(buf.data_ptr()))
+    from ranking_amd import _ops
+    order = _ops.list_order(labels) if os.environ.get('ORDER', '1') != '0' else None
+    f = lib.tfr_pairwise_loss_f32
+    f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] * 2 + \
+        [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 7
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda: f(0, logits.data_ptr(), labels.data_ptr(), None, None, lw.data_ptr(), 2, 0, 0.0, 1, 1, None,
+                     disc.data_ptr(), B, L, 1.0, None, None, None, dl.data_ptr(),
+                     None if order is None else order.data_ptr(), lst.data_ptr(), st)
+    for _ in range(3):
+        rc = call()
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    print('lambdarank group kernel (stamped build) B=%d W=%d: %.4f ms' % (B, W, e0.elapsed_time(e1) / 20))
+    d = buf.cpu()
+    t = d[:, :8].double()
+    build = t[:, 5] > t[:, 1]                                  # builder waves (helpers skip phase 1)
+    names = ['loads + table + barrier', 'gains + compaction', 'rank count', 'grade order + ideal DCG', 'records + publish']
+    tot = (t[:, 7] - t[:, 0]).mean().item()
+    print('mean ticks per wave: total %.0f   (%d waves, %d builders)' % (tot, t.shape[0], int(build.sum())))
+    tb = t[build]
+    for i, nme in enumerate(names):
+        dt = (tb[:, i + 1] - tb[:, i])
+        print('  %-28s mean %8.0f  %5.1f %%   max %8.0f' % (nme, dt.mean().item(), 100 * dt.mean().item() / tot, dt.max().item()))
+    sw = (t[:, 7] - torch.where(build, t[:, 5], t[:, 1]))
+    print('  %-28s mean %8.0f  %5.1f %%   max %8.0f' % ('sweeps (+ waiting for lists)', sw.mean().item(), 100 * sw.mean().item() / tot, sw.max().item()))
+    print('mean n_valid %.1f, passes per wave mean %.2f max %d, sleeps per wave mean %.1f max %d' % (
+        d[build, 8].double().mean().item(), d[:, 9].double().mean().item(), int(d[:, 9].max()),
+        d[:, 10].double().mean().item(), int(d[:, 10].max())))
+    print('sweep ticks per pass: %.0f' % (sw.sum().item() / max(1, d[:, 9].sum().item())))
+    # per-workgroup lifetime (waves of a workgroup share the XCD clock)
+    Wt = t.shape[0] // ((B + W - 1) // W)
+    tw = t.reshape(-1, Wt, 8)
+    life = (tw[:, :, 7].max(dim=1).values - tw[:, :, 0].min(dim=1).values)
+    print('workgroup lifetime: mean %.0f  max %.0f  min %.0f ticks' % (life.mean().item(), life.max().item(), life.min().item()))
+
+
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'pairwise':
+    if len(sys.argv) > 1 and sys.argv[1] == 'group':
+        main_group()
+    elif len(sys.argv) > 1 and sys.argv[1] == 'pairwise':
         main_pairwise()
     else:
         main()

@@ -116,6 +116,69 @@ __global__ void k_pair(float* out, float seed, int N) {
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + p0.x + p0.y + p1.x + p1.y;
 }
 
+
+// LambdaRank group-kernel trips (ranking_amd/csrc/lambdarank_group.h): records (B, rank) as float2 in LDS, the
+// rank-difference table replicated per bank, v_sad_u16 address, two columns per lane and trip.
+// VAR 0: hi trip (fma, rcp, log, 2 fma per column)   VAR 1: lo trip (fma, rcp, fma per column)
+// DEPTH: trips in flight (1 = load, wait, compute; 2 / 3 = software pipelined like the kernel)
+typedef const __attribute__((address_space(3))) float lds_cf;
+__device__ __forceinline__ float gat(unsigned ri, float rj, unsigned ubase) {
+  return *(lds_cf*)(uintptr_t)__builtin_amdgcn_sad_u16(ri, (unsigned)__float_as_int(rj), ubase);
+}
+template <int VAR, int DEPTH>
+__global__ void k_trip(float* out, float seed, int NREC, int L) {
+  extern __shared__ __attribute__((aligned(128))) float lds[];
+  float* U = lds;                      // [L * 32]
+  float2* rec = reinterpret_cast<float2*>(lds + L * 32);   // [NREC + 16]
+  for (int i = threadIdx.x; i < L * 32; i += blockDim.x) U[i] = 1.0f / (1.0f + (i >> 5));
+  for (int i = threadIdx.x; i < NREC + 16; i += blockDim.x) rec[i] = make_float2(0.5f + (i % 7) * 0.1f, __int_as_float(((i * 37) % L) * 128));
+  __syncthreads();
+  const int lane = threadIdx.x & 63, c = lane & 1;
+  const unsigned ubase = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void*)U + 4u * (lane & 31);
+  const unsigned ri = (unsigned)(((lane * 13) % L) * 128);
+  const float Ai = seed + lane * 1e-3f;
+  const float4* p = reinterpret_cast<const float4*>(rec + 2 * c);
+  const int trips = NREC / 4;
+  float al = 0.f, ag = 0.f;
+  for (int rep = 0; rep < 64; ++rep) {
+#define TRIP(CR, U0, U1)                                                             \
+    do {                                                                             \
+      const float w0 = __builtin_fmaf(Ai, CR.x, 1.0f), w1 = __builtin_fmaf(Ai, CR.z, 1.0f);   \
+      const float q0 = __builtin_amdgcn_rcpf(w0), q1 = __builtin_amdgcn_rcpf(w1);     \
+      if (VAR == 0) {                                                                \
+        const float l0 = __builtin_amdgcn_logf(w0), l1 = __builtin_amdgcn_logf(w1);   \
+        al = __builtin_fmaf(U0, l0, al); al = __builtin_fmaf(U1, l1, al);             \
+      }                                                                              \
+      ag = __builtin_fmaf(U0, 1.0f - q0, ag); ag = __builtin_fmaf(U1, 1.0f - q1, ag); \
+    } while (0)
+    if (DEPTH == 1) {
+      for (int t = 0; t < trips; ++t) {
+        const float4 cr = p[2 * t];
+        const float u0 = gat(ri, cr.y, ubase), u1 = gat(ri, cr.w, ubase);
+        TRIP(cr, u0, u1);
+      }
+    } else {
+      float4 ca = p[0], cb = p[2], cc = p[4];
+      float ua0 = gat(ri, ca.y, ubase), ua1 = gat(ri, ca.w, ubase);
+      float ub0 = gat(ri, cb.y, ubase), ub1 = gat(ri, cb.w, ubase);
+      for (int t = 0; t + 3 <= trips; t += 3) {
+        float4 cd = p[2 * t + 6];
+        float uc0 = gat(ri, cc.y, ubase), uc1 = gat(ri, cc.w, ubase);
+        TRIP(ca, ua0, ua1);
+        float4 ce = p[2 * t + 8];
+        float ud0 = gat(ri, cd.y, ubase), ud1 = gat(ri, cd.w, ubase);
+        TRIP(cb, ub0, ub1);
+        float4 cf = p[2 * t + 10];
+        float ue0 = gat(ri, ce.y, ubase), ue1 = gat(ri, ce.w, ubase);
+        TRIP(cc, uc0, uc1);
+        ca = cd; ua0 = ud0; ua1 = ud1; cb = ce; ub0 = ue0; ub1 = ue1; cc = cf;
+      }
+    }
+#undef TRIP
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = al + ag;
+}
+
 template <typename Fn>
 double time_ms(Fn launch, int reps = 5) {
   hipEvent_t a, b;
@@ -151,5 +214,15 @@ int main() {
 #define RUN_PAIR(V) { double ms = time_ms([&] { hipLaunchKernelGGL(k_pair<V>, dim3(blocks), dim3(threads), 2 * N * sizeof(float), 0, out, 1.5f, N); }); \
     double pe = (double)blocks * threads * 16.0 * N; printf("%-14s %10.4f %16.2f %22.2f\n", vn[V], ms, pe / ms / 1e6, 1024.0 * 2.4e9 * ms * 1e-3 / (pe / 64.0)); }
   RUN_PAIR(0) RUN_PAIR(1) RUN_PAIR(2) RUN_PAIR(3) RUN_PAIR(4)
+  {
+    const int NREC = 96, L = 200;                       // 24 trips per lane pair and repetition
+    const size_t lds_b = (size_t)L * 32 * 4 + (NREC + 16) * 8;
+    printf("%-34s %10s %22s\n", "lambdarank trip (2 columns/lane)", "ms", "cyc/trip/SIMD@2.4GHz");
+#define RUN_TRIP(V, D, WPS) { const int wg = 256 * WPS; CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trip<V, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+      double ms = time_ms([&] { hipLaunchKernelGGL((k_trip<V, D>), dim3(wg), dim3(256), lds_b, 0, out, 0.7f, NREC, L); }); \
+      double tr = (double)wg * 4 * 64.0 * (NREC / 4); printf("%s depth %d, %d waves/SIMD            %10.4f %22.2f\n", V ? "lo" : "hi", D, WPS, ms, 1024.0 * 2.4e9 * ms * 1e-3 / tr); }
+    RUN_TRIP(0, 1, 1) RUN_TRIP(0, 1, 2) RUN_TRIP(0, 1, 4) RUN_TRIP(0, 3, 1) RUN_TRIP(0, 3, 2) RUN_TRIP(0, 3, 4)
+    RUN_TRIP(1, 1, 1) RUN_TRIP(1, 1, 2) RUN_TRIP(1, 1, 4) RUN_TRIP(1, 3, 1) RUN_TRIP(1, 3, 2) RUN_TRIP(1, 3, 4)
+  }
   return 0;
 }
