@@ -30,16 +30,7 @@ def pytest_collection_modifyitems(config, items):
 # Parity margins: every tolerance check of the GPU suites reports (what, achieved max error, bar) here, and the
 # session prints the worst margin per check and writes them to gpurun_out/parity_margins.json, so that pytest.log
 # records HOW MUCH of each bar is used, not only that it held ("Next round" #2).
-MARGINS = {}
-
-
-def record_margin(what, err, bar):
-    test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
-    key = what or test
-    frac = float(err) / float(bar) if bar else 0.0
-    cur = MARGINS.get(key)
-    if cur is None or frac > cur['used']:
-        MARGINS[key] = {'max_err': float(err), 'bar': float(bar), 'used': frac, 'test': test}
+from tests.margins import MARGINS, record_margin  # noqa: E402,F401  (one shared dict: the plugin copy of this file is a different module object)
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):

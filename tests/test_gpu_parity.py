@@ -14,7 +14,7 @@ import torch
 
 from oracle import tfr_ref as R
 from tests.common import make_batch, make_weights
-from tests.conftest import record_margin
+from tests.margins import record_margin
 
 pytestmark = pytest.mark.gpu
 
