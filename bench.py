@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
-TRAFFIC_FILES = ('profiles/r02_traffic.json', 'profiles/r01_traffic.json')     # newest first
+TRAFFIC_FILES = ('profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json')     # newest first
 
 WORKLOADS = {
     # name: (B per GPU, L, description, algorithmic HBM bytes per list -- SURVEY.md 8d)
@@ -75,8 +75,26 @@ DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbe
 # measured on MI355X with tools/ubench.hip (profiles/: plain VALU 2.4, v_rcp / v_log / v_exp 8.5 cycles per
 # wave-instruction): ApproxNDCG forward + backward sweep; pairwise = the LambdaRank fast path per ACTIVE ordered pair
 # (l_i > l_j): "hi" sweep 8 plain + rcp + log, "lo" sweep 7 plain + rcp.  Used for `roofline.valu_frac`.
-VALU_CYCLES_PER_64_PAIRS = {'approx_ndcg': 15.3 + 20.5, 'pairwise': (8 + 7) * 2.4 + 3 * 8.5}
+REFERENCE_DROPOUT = 0.5        # create_tower(dropout=0.5) keras/layers.py:32; --dropout of examples/tf_ranking_libsvm.py:86
+VALU_CYCLES_PER_64_PAIRS = {'approx_ndcg': 15.3 + 20.5, 'pairwise': (8 + 7) * 2.4 + 3 * 8.5}     # round-2 constants: fallback only
+TRANS_CYCLES_PER_64_PAIRS = {'approx_ndcg': 2 * 8.5, 'pairwise': 3 * 8.5}
 SIMDS, PEAK_CLOCK_HZ = 1024, 2.4e9
+
+
+def pair_floor(kind):
+    """(VALU cycles, transcendental-only cycles, source) per 64 pair evaluations of the pair sweeps.  Round 3: derived
+    from the COMPILED kernels by tools/isa_floor.py (instruction classes of the innermost sweep loops x the issue costs
+    measured by tools/ubench.hip) and stored next to the library, so the floor moves when the loop does; the hand-kept
+    constants of round 2 remain only as the fallback when that file is missing."""
+    path = os.path.join(ROOT, 'ranking_amd', 'csrc', 'isa_floor.json')
+    try:
+        with open(path) as f:
+            d = json.load(f)[kind]
+        return (d['valu_cycles_per_64_pairs'], d['trans_cycles_per_64_pairs'],
+                'ranking_amd/csrc/isa_floor.json (tools/isa_floor.py: %s)' % ', '.join(
+                    '%s %.1f' % (k, v['valu_cycles_per_64_pairs']) for k, v in d['parts'].items()))
+    except (OSError, ValueError, KeyError):
+        return VALU_CYCLES_PER_64_PAIRS[kind], TRANS_CYCLES_PER_64_PAIRS[kind], 'round-2 constants (isa_floor.json missing)'
 
 
 def e2e_flops_per_list(workload, L):
@@ -174,7 +192,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
                         logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_rows=False,
                         want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC,
                         balance=order if order is not None else False, **lam),
-                    kernel_name='pairwise_lean_kernel' if L <= 256 else 'pairwise_logistic_kernel')
+                    kernel_name=('lambdarank_group_kernel' if B >= 512 else 'pairwise_lean_kernel') if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()
         w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
@@ -262,7 +280,28 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         sgd()
         return s[0] / max(world, 1)
 
-    info = dict(kernel=None, kernel_name='whole training step (tower_gemm256p_kernel / tower_wgrad256_kernel dominate)',
+    # the dominant kernel alone: one hidden-layer forward GEMM of the tower ([M, 512] x [512, 512], BatchNorm + ReLU
+    # (+ Dropout) of the layer below applied to the operand, bias and BatchNorm statistics in the epilogue), at the
+    # M = rows-per-step of this workload, in the form the step runs it
+    from ranking_amd import _tower_ops as TO
+    M_rows = B * L
+    gk = torch.Generator(device=dev).manual_seed(7)
+    k_a = (torch.randn((M_rows, 512), generator=gk, device=dev)).to(torch.bfloat16)
+    k_w = (torch.randn((512, 512), generator=gk, device=dev) * 0.05).to(torch.bfloat16)
+    k_sc = torch.rand(512, generator=gk, device=dev) + 0.5
+    k_sh = torch.randn(512, generator=gk, device=dev) * 0.1
+    k_b = torch.zeros(512, device=dev)
+    k_out = torch.empty((M_rows, 512), dtype=torch.bfloat16, device=dev)
+    k_drop = TO.Dropout.make(dropout, 12345) if dropout > 0.0 else None
+
+    def dominant_kernel():
+        TO.gemm(k_a, k_w, 512, 512, prologue=TO.PRO_AFFINE_RELU, a_scale=k_sc, a_shift=k_sh, bias=k_b,
+                epilogue=TO.EPI_STATS, out=k_out, pro_dropout=k_drop)
+    info = dict(kernel=dominant_kernel,
+                kernel_name='tower_gemm256p_kernel<BN+ReLU%s prologue, bias + BatchNorm-statistics epilogue>: one hidden-layer '
+                            'forward GEMM [%d, 512] x [512, 512] bf16 (2 of the ~15 GEMM-class launches of the step)'
+                            % ('+Dropout' if dropout > 0.0 else '', M_rows),
+                kernel_flops=2.0 * M_rows * 512 * 512, kernel_bytes=2.0 * M_rows * 512 * 2 + 512 * 512 * 2,
                 all_reduce_bytes=int(bucket.flat.numel() * 4), params=int(bucket.numel))
     if not use_graph:
         scal = torch.zeros(2, device=dev)
@@ -285,13 +324,12 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
     if world <= 1:
         # one replica: no collective between backward and the optimizer -> the whole step is ONE graph
         with capture(g_fb):
-            static_value = fwd_bwd()
-            static_scalars = torch.stack([static_value, one])
+            static_value = fwd_bwd()                        # (no scalar stack: it only feeds the all-reduce at N > 1)
             sgd()
 
         def graph_step():
             g_fb.replay()
-            return static_scalars[0]
+            return static_value
         info.update(step=graph_step, all_reduce=lambda: None)
         return info
     with capture(g_fb):
@@ -513,7 +551,7 @@ def cpu_fused_c_baseline(workload, B, L):
 
 
 # ------------------------------------------------------------------------------------------ measuring one workload
-def _timed_loop(fn, n, dist):
+def _timed_loop(fn, n, dist, want_local=False):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -522,6 +560,7 @@ def _timed_loop(fn, n, dist):
     for _ in range(n):
         fn()
     torch.cuda.synchronize()
+    local = time.perf_counter() - t0                        # this rank's own time (before the closing barrier)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -530,7 +569,7 @@ def _timed_loop(fn, n, dist):
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed
+    return (elapsed, local) if want_local else elapsed
 
 
 def _kernel_ms(kernel, n):
@@ -571,9 +610,10 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
     if args.batch > 0 and name == args.workload:
         B = args.batch
     labels, logits = make_inputs(B, L, seed=4 + rank, device=dev)
-    info = build_step(name, labels, logits, args.dropout, args.graph)
-    step = info['step']
     is_e2e = name.startswith('e2e_')
+    dropout = (REFERENCE_DROPOUT if args.dropout is None else args.dropout) if is_e2e else 0.0
+    info = build_step(name, labels, logits, dropout, args.graph)
+    step = info['step']
     if args.graph and not is_e2e:
         # The loss step is a handful of short launches (order, loss kernel, reduction): replay it from a
         # hipGraph so that the measured rate is the GPU's, not the Python launch path's.
@@ -595,11 +635,34 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
 
     for _ in range(warmup):
         step()
-    elapsed = _timed_loop(step, steps, dist)
+    elapsed, local_elapsed = _timed_loop(step, steps, dist, want_local=True)
+    per_rank = None
+    if dist is not None:                                    # a straggler must be visible: every rank's own rate
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = B * steps / local_elapsed
+        dist.all_reduce(t)
+        per_rank = [float(v) for v in t.tolist()]
+    if name == args.workload and args.busy_seconds > 0:
+        # keep the GPU visibly busy: the timed region of a loss workload is a few milliseconds of a run dominated by the
+        # CPU baselines, and a 5-second utilisation sampler never saw it.  NOT part of any reported number.
+        t_end = time.perf_counter() + args.busy_seconds
+        while time.perf_counter() < t_end:
+            for _ in range(200):
+                step()
+            torch.cuda.synchronize()
     kernel_ms = _kernel_ms(info['kernel'], steps) if info.get('kernel') is not None else None
     all_reduce_ms = None
     if is_e2e:
         all_reduce_ms = 1e3 * _timed_loop(info['all_reduce'], steps, dist) / steps if world > 1 else 0.0
+    e_drop0 = None
+    if is_e2e and dropout > 0.0 and args.dropout is None:
+        # the same step without Dropout (what rounds 1-2 timed), beside the reference-default number: every rank
+        # runs it (the step has a collective at N > 1)
+        info0 = build_step(name, labels, logits, 0.0, args.graph)
+        for _ in range(warmup):
+            info0['step']()
+        e_drop0 = _timed_loop(info0['step'], steps, dist)
+        del info0
     if rank != 0:
         return None
 
@@ -611,13 +674,16 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         'value': value, 'unit': 'lists/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
         'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16' if is_e2e else 'f32', 'data': 'synthetic',
-        'config': {'workload': desc, 'lists_per_gpu_per_step': B, 'list_size': L,
+        'config': {'workload': desc + (', dropout=%g (fused counter-based keep mask)' % dropout if is_e2e else ''),
+                   'lists_per_gpu_per_step': B, 'list_size': L,
                    'valid_length': 'U{ceil(L/2)..L}', 'labels': 'randint{0..4}, -1 padding',
                    'logits': 'N(0,1) tie-free',
                    'parallelism': ('dp%d (lists sharded, ONE all-reduce of the flat gradient bucket per step)' % world)
                    if is_e2e else 'dp%d (lists sharded, no collective)' % world},
     }
-    if kernel_ms is not None:
+    if per_rank is not None:
+        result['lists_per_s_per_rank'] = per_rank
+    if kernel_ms is not None and not is_e2e:
         algo_bytes = bytes_per_list(L) * B
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         roof = {
@@ -631,24 +697,33 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         if name.startswith('approx_ndcg') or name == 'gumbel_approx_ndcg':
             mult = 8.0 if name == 'gumbel_approx_ndcg' else 1.0
             n_valid_sq = mult * float((valid.sum(dim=1).double() ** 2).sum().item())
-            floor_ms = n_valid_sq / 64.0 * VALU_CYCLES_PER_64_PAIRS['approx_ndcg'] / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            vc, tc, fsrc = pair_floor('approx_ndcg')
+            floor_ms = n_valid_sq / 64.0 * vc / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            tfloor_ms = n_valid_sq / 64.0 * tc / (SIMDS * PEAK_CLOCK_HZ) * 1e3
             roof.update(pairs_per_s=2.0 * n_valid_sq / (kernel_ms * 1e-3), valu_floor_ms=floor_ms,
-                        valu_frac=floor_ms / kernel_ms,
+                        valu_frac=floor_ms / kernel_ms, trans_floor_ms=tfloor_ms, trans_frac=tfloor_ms / kernel_ms,
+                        floor_source=fsrc,
                         note='O(L^2) pair work is on-chip: the kernel is VALU/transcendental bound, the HBM fraction '
-                             'is reported as the contract asks; valu_frac = issue floor of the two pair sweeps '
-                             '(tools/ubench.hip cycle costs, 1024 SIMDs at 2.4 GHz) / kernel time (DESIGN.md)')
+                             'is reported as the contract asks; valu_frac = instruction-mix issue floor of the two pair '
+                             'sweeps (forward + backward, one evaluation of every ordered pair each; 1024 SIMDs at 2.4 GHz) '
+                             '/ kernel time; trans_frac = the same with the v_rcp_f32 of the sigmoids alone (DESIGN.md 4.1)')
         elif name == 'pairwise_lambda':
             lab = torch.where(valid, labels, torch.full_like(labels, -1.0))
             # ordered pairs with l_i > l_j among valid items = the pairs the loss sums over
             cnt = torch.stack([(lab == g).sum(dim=1).double() for g in range(5)], dim=1)          # [B, 5]
             higher = torch.flip(torch.cumsum(torch.flip(cnt, [1]), 1), [1]) - cnt                # items with a larger grade
             active = float((cnt * higher).sum().item())
-            floor_ms = active / 64.0 * VALU_CYCLES_PER_64_PAIRS['pairwise'] / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            vc, tc, fsrc = pair_floor('pairwise')
+            floor_ms = active / 64.0 * vc / (SIMDS * PEAK_CLOCK_HZ) * 1e3
+            tfloor_ms = active / 64.0 * tc / (SIMDS * PEAK_CLOCK_HZ) * 1e3
             roof.update(pairs_per_s=active / (kernel_ms * 1e-3), active_pairs_per_launch=active,
-                        valu_floor_ms=floor_ms, valu_frac=floor_ms / kernel_ms,
+                        valu_floor_ms=floor_ms, valu_frac=floor_ms / kernel_ms, trans_floor_ms=tfloor_ms,
+                        trans_frac=tfloor_ms / kernel_ms, floor_source=fsrc,
                         note='active pairs = ordered (i, j) with l_i > l_j (about 20 % of n^2 for 5 uniform grades); '
-                             'valu_frac = issue floor of the two LambdaRank sweeps over the ACTIVE pairs only / kernel '
-                             'time (rank counting, grade ordering and range rounding are overhead against it)')
+                             'valu_frac = instruction-mix issue floor of the two LambdaRank sweeps (one "hi" evaluation: '
+                             'rcp + log, and one "lo" evaluation: rcp, per ACTIVE pair) / kernel time -- the rank count, '
+                             'the grade order, padded / idle lanes of the 32-row passes and everything that is not '
+                             'sweep issue are overhead against it; trans_frac = the three transcendentals per pair alone')
         else:
             roof['note'] = 'O(L) / sort kernel: HBM-bound by design; the batch (%.1f MB) fits the 256 MB Infinity ' \
                            'Cache under graph replay, so achieved GB/s is a cache-resident rate' % (algo_bytes / 1e6)
@@ -660,12 +735,22 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
                             '(tests/test_gpu_parity.py)')
     if is_e2e:
         tflops = e2e_flops_per_list(name, L) * B / (ms_per_step * 1e-3) / 1e12
+        k_tflops = info['kernel_flops'] / (kernel_ms * 1e-3) / 1e12
         result['roofline'] = {
-            'bound': 'mfma', 'achieved': tflops, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': tflops / MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(name, B, L),
-            'traffic_source': traffic_source(name, B, L), 'kernel': info['kernel_name'],
-            'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / step time, per GPU; the [M,512] layers '
-                    'are HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
+            'bound': 'mfma', 'achieved': k_tflops, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': k_tflops / MFMA_PEAK_TFLOPS, 'traffic': measured_traffic(name, B, L),
+            'traffic_source': traffic_source(name, B, L), 'kernel': info['kernel_name'], 'kernel_ms': kernel_ms,
+            'algorithmic_flops_per_launch': info['kernel_flops'], 'algorithmic_bytes_per_launch': info['kernel_bytes'],
+            'kernel_hbm_gbs': info['kernel_bytes'] / (kernel_ms * 1e-3) / 1e9,
+            'kernel_hbm_frac': info['kernel_bytes'] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            'step': {'achieved': tflops, 'unit': 'TFLOP/s', 'frac': tflops / MFMA_PEAK_TFLOPS,
+                     'note': 'algorithmic scorer flops (fwd+bwd = 6 x MACs) / WHOLE step time, per GPU'},
+            'note': 'achieved / frac = the dominant kernel (HIP events on graph-replayed launches of that GEMM alone); '
+                    'a [M,512] layer moves one read + one write of an [M,512] bf16 matrix per 2*M*512*512 flops = '
+                    '256 flop/B, below the machine balance: HBM-bound above ~55 % MFMA utilisation (DESIGN.md 4.3)'}
+        if e_drop0 is not None:
+            result['dropout_0'] = {'ms_per_step': 1e3 * e_drop0 / steps, 'value': B * world * steps / e_drop0, 'unit': 'lists/s',
+                                   'note': 'same workload with dropout=0.0 (no keep-mask hash in the GEMM prologues)'}
         result['all_reduce'] = {'ms': all_reduce_ms, 'bytes': info['all_reduce_bytes'], 'params': info['params'],
                                 'frac_of_step': (all_reduce_ms / ms_per_step) if ms_per_step else None,
                                 'compute_ms': ms_per_step - all_reduce_ms,
@@ -698,7 +783,12 @@ def main(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
                     help='launch eagerly instead of replaying the step from hipGraphs')
-    ap.add_argument('--dropout', type=float, default=0.0, help='e2e workloads: Dropout rate of the scorer tower')
+    ap.add_argument('--dropout', type=float, default=None,
+                    help='e2e workloads: Dropout rate of the scorer tower (default: the reference default 0.5 -- '
+                         'keras/layers.py:32, examples/tf_ranking_libsvm.py:86 -- with the dropout-free step reported beside it)')
+    ap.add_argument('--busy-seconds', type=float, default=2.5,
+                    help='after the timed steps of the main workload, keep replaying the step for this long (not counted): '
+                         'makes the GPU phase visible to a utilisation sampler; 0 to disable')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
     ap.add_argument('--plumbing-check', action='store_true',

@@ -16,8 +16,8 @@
  *     (utils.py:78-81);
  *   - work is enqueued on `stream` (a hipStream_t passed as void*); the call
  *     never synchronises and is re-entrant;
- *   - return 0 = ok, <0 = invalid argument (TFR_EINVAL -1, TFR_ETOOLARGE -2:
- *     L > 8192), >0 = hipError_t from the launch.
+ *   - return 0 = ok, <0 = invalid argument (TFR_EINVAL -1, TFR_ETOOLARGE -2: list_size beyond the entry point's
+ *     TFR_MAX_LIST_SIZE* limit below), >0 = hipError_t from the launch.
  *   - tie rule (the reference shuffles ties at random, utils.py:100-112):
  *     descending score, equal scores by `tiebreak` then by index, invalid last.
  */
@@ -31,6 +31,15 @@ extern "C" {
 #endif
 
 #define TFR_MAX_TOPN 8
+
+/* List-size limits (TFR_ETOOLARGE beyond).  These macros are what the kernels' launchers test; every "list_size <= N"
+ * statement in this header is checked against them by tests/test_host_logic.py. */
+#define TFR_MAX_LIST_SIZE 8192              /* ApproxNDCG / ApproxMRR, pairwise losses, softmax, Gumbel sampler, sort / ranks,
+                                               list order, group indices: workgroup kernels beyond the wave-per-list range */
+#define TFR_MAX_LIST_SIZE_METRIC 4096       /* rank / diversity metrics: keys and values in LDS, 25-32 B per item */
+#define TFR_MAX_LIST_SIZE_LISTWISE 4096     /* ListMLE, UniqueSoftmax, Circle: LDS block sort + scans, 24-36 B per item */
+#define TFR_MAX_LIST_SIZE_NEURAL_SORT 2048  /* NeuralSort losses: one wavefront per list, 40 / 60 B of LDS per item */
+#define TFR_MAX_LIST_SIZE_FLATTEN 4096      /* tfr_flatten_row_index: 16 B of LDS per item, four list-waves per workgroup */
 
 /* gain_kind */
 #define TFR_GAIN_IDENTITY 0   /* keras/utils.py:51  identity                  */
@@ -86,7 +95,7 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
  *   TFR_METRIC_HITS (:462-506)       TFR_METRIC_RECALL (:154-177, 539-561)   TFR_METRIC_PRECISION (:180-207, 564-586)
  *   TFR_METRIC_MAP (:589-628)        TFR_METRIC_ARP (:509-536; stats_out[:, 2] = its per-list weight)
  * stats_out [B, 3] = (sum w, sum rel, sum w*rel) with rel = gain (DCG), label (ARP) or 1{label >= 1}.
- * list_size <= 1024 for the kinds other than NDCG / MRR (TFR_ETOOLARGE otherwise). */
+ * list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC) for every kind: one wavefront per list up to 512 items, one workgroup beyond. */
 #define TFR_METRIC_NDCG 0
 #define TFR_METRIC_MRR 1
 #define TFR_METRIC_DCG 2
@@ -109,7 +118,7 @@ int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions,
  *                        discount[p] = rank_discount_fn(p + 1); the caller divides by the per-list weight
  *   TFR_DIV_PRECISION_IA PrecisionIAMetric: the metric itself
  * mask [B, L] or NULL (then an item is valid when any of its subtopic labels is >= 0); stats_out as above
- * with relevance = any_s [y >= 1].  L <= 1024. */
+ * with relevance = any_s [y >= 1].  list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC). */
 #define TFR_DIV_ALPHA_DCG 0
 #define TFR_DIV_PRECISION_IA 1
 int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
@@ -162,7 +171,7 @@ int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* 
  *   pos_weight   nullable [L]: rank_discount_fn(p + 1) of a ListMLELambdaWeight (host table)
  *   loss_out     [B] negative log likelihood per list (the list weight is 1)
  *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
- * list_size <= 4096 (one wavefront per list up to 1024, one workgroup beyond; TFR_ETOOLARGE otherwise); ties between
+ * list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE: one wavefront per list up to 1024, one workgroup beyond); ties between
  * equal labels keep index order. */
 int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                      const float* pos_weight, const float* list_scale, int B, int L,
@@ -170,7 +179,7 @@ int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* ma
 
 /* losses_impl.UniqueSoftmaxLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:1250-1281): loss_b = sum_i (2^l_i - 1) (log(e^s_i + sum_{j: l_j < l_i} e^s_j) - s_i).
- * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 4096). */
+ * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE)). */
 int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
                            const float* list_scale, int B, int L, float temperature,
                            float* loss_out, float* dlogits_out, void* stream);
@@ -178,7 +187,7 @@ int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8
 /* NeuralSort losses (losses_impl.py:1635-1673 NeuralSortCrossEntropyLoss, :1676-1713 NeuralSortNDCGLoss,
  * :1716-1801 neural_sort): per-list loss [B] and d loss / d logits [B, L] (x list_scale[b] when given),
  * one wavefront per list, no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG
- * kind only).  L <= 2048 (TFR_ETOOLARGE beyond: 40 / 60 B of LDS per item).  The Gumbel variants are this kernel on the sampler's
+ * kind only).  list_size <= 2048 (TFR_MAX_LIST_SIZE_NEURAL_SORT: 40 / 60 B of LDS per item).  The Gumbel variants are this kernel on the sampler's
  * expanded batch. */
 #define TFR_NEURAL_SORT_NDCG 0
 #define TFR_NEURAL_SORT_CE 1
@@ -190,7 +199,7 @@ int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels,
  * clipped to [0, 1]; weight[b] = 1, or NaN for a list without any preference pair (the reference's 0 / 0);
  * dlogits = d loss / d logits (x list_scale[b]).  clip != 0 applies get_logits' clip_by_value(0, 1) in
  * the kernel (compute()); compute_per_list / compute_unreduced_loss hand the scores over as they are.
- * L <= 4096 (one wavefront per list up to 1024, one workgroup beyond). */
+ * list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE: one wavefront per list up to 1024, one workgroup beyond). */
 int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                         const float* list_scale, int B, int L, float gamma, float margin, int clip,
                         float* loss_out, float* weight_out, float* dlogits_out, void* stream);
@@ -234,7 +243,9 @@ int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const ui
  *   list_loss_out  nullable [B]: sum over the rows of a list of row_loss (what every scalar reduction consumes;
  *                  with row_loss_out = NULL nothing [B, L]-sized is written for the loss).
  * PairwiseLogisticLoss with a DCGLambdaWeight (smooth_fraction 0, no topn, identity / 2^l - 1 gain, no mask) and
- * list_size <= 256 runs the LambdaRank fast path: items re-homed by grade, only the pairs with l_i > l_j visited. */
+ * list_size <= 256 runs the LambdaRank fast path: items re-homed by grade, only the pairs with l_i > l_j visited (from 512
+ * lists: the group kernel of csrc/lambdarank_group.h -- several lists per workgroup, shared pair sweeps); any
+ * list_size <= 8192 (TFR_MAX_LIST_SIZE) through the general wave / workgroup kernels. */
 int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                           const float* item_weights, const float* list_weights,
                           int lambda_kind, int topn, float smooth_fraction, int normalized,
@@ -312,7 +323,7 @@ int tfr_tower_multi_add(float* const* dst, const float* const* src, const int* n
 
 /* FlattenList's gather index (keras/layers.py:122-183; utils.py:203-230, :308-356 with shuffle=False) in one
  * launch: rows[b * L + p] = b * L + v_b[p mod max(n_b, 1)], v_b = valid positions of list b in index order
- * (0 when the list has none).  mask uint8 [B, L]; rows int32 [B * L]; L <= 4096. */
+ * (0 when the list has none).  mask uint8 [B, L]; rows int32 [B * L]; list_size <= 4096 (TFR_MAX_LIST_SIZE_FLATTEN). */
 int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream);
 
 /* The same with a row gather: out[m] = cast(x[row_index[m]]) (row_index NULL = identity).  Fuses FlattenList's

@@ -52,6 +52,8 @@ def _u8(t, name):
     if t is None:
         return None
     require_device(t, name)
+    if t.dtype == torch.bool:                       # same storage (one byte, 0 / 1): no conversion launch
+        return t.contiguous().view(torch.uint8)
     if t.dtype != torch.uint8:
         t = t.to(torch.uint8)
     return t.contiguous()

@@ -27,18 +27,32 @@ def _dp(d):
     return None if d is None else ctypes.byref(d)
 
 
+def dropout_field(d: 'Dropout'):
+    """(lge, threshold in field units, scale) the kernels derive from the struct (csrc/tower.hip to_drop): a hash word
+    serves 2^lge columns with 32 >> lge bits each -- the narrowest field (1, 2, 4 or 8 bits) that represents the rate
+    exactly; a rate that is not a multiple of 1 / 256 is rounded to one and the scale follows the rounded rate."""
+    t16 = min(int(d.threshold16), 65535)
+    for lge in (5, 4, 3, 2):
+        fb = 32 >> lge
+        if t16 & ((1 << (16 - fb)) - 1) == 0:
+            return lge, t16 >> (16 - fb), float(d.scale)
+    t8 = max(1, min(255, (t16 + 128) >> 8))
+    return 2, t8, 256.0 / (256.0 - t8)
+
+
 def dropout_mask(d: 'Dropout', M: int, K: int, device) -> torch.Tensor:
-    """The [M, K] keep-factor matrix the kernels apply (torch restatement of drop_hash; tests / debugging)."""
+    """The [M, K] keep-factor matrix the kernels apply (torch restatement of drop_run; tests / debugging)."""
+    lge, thr, scale = dropout_field(d)
+    fb = 32 >> lge
     m = torch.arange(M, device=device, dtype=torch.int64).unsqueeze(1)
-    kp = torch.arange((K + 1) // 2, device=device, dtype=torch.int64).unsqueeze(0)
+    c = torch.arange(K, device=device, dtype=torch.int64).unsqueeze(0)
     mask32 = 0xffffffff
-    h = (m * 0x9E3779B1 + kp * 0x85EBCA77 + int(d.seed)) & mask32
+    h = (m * 0x9E3779B1 + (c >> lge) * 0x85EBCA77 + int(d.seed)) & mask32
     h = h ^ (h >> 16); h = (h * 0x7feb352d) & mask32
     h = h ^ (h >> 15); h = (h * 0x846ca68b) & mask32
     h = h ^ (h >> 16)
-    lo = ((h & 0xffff) >= int(d.threshold16)); hi = ((h >> 16) >= int(d.threshold16))
-    keep = torch.stack([lo, hi], dim=2).reshape(M, -1)[:, :K]
-    return keep.to(torch.float32) * float(d.scale)
+    field = (h >> ((c & ((1 << lge) - 1)) * fb)) & ((1 << fb) - 1)
+    return (field >= thr).to(torch.float32) * scale
 
 
 PRO_NONE, PRO_AFFINE, PRO_AFFINE_RELU, PRO_AFFINE_ACT = 0, 1, 2, 3
@@ -354,4 +368,4 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
     return out
 
 
-_ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask'))
+_ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask', 'dropout_field'))

@@ -10,7 +10,7 @@
 
 #define TFR_WAVE 64
 #define TFR_MAX_THREADS 1024
-#define TFR_MAX_LIST 8192
+#define TFR_MAX_LIST 8192      /* = TFR_MAX_LIST_SIZE of include/tfr_hip.h (checked by tests/test_host_logic.py) */
 
 #define TFR_OK 0
 #define TFR_EINVAL (-1)

@@ -688,7 +688,7 @@ extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const 
                                 const float* pos_weight, const float* list_scale, int B, int L,
                                 float temperature, float* loss_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > 4096) return TFR_ETOOLARGE;            // 24 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 24 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
@@ -710,7 +710,7 @@ extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, 
                                       const float* list_scale, int B, int L, float temperature,
                                       float* loss_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > 4096) return TFR_ETOOLARGE;            // 36 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 36 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
@@ -732,7 +732,7 @@ extern "C" int tfr_circle_loss_f32(const float* logits, const float* labels, con
                                    const float* list_scale, int B, int L, float gamma, float margin, int clip,
                                    float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0) return TFR_EINVAL;
-  if (L > 4096) return TFR_ETOOLARGE;            // 36 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 36 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {

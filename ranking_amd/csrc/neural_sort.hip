@@ -323,7 +323,7 @@ extern "C" int tfr_neural_sort_loss_f32(int kind, const float* logits, const flo
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind != TFR_NEURAL_SORT_NDCG && kind != TFR_NEURAL_SORT_CE) return TFR_EINVAL;
   if (kind == TFR_NEURAL_SORT_NDCG && !inv_log1p) return TFR_EINVAL;
-  if (L > 2048) return TFR_ETOOLARGE;            // 40 / 60 B of LDS per item, one wavefront per list (32 items per lane)
+  if (L > TFR_MAX_LIST_SIZE_NEURAL_SORT) return TFR_ETOOLARGE;            // 40 / 60 B of LDS per item, one wavefront per list (32 items per lane)
   if (B == 0) return TFR_OK;
   static const int max_runs = env_int_ns("TFR_APPROX_MAX_RUNS", 8);
   hipStream_t st = (hipStream_t)stream;

@@ -64,20 +64,44 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 // Dropout (keras/layers.py:72-73: tf.keras.layers.Dropout after every hidden activation).  The
-// keep mask is a counter-based hash of (layer seed, row, column pair) -- the same function in the
-// forward prologues and in the backward kernels, so nothing is stored.  threshold16 = rate * 65536;
-// an element is kept iff its 16 hash bits >= threshold16 and is then scaled by 1 / (1 - rate).
-struct Drop { uint32_t seed; uint32_t thr; float scale; };
-__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t m, uint32_t kpair) {
-  uint32_t h = m * 0x9E3779B1u + kpair * 0x85EBCA77u + seed;
+// keep mask is a counter-based hash of (layer seed, row, column word) -- the same function in the
+// forward prologues and in the backward kernels, so nothing is stored.  A 32-bit hash word serves 2^lge
+// consecutive columns with a field of 32 >> lge bits each: an element is kept iff its field >= thr (the rate in
+// field units) and is then scaled by 1 / (1 - rate).  Round 3: the field is as narrow as the rate allows EXACTLY,
+// at most 8 bits (rate 0.5 -- the reference default -- needs ONE bit: a word serves 32 columns; 0.25 two bits; a
+// rate that is not a multiple of 1 / 256 is rounded to one, the scale following the rounded rate so that the mask
+// stays unbiased).  Round 2 hashed once per column PAIR (16-bit fields): the two 32-bit multiplies of the hash are
+// quarter-rate instructions and sat in every GEMM prologue -- the hidden-layer forward GEMM of BASELINE config 5
+// took 41.8 us with Dropout against 27.7 us without.  The callers walk aligned runs of 4 / 8 columns: one hash per
+// run (two for an 8-run at 8-bit fields).
+struct Drop { uint32_t seed; uint32_t thr; float scale; uint32_t lge; };     // lge = 2 .. 5
+__device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t m, uint32_t word) {
+  uint32_t h = m * 0x9E3779B1u + word * 0x85EBCA77u + seed;
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
 }
-// keep factors of columns (2 * kpair, 2 * kpair + 1) of row m
+// keep factors of the N (4 or 8) consecutive columns c .. c + N - 1 of row m, c a multiple of N
+template <int N>
+__device__ __forceinline__ void drop_run(const Drop d, uint32_t m, uint32_t c, float (&f)[N]) {
+  const uint32_t fb = 32u >> d.lge;                          // (wave-uniform: scalar registers)
+  const uint32_t off = (c & ((1u << d.lge) - 1u)) << (5u - d.lge);
+  uint32_t x0 = drop_hash(d.seed, m, c >> d.lge) >> off;
+  uint32_t x1 = x0 >> (4u * fb);
+  if (N == 8 && d.lge == 2u) x1 = drop_hash(d.seed, m, (c + 4u) >> 2);     // 8-bit fields: four columns per word
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    const uint32_t fld = __builtin_amdgcn_ubfe(j < 4 ? x0 : x1, (uint32_t)(j & 3) * fb, fb);
+    f[j] = (fld >= d.thr) ? d.scale : 0.0f;
+  }
+}
+// keep factors of columns (2 * kpair, 2 * kpair + 1) of row m (the non-persistent kernels' chunk loops)
 __device__ __forceinline__ void drop_pair(const Drop d, uint32_t m, uint32_t kpair, float& f0, float& f1) {
-  const uint32_t h = drop_hash(d.seed, m, kpair);
-  f0 = ((h & 0xffffu) >= d.thr) ? d.scale : 0.0f;
-  f1 = ((h >> 16) >= d.thr) ? d.scale : 0.0f;
+  const uint32_t c0 = 2u * kpair;
+  const uint32_t fb = 32u >> d.lge;
+  const uint32_t h = drop_hash(d.seed, m, c0 >> d.lge);
+  const uint32_t off = (c0 & ((1u << d.lge) - 1u)) << (5u - d.lge);
+  f0 = (__builtin_amdgcn_ubfe(h, off, fb) >= d.thr) ? d.scale : 0.0f;
+  f1 = (__builtin_amdgcn_ubfe(h, off + fb, fb) >= d.thr) ? d.scale : 0.0f;
 }
 
 // byte offset of 16-byte chunk c (0..7) of row r inside a swizzled [128][64] bf16 tile
@@ -132,21 +156,19 @@ __device__ __forceinline__ float act_grad(int act, float y) {
 }
 
 template <int PRO>
-__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f},
+__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f, 2},
                                                  uint32_t m = 0, uint32_t k = 0, int act = 0) {
   if (PRO == PRO_NONE) return v;
   uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float kf[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+  if (drop.thr) drop_run<8>(drop, m, k, kf);            // wave-uniform
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     float a = __builtin_fmaf(bf16_lo(w[i]), sc[2 * i], sh[2 * i]);
     float b = __builtin_fmaf(bf16_hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
     if (PRO == PRO_AFFINE_RELU) { a = fmaxf(a, 0.f); b = fmaxf(b, 0.f); }
     if (PRO == PRO_AFFINE_ACT) { a = act_fwd(act, a); b = act_fwd(act, b); }
-    if (drop.thr) {                                     // wave-uniform
-      float f0, f1;
-      drop_pair(drop, m, (k >> 1) + i, f0, f1);
-      a *= f0; b *= f1;
-    }
+    if (drop.thr) { a *= kf[2 * i]; b *= kf[2 * i + 1]; }
     w[i] = pack_bf16(a, b);
   }
   return make_uint4(w[0], w[1], w[2], w[3]);
@@ -412,8 +434,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
         const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
         float kf[4] = {1.f, 1.f, 1.f, 1.f};
         if (g.epi_drop.thr) {                           // d a / d relu = keep / (1 - rate): same hash as the forward
-          drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
-          drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+          drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -678,8 +699,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
           const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
           float kf[4] = {1.f, 1.f, 1.f, 1.f};
           if (g.epi_drop.thr) {
-            drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1), kf[0], kf[1]);
-            drop_pair(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)((nb + fn * 16 + fq * 4) >> 1) + 1, kf[2], kf[3]);
+            drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -789,17 +809,15 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
   const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
   const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
   uint32_t o[4];
+  float kf[8];
+  if (DROP) drop_run<8>(d, m, k, kf);                // one hash for the fragment's 8 columns when the rate allows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
     const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
     x = x * s + h;
     if (PRO == PRO_AFFINE_ACT) { x[0] = act_fwd(act, x[0]); x[1] = act_fwd(act, x[1]); }
-    if (DROP) {                                     // relu(y) * f == relu(y * f) for f >= 0
-      float f0, f1;
-      drop_pair(d, m, (k >> 1) + i, f0, f1);
-      x = x * f32x2{f0, f1};
-    }
+    if (DROP) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
     uint32_t pk = pack_bf16(x[0], x[1]);
     if (PRO == PRO_AFFINE_RELU)
       pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
@@ -1035,9 +1053,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
             const f32x4 y = z * pb[fn] + pe[fn];
             if (DROP) {
               float kf[4];
-              const uint32_t row = (uint32_t)(g.row0 + mb + fm * 16 + fr), cp = (uint32_t)((n0 + nl + fn * 16 + fq * 4) >> 1);
-              drop_pair(g.epi_drop, row, cp, kf[0], kf[1]);
-              drop_pair(g.epi_drop, row, cp + 1, kf[2], kf[3]);
+              drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + fm * 16 + fr), (uint32_t)(n0 + nl + fn * 16 + fq * 4), kf);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= kf[r];
             }
@@ -1362,12 +1378,10 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
         a[e] = t;
       }
       if (PRO != PRO_NONE && drop.thr) {
+        float kf[8];
+        drop_run<8>(drop, (uint32_t)m, (uint32_t)k, kf);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float f0, f1;
-          drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), f0, f1);
-          a[2 * i] *= f0; a[2 * i + 1] *= f1;
-        }
+        for (int e = 0; e < 8; ++e) a[e] *= kf[e];
       }
       for (int o = 0; o < O; ++o) {
 #pragma unroll
@@ -1441,12 +1455,8 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     }
     auto row = [&](long m, const uint4 v, const float (&dl)[OT]) {
       const uint32_t u[4] = {v.x, v.y, v.z, v.w};
-      float out[8], kf[8];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        kf[2 * i] = 1.f; kf[2 * i + 1] = 1.f;
-        if (PRO != PRO_NONE && drop.thr) drop_pair(drop, (uint32_t)m, (uint32_t)((k >> 1) + i), kf[2 * i], kf[2 * i + 1]);
-      }
+      float out[8], kf[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+      if (PRO != PRO_NONE && drop.thr) drop_run<8>(drop, (uint32_t)m, (uint32_t)k, kf);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float zz = (e & 1) ? bf16_hi(u[e >> 1]) : bf16_lo(u[e >> 1]);
@@ -1869,8 +1879,19 @@ static inline bool split_mode(int arg, int& mode, int& act) {
 }
 
 Drop to_drop(const tfr_tower_dropout* d) {
-  if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f};
-  return Drop{d->seed, d->threshold16 > 65535u ? 65535u : d->threshold16, d->scale};
+  if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f, 2u};
+  const uint32_t t16 = d->threshold16 > 65535u ? 65535u : d->threshold16;
+  // the narrowest field that represents the rate exactly: lge = 5 (1 bit) ... 2 (8 bits); the caller's scale is the
+  // exact 1 / (1 - rate) in those cases
+  for (uint32_t lge = 5; lge >= 2; --lge) {
+    const uint32_t fb = 32u >> lge;
+    if ((t16 & ((1u << (16u - fb)) - 1u)) == 0u) return Drop{d->seed, t16 >> (16u - fb), d->scale, lge};
+  }
+  // otherwise the rate is rounded to a multiple of 1 / 256 and the scale follows the rounded rate (unbiased mask)
+  uint32_t t8 = (t16 + 128u) >> 8;
+  if (t8 < 1u) t8 = 1u;
+  if (t8 > 255u) t8 = 255u;
+  return Drop{d->seed, t8, 256.0f / (256.0f - (float)t8), 2u};
 }
 
 int grid_for(long work_items, int block) {
@@ -2008,7 +2029,7 @@ extern "C" int tfr_tower_multi_add(float* const* dst, const float* const* src, c
 // rows[b * L + p] for tfr_tower_cast_gather_f32_bf16 (keras/layers.py:122-183 FlattenList, utils.py:308-356).
 extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream) {
   if (!mask || !rows || B < 0 || L <= 0 || (long)B * L > 0x7fffffffL) return TFR_EINVAL;
-  if ((size_t)L * 16 > 64 * 1024) return TFR_ETOOLARGE;
+  if (L > TFR_MAX_LIST_SIZE_FLATTEN) return TFR_ETOOLARGE;   // 16 B of LDS per item x 4 list-waves <= 64 KiB
   if (B == 0) return TFR_OK;
   hipLaunchKernelGGL(flatten_row_index_kernel, dim3((B + 3) / 4), dim3(256), (size_t)L * 16, (hipStream_t)stream,
                      mask, B, L, rows);

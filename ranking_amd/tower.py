@@ -79,22 +79,24 @@ class _TowerFn(torch.autograd.Function):
         betas = params[3 * n_h:4 * n_h] if use_bn else [None] * n_h
         w_out, b_out = params[-2], params[-1]
         dev = x.device
-        if ctx.needs_input_grad[0]:
-            # the layer-0 dgrad (d loss / d features) is not implemented: anything upstream of the tower
-            # (an embedding, a projection) would silently train on no gradient -- refuse instead
-            raise NotImplementedError('FusedTower does not propagate a gradient to its input; detach the features '
-                                      'or use the torch-op tower (compute_dtype=torch.float32) below trainable layers')
+        # d loss / d features (the tower under trainable layers, keras/model.py:755-817): the layer-0 dgrad in backward
+        ctx.want_dx = bool(ctx.needs_input_grad[0])
+        ctx.x_shape, ctx.x_dtype, ctx.row_index = tuple(x.shape), x.dtype, row_index
         in_bn = None                                       # (scale, shift) of create_tower's input BatchNormalization
+        ctx.in_stats = None
         if tower.input_batch_norm:
             g_in, b_in = params[-4], params[-3]
             if training:                                   # batch statistics of the raw fp32 features
                 part, rows = T.input_stats(x, row_index=row_index)
-                in_sc, in_sh, _, _ = T.bn_finalize(part, rows, g_in, b_in, _BN_EPS, tower.momentum,
-                                                   tower.moving_mean_in, tower.moving_var_in)
+                in_sc, in_sh, in_mean, in_rstd = T.bn_finalize(part, rows, g_in, b_in, _BN_EPS, tower.momentum,
+                                                               tower.moving_mean_in, tower.moving_var_in)
             else:
-                in_sc = g_in.detach() * torch.rsqrt(tower.moving_var_in + _BN_EPS)
-                in_sh = b_in.detach() - tower.moving_mean_in * in_sc
+                in_rstd = torch.rsqrt(tower.moving_var_in + _BN_EPS)
+                in_mean = tower.moving_mean_in
+                in_sc = g_in.detach() * in_rstd
+                in_sh = b_in.detach() - in_mean * in_sc
             in_bn = (in_sc, in_sh)
+            ctx.in_stats = (in_mean, in_rstd, x)           # backward: xhat from the fp32 features, not from the bf16 copy
             x0 = T.cast_rows(x, scale=in_sc, shift=in_sh, row_index=row_index, width=T.pad_k(x.shape[1]))
         elif row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
             x0 = T.cast_rows(x, row_index=row_index, width=T.pad_k(x.shape[1]))
@@ -188,7 +190,9 @@ class _TowerFn(torch.autograd.Function):
         dw_out = sums[2:].contiguous()
         db_out = dlogits.sum(dim=0)
         cc = sums                                          # rows 0 / 1: sum dy, sum dy * zhat of the layer below
-        db_zero = torch.zeros(sum(z.shape[1] for z in zs), device=dev).split([z.shape[1] for z in zs]) if use_bn else None
+        # (a bias below BatchNorm has no gradient: zeros for autograd; the in-place mode skips them -- no fill launch)
+        db_zero = (torch.zeros(sum(z.shape[1] for z in zs), device=dev).split([z.shape[1] for z in zs])
+                   if (use_bn and not direct) else [None] * n_h)
         for l in range(n_h - 1, -1, -1):
             n_out = zs[l].shape[1]
             pro_l, sc_l, sh_l, mean_l, rstd_l, _ = coefs[l]
@@ -233,30 +237,47 @@ class _TowerFn(torch.autograd.Function):
         grads = list(dW) + list(db)
         if use_bn:
             grads += list(dgam) + list(dbet)
-        if tower.input_batch_norm:
-            # d gamma_in = sum_m dxbn * xhat, d beta_in = sum_m dxbn with dxbn = dz_1 . W_1 (the layer-0 dgrad, run for
-            # these two vectors only: the features themselves take no gradient); xhat = (x0 - beta_in) / gamma_in is
-            # recovered from the staged bf16 input by the epilogue's (Zp - e_mean) * e_rstd
-            g_in, b_in = params[-4], params[-3]
+        dx = None
+        if tower.input_batch_norm or ctx.want_dx:
+            # layer-0 dgrad dxin = dz_0 . W_0 ([M, F], bf16 out of the MFMA kernel like every other dgrad)
             F = Ws[0].shape[1]
             k0 = x0.shape[1]
             wt0 = T.cast_weight(Ws[0], transpose=True, pitch=T.pad8(Ws[0].shape[0]))      # [F, pad8(N)]
             if wt0.shape[0] != k0:                                                       # rows up to the staged width
                 wt0 = torch.cat([wt0, torch.zeros((k0 - wt0.shape[0], wt0.shape[1]), dtype=wt0.dtype, device=dev)])
-            e_mean = torch.zeros(k0, device=dev); e_mean[:F] = b_in.detach()
-            e_rstd = torch.ones(k0, device=dev); e_rstd[:F] = 1.0 / g_in.detach()
-            _, partial = T.gemm(dz0, wt0, k0, Ws[0].shape[0], prologue=T.PRO_NONE, epilogue=T.EPI_RELU_BWD, Zp=x0,
-                                e_scale=torch.zeros(k0, device=dev), e_shift=torch.ones(k0, device=dev),
-                                e_mean=e_mean, e_rstd=e_rstd)
-            cin = T.reduce_partials(partial)
-            grads += [cin[1][:F].contiguous(), cin[0][:F].contiguous()]
+            dxin, _ = T.gemm(dz0, wt0, k0, Ws[0].shape[0], prologue=T.PRO_NONE, epilogue=T.EPI_PLAIN)
+            dxin = dxin[:, :F].to(torch.float32)
+            if tower.input_batch_norm:
+                # BatchNormalization backward on the raw features: xhat comes from the saved batch mean / rstd and the
+                # fp32 features (round 2 recovered it from the bf16-staged input as (x0 - beta) / gamma: inf / NaN for
+                # gamma = 0 and bf16 noise amplified when |beta| >> |gamma| -- ADVICE r2)
+                g_in = params[-4]
+                in_mean, in_rstd, x_raw = ctx.in_stats
+                xr = x_raw if ctx.row_index is None else x_raw.index_select(0, ctx.row_index.long())
+                xhat = (xr.to(torch.float32) - in_mean) * in_rstd
+                d_gamma_in = (dxin * xhat).sum(dim=0)
+                d_beta_in = dxin.sum(dim=0)
+                grads += [d_gamma_in, d_beta_in]
+                if ctx.want_dx:
+                    gsc = g_in.detach() * in_rstd
+                    if ctx.training:                       # through the batch statistics
+                        dx = gsc * (dxin - d_beta_in / M - xhat * (d_gamma_in / M))
+                    else:
+                        dx = gsc * dxin
+            elif ctx.want_dx:
+                dx = dxin
+            if dx is not None and ctx.row_index is not None:
+                # FlattenList's circular padding scores an item several times: the adjoint of the gather adds them up
+                full = torch.zeros((ctx.x_shape[0], F), dtype=torch.float32, device=dev)
+                dx = full.index_add_(0, ctx.row_index.long(), dx)
+            if dx is not None and dx.shape[1] != ctx.x_shape[1]:          # the caller passed a k-step padded input
+                dx = torch.nn.functional.pad(dx, (0, ctx.x_shape[1] - dx.shape[1]))
         grads += [dw_out, db_out]
         if direct:
-            todo = [(p.grad, g) for p, g in zip(params, grads)
-                    if g is not None and not (use_bn and any(g is z for z in db_zero))]   # zero bias grads: no-op
+            todo = [(p.grad, g) for p, g in zip(params, grads) if g is not None]         # (zero bias grads are None here)
             T.multi_add_([a for a, _ in todo], [g for _, g in todo])
             grads = [None] * len(grads)
-        return (None, None, None, None) + tuple(grads)
+        return (None if dx is None else dx.to(ctx.x_dtype), None, None, None) + tuple(grads)
 
 
 class FusedTower(nn.Module):

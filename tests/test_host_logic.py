@@ -272,3 +272,50 @@ def test_every_environment_switch_is_documented():
     section = design[design.index('## 8. Developer switches'):]
     missing = sorted(v for v in used if v not in section)
     assert not missing, missing
+
+
+def test_isa_floor_json_describes_the_current_kernels():
+    """bench.py's `valu_frac` / `trans_frac` floors come from ranking_amd/csrc/isa_floor.json, derived from the compiled
+    sweep loops by tools/isa_floor.py: its fingerprint covers every kernel source, the tool and the issue costs, so a
+    changed loop with a stale floor fails here (run `python tools/isa_floor.py`, or __graft_entry__.build())."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import isa_floor
+    with open(isa_floor.OUT) as f:
+        d = json.load(f)
+    assert d['fingerprint'] == isa_floor.fingerprint(), 'isa_floor.json is stale: python tools/isa_floor.py'
+    for kind in ('approx_ndcg', 'pairwise'):
+        assert 10.0 < d[kind]['trans_cycles_per_64_pairs'] < d[kind]['valu_cycles_per_64_pairs'] < 200.0
+        for part in d[kind]['parts'].values():
+            assert part['loop_body']['rcp'] >= 2 and part['loop_body']['lds'] >= 1
+
+
+def test_list_size_limits_in_the_header_are_the_ones_the_launchers_test():
+    """the public header said "L <= 1024" where the code took 4096.  The limits are macros of
+    include/tfr_hip.h now; every "list_size <= N" statement of the header must name a macro with that value, the
+    launchers must compare against the macros (no literal next to TFR_ETOOLARGE), and common.h's TFR_MAX_LIST must
+    equal TFR_MAX_LIST_SIZE."""
+    import re
+    hdr = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
+    macros = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define (TFR_MAX_LIST_SIZE\w*) (\d+)', hdr)}
+    assert set(macros) == {'TFR_MAX_LIST_SIZE', 'TFR_MAX_LIST_SIZE_METRIC', 'TFR_MAX_LIST_SIZE_LISTWISE',
+                           'TFR_MAX_LIST_SIZE_NEURAL_SORT', 'TFR_MAX_LIST_SIZE_FLATTEN'}, macros
+    # statements: "list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC" -- the number and the macro must agree
+    stated = re.findall(r'list_size <= (\d+) \((TFR_MAX_LIST_SIZE\w*)', hdr)
+    assert len(stated) >= 6, stated
+    for n, name in stated:
+        assert macros[name] == int(n), (n, name, macros[name])
+    # no other "L <= <number >= 1000>" / "list_size <= <number>" claims without a macro (256 = the fast-path range, not a limit)
+    loose = [m.group(0) for m in re.finditer(r'(?:\bL|list_size) <= (\d{4,})(?! \(TFR_MAX_LIST_SIZE)', hdr)]
+    assert not loose, loose
+    csrc = os.path.join(ROOT, 'ranking_amd', 'csrc')
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith(('.hip', '.h', '.cpp')):
+            continue
+        for ln in open(os.path.join(csrc, f)):
+            m = re.search(r'if \(L > (\w+)\) return TFR_ETOOLARGE', ln)
+            if m:
+                assert m.group(1) in macros or m.group(1) == 'TFR_MAX_LIST', (f, ln.strip())
+    common = open(os.path.join(csrc, 'common.h')).read()
+    assert int(re.search(r'#define TFR_MAX_LIST (\d+)', common).group(1)) == macros['TFR_MAX_LIST_SIZE']

@@ -98,6 +98,12 @@ def test_ndcg():  # losses_impl_test.py:182-196
     ranks = torch.tensor([[1, 2, 3, 4], [1, 3, 4, 2], [1, 2, 3, 4]])
     close(R.ndcg(labels), [[0.679685], [0.95176], [0.]])
     close(R.ndcg(labels, ranks), [[0.679685], [1.], [0.]])
+    perm_mat = torch.tensor([[[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]],       # third assertion (:184-196):
+                             [[1, 0, 0, 0], [0, 0, 0, 1], [0, 1, 0, 0], [0, 0, 1, 0]],       # the branch NeuralSortNDCG
+                             [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]]], dtype=torch.float32)   # goes through
+    close(R.ndcg(labels, perm_mat=perm_mat), [[0.679685], [1.], [0.]])
+    with pytest.raises(ValueError):
+        R.ndcg(labels, ranks, perm_mat)
 
 
 def test_label_diff_lambda_weight():  # losses_impl_test.py:325-336
