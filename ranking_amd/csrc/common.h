@@ -277,33 +277,59 @@ __device__ __forceinline__ float wave_sum_u(float v) {
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // 0-based rank (score descending, ties by lower compact index) of the n compact scores XS[0 .. n) of ONE wavefront's
-// list, into RKS[0 .. n).  XS is padded with -inf up to a multiple of 4 (+4).  Compact item p = lane + 64 q counts the
-// scores above its own: one v_cmp + half a carry-add per compare, the columns are float4 LDS broadcasts.  Items with
-// tied scores end up with the SAME count: an occupancy table (OCC, n ints of scratch) finds them -- rare -- and only
-// those add the equal scores in front of them.  (The previous form evaluated the full tie rule in every compare and
-// walked the 4 x 64 register layout: 6 VALU per compare over 4 passes, as much issue time as the pair sweep.)
-__device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
+// list, for up to IPL row chunks of 64 compact items AT ONCE: every float4 of column scores is read once (not once per
+// chunk) and compared against the NC chunk registers, two column groups per trip with both loads issued first -- the
+// one-chunk-at-a-time form of round 2 waited one LDS round trip per 8 VALU instructions (17 % of the LambdaRank kernel).
+// Items with tied scores end up with the SAME count: an occupancy table (OCC, n ints of scratch) finds them -- rare --
+// and only those add the equal scores in front of them.  XS is padded with -inf up to a multiple of 4 (+4).
+template <int NC>
+__device__ __forceinline__ void wave_rank_chunks(const float* XS, int n, int lane, int* RKS, int* OCC) {
   const float4* X4 = reinterpret_cast<const float4*>(XS);
   const int n4 = (n + 3) >> 2;
+  float xi[NC];
+  int cnt[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) { const int p = lane + 64 * k; xi[k] = p < n ? XS[p] : INFINITY; cnt[k] = 0; }
+  int gq = 0;
+  for (; gq + 2 <= n4; gq += 2) {
+    const float4 xa = X4[gq], xb = X4[gq + 1];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
+      cnt[k] += (xb.x > xi[k]) ? 1 : 0; cnt[k] += (xb.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xb.z > xi[k]) ? 1 : 0; cnt[k] += (xb.w > xi[k]) ? 1 : 0;
+    }
+  }
+  if (gq < n4) {
+    const float4 xa = X4[gq];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
+      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int p = lane + 64 * k;
+    if (p < n) { RKS[p] = cnt[k]; atomicAdd(&OCC[cnt[k]], 1); }
+  }
+}
+
+__device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
   for (int p = lane; p < n; p += 64) OCC[p] = 0;
   WAVE_LDS_SYNC();
-  for (int q0 = 0; q0 < n; q0 += 64) {
-    const int p = q0 + lane;
-    const bool on = p < n;
-    const float xi = on ? XS[p] : INFINITY;
-    int cnt = 0;
-    for (int gq = 0; gq < n4; ++gq) {
-      const float4 xx = X4[gq];
-      cnt += (xx.x > xi) ? 1 : 0; cnt += (xx.y > xi) ? 1 : 0;
-      cnt += (xx.z > xi) ? 1 : 0; cnt += (xx.w > xi) ? 1 : 0;
-    }
-    if (on) { RKS[p] = cnt; atomicAdd(&OCC[cnt], 1); }
-  }
+  if (n <= 64) wave_rank_chunks<1>(XS, n, lane, RKS, OCC);
+  else if (n <= 128) wave_rank_chunks<2>(XS, n, lane, RKS, OCC);
+  else if (n <= 192) wave_rank_chunks<3>(XS, n, lane, RKS, OCC);
+  else if (n <= 256) wave_rank_chunks<4>(XS, n, lane, RKS, OCC);
+  else if (n <= 384) wave_rank_chunks<6>(XS, n, lane, RKS, OCC);      // (the NDCG counting kernel serves lists up to 512)
+  else wave_rank_chunks<8>(XS, n, lane, RKS, OCC);
   WAVE_LDS_SYNC();
   for (int q0 = 0; q0 < n; q0 += 64) {
     const int p = q0 + lane;
     const bool tie = p < n && OCC[RKS[p]] > 1;
-    if (__ballot(tie)) {                                     // wave-uniform: some item of this pass shares its score
+    if (__ballot(tie)) {                                     // wave-uniform: some item of this chunk shares its score
       if (tie) {
         const float xi = XS[p];
         int cnt = RKS[p];

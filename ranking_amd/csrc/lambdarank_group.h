@@ -278,68 +278,6 @@ __device__ __forceinline__ void grp_lo_sweep(const float2* recL, const float* WS
   accG2 = __builtin_fmaf(dG, ag, accG2);
 }
 
-// 0-based rank (score descending, ties by lower compact index) of the n compact scores XS[0 .. n) of ONE wavefront's
-// list, for up to IPL row chunks of 64 compact items AT ONCE: every float4 of column scores is read once (not once per
-// chunk) and compared against the NC chunk registers, two column groups per trip with both loads issued first -- the
-// one-chunk-at-a-time form (common.h) waited one LDS round trip per 8 VALU instructions and took 17 % of the kernel.
-// Ties as in wave_rank_by_count: items with equal scores get the same count, an occupancy table finds them (rare).
-template <int NC>
-__device__ __forceinline__ void grp_rank_chunks(const float* XS, int n, int lane, int* RKS, int* OCC) {
-  const float4* X4 = reinterpret_cast<const float4*>(XS);
-  const int n4 = (n + 3) >> 2;
-  float xi[NC];
-  int cnt[NC];
-#pragma unroll
-  for (int k = 0; k < NC; ++k) { const int p = lane + 64 * k; xi[k] = p < n ? XS[p] : INFINITY; cnt[k] = 0; }
-  int gq = 0;
-  for (; gq + 2 <= n4; gq += 2) {
-    const float4 xa = X4[gq], xb = X4[gq + 1];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
-      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
-      cnt[k] += (xb.x > xi[k]) ? 1 : 0; cnt[k] += (xb.y > xi[k]) ? 1 : 0;
-      cnt[k] += (xb.z > xi[k]) ? 1 : 0; cnt[k] += (xb.w > xi[k]) ? 1 : 0;
-    }
-  }
-  if (gq < n4) {
-    const float4 xa = X4[gq];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      cnt[k] += (xa.x > xi[k]) ? 1 : 0; cnt[k] += (xa.y > xi[k]) ? 1 : 0;
-      cnt[k] += (xa.z > xi[k]) ? 1 : 0; cnt[k] += (xa.w > xi[k]) ? 1 : 0;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NC; ++k) {
-    const int p = lane + 64 * k;
-    if (p < n) { RKS[p] = cnt[k]; atomicAdd(&OCC[cnt[k]], 1); }
-  }
-}
-
-__device__ __forceinline__ void grp_rank_by_count(const float* XS, int n, int lane, int* RKS, int* OCC) {
-  for (int p = lane; p < n; p += 64) OCC[p] = 0;
-  WAVE_LDS_SYNC();
-  if (n <= 64) grp_rank_chunks<1>(XS, n, lane, RKS, OCC);
-  else if (n <= 128) grp_rank_chunks<2>(XS, n, lane, RKS, OCC);
-  else if (n <= 192) grp_rank_chunks<3>(XS, n, lane, RKS, OCC);
-  else grp_rank_chunks<4>(XS, n, lane, RKS, OCC);
-  WAVE_LDS_SYNC();
-  for (int q0 = 0; q0 < n; q0 += 64) {
-    const int p = q0 + lane;
-    const bool tie = p < n && OCC[RKS[p]] > 1;
-    if (__ballot(tie)) {                                     // wave-uniform: some item of this chunk shares its score
-      if (tie) {
-        const float xi = XS[p];
-        int cnt = RKS[p];
-        for (int j = 0; j < p; ++j) cnt += (XS[j] == xi) ? 1 : 0;
-        RKS[p] = cnt;                                        // (other lanes read OCC at their OWN first count only)
-      }
-    }
-  }
-  WAVE_LDS_SYNC();
-}
-
 template <int IPL, bool AUX, bool ITEMW>
 __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp,
                                                                 const int G) {
@@ -465,7 +403,7 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
 
       // 1b. ranks by counting (score descending, ties by index) (:483-500).
       int rk[IPL];
-      grp_rank_by_count(XS, n, lane, RKS, OCC);
+      wave_rank_by_count(XS, n, lane, RKS, OCC);         // (common.h: all row chunks against each float4 of columns at once)
 #pragma unroll
       for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
       WAVE_LDS_SYNC();                                                       // the scratch is rewritten below

@@ -17,7 +17,7 @@ for what in "$@"; do
     pw_bench)
       for b in 4096 16384; do
         for g in 1 0; do
-          TFR_LAMBDARANK_GROUP=$g timeout 300 python bench.py --workload pairwise_lambda --batch $b --steps 100 --warmup 10 --no-cpu-baseline --also none > $OUT/pw_B${b}_g$g.json 2> $OUT/pw_B${b}_g$g.err
+          TFR_LAMBDARANK_GROUP=$g timeout 300 python bench.py --workload pairwise_lambda --batch $b --steps 100 --warmup 10 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pw_B${b}_g$g.json 2> $OUT/pw_B${b}_g$g.err
           echo "B=$b group=$g rc=$?"; python - <<PY
 import json
 try:
@@ -41,9 +41,9 @@ PY
       for b in 4096 16384; do B=$b timeout 200 python tools/phase_profile.py group > $OUT/phase_group_B$b.txt 2>&1; cat $OUT/phase_group_B$b.txt; done
       B=4096 TFR_LAMBDARANK_WAVES=4 TFR_LAMBDARANK_REP=16 timeout 200 python tools/phase_profile.py group > $OUT/phase_group_B4096_W4.txt 2>&1; cat $OUT/phase_group_B4096_W4.txt
       for b in 4096 16384; do
-        timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_sq_pw$b.log 2>&1
+        timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_sq_pw$b.log 2>&1
         python tools/rocpd_summary.py pmc $OUT/pmc_sq_pw$b/r_results.db lambdarank > $OUT/pmc_sq_pw$b.txt 2>&1; cat $OUT/pmc_sq_pw$b.txt
-        timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_sq2_pw$b.log 2>&1
+        timeout 300 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA -d $OUT/pmc_sq2_pw$b -o r -- python bench.py --workload pairwise_lambda --batch $b --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_sq2_pw$b.log 2>&1
         python tools/rocpd_summary.py pmc $OUT/pmc_sq2_pw$b/r_results.db lambdarank > $OUT/pmc_sq2_pw$b.txt 2>&1; cat $OUT/pmc_sq2_pw$b.txt
       done ;;
     tests)
@@ -51,7 +51,7 @@ PY
       tail -n 70 $OUT/pytest_gpu.log
       timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log ;;
     bench)
-      timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench rc=$?"
+      ( time timeout 1200 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err ) 2> $OUT/bench_default.time; echo "bench rc=$?"
       tail -n 1 $OUT/bench_default.json | cut -c1-1500; tail -n 5 $OUT/bench_default.err ;;
     all)
       for w in pairwise_lambda softmax gumbel_approx_ndcg ndcg_metric approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
@@ -60,14 +60,19 @@ PY
       done ;;
     prof:*)
       w=${what#prof:}
-      timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none > $OUT/prof_$w.log 2>&1
+      timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
       python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1
       head -n 40 $OUT/stats_$w.txt ;;
+    traffic:*)          # FETCH_SIZE / WRITE_SIZE only, few steps (the e2e workloads: thousands of dispatches per second of bench)
+      w=${what#traffic:}
+      timeout 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --also none --busy-seconds 0 --dropout 0.5 > $OUT/pmc_fetch_$w.log 2>&1
+      timeout 200 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --also none --busy-seconds 0 --dropout 0.5 > $OUT/pmc_write_$w.log 2>&1
+      for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db tower_gemm256p > $OUT/pmc_${p}_$w.txt 2>&1; head -n 8 $OUT/pmc_${p}_$w.txt | cut -c1-200; done ;;
     pmc:*)
       w=${what#pmc:}
-      timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_fetch_$w.log 2>&1
-      timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_write_$w.log 2>&1
-      timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none > $OUT/pmc_sq_$w.log 2>&1
+      timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_fetch_$w.log 2>&1
+      timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
+      timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_sq_$w.log 2>&1
       for p in fetch write sq; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; head -n 30 $OUT/pmc_${p}_$w.txt; done ;;
   esac
 done

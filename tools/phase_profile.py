@@ -133,7 +133,8 @@ def main_group():
     disc = (math.log(2.) / torch.log1p(r)).to(dev)
     dl = torch.empty((B, L), device=dev); lst = torch.empty((B,), device=dev)
     lw = torch.full((B,), 1.0 / (B * L), device=dev)
-    Wt_ = W + max(0, int(os.environ.get('TFR_LAMBDARANK_HELPERS', '0')))
+    Wt_ = W + (max(0, int(os.environ['TFR_LAMBDARANK_HELPERS'])) if 'TFR_LAMBDARANK_HELPERS' in os.environ else W // 2)   # = grp_geometry()
+    Wt_ = min(Wt_, 16)
     nwaves = ((B + W - 1) // W) * Wt_
     buf = torch.zeros((nwaves, 12), dtype=torch.int64, device=dev)
     lib.tfr_prof_set_buffer_pw(ctypes.c_void_p(buf.data_ptr()))
@@ -155,10 +156,10 @@ def main_group():
     for _ in range(20):
         call()
     e1.record(); torch.cuda.synchronize()
-    print('lambdarank group kernel (stamped build) B=%d W=%d: %.4f ms' % (B, W, e0.elapsed_time(e1) / 20))
+    print('lambdarank group kernel (stamped build) B=%d, %d lists + %d sweep-only waves per workgroup: %.4f ms' % (B, W, Wt_ - W, e0.elapsed_time(e1) / 20))
     d = buf.cpu()
     t = d[:, :8].double()
-    build = t[:, 5] > t[:, 1]                                  # builder waves (helpers skip phase 1)
+    build = t[:, 2] > 0                                        # builder waves (the sweep-only waves skip phase 1)
     names = ['loads + table + barrier', 'gains + compaction', 'rank count', 'grade order + ideal DCG', 'records + publish']
     tot = (t[:, 7] - t[:, 0]).mean().item()
     print('mean ticks per wave: total %.0f   (%d waves, %d builders)' % (tot, t.shape[0], int(build.sum())))
@@ -173,7 +174,7 @@ def main_group():
         d[:, 10].double().mean().item(), int(d[:, 10].max())))
     print('sweep ticks per pass: %.0f' % (sw.sum().item() / max(1, d[:, 9].sum().item())))
     # per-workgroup lifetime (waves of a workgroup share the XCD clock)
-    Wt = t.shape[0] // ((B + W - 1) // W)
+    Wt = Wt_
     tw = t.reshape(-1, Wt, 8)
     life = (tw[:, :, 7].max(dim=1).values - tw[:, :, 0].min(dim=1).values)
     print('workgroup lifetime: mean %.0f  max %.0f  min %.0f ticks' % (life.mean().item(), life.max().item(), life.min().item()))
