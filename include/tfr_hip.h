@@ -332,9 +332,11 @@ int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int K
                                    const float* shift, const int* row_index, void* out_bf16, void* stream);
 /* create_tower(input_batch_norm=True) (keras/layers.py:57-60): per-column partial sums of the raw fp32 features,
  * partial[n_blocks][2][F] = (sum x, sum x^2) over the block's rows (rows gathered through row_index like the cast);
- * tfr_tower_bn_finalize turns them into the scale / shift the cast applies. */
+ * tfr_tower_bn_finalize turns them into the scale / shift the cast applies.  `pivot` [F] (nullable): the sums are taken
+ * of x - pivot (a sample of each column, e.g. the first row): mean = pivot + finalize's mean, the variance is unchanged
+ * and keeps its digits when |mean| >> std. */
 int tfr_tower_input_stats_f32(const float* x, long ldx, int M, int F, const int* row_index, float* partial,
-                              int n_blocks, void* stream);
+                              int n_blocks, const float* pivot, void* stream);
 /* fp32 w[R, C] -> bf16 [R, pitch] or (transpose) bf16 [C, pitch]: the per-step operand copy of a
  * Dense kernel (fp32 master weights stay with the optimizer). */
 int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,

@@ -73,7 +73,7 @@ _SIGNATURES = {
     'tfr_tower_bn_bwd_coeffs': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_long]
                                 + [ctypes.c_void_p] * 2),
     'tfr_tower_input_stats_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+                                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_cast_gather_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                                        + [ctypes.c_void_p] * 5),
     'tfr_tower_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3

@@ -136,9 +136,11 @@ def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Opti
     return out
 
 
-def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blocks: int = 512):
+def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blocks: int = 512,
+                pivot: Optional[torch.Tensor] = None):
     """Per-column partial sums [T, 2, F] (sum x, sum x^2) of the fp32 features (rows gathered through
-    ``row_index``): the batch statistics of create_tower's input BatchNormalization, in bn_finalize's format."""
+    ``row_index``): the batch statistics of create_tower's input BatchNormalization, in bn_finalize's format.
+    ``pivot`` [F]: sums of ``x - pivot`` (the variance keeps its digits when |mean| >> std; add it back to the mean)."""
     require_device(x, 'x')
     x = x.to(torch.float32)
     if x.stride(1) != 1:
@@ -151,8 +153,10 @@ def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blo
     F = x.shape[1]
     T = max(1, min(n_blocks, (M + 63) // 64))
     partial = torch.empty((T, 2, F), dtype=torch.float32, device=x.device)
+    if pivot is not None:
+        pivot = pivot.to(torch.float32).contiguous()
     _lib.check(_lib.load().tfr_tower_input_stats_f32(_ptr(x), x.stride(0), M, F, _ptr(row_index), _ptr(partial), T,
-                                                     _stream()), 'tfr_tower_input_stats_f32')
+                                                     _ptr(pivot), _stream()), 'tfr_tower_input_stats_f32')
     return partial, M
 
 

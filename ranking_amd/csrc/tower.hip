@@ -2041,14 +2041,19 @@ extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, in
 // whose scale / shift the cast kernel then applies.
 __global__ __launch_bounds__(256) void tower_input_stats_kernel(const float* __restrict__ x, long ldx, int M, int F,
                                                                 const int* __restrict__ row_index,
-                                                                float* __restrict__ partial, int rows_per_block) {
+                                                                float* __restrict__ partial, int rows_per_block,
+                                                                const float* __restrict__ pivot) {
+  // `pivot` (nullable, [F]): the sums are taken of x - pivot.  var = E[x^2] - mean^2 from fp32 partial sums loses
+  // every digit of a column with |mean| >> std (raw features are exactly that case: ADVICE r2); shifted by a sample
+  // of the column (the caller passes the first row) both sums stay at the scale of the spread.
   const long mb = (long)blockIdx.x * rows_per_block;
   const long me = (mb + rows_per_block < M) ? mb + rows_per_block : M;
   for (int c = threadIdx.x; c < F; c += blockDim.x) {
     float s1 = 0.f, s2 = 0.f;
+    const float pv = pivot ? pivot[c] : 0.0f;
     for (long m = mb; m < me; ++m) {
       const long ms = row_index ? (long)row_index[m] : m;
-      const float v = x[ms * ldx + c];
+      const float v = x[ms * ldx + c] - pv;
       s1 += v; s2 = __builtin_fmaf(v, v, s2);
     }
     partial[((long)blockIdx.x * 2) * F + c] = s1;
@@ -2057,11 +2062,11 @@ __global__ __launch_bounds__(256) void tower_input_stats_kernel(const float* __r
 }
 
 extern "C" int tfr_tower_input_stats_f32(const float* x, long ldx, int M, int F, const int* row_index, float* partial,
-                                         int n_blocks, void* stream) {
+                                         int n_blocks, const float* pivot, void* stream) {
   if (!x || !partial || M <= 0 || F <= 0 || n_blocks < 1 || ldx < F) return TFR_EINVAL;
   const int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
   hipLaunchKernelGGL(tower_input_stats_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, F, row_index,
-                     partial, rows);
+                     partial, rows, pivot);
   return (int)hipGetLastError();
 }
 

@@ -87,9 +87,16 @@ class _TowerFn(torch.autograd.Function):
         if tower.input_batch_norm:
             g_in, b_in = params[-4], params[-3]
             if training:                                   # batch statistics of the raw fp32 features
-                part, rows = T.input_stats(x, row_index=row_index)
+                # shifted by a sample of every column (the first scored row): var = E[x^2] - mean^2 from fp32 partial
+                # sums keeps its digits for raw features with |mean| >> std (Keras uses two-pass moments)
+                first = x[0] if row_index is None else x.index_select(0, row_index[:1].long())[0]
+                pivot = first.detach().to(torch.float32)
+                part, rows = T.input_stats(x, row_index=row_index, pivot=pivot)
                 in_sc, in_sh, in_mean, in_rstd = T.bn_finalize(part, rows, g_in, b_in, _BN_EPS, tower.momentum,
                                                                tower.moving_mean_in, tower.moving_var_in)
+                in_mean = in_mean + pivot                               # finalize saw x - pivot: mean, shift and the moving
+                in_sh = in_sh - pivot * in_sc                           # mean take the pivot back; scale / rstd / var do not
+                tower.moving_mean_in.add_(pivot, alpha=1.0 - tower.momentum)
             else:
                 in_rstd = torch.rsqrt(tower.moving_var_in + _BN_EPS)
                 in_mean = tower.moving_mean_in

@@ -369,6 +369,36 @@ def test_fused_tower_input_gradient(M, F, hidden, O, act, bn, in_bn, gather):
         assert torch.isfinite(xc.grad).all()
 
 
+def test_input_batch_norm_statistics_with_large_offsets():
+    """raw features with |mean| >> std (what input_batch_norm exists for).  E[x^2] - mean^2 from fp32 partial sums
+    loses the variance there (a column at 3000 +- 0.5: mean^2 = 9e6, one fp32 ulp of it = 1 >> var = 0.25); the statistics kernel
+    sums x - pivot (the first scored row) instead.  Logits against the replica (two-pass moments, like Keras) and the moving
+    statistics against the true ones."""
+    from ranking_amd.tower import FusedTower
+    torch.manual_seed(5)
+    M, F = 4000, 24
+    tower = FusedTower(F, [64, 32], 1, activation='relu', use_batch_norm=True, input_batch_norm=True,
+                       batch_norm_moment=0.5).to(DEV)
+    offs = torch.tensor([0.0, 100.0, 1000.0, -3000.0], device=DEV)[torch.arange(F, device=DEV) % 4]
+    x = rnd((M, F), 90).to(DEV) * 0.5 + offs
+    tower.train()
+    got = tower(x)
+    want = ref_tower(x, tower)
+    scale = max(1.0, want.abs().max().item())
+    err = (got - want).abs().max().item() / scale
+    record_margin('input BatchNorm at |mean| / std up to 6000: logits vs two-pass replica', err, 3e-2)
+    assert err <= 3e-2, err
+    true_var = x.double().var(0, unbiased=False)
+    true_mean = x.double().mean(0)
+    mv = (tower.moving_var_in.double() - 0.5) / 0.5             # moving = 0.5 * 1 + 0.5 * batch variance
+    mm = tower.moving_mean_in.double() / 0.5                   # moving = 0.5 * 0 + 0.5 * batch mean
+    rel_v = ((mv - true_var).abs() / true_var).max().item()
+    rel_m = ((mm - true_mean).abs() / true_mean.abs().clamp(min=1.0)).max().item()
+    record_margin('input BatchNorm at |mean| / std up to 6000: batch variance, relative', rel_v, 1e-3)
+    record_margin('input BatchNorm at |mean| / std up to 6000: batch mean, relative', rel_m, 1e-5)
+    assert rel_v <= 1e-3 and rel_m <= 1e-5, (rel_v, rel_m)
+
+
 def ref_tower_dropout(x, tower, masks):
     a = _ste(x)
     n_h = len(tower.hidden_layer_dims)
