@@ -178,6 +178,30 @@ def main_group():
     tw = t.reshape(-1, Wt, 8)
     life = (tw[:, :, 7].max(dim=1).values - tw[:, :, 0].min(dim=1).values)
     print('workgroup lifetime: mean %.0f  max %.0f  min %.0f ticks' % (life.mean().item(), life.max().item(), life.min().item()))
+    # placement: HW_ID (cu 11:8, sh 12, se 15:13) and XCC_ID of wave 0 of every workgroup
+    hw = d[:, 11].reshape(-1, Wt)[:, 0]
+    xcc = (hw >> 32) & 0xf
+    cu = ((hw & 0xffffffff) >> 8) & 0xff                      # cu | sh | se bits
+    key = (xcc * 256 + cu).tolist()
+    from collections import defaultdict
+    per_cu = defaultdict(list)
+    for i, k in enumerate(key):
+        per_cu[k].append(i)
+    cnts = [len(v) for v in per_cu.values()]
+    print('distinct (XCC, SE/SH/CU) keys %d; workgroups per key: min %d max %d; histogram %s' % (
+        len(per_cu), min(cnts), max(cnts), {c: cnts.count(c) for c in sorted(set(cnts))}))
+    st0 = tw[:, :, 0].min(dim=1).values
+    en0 = tw[:, :, 7].max(dim=1).values
+    for x in range(8):
+        sel = (xcc == x)
+        if sel.any():
+            print('  XCC %d: %3d workgroups, lifetime mean %.0f max %.0f, start spread %.0f, last end - first start %.0f' % (
+                x, int(sel.sum()), life[sel].mean().item(), life[sel].max().item(),
+                (st0[sel].max() - st0[sel].min()).item(), (en0[sel].max() - st0[sel].min()).item()))
+    # lifetime by how many workgroups shared the CU key
+    for c in sorted(set(cnts)):
+        idx = [i for v in per_cu.values() if len(v) == c for i in v]
+        print('  CUs hosting %d workgroups: mean lifetime %.0f (n = %d)' % (c, life[idx].mean().item(), len(idx)))
 
 
 if __name__ == '__main__':
