@@ -35,8 +35,9 @@ extern "C" {
 /* List-size limits (TFR_ETOOLARGE beyond).  These macros are what the kernels' launchers test; every "list_size <= N"
  * statement in this header is checked against them by tests/test_host_logic.py. */
 #define TFR_MAX_LIST_SIZE 8192              /* ApproxNDCG / ApproxMRR, pairwise losses, softmax, Gumbel sampler, sort / ranks,
-                                               list order, group indices: workgroup kernels beyond the wave-per-list range */
-#define TFR_MAX_LIST_SIZE_METRIC 4096       /* rank / diversity metrics: keys and values in LDS, 25-32 B per item */
+                                               NDCG / MRR metrics, list order, group indices: workgroup kernels beyond the
+                                               wave-per-list range */
+#define TFR_MAX_LIST_SIZE_METRIC 4096       /* the other rank metrics and the diversity metrics: 28-32 B of LDS per item */
 #define TFR_MAX_LIST_SIZE_LISTWISE 4096     /* ListMLE, UniqueSoftmax, Circle: LDS block sort + scans, 24-36 B per item */
 #define TFR_MAX_LIST_SIZE_NEURAL_SORT 2048  /* NeuralSort losses: one wavefront per list, 40 / 60 B of LDS per item */
 #define TFR_MAX_LIST_SIZE_FLATTEN 4096      /* tfr_flatten_row_index: 16 B of LDS per item, four list-waves per workgroup */
@@ -83,7 +84,9 @@ int tfr_sort_ranks_f32(const float* scores, const float* labels, const uint8_t* 
  *   ndcg_out     [K, B]
  *   stats_out    [B, 3] = (sum w, sum gain, sum w*gain) in tree_sum order; the
  *                cross-list part of _per_example_weights_to_per_list_weights
- *                (metrics_impl.py:63-119) is done by the caller on [B] vectors. */
+ *                (metrics_impl.py:63-119) is done by the caller on [B] vectors.
+ * NDCG and MRR (below): list_size <= 8192 (TFR_MAX_LIST_SIZE) -- one wavefront per list up to 512 / 256 items, one
+ * workgroup with 16 B of LDS per item beyond. */
 int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const float* weights,
                         int weights_per_list, const uint8_t* mask, const float* gains,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
@@ -95,7 +98,8 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
  *   TFR_METRIC_HITS (:462-506)       TFR_METRIC_RECALL (:154-177, 539-561)   TFR_METRIC_PRECISION (:180-207, 564-586)
  *   TFR_METRIC_MAP (:589-628)        TFR_METRIC_ARP (:509-536; stats_out[:, 2] = its per-list weight)
  * stats_out [B, 3] = (sum w, sum rel, sum w*rel) with rel = gain (DCG), label (ARP) or 1{label >= 1}.
- * list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC) for every kind: one wavefront per list up to 512 items, one workgroup beyond. */
+ * NDCG / MRR as above; the other kinds: list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC): one wavefront per list up to 512
+ * items, one workgroup (32 B of LDS per item) beyond. */
 #define TFR_METRIC_NDCG 0
 #define TFR_METRIC_MRR 1
 #define TFR_METRIC_DCG 2

@@ -45,7 +45,10 @@ __global__ void sort_ranks_kernel(const float* __restrict__ scores, const float*
   }
 }
 
-// kind 0 = NDCG, 1 = MRR.
+// kind 0 = NDCG, 1 = MRR.  LDS per item: the 64-bit sort key, one tree-sum scratch float and the product
+// w * gain -- 16 bytes (round 2: 25, with separate weight / gain / mask / un-cut-term arrays), so that the workgroup
+// form reaches the 8192 items of the loss kernels (P = 8192: 128 KiB).  Weights, gains and the mask are recomputed
+// from the (cache resident) global rows where they are needed; the sums run in the same order as before.
 template <int KIND>
 __global__ void rank_metric_kernel(const float* __restrict__ labels, const float* __restrict__ predictions,
                                    const float* __restrict__ weights, int weights_per_list,
@@ -57,19 +60,15 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
   float* dcg = red + 20;
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
   float* term = reinterpret_cast<float*>(keys + P);               // [P] tree-sum scratch
-  float* term0 = term + P;                                        // [P] un-cut terms
-  float* W = term0 + P;                                           // [P] example weights
-  float* G = W + P;                                               // [P] gain / relevance
-  uint8_t* M = reinterpret_cast<uint8_t*>(G + P);                 // [P] metric mask
+  float* WG = term + P;                                           // [P] example weight x gain (relevance for MRR)
 
   const int b = blockIdx.x;
   const size_t base = (size_t)b * L;
   const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
 
-  // ---- _prepare_and_validate_params (metrics_impl.py:228-266)
-  for (int i = threadIdx.x; i < P; i += blockDim.x) {
-    float w = 0.f, g = 0.f;
-    bool m = false;
+  // ---- _prepare_and_validate_params (metrics_impl.py:228-266) of item i
+  auto item = [&](int i, float& w, float& g, bool& m) {
+    w = 0.f; g = 0.f; m = false;
     if (i < L) {
       const float lab = labels[base + i];
       w = weights ? (weights_per_list ? wl : weights[base + i]) : 1.0f;
@@ -79,17 +78,15 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
       if (KIND == 0) g = gains ? gains[base + i] : gain_pow2m1(labc);
       else g = (labc >= 1.0f) ? 1.0f : 0.0f;
     }
-    W[i] = w; G[i] = g; M[i] = m ? 1 : 0;
-  }
-  __syncthreads();
+  };
 
   // ---- per-list weight statistics, tree_sum order over the original index.
   float s_w, s_g, s_wg;
-  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = W[i];
+  for (int i = threadIdx.x; i < P; i += blockDim.x) { float w, g; bool m; item(i, w, g, m); term[i] = w; }
   block_tree_sum(term, P); s_w = term[0]; __syncthreads();
-  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = G[i];
+  for (int i = threadIdx.x; i < P; i += blockDim.x) { float w, g; bool m; item(i, w, g, m); term[i] = g; }
   block_tree_sum(term, P); s_g = term[0]; __syncthreads();
-  for (int i = threadIdx.x; i < P; i += blockDim.x) term[i] = W[i] * G[i];
+  for (int i = threadIdx.x; i < P; i += blockDim.x) { float w, g; bool m; item(i, w, g, m); WG[i] = w * g; term[i] = w * g; }
   block_tree_sum(term, P); s_wg = term[0]; __syncthreads();
   if (threadIdx.x == 0) {
     stats_out[(size_t)b * 3 + 0] = s_w;
@@ -98,15 +95,18 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
   }
 
   // ---- sort by prediction (masked entries last): utils.py:115-164.
-  for (int i = threadIdx.x; i < P; i += blockDim.x)
-    keys[i] = (i < L) ? make_sort_key(M[i] != 0, predictions[base + i], 0, i) : 0ull;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    float w, g; bool m; item(i, w, g, m);
+    keys[i] = (i < L) ? make_sort_key(m, predictions[base + i], 0, i) : 0ull;
+    if (KIND == 1) WG[i] = g;                                  // MRR asks for the relevance of the sorted items
+  }
   block_bitonic_sort_desc(keys, P);
 
   if (KIND == 1) {
     // MRR: first sorted position holding a relevant item (metrics_impl.py:443-459).
     float pmin = INFINITY;
     for (int p = threadIdx.x; p < L; p += blockDim.x)
-      if (G[sort_key_index(keys[p])] > 0.0f) pmin = fminf(pmin, (float)p);
+      if (WG[sort_key_index(keys[p])] > 0.0f) pmin = fminf(pmin, (float)p);
     pmin = block_min(pmin, red);
     if (threadIdx.x == 0) {
       for (int q = 0; q < topn.n; ++q) {
@@ -117,34 +117,26 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
     return;
   }
 
-  // ---- DCG terms in sorted order: (w * gain) * discount(rank)  (:122-151)
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    float t = 0.f;
-    if (p < L) { const int idx = sort_key_index(keys[p]); t = (W[idx] * G[idx]) * discount[p]; }
-    term0[p] = t;
-  }
-  __syncthreads();
+  // ---- DCG terms in sorted order: (w * gain) * discount(rank)  (:122-151), cut at every topn
   for (int q = 0; q < topn.n; ++q) {
     const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
-    for (int p = threadIdx.x; p < P; p += blockDim.x) term[p] = (p < k) ? term0[p] : 0.0f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+      term[p] = (p < k) ? WG[sort_key_index(keys[p])] * discount[p] : 0.0f;
     block_tree_sum(term, P);
     if (threadIdx.x == 0) dcg[q] = term[0];
     __syncthreads();
   }
 
   // ---- ideal ordering: sort by weighted gain (metrics_impl.py:660-666)
-  for (int i = threadIdx.x; i < P; i += blockDim.x)
-    keys[i] = (i < L) ? make_sort_key(M[i] != 0, W[i] * G[i], 0, i) : 0ull;
-  block_bitonic_sort_desc(keys, P);
-  for (int p = threadIdx.x; p < P; p += blockDim.x) {
-    float t = 0.f;
-    if (p < L) { const int idx = sort_key_index(keys[p]); t = (W[idx] * G[idx]) * discount[p]; }
-    term0[p] = t;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) {
+    float w, g; bool m; item(i, w, g, m);
+    keys[i] = (i < L) ? make_sort_key(m, WG[i], 0, i) : 0ull;
   }
-  __syncthreads();
+  block_bitonic_sort_desc(keys, P);
   for (int q = 0; q < topn.n; ++q) {
     const int k = (topn.k[q] <= 0 || topn.k[q] > L) ? L : topn.k[q];
-    for (int p = threadIdx.x; p < P; p += blockDim.x) term[p] = (p < k) ? term0[p] : 0.0f;
+    for (int p = threadIdx.x; p < P; p += blockDim.x)
+      term[p] = (p < k) ? WG[sort_key_index(keys[p])] * discount[p] : 0.0f;
     block_tree_sum(term, P);
     const float idcg = term[0];
     if (threadIdx.x == 0)
@@ -1282,7 +1274,7 @@ static int launch_metric(int kind, const float* labels, const float* predictions
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == 0 && !discount) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_METRIC) return TFR_ETOOLARGE;     // 25 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST_SIZE) return TFR_ETOOLARGE;            // NDCG / MRR: 16 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
@@ -1295,8 +1287,8 @@ static int launch_metric(int kind, const float* labels, const float* predictions
     return (int)hipGetLastError();
   }
   const int T = block_threads_for(P);
-  const size_t lds = 128 + (size_t)P * (sizeof(uint64_t) + 4 * sizeof(float) + 1) + 16;
-  if (lds > 160 * 1024) return TFR_ETOOLARGE;     // list_size <= 4096 (25 B of LDS per item)
+  const size_t lds = 128 + (size_t)P * (sizeof(uint64_t) + 2 * sizeof(float));
+  if (lds > 160 * 1024) return TFR_ETOOLARGE;
   if (lds > 64 * 1024) {
     hipError_t e = (kind == 0)
         ? hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_metric_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)

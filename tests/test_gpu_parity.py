@@ -98,8 +98,9 @@ def test_sort_reference_goldens():
 
 
 # ---------------------------------------------------------------------- metrics
-# (1100, 300): wave kernel with 8 keys per lane; 512 < L <= 4096: the workgroup kernels (LDS bitonic sort)
-@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (1024, 700), (3, 3000), (2, 4096)])
+# (1100, 300): wave kernel with 8 keys per lane; 512 < L <= 8192: the workgroup kernels (LDS bitonic sort; round 3: 16 B of
+# LDS per item, up to the 8192 items of the loss kernels -- round 2 stopped at 4096)
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (1024, 700), (3, 3000), (2, 4096), (3, 5000), (2, 8192)])
 @pytest.mark.parametrize('weighted', [False, True])
 def test_ndcg_mrr_bit_exact(B, L, weighted):
     labels, preds = make_batch(B, L, seed=100 + L)
