@@ -645,11 +645,14 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
     if name == args.workload and args.busy_seconds > 0:
         # keep the GPU visibly busy: the timed region of a loss workload is a few milliseconds of a run dominated by the
         # CPU baselines, and a 5-second utilisation sampler never saw it.  NOT part of any reported number.
-        t_end = time.perf_counter() + args.busy_seconds
-        while time.perf_counter() < t_end:
-            for _ in range(200):
-                step()
-            torch.cuda.synchronize()
+        # (a fixed replay count from the measured step time -- `elapsed` is the max over ranks, identical everywhere -- so
+        # that every rank issues the same number of steps: an e2e step contains a collective)
+        n_busy = int(min(2_000_000, max(1, args.busy_seconds / max(elapsed / steps, 1e-7))))
+        for i in range(n_busy):
+            step()
+            if i % 1000 == 999:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
     kernel_ms = _kernel_ms(info['kernel'], steps) if info.get('kernel') is not None else None
     all_reduce_ms = None
     if is_e2e:
