@@ -356,6 +356,23 @@ int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* 
                         const float* e_scale, const float* e_shift, const float* e_mean,
                         const float* e_rstd, const tfr_tower_dropout* pro_dropout,
                         const tfr_tower_dropout* epi_dropout, void* stream);
+/* Dense in the REFERENCE's precision (keras/layers.py:26-77 builds fp32 Dense layers; model.py:755-817 trains through
+ * them): C[M, N] = op(A)[M, K] . op(B)[K, N] (+ bias[N]) with fp32 operands, fp32 accumulation on the matrix cores
+ * (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fma chain).  Any M, N, K >= 0 and any pitches.
+ *   a_k_contiguous != 0: A(m, k) = A[m * lda + k], else A(m, k) = A[k * lda + m]
+ *   b_k_contiguous != 0: B(k, n) = B[n * ldb + k], else B(k, n) = B[k * ldb + n]
+ * so that   y  = x . W^T + b : (x, 1, W, 1)      dx = dy . W : (dy, 1, W, 0)      dW = dy^T . x : (dy, 0, x, 0).
+ *   splits > 1 cuts the contraction into that many slabs (the weight gradient contracts over batch_size * list_size
+ *   rows): `workspace` = splits * M * N floats, summed in ascending order by a second launch (same bits every run);
+ *   tfr_tower_gemm_f32_splits(M, N, K) proposes a count. */
+int tfr_tower_gemm_f32(const float* A, long lda, int a_k_contiguous, const float* B, long ldb, int b_k_contiguous,
+                       float* C, long ldc, int M, int N, int K, const float* bias, int splits, float* workspace,
+                       void* stream);
+int tfr_tower_gemm_f32_splits(int M, int N, int K);
+/* Bias gradient of that Dense layer: out[n] = sum_m X[m * ldx + n], two deterministic stages;
+ * `partial` = tfr_tower_colsum_rows(M) * N floats of scratch. */
+int tfr_tower_colsum_f32(const float* X, long ldx, int M, int N, float* partial, float* out, void* stream);
+int tfr_tower_colsum_rows(int M);
 int tfr_tower_gemm_stats_rows(int M);            /* rows of `stats` for a given M            */
 int tfr_tower_reduce_scratch_rows(int T);     /* rows of the `scratch` buffers below      */
 /* BatchNormalization (training): partial[T][2][N] -> mean / biased variance -> scale = gamma *

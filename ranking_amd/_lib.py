@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(CSRC, 'libtfr_hip.so')
 STAMP_PATH = LIB_PATH + '.stamp'                           # fingerprint of what LIB_PATH was built from
 PROF_LIB_PATH = os.path.join(CSRC, 'libtfr_hip_prof.so')     # developer aid: -DTFR_PROFILE_STAMPS build
 SOURCES = ['sort_metrics.hip', 'approx_ndcg.hip', 'pairwise.hip', 'softmax_gumbel.hip', 'tower.hip', 'listwise.hip',
-           'neural_sort.hip', 'pointwise.hip', 'groupwise.hip']
+           'neural_sort.hip', 'pointwise.hip', 'groupwise.hip', 'gemm_f32.hip']
 HIPCC_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
                '-fvisibility=default']
 
@@ -106,6 +106,13 @@ _SIGNATURES = {
                              + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    # fp32 Dense on the matrix cores (gemm_f32.hip)
+    'tfr_tower_gemm_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int] * 2 + [ctypes.c_void_p, ctypes.c_long]
+                           + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'tfr_tower_gemm_f32_splits': (ctypes.c_int, [ctypes.c_int] * 3),
+    'tfr_tower_colsum_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int]
+                             + [ctypes.c_void_p] * 3),
+    'tfr_tower_colsum_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_list_dot_f32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 2),
     # groupwise scoring (groupwise.hip)
     'tfr_group_indices_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),

@@ -373,3 +373,57 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
 
 
 _ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask', 'dropout_field'))
+
+
+# ---- fp32 Dense on the matrix cores (csrc/gemm_f32.hip): the reference's own precision (keras/layers.py:26-77) ----
+def _f32_2d(t, name):
+    require_device(t, name)
+    if t.dtype != torch.float32 or t.dim() != 2:
+        raise TypeError('%s must be a 2-D float32 tensor' % name)
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t
+
+
+def gemm_f32(A, a_k_contiguous, B, b_k_contiguous, M, N, K, bias=None, splits=1, out=None):
+    """C[M, N] = op(A)[M, K] . op(B)[K, N] (+ bias), fp32 in / fp32 accumulate (tfr_tower_gemm_f32)."""
+    A = _f32_2d(A, 'A'); B = _f32_2d(B, 'B')
+    C = out if out is not None else torch.empty((M, N), dtype=torch.float32, device=A.device)
+    if bias is not None:
+        bias = bias.detach().to(torch.float32).contiguous()
+    ws = torch.empty((splits, M, N), dtype=torch.float32, device=A.device) if splits > 1 else None
+    lda = A.stride(0) if A.shape[0] > 1 else max(A.shape[1], 1)
+    ldb = B.stride(0) if B.shape[0] > 1 else max(B.shape[1], 1)
+    _lib.check(_lib.load().tfr_tower_gemm_f32(_ptr(A), lda, int(a_k_contiguous), _ptr(B), ldb, int(b_k_contiguous),
+                                              _ptr(C), C.stride(0) if M > 1 else max(N, 1), M, N, K, _ptr(bias), splits,
+                                              _ptr(ws), _stream()), 'tfr_tower_gemm_f32')
+    return C
+
+
+def dense_f32(x, w, bias=None):
+    """y[M, N] = x[M, K] . w[N, K]^T + bias."""
+    return gemm_f32(x, True, w, True, x.shape[0], w.shape[0], x.shape[1], bias=bias)
+
+
+def dense_f32_dgrad(dy, w):
+    """dx[M, K] = dy[M, N] . w[N, K]."""
+    return gemm_f32(dy, True, w, False, dy.shape[0], w.shape[1], w.shape[0])
+
+
+def dense_f32_wgrad(dy, x):
+    """dW[N, K] = dy[M, N]^T . x[M, K]: the contraction over the M rows cut into slabs, summed in a fixed order."""
+    N, K, M = dy.shape[1], x.shape[1], x.shape[0]
+    splits = int(_lib.load().tfr_tower_gemm_f32_splits(N, K, M))
+    return gemm_f32(dy, False, x, False, N, K, M, splits=splits)
+
+
+def colsum_f32(x):
+    """out[n] = sum_m x[m, n] (the bias gradient), two deterministic stages (tfr_tower_colsum_f32)."""
+    x = _f32_2d(x, 'x')
+    M, N = x.shape
+    out = torch.empty((N,), dtype=torch.float32, device=x.device)
+    T = int(_lib.load().tfr_tower_colsum_rows(M))
+    partial = torch.empty((T, max(N, 1)), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tfr_tower_colsum_f32(_ptr(x), x.stride(0) if M > 1 else max(N, 1), M, N, _ptr(partial), _ptr(out),
+                                                _stream()), 'tfr_tower_colsum_f32')
+    return out
