@@ -35,7 +35,7 @@ struct GemmF32Args {
   float* C; long ldc; long slab;
   int M, N, K;
   const float* bias;
-  int k_per_split, tiles_m, tiles_n, chunk;
+  int k_per_split, tiles_m, tiles_n, chunk, S;
 };
 
 // One operand tile: 128 rows (m of A, n of B) x 16 steps of the contraction, two float4 per thread.
@@ -111,12 +111,24 @@ template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
   __shared__ __attribute__((aligned(16))) float As[2][kBK * kLdp];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * kLdp];
-  // blockIdx.x round-robins over the 8 XCDs: give every XCD a contiguous run of tiles (n fastest)
-  const int logical = (int)(blockIdx.x & 7) * a.chunk + (int)(blockIdx.x >> 3);
-  if (logical >= a.tiles_m * a.tiles_n) return;
+  // Workgroup ids round-robin over the 8 XCDs (each with its own L2).
+  //   one slab:  every XCD gets a contiguous run of tiles, n fastest: the tiles of one row block of A are neighbours
+  //   S slabs (weight gradient): all tiles of slab z run on XCD z % 8, back to back: the [k slab] x 128 panels of both
+  //              operands, which tiles_m + tiles_n tiles share, come from that XCD's L2 and from HBM once
+  const int tiles = a.tiles_m * a.tiles_n;
+  int logical, z;
+  if (a.S == 1) {
+    logical = (int)(blockIdx.x & 7) * a.chunk + (int)(blockIdx.x >> 3);
+    z = 0;
+    if (logical >= tiles) return;
+  } else {
+    const int q = (int)(blockIdx.x >> 3);
+    z = (int)(blockIdx.x & 7) + 8 * (q / tiles);
+    logical = q % tiles;
+    if (z >= a.S) return;
+  }
   const int tn = logical % a.tiles_n, tm = logical / a.tiles_n;
   const int m0 = tm * kBM, n0 = tn * kBN;
-  const int z = blockIdx.y;
   const int kbeg = z * a.k_per_split;
   const int kend = min(a.K, kbeg + a.k_per_split);
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -203,11 +215,15 @@ __global__ __launch_bounds__(256) void colsum_f32_stage1_kernel(const float* __r
   const int r0 = blockIdx.x * rows_per;
   const int r1 = min(M, r0 + rows_per);
   for (int n = threadIdx.x; n < N; n += 256) {
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* __restrict__ p = X + n;
     int r = r0;
-    for (; r + 1 < r1; r += 2) { s0 += X[(long)r * ldx + n]; s1 += X[(long)(r + 1) * ldx + n]; }
-    if (r < r1) s0 += X[(long)r * ldx + n];
-    partial[(long)blockIdx.x * N + n] = s0 + s1;
+    for (; r + 3 < r1; r += 4) {
+      const float v0 = p[(long)r * ldx], v1 = p[(long)(r + 1) * ldx], v2 = p[(long)(r + 2) * ldx], v3 = p[(long)(r + 3) * ldx];
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; r < r1; ++r) s0 += p[(long)r * ldx];
+    partial[(long)blockIdx.x * N + n] = (s0 + s1) + (s2 + s3);
   }
 }
 
@@ -220,15 +236,73 @@ __global__ __launch_bounds__(256) void colsum_f32_stage2_kernel(const float* __r
   out[n] = s;
 }
 
+// ---- output_units <= 4 (the last Dense of the tower): HBM-bound on the [M, K] activations, no matrix cores ----
+// y[m, n] = sum_k x[m, k] w[n, k] + b[n]: one wavefront per row, lanes along k
+template <int NN>
+__global__ __launch_bounds__(256) void dense_thin_fwd_kernel(const float* __restrict__ x, const long ldx,
+                                                             const float* __restrict__ w, const long ldw,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             const long ldy, const int M, const int K) {
+  const int lane = threadIdx.x & 63;
+  const int nw = gridDim.x * 4;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += nw) {
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+    const float* __restrict__ xr = x + (long)m * ldx;
+#pragma unroll 4
+    for (int k = lane; k < K; k += 64) {
+      const float xv = xr[k];
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[n] = fmaf(xv, w[(long)n * ldw + k], acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      const float sum = wave_sum(acc[n]);
+      if (lane == 0) y[(long)m * ldy + n] = sum + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+// dW[n, k] = sum_m dy[m, n] x[m, k]: block b adds its run of rows for every k (threads along k), then the column-sum
+// second stage adds the T partial [NN, K] slabs in ascending order
+template <int NN>
+__global__ __launch_bounds__(256) void dense_thin_wgrad_stage1_kernel(const float* __restrict__ dy, const long ldy,
+                                                                      const float* __restrict__ x, const long ldx,
+                                                                      const int M, const int K, const int rows_per,
+                                                                      float* __restrict__ partial) {
+  const int r0 = blockIdx.x * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = 0.f;
+    const float* __restrict__ p = x + k;
+#pragma unroll 4
+    for (int r = r0; r < r1; ++r) {
+      const float xv = p[(long)r * ldx];
+#pragma unroll
+      for (int n = 0; n < NN; ++n) acc[n] = fmaf(dy[(long)r * ldy + n], xv, acc[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) partial[((long)blockIdx.x * NN + n) * K + k] = acc[n];
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+extern "C" int tfr_tower_colsum_rows(int M);
+
 extern "C" int tfr_tower_gemm_f32_splits(int M, int N, int K) {
-  // enough slabs for ~4 workgroups per CU, at least 16 k tiles each
+  // One resident round of workgroups: 140 registers and 33 KB of LDS allow three 256-thread workgroups per CU = 768 on
+  // the chip; 1 024 equal workgroups would run as a full round plus a third of one (measured: 75 TFLOP/s against the
+  // forward product's 105).  At least 16 k tiles per slab.
   if (M <= 0 || N <= 0 || K <= 0) return 1;
+  if (M <= 4) return tfr_tower_colsum_rows(K);      // the thin weight gradient: one partial slab per run of rows
   const long tiles = (long)((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
-  long s = (1024 + tiles - 1) / tiles;
+  long s = 768 / tiles;
   const long smax = (K + 16 * kBK - 1) / (16 * kBK);
   if (s > smax) s = smax;
   if (s > 256) s = 256;
@@ -243,6 +317,27 @@ extern "C" int tfr_tower_gemm_f32(const float* A, long lda, int a_k_contiguous, 
   if (!C || (K > 0 && (!A || !B)) || ldc < N) return TFR_EINVAL;
   if (K > 0) {
     if (lda < (a_k_contiguous ? K : M) || ldb < (b_k_contiguous ? K : N)) return TFR_EINVAL;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (a_k_contiguous && b_k_contiguous && N <= 4 && K > 0) {
+    // the tower's last Dense: output_units <= 4
+    const unsigned g = (unsigned)((M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4);
+#define TFR_THIN_FWD(NN) hipLaunchKernelGGL((dense_thin_fwd_kernel<NN>), dim3(g), dim3(256), 0, st, A, lda, B, ldb, bias, C, ldc, M, K)
+    if (N == 1) TFR_THIN_FWD(1); else if (N == 2) TFR_THIN_FWD(2); else if (N == 3) TFR_THIN_FWD(3); else TFR_THIN_FWD(4);
+#undef TFR_THIN_FWD
+    return (int)hipGetLastError();
+  }
+  if (!a_k_contiguous && !b_k_contiguous && M <= 4 && K > 0 && workspace && ldc == N && !bias && splits <= 1024) {
+    // its weight gradient: dW[M <= 4, N] = dy^T . x over K rows; `splits` partial slabs of [M, N]
+    const int rows_per = (K + splits - 1) / splits;
+    const int T = (K + rows_per - 1) / rows_per;
+#define TFR_THIN_WG(NN) hipLaunchKernelGGL((dense_thin_wgrad_stage1_kernel<NN>), dim3(T), dim3(256), 0, st, A, lda, B, ldb, K, N, rows_per, workspace)
+    if (M == 1) TFR_THIN_WG(1); else if (M == 2) TFR_THIN_WG(2); else if (M == 3) TFR_THIN_WG(3); else TFR_THIN_WG(4);
+#undef TFR_THIN_WG
+    const int rc = (int)hipGetLastError();
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(colsum_f32_stage2_kernel, dim3((M * N + 255) / 256), dim3(256), 0, st, workspace, T, M * N, C);
+    return (int)hipGetLastError();
   }
   GemmF32Args a;
   a.A = A; a.lda = lda; a.a_kc = a_k_contiguous != 0; a.a_vec = A && aligned16(A) && (lda % 4 == 0);
@@ -260,8 +355,10 @@ extern "C" int tfr_tower_gemm_f32(const float* A, long lda, int a_k_contiguous, 
   a.k_per_split = kps;
   if (S > 1) { a.C = workspace; a.ldc = N; a.slab = (long)M * N; a.bias = nullptr; }
   else { a.C = C; a.ldc = ldc; a.slab = 0; a.bias = bias; }
-  hipStream_t st = (hipStream_t)stream;
-  const dim3 grid((unsigned)(a.chunk * 8), (unsigned)S), block(256);
+  a.S = S;
+  const long nblk = S == 1 ? (long)a.chunk * 8 : 8L * tiles * ((S + 7) / 8);
+  if (nblk > (1L << 30)) return TFR_ETOOLARGE;
+  const dim3 grid((unsigned)nblk), block(256);
   if (a.a_kc && a.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, a);
   else if (a.a_kc) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, a);
   else if (a.b_kc) hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, 0, st, a);

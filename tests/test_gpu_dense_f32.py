@@ -25,7 +25,7 @@ def _rel(got, want64, scale64):
 
 
 SHAPES = [(1000, 512, 136), (333, 37, 19), (4096, 512, 512), (130, 1, 512), (1, 7, 3), (257, 129, 17), (5000, 3, 250),
-          (128, 128, 16), (129, 130, 4100)]
+          (128, 128, 16), (129, 130, 4100), (70000, 2, 300), (4097, 4, 33), (300000, 1, 64)]
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
