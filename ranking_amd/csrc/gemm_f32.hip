@@ -107,6 +107,9 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, const int t, c
   }
 }
 
+// (Measured and dropped, profiles/r03_gemm_f32.txt: pairing rows j and j + 8 in one MFMA so that the two half-waves read
+// banks 32 apart, and reading the next group's fragments ahead of the current MFMAs -- each within +-5 % on every
+// product: neither LDS bank conflicts nor fragment latency is what holds the loop at two thirds of the MFMA peak.)
 template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
   __shared__ __attribute__((aligned(16))) float As[2][kBK * kLdp];
@@ -289,6 +292,79 @@ __global__ __launch_bounds__(256) void dense_thin_wgrad_stage1_kernel(const floa
   }
 }
 
+// The same two reductions with 16-byte loads (columns a multiple of 4, pitch and pointer 16-byte aligned): the 256
+// threads of a block cover C = min(N / 4, 256) column quads x 256 / C row phases, four rows of a phase in flight
+// (64 B per lane), the row phases meet in LDS in ascending order.  partial[block][NN][N]; WEIGHTED: out[n, :] =
+// sum_r w[r, n] X[r, :] (the weight gradient of output_units <= 4), else NN = 1 and out = sum_r X[r, :].
+template <int NN, bool WEIGHTED>
+__global__ __launch_bounds__(256) void rowsum_v4_stage1_kernel(const float* __restrict__ X, const long ldx,
+                                                               const float* __restrict__ W, const long ldw, const int M,
+                                                               const int N, const int rows_per,
+                                                               float* __restrict__ partial) {
+  __shared__ float4 red[256];
+  const int N4 = N >> 2;
+  const int C = N4 < 256 ? N4 : 256;
+  const int RP = 256 / C;
+  const int c = threadIdx.x % C, rp = threadIdx.x / C;
+  const int r0 = blockIdx.x * rows_per;
+  const int r1 = min(M, r0 + rows_per);
+  for (int cb = 0; cb < N4; cb += C) {
+    const int cq = cb + c;
+    const bool active = rp < RP && cq < N4;
+    float4 acc[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+      const float* __restrict__ p = X + 4 * cq;
+      int r = r0 + rp;
+      for (; r + 3 * RP < r1; r += 4 * RP) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (long)(r + u * RP) * ldx);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int n = 0; n < NN; ++n) {
+            const float wv = WEIGHTED ? W[(long)(r + u * RP) * ldw + n] : 1.0f;
+            if (WEIGHTED) {
+              acc[n].x = fmaf(wv, v[u].x, acc[n].x); acc[n].y = fmaf(wv, v[u].y, acc[n].y);
+              acc[n].z = fmaf(wv, v[u].z, acc[n].z); acc[n].w = fmaf(wv, v[u].w, acc[n].w);
+            } else {
+              acc[n].x += v[u].x; acc[n].y += v[u].y; acc[n].z += v[u].z; acc[n].w += v[u].w;
+            }
+          }
+      }
+      for (; r < r1; r += RP) {
+        const float4 v = *reinterpret_cast<const float4*>(p + (long)r * ldx);
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+          const float wv = WEIGHTED ? W[(long)r * ldw + n] : 1.0f;
+          if (WEIGHTED) {
+            acc[n].x = fmaf(wv, v.x, acc[n].x); acc[n].y = fmaf(wv, v.y, acc[n].y);
+            acc[n].z = fmaf(wv, v.z, acc[n].z); acc[n].w = fmaf(wv, v.w, acc[n].w);
+          } else {
+            acc[n].x += v.x; acc[n].y += v.y; acc[n].z += v.z; acc[n].w += v.w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NN; ++n) {
+      red[threadIdx.x] = acc[n];
+      __syncthreads();
+      if (active && rp == 0) {
+        float4 s4 = red[c];
+        for (int q = 1; q < RP; ++q) {
+          const float4 o = red[q * C + c];
+          s4.x += o.x; s4.y += o.y; s4.z += o.z; s4.w += o.w;
+        }
+        *reinterpret_cast<float4*>(partial + ((long)blockIdx.x * NN + n) * N + 4 * cq) = s4;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -331,7 +407,10 @@ extern "C" int tfr_tower_gemm_f32(const float* A, long lda, int a_k_contiguous, 
     // its weight gradient: dW[M <= 4, N] = dy^T . x over K rows; `splits` partial slabs of [M, N]
     const int rows_per = (K + splits - 1) / splits;
     const int T = (K + rows_per - 1) / rows_per;
-#define TFR_THIN_WG(NN) hipLaunchKernelGGL((dense_thin_wgrad_stage1_kernel<NN>), dim3(T), dim3(256), 0, st, A, lda, B, ldb, K, N, rows_per, workspace)
+    const bool v4 = (N % 4 == 0) && (ldb % 4 == 0) && aligned16(B) && aligned16(workspace);
+#define TFR_THIN_WG(NN) do { \
+      if (v4) hipLaunchKernelGGL((rowsum_v4_stage1_kernel<NN, true>), dim3(T), dim3(256), 0, st, B, ldb, A, lda, K, N, rows_per, workspace); \
+      else hipLaunchKernelGGL((dense_thin_wgrad_stage1_kernel<NN>), dim3(T), dim3(256), 0, st, A, lda, B, ldb, K, N, rows_per, workspace); } while (0)
     if (M == 1) TFR_THIN_WG(1); else if (M == 2) TFR_THIN_WG(2); else if (M == 3) TFR_THIN_WG(3); else TFR_THIN_WG(4);
 #undef TFR_THIN_WG
     const int rc = (int)hipGetLastError();
@@ -386,7 +465,11 @@ extern "C" int tfr_tower_colsum_f32(const float* X, long ldx, int M, int N, floa
   const int rows_per = M > 0 ? (M + T - 1) / T : 1;
   const int Tu = M > 0 ? (M + rows_per - 1) / rows_per : 0;
   if (Tu > 0) {
-    hipLaunchKernelGGL(colsum_f32_stage1_kernel, dim3(Tu), dim3(256), 0, st, X, ldx, M, N, rows_per, partial);
+    if ((N % 4 == 0) && (ldx % 4 == 0) && aligned16(X) && aligned16(partial))
+      hipLaunchKernelGGL((rowsum_v4_stage1_kernel<1, false>), dim3(Tu), dim3(256), 0, st, X, ldx, (const float*)nullptr, 0L,
+                         M, N, rows_per, partial);
+    else
+      hipLaunchKernelGGL(colsum_f32_stage1_kernel, dim3(Tu), dim3(256), 0, st, X, ldx, M, N, rows_per, partial);
     const int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
   }
