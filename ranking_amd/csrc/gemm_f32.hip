@@ -111,7 +111,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, const int t, c
 // banks 32 apart, and reading the next group's fragments ahead of the current MFMAs -- each within +-5 % on every
 // product: neither LDS bank conflicts nor fragment latency is what holds the loop at two thirds of the MFMA peak.)
 template <bool AKC, bool BKC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmF32Args a) {
+__global__ __launch_bounds__(256, 4) void gemm_f32_kernel(const GemmF32Args a) {
   __shared__ __attribute__((aligned(16))) float As[2][kBK * kLdp];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBK * kLdp];
   // Workgroup ids round-robin over the 8 XCDs (each with its own L2).
@@ -372,13 +372,13 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 extern "C" int tfr_tower_colsum_rows(int M);
 
 extern "C" int tfr_tower_gemm_f32_splits(int M, int N, int K) {
-  // One resident round of workgroups: 140 registers and 33 KB of LDS allow three 256-thread workgroups per CU = 768 on
-  // the chip; 1 024 equal workgroups would run as a full round plus a third of one (measured: 75 TFLOP/s against the
-  // forward product's 105).  At least 16 k tiles per slab.
+  // One resident round of workgroups: four 256-thread workgroups per CU (<= 128 registers, 33 KB of LDS each) = 1 024 on
+  // the chip; a count that needs a partial second round wastes it (measured with three per CU: 1 024 equal workgroups
+  // ran as a round and a third, 75 TFLOP/s against 86-89 with 768).  At least 16 k tiles per slab.
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   if (M <= 4) return tfr_tower_colsum_rows(K);      // the thin weight gradient: one partial slab per run of rows
   const long tiles = (long)((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
-  long s = 768 / tiles;
+  long s = 1024 / tiles;
   const long smax = (K + 16 * kBK - 1) / (16 * kBK);
   if (s > smax) s = smax;
   if (s > 256) s = 256;
