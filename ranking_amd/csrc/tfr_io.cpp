@@ -149,16 +149,21 @@ struct SpecTable {
 
 // Feature { oneof kind { BytesList bytes_list = 1; FloatList float_list = 2; Int64List int64_list = 3; } }
 // Writes exactly `width` values; returns 0, TFR_IO_ESHAPE, TFR_IO_ETYPE or TFR_IO_ECORRUPT.
-int decode_feature(const uint8_t* b, size_t n, int width, float* out) {
+// `payload_at`: set to the offset of the 4 * width payload bytes inside `b` when one of the two fixed-image fast
+// paths decoded the feature (the only cases the example template below can replay), -1 otherwise.
+int decode_feature(const uint8_t* b, size_t n, int width, float* out, int* payload_at) {
   // Fast paths for what TensorFlow writes for a float feature of `width` values, all lengths < 128:
   //   packed    12 <4w+2> 0a <4w> <4w bytes>          unpacked (w = 1)   12 05 0d <4 bytes>
   const size_t pw = (size_t)width * 4;
+  *payload_at = -1;
   if (pw + 2 < 128 && n == pw + 4 && b[0] == 0x12 && b[1] == pw + 2 && b[2] == 0x0a && b[3] == pw) {
     memcpy(out, b + 4, pw);
+    *payload_at = 4;
     return 0;
   }
   if (width == 1 && n == 7 && b[0] == 0x12 && b[1] == 5 && b[2] == 0x0d) {
     memcpy(out, b + 3, 4);
+    *payload_at = 3;
     return 0;
   }
   Reader r(b, n);
@@ -226,9 +231,95 @@ int decode_feature(const uint8_t* b, size_t n, int width, float* out) {
   return count == width ? 0 : TFR_IO_ESHAPE;
 }
 
+#if defined(__x86_64__)
+// ((a ^ t) & m) == 0 over `len` bytes, 64 bytes per iteration (chosen at run time like the crc above)
+__attribute__((target("avx2"))) bool masked_equal_avx2(const uint8_t* a, const uint8_t* t, const uint8_t* m, size_t len) {
+  typedef long long v4 __attribute__((vector_size(32), aligned(1), may_alias));
+  v4 acc = {0, 0, 0, 0};
+  size_t i = 0;
+  for (; i + 64 <= len; i += 64) {
+    const v4 a0 = *reinterpret_cast<const v4*>(a + i), a1 = *reinterpret_cast<const v4*>(a + i + 32);
+    const v4 t0 = *reinterpret_cast<const v4*>(t + i), t1 = *reinterpret_cast<const v4*>(t + i + 32);
+    const v4 m0 = *reinterpret_cast<const v4*>(m + i), m1 = *reinterpret_cast<const v4*>(m + i + 32);
+    acc |= ((a0 ^ t0) & m0) | ((a1 ^ t1) & m1);
+  }
+  uint64_t tail = 0;
+  for (; i < len; ++i) tail |= (uint64_t)((a[i] ^ t[i]) & m[i]);
+  return (acc[0] | acc[1] | acc[2] | acc[3] | (long long)tail) == 0;
+}
+#endif
+
+// Example template.  The examples of one file are written by one writer: same features, same order, same lengths --
+// only the value bytes differ.  After a generic parse in which every feature the spec names came through one of the
+// fixed-image fast paths of decode_feature, the example's bytes are kept together with a mask that is zero on every
+// byte the generic parser never interprets (the float payloads of the named features, the whole value of the features
+// the spec does not name) and a list of (payload offset -> column) copies.  The next example of the same length whose
+// unmasked bytes are identical has, byte for byte, the structure the generic parser would walk -- its control flow
+// depends on nothing else -- so the parse is: defaults, then the copies, in the same order (a repeated key still lets
+// the later entry win).  Anything else (a missing feature, an int64 list, another length) falls back to the generic
+// parse, which re-arms the template.  Per worker thread; `streak` stops the re-arming on data that never repeats.
+struct ExampleTemplate {
+  struct Copy { uint32_t src, dst, len; };
+  std::vector<uint8_t> bytes, mask;                       // padded to a multiple of 8
+  std::vector<Copy> copies;
+  size_t n = 0;
+  bool valid = false;
+  int streak = 0;                                         // consecutive generic parses that matched no template
+  // scratch of the generic parse that may arm the template
+  std::vector<Copy> rec_copies;
+  std::vector<std::pair<uint32_t, uint32_t>> rec_skips;  // (offset, length) of never-interpreted value bytes
+  bool matches(const uint8_t* b, size_t len) const {
+    if (!valid || len != n) return false;
+    const uint8_t* t = bytes.data(); const uint8_t* m = mask.data();
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) return masked_equal_avx2(b, t, m, len);
+#endif
+    uint64_t acc = 0;
+    size_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+      uint64_t a0, a1, a2, a3, t0, t1, t2, t3, m0, m1, m2, m3;
+      memcpy(&a0, b + i, 8); memcpy(&a1, b + i + 8, 8); memcpy(&a2, b + i + 16, 8); memcpy(&a3, b + i + 24, 8);
+      memcpy(&t0, t + i, 8); memcpy(&t1, t + i + 8, 8); memcpy(&t2, t + i + 16, 8); memcpy(&t3, t + i + 24, 8);
+      memcpy(&m0, m + i, 8); memcpy(&m1, m + i + 8, 8); memcpy(&m2, m + i + 16, 8); memcpy(&m3, m + i + 24, 8);
+      acc |= ((a0 ^ t0) & m0) | ((a1 ^ t1) & m1) | ((a2 ^ t2) & m2) | ((a3 ^ t3) & m3);
+    }
+    for (; i < len; ++i) acc |= (uint64_t)((b[i] ^ t[i]) & m[i]);
+    return acc == 0;
+  }
+  void arm(const uint8_t* b, size_t len) {
+    n = len;
+    bytes.assign(b, b + len); bytes.resize((len + 7) / 8 * 8 + 32, 0);
+    mask.assign(bytes.size(), 0);
+    memset(mask.data(), 0xff, len);
+    for (const Copy& c : rec_copies) memset(mask.data() + c.src, 0, c.len);
+    for (const auto& sk : rec_skips) memset(mask.data() + sk.first, 0, sk.second);
+    copies = rec_copies;
+    valid = true;
+  }
+};
+
+bool template_enabled() {
+  static const bool on = [] { const char* e = getenv("TFR_IO_TEMPLATE"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 // tf.Example { Features features = 1; }  Features { map<string, Feature> feature = 1; }
-int decode_example(const uint8_t* b, size_t n, const SpecTable& specs, float* row, std::vector<int>& hint) {
+int decode_example(const uint8_t* b, size_t n, const SpecTable& specs, float* row, std::vector<int>& hint,
+                   ExampleTemplate& tpl) {
   specs.fill_defaults(row);
+  const bool use_tpl = template_enabled() && n < (1u << 30);
+  if (use_tpl && tpl.matches(b, n)) {
+    for (const ExampleTemplate::Copy& c : tpl.copies) {
+      if (c.len == 4) { uint32_t v; memcpy(&v, b + c.src, 4); memcpy(row + c.dst, &v, 4); }   // the scalar feature
+      else memcpy(row + c.dst, b + c.src, c.len);
+    }
+    tpl.streak = 0;
+    return 0;
+  }
+  const bool record = use_tpl && tpl.streak < 16;         // data that never repeats: stop paying for the copies
+  bool replayable = record;
+  if (record) { tpl.rec_copies.clear(); tpl.rec_skips.clear(); }
   size_t pos = 0;                                         // index of the map entry inside this example
   Reader r(b, n);
   while (!r.done()) {
@@ -267,19 +358,34 @@ int decode_example(const uint8_t* b, size_t n, const SpecTable& specs, float* ro
       }
       if (!e.ok) return TFR_IO_ECORRUPT;
       const int s = specs.lookup(key, pos++, hint);
-      if (s < 0 || vb == nullptr) continue;
-      const int rc = decode_feature(vb, vn, specs.width[s], row + specs.offset[s]);
+      if (s < 0 || vb == nullptr) {
+        if (replayable && vb != nullptr && vn > 0)        // a feature the spec does not name: its value is never read
+          tpl.rec_skips.emplace_back((uint32_t)(vb - b), (uint32_t)vn);
+        continue;
+      }
+      int payload_at = -1;
+      const int rc = decode_feature(vb, vn, specs.width[s], row + specs.offset[s], &payload_at);
       if (rc < 0) return rc;
       if (rc == 1)                                        // present but empty: default
         for (int k = 0; k < specs.width[s]; ++k) row[specs.offset[s] + k] = specs.dflt[s];
+      if (replayable) {
+        if (payload_at < 0) replayable = false;
+        else tpl.rec_copies.push_back({(uint32_t)(vb - b) + (uint32_t)payload_at, (uint32_t)specs.offset[s],
+                                       (uint32_t)specs.width[s] * 4u});
+      }
     }
     if (!f.ok) return TFR_IO_ECORRUPT;
   }
-  return r.ok ? 0 : TFR_IO_ECORRUPT;
+  if (!r.ok) return TFR_IO_ECORRUPT;
+  if (use_tpl) {
+    ++tpl.streak;
+    if (replayable) tpl.arm(b, n); else tpl.valid = false;
+  }
+  return 0;
 }
 
 // ExampleListWithContext { repeated bytes examples = 1; bytes context = 2; }   (data.py:59-77)
-struct Hints { std::vector<int> example, context; };   // per worker thread
+struct Hints { std::vector<int> example, context; ExampleTemplate example_tpl, context_tpl; };   // per worker thread
 
 int decode_elwc(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, const SpecTable* ctx,
                 float* example_rows, float* context_row, int32_t* size_out, uint8_t* mask_row, Hints& hints) {
@@ -295,12 +401,12 @@ int decode_elwc(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, 
     if (!r.bytes(pb, pn)) return TFR_IO_ECORRUPT;
     if (field == 1) {
       if (count < list_size) {                            // truncation keeps the first list_size (:170-172)
-        const int rc = decode_example(pb, pn, ex, example_rows + (size_t)count * ex.total, hints.example);
+        const int rc = decode_example(pb, pn, ex, example_rows + (size_t)count * ex.total, hints.example, hints.example_tpl);
         if (rc < 0) return rc;
       }
       ++count;
     } else if (ctx && context_row) {
-      const int rc = decode_example(pb, pn, *ctx, context_row, hints.context);
+      const int rc = decode_example(pb, pn, *ctx, context_row, hints.context, hints.context_tpl);
       if (rc < 0) return rc;
       ctx_seen = true;
     }

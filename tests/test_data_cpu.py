@@ -409,3 +409,83 @@ def test_data_parallel_sharding_of_the_record_stream(tmp_path):
         assert all(parts[r] == whole[r:42:3] for r in range(3))
     with pytest.raises(ValueError):
         epoch((3, 3), shuffle=False)
+
+
+def _template_batch(seed):
+    """Lists whose examples repeat one byte structure (what the example template of tfr_io.cpp replays), salted with
+    every way an example can leave it."""
+    rng = np.random.RandomState(seed)
+    names = ['1', '2', '3', 'lab', 'wide', 'cnt']
+    widths = {'1': 1, '2': 1, '3': 1, 'lab': 1, 'wide': 6, 'cnt': 1}
+    tricky = [1.0, -0.0, float(np.frombuffer(b'\x0a\x12\x0d\x05', dtype=np.float32)[0]),
+              float(np.frombuffer(b'\x12\x05\x0d\x0a', dtype=np.float32)[0]), 3.5e-39]     # payloads that look like tags
+    records = []
+    for b in range(20):
+        exs = []
+        for i in range(int(rng.randint(3, 14))):
+            e = {}
+            for k in ['1', '2', 'skip', '3', 'lab', 'wide']:
+                w = widths.get(k, 1)
+                vals = [float(np.float32(rng.randn())) if rng.rand() < 0.8 else tricky[rng.randint(len(tricky))]
+                        for _ in range(w)]
+                e[k] = ('float', vals)
+            roll = rng.rand()
+            if roll < 0.08:
+                del e['2']                                                   # a feature missing: shorter example
+            elif roll < 0.16:
+                e = {('2' if k == '1' else '1' if k == '2' else k): v for k, v in e.items()}   # same length, keys swapped
+            elif roll < 0.24:
+                e['skip'] = ('float', [1.0, 2.0])                            # an unnamed feature of another length
+            elif roll < 0.32:
+                e['cnt'] = ('int64', [int(rng.randint(0, 300))])             # a varint list: not replayable
+            elif roll < 0.40:
+                e['1'] = ('float', [])                                       # present but empty -> default
+            exs.append(e)
+        ctx = {'q': ('float', [float(np.float32(rng.randn()))]), 'other': ('float', [float(rng.randn())])}
+        rec = D.encode_elwc(ctx, exs, packed=(b % 3 != 0))
+        if b % 4 == 1:                                                       # a repeated key inside the repeated structure
+            def with_dup(e):
+                inner = b''.join(D._ld(1, D._ld(1, k.encode()) + D._ld(2, D.encode_feature(kind, vals, True)))
+                                 for k, (kind, vals) in e.items())
+                inner += D._ld(1, D._ld(1, b'3') + D._ld(2, D.encode_feature('float', [e['lab'][1][0] + 7.0], True)))
+                return D._ld(1, D._ld(1, inner))
+            rec = b''.join(with_dup(e) for e in exs) + D._ld(2, D.encode_example(ctx, True))
+            for e in exs:
+                e['3'] = ('float', [e['lab'][1][0] + 7.0])                   # what the oracle must see: the later entry
+        records.append((rec, exs, ctx))
+    return names, widths, records
+
+
+def test_example_template_replay_equals_the_generic_parse():
+    """tfr_io.cpp replays the byte structure of the previous example when the unmasked bytes are identical; whatever
+    leaves the structure (missing / swapped / unnamed-of-another-length / int64 / empty / unpacked features) must fall
+    back.  Checked against the pure-Python oracle with the template on (this process) and off (TFR_IO_TEMPLATE=0 in a
+    child process: the switch is read once)."""
+    import subprocess
+    import sys
+    names, widths, records = _template_batch(11)
+    spec = {k: data.FixedLenFeature([widths[k]], F32, -2.0 - i) for i, k in enumerate(names)}
+    cspec = {'q': data.FixedLenFeature([1], F32, 9.0)}
+    ospec = {k: (widths[k], -2.0 - i) for i, k in enumerate(names)}
+    recs = [r for r, _, _ in records]
+    feats, ctxs, sizes, mask = D.parse_from_example_list(recs, 12, ospec, {'q': (1, 9.0)})
+    for threads in (1, 2):
+        got = data.parse_from_example_list(recs, list_size=12, example_feature_spec=spec, context_feature_spec=cspec,
+                                           size_feature_name='n', mask_feature_name='m', num_threads=threads)
+        for k in names:
+            assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), k
+        assert torch.equal(got['q'], torch.tensor(ctxs['q'], dtype=F32))
+        assert got['n'].tolist() == sizes and got['m'].tolist() == mask
+    code = ("import os, sys, torch; sys.path.insert(0, %r); os.environ['TFR_IO_TEMPLATE'] = '0'\n"
+            "from tests.test_data_cpu import _template_batch, data, F32\n"
+            "names, widths, records = _template_batch(11)\n"
+            "spec = {k: data.FixedLenFeature([widths[k]], F32, -2.0 - i) for i, k in enumerate(names)}\n"
+            "got = data.parse_from_example_list([r for r, _, _ in records], list_size=12, example_feature_spec=spec)\n"
+            "torch.save({k: got[k] for k in names}, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'off.pt')
+        subprocess.run([sys.executable, '-c', code, out], check=True, timeout=300)
+        off = torch.load(out)
+    for k in names:
+        assert torch.equal(off[k], torch.tensor(feats[k], dtype=F32)), k
