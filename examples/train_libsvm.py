@@ -41,6 +41,8 @@ def main():
     ap.add_argument('--num_features', type=int, default=136)             # :90
     ap.add_argument('--list_size', type=int, default=100)                # :91
     ap.add_argument('--loss', default='sigmoid_cross_entropy_loss')      # :93
+    ap.add_argument('--compute_dtype', default='bfloat16', choices=['bfloat16', 'float32'],
+                    help='float32 = the reference\'s own tower precision (fp32 MFMA Dense); bfloat16 = the fused tower')
     args = ap.parse_args()
 
     feats, labels = tfr.data.load_libsvm_data(args.train_path, args.list_size, args.num_features)
@@ -51,7 +53,7 @@ def main():
         def build(self):
             scorer = tfr.keras.model.DNNScorer(input_dim=args.num_features, hidden_layer_dims=hidden, output_units=1,
                                                activation=torch.relu, use_batch_norm=True, dropout=args.dropout_rate,
-                                               compute_dtype=torch.bfloat16)
+                                               compute_dtype=getattr(torch, args.compute_dtype))
 
             class M(torch.nn.Module):
                 def __init__(self):

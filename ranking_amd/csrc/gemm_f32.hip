@@ -16,8 +16,10 @@
 // registers); operands staged k-major in LDS ([16][128 + 4] floats each: the fragment of a wave is one ds_read_b32 per
 // lane over 32 consecutive floats, the +4 keeps the transposing stores of a k-contiguous operand conflict-free), two
 // LDS stages with the next tile's global loads in flight during the 32 MFMAs of the current one.  Per k tile a wave
-// issues 32 MFMAs (2 048 cycles) against 32 ds_read_b32: MFMA-issue bound.  Workgroups are numbered so that the tiles
-// of one row block of A (all N) are neighbours on one XCD and find A in that XCD's L2.
+// issues 32 MFMAs (2 048 cycles) against 32 ds_read_b32: MFMA-issue bound.  Bounded to 128 registers so that FOUR
+// workgroups share a CU (33 KB of LDS each): with three the counters showed the MFMA pipe 73 % busy and the waves parked
+// a quarter of their time on the per-tile barrier / s_waitcnt (profiles/r03_gemm_f32_pmc.txt).  Workgroups are numbered
+// so that the tiles of one row block of A (all N) are neighbours on one XCD and find A in that XCD's L2.
 #include "common.h"
 #include "../../include/tfr_hip.h"
 
