@@ -2,7 +2,7 @@
 (keras/layers.py:26-77); `create_tower(compute_dtype=float32)` now runs hand-written MFMA kernels forward and backward.
 
 Bars: every product against the same product evaluated in float64, error relative to sum_k |a_k| |b_k| (the scale
-fp32 accumulation works at) <= 1e-6 -- an fp32 fma chain over K <= 4096 sits at 1e-7 (measured <= 2.7e-7) -- and the
+fp32 accumulation works at) <= 1e-6 -- an fp32 fma chain over K <= 4096 sits at 1e-7 (measured <= 3.4e-7) -- and the
 whole fp32 tower, logits and every gradient, within 1e-5 of the fp32 torch-op replica (north_star's floating-point
 bar; measured <= 1.3e-6 with a smooth activation; ReLU: see the kink note below).
 """
