@@ -319,3 +319,36 @@ def test_list_size_limits_in_the_header_are_the_ones_the_launchers_test():
                 assert m.group(1) in macros or m.group(1) == 'TFR_MAX_LIST', (f, ln.strip())
     common = open(os.path.join(csrc, 'common.h')).read()
     assert int(re.search(r'#define TFR_MAX_LIST (\d+)', common).group(1)) == macros['TFR_MAX_LIST_SIZE']
+
+
+def test_fp32_dense_argument_checks_and_slab_proposals():
+    """tfr_tower_gemm_f32 / tfr_tower_colsum_f32 reject bad arguments before any launch; the slab-count proposals are
+    host arithmetic: one resident round of workgroups (four per CU on 256 CUs), at least 16 k tiles per slab, the thin
+    weight gradient (output_units <= 4) by runs of rows.  No GPU needed."""
+    lib = _lib.load()
+    one = ctypes.c_void_p(256)
+    g = lib.tfr_tower_gemm_f32
+    assert g(one, 8, 1, one, 8, 1, one, 8, -1, 8, 8, None, 1, None, None) == -1          # M < 0
+    assert g(one, 8, 1, one, 8, 1, one, 8, 4, 8, 8, None, 0, None, None) == -1           # splits < 1
+    assert g(one, 8, 1, one, 8, 1, one, 4, 4, 8, 8, None, 1, None, None) == -1           # ldc < N
+    assert g(one, 4, 1, one, 8, 1, one, 8, 4, 8, 8, None, 1, None, None) == -1           # lda < K (k-contiguous A)
+    assert g(one, 2, 0, one, 8, 1, one, 8, 4, 8, 8, None, 1, None, None) == -1           # lda < M (row-contiguous A)
+    assert g(one, 8, 1, one, 4, 0, one, 8, 4, 8, 8, None, 1, None, None) == -1           # ldb < N (column-contiguous B)
+    assert g(None, 8, 1, one, 8, 1, one, 8, 4, 8, 8, None, 1, None, None) == -1          # A missing with K > 0
+    assert g(one, 8, 1, one, 8, 1, None, 8, 4, 8, 8, None, 1, None, None) == -1          # C missing
+    assert g(one, 8, 1, one, 8, 1, one, 8, 0, 8, 8, None, 1, None, None) == 0            # M == 0: nothing to do
+    assert g(one, 8192, 0, one, 512, 0, one, 512, 512, 512, 8192, None, 8, None, None) == -1   # slabs without a workspace
+    c = lib.tfr_tower_colsum_f32
+    assert c(one, 4, 8, 8, one, one, None) == -1                                          # ldx < N
+    assert c(one, 8, 8, 8, None, one, None) == -1                                         # no scratch
+    assert c(one, 8, 8, 0, one, one, None) == 0
+    s = lib.tfr_tower_gemm_f32_splits
+    assert s(512, 512, 409600) == 64             # 16 tiles x 64 slabs = 1 024 workgroups
+    assert s(512, 136, 409600) == 128            # 4 x 2 tiles
+    assert s(512, 512, 1000) == 4                # at least 16 k tiles (256 rows) per slab
+    assert s(512, 512, 100) == 1
+    assert s(4096, 4096, 4096) == 1              # already 1 024 tiles
+    assert s(1, 512, 409600) == 1024 and s(4, 64, 3000) == 12     # thin weight gradient: rows / 256, capped
+    assert s(0, 5, 5) == 1
+    r = lib.tfr_tower_colsum_rows
+    assert r(0) == 1 and r(1) == 1 and r(257) == 2 and r(409600) == 1024
