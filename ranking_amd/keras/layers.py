@@ -29,11 +29,24 @@ class _Activation(nn.Module):
         return x if self._fn is None else self._fn(x)
 
 
+class _LayerStack(nn.Sequential):
+    """The unfused Dense -> BatchNorm -> activation -> Dropout stack.  Keras layers act on the LAST axis of an input
+    of any rank (keras/layers_test.py:25-30 feeds [batch, list, 1]); torch's BatchNorm1d reads axis 1 of a 3-D input
+    as the channels, so inputs are flattened to [rows, features] here and restored."""
+
+    def forward(self, x):
+        if x.dim() <= 2:
+            return super().forward(x)
+        lead = tuple(x.shape[:-1])
+        y = super().forward(x.reshape(-1, x.shape[-1]))
+        return y.reshape(lead + (y.shape[-1],))
+
+
 def create_tower(hidden_layer_dims: List[int], output_units: int, activation: Optional[Callable] = None,
                  input_batch_norm: bool = False, use_batch_norm: bool = True,
                  batch_norm_moment: float = 0.999, dropout: float = 0.5, name: Optional[str] = None,
                  input_dim: Optional[int] = None, compute_dtype: torch.dtype = torch.float32,
-                 **kwargs) -> nn.Sequential:
+                 **kwargs) -> nn.Module:
     """keras/layers.py:26-77.  ``input_dim`` is required up front (torch layers are
     not lazily shaped); Keras' BatchNormalization(momentum=m, epsilon=1e-3) maps to
     torch BatchNorm1d(momentum=1-m, eps=1e-3)."""
@@ -65,7 +78,7 @@ def create_tower(hidden_layer_dims: List[int], output_units: int, activation: Op
             layers.append(nn.Dropout(p=dropout))
         width = layer_width
     layers.append(make_dense(width, output_units, compute_dtype))
-    return nn.Sequential(*layers)
+    return _LayerStack(*layers)
 
 
 class FlattenList(nn.Module):

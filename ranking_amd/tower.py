@@ -352,6 +352,10 @@ class FusedTower(nn.Module):
     def forward(self, x: torch.Tensor, row_index: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``row_index`` (int [M]): score row ``row_index[m]`` of ``x`` at position m -- the gather of
         ``FlattenList``'s circular padding, fused into the input cast."""
+        lead = None
+        if x.dim() > 2 and row_index is None:              # Keras Dense / BatchNormalization act on the last axis:
+            lead = tuple(x.shape[:-1])                     # [..., F] is [prod(...), F] (keras/layers_test.py:25-30)
+            x = x.reshape(-1, x.shape[-1])
         if x.dim() != 2 or x.shape[1] not in (self.input_dim, T.pad8(self.input_dim), T.pad_k(self.input_dim)):
             raise ValueError('expected [M, %d] features, got %s' % (self.input_dim, tuple(x.shape)))
         params = list(self.weights) + list(self.biases)
@@ -362,4 +366,5 @@ class FusedTower(nn.Module):
                 raise ValueError('input_batch_norm needs the raw fp32 [M, %d] features' % self.input_dim)
             params += [self.gamma_in, self.beta_in]
         params += [self.out_weight, self.out_bias]
-        return _TowerFn.apply(x, self, self.training, row_index, *params)
+        out = _TowerFn.apply(x, self, self.training, row_index, *params)
+        return out if lead is None else out.reshape(lead + (out.shape[-1],))

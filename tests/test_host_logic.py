@@ -180,7 +180,7 @@ def test_ragged_to_dense_and_indices():   # utils.py:421-443, 203-356
     assert org.tolist() == [[1, 2, 0]]
 
 
-def test_flatten_restore_and_tower_shapes():   # keras/layers.py:87-108,195-216
+def test_flatten_restore_and_tower_shapes():   # keras/layers.py:87-108,195-216 = keras/layers_test.py:25-30,34-90,109-135,156-166
     import math
     L = ra.keras.layers
     ctx = {'c': torch.tensor([[1.], [0.]])}
@@ -198,10 +198,27 @@ def test_flatten_restore_and_tower_shapes():   # keras/layers.py:87-108,195-216
     assert torch.allclose(L.RestoreList()((doc, mask)), torch.tensor([[1., .5, e], [0., e, e]]))
     assert torch.allclose(L.RestoreList(by_scatter=True)((doc, mask)),
                           torch.tensor([[1.5, .5, e], [-1. / 3., e, e]]))
+    fc, fe = L.FlattenList(circular_padding=False)((ctx, ex, mask))            # keras/layers_test.py:58-80
+    assert fc['c'].reshape(-1).tolist() == [1., 1., 1., 0., 0., 0.]
+    assert fe['e'].reshape(-1).tolist() == [1., 0., -1., 0., 1., 0.]
+    doc2 = doc.reshape(6, 1)                                                    # keras/layers_test.py:116-120,129-135
+    assert torch.allclose(L.RestoreList()((doc2, mask)), torch.tensor([[1., .5, e], [0., e, e]]))
+    assert torch.allclose(L.RestoreList(by_scatter=True)((doc2, mask)), torch.tensor([[1.5, .5, e], [-1. / 3., e, e]]))
     with pytest.raises(ValueError):
         L.FlattenList()(({}, {}, mask))
     with pytest.raises(ValueError):
+        L.FlattenList()((ctx, {}, mask))                                        # keras/layers_test.py:82-90
+    with pytest.raises(ValueError):
         L.RestoreList()((torch.zeros(5), mask))
+    with pytest.raises(ValueError):
+        L.RestoreList()((torch.zeros(4, 2), mask))                              # keras/layers_test.py:156-166
+    assert L.FlattenList().get_config() == {'circular_padding': True}           # :92-97, :137-141 (serialisation = config)
+    assert L.RestoreList(by_scatter=True).get_config() == {'by_scatter': True}
+    t3 = L.create_tower([3, 2, 1], 1, input_dim=1)                              # keras/layers_test.py:25-30
+    x3 = torch.tensor([[[1.], [0.], [-1.]], [[0.], [1.], [0.]]])
+    t3.eval()
+    assert t3(x3).shape == (2, 3, 1)                                            # the last axis is the feature axis
+    assert torch.equal(t3(x3).reshape(6, 1), t3(x3.reshape(6, 1)))
     tower = L.create_tower([8, 4], 1, activation=torch.relu, input_dim=3)
     assert tower(torch.zeros(6, 3)).shape == (6, 1)
     scorer = ra.keras.model.DNNScorer(input_dim=2, hidden_layer_dims=[4], output_units=1,

@@ -821,3 +821,62 @@ def test_poly_one_softmax_reference_literal():
     s0, s1 = _softmax_py(scores[0])[2], _softmax_py(scores[1])[2]
     want = -((math.log(s0) - 3 * (1 - s0)) + (math.log(s1) - 3 * (1 - s1)) * 2.) / 2.
     assert abs(got.item() - want) < 1e-5
+
+
+# ------------------------------------------------------------------ round 3: the remaining in-scope literals of
+# losses_impl_test.py (hinge / soft zero-one with lambda weights, invalid labels and masks; sigmoid cross-entropy;
+# the pointwise compute_per_list).  The reference tests of Ordinal / MultiClass / ClickEM / MixtureEM /
+# CoupledRankDistil losses are out of scope ("--").
+@pytest.mark.parametrize('ctor,fn', [
+    (R.PairwiseHingeLoss, lambda x: max(0, 1. - x)),                   # losses_impl_test.py:772-788
+    (R.PairwiseSoftZeroOneLoss, lambda x: 1 / (1 + math.exp(x))),     # losses_impl_test.py:862-878
+])
+def test_pairwise_hinge_and_soft_zero_one_with_lambda_weights(ctor, fn):
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 0., 2.]]
+    got = ctor(lambda_weight=R.DCGLambdaWeight()).compute(labels, scores, None, R.Reduction.MEAN)
+    want = (((3. / 2.) * fn(3. - 2.) + (3. / 2.) * fn(1. - 2.)) + ((1. / 1.) * fn(3. - 1.) + (3. / 1.) * fn(3. - 2.))) \
+        / ((3. / 2.) + (3. / 2.) + (1. / 1.) + (3. / 1.))
+    assert abs(got.item() - want) < 1e-6
+
+
+@pytest.mark.parametrize('ctor,fn', [
+    (R.PairwiseHingeLoss, lambda x: max(0, 1. - x)),                   # losses_impl_test.py:790-816
+    (R.PairwiseSoftZeroOneLoss, lambda x: 1 / (1 + math.exp(x))),     # losses_impl_test.py:880-903
+])
+def test_pairwise_hinge_and_soft_zero_one_invalid_labels_and_mask(ctor, fn):
+    got = ctor().compute([[0., -1., 1.]], [[1., 3., 2.]], None, R.Reduction.MEAN)
+    assert abs(got.item() - fn(2. - 1.)) < 1e-5
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[1., 0., 0.], [0., 0., 2.]]
+    mask = [[True, False, True], [True, True, True]]
+    got = ctor().compute(labels, scores, None, R.Reduction.MEAN, mask)
+    assert abs(got.item() - (fn(1. - 2.) + fn(3. - 1.) + fn(3. - 2.)) / 3.) < 1e-6
+
+
+def _sigmoid_ce(labels, logits):  # losses_impl_test.py:111-117
+    return sum(max(x, 0) - x * y + math.log(1 + math.exp(-abs(x))) for y, x in zip(labels, logits))
+
+
+def test_sigmoid_cross_entropy_reference_literals():  # losses_impl_test.py:1376-1418
+    scores = [[0.2, 0.5, 0.3], [0.2, 0.3, 0.5], [0.2, 0.3, 0.5]]
+    labels = [[0., 0., 1.], [0., 0., 2.], [0., 0., 0.]]
+    red = R.Reduction.SUM_BY_NONZERO_WEIGHTS
+    per = [_sigmoid_ce(l, s) for l, s in zip(labels, scores)]
+    got = R.SigmoidCrossEntropyLoss().compute(labels, scores, None, red)
+    assert abs(got.item() - sum(per) / 9.) < 1e-5
+    got = R.SigmoidCrossEntropyLoss().compute(labels, scores, [[2.], [1.], [1.]], red)
+    assert abs(got.item() - (2. * per[0] + per[1] + per[2]) / 9.) < 1e-5
+    want = (math.log(1. + math.exp(-2.)) + math.log(1. + math.exp(1.))) / 2.
+    got = R.SigmoidCrossEntropyLoss().compute([[0., -1., 1.]], [[1., 3., 2.]], None, red)          # :1395-1404
+    assert abs(got.item() - want) < 1e-5
+    got = R.SigmoidCrossEntropyLoss().compute([[0., 1., 1.]], [[1., 3., 2.]], None, red, [[True, False, True]])   # :1406-1418
+    assert abs(got.item() - want) < 1e-5
+
+
+def test_pointwise_compute_per_list():  # losses_impl_test.py:517-528
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 0., 2.]]
+    losses, weights = R.SigmoidCrossEntropyLoss().compute_per_list(labels, scores, [[2., 3., 4.], [1., 1., 1.]])
+    close(losses, [1.3644443, 0.16292572])
+    close(weights, [9., 3.])
