@@ -369,3 +369,35 @@ def test_fp32_dense_argument_checks_and_slab_proposals():
     assert s(0, 5, 5) == 1
     r = lib.tfr_tower_colsum_rows
     assert r(0) == 1 and r(1) == 1 and r(257) == 2 and r(409600) == 1024
+
+
+def test_utils_reference_literals():
+    """The deterministic literals of python/utils_test.py for the helpers the path keeps on the host (the shuffled
+    variants draw from TF's random stream and are checked structurally elsewhere)."""
+    U = ra.utils
+    assert U.is_label_valid(torch.tensor([[1.0, 0.0, -1.0]])).tolist() == [[True, True, False]]        # utils_test.py:30-34
+    feat = torch.tensor([[[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]], [[10., 20., 30.], [40., 50., 60.], [70., 80., 90.]]])
+    got = U.gather_per_row(feat, torch.tensor([[1, 2, 0], [2, 1, 0]]))                                 # utils_test.py:47-62
+    assert got.tolist() == [[[4., 5., 6.], [7., 8., 9.], [1., 2., 3.]], [[70., 80., 90.], [40., 50., 60.], [10., 20., 30.]]]
+    got = U.gather_per_row(feat, torch.tensor([[2, 0], [1, 0]]))
+    assert got.tolist() == [[[7., 8., 9.], [1., 2., 3.]], [[40., 50., 60.], [10., 20., 30.]]]
+    ids = torch.tensor([[1, 2, 3], [4, 5, 6]])                                                         # utils_test.py:36-45 (ids for names)
+    assert U.gather_per_row(ids, torch.tensor([[1, 2, 0], [2, 1, 0]])).tolist() == [[2, 3, 1], [6, 5, 4]]
+    assert U.gather_per_row(ids, torch.tensor([[2, 0], [1, 0]])).tolist() == [[3, 1], [5, 4]]
+    is_valid = U.is_label_valid(torch.tensor([[1.0, 0.0, -1.0], [-1.0, 1.0, 2.0]]))                    # utils_test.py:156-165
+    assert U.organize_valid_indices(is_valid, shuffle=False).tolist() == [[0, 1, 2], [1, 2, 0]]       # (column of the nd index)
+    assert U.reshape_to_2d(torch.tensor([[[1], [2], [3]], [[4], [5], [6]]])).tolist() == [[1, 2, 3], [4, 5, 6]]   # :195-201
+    assert U.reshape_to_2d(torch.tensor([1, 2, 3])).tolist() == [[1], [2], [3]]
+    idx, mask = U.padded_nd_indices(torch.tensor([[True, True, True], [True, True, False]]), shuffle=False)   # :221-240
+    assert idx.tolist() == [[0, 1, 2], [0, 1, 0]] and mask.tolist() == [[True, True, True], [True, True, False]]
+    for n, want_i, want_m in ((3, [0, 1, 2], [True] * 3), (2, [0, 1, 0], [True, True, False]), (0, [0, 0, 0], [False] * 3)):
+        valid = torch.arange(3).unsqueeze(0) < n                                                        # utils_test.py:203-219
+        idx, mask = U.padded_nd_indices(valid, shuffle=False)
+        assert idx.tolist() == [want_i] and mask.tolist() == [want_m]
+    l, p, w, m = U.ragged_to_dense([[0., 1.], [2., 3., 4.]], [[5., 6.], [7., 8., 9.]], [[1., 1.], [2., 1., 2.]])   # :282-295
+    assert l.tolist() == [[0., 1., -1.], [2., 3., 4.]] and p.tolist() == [[5., 6., -1e6], [7., 8., 9.]]
+    assert w.tolist() == [[1., 1., 0.], [2., 1., 2.]] and m.tolist() == [[True, True, False], [True, True, True]]
+    pk = U.parse_keys_and_weights                                                                       # utils_test.py:297-322
+    assert pk('a') == {'a': 1.0} and pk('a :0.9') == {'a': 0.9} and pk('a,b') == {'a': 1., 'b': 1.}
+    assert pk('a, b') == {'a': 1., 'b': 1.} and pk('a, b: 2.') == {'a': 1., 'b': 2.}
+    assert pk('a:0.1,b:0.9') == {'a': 0.1, 'b': 0.9} and pk('a:0.1, b : 0.9') == {'a': 0.1, 'b': 0.9}
