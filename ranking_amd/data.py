@@ -216,6 +216,35 @@ class Prefetcher:
             return [self._map(v, fn) for v in obj]
         return obj
 
+    def _transfer(self, t: torch.Tensor) -> torch.Tensor:
+        if self._cuda:
+            return (t if t.is_cuda else t.pin_memory()).to(self._device, non_blocking=True)
+        return t.to(self._device)
+
+    def _stage(self, batch):
+        """Device copies of every tensor of the batch.  Tensors that are views of ONE host storage -- the per-feature
+        slices ``parse_from_example_list`` cuts out of its dense ``[B, list_size, F]`` array: 137 of them for the
+        reference's one-feature-per-column data -- move with one pinned copy of that storage and are re-cut on the
+        device; staged one by one, every slice is a strided gather over the whole array on the host (137 passes over it)
+        and a copy of its own."""
+        leaves = []
+        self._map(batch, lambda t: (leaves.append(t), t)[1])
+        groups = {}
+        for t in leaves:
+            if not t.is_cuda and t.numel() > 0:
+                groups.setdefault((t.untyped_storage().data_ptr(), t.dtype), []).append(t)
+        moved = {}
+        for (_, dtype), views in groups.items():
+            if len(views) < 2:
+                continue
+            base = torch.empty(0, dtype=dtype).set_(views[0].untyped_storage())      # the whole storage, 1-D
+            if 2 * sum(v.numel() for v in views) < base.numel():                     # a few small views of a big array
+                continue
+            on_device = self._transfer(base)
+            for v in views:
+                moved[id(v)] = on_device.as_strided(v.size(), v.stride(), v.storage_offset())
+        return self._map(batch, lambda t: moved[id(t)] if id(t) in moved else self._transfer(t))
+
     def _put(self, item) -> bool:
         while not self._stop.is_set():
             try:
@@ -233,12 +262,11 @@ class Prefetcher:
                 event = None
                 if self._cuda:
                     with torch.cuda.stream(self._stream):
-                        batch = self._map(batch, lambda t: (t if t.is_cuda else t.pin_memory()).to(
-                            self._device, non_blocking=True))
+                        batch = self._stage(batch)
                         event = torch.cuda.Event()
                         event.record(self._stream)
                 elif self._device is not None:
-                    batch = self._map(batch, lambda t: t.to(self._device))
+                    batch = self._stage(batch)
                 if not self._put((batch, event)):
                     return
             self._put(self._END)

@@ -489,3 +489,30 @@ def test_example_template_replay_equals_the_generic_parse():
         off = torch.load(out)
     for k in names:
         assert torch.equal(off[k], torch.tensor(feats[k], dtype=F32)), k
+
+
+def test_prefetcher_moves_the_slices_of_one_array_with_one_copy(monkeypatch):
+    """Per-feature views of the parser's dense array are staged as ONE transfer of their storage and re-cut on the
+    other side; lone tensors, small views of a big array and non-tensors take the plain path.  (Host-only: the
+    transfer is replaced by a counting clone.)"""
+    base = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)
+    feats = {'a': base[:, :, 0:1], 'b': base[:, :, 1:4], 'c': base[:, :, 4:5]}
+    lone = torch.arange(6, dtype=torch.int32).reshape(2, 3)
+    big = torch.zeros(1000)
+    batch = ({**feats, 'n': lone, 'tiny': big[3:5], 'tiny2': big[7:9], 'name': 'x'}, lone.clone())
+    calls = []
+
+    def counting_transfer(self, t):
+        calls.append(tuple(t.shape))
+        return t.clone()
+    monkeypatch.setattr(data.Prefetcher, '_transfer', counting_transfer)
+    pf = data.Prefetcher(iter([batch]), buffer_size=1, device='cpu')
+    got = list(pf)[0]
+    assert (30,) in calls and calls.count((30,)) == 1                      # the whole [2, 3, 5] storage, once
+    assert (2, 3, 1) not in calls and (2, 3, 3) not in calls                # no per-slice transfer
+    assert calls.count((2,)) == 2                                           # the two small views of `big`: plain path
+    for k in feats:
+        assert torch.equal(got[0][k], feats[k]) and got[0][k].data_ptr() != feats[k].data_ptr()
+    assert got[0]['a'].untyped_storage().data_ptr() == got[0]['b'].untyped_storage().data_ptr()
+    assert torch.equal(got[0]['n'], lone) and torch.equal(got[1], lone) and got[0]['name'] == 'x'
+    assert torch.equal(got[0]['tiny'], big[3:5])
