@@ -45,6 +45,14 @@ class DNNScorer(UnivariateScorer):
         """keras/model.py:712-777.  With the fused tower and one dense example feature the flatten step's
         circular-padding gather (a full copy of the [B, L, F] tensor) is folded into the tower's input cast."""
         from ..tower import FusedTower
+        if not context_features and len(example_features) > 1 and all(
+                torch.is_tensor(v) and v.dim() >= 2 and v.dtype == torch.float32 for v in example_features.values()):
+            # Many per-column features (the reference's data: "1".."136"): concatenate ONCE, in the order
+            # _score_flattened concatenates the flattened columns (:803-813) -- the flatten gather uses one index for
+            # every feature, so flatten(concat) == concat(flatten) -- instead of one gather per feature and a concat.
+            example_features = {'concat': torch.cat(
+                [example_features[k].reshape(example_features[k].shape[0], example_features[k].shape[1], -1)
+                 for k in sorted(example_features)], dim=2)}
         if (isinstance(self._tower, FusedTower) and not context_features and len(example_features) == 1):
             (x,) = example_features.values()
             if torch.is_tensor(x) and x.dim() == 3 and x.dtype == torch.float32:

@@ -145,3 +145,25 @@ def test_create_tower_routes_the_keras_options_to_the_fused_tower():
                           FusedTower)                        # hidden width not a multiple of 8
     assert not isinstance(create_tower([64, 32], 1, activation=torch.relu, input_dim=24, compute_dtype=torch.float32),
                           FusedTower)                        # fp32 compute
+
+
+def test_dnn_scorer_concatenates_many_example_features_once():
+    """No context and several example features: DNNScorer concatenates them once (sorted names, keras/model.py:803-813)
+    and flattens the result -- the same logits as flatten-then-concatenate (the oracle's order), including circular
+    padding of ragged lists and a [B, L] feature without a trailing axis."""
+    g = torch.Generator().manual_seed(9)
+    b, l = 4, 6
+    feats = {'10': torch.randn(b, l, 1, generator=g), '2': torch.randn(b, l, 3, generator=g), 'a': torch.randn(b, l, generator=g)}
+    mask = torch.rand(b, l, generator=g) > 0.35
+    mask[0] = True
+    scorer = ra.keras.model.DNNScorer(input_dim=5, hidden_layer_dims=[7], output_units=1, activation=torch.tanh,
+                                      use_batch_norm=False, dropout=0.)
+    got = scorer({}, feats, mask)
+    lin = [m for m in scorer._tower if isinstance(m, torch.nn.Linear)]
+    cols = [feats[k].reshape(b, l, -1) for k in sorted(feats)]                  # '10' < '2' < 'a'
+    _, fe = R.flatten_list(torch.zeros(b, 0), torch.cat(cols, dim=2), mask)
+    flat = R.dnn_tower(fe, [m.weight.t() for m in lin], [m.bias for m in lin], activation=torch.tanh)
+    assert torch.allclose(got, R.restore_list(flat, mask), atol=1e-6)
+    # and equal to scoring the features one by one through the generic path
+    want = ra.keras.model.UnivariateScorer.forward(scorer, {}, feats, mask)
+    assert torch.allclose(got, want, atol=1e-6)
