@@ -56,7 +56,8 @@ def sort_by_scores(scores, features_list, topn=None, mask=None):
     shuffle_ind = None
     if mask is not None:
         mask = _t(mask, torch.bool)
-        scores = torch.where(mask, scores, scores.min())          # :150 (global min)
+        # :150 (global min; TF reduces an empty tensor to +inf, torch refuses it)
+        scores = torch.where(mask, scores, scores.min() if scores.numel() else scores.new_tensor(float('inf')))
         shuffle_ind = _get_shuffle_indices(scores.shape, mask)
         scores = torch.gather(scores, 1, shuffle_ind)
     # tf.math.top_k(sorted=True): descending, ties -> lower index first.
@@ -1020,6 +1021,14 @@ def _discounted_cumulative_gain(labels, weights, gain_fn=pow_minus_1,
     return rs(weights * gain * discount)
 
 
+def _row_min(x):
+    """tf.reduce_min(x, axis=1, keepdims=True); an empty axis reduces to +inf in TF (metrics_impl_test.py:1498-1506
+    feeds lists without items), torch refuses it."""
+    if x.shape[1] == 0:
+        return torch.full((x.shape[0], 1), float('inf'), dtype=x.dtype)
+    return x.min(dim=1, keepdim=True).values
+
+
 class _RankingMetric:
     """metrics_impl.py:210-310."""
 
@@ -1037,7 +1046,7 @@ class _RankingMetric:
         labels = torch.where(mask, labels, torch.zeros_like(labels))
         predictions = torch.where(
             mask, predictions,
-            -1e-6 * torch.ones_like(predictions) + predictions.min(dim=1, keepdim=True).values)
+            -1e-6 * torch.ones_like(predictions) + _row_min(predictions))
         return labels, predictions, example_weights, mask
 
     def compute(self, labels, predictions, weights=None, mask=None):
@@ -1317,7 +1326,7 @@ class _DivRankingMetric(_RankingMetric):
         if mask.dim() == 3:
             mask = mask.any(dim=2)
         predictions = torch.where(mask, predictions,
-                                  -1e-6 * torch.ones_like(predictions) + predictions.min(dim=1, keepdim=True).values)
+                                  -1e-6 * torch.ones_like(predictions) + _row_min(predictions))
         labels = torch.where(mask.unsqueeze(2), labels, torch.zeros_like(labels))
         weights = torch.tensor(1.0) if weights is None else _t(weights)
         example_weights = torch.ones_like(predictions) * weights

@@ -82,15 +82,28 @@ class _RankingMetric(object, metaclass=abc.ABCMeta):
             mask = torch.as_tensor(mask, device=predictions.device).to(torch.bool)
         return labels, predictions, weights, mask
 
+    @staticmethod
+    def _no_items(predictions, n_cutoffs):
+        """Lists without items (metrics_impl_test.py:1498-1506 feeds ``[[]]``): every sum over an empty list is 0, and
+        so are the per-list weights; nothing to launch."""
+        b = predictions.shape[0]
+        return (torch.zeros((n_cutoffs, b), dtype=torch.float32, device=predictions.device),
+                torch.zeros((b, 1), dtype=torch.float32, device=predictions.device))
+
     def compute(self, labels, predictions, weights=None, mask=None):
         labels, predictions, weights, mask = self._prepare(labels, predictions, weights, mask)
-        out, w = self._compute_multi(labels, predictions, weights, mask, [self._topn])
+        if predictions.shape[1] == 0:
+            out, w = self._no_items(predictions, 1)
+        else:
+            out, w = self._compute_multi(labels, predictions, weights, mask, [self._topn])
         return out[0].unsqueeze(1), w
 
     def compute_multi(self, labels, predictions, weights=None, mask=None,
                       topns: Sequence[Optional[int]] = (None,)):
         """Several cutoffs in ONE launch: returns ([K, B] metric, [B, 1] weights)."""
         labels, predictions, weights, mask = self._prepare(labels, predictions, weights, mask)
+        if predictions.shape[1] == 0:
+            return self._no_items(predictions, len(list(topns)))
         return self._compute_multi(labels, predictions, weights, mask, list(topns))
 
 

@@ -1879,3 +1879,16 @@ def test_softmax_large_batches_against_the_c_arbiter(B, L, wkind):
     l1, w1, g1 = _ops.softmax_loss(d(logits[:n]), d(labels[:n]), None, d(None if w is None else w[:n]), temperature=0.7,
                                    want_grad=True)
     assert torch.equal(loss[:n], l1) and torch.equal(weight[:n], w1) and torch.equal(grad[:n], g1)
+
+
+def test_metrics_of_lists_without_items_are_zero():
+    """metrics_impl_test.py:1498-1506 feeds ``[[]]`` to BPref and expects 0 (TF reduces over nothing); host logic of
+    the metric wrappers, no launch."""
+    mi = ra().metrics_impl
+    z = torch.zeros(2, 0, device=DEV)
+    for metric in (mi.BPrefMetric(None, None), mi.NDCGMetric(None, 10), mi.PrecisionMetric(None, None),
+                   mi.DCGMetric(None, None), mi.MRRMetric(None, None)):
+        out, w = metric.compute(z, z, None)
+        assert out.tolist() == [[0.], [0.]] and w.tolist() == [[0.], [0.]]
+    out, _ = mi.NDCGMetric(None, None).compute_multi(z, z, None, None, [1, 5, None])
+    assert out.shape == (3, 2) and float(out.abs().sum()) == 0.0

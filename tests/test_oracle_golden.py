@@ -590,6 +590,25 @@ def test_more_metrics_reference_literals(case):
         close(w, exp_w, 1e-6)
 
 
+from tests.metric_cases import RAGGED_CASES as _RAGGED_METRIC_CASES
+
+
+@pytest.mark.parametrize('case', _RAGGED_METRIC_CASES, ids=lambda c: '%s:%d' % (c[0], c[6]))
+def test_more_metrics_ragged_reference_literals(case):
+    cls, kw, labels, scores, exp, exp_w, _line = case
+    out, w = getattr(R, cls)(**kw).compute(labels, scores, None)
+    close(out, exp, 1e-6)
+    if exp_w is not None:
+        close(w, exp_w, 1e-6)
+    with pytest.raises(ValueError):                                   # ragged inputs need ragged=True (metrics_impl.py:236-241)
+        getattr(R, cls)(**{k: v for k, v in kw.items() if k != 'ragged'}).compute(labels, scores, None)
+
+
+def test_bpref_is_zero_without_input_items():  # metrics_impl_test.py:1498-1506
+    out, _ = R.BPrefMetric(topn=None).compute(torch.zeros(1, 0), torch.zeros(1, 0), None)
+    close(out, [[0.]], 1e-6)
+
+
 # ------------------------------------------------------------------ ListMLE
 def test_list_mle_reference_literals():
     """losses_impl_test.py:1276-1328 (the tie test :1293-1302 depends on TF's shuffle: unpinned)."""
