@@ -71,6 +71,11 @@ int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengt
                             int32_t n_context, float* example_out, float* context_out,
                             int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads);
 
+/* Process-wide totals of tf.Example messages (examples and contexts) decoded so far by tfr_io_parse_elwc_batch: by
+ * replaying the previous example's byte structure (identical unmasked bytes: defaults + payload copies) and by the
+ * generic protobuf walk.  Observability only -- the two paths return the same rows.  Either pointer may be NULL. */
+void tfr_io_parse_counters(uint64_t* replayed, uint64_t* walked);
+
 /* LibSVM text ("label qid:Q fid:val ... # comment" per line, features named 1..num_features).
  * Pass 1 (features_out == NULL): returns the number of distinct qids (first-seen order).
  * Pass 2: fills features_out [Q, list_size, num_features] (zeros) and labels_out [Q, list_size]

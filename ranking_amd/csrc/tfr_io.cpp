@@ -265,6 +265,7 @@ struct ExampleTemplate {
   size_t n = 0;
   bool valid = false;
   int streak = 0;                                         // consecutive generic parses that matched no template
+  uint64_t replayed = 0, walked = 0;                      // examples parsed by replay / by the generic walk (this thread)
   // scratch of the generic parse that may arm the template
   std::vector<Copy> rec_copies;
   std::vector<std::pair<uint32_t, uint32_t>> rec_skips;  // (offset, length) of never-interpreted value bytes
@@ -299,6 +300,8 @@ struct ExampleTemplate {
   }
 };
 
+std::atomic<uint64_t> g_examples_replayed{0}, g_examples_walked{0};   // process totals (tfr_io_parse_counters)
+
 bool template_enabled() {
   static const bool on = [] { const char* e = getenv("TFR_IO_TEMPLATE"); return !(e && e[0] == '0'); }();
   return on;
@@ -315,8 +318,10 @@ int decode_example(const uint8_t* b, size_t n, const SpecTable& specs, float* ro
       else memcpy(row + c.dst, b + c.src, c.len);
     }
     tpl.streak = 0;
+    ++tpl.replayed;
     return 0;
   }
+  ++tpl.walked;
   const bool record = use_tpl && tpl.streak < 16;         // data that never repeats: stop paying for the copies
   bool replayable = record;
   if (record) { tpl.rec_copies.clear(); tpl.rec_skips.clear(); }
@@ -479,6 +484,11 @@ extern "C" int64_t tfr_io_elwc_max_list_size(const uint8_t* const* records, cons
   return best;
 }
 
+extern "C" void tfr_io_parse_counters(uint64_t* replayed, uint64_t* walked) {
+  if (replayed) *replayed = g_examples_replayed.load(std::memory_order_relaxed);
+  if (walked) *walked = g_examples_walked.load(std::memory_order_relaxed);
+}
+
 extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
                                        int32_t list_size, const tfr_io_feature_spec* example_specs,
                                        int32_t n_example, const tfr_io_feature_spec* context_specs,
@@ -502,6 +512,8 @@ extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint
                                  mask_out ? mask_out + (size_t)b * list_size : nullptr, hints);
       if (rc < 0) { int z = 0; err.compare_exchange_strong(z, rc); }
     }
+    g_examples_replayed.fetch_add(hints.example_tpl.replayed + hints.context_tpl.replayed, std::memory_order_relaxed);
+    g_examples_walked.fetch_add(hints.example_tpl.walked + hints.context_tpl.walked, std::memory_order_relaxed);
   };
   int T = num_threads > 1 ? std::min(num_threads, std::max(1, B)) : 1;
   if (T <= 1) {

@@ -469,6 +469,13 @@ def test_example_template_replay_equals_the_generic_parse():
     ospec = {k: (widths[k], -2.0 - i) for i, k in enumerate(names)}
     recs = [r for r, _, _ in records]
     feats, ctxs, sizes, mask = D.parse_from_example_list(recs, 12, ospec, {'q': (1, 9.0)})
+
+    def counters():
+        import ctypes
+        a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+        _io_lib.load().tfr_io_parse_counters(ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+    before = counters()
     for threads in (1, 2):
         got = data.parse_from_example_list(recs, list_size=12, example_feature_spec=spec, context_feature_spec=cspec,
                                            size_feature_name='n', mask_feature_name='m', num_threads=threads)
@@ -476,12 +483,27 @@ def test_example_template_replay_equals_the_generic_parse():
             assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), k
         assert torch.equal(got['q'], torch.tensor(ctxs['q'], dtype=F32))
         assert got['n'].tolist() == sizes and got['m'].tolist() == mask
+    replayed, walked = (x - y for x, y in zip(counters(), before))
+    # both paths ran: more than a quarter of the tf.Example messages replayed the previous structure, and the salted
+    # ones (and every first example) went through the generic walk
+    assert replayed > 0.25 * (replayed + walked) and walked > 0.2 * (replayed + walked), (replayed, walked)
     code = ("import os, sys, torch; sys.path.insert(0, %r); os.environ['TFR_IO_TEMPLATE'] = '0'\n"
             "from tests.test_data_cpu import _template_batch, data, F32\n"
             "names, widths, records = _template_batch(11)\n"
             "spec = {k: data.FixedLenFeature([widths[k]], F32, -2.0 - i) for i, k in enumerate(names)}\n"
             "got = data.parse_from_example_list([r for r, _, _ in records], list_size=12, example_feature_spec=spec)\n"
             "torch.save({k: got[k] for k in names}, sys.argv[1])\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for seed in range(20, 32):                                           # more structures, template on
+        names, widths, records = _template_batch(seed)
+        recs = [r for r, _, _ in records]
+        feats, ctxs, sizes, mask = D.parse_from_example_list(recs, 12, ospec, {'q': (1, 9.0)})
+        got = data.parse_from_example_list(recs, list_size=12, example_feature_spec=spec, context_feature_spec=cspec,
+                                           size_feature_name='n', mask_feature_name='m', num_threads=1 + seed % 3)
+        for k in names:
+            assert torch.equal(got[k], torch.tensor(feats[k], dtype=F32)), (seed, k)
+        assert torch.equal(got['q'], torch.tensor(ctxs['q'], dtype=F32)) and got['n'].tolist() == sizes
+    names, widths, records = _template_batch(11)
+    feats, ctxs, sizes, mask = D.parse_from_example_list([r for r, _, _ in records], 12, ospec, {'q': (1, 9.0)})
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, 'off.pt')
