@@ -484,9 +484,10 @@ def test_example_template_replay_equals_the_generic_parse():
         assert torch.equal(got['q'], torch.tensor(ctxs['q'], dtype=F32))
         assert got['n'].tolist() == sizes and got['m'].tolist() == mask
     replayed, walked = (x - y for x, y in zip(counters(), before))
-    # both paths ran: more than a quarter of the tf.Example messages replayed the previous structure, and the salted
+    # both paths ran: a good part of the tf.Example messages replayed the previous structure (every salted example costs
+    # two walks: its own and the re-arming one after it), and the salted
     # ones (and every first example) went through the generic walk
-    assert replayed > 0.25 * (replayed + walked) and walked > 0.2 * (replayed + walked), (replayed, walked)
+    assert replayed > 0.1 * (replayed + walked) and walked > 0.2 * (replayed + walked), (replayed, walked)
     code = ("import os, sys, torch; sys.path.insert(0, %r); os.environ['TFR_IO_TEMPLATE'] = '0'\n"
             "from tests.test_data_cpu import _template_batch, data, F32\n"
             "names, widths, records = _template_batch(11)\n"
