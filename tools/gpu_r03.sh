@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r03.sh <tag> <what...>
-#   what: pw_tests pw_bench tests bench all prof:<workload> pmc:<workload>
+#   what: pw_tests pw_bench tests bench all gemm32 prof:<workload> traffic:<workload> pmc:<workload>
 set -u
 TAG=${1:-r03}; shift
 OUT=gpurun_out/$TAG
@@ -63,6 +63,12 @@ PY
       timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
       python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1
       head -n 40 $OUT/stats_$w.txt ;;
+    gemm32)             # fp32 Dense kernels: timings, kernel-trace table, SQ counters (separate passes)
+      timeout 100 python tools/time_gemm_f32.py > $OUT/gemm32_time.txt 2>&1; tail -n 16 $OUT/gemm32_time.txt
+      GEMM_QUICK=1 timeout 100 rocprofv3 --kernel-trace --stats -d $OUT/gemm32_st -o r -- python tools/time_gemm_f32.py > $OUT/gemm32_st.log 2>&1
+      python tools/rocpd_summary.py stats $OUT/gemm32_st/r_results.db > $OUT/gemm32_stats.txt 2>&1; head -n 8 $OUT/gemm32_stats.txt
+      GEMM_QUICK=1 timeout 100 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT -d $OUT/gemm32_pmc -o r -- python tools/time_gemm_f32.py > $OUT/gemm32_pmc.log 2>&1
+      python tools/rocpd_summary.py pmc $OUT/gemm32_pmc/r_results.db gemm_f32 > $OUT/gemm32_pmc.txt 2>&1; head -n 30 $OUT/gemm32_pmc.txt | cut -c1-150 ;;
     traffic:*)          # FETCH_SIZE / WRITE_SIZE only, few steps (the e2e workloads: thousands of dispatches per second of bench)
       w=${what#traffic:}
       timeout 200 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 4 --warmup 1 --no-cpu-baseline --also none --busy-seconds 0 --dropout 0.5 > $OUT/pmc_fetch_$w.log 2>&1
