@@ -421,6 +421,17 @@ def create_ndcg_lambda_weight(topn=None, smooth_fraction=0.0):
                            normalized=True, smooth_fraction=smooth_fraction)
 
 
+def create_reciprocal_rank_lambda_weight(topn=None, smooth_fraction=0.0):
+    """losses.py:460-467."""
+    return DCGLambdaWeight(topn, gain_fn=identity, rank_discount_fn=inverse, normalized=True,
+                           smooth_fraction=smooth_fraction)
+
+
+def create_p_list_mle_lambda_weight(list_size):
+    """losses.py:470-484: rank discount 2^(list_size - rank) - 1."""
+    return ListMLELambdaWeight(rank_discount_fn=lambda rank: torch.pow(torch.tensor(2.), list_size - rank) - 1.)
+
+
 # ----------------------------------------------------------------------------
 # Gumbel sampler (losses_impl.py:540-649).
 # ----------------------------------------------------------------------------
@@ -921,6 +932,77 @@ class MeanSquaredLoss(_PointwiseLoss):
 # ----------------------------------------------------------------------------
 # Keras-level wrappers (keras/losses.py:247-335, 824-832, 1332-1341).
 # ----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------
+# losses.make_loss_fn (losses.py:57-311): the estimator-era factory over the classes above.
+# ----------------------------------------------------------------------------
+def make_loss_fn(loss_keys, loss_weights=None, weights_feature_name=None, lambda_weight=None,
+                 reduction=Reduction.SUM_BY_NONZERO_WEIGHTS, name=None, params=None, gumbel_params=None, uniform=None):
+    """losses.py:258-311 / _LossFunctionMaker (:57-255).  ``'a:0.1,b:0.9'`` keys carry their weights (:100-108); the
+    per-example weights come from ``features[weights_feature_name]`` reshaped to 2-D (:204-209); the Gumbel keys see the
+    sampled (labels, logits, weights) and the caller's lambda_weight, pointwise / approx / neural-sort keys never see a
+    lambda_weight (:125-160, :225-236); the result is the weighted sum of the per-key reduced losses (:241-252).
+    ``uniform`` injects the sampler's noise (TF's stream is unpinned)."""
+    if isinstance(loss_keys, str) and (':' in loss_keys or ',' in loss_keys):
+        if loss_weights is not None:
+            raise ValueError('`loss_weights` has to be None when weights are encoded in `loss_keys`.')
+        parsed = {}
+        for part in loss_keys.split(','):                       # utils.py:382-418 parse_keys_and_weights
+            if ':' in part:
+                k, w = part.split(':')
+                parsed[k.strip()] = float(w.strip())
+            else:
+                parsed[part.strip()] = 1.0
+        loss_keys, loss_weights = list(parsed.keys()), list(parsed.values())
+    if reduction not in (Reduction.SUM, Reduction.MEAN, Reduction.SUM_BY_NONZERO_WEIGHTS, Reduction.SUM_OVER_BATCH_SIZE):
+        raise ValueError('Invalid reduction: %s' % reduction)
+    if not loss_keys:
+        raise ValueError('loss_keys cannot be None or empty.')
+    if not isinstance(loss_keys, list):
+        loss_keys = [loss_keys]
+    if loss_weights and len(loss_keys) != len(loss_weights):
+        raise ValueError('loss_keys and loss_weights must have the same size.')
+    params = dict(params or {})
+    sampler = GumbelSampler(**(gumbel_params or {}))
+    with_lambda = {'pairwise_hinge_loss': PairwiseHingeLoss, 'pairwise_logistic_loss': PairwiseLogisticLoss,
+                   'pairwise_soft_zero_one_loss': PairwiseSoftZeroOneLoss, 'pairwise_mse_loss': PairwiseMSELoss,
+                   'circle_loss': CircleLoss, 'softmax_loss': SoftmaxLoss, 'poly_one_softmax_loss': PolyOneSoftmaxLoss,
+                   'unique_softmax_loss': UniqueSoftmaxLoss, 'list_mle_loss': ListMLELoss}
+    plain = {'sigmoid_cross_entropy_loss': SigmoidCrossEntropyLoss, 'mean_squared_loss': MeanSquaredLoss,
+             'approx_ndcg_loss': ApproxNDCGLoss, 'approx_mrr_loss': ApproxMRRLoss,
+             'neural_sort_cross_entropy_loss': NeuralSortCrossEntropyLoss, 'neural_sort_ndcg_loss': NeuralSortNDCGLoss}
+    gumbel = {'yeti_logistic_loss': PairwiseLogisticLoss, 'gumbel_approx_ndcg_loss': ApproxNDCGLoss,
+              'gumbel_neural_sort_cross_entropy_loss': NeuralSortCrossEntropyLoss,
+              'gumbel_neural_sort_ndcg_loss': NeuralSortNDCGLoss}
+
+    def _loss_fn(labels, logits, features):
+        weights = None
+        if weights_feature_name:
+            weights = _t(features[weights_feature_name])
+            weights = weights.reshape(weights.shape[0], -1) if weights.dim() != 1 else weights.reshape(-1, 1)
+        terms = []
+        for key in loss_keys:
+            if key in with_lambda:
+                loss = with_lambda[key](lambda_weight=lambda_weight, **params)
+                terms.append(loss.compute(labels, logits, weights, reduction))
+            elif key in plain:
+                terms.append(plain[key](**params).compute(labels, logits, weights, reduction))
+            elif key in gumbel:
+                g_labels, g_logits, g_weights = sampler.sample(labels, logits, weights=weights, uniform=uniform)
+                kw = dict(params)
+                if lambda_weight is not None and key == 'yeti_logistic_loss':
+                    kw['lambda_weight'] = lambda_weight
+                terms.append(gumbel[key](**kw).compute(g_labels, g_logits, g_weights, reduction))
+            else:
+                raise ValueError('Invalid loss_key: %s.' % key)
+        if loss_weights:
+            terms = [t * w for t, w in zip(terms, loss_weights)]
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
+    return _loss_fn
+
+
 def keras_loss_call(loss, y_true, y_pred, sample_weight=None, reduction=Reduction.AUTO,
                     gumbel_sampler: Optional[GumbelSampler] = None, uniform=None):
     """Restates ``tfr.keras.losses.<Loss>.__call__`` for an L1 ``loss`` object."""

@@ -76,7 +76,7 @@ def make_loss_fn(loss_keys: Union[str, Sequence[str]],
                  gumbel_params: Optional[Mapping[str, Any]] = None) -> Callable:
     """losses.py:265-311 / _LossFunctionMaker.make :163-260."""
     if isinstance(loss_keys, str) and ':' in loss_keys or (isinstance(loss_keys, str) and ',' in loss_keys):
-        if loss_weights:
+        if loss_weights is not None:
             raise ValueError('`loss_weights` has to be None when weights are encoded in `loss_keys`.')
         kw = utils.parse_keys_and_weights(loss_keys)
         loss_keys, loss_weights = list(kw.keys()), list(kw.values())

@@ -126,12 +126,21 @@ def test_keys_and_factories():
         ra.keras.metrics.get(3)
     assert [m.name for m in ra.keras.metrics.default_keras_metrics()][:4] == [
         'metric/ndcg_1', 'metric/ndcg_3', 'metric/ndcg_5', 'metric/ndcg_10']
-    with pytest.raises(ValueError):
+    # the messages python/losses_test.py:1066-1086,1168-1172 match on
+    with pytest.raises(ValueError, match='loss_keys cannot be None or empty.'):
         ra.losses.make_loss_fn([], None)
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match='loss_keys cannot be None or empty.'):
+        ra.losses.make_loss_fn('')
+    with pytest.raises(ValueError, match='loss_keys and loss_weights must have the same size.'):
         ra.losses.make_loss_fn(['softmax_loss'], [1.0, 2.0])
-    with pytest.raises(ValueError):
+    with pytest.raises(ValueError, match='`loss_weights` has to be None when weights are encoded in `loss_keys`'):
         ra.losses.make_loss_fn('softmax_loss:0.5', [1.0])
+    with pytest.raises(ValueError, match='`loss_weights` has to be None'):
+        ra.losses.make_loss_fn('softmax_loss:0.5,mean_squared_loss:2', [])
+    with pytest.raises(ValueError, match='Invalid reduction'):
+        ra.losses.make_loss_fn('softmax_loss', reduction='none')
+    with pytest.raises(ValueError, match='Invalid loss_key: invalid_key.'):
+        ra.losses.make_loss_fn(['invalid_key'])(torch.zeros(1, 2), torch.zeros(1, 2), {})
     with pytest.raises(ValueError):
         ra.losses_impl.DCGLambdaWeight(smooth_fraction=-0.1)          # losses_impl.py:329-331
     with pytest.raises(ValueError):
