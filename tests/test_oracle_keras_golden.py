@@ -204,3 +204,141 @@ def test_keras_mrr_metric():
     near(m(R.MRRMetric(topn=1), labels, scores), (0. + 1. + 0.) / 3.)
     near(m(R.MRRMetric(), labels, scores, weights),
          sum(w / r for w, r in zip(mean_rel_w, rel_rank)) / sum(mean_rel_w))
+
+
+# ---------------------------------------------------------------------------- the other Keras metrics
+# (keras/metrics_test.py:413-1354: Hits, ARP, Precision, MAP, DCG, OPA, Recall -- dense and ragged, item / list / zero
+# weights).  The Keras metric is the mean of the per-list metric under the per-list weights (keras/metrics.py:69-201);
+# expectations are the reference tests' closed forms, evaluated by the helpers below.
+def _mean(metric, yt, yp, w=None):
+    return R.keras_metric_mean(metric, [(yt, yp, w)])
+
+
+def _binary_list_weights(weights, labels):
+    """Per-list weights of the binary-relevance metrics: sum(w * [label >= 1]) / #[label >= 1]; lists without a
+    relevant item take the mean of the others (keras/metrics_test.py:121-160 `_example_weights_to_list_weights`)."""
+    out = []
+    for w, l in zip(weights, labels):
+        rel = [1.0 if x >= 1.0 else 0.0 for x in l]
+        out.append(sum(a * b for a, b in zip(w, rel)) / sum(rel) if sum(rel) > 0 else None)
+    have = [x for x in out if x is not None]
+    fill = sum(have) / len(have) if have else 0.0
+    return [fill if x is None else x for x in out]
+
+
+def _average_precision(rels, scores, topn=None):
+    order = sorted(range(len(scores)), key=lambda i: -scores[i])[:topn or len(scores)]
+    hits, total = 0.0, 0.0
+    for k, i in enumerate(order, start=1):
+        if rels[i]:
+            hits += 1.0
+            total += hits / k
+    return total / sum(rels) if sum(rels) else 0.0
+
+
+RAGGED_SCORES = [[1., 2., 0.], [1., 2.], [3., 4., 2., 1.]]
+RAGGED_LABELS = [[1., 0., 0.], [0., 2.], [2., 0., 1., 0.]]
+RAGGED_WEIGHTS = [[2., 1., 4.], [2., 1.], [2., 1., 4., 8.]]
+
+
+def test_keras_hits_metric():  # keras/metrics_test.py:413-542
+    scores = [[1., 3., 2.], [1., 2., 3.], [3., 1., 2.]]                 # ranks [[3,1,2],[3,2,1],[1,3,2]]
+    labels = [[0., 0., 1.], [0., 1., 2.], [0., 1., 0.]]
+    weights = [[1., 2., 3.], [4., 5., 6.], [7., 8., 9.]]
+    mean_rel_w = [weights[0][2], sum(weights[1][1:]) / 2, weights[2][1]]
+    for b, expect in ((0, {None: 1., 1: 0., 2: 1.}), (1, {None: 1., 1: 1., 2: 1.}), (2, {None: 1., 1: 0., 2: 0., 3: 1.})):
+        for topn, e in expect.items():
+            near(_mean(R.HitsMetric(topn=topn), [labels[b]], [scores[b]]), e)
+    near(_mean(R.HitsMetric(topn=1), labels[:2], scores[:2]), 0.5)
+    near(_mean(R.HitsMetric(topn=1), labels[:2], scores[:2], weights[:2]), ((6. + 5.) / 2.) / (3. + (6. + 5.) / 2.))
+    for topn, e in ((1, 1. / 3.), (2, 2. / 3.), (3, 1.)):
+        near(_mean(R.HitsMetric(topn=topn), labels, scores), e)
+    near(_mean(R.HitsMetric(topn=1), labels, scores, weights), mean_rel_w[1] / sum(mean_rel_w))
+    sc, lb, wt = [[1., 2., 0.], [1., 2.], [1., 4., 2., 3.]], RAGGED_LABELS, RAGGED_WEIGHTS    # ragged (:509-542)
+    for topn, hits in ((1, [0., 1., 0.]), (2, [1., 1., 0.]), (3, [1., 1., 1.])):
+        near(_mean(R.HitsMetric(topn=topn, ragged=True), lb, sc), sum(hits) / 3.)
+        near(_mean(R.HitsMetric(topn=topn, ragged=True), lb, sc, wt), (hits[0] * 2. + hits[1] * 1. + hits[2] * 3.) / 6.)
+
+
+def test_keras_arp_precision_recall_metrics():  # keras/metrics_test.py:544-660, 1294-1354
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    weights = [[1., 2., 3.], [4., 5., 6.]]
+    near(_mean(R.ARPMetric(), [labels[0]], [scores[0]]), 2.)
+    near(_mean(R.ARPMetric(), labels, scores), (1. * 2. + 2. * 1. + 1. * 2.) / 4.)
+    near(_mean(R.ARPMetric(), labels, scores, weights), (3. * 1. * 2. + 6. * 2. * 1. + 5 * 1. * 2.) / (3. + 12. + 5.))
+    near(_mean(R.PrecisionMetric(), [labels[0]], [scores[0]]), 1. / 3.)
+    near(_mean(R.PrecisionMetric(topn=1), [labels[0]], [scores[0]]), 0.)
+    near(_mean(R.PrecisionMetric(), labels, scores), (1. / 3. + 2. / 3.) / 2.)
+    zero = [[0., 0., 0.], [0., 1., 2.]]                                                       # :583-595
+    near(_mean(R.PrecisionMetric(), [zero[0]], [scores[0]]), 0.)
+    near(_mean(R.PrecisionMetric(), zero, scores), (0. + 2. / 3.) / 2.)
+    lw = _binary_list_weights(weights, labels)                                                # :615-645
+    near(_mean(R.PrecisionMetric(), labels, scores, weights), ((1. / 3.) * lw[0] + (2. / 3.) * lw[1]) / sum(lw))
+    near(_mean(R.PrecisionMetric(topn=2), labels, scores, weights), ((1. / 2.) * lw[0] + 1. * lw[1]) / sum(lw))
+    near(_mean(R.PrecisionMetric(), labels, scores, [[1.], [2.]]), ((1. / 3.) * 1. + (2. / 3.) * 2.) / 3.)
+    near(_mean(R.PrecisionMetric(topn=2), labels, scores, [[0., 0., 0.], [0., 0., 0.]]), 0.)
+    s3 = [[1., 3., 2.], [1., 3., 2.], [1., 2., 3.]]                                           # :597-613, 1327-1339
+    l3 = [[0., 0., 0.], [0., 0., 1.], [0., 1., 2.]]
+    w3 = [[0., 0., 1.], [1., 2., 3.], [4., 5., 6.]]
+    lw3 = _binary_list_weights(w3, l3)
+    assert lw3 == pytest.approx([(3 + 5.5) / 2., 3, 5.5])
+    near(_mean(R.PrecisionMetric(topn=2), l3, s3, w3), (0. * lw3[0] + .5 * lw3[1] + 1. * lw3[2]) / sum(lw3))
+    near(_mean(R.PrecisionMetric(), l3[:2], s3[:2], [[0., 0., 0.], [0., 0., 0.]]), 0.)
+    near(_mean(R.RecallMetric(topn=1), l3, s3, w3), (0. * lw3[0] + 0. * lw3[1] + .5 * lw3[2]) / sum(lw3))
+    near(_mean(R.RecallMetric(), [labels[0]], [scores[0]]), 1.)
+    near(_mean(R.RecallMetric(topn=1), [labels[0]], [scores[0]]), 0.)
+    near(_mean(R.RecallMetric(topn=2), labels, scores), 1.)
+    near(_mean(R.RecallMetric(), [zero[0]], [scores[0]]), 0.)
+    near(_mean(R.RecallMetric(), zero, scores), 0.5)
+    near(_mean(R.PrecisionMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES), (1. / 3. + 1. / 2. + 2. / 4.) / 3.)        # :647-660
+    near(_mean(R.PrecisionMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES, RAGGED_WEIGHTS), (2. / 3. + 1. / 2. + 3. * 2. / 4.) / 6.)
+    near(_mean(R.RecallMetric(topn=2, ragged=True), RAGGED_LABELS, RAGGED_SCORES), (1. + 1. + 1. / 2.) / 3.)            # :1341-1354
+    near(_mean(R.RecallMetric(topn=2, ragged=True), RAGGED_LABELS, RAGGED_SCORES, RAGGED_WEIGHTS), (2. + 1. + 3. / 2.) / 6.)
+
+
+def test_keras_map_metric():  # keras/metrics_test.py:746-854
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    rels = [[0, 0, 1], [0, 1, 1]]
+    weights = [[1., 2., 3.], [4., 5., 6.]]
+    M = R.MeanAveragePrecisionMetric
+    for topn in (None, 1, 2):
+        near(_mean(M(topn=topn), [labels[0]], [scores[0]]), _average_precision(rels[0], scores[0], topn))
+    near(_mean(M(), labels, scores), sum(_average_precision(rels[i], scores[i]) for i in range(2)) / 2.)
+    near(_mean(M(topn=1), labels, scores), sum(_average_precision(rels[i], scores[i], 1) for i in range(2)) / 2.)
+    lw = _binary_list_weights(weights, labels)
+    ap0 = ((1. / 2.) * 3.) / 3.
+    ap1 = ((1. / 1.) * 6. + (2. / 2.) * 5.) / (5. + 6.)
+    near(_mean(M(), [labels[0]], [scores[0]], [weights[0]]), ap0)
+    near(_mean(M(), [labels[1]], [scores[1]], [weights[1]]), ap1)
+    near(_mean(M(), labels, scores, weights), (ap0 * lw[0] + ap1 * lw[1]) / sum(lw))
+    near(_mean(M(topn=1), labels, scores, weights), (0. * lw[0] + (6. / 11.) * lw[1]) / sum(lw))
+    near(_mean(M(topn=2), labels, scores, weights), (ap0 * lw[0] + ap1 * lw[1]) / sum(lw))
+    near(_mean(M(), labels, scores, [[1.], [2.]]), sum(_average_precision(rels[i], scores[i]) * (i + 1.) for i in range(2)) / 3.)
+    near(_mean(M(ragged=True), RAGGED_LABELS, RAGGED_SCORES), (1. / 2. + 1. + (1. / 2. + 2. / 3.) / 2.) / 3.)
+    near(_mean(M(ragged=True), RAGGED_LABELS, RAGGED_SCORES, RAGGED_WEIGHTS), (2. * 1. / 2. + 1. + 3. * (2. * 1. / 2. + 2. * 4. / 3.) / 6.) / 6.)
+
+
+def test_keras_dcg_and_opa_metrics():  # keras/metrics_test.py:1015-1057, 1250-1292
+    scores = [[1., 3., 2.], [1., 2., 3.]]
+    labels = [[0., 0., 1.], [0., 1., 2.]]
+    weights = [[1., 1., 1.], [2., 2., 1.]]
+    d1 = _dcg(0., 1) + _dcg(1., 2) + _dcg(0., 3)
+    d2 = _dcg(2., 1) + _dcg(1., 2)
+    d2w = _dcg(2., 1) + _dcg(1., 2) * 2.
+    w2 = ((4 - 1) * 1. + (2 - 1) * 2.) / (4 - 1 + 2 - 1)
+    near(_mean(R.DCGMetric(), [labels[0]], [scores[0]]), d1)
+    near(_mean(R.DCGMetric(), labels, scores), (d1 + d2) / 2.)
+    near(_mean(R.DCGMetric(), labels, scores, weights), (d1 + d2w) / (1. + w2))
+    near(_mean(R.DCGMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES), (_dcg(1., 2) + _dcg(2., 1) + _dcg(2., 2) + _dcg(1., 3)) / 3.)
+    near(_mean(R.DCGMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES, RAGGED_WEIGHTS),
+         (2. * _dcg(1., 2) + 1. * _dcg(2., 1) + 2. * _dcg(2., 2) + 4. * _dcg(1., 3)) / 5.5)
+    labels = [[-1., 0., 1.], [0., 1., 2.]]
+    near(_mean(R.OPAMetric(), [labels[0]], [scores[0]]), 0.)
+    near(_mean(R.OPAMetric(), [labels[1]], [scores[1]]), 1.)
+    near(_mean(R.OPAMetric(), labels, scores), 3. / 4.)
+    near(_mean(R.OPAMetric(), labels, scores, [[1.], [2.]]), 6. / 7.)
+    near(_mean(R.OPAMetric(), labels, scores, [[1., 1., 1.], [2., 2., 3.]]), (2. + 3. + 3.) / (1. + 2. + 3. + 3.))
+    near(_mean(R.OPAMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES), (1. + 1. + 3.) / (2. + 1. + 5.))
+    near(_mean(R.OPAMetric(ragged=True), RAGGED_LABELS, RAGGED_SCORES, RAGGED_WEIGHTS), (2. + 1. + 8.) / (4. + 1. + 14.))
