@@ -39,6 +39,21 @@ def test_form_group_indices_no_shuffle():   # model_test.py:96-112
     assert oidx.tolist() == idx.tolist() and omask.tolist() == mask.tolist()
 
 
+def test_scatter_gather_indices_reference_literals():   # model_test.py:156-189 (column of the reference's nd index)
+    idx, mask = M._form_group_indices_nd(torch.tensor([[True, True, False]]), 1, shuffle=False)    # group_size 1
+    assert idx.tolist() == [[[0], [1], [0]]] and mask.tolist() == [[True, True, False]]
+    idx, mask = M._form_group_indices_nd(torch.tensor([[True, True, True]]), 2, shuffle=False)     # PREDICT: no shuffle
+    assert idx.tolist() == [[[0, 1], [1, 2], [2, 0]]] and mask.tolist() == [[True, True, True]]
+    oidx, omask = R.form_group_indices(torch.tensor([[True, True, False]]), 1)
+    assert oidx.tolist() == [[[0], [1], [0]]] and omask.tolist() == [[True, True, False]]
+    # two shuffles of a list with two valid items (:191-221): whatever the shuffle draws, every round forms the groups
+    # {[0, 1], [1, 0], [x, y]} and masks the third one
+    torch.manual_seed(2)
+    for _ in range(4):
+        idx, mask = M._form_group_indices_nd(torch.tensor([[True, True, False]]), 2, shuffle=True)
+        assert sorted(idx[0, :2].tolist()) == [[0, 1], [1, 0]] and mask.tolist() == [[True, True, False]]
+
+
 @pytest.mark.parametrize('training', [True, False])
 def test_compute_logits_known_answers(training):   # model_test.py:223-277
     gs = 2
