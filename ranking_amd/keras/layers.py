@@ -2,10 +2,12 @@
 ``create_tower`` (:26-77), ``FlattenList`` (:81-182), ``RestoreList`` (:186-272).
 
 The tower is a stack of Dense -> BatchNorm -> activation -> Dropout blocks on the
-flattened ``[B*L, F]`` matrix; its GEMMs run on the MFMA units (bf16 operands,
-fp32 accumulate) through ``ranking_amd.scorer.DenseBf16`` when
-``compute_dtype=torch.bfloat16`` (config 2 of BASELINE.json) and in fp32
-otherwise (what the reference does).
+flattened ``[B*L, F]`` matrix.  ``compute_dtype=torch.bfloat16`` (config 2 of
+BASELINE.json) builds the fused MFMA tower (``ranking_amd/tower.py`` over
+``csrc/tower.hip``) when the shapes allow it; ``torch.float32`` -- what the
+reference computes in -- and the shapes the fused tower refuses build the layer
+stack below with every Dense on the fp32 matrix-core kernels of
+``csrc/gemm_f32.hip`` (``ranking_amd/scorer.py``).
 """
 from __future__ import annotations
 
