@@ -16,9 +16,11 @@ reduction the Keras call returns).
 (WORLD_SIZE set) it just joins them.  The loss kernels shard the lists across
 ranks with no data-path collective -> "scaling": "weak"; the
 end-to-end workloads (`e2e_*`) run ONE all-reduce of the flat gradient bucket per
-step and report its time separately.  Rank 0 prints ONE JSON line; with `--also`
-(the default set is the BASELINE multi-GPU configs 4 and 5 plus the pairwise
-kernel north_star names) the same line carries those workloads under "also".
+step and report its time separately.  Rank 0 prints the JSON line of the main workload as soon as it is measured; with
+`--also` (the default set is the BASELINE multi-GPU configs 4 and 5 plus the
+pairwise kernel north_star names) every extra workload then runs in its OWN child
+process (own HIP context and timeout: a faulting extra costs one entry, never the
+headline) and the same line is printed once more, last, with them under "also".
 Every workload entry has `roofline` (dominant kernel, HIP events) and, at N = 1,
 `cpu_baseline` (the oracle on a bounded sample on the host cores).
 """
@@ -551,6 +553,26 @@ def cpu_fused_c_baseline(workload, B, L):
 
 
 # ------------------------------------------------------------------------------------------ measuring one workload
+def graph_of(eager):
+    """The loss step is a handful of short launches (order, loss kernel, reduction): replay it from a hipGraph so that
+    the measured rate is the GPU's, not the Python launch path's.  Returns a callable with the step's (static) outputs."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            eager()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with capture(graph):
+        static_out = eager()
+
+    def step():
+        graph.replay()
+        return static_out
+    return step
+
+
 def _timed_loop(fn, n, dist, want_local=False):
     torch.cuda.synchronize()
     if dist is not None:
@@ -615,29 +637,14 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
     info = build_step(name, labels, logits, dropout, args.graph)
     step = info['step']
     if args.graph and not is_e2e:
-        # The loss step is a handful of short launches (order, loss kernel, reduction): replay it from a
-        # hipGraph so that the measured rate is the GPU's, not the Python launch path's.
-        eager = step
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                eager()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with capture(graph):
-            static_out = eager()
-
-        def step():
-            graph.replay()
-            return static_out
+        step = graph_of(step)
 
     # The roofline's kernel-only timing (HIP events around graph-replayed launches of the dominant kernel) runs BEFORE
     # the step timing: it needs nothing from it, and it leaves the clocks where a long-running job has them -- with
     # the driver's K = 20 the timed region is ~3 ms of GPU work, which from an idle device measures the power state's
     # ramp, not the step (`steady_state` below is the cross-check: the same step replayed for seconds afterwards).
-    kernel_ms = _kernel_ms(info['kernel'], steps) if info.get('kernel') is not None else None
+    want_kernel = info.get('kernel') is not None and args.kernel_timing != 'none'
+    kernel_ms = _kernel_ms(info['kernel'], steps) if (want_kernel and args.kernel_timing == 'first') else None
     for _ in range(warmup):
         step()
     elapsed, local_elapsed = _timed_loop(step, steps, dist, want_local=True)
@@ -679,6 +686,8 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
             info0['step']()
         e_drop0 = _timed_loop(info0['step'], steps, dist)
         del info0
+    if want_kernel and kernel_ms is None:                   # --kernel-timing last (developer A/B of the measurement order)
+        kernel_ms = _kernel_ms(info['kernel'], steps)
     if rank != 0:
         return None
 
@@ -751,7 +760,9 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
                             'order (tree_sum), the host-computed discount table and exact 2^l gains; the independent fp64 '
                             'plain-C arbiter (oracle/pairwise_softmax_c.c) agrees to 5e-6 and the reference literals to 1e-6 '
                             '(tests/test_gpu_parity.py)')
-    if is_e2e:
+    if is_e2e and kernel_ms is None:
+        result['roofline'] = None
+    elif is_e2e:
         tflops = e2e_flops_per_list(name, L) * B / (ms_per_step * 1e-3) / 1e12
         k_tflops = info['kernel_flops'] / (kernel_ms * 1e-3) / 1e12
         result['roofline'] = {
@@ -775,7 +786,11 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
                                 'note': 'the step\'s ONE collective (flat fp32 gradient bucket + 2 scalars) timed '
                                         'alone over the same number of iterations; 0 at N = 1 (no collective issued)'}
     if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample)
-        cb = cpu_baseline(name, L, cpu_budget_s)
+        try:
+            cb = cpu_baseline(name, L, cpu_budget_s)
+        except Exception as e:                              # the checker's leg must never take the measured line down
+            cb = None
+            result['cpu_baseline_error'] = '%s: %s' % (type(e).__name__, e)
         if cb is not None:
             result['cpu_baseline'] = cb
             result['gpu_over_cpu'] = value / cb['value']
@@ -787,6 +802,69 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
     return result
 
 
+# ------------------------------------------------------------------------------------------ extras in child processes
+_RANK_ENV = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'GROUP_WORLD_SIZE', 'ROLE_RANK',
+             'ROLE_WORLD_SIZE', 'ROLE_NAME', 'MASTER_ADDR', 'MASTER_PORT', 'OMP_NUM_THREADS')
+
+
+def child_command(workload, args, n_gpus, steps, warmup, port=None):
+    """The command line that measures ONE extra workload in its own process (at N > 1: its own N ranks under
+    torch.distributed.run on a fresh port)."""
+    tail = ['--gpus', str(n_gpus), '--workload', workload, '--also', 'none', '--steps', str(steps), '--warmup',
+            str(warmup), '--busy-seconds', '0', '--cpu-budget', '4']
+    if args.no_cpu_baseline:
+        tail.append('--no-cpu-baseline')
+    if not args.graph:
+        tail.append('--no-graph')
+    if args.dropout is not None:
+        tail += ['--dropout', str(args.dropout)]
+    if n_gpus > 1:
+        return launch_command(n_gpus, tail, port if port is not None else free_port())
+    return [sys.executable, os.path.abspath(__file__)] + tail
+
+
+def last_json_line(text):
+    for line in reversed(text.splitlines()):
+        line = line.strip()
+        if line.startswith('{'):
+            try:
+                return json.loads(line)
+            except ValueError:
+                continue
+    return None
+
+
+def run_child(workload, args, n_gpus, steps, warmup, budget_s):
+    """Runs one extra workload in a child process and returns its result dict.  A child that dies (a GPU fault
+    aborts the whole process -- no `except` can catch it), hangs or prints nothing costs ONE `also` entry: the
+    headline line is already on stdout by then."""
+    import signal
+    env = {k: v for k, v in os.environ.items() if k not in _RANK_ENV and not k.startswith('TORCHELASTIC_')}
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = child_command(workload, args, n_gpus, steps, warmup)
+    t0 = time.perf_counter()
+    try:
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                                start_new_session=True)
+    except OSError as e:
+        return {'error': 'could not start the child: %s' % e}
+    try:
+        out, err = proc.communicate(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)             # exactly the process group this call started
+        except OSError:
+            pass
+        out, err = proc.communicate()
+        return {'error': 'child exceeded %d s' % budget_s, 'stderr_tail': (err or '')[-400:]}
+    r = last_json_line(out or '')
+    if proc.returncode != 0 or r is None:
+        return {'error': 'child exited with rc %s%s' % (proc.returncode, '' if r is not None else ' and printed no JSON line'),
+                'stderr_tail': (err or '')[-600:], 'wall_s': time.perf_counter() - t0}
+    r['wall_s'] = time.perf_counter() - t0
+    return r
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
@@ -795,10 +873,12 @@ def main(argv=None):
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='approx_ndcg', choices=sorted(WORKLOADS))
     ap.add_argument('--also', default=None,
-                    help='comma-separated extra workloads measured after the main one and reported under "also" '
-                         '(default: %s when --workload is the headline; "none" to disable)' % ','.join(DEFAULT_ALSO))
+                    help='comma-separated extra workloads, each measured in its OWN child process after the main one and '
+                         'reported under "also" (default: %s when --workload is the headline; "none" to disable)'
+                         % ','.join(DEFAULT_ALSO))
     ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of host time for the CPU-baseline sample')
     ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
                     help='launch eagerly instead of replaying the step from hipGraphs')
     ap.add_argument('--dropout', type=float, default=None,
@@ -807,6 +887,9 @@ def main(argv=None):
     ap.add_argument('--busy-seconds', type=float, default=2.5,
                     help='after the timed steps of the main workload, keep replaying the step for this long (not counted): '
                          'makes the GPU phase visible to a utilisation sampler; 0 to disable')
+    ap.add_argument('--kernel-timing', choices=('first', 'last', 'none'), default='first',
+                    help='when the dominant kernel is timed alone (HIP events): before the step timing (default), after '
+                         'it, or not at all (no roofline object) -- developer A/B')
     ap.add_argument('--traffic-bytes', type=float, default=None,
                     help='HBM bytes per launch from a separate rocprofv3 --pmc pass (profiles/)')
     ap.add_argument('--plumbing-check', action='store_true',
@@ -840,48 +923,33 @@ def main(argv=None):
     if dist is not None:
         dist.barrier()
 
-    result = run_workload(args.workload, args, dist, rank, world, dev, args.steps, args.warmup, 12.0)
+    result = run_workload(args.workload, args, dist, rank, world, dev, args.steps, args.warmup, args.cpu_budget)
     also = DEFAULT_ALSO if (args.also is None and args.workload == 'approx_ndcg') else tuple(
         w for w in (args.also or '').split(',') if w and w != 'none')
-    extra = {}
-
-    def emit_and_leave(why):
-        """N > 1 only: the extra workloads run collectives; a rank that fails or stalls inside one must not take the
-        headline line down with it.  Rank 0 prints the line with what it has, every rank leaves without the
-        process-group teardown (which would wait for the stuck peers)."""
-        if rank == 0:
-            result['rccl_ranks'] = rccl_ranks
-            extra.setdefault('error', why)
-            result['also'] = extra
-            print(json.dumps(result), flush=True)
-        sys.stdout.flush()
-        os._exit(0)
-
-    if world > 1 and also:
-        import signal
-        budget = int(os.environ.get('TFR_BENCH_ALSO_BUDGET_S', '420'))
-        signal.signal(signal.SIGALRM, lambda *_: emit_and_leave('extra workloads exceeded %d s at %d ranks' % (budget, world)))
-        signal.alarm(budget)
     for w in also:
         if w not in WORKLOADS:
             raise SystemExit('unknown workload in --also: %s' % w)
-        try:
-            r = run_workload(w, args, dist, rank, world, dev, max(10, min(args.steps, 50)),
-                             max(3, min(args.warmup, 10)), 4.0)
-        except Exception as e:                              # an extra line must never take the headline down
-            if world > 1:                                   # ... and the ranks must not diverge inside collectives
-                emit_and_leave('%s: %s: %s' % (w, type(e).__name__, e))
-            r = {'error': '%s: %s' % (type(e).__name__, e)}
-        extra[w] = r
-    if world > 1 and also:
-        signal.alarm(0)
+    # The line of the main workload goes out NOW, complete (roofline + cpu_baseline), before any extra runs: whatever
+    # happens to an extra, this line is on stdout.  With extras the same line is printed again at the end with "also"
+    # merged in -- a reader that takes the last parseable line gets everything, one that takes the first gets the metric.
     if rank == 0:
         result['rccl_ranks'] = rccl_ranks
-        if extra:
-            result['also'] = extra
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dist is not None:
-        dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()                         # the extras bring up their own ranks
+    if not also or rank != 0:
+        return
+    # Every extra in its own process (own HIP context, own timeout): at N > 1 a fresh `torch.distributed.run` of N
+    # ranks -- this job's other ranks have left their GPUs by now.
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    budget = int(os.environ.get('TFR_BENCH_ALSO_BUDGET_S', '420'))
+    extra = {}
+    for w in also:
+        extra[w] = run_child(w, args, world, max(10, min(args.steps, 50)), max(3, min(args.warmup, 10)), budget)
+    result['also'] = extra
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

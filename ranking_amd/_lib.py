@@ -294,7 +294,17 @@ def load():
     return lib
 
 
+_TRACE_CALLS = bool(os.environ.get('TFR_SYNC_EVERY_CALL'))     # developer switch: localise an asynchronous GPU fault
+
+
 def check(code: int, what: str):
+    if _TRACE_CALLS:                                          # name first, then wait: the last name printed is the culprit
+        import sys
+        import torch
+        sys.stderr.write('[tfr] %s\n' % what)
+        sys.stderr.flush()
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
     if code == 0:
         return
     if code == -1:

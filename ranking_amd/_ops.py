@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+from collections import OrderedDict
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
@@ -70,25 +71,61 @@ def _same_shape(a, b, na, nb):
 
 
 # ------------------------------------------------------------------ tables
-_table_cache: Dict[Tuple, torch.Tensor] = {}
+class DeviceConstCache:
+    """Small read-only device tensors (rank tables, per-list scale vectors) keyed by value.
+
+    A hipGraph bakes the ADDRESS of every tensor a captured launch reads, so an entry a capture has seen must
+    outlive every replay: entries touched while the current stream is capturing are pinned for the life of the
+    process, only never-captured entries are evicted (least recently used first) once `capacity` is exceeded.
+    An entry that would have to be CREATED during a capture is not cached at all -- its storage belongs to the
+    graph's private pool and the fill is a node of the graph."""
+
+    def __init__(self, capacity: int):
+        self.capacity = int(capacity)
+        self._lru: 'OrderedDict[Tuple, torch.Tensor]' = OrderedDict()
+        self._pinned: Dict[Tuple, torch.Tensor] = {}
+
+    def __len__(self):
+        return len(self._lru) + len(self._pinned)
+
+    def pinned(self) -> int:
+        return len(self._pinned)
+
+    def get(self, key, make: Callable[[], torch.Tensor]) -> torch.Tensor:
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        t = self._pinned.get(key)
+        if t is not None:
+            return t
+        t = self._lru.get(key)
+        if t is not None:
+            if capturing:
+                self._pinned[key] = self._lru.pop(key)
+            else:
+                self._lru.move_to_end(key)
+            return t
+        t = make()
+        if capturing:
+            return t
+        self._lru[key] = t
+        while len(self._lru) > self.capacity:
+            self._lru.popitem(last=False)
+        return t
+
+
+_table_cache = DeviceConstCache(256)
 
 
 def rank_table(fn: Callable, n: int, device) -> torch.Tensor:
     """fp32 table fn(r), r = 1..n, evaluated ONCE on the host (so that it is
     bit-identical to what the CPU oracle uses) and cached on the device."""
-    key = (fn, int(n), str(device))
-    t = _table_cache.get(key)
-    if t is None:
+    def make():
         r = torch.arange(1, n + 1, dtype=torch.float32)
         v = fn(r)
         if not torch.is_tensor(v):
             v = torch.as_tensor(v, dtype=torch.float32)
         v = torch.broadcast_to(v.to(torch.float32), r.shape).contiguous()
-        t = v.to(device)
-        if len(_table_cache) > 256:
-            _table_cache.clear()
-        _table_cache[key] = t
-    return t
+        return v.to(device)
+    return _table_cache.get((fn, int(n), str(device)), make)
 
 
 def _inv_log1p(rank):

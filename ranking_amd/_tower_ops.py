@@ -14,13 +14,30 @@ from . import _ops
 from ._ops import _ptr, _stream, require_device
 
 class Dropout(ctypes.Structure):
-    """tfr_tower_dropout (include/tfr_hip.h): counter-based keep mask shared by forward and backward."""
-    _fields_ = [('seed', ctypes.c_uint32), ('threshold16', ctypes.c_uint32), ('scale', ctypes.c_float)]
+    """tfr_tower_dropout (include/tfr_hip.h): counter-based keep mask shared by forward and backward.  ``step``: an
+    int32 / uint32 device tensor of one element added to the seed (times the golden ratio) by the kernels -- the
+    training-step counter, in device memory so that hipGraph replays draw fresh masks."""
+    _fields_ = [('seed', ctypes.c_uint32), ('threshold16', ctypes.c_uint32), ('scale', ctypes.c_float),
+                ('step', ctypes.c_void_p)]
 
     @classmethod
-    def make(cls, rate: float, seed: int):
+    def make(cls, rate: float, seed: int, step: Optional[torch.Tensor] = None):
         thr = max(0, min(65535, int(round(float(rate) * 65536.0))))
-        return cls(int(seed) & 0xffffffff, thr, 65536.0 / (65536.0 - thr))
+        d = cls(int(seed) & 0xffffffff, thr, 65536.0 / (65536.0 - thr), None)
+        if step is not None:
+            if step.numel() != 1 or step.dtype not in (torch.int32, torch.uint32) or not step.is_cuda:
+                raise ValueError('Dropout step must be a one-element int32 device tensor')
+            d.step = step.data_ptr()
+            d._step_tensor = step                     # keeps the storage alive as long as the struct
+        return d
+
+    def resolved(self) -> 'Dropout':
+        """The struct with the step counter folded into the seed (reads the device value: tests / debugging)."""
+        seed = int(self.seed)
+        t = getattr(self, '_step_tensor', None)
+        if t is not None:
+            seed = (seed + (int(t.item()) & 0xffffffff) * 0x9E3779B9) & 0xffffffff
+        return Dropout(seed, int(self.threshold16), float(self.scale), None)
 
 
 def _dp(d):

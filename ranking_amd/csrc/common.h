@@ -283,13 +283,13 @@ __device__ __forceinline__ float wave_sum_u(float v) {
 // Items with tied scores end up with the SAME count: an occupancy table (OCC, n ints of scratch) finds them -- rare --
 // and only those add the equal scores in front of them.  XS is padded with -inf up to a multiple of 4 (+4).
 template <int NC>
-__device__ __forceinline__ void wave_rank_chunks(const float* XS, int n, int lane, int* RKS, int* OCC) {
+__device__ __forceinline__ void wave_rank_chunks(const float* XS, int n, int lane, int* RKS, int* OCC, int p0 = 0) {
   const float4* X4 = reinterpret_cast<const float4*>(XS);
   const int n4 = (n + 3) >> 2;
   float xi[NC];
   int cnt[NC];
 #pragma unroll
-  for (int k = 0; k < NC; ++k) { const int p = lane + 64 * k; xi[k] = p < n ? XS[p] : INFINITY; cnt[k] = 0; }
+  for (int k = 0; k < NC; ++k) { const int p = p0 + lane + 64 * k; xi[k] = p < n ? XS[p] : INFINITY; cnt[k] = 0; }
   int gq = 0;
   for (; gq + 2 <= n4; gq += 2) {
     const float4 xa = X4[gq], xb = X4[gq + 1];
@@ -311,7 +311,7 @@ __device__ __forceinline__ void wave_rank_chunks(const float* XS, int n, int lan
   }
 #pragma unroll
   for (int k = 0; k < NC; ++k) {
-    const int p = lane + 64 * k;
+    const int p = p0 + lane + 64 * k;
     if (p < n) { RKS[p] = cnt[k]; atomicAdd(&OCC[cnt[k]], 1); }
   }
 }
@@ -324,7 +324,8 @@ __device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int l
   else if (n <= 192) wave_rank_chunks<3>(XS, n, lane, RKS, OCC);
   else if (n <= 256) wave_rank_chunks<4>(XS, n, lane, RKS, OCC);
   else if (n <= 384) wave_rank_chunks<6>(XS, n, lane, RKS, OCC);      // (the NDCG counting kernel serves lists up to 512)
-  else wave_rank_chunks<8>(XS, n, lane, RKS, OCC);
+  else if (n <= 512) wave_rank_chunks<8>(XS, n, lane, RKS, OCC);
+  else for (int p0 = 0; p0 < n; p0 += 512) wave_rank_chunks<8>(XS, n, lane, RKS, OCC, p0);     // any n: 512 row items per sweep of the columns
   WAVE_LDS_SYNC();
   for (int q0 = 0; q0 < n; q0 += 64) {
     const int p = q0 + lane;

@@ -536,9 +536,10 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
         }
       }
     }
-    // publish: the wave's DS operations complete in order, so the state lands behind everything written above
+    // publish: release at workgroup scope (every LDS store above is ordered before the flag; the sweepers acquire it)
     WAVE_LDS_SYNC();
-    if (lane == 0) *reinterpret_cast<volatile int*>(&H->state) = 2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&H->state, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   GRP_STAMP(5);
 
@@ -555,9 +556,10 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
     int q = -1, npass = 0;
     {
       int st = 0;
-      if (lane == 0) st = *reinterpret_cast<volatile int*>(&H->state);
+      if (lane == 0) st = __hip_atomic_load(&H->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       st = __builtin_amdgcn_readfirstlane(st);
       if (st == 2) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the image and the header fields below were written before the flag
         npass = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&H->npass));
         int t = 0;
         if (lane == 0) t = (npass > 0) ? atomicAdd(&H->next_pass, 1) : 0;
@@ -573,7 +575,21 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
 #ifdef TFR_PROFILE_STAMPS
         ++grp_polls;
 #endif
-        if (++spins > (1l << 22)) break;                      // (a builder always finishes; never spin forever on a bug)
+        if (++spins > (1l << 22)) {
+          // a builder always finishes; if one ever does not, do not spin forever AND do not leave the outputs of the
+          // unswept lists uninitialised: poison them (NaN loss / gradient) so that the caller fails loudly
+          if (lane == 0) {
+            for (int pl = 0; pl < G; ++pl) {
+              if (!((pending >> pl) & 1u)) continue;
+              const int pb = GRP_HDR(pl)->b;
+              if (pb < 0) continue;
+              if (a.list_loss) a.list_loss[pb] = __builtin_nanf("");
+              if (a.dlogits) a.dlogits[(size_t)pb * L] = __builtin_nanf("");
+              if (a.row_loss) a.row_loss[(size_t)pb * L] = __builtin_nanf("");
+            }
+          }
+          break;
+        }
       }
       continue;
     }

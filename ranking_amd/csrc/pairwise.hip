@@ -1016,12 +1016,10 @@ int env_int(const char* name, int dflt);
 // One launch of the group kernel (dynamic LDS beyond 64 KiB needs the attribute once per instantiation).
 template <int IPL, bool AUX, bool IW>
 int launch_grp(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  if (lds > 64 * 1024) {                                     // per device and cheap: set whenever it is needed (thread-safe, any GPU)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lambdarank_group_kernel<IPL, AUX, IW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   const int N = (B + G - 1) / G;
   hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R, grp_lp(a.L), G);

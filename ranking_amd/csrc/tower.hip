@@ -74,7 +74,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // quarter-rate instructions and sat in every GEMM prologue -- the hidden-layer forward GEMM of BASELINE config 5
 // took 41.8 us with Dropout against 27.7 us without.  The callers walk aligned runs of 4 / 8 columns: one hash per
 // run (two for an 8-run at 8-bit fields).
-struct Drop { uint32_t seed; uint32_t thr; float scale; uint32_t lge; };     // lge = 2 .. 5
+struct Drop { uint32_t seed; uint32_t thr; float scale; uint32_t lge; const uint32_t* sp; };     // lge = 2 .. 5
+// The seed a kernel hashes with: the host's layer seed + (device step counter) * golden ratio.  The counter lives in
+// device memory (tfr_tower_dropout.step, nullable) so that a hipGraph replay of a training step draws a NEW mask: a
+// seed passed by value is baked into the captured launch and every replay would reuse the first step's mask.
+__device__ __forceinline__ Drop drop_resolve(const Drop d) {
+  Drop r = d;
+  if (d.thr != 0u && d.sp) r.seed = d.seed + (uint32_t)__builtin_amdgcn_readfirstlane((int)*d.sp) * 0x9E3779B9u;
+  r.sp = nullptr;
+  return r;
+}
 __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t m, uint32_t word) {
   uint32_t h = m * 0x9E3779B1u + word * 0x85EBCA77u + seed;
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
@@ -86,7 +95,7 @@ __device__ __forceinline__ void drop_run(const Drop d, uint32_t m, uint32_t c, f
   const uint32_t fb = 32u >> d.lge;                          // (wave-uniform: scalar registers)
   const uint32_t off = (c & ((1u << d.lge) - 1u)) << (5u - d.lge);
   uint32_t x0 = drop_hash(d.seed, m, c >> d.lge) >> off;
-  uint32_t x1 = x0 >> (4u * fb);
+  uint32_t x1 = d.lge == 2u ? 0u : x0 >> (4u * fb);          // (fb = 8: the shift would be by 32 -- x1 comes from the next word below)
   if (N == 8 && d.lge == 2u) x1 = drop_hash(d.seed, m, (c + 4u) >> 2);     // 8-bit fields: four columns per word
 #pragma unroll
   for (int j = 0; j < N; ++j) {
@@ -156,7 +165,7 @@ __device__ __forceinline__ float act_grad(int act, float y) {
 }
 
 template <int PRO>
-__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f, 2},
+__device__ __forceinline__ uint4 transform_chunk(uint4 v, const float* sc, const float* sh, const Drop drop = Drop{0, 0, 1.f, 2, nullptr},
                                                  uint32_t m = 0, uint32_t k = 0, int act = 0) {
   if (PRO == PRO_NONE) return v;
   uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -193,6 +202,7 @@ constexpr int WPITCH = 144;                      // bytes per row of a wave's 64
 template <int PRO, int EPI, bool GL>
 __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
   // [buf][A tile | B tile], then the per-column prologue coefficients.
   unsigned char* tiles = smem;
   float* s_scale = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
       // columns beyond K have scale = shift = 0 -> transform(0) = 0 for both modes
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, pdrop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 32 * i;
       uint4 va = RA.a[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, pdrop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
       *reinterpret_cast<uint4*>(tb + swz(row, c)) = RB.b[i];
     }
@@ -433,8 +443,8 @@ __global__ __launch_bounds__(256, 2) void tower_gemm_kernel(const GemmArgs g) {
         const uint2 zz = *reinterpret_cast<const uint2*>(slot);
         const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
         float kf[4] = {1.f, 1.f, 1.f, 1.f};
-        if (g.epi_drop.thr) {                           // d a / d relu = keep / (1 - rate): same hash as the forward
-          drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
+        if (edrop.thr) {                           // d a / d relu = keep / (1 - rate): same hash as the forward
+          drop_run<4>(edrop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -504,6 +514,7 @@ __device__ unsigned long long* g_prof_gemm = nullptr;
 template <int PRO, int EPI>
 __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
   unsigned char* tiles = smem;                    // [buf][A tile | B tile]
   float* s_scale = reinterpret_cast<float*>(smem + 4 * TILE2_BYTES);
   float* s_shift = s_scale + g.K;                 // K % 64 == 0
@@ -544,7 +555,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 64 * i;
-      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, g.pro_drop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
+      const uint4 va = transform_chunk<PRO>(RA.a[i], sc, sh, pdrop, (uint32_t)(g.row0 + m0 + row), (uint32_t)k, g.act);
       *reinterpret_cast<uint4*>(ta + swz(row, c)) = va;
     }
   };
@@ -698,8 +709,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256_kernel(const GemmArgs g)
           const uint2 zz = *reinterpret_cast<const uint2*>(slot);
           const float z[4] = {bf16_lo(zz.x), bf16_hi(zz.x), bf16_lo(zz.y), bf16_hi(zz.y)};
           float kf[4] = {1.f, 1.f, 1.f, 1.f};
-          if (g.epi_drop.thr) {
-            drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
+          if (edrop.thr) {
+            drop_run<4>(edrop, (uint32_t)(g.row0 + mb + row), (uint32_t)(nb + fn * 16 + fq * 4), kf);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -829,6 +840,7 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
 template <int PRO, int EPI, bool DROP>
 __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave & 3, wn = wave >> 2;
@@ -903,7 +915,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + k), sh1 = *reinterpret_cast<const f32x4*>(s_shift + k + 4);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
-          fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, g.pro_drop,
+          fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, pdrop,
                                             (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act);
       }
 #pragma unroll
@@ -1053,7 +1065,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
             const f32x4 y = z * pb[fn] + pe[fn];
             if (DROP) {
               float kf[4];
-              drop_run<4>(g.epi_drop, (uint32_t)(g.row0 + mb + fm * 16 + fr), (uint32_t)(n0 + nl + fn * 16 + fq * 4), kf);
+              drop_run<4>(edrop, (uint32_t)(g.row0 + mb + fm * 16 + fr), (uint32_t)(n0 + nl + fn * 16 + fq * 4), kf);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= kf[r];
             }
@@ -1346,8 +1358,9 @@ __global__ __launch_bounds__(256) void tower_out_kernel(const uint16_t* __restri
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         const float* __restrict__ w, const float* __restrict__ b,
-                                                        int O, float* __restrict__ out, const Drop drop, const int act) {
+                                                        int O, float* __restrict__ out, const Drop drop_in, const int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Drop drop = drop_resolve(drop_in);
   float* coef = reinterpret_cast<float*>(smem);          // [K/8][2 + O][8]
   const int stride = (2 + O) * 8;
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
@@ -1421,7 +1434,8 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
-    float* __restrict__ partial, int rows_per_block, const Drop drop, const float* __restrict__ pqr, const int act) {
+    float* __restrict__ partial, int rows_per_block, const Drop drop_in, const float* __restrict__ pqr, const int act) {
+  const Drop drop = drop_resolve(drop_in);
   constexpr int G = 256 / LPR, CW = LPR * 8;                   // row groups per block, columns per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem);                 // [G][(2 + O) * CW]
@@ -1583,6 +1597,7 @@ __device__ __forceinline__ bf16x4 lds_tr16(const unsigned char* p) {
 template <int PRO>
 __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Drop pdrop = drop_resolve(g.drop);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
   // XCD-aware map: the tiles_n * tiles_k output tiles of one M-slice run on ONE XCD at about
@@ -1623,7 +1638,7 @@ __global__ __launch_bounds__(256, 2) void tower_wgrad_kernel(const WgradArgs g) 
     for (int i = 0; i < 4; ++i) {
       const int row = r0 + 16 * i;
       uint4 va = ra[i];
-      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, g.drop, (uint32_t)(ms + (long)cur_step * 64 + row), (uint32_t)(k0 + cc * 8), g.act);
+      if (PRO != PRO_NONE) va = transform_chunk<PRO>(va, sc, sh, pdrop, (uint32_t)(ms + (long)cur_step * 64 + row), (uint32_t)(k0 + cc * 8), g.act);
       *reinterpret_cast<uint4*>(td + swz_t(row, cc)) = rd[i];
       *reinterpret_cast<uint4*>(ta + swz_t(row, cc)) = va;
     }
@@ -1879,19 +1894,19 @@ static inline bool split_mode(int arg, int& mode, int& act) {
 }
 
 Drop to_drop(const tfr_tower_dropout* d) {
-  if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f, 2u};
+  if (!d || d->threshold16 == 0) return Drop{0u, 0u, 1.0f, 2u, nullptr};
   const uint32_t t16 = d->threshold16 > 65535u ? 65535u : d->threshold16;
   // the narrowest field that represents the rate exactly: lge = 5 (1 bit) ... 2 (8 bits); the caller's scale is the
   // exact 1 / (1 - rate) in those cases
   for (uint32_t lge = 5; lge >= 2; --lge) {
     const uint32_t fb = 32u >> lge;
-    if ((t16 & ((1u << (16u - fb)) - 1u)) == 0u) return Drop{d->seed, t16 >> (16u - fb), d->scale, lge};
+    if ((t16 & ((1u << (16u - fb)) - 1u)) == 0u) return Drop{d->seed, t16 >> (16u - fb), d->scale, lge, d->step};
   }
   // otherwise the rate is rounded to a multiple of 1 / 256 and the scale follows the rounded rate (unbiased mask)
   uint32_t t8 = (t16 + 128u) >> 8;
   if (t8 < 1u) t8 = 1u;
   if (t8 > 255u) t8 = 255u;
-  return Drop{d->seed, t8, 256.0f / (256.0f - (float)t8), 2u};
+  return Drop{d->seed, t8, 256.0f / (256.0f - (float)t8), 2u, d->step};
 }
 
 int grid_for(long work_items, int block) {

@@ -180,20 +180,14 @@ class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
 
 
 # ------------------------------------------------------------------- helpers
-_CONST_CACHE: Dict[Any, torch.Tensor] = {}
+_CONST_CACHE = _ops.DeviceConstCache(64)        # graph-safe: entries a hipGraph capture has read are never evicted
 
 
 def _const_vector(n: int, value: float, device) -> torch.Tensor:
     """A cached, read-only [n] fp32 tensor filled with `value` (the per-list scale of an unweighted batch):
     saves a fill launch in every loss_and_grad call."""
-    key = (int(n), float(value), str(device))
-    t = _CONST_CACHE.get(key)
-    if t is None:
-        if len(_CONST_CACHE) > 64:
-            _CONST_CACHE.clear()
-        t = torch.full((n,), float(value), dtype=torch.float32, device=device)
-        _CONST_CACHE[key] = t
-    return t
+    return _CONST_CACHE.get((int(n), float(value), str(device)),
+                            lambda: torch.full((n,), float(value), dtype=torch.float32, device=device))
 
 
 def _keras_reduce(weighted, reduction):

@@ -114,9 +114,13 @@ class _TowerFn(torch.autograd.Function):
         zs, coefs = [], []
         k_in = x0.shape[1]
         rate = tower.dropout if training else 0.0
+        step_t = None
         if rate > 0.0:
-            tower._drop_step += 1
-            base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
+            # the step counter lives on the device (one add + one copy launch): a hipGraph replay of this forward draws a
+            # new mask, and the backward of THIS forward reads the copy it saved whatever runs in between
+            tower._drop_counter.add_(1)
+            step_t = tower._drop_counter.clone()
+            base = torch.initial_seed() & 0xffffffff
         # every weight cast of the step in one launch: [N, k_in] forward operands (k_in = staged width of the layer
         # input) and, when a backward will follow, the transposed [K, pad8(N)] dgrad operands of layers >= 1
         specs = [(Ws[l], False, k_in if l == 0 else Ws[l - 1].shape[0]) for l in range(n_h)]
@@ -149,11 +153,12 @@ class _TowerFn(torch.autograd.Function):
                     sc = sh = None
                     pro = T.PRO_NONE
             # Dropout after this layer's activation (keras/layers.py:72-73): applied by its consumers
-            drop = T.Dropout.make(rate, base + l * 0x632BE5AB) if rate > 0.0 else None
+            drop = T.Dropout.make(rate, base + l * 0x632BE5AB, step=step_t) if rate > 0.0 else None
             zs.append(z); coefs.append((pro, sc, sh, mean, rstd, drop))
             a_in, k_in = z, n_out
         logits = T.out_layer(a_in, k_in, pro, sc, sh, w_out, b_out, dropout=drop)
         ctx.tower, ctx.training = tower, training
+        tower._last_drops = [c[5] for c in coefs]
         ctx.x0, ctx.zs, ctx.coefs, ctx.in_bn = x0, zs, coefs, in_bn
         ctx.params = params
         return logits
@@ -310,7 +315,9 @@ class FusedTower(nn.Module):
         if not 0.0 <= float(dropout or 0.0) < 1.0:
             raise ValueError('dropout rate must be in [0, 1)')
         self.dropout = float(dropout or 0.0)
-        self._drop_step = 0
+        # training-step counter of the Dropout masks, on the device (see _TowerFn.forward)
+        self.register_buffer('_drop_counter', torch.zeros(1, dtype=torch.int32), persistent=False)
+        self._last_drops = []
         # True: backward adds into the existing .grad buffers itself (see _TowerFn.backward); set by
         # distributed.FlatGradBucket.attach(), whose flat buffer owns every .grad for the life of the model.
         self.accumulate_grads_in_place = False
@@ -340,6 +347,11 @@ class FusedTower(nn.Module):
         nn.init.xavier_uniform_(w)
         self.out_weight = nn.Parameter(w)
         self.out_bias = nn.Parameter(torch.zeros(self.output_units))
+
+    def dropout_structs(self):
+        """The Dropout structs (step counter folded into the seed) of the LAST training forward, one per hidden layer:
+        what a test needs to rebuild the keep masks with ``_tower_ops.dropout_mask``."""
+        return [d.resolved() if d is not None else None for d in self._last_drops]
 
     @property
     def moving_mean(self):

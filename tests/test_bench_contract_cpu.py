@@ -95,3 +95,48 @@ def test_bench_refuses_to_run_without_a_gpu():
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0'],
                          capture_output=True, text=True)
     assert res.returncode != 0 and 'MI355X' in (res.stderr + res.stdout)              # no CPU fallback, loudly
+
+
+def test_extra_workloads_run_in_child_processes():
+    """a GPU fault aborts the whole process, so every `also` workload gets its own: the child command is
+    this script with --workload X --also none (N ranks of it under torch.distributed.run at N > 1)."""
+    import argparse
+    args = argparse.Namespace(no_cpu_baseline=False, graph=True, dropout=None)
+    cmd = bench.child_command('pairwise_lambda', args, 1, 20, 5)
+    assert cmd[0] == sys.executable and cmd[1].endswith('bench.py')
+    assert cmd[cmd.index('--workload') + 1] == 'pairwise_lambda' and cmd[cmd.index('--also') + 1] == 'none'
+    assert cmd[cmd.index('--steps') + 1] == '20' and cmd[cmd.index('--warmup') + 1] == '5'
+    assert '--no-cpu-baseline' not in cmd and '--no-graph' not in cmd and '--dropout' not in cmd
+    args = argparse.Namespace(no_cpu_baseline=True, graph=False, dropout=0.25)
+    cmd = bench.child_command('e2e_softmax', args, 4, 10, 3, port=29999)
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-port') + 1] == '29999' and cmd[cmd.index('--gpus') + 1] == '4'
+    assert '--no-cpu-baseline' in cmd and '--no-graph' in cmd and cmd[cmd.index('--dropout') + 1] == '0.25'
+
+
+def test_a_dead_or_silent_child_costs_one_entry(monkeypatch, tmp_path):
+    """run_child returns an error dict (never raises) when the child aborts, prints no JSON line or hangs; a healthy
+    child's last JSON line is the result."""
+    import argparse
+    args = argparse.Namespace(no_cpu_baseline=True, graph=True, dropout=None)
+
+    def fake(code):
+        script = tmp_path / 'child.py'
+        script.write_text(code)
+        monkeypatch.setattr(bench, 'child_command', lambda *a, **k: [sys.executable, str(script)])
+
+    fake('import os, sys\nsys.stderr.write("Memory access fault by GPU node-2\\n")\nos.abort()\n')
+    r = bench.run_child('pairwise_lambda', args, 1, 10, 3, 30)
+    assert 'error' in r and 'rc' in r['error'] and 'Memory access fault' in r['stderr_tail']
+    fake('print("no json here")\n')
+    assert 'printed no JSON line' in bench.run_child('pairwise_lambda', args, 1, 10, 3, 30)['error']
+    fake('import time\ntime.sleep(60)\n')
+    assert 'exceeded' in bench.run_child('pairwise_lambda', args, 1, 10, 3, 1)['error']
+    fake('print("noise")\nprint(\'{"metric": "m", "value": 2.5}\')\nprint("trailing noise")\n')
+    r = bench.run_child('pairwise_lambda', args, 1, 10, 3, 30)
+    assert r['value'] == 2.5 and r['wall_s'] > 0
+
+
+def test_last_json_line_takes_the_last_parseable_one():
+    assert bench.last_json_line('{"a": 1}\n{"a": 2}\nnot json\n{broken') == {'a': 2}
+    assert bench.last_json_line('nothing') is None

@@ -433,8 +433,7 @@ def test_fused_tower_dropout_forward_backward(M, F, hidden, O, act, bn, rate):
     got.backward(up)
     g_got = [p.grad.clone() for p in tower.parameters()]
     tower.zero_grad()
-    base = (torch.initial_seed() + tower._drop_step * 0x9E3779B9) & 0xffffffff
-    masks = [t.dropout_mask(t.Dropout.make(rate, base + l * 0x632BE5AB), M, h, DEV) for l, h in enumerate(hidden)]
+    masks = [t.dropout_mask(d, M, h, DEV) for d, h in zip(tower.dropout_structs(), hidden)]   # (step counter read back)
     want = ref_tower_dropout(x, tower, masks)
     want.backward(up)
     g_want = [p.grad.clone() for p in tower.parameters()]

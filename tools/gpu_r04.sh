@@ -1,0 +1,72 @@
+#!/bin/bash
+# Round-4 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r04.sh <tag> <what...>
+#   what: repro | final | tests | one:<workload> | prof:<workload> | pmc:<workload>
+set -u
+TAG=${1:-r04}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+DRV="--gpus 1 --steps 20 --warmup 5"
+brief() { python tools/bench_brief.py "$1" 2>/dev/null || tail -c 600 "$1"; }
+for what in "$@"; do
+  case $what in
+    repro)
+      # the driver's exact command first, then every workload of it alone (driver's K / W), graph and eager
+      ( time timeout 900 python3 bench.py $DRV > $OUT/driver.out 2> $OUT/driver.err ) 2> $OUT/driver.time; echo "driver rc=$?"
+      tail -n 4 $OUT/driver.err; tail -n 1 $OUT/driver.out | cut -c1-400
+      for w in approx_ndcg pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        for mode in graph eager; do
+          extra=""; [ $mode = eager ] && extra="--no-graph"
+          timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 20 --warmup 5 $extra > $OUT/one_${w}_$mode.out 2> $OUT/one_${w}_$mode.err
+          echo "$w $mode rc=$?"; tail -n 2 $OUT/one_${w}_$mode.err | cut -c1-300
+        done
+      done ;;
+    hunt)
+      # localise the e2e graph-mode fault: tight allocations (one hipMalloc per tensor), a sync + name after every ABI call
+      for w in e2e_groupwise_gumbel e2e_approx_ndcg_l1000; do
+        for d in 0.5 0; do
+          PYTORCH_NO_HIP_MEMORY_CACHING=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1 TFR_SYNC_EVERY_CALL=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 3 --warmup 1 --no-graph --dropout $d > $OUT/hunt_${w}_d$d.out 2> $OUT/hunt_${w}_d$d.err
+          echo "hunt eager nocache $w dropout=$d rc=$?"; grep -v "^\[tfr\]" $OUT/hunt_${w}_d$d.err | tail -n 2 | cut -c1-300; grep "^\[tfr\]" $OUT/hunt_${w}_d$d.err | tail -n 3
+          timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 20 --warmup 5 --dropout $d > $OUT/graph_${w}_d$d.out 2> $OUT/graph_${w}_d$d.err
+          echo "graph $w dropout=$d rc=$?"; tail -n 2 $OUT/graph_${w}_d$d.err | cut -c1-300
+        done
+      done ;;
+    hunt2)
+      C="--also none --no-cpu-baseline --busy-seconds 0 --steps 20 --warmup 5"
+      for w in e2e_groupwise_gumbel e2e_approx_ndcg_l1000; do
+        for kt in none last first; do
+          timeout 300 python3 bench.py --workload $w $C --kernel-timing $kt --dropout 0 > $OUT/g_${w}_$kt.out 2> $OUT/g_${w}_$kt.err
+          echo "graph $w kernel-timing=$kt dropout=0 rc=$?"; tail -n 2 $OUT/g_${w}_$kt.err | cut -c1-200
+        done
+      done
+      for w in e2e_groupwise_gumbel e2e_approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda; do
+        PYTORCH_NO_HIP_MEMORY_CACHING=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1 TFR_SYNC_EVERY_CALL=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 3 --warmup 1 --no-graph --kernel-timing none > $OUT/hunt_$w.out 2> $OUT/hunt_$w.err
+        echo "hunt eager nocache $w rc=$?"; grep -v "^\[tfr\]" $OUT/hunt_$w.err | tail -n 2 | cut -c1-300; grep "^\[tfr\]" $OUT/hunt_$w.err | tail -n 3; grep -c "^\[tfr\]" $OUT/hunt_$w.err
+      done ;;
+    final)
+      # the LAST GPU action of the round: the driver command, three times, on the final tree
+      for i in 1 2 3; do
+        ( time timeout 1200 python3 bench.py $DRV > $OUT/final_$i.out 2> $OUT/final_$i.err ) 2> $OUT/final_$i.time; echo "final $i rc=$?"
+        tail -n 2 $OUT/final_$i.err | cut -c1-300; tail -n 1 $OUT/final_$i.out | cut -c1-600; tail -n 3 $OUT/final_$i.time
+      done ;;
+    tests)
+      timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+      tail -n 40 $OUT/pytest_gpu.log
+      timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log ;;
+    one:*)
+      w=${what#one:}
+      timeout 400 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
+      echo "$w rc=$?"; tail -n 2 $OUT/one_$w.err | cut -c1-300; tail -n 1 $OUT/one_$w.out | cut -c1-700 ;;
+    prof:*)
+      w=${what#prof:}
+      timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
+      python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1
+      head -n 40 $OUT/stats_$w.txt ;;
+    pmc:*)
+      w=${what#pmc:}
+      timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_fetch_$w.log 2>&1
+      timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
+      for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; head -n 12 $OUT/pmc_${p}_$w.txt | cut -c1-200; done ;;
+    *) echo "unknown step $what" ;;
+  esac
+done
