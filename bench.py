@@ -332,7 +332,11 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         def graph_step():
             g_fb.replay()
             return static_value
-        info.update(step=graph_step, all_reduce=lambda: None)
+        # The captured launches hold the ADDRESSES of the model, the gradient bucket, the features: those objects must
+        # live as long as the graph does.  (Round 3 returned only `graph_step`; the scorer and the bucket were garbage
+        # collected on return, their blocks went back to the allocator's cache, and the first empty_cache() -- the entry
+        # of the next capture -- unmapped what the replays read and write: the driver's bench died of a GPU page fault.)
+        info.update(step=graph_step, all_reduce=lambda: None, keep_alive=(fwd_bwd, sgd, eager_step, g_fb, static_value))
         return info
     with capture(g_fb):
         static_value = fwd_bwd()
@@ -345,7 +349,8 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         s = bucket.all_reduce(static_scalars, average=True)
         g_sgd.replay()
         return s[0] / max(world, 1)
-    info.update(step=graph_step, all_reduce=lambda: bucket.all_reduce(static_scalars, average=True))
+    info.update(step=graph_step, all_reduce=lambda: bucket.all_reduce(static_scalars, average=True),
+                keep_alive=(fwd_bwd, sgd, eager_step, g_fb, g_sgd, static_value, static_scalars))
     return info
 
 
@@ -570,6 +575,7 @@ def graph_of(eager):
     def step():
         graph.replay()
         return static_out
+    step.keep_alive = (eager, graph)                        # the captured addresses belong to what `eager` closes over
     return step
 
 

@@ -43,6 +43,13 @@ for what in "$@"; do
         PYTORCH_NO_HIP_MEMORY_CACHING=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1 TFR_SYNC_EVERY_CALL=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 3 --warmup 1 --no-graph --kernel-timing none > $OUT/hunt_$w.out 2> $OUT/hunt_$w.err
         echo "hunt eager nocache $w rc=$?"; grep -v "^\[tfr\]" $OUT/hunt_$w.err | tail -n 2 | cut -c1-300; grep "^\[tfr\]" $OUT/hunt_$w.err | tail -n 3; grep -c "^\[tfr\]" $OUT/hunt_$w.err
       done ;;
+    hunt3)
+      for e in none empty_cache gc gc_empty kernel_eager trivial_graph trivial_graph_keep kernel_graph replay_first_then_kernel_graph; do
+        timeout 200 python3 tools/fault_repro.py $e > $OUT/fr_$e.out 2> $OUT/fr_$e.err
+        echo "experiment $e rc=$? : $(tail -n 1 $OUT/fr_$e.out) | $(grep -v amdgpu.ids $OUT/fr_$e.err | tail -n 1 | cut -c1-160)"
+      done ;;
+    hunt4)
+      TAG=$TAG timeout 300 python3 tools/fault_repro.py snapshot e2e_groupwise_gumbel > $OUT/snap.out 2> $OUT/snap.err; echo "snapshot rc=$?"; tail -n 3 $OUT/snap.err | cut -c1-200; ls -la $OUT ;;
     final)
       # the LAST GPU action of the round: the driver command, three times, on the final tree
       for i in 1 2 3; do
