@@ -155,6 +155,17 @@ int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t*
                         float temperature, int lanes_per_row, float* loss_out, float* weight_out,
                         float* dlogits_out, const int32_t* list_order, void* stream);
 
+/* tfr_approx_ndcg_f32 that also returns the reduced scalar without a launch of its own:
+ *   loss_sum_out [1]  sum_b loss_out[b] * list_scale[b] (list_scale NULL: sum_b loss_out[b]), added in a fixed order
+ *                     by the last workgroup to finish its forward pass (compute_weighted_loss / the Keras reduction,
+ *                     losses_impl.py:787-814, keras/losses.py:264-280)
+ *   ticket       [1]  uint32 in device memory, zero before the first launch, left zero; one per stream in flight. */
+int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                            const float* inv_log1p, const float* list_scale, int B, int L,
+                            float temperature, int lanes_per_row, float* loss_out, float* weight_out,
+                            float* dlogits_out, const int32_t* list_order, float* loss_sum_out,
+                            uint32_t* ticket, void* stream);
+
 /* Longest-first launch order for the O(n^2) loss kernels (their `list_order` argument, nullable):
  * order_out[B] = list indices by decreasing number of valid items (64 length classes; arbitrary
  * order inside a class).  Results of the loss kernels
@@ -162,6 +173,12 @@ int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t*
  *   workspace  int32[B] scratch owned by the caller. */
 int tfr_list_order_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
                        int32_t* workspace, void* stream);
+/* The same order from ONE launch (a persistent grid around a grid barrier).
+ *   state  int32[tfr_list_order_state_ints()] in device memory, zero before the first launch, left zero; one per
+ *          stream in flight. */
+int tfr_list_order_state_ints(void);
+int tfr_list_order_fused_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
+                             int32_t* workspace, int32_t* state, void* stream);
 
 /* losses_impl.ApproxMRRLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:77-106, 1606-1632): loss_b = -sum_i (l_i / sum l) / approx_rank_i; same

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import functools
+import os
 from collections import OrderedDict
 from typing import Callable, Dict, Optional, Sequence, Tuple
 
@@ -263,6 +264,28 @@ def mrr_metric(labels, predictions, weights, mask, topns):
 _BALANCE_MIN_LISTS = 1024      # below this the ordering launch costs more than the tail it removes
 
 
+_device_state: Dict[Tuple, torch.Tensor] = {}
+
+
+def _zero_state(kind: str, n_ints: int, device) -> torch.Tensor:
+    """A persistent zero-initialised int32 scratch of a kernel that synchronises its workgroups through device memory
+    (grid barrier / last-workgroup ticket) and leaves it zero: one per (kind, device), never freed -- a captured hipGraph
+    holds its address.  The launches that use it must be stream-ordered per device (they are: the loss kernels run on the
+    training stream).  It cannot be created inside a stream capture (its storage would belong to the graph's pool and
+    the zero fill would become a node of the graph): run the step once eagerly first, as every capture does anyway."""
+    key = (kind, str(device))
+    t = _device_state.get(key)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the %s scratch must exist before a stream capture: run the step once eagerly first' % kind)
+        t = torch.zeros(n_ints, dtype=torch.int32, device=device)
+        _device_state[key] = t
+    return t
+
+
+_ORDER_FUSED = bool(int(os.environ.get('TFR_ORDER_FUSED', '1')))
+
+
 def list_order(labels, mask=None):
     """tfr_list_order_i32: int32 [B] list indices, longest valid length first (launch order of the
     O(n^2) loss kernels; their results do not depend on it)."""
@@ -270,7 +293,13 @@ def list_order(labels, mask=None):
     B, L = labels.shape
     order = torch.empty((B,), dtype=torch.int32, device=labels.device)
     ws = torch.empty((B,), dtype=torch.int32, device=labels.device)
-    rc = _lib.load().tfr_list_order_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _stream())
+    lib = _lib.load()
+    if _ORDER_FUSED and B >= 512:                             # one launch: a persistent grid around a grid barrier
+        state = _zero_state('list_order', int(lib.tfr_list_order_state_ints()), labels.device)
+        rc = lib.tfr_list_order_fused_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _ptr(state), _stream())
+        _lib.check(rc, 'tfr_list_order_fused_i32')
+        return order
+    rc = lib.tfr_list_order_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _stream())
     _lib.check(rc, 'tfr_list_order_i32')
     return order
 
@@ -290,7 +319,9 @@ def _auto_order(labels, mask, balance, min_list_size):
 
 
 def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lanes_per_row=0,
-                want_grad=True, balance=None):
+                want_grad=True, balance=None, want_sum=False):
+    """want_sum=True: a fourth result, the 0-d sum_b loss_b * list_scale_b, added up in a fixed order inside the same
+    launch (tfr_approx_ndcg_sum_f32) -- the scalar a reduced loss returns."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
@@ -299,6 +330,16 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    if want_sum:
+        total = torch.empty((), dtype=torch.float32, device=logits.device)
+        ticket = _zero_state('loss_sum', 1, logits.device)
+        rc = _lib.load().tfr_approx_ndcg_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
+                                                 _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
+                                                 _ptr(loss), _ptr(weight), _ptr(dlogits),
+                                                 _ptr(_auto_order(labels, mask, balance, 192)), _ptr(total),
+                                                 _ptr(ticket), _stream())
+        _lib.check(rc, 'tfr_approx_ndcg_sum_f32')
+        return loss, weight, dlogits, total
     rc = _lib.load().tfr_approx_ndcg_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                          _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
                                          _ptr(loss), _ptr(weight), _ptr(dlogits),

@@ -37,6 +37,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kFastRange = 160.0f;
+// Two sigmoids from ONE v_rcp_f32 (round 4): 1/a = b * rcp(a b), 1/b = a * rcp(a b).  The reciprocal is a
+// quarter-rate instruction (8.5 issue cycles against 2.4 for an fma, tools/ubench.hip), so a pair of columns costs
+// one rcp + one multiply + two fmas into the accumulators instead of two rcps + two adds.  a, b = 1 + E_i F_j must
+// stay FINITE (inf * rcp(inf) = NaN): the logit range of the list is bounded so that E_i F_j <= e^87 < FLT_MAX; a
+// product a b that overflows has both sigmoids below 2^-64 and yields 0 for both.  Lists beyond that range keep one
+// rcp per pair (kFastRange), beyond that the per-pair exponential.
+constexpr float kPairRange = 87.0f;
+// ... and r = rcp(a b) must stay NORMAL (v_rcp_f32 flushes a denormal result to 0, and 0 times a huge partner is 0
+// where the true sigmoid may be 1/3): a and b are carried scaled by c = 2^-40 (a' = c + (c E_i) F_j, the same fma),
+// so a' b' lies in [2^-80, 2^171): a product beyond FLT_MAX (or one whose reciprocal flushes) has BOTH sigmoids below
+// 2^-80.  The row sums accumulate sigma / c (the fma into the accumulator is unchanged) and are scaled back once per row.
+constexpr float kPairScale = 0x1p-40f;
 
 struct Smem {
   float* red;      // [32]
@@ -97,7 +109,8 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
                                    const float* __restrict__ list_scale, int L, int Lp, int P,
                                    float temperature, int C, float* __restrict__ loss_out,
                                    float* __restrict__ weight_out, float* __restrict__ dlogits_out, int metric,
-                                   const int* __restrict__ order) {
+                                   const int* __restrict__ order, float* __restrict__ loss_sum,
+                                   unsigned int* __restrict__ ticket, int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const Smem s = carve(smem_raw, Lp, P);
   const int tid = threadIdx.x, T = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = T >> 6;
@@ -233,6 +246,7 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
     loss_out[b] = -(dcg * inv_max_dcg);
     weight_out[b] = nonzero ? 1.0f : 0.0f;
   }
+  if (loss_sum && wid == 0) grid_weighted_sum_last(loss_out, list_scale, B, loss_sum, ticket, lane);   // (wave 0 stored the entry)
   if (!dlogits_out) return;
   __syncthreads();
 
@@ -371,7 +385,8 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
     float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
-    float* __restrict__ dlogits_out, int max_runs, int metric, const int* __restrict__ order) {
+    float* __restrict__ dlogits_out, int max_runs, int metric, const int* __restrict__ order, int pair_rcp,
+    float* __restrict__ loss_sum, unsigned int* __restrict__ ticket, int B) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
   float* E = X + Lp;                               // [Lp] exp(x - m)
@@ -462,8 +477,12 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   const int n4p = iters * C;                          // group walks `iters` float4 column groups; the padding
   const float m = 0.5f * (xmax + xmin);               // groups hold F = +inf (sigma = 0) and A = 0
   const bool fast = (xmax - xmin) <= kFastRange;
+  const bool pair2 = pair_rcp && (xmax - xmin) <= kPairRange;      // two sigmoids per reciprocal in the forward sweep
+  // padding columns: F = +inf (sigma = 0); on the pair path F = 0 (a = 1, sigma = 1 EXACTLY when both columns of a
+  // pair are padding, within an ulp next to a real column) and the padding count is taken off the rank afterwards
+  const float f_pad = pair2 ? 0.0f : INFINITY;
   for (int i = lane; i < n4p * 4; i += 64) {
-    float e = 0.f, f = INFINITY;
+    float e = 0.f, f = f_pad;
     if (i < n) {
       const float xv = X[i];
       const float t_hi = xv - m;
@@ -485,12 +504,29 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   const float4* F4 = reinterpret_cast<const float4*>(F);
   const float4* X4 = reinterpret_cast<const float4*>(X);
   const float4* A4 = reinterpret_cast<const float4*>(A);
+  const float pad_cols = pair2 ? (float)(n4p * 4 - n) : 0.0f;       // every padding column added sigma = 1 to a row's sum
   float dcg = 0.f;
   for (int row0 = 0; row0 < n; row0 += rows_per_pass) {
     const int row = row0 + rsub;
     const bool active = row < n;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (fast) {
+    if (pair2) {
+      // columns (0, 2) and (1, 3) of a float4 share a reciprocal: d01 * d23 = {a0 a2, a1 a3}, r = 1 / that,
+      // {s0, s1} = d23 * r, {s2, s3} = d01 * r -- 2 v_pk_fma + 1 v_pk_mul + 2 v_rcp + 2 v_pk_fma per 4 pairs
+      const float Ei = (active ? E[row] : 0.f) * kPairScale;
+      const f32x2 Ei2 = {Ei, Ei}, one2 = {kPairScale, kPairScale};
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+        const float4 f = F4[c + it * C];
+        const f32x2 d01 = __builtin_elementwise_fma(Ei2, f32x2{f.x, f.y}, one2);
+        const f32x2 d23 = __builtin_elementwise_fma(Ei2, f32x2{f.z, f.w}, one2);
+        const f32x2 pq = d01 * d23;
+        const f32x2 r = {fast_rcp(pq.x), fast_rcp(pq.y)};
+        acc01 = __builtin_elementwise_fma(d23, r, acc01);
+        acc23 = __builtin_elementwise_fma(d01, r, acc23);
+      }
+      a0 = acc01.x * kPairScale; a1 = acc01.y * kPairScale; a2 = acc23.x * kPairScale; a3 = acc23.y * kPairScale;
+    } else if (fast) {
       // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): 2 + 2 full-rate instructions and 4 v_rcp_f32 per 4 pairs
       const float Ei = active ? E[row] : 0.f;
       const f32x2 Ei2 = {Ei, Ei}, one2 = {1.0f, 1.0f};
@@ -514,7 +550,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     float acc = (a0 + a1) + (a2 + a3);
     for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (active && c == 0) {
-      const float r = acc + 0.5f;
+      const float r = (acc - pad_cols) + 0.5f;                           // (pad_cols = 0 off the pair path)
       const float gg = G[row];
       if (metric == TFR_APPROX_MRR) {                                 // term = l / r, d term / d r = -l / r^2
         const float ir = 1.0f / r;                                    // (per row, not per pair: exact division)
@@ -533,6 +569,9 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     loss_out[b] = -(dcg * inv_max_dcg);
     weight_out[b] = nonzero ? 1.0f : 0.0f;
   }
+  // sum_b loss_b * list_scale_b (the scalar the reduced loss returns): by the last wave to get here, while the others
+  // are in their backward sweeps
+  if (loss_sum) grid_weighted_sum_last(loss_out, list_scale, B, loss_sum, ticket, lane);
   TFR_STAMP(4);
   if (!dlogits_out) return;
   __syncthreads();
@@ -598,12 +637,15 @@ int env_int(const char* name, int dflt);
 template <int IPL>
 int launch_wave(const float* logits, const float* labels, const uint8_t* mask, const float* inv_log1p,
                 const float* list_scale, int B, int L, float temperature, int C, float* loss_out,
-                float* weight_out, float* dlogits_out, hipStream_t stream, int metric, const int* order) {
+                float* weight_out, float* dlogits_out, hipStream_t stream, int metric, const int* order,
+                float* loss_sum, unsigned int* ticket) {
   const int Lp = ((L + 3) / 4 + C) * 4;           // room for the padding column groups of the uniform sweeps
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
+  static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 1);   // 0: one reciprocal per pair everywhere (round 3)
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
-                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order);
+                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order,
+                     pair_rcp, loss_sum, ticket, B);
   return (int)hipGetLastError();
 }
 
@@ -617,12 +659,17 @@ int env_int(const char* name, int dflt) {
 static int approx_dispatch(int metric, const float* logits, const float* labels, const uint8_t* mask,
                            const float* inv_log1p, const float* list_scale, int B, int L,
                            float temperature, int lanes_per_row, float* loss_out,
-                           float* weight_out, float* dlogits_out, const int* order, void* stream) {
+                           float* weight_out, float* dlogits_out, const int* order, void* stream,
+                           float* loss_sum = nullptr, unsigned int* ticket = nullptr) {
   if (!logits || !labels || (!inv_log1p && metric == TFR_APPROX_NDCG) || !loss_out || !weight_out || B < 0 || L <= 0)
     return TFR_EINVAL;
   if (!(temperature > 0.0f)) return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
-  if (B == 0) return TFR_OK;
+  if ((loss_sum != nullptr) != (ticket != nullptr)) return TFR_EINVAL;
+  if (B == 0) {
+    if (loss_sum) return (int)hipMemsetAsync(loss_sum, 0, sizeof(float), (hipStream_t)stream);
+    return TFR_OK;
+  }
   static const int env_threads = env_int("TFR_APPROX_THREADS", 0);
   static const int env_lanes = env_int("TFR_APPROX_LANES", 0);
   static const int env_wave = env_int("TFR_APPROX_WAVE", 1);      // 0 forces the block kernel
@@ -633,11 +680,11 @@ static int approx_dispatch(int metric, const float* logits, const float* labels,
   // alone fills the chip with single waves (otherwise several waves share a list).
   if (env_wave && env_threads == 0 && (L <= 256 || (L <= 1024 && B >= env_wave_min_b))) {
     hipStream_t st = (hipStream_t)stream;
-    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
-    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
-    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
-    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
-    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order);
+    if (L <= 64) return launch_wave<1>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order, loss_sum, ticket);
+    if (L <= 128) return launch_wave<2>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order, loss_sum, ticket);
+    if (L <= 256) return launch_wave<4>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order, loss_sum, ticket);
+    if (L <= 512) return launch_wave<8>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order, loss_sum, ticket);
+    return launch_wave<16>(logits, labels, mask, inv_log1p, list_scale, B, L, temperature, C, loss_out, weight_out, dlogits_out, st, metric, order, loss_sum, ticket);
   }
   int T = env_threads > 0 ? env_threads : (L <= 128 ? 64 : (L <= 512 ? 128 : 512));
   if (T % 64 || T > 1024) return TFR_EINVAL;
@@ -652,7 +699,7 @@ static int approx_dispatch(int metric, const float* logits, const float* labels,
   }
   hipLaunchKernelGGL(approx_ndcg_kernel, dim3(B), dim3(T), lds, (hipStream_t)stream, logits, labels,
                      mask, inv_log1p, list_scale, L, Lp, P, temperature, C, loss_out, weight_out,
-                     dlogits_out, metric, order);
+                     dlogits_out, metric, order, loss_sum, ticket, B);
   return (int)hipGetLastError();
 }
 
@@ -664,6 +711,16 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
                                    void* stream) {
   return approx_dispatch(TFR_APPROX_NDCG, logits, labels, mask, inv_log1p, list_scale, B, L, temperature,
                          lanes_per_row, loss_out, weight_out, dlogits_out, list_order, stream);
+}
+
+extern "C" int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                       const float* inv_log1p, const float* list_scale, int B, int L,
+                                       float temperature, int lanes_per_row, float* loss_out,
+                                       float* weight_out, float* dlogits_out, const int32_t* list_order,
+                                       float* loss_sum_out, uint32_t* ticket, void* stream) {
+  if (!loss_sum_out || !ticket) return TFR_EINVAL;
+  return approx_dispatch(TFR_APPROX_NDCG, logits, labels, mask, inv_log1p, list_scale, B, L, temperature,
+                         lanes_per_row, loss_out, weight_out, dlogits_out, list_order, stream, loss_sum_out, ticket);
 }
 
 extern "C" int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* mask,

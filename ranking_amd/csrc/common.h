@@ -342,6 +342,40 @@ __device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int l
   WAVE_LDS_SYNC();
 }
 
+// out[0] = sum_i vec[i] * w[i] (w nullable) over the B per-list values of a launch, computed by the LAST workgroup to
+// reach this point (a ticket in device memory), in a FIXED order (lane l adds i = l, l + 64, ... then the wave tree), so
+// that the scalar a reduced loss returns needs no launch of its own.  Called by ONE wavefront of every workgroup after
+// the workgroup's own vec entry has been stored by that wavefront.  `ticket` (one uint32, zero before the first launch)
+// is left zero.  Release / acquire at agent scope order the stores of the other workgroups before the loads here.
+__device__ __forceinline__ void grid_weighted_sum_last(const float* __restrict__ vec, const float* __restrict__ w, int B, float* out,
+                                                       unsigned int* ticket, int lane) {
+  unsigned int t = 0;
+  if (lane == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+  if (t != gridDim.x - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  // (plain loads: the acquire above has dropped this CU's stale lines, and ordinary loads can be batched -- 16 in flight
+  // per lane; one atomic load at a time made this loop 256 dependent round trips = 0.27 ms at B = 16384)
+  float acc = 0.f;
+  int i = lane;
+  for (; i + 15 * 64 < B; i += 16 * 64) {
+    float v[16], ww[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { v[u] = vec[i + 64 * u]; ww[u] = w ? w[i + 64 * u] : 1.0f; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(v[u], ww[u], acc);
+  }
+  for (; i < B; i += 64) acc = __builtin_fmaf(vec[i], w ? w[i] : 1.0f, acc);
+  acc = wave_sum_u(acc);
+  if (lane == 0) {
+    out[0] = acc;
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // sum_p sorted_desc(g)[p] * table[p] for NON-NEGATIVE g (element e = lane + 64*r, zero beyond
 // L) without sorting: the sorted sequence is a few runs of equal values, so repeatedly take the
 // largest remaining value v, its multiplicity c, and add v * sum(table[pos .. pos + c)).  Graded

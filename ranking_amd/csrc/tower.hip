@@ -113,6 +113,22 @@ __device__ __forceinline__ void drop_pair(const Drop d, uint32_t m, uint32_t kpa
   f1 = (__builtin_amdgcn_ubfe(h, off + fb, fb) >= d.thr) ? d.scale : 0.0f;
 }
 
+// Stochastic rounding of the BatchNorm-backward output dz = p * dy + q * z + r to bf16 (round 4).  dy is stored as bf16
+// (an 8-bit lattice k * 2^e), p is one fp32 factor per column, and s = q * z + r -- the terms that make sum_m dz = 0 and
+// sum_m dz * zhat = 0 -- is ~ 1 / sqrt(M) of |dy|: below half a bf16 ulp once M reaches 10^5.  Round-to-nearest of
+// p * k * 2^e + s then returns round(p * k * 2^e) unless p * k sits within |s| of a rounding boundary, and p * k takes only
+// 128 positions per column: the share of s that survives is a per-column accident, the column sums of dz drift away from
+// zero, and every gradient that sees the MEAN of the layer input (weights / BatchNorm parameters below a ReLU) picks up an
+// error that grows like sqrt(M) against the signal (measured at M = 819 200: 3.4 % on a weight matrix, 5.4 % on a beta,
+// against 0.6 % at M = 51 200; tools/tower_error_probe.py).  Adding 16 uniform bits below the kept mantissa before the
+// truncation makes E[bf16(x)] = x whatever the lattice: the drift becomes zero-mean noise that averages out over M.
+// The dither is a fixed hash of (row, column pair): the same bits on every run and in both backward paths.
+constexpr uint32_t kDitherSeed = 0x5bd1e995u;
+__device__ __forceinline__ uint32_t pack_bf16_sr(float a, float b, uint32_t h) {
+  const uint32_t ua = __float_as_uint(a) + (h & 0xffffu), ub = __float_as_uint(b) + (h >> 16);
+  return (ub & 0xffff0000u) | (ua >> 16);
+}
+
 // byte offset of 16-byte chunk c (0..7) of row r inside a swizzled [128][64] bf16 tile
 __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
@@ -1434,7 +1450,8 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
     const uint16_t* __restrict__ z, long ldz, int M, int K, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ dlogits, int O, uint16_t* __restrict__ dy, long lddy,
-    float* __restrict__ partial, int rows_per_block, const Drop drop_in, const float* __restrict__ pqr, const int act) {
+    float* __restrict__ partial, int rows_per_block, const Drop drop_in, const float* __restrict__ pqr, const int act,
+    const int sr) {
   const Drop drop = drop_resolve(drop_in);
   constexpr int G = 256 / LPR, CW = LPR * 8;                   // row groups per block, columns per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1492,7 +1509,14 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
           out[e] = __builtin_fmaf(cp[e], db, __builtin_fmaf(cq[e], zz, cr[e]));
         }
       }
-      if (MODE != 1)
+      if (MODE == 2 && sr) {                                   // dz: unbiased rounding (see pack_bf16_sr)
+        const uint32_t kp2 = (uint32_t)k >> 1;
+        *reinterpret_cast<uint4*>(dy + m * lddy + k) =
+            make_uint4(pack_bf16_sr(out[0], out[1], drop_hash(kDitherSeed, (uint32_t)m, kp2)),
+                       pack_bf16_sr(out[2], out[3], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 1u)),
+                       pack_bf16_sr(out[4], out[5], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 2u)),
+                       pack_bf16_sr(out[6], out[7], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 3u)));
+      } else if (MODE != 1)
         *reinterpret_cast<uint4*>(dy + m * lddy + k) =
             make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]), pack_bf16(out[6], out[7]));
     };
@@ -1543,7 +1567,8 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
 // dz = p[k] * dy + q[k] * z + r[k], in place over dy (bf16 [M, K]).
 __global__ __launch_bounds__(256) void tower_bn_bwd_apply_kernel(uint16_t* __restrict__ dy, long lddy,
                                                                  const uint16_t* __restrict__ z, long ldz,
-                                                                 int M, int K, const float* __restrict__ pqr) {
+                                                                 int M, int K, const float* __restrict__ pqr,
+                                                                 const int sr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* c = reinterpret_cast<float*>(smem);                   // [3][K]
   for (int i = threadIdx.x; i < 3 * K; i += blockDim.x) c[i] = pqr[i];
@@ -1562,7 +1587,7 @@ __global__ __launch_bounds__(256) void tower_bn_bwd_apply_kernel(uint16_t* __res
       const int k0 = k + 2 * i, k1 = k0 + 1;
       const float lo = __builtin_fmaf(c[k0], bf16_lo(ua[i]), __builtin_fmaf(c[K + k0], bf16_lo(ub[i]), c[2 * K + k0]));
       const float hi = __builtin_fmaf(c[k1], bf16_hi(ua[i]), __builtin_fmaf(c[K + k1], bf16_hi(ub[i]), c[2 * K + k1]));
-      o[i] = pack_bf16(lo, hi);
+      o[i] = sr ? pack_bf16_sr(lo, hi, drop_hash(kDitherSeed, (uint32_t)m, (uint32_t)(k0 >> 1))) : pack_bf16(lo, hi);
     }
     *reinterpret_cast<uint4*>(dy + m * lddy + k) = make_uint4(o[0], o[1], o[2], o[3]);
   }
@@ -2243,6 +2268,12 @@ extern "C" int tfr_tower_out_bwd(const void* z, long ldz, int M, int K, int prol
                             n_blocks, dropout, nullptr, stream);
 }
 
+// TFR_TOWER_DZ_SR=0: round-to-nearest dz (rounds 1-3) instead of the stochastic rounding of pack_bf16_sr
+static int tower_dz_sr() {
+  static const int v = [] { const char* e = getenv("TFR_TOWER_DZ_SR"); return (e && *e) ? atoi(e) : 1; }();
+  return v;
+}
+
 extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                                   const float* shift, const float* mean, const float* rstd, const float* w,
                                   const float* dlogits, int O, void* dy_bf16, long lddy, float* partial,
@@ -2261,7 +2292,7 @@ extern "C" int tfr_tower_out_bwd2(const void* z, long ldz, int M, int K, int pro
   const Drop dr = to_drop(dropout);
   const int mode = pqr ? 2 : (dy_bf16 ? 0 : 1);
   const bool wide = K >= 512;
-#define OB4(P, OT, LPR, MD) hipLaunchKernelGGL((tower_out_bwd_kernel<P, OT, LPR, MD>), dim3(n_blocks), dim3(256), MD == 2 ? 0 : lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr, pqr, act)
+#define OB4(P, OT, LPR, MD) hipLaunchKernelGGL((tower_out_bwd_kernel<P, OT, LPR, MD>), dim3(n_blocks), dim3(256), MD == 2 ? 0 : lds, st, (const uint16_t*)z, ldz, M, K, scale, shift, mean, rstd, w, dlogits, O, (uint16_t*)dy_bf16, lddy, partial, rows, dr, pqr, act, tower_dz_sr())
 #define OB3(P, OT, LPR) do { if (mode == 0) OB4(P, OT, LPR, 0); else if (mode == 1) OB4(P, OT, LPR, 1); else OB4(P, OT, LPR, 2); } while (0)
 #define OB(P) do { if (O == 1) { if (wide) OB3(P, 1, 64); else OB3(P, 1, 16); } else { if (wide) OB3(P, 4, 64); else OB3(P, 4, 16); } } while (0)
   if (prologue == PRO_NONE) OB(PRO_NONE); else if (prologue == PRO_AFFINE) OB(PRO_AFFINE);
@@ -2280,7 +2311,7 @@ extern "C" int tfr_tower_bn_bwd_apply(void* dy_bf16, long lddy, const void* z, l
   if (M == 0) return TFR_OK;
   hipLaunchKernelGGL(tower_bn_bwd_apply_kernel, dim3(grid_for((long)M * (K / 8), 256) > 2048 ? 2048 : grid_for((long)M * (K / 8), 256)),
                      dim3(256), 3 * (size_t)K * 4, (hipStream_t)stream, (uint16_t*)dy_bf16, lddy,
-                     (const uint16_t*)z, ldz, M, K, pqr);
+                     (const uint16_t*)z, ldz, M, K, pqr, tower_dz_sr());
   return (int)hipGetLastError();
 }
 

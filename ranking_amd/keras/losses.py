@@ -501,10 +501,12 @@ class ApproxNDCGLoss(_ListwiseLoss):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
-        loss, weight, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
-                                                 self._temperature, 0, True)
-        # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`
-        return _ops.list_dot(loss, list_scale), dlogits
+        # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`.
+        # The reduced scalar sum_b loss_b * list_scale_b comes out of the same launch (a fixed-order sum by the last
+        # workgroup to finish its forward pass): no reduction launch.
+        _, _, dlogits, total = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
+                                                self._temperature, 0, True, want_sum=True)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()

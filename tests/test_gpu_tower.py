@@ -177,6 +177,30 @@ def test_out_layer_bwd_and_bn_apply():
     bf16_close(got, want, 'dz')
 
 
+def test_bn_bwd_apply_rounds_dz_without_bias():
+    """dz = p dy + q z + r is rounded to bf16 STOCHASTICALLY (csrc/tower.hip pack_bf16_sr): dy is a bf16 lattice, the
+    mean-removal terms are a fraction of a bf16 ulp at training batch sizes, and round-to-nearest drops them -- the column
+    sums of dz drift from zero and the gradients that see the mean of a layer input are off by an amount that grows like
+    sqrt(M) (3.4 % of a weight gradient at M = 819 200, tools/tower_error_probe.py).  Here p dy sits ON the lattice
+    (dy = 1, p = 1) and r = 1/8 of an ulp: round-to-nearest returns exactly 1 for every element, the unbiased rounding
+    returns 1 + ulp on one element in eight -- the column means carry r."""
+    t = T()
+    M, K = 1 << 16, 64
+    dy = torch.ones((M, K), device=DEV, dtype=torch.bfloat16)
+    z = torch.zeros((M, K), device=DEV, dtype=torch.bfloat16)
+    r = 2.0 ** -10                                                       # ulp(1.0) of bf16 = 2^-7
+    pqr = torch.stack([torch.ones(K), torch.zeros(K), torch.full((K,), r)]).to(DEV)
+    got = t.bn_bwd_apply_(dy.clone(), z, K, pqr).float()
+    assert set(got.unique().tolist()) <= {1.0, 1.0 + 2.0 ** -7}
+    col_mean = got.mean(0)
+    assert (col_mean - (1.0 + r)).abs().max().item() <= 0.25 * r, (col_mean - 1.0).abs().max().item()
+    # the same bits on every call (a fixed hash of row and column pair, no generator state)
+    assert torch.equal(got, t.bn_bwd_apply_(dy.clone(), z, K, pqr).float())
+    # negative values round symmetrically
+    neg = t.bn_bwd_apply_((-dy).clone(), z, K, torch.stack([torch.ones(K), torch.zeros(K), torch.full((K,), -r)]).to(DEV)).float()
+    assert (neg.mean(0) + (1.0 + r)).abs().max().item() <= 0.25 * r
+
+
 @pytest.mark.parametrize('M,K,O', [(1000, 264, 2), (37, 8, 1), (4099, 512, 1), (513, 136, 4)])
 @pytest.mark.parametrize('pro', [1, 2])
 def test_out_layer_bwd_bn_two_pass_is_bit_identical_to_three_kernels(M, K, O, pro):

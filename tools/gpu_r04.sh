@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 DRV="--gpus 1 --steps 20 --warmup 5"
-brief() { python tools/bench_brief.py "$1" 2>/dev/null || tail -c 600 "$1"; }
+brief() { python tools/bench_summary.py "$1" 2>/dev/null || tail -c 600 "$1"; }
 for what in "$@"; do
   case $what in
     repro)
@@ -50,6 +50,26 @@ for what in "$@"; do
       done ;;
     hunt4)
       TAG=$TAG timeout 300 python3 tools/fault_repro.py snapshot e2e_groupwise_gumbel > $OUT/snap.out 2> $OUT/snap.err; echo "snapshot rc=$?"; tail -n 3 $OUT/snap.err | cut -c1-200; ls -la $OUT ;;
+    driver1)
+      ( time timeout 1200 python3 bench.py $DRV > $OUT/driver.out 2> $OUT/driver.err ) 2> $OUT/driver.time; echo "driver rc=$?"
+      tail -n 3 $OUT/driver.err | cut -c1-300; python tools/bench_summary.py $OUT/driver.out; tail -n 3 $OUT/driver.time ;;
+    newtests)
+      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_distributed.py tests/test_gpu_tower.py -x -q -m gpu > $OUT/newtests.log 2>&1; echo "newtests rc=$?"; tail -n 30 $OUT/newtests.log ;;
+    probe)
+      timeout 600 python3 tools/tower_error_probe.py 51200 204800 819200 > $OUT/tower_probe.txt 2>&1; echo "probe rc=$?"; cat $OUT/tower_probe.txt | tail -n 40
+      TFR_TOWER_NO_FUSED_LAST=1 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_nofused.txt 2>&1; echo "probe nofused rc=$?"; tail -n 12 $OUT/tower_probe_nofused.txt
+      TFR_WGRAD_256=0 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_w128.txt 2>&1; echo "probe wgrad128 rc=$?"; tail -n 12 $OUT/tower_probe_w128.txt
+      TFR_TOWER_PERSIST=0 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_nopersist.txt 2>&1; echo "probe nopersist rc=$?"; tail -n 12 $OUT/tower_probe_nopersist.txt
+      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_distributed.py tests/test_gpu_tower.py -q -m gpu -k "not baseline_rows" > $OUT/newtests2.log 2>&1; echo "newtests2 rc=$?"; tail -n 15 $OUT/newtests2.log ;;
+    headline_ab)
+      H="--workload approx_ndcg --also none --no-cpu-baseline --busy-seconds 0 --steps 200 --warmup 20"
+      for v in "" "TFR_APPROX_PAIR_RCP=0" "TFR_ORDER_FUSED=0" "TFR_APPROX_PAIR_RCP=0 TFR_ORDER_FUSED=0"; do
+        env $v timeout 200 python3 bench.py $H > $OUT/h_$(echo $v | tr ' =' '__').out 2> $OUT/h.err; echo "[$v] rc=$?"; python tools/bench_summary.py $OUT/h_$(echo $v | tr ' =' '__').out | tail -n 1; tail -n 1 $OUT/h.err | cut -c1-200
+      done ;;
+    sr_probe)
+      timeout 300 python3 tools/tower_error_probe.py 51200 819200 > $OUT/tower_probe_sr.txt 2>&1; echo "probe SR rc=$?"; grep -v "biases\|out_" $OUT/tower_probe_sr.txt | tail -n 22
+      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_tower.py -x -q -m gpu > $OUT/t_full.log 2>&1; echo "full-size+tower tests rc=$?"; tail -n 25 $OUT/t_full.log
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel" > $OUT/t_approx.log 2>&1; echo "approx parity tests rc=$?"; tail -n 12 $OUT/t_approx.log ;;
     final)
       # the LAST GPU action of the round: the driver command, three times, on the final tree
       for i in 1 2 3; do

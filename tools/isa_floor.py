@@ -6,8 +6,9 @@
 
 For each hot kernel the gfx950 assembly (hipcc --cuda-device-only -S of the product source, product flags) is scanned for
 its innermost loops (a backward branch to a label with no other loop inside).  A sweep loop is recognised by what it
-evaluates per pair: every pair evaluation issues exactly one v_rcp_f32 (the sigmoid), so
-    cycles per 64 pair evaluations = sum of the issue costs of the VALU instructions of the loop body / #v_rcp_f32 in it
+evaluates per pair: a pair evaluation issues one v_rcp_f32 (the sigmoid) -- half of one in ApproxNDCG's forward sweep
+since round 4, where two columns share a reciprocal (the loop with the v_pk_mul_f32 of their product) --, so
+    cycles per 64 pair evaluations = sum of the issue costs of the VALU instructions of the loop body / #pairs in it
 with the per-instruction issue costs measured on MI355X by tools/ubench.hip (cycles per wave-instruction and SIMD at the
 2.4 GHz the roofline uses: plain VALU 2.38, v_pk_* 4.56, transcendental 8.5; profiles/r03_ubench.txt).  LDS / SALU /
 waitcnt instructions issue from other ports and are not counted: this is a FLOOR of the sweeps' VALU issue time.
@@ -89,7 +90,7 @@ def innermost_loops(body):
 def classify(body, lo, hi):
     """Instruction classes of the loop body [lo, hi].  Blocks that a forward conditional branch inside the loop jumps
     over (the once-per-segment flush of the LambdaRank sweeps) are NOT counted: the floor is the straight-line trip."""
-    c = {'plain': 0, 'pk': 0, 'trans': 0, 'lds': 0, 'rcp': 0, 'log': 0, 'exp': 0}
+    c = {'plain': 0, 'pk': 0, 'trans': 0, 'lds': 0, 'rcp': 0, 'log': 0, 'exp': 0, 'pk_mul': 0}
     labels = {}
     for i in range(lo, hi + 1):
         m = re.match(r'^(\.LBB\d+_\d+):', body[i])
@@ -118,6 +119,7 @@ def classify(body, lo, hi):
                 c['exp'] += op == 'v_exp_f32'
             elif op.startswith('v_pk_'):
                 c['pk'] += 1
+                c['pk_mul'] += op == 'v_pk_mul_f32'
             else:
                 c['plain'] += 1
     c['cycles'] = c['plain'] * COST['plain'] + c['pk'] * COST['pk'] + c['trans'] * COST['trans']
@@ -125,8 +127,10 @@ def classify(body, lo, hi):
     return c
 
 
-def per_pair(c):
-    return {'valu_cycles_per_64_pairs': c['cycles'] / c['rcp'], 'trans_cycles_per_64_pairs': c['trans_cycles'] / c['rcp'],
+def per_pair(c, pairs_per_rcp=1):
+    n = c['rcp'] * pairs_per_rcp
+    return {'valu_cycles_per_64_pairs': c['cycles'] / n, 'trans_cycles_per_64_pairs': c['trans_cycles'] / n,
+            'pairs_per_rcp': pairs_per_rcp,
             'loop_body': {k: c[k] for k in ('plain', 'pk', 'trans', 'lds', 'rcp', 'log', 'exp')}}
 
 
@@ -138,10 +142,17 @@ def analyse(name):
     if mode == 'two_largest_rcp':
         # ApproxNDCG: the forward (ranks) and the backward sweep are the two loops with the most reciprocals (the x8
         # unrolled bodies); a pair is evaluated once in each
-        loops.sort(key=lambda c: -c['rcp'])
-        parts = {'forward_sweep': per_pair(loops[0]), 'backward_sweep': per_pair(loops[1])}
-        if parts['forward_sweep']['valu_cycles_per_64_pairs'] > parts['backward_sweep']['valu_cycles_per_64_pairs']:
-            parts = {'forward_sweep': parts['backward_sweep'], 'backward_sweep': parts['forward_sweep']}
+        # Round 4: the forward sweep of the default path shares ONE reciprocal between two columns (1/a = b rcp(a b)):
+        # it is the loop with a v_pk_mul_f32 (the product a b), two pair evaluations per v_rcp_f32; the backward sweep
+        # is the loop that reads two float4 (F and A) per four reciprocals.
+        fwd2 = [c for c in loops if c['pk_mul'] > 0]
+        rest = sorted((c for c in loops if c['pk_mul'] == 0), key=lambda c: -c['rcp'])
+        bwd = next(c for c in rest if 2 * c['lds'] >= c['rcp'])
+        if fwd2:
+            parts = {'forward_sweep': per_pair(max(fwd2, key=lambda c: c['rcp']), 2), 'backward_sweep': per_pair(bwd)}
+        else:
+            fwd = next(c for c in rest if c is not bwd)
+            parts = {'forward_sweep': per_pair(fwd), 'backward_sweep': per_pair(bwd)}
     else:
         # LambdaRank: per ACTIVE pair one "hi" evaluation (rcp + log) and one "lo" evaluation (rcp only)
         hi = max((c for c in loops if c['log'] > 0 and c['exp'] == 0), key=lambda c: c['rcp'])
