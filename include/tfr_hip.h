@@ -159,7 +159,9 @@ int tfr_approx_ndcg_f32(const float* logits, const float* labels, const uint8_t*
  *   loss_sum_out [1]  sum_b loss_out[b] * list_scale[b] (list_scale NULL: sum_b loss_out[b]), added in a fixed order
  *                     by the last workgroup to finish its forward pass (compute_weighted_loss / the Keras reduction,
  *                     losses_impl.py:787-814, keras/losses.py:264-280)
- *   ticket       [1]  uint32 in device memory, zero before the first launch, left zero; one per stream in flight. */
+ *   ticket       [tfr_grid_sum_state_ints()] uint32 in device memory (group tickets + partial sums), zero before the
+ *                     first launch, left zero; one per stream in flight. */
+int tfr_grid_sum_state_ints(void);
 int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                             const float* inv_log1p, const float* list_scale, int B, int L,
                             float temperature, int lanes_per_row, float* loss_out, float* weight_out,
@@ -173,12 +175,6 @@ int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint
  *   workspace  int32[B] scratch owned by the caller. */
 int tfr_list_order_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
                        int32_t* workspace, void* stream);
-/* The same order from ONE launch (a persistent grid around a grid barrier).
- *   state  int32[tfr_list_order_state_ints()] in device memory, zero before the first launch, left zero; one per
- *          stream in flight. */
-int tfr_list_order_state_ints(void);
-int tfr_list_order_fused_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
-                             int32_t* workspace, int32_t* state, void* stream);
 
 /* losses_impl.ApproxMRRLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:77-106, 1606-1632): loss_b = -sum_i (l_i / sum l) / approx_rank_i; same

@@ -39,8 +39,7 @@ _SIGNATURES = {
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                             + [ctypes.c_int] + [ctypes.c_void_p] * 5),
     'tfr_list_order_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
-    'tfr_list_order_state_ints': (ctypes.c_int, []),
-    'tfr_list_order_fused_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 4),
+    'tfr_grid_sum_state_ints': (ctypes.c_int, []),
     'tfr_approx_ndcg_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     'tfr_approx_mrr_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]

@@ -283,9 +283,6 @@ def _zero_state(kind: str, n_ints: int, device) -> torch.Tensor:
     return t
 
 
-_ORDER_FUSED = bool(int(os.environ.get('TFR_ORDER_FUSED', '1')))
-
-
 def list_order(labels, mask=None):
     """tfr_list_order_i32: int32 [B] list indices, longest valid length first (launch order of the
     O(n^2) loss kernels; their results do not depend on it)."""
@@ -294,11 +291,6 @@ def list_order(labels, mask=None):
     order = torch.empty((B,), dtype=torch.int32, device=labels.device)
     ws = torch.empty((B,), dtype=torch.int32, device=labels.device)
     lib = _lib.load()
-    if _ORDER_FUSED and B >= 512:                             # one launch: a persistent grid around a grid barrier
-        state = _zero_state('list_order', int(lib.tfr_list_order_state_ints()), labels.device)
-        rc = lib.tfr_list_order_fused_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _ptr(state), _stream())
-        _lib.check(rc, 'tfr_list_order_fused_i32')
-        return order
     rc = lib.tfr_list_order_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _ptr(ws), _stream())
     _lib.check(rc, 'tfr_list_order_i32')
     return order
@@ -332,7 +324,7 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
     if want_sum:
         total = torch.empty((), dtype=torch.float32, device=logits.device)
-        ticket = _zero_state('loss_sum', 1, logits.device)
+        ticket = _zero_state('loss_sum', int(_lib.load().tfr_grid_sum_state_ints()), logits.device)
         rc = _lib.load().tfr_approx_ndcg_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                                  _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
                                                  _ptr(loss), _ptr(weight), _ptr(dlogits),

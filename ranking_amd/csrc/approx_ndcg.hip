@@ -222,7 +222,7 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
       }
     }
     float acc = (a0 + a1) + (a2 + a3);
-    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    acc = lanes_sum_c(acc, C);
     if (active && c == 0) s.Rk[row] = acc + 0.5f;
   }
   __syncthreads();
@@ -243,10 +243,10 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
   }
   dcg = block_sum(dcg, s.red);          // (ends with the barrier that publishes A)
   if (tid == 0) {
-    loss_out[b] = -(dcg * inv_max_dcg);
+    if (!loss_sum) loss_out[b] = -(dcg * inv_max_dcg);
     weight_out[b] = nonzero ? 1.0f : 0.0f;
   }
-  if (loss_sum && wid == 0) grid_weighted_sum_last(loss_out, list_scale, B, loss_sum, ticket, lane);   // (wave 0 stored the entry)
+  if (loss_sum && wid == 0) grid_weighted_sum_last(loss_out, b, -(dcg * inv_max_dcg), list_scale, B, loss_sum, ticket, lane);
   if (!dlogits_out) return;
   __syncthreads();
 
@@ -288,7 +288,7 @@ __global__ void approx_ndcg_kernel(const float* __restrict__ logits, const float
       }
     }
     float acc = (a0 + a1) + (a2 + a3);
-    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    acc = lanes_sum_c(acc, C);
     if (active && c == 0) dlogits_out[base + s.CI[row]] = scale * (acc / temperature);
   }
 }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       }
     }
     float acc = (a0 + a1) + (a2 + a3);
-    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    acc = lanes_sum_c(acc, C);
     if (active && c == 0) {
       const float r = (acc - pad_cols) + 0.5f;                           // (pad_cols = 0 off the pair path)
       const float gg = G[row];
@@ -565,13 +565,14 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     }
   }
   dcg = wave_sum_u(dcg);
+  const float list_loss = -(dcg * inv_max_dcg);
   if (lane == 0) {
-    loss_out[b] = -(dcg * inv_max_dcg);
+    if (!loss_sum) loss_out[b] = list_loss;
     weight_out[b] = nonzero ? 1.0f : 0.0f;
   }
   // sum_b loss_b * list_scale_b (the scalar the reduced loss returns): by the last wave to get here, while the others
-  // are in their backward sweeps
-  if (loss_sum) grid_weighted_sum_last(loss_out, list_scale, B, loss_sum, ticket, lane);
+  // are in their backward sweeps (the helper stores loss_out[b] itself, written through)
+  if (loss_sum) grid_weighted_sum_last(loss_out, b, list_loss, list_scale, B, loss_sum, ticket, lane);
   TFR_STAMP(4);
   if (!dlogits_out) return;
   __syncthreads();
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       }
     }
     float acc = (a0 + a1) + (a2 + a3);
-    for (int o = 1; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+    acc = lanes_sum_c(acc, C);
     if (active && c == 0) dlogits_out[base + CI[row]] = acc * gscale;
   }
   TFR_STAMP(5);
@@ -712,6 +713,8 @@ extern "C" int tfr_approx_ndcg_f32(const float* logits, const float* labels, con
   return approx_dispatch(TFR_APPROX_NDCG, logits, labels, mask, inv_log1p, list_scale, B, L, temperature,
                          lanes_per_row, loss_out, weight_out, dlogits_out, list_order, stream);
 }
+
+extern "C" int tfr_grid_sum_state_ints(void) { return kGridSumStateInts; }
 
 extern "C" int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                        const float* inv_log1p, const float* list_scale, int B, int L,

@@ -235,13 +235,38 @@ __device__ __forceinline__ float wave_tree_sum(float (&t)[IPL], int P) {
       for (int r = 0; r < hr; ++r) t[r] = t[r] + t[r + hr];
     }
   }
+  // lane l adds lane l + h for h = 32, 16, 8, 4, 2, 1 (lanes >= h hold don't-care values) -- the same pairs as the
+  // __shfl_down form of rounds 1-3, without its seven dependent ds_bpermute round trips through the LDS crossbar
+  // (13 tree sums per list in the NDCG metric: ~90 of them in a row): the two cross-row levels are gfx950's
+  // v_permlane32_swap / v_permlane16_swap (the "source" result holds lanes [32, 64) in lanes [0, 32), resp. the odd
+  // rows in the even ones), the four levels inside a 16-lane row are DPP row_shl, the broadcast is a v_readlane.
   float v = t[0];
-#pragma unroll
-  for (int h = 32; h >= 1; h >>= 1) {
-    const float o = __shfl_down(v, h, 64);
-    if (2 * h <= P) v = v + o;                           // lanes >= h hold don't-care values
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+    if (64 <= P) v = v + o;
   }
-  return __shfl(v, 0, 64);
+  {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const float o = __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
+    if (32 <= P) v = v + o;
+  }
+#define TFR_ROW_SHL(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(x)), 0x100 + (n), 0xf, 0xf, true))
+  { const float o = TFR_ROW_SHL(v, 8); if (16 <= P) v = v + o; }
+  { const float o = TFR_ROW_SHL(v, 4); if (8 <= P) v = v + o; }
+  { const float o = TFR_ROW_SHL(v, 2); if (4 <= P) v = v + o; }
+  { const float o = TFR_ROW_SHL(v, 1); if (2 <= P) v = v + o; }
+#undef TFR_ROW_SHL
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+}
+
+// acc + (acc of lane ^ 1) [+ lanes ^ 2]: the C = 2 / 4 lanes of a row of the pair sweeps, on the DPP network (quad_perm)
+// instead of a ds_bpermute round trip per pass.
+__device__ __forceinline__ float lanes_sum_c(float acc, int C) {
+  if (C >= 2) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+  if (C >= 4) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+  for (int o = 4; o < C; o <<= 1) acc += __shfl_xor(acc, o, 64);
+  return acc;
 }
 
 // Wave-wide reductions on the DPP network (no LDS traffic, unlike __shfl_xor which lowers to
@@ -342,37 +367,55 @@ __device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int l
   WAVE_LDS_SYNC();
 }
 
-// out[0] = sum_i vec[i] * w[i] (w nullable) over the B per-list values of a launch, computed by the LAST workgroup to
-// reach this point (a ticket in device memory), in a FIXED order (lane l adds i = l, l + 64, ... then the wave tree), so
-// that the scalar a reduced loss returns needs no launch of its own.  Called by ONE wavefront of every workgroup after
-// the workgroup's own vec entry has been stored by that wavefront.  `ticket` (one uint32, zero before the first launch)
-// is left zero.  Release / acquire at agent scope order the stores of the other workgroups before the loads here.
-__device__ __forceinline__ void grid_weighted_sum_last(const float* __restrict__ vec, const float* __restrict__ w, int B, float* out,
-                                                       unsigned int* ticket, int lane) {
+// out[0] = sum_i vec[i] * w[i] (w nullable) over the B per-list values of a launch, without a launch of its own: the
+// scalar a reduced loss returns.  Called by ONE wavefront of every workgroup; lane 0 stores the workgroup's own entry
+// vec[b] = value HERE.  Two levels, both in a FIXED order whoever computes them (the result does not depend on the order
+// in which the workgroups finish): entry i belongs to group i % 64; the wave that completes a group (a ticket per
+// group) adds the group's entries (lane l takes the l-th, (l + 64)-th, ... entry of the group, then the wave tree) into
+// partial[group]; the wave that completes the last group adds the 64 partials.  `st` = kGridSumStateInts uint32 in
+// device memory, zero before the first launch, left zero.
+// Why two levels: 16 384 fetch-adds on ONE address took 90 us (same-address atomics serialise at the memory side), and
+// one wave adding 16 384 entries is 16 dependent round trips.  Coherence without fences: an agent-scope RELEASE fence on
+// gfx950 is a write-back of the XCD's whole L2 (buffer_wbl2) with 13 MB of gradient rows dirty in it -- 0.2 ms over a
+// launch (measured).  Instead every shared value is stored with an agent-scope atomic store (written through:
+// global_store ... sc1), the wave waits for that store (s_waitcnt vmcnt(0)) before it takes its ticket (a device-scope
+// atomic, performed at the coherence point), and readers use agent-scope atomic loads (global_load ... sc1).
+constexpr int kGridSumGroups = 64;
+constexpr int kGridSumStateInts = 2 * kGridSumGroups + 1;    // [0, 64) group tickets, [64] top ticket, [65, 129) partials
+__device__ __forceinline__ void grid_weighted_sum_last(float* vec, int b, float value, const float* __restrict__ w, int B,
+                                                       float* out, unsigned int* st, int lane) {
+  const int j = b & (kGridSumGroups - 1);
+  const int cnt = (B - j + kGridSumGroups - 1) / kGridSumGroups;      // entries of group j
   unsigned int t = 0;
   if (lane == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(vec + b, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t = __hip_atomic_fetch_add(st + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-  if (t != gridDim.x - 1) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  // (plain loads: the acquire above has dropped this CU's stale lines, and ordinary loads can be batched -- 16 in flight
-  // per lane; one atomic load at a time made this loop 256 dependent round trips = 0.27 ms at B = 16384)
+  if ((int)t != cnt - 1) return;
   float acc = 0.f;
-  int i = lane;
-  for (; i + 15 * 64 < B; i += 16 * 64) {
-    float v[16], ww[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) { v[u] = vec[i + 64 * u]; ww[u] = w ? w[i + 64 * u] : 1.0f; }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc = __builtin_fmaf(v[u], ww[u], acc);
+  for (int q = lane; q < cnt; q += 64) {
+    const int i = j + kGridSumGroups * q;
+    acc = __builtin_fmaf(__hip_atomic_load(vec + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w ? w[i] : 1.0f, acc);
   }
-  for (; i < B; i += 64) acc = __builtin_fmaf(vec[i], w ? w[i] : 1.0f, acc);
   acc = wave_sum_u(acc);
+  const int groups = B < kGridSumGroups ? B : kGridSumGroups;
+  unsigned int t2 = 0;
   if (lane == 0) {
-    out[0] = acc;
-    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<float*>(st + kGridSumGroups + 1 + j), acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(st + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    t2 = __hip_atomic_fetch_add(st + kGridSumGroups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  t2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t2);
+  if ((int)t2 != groups - 1) return;
+  float p = (lane < groups) ? __hip_atomic_load(reinterpret_cast<float*>(st + kGridSumGroups + 1 + lane), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+  p = wave_sum_u(p);
+  if (lane == 0) {
+    out[0] = p;
+    __hip_atomic_store(st + kGridSumGroups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -328,7 +328,9 @@ inline int threads_for(int L) {
 // items of a lane serialise the exp / divide chain.  Dropped.  So was a form with 2 / 4 lists per wavefront and all
 // loads issued up front: 12.5 / 13.7 us against 11.9 us per launch at B = 16384, L = 100 -- the kernel is not short of
 // bytes in flight; ~4 us of every launch are fixed cost and the rest streams at ~2.5 TB/s out of the Infinity Cache.)
-template <int IPL>
+// NT (round 4): the launch streams more than the Infinity Cache holds (B * L * 12 B > 128 MB) -- loads and the gradient
+// store carry the non-temporal hint, so that lines which will not be touched again do not evict each other.
+template <int IPL, bool NT>
 __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -347,8 +349,8 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
     const int i = lane + 64 * r;
     z[r] = -INFINITY; y[r] = 0.f; mv[r] = false;
     if (i < L) {
-      const float lab = a.labels[base + i];
-      const float x = a.logits[base + i];
+      const float lab = NT ? __builtin_nontemporal_load(a.labels + base + i) : a.labels[base + i];
+      const float x = NT ? __builtin_nontemporal_load(a.logits + base + i) : a.logits[base + i];
       mv[r] = a.mask ? (a.mask[base + i] != 0) : (lab >= 0.0f);
       float w = 1.0f;
       if (a.item_weights) w = a.weights_per_list ? wl : a.item_weights[base + i];
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
         if (a.poly_eps != 0.0f) d -= a.poly_eps * sm * (y[r] - pt);
         g = (lsum * inv_t) * d;
       }
-      a.dlogits[base + i] = g;
+      if (NT) __builtin_nontemporal_store(g, a.dlogits + base + i); else a.dlogits[base + i] = g;
     }
   }
 }
@@ -453,7 +455,10 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
   static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
   if (env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
-#define SMW(I) hipLaunchKernelGGL(softmax_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, a, B)
+    static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
+    const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
+#define SMW(I) do { if (nt) hipLaunchKernelGGL((softmax_wave_kernel<I, true>), dim3((B + 3) / 4), dim3(256), 0, st, a, B); \
+                    else hipLaunchKernelGGL((softmax_wave_kernel<I, false>), dim3((B + 3) / 4), dim3(256), 0, st, a, B); } while (0)
     if (L <= 64) SMW(1); else if (L <= 128) SMW(2); else if (L <= 256) SMW(4); else if (L <= 512) SMW(8); else SMW(16);
 #undef SMW
     return (int)hipGetLastError();

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
   bool complete = false;
 #pragma unroll
   for (int it = 0; it < kNdcgRuns; ++it) {
+    if (complete) break;                                     // (wave-uniform; rv / rs beyond nruns are never read)
     float mx = rem[0];
 #pragma unroll
     for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
@@ -1235,92 +1236,6 @@ __global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const 
   if (b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
 }
 
-// The same order from ONE launch (round 4; the two launches above cost 6.1 + 5.1 us + a launch gap in front of a
-// 128 us loss kernel).  A persistent grid (every workgroup resident: <= 1024 workgroups of 256 threads) in two phases
-// around a grid barrier:
-//   phase 1: four threads per list count its valid items (as in list_class_kernel); the class goes to `cls`, the
-//            workgroup's class histogram to LDS; ONE global fetch-add per class and workgroup reserves the workgroup's
-//            slice inside the class (its return value) and builds the class totals;
-//   barrier: arrive counter in `state` (all workgroups are resident, so spinning on it cannot starve anyone);
-//   phase 2: class bases = exclusive prefix of the totals (one wave scan per workgroup); every list goes to
-//            base[class] + the workgroup's slice offset + an LDS cursor.
-// `state` (kOrderStateInts ints, zero before the first launch) is left zero by the last workgroup to leave.  The order
-// inside a class depends on the order of the fetch-adds; the loss kernels' results do not depend on it.
-constexpr int kOrderStateInts = kOrderClasses + 2;
-constexpr int kOrderFusedLists = 64;     // lists per workgroup and trip: 4 threads each
-
-__global__ __launch_bounds__(256) void list_order_fused_kernel(const float* __restrict__ labels,
-                                                               const uint8_t* __restrict__ mask, int B, int L,
-                                                               int* __restrict__ order_out, uint8_t* __restrict__ cls,
-                                                               int* __restrict__ state) {
-  __shared__ int s_hist[kOrderClasses];
-  __shared__ int s_cur[kOrderClasses];
-  const int tid = threadIdx.x, t = tid & 3;
-  if (tid < kOrderClasses) s_hist[tid] = 0;
-  __syncthreads();
-  const int stride = gridDim.x * kOrderFusedLists;
-  for (int b0 = blockIdx.x * kOrderFusedLists; b0 < B; b0 += stride) {
-    const int b = b0 + (tid >> 2);
-    int n = 0;
-    if (b < B) {
-      const size_t base = (size_t)b * L;
-      if (!mask && (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0)) {
-        const float4* p = reinterpret_cast<const float4*>(labels + base);     // the quad reads 64 contiguous bytes a step
-#pragma unroll 4
-        for (int i = t; i < L / 4; i += 4) {
-          const float4 v = p[i];
-          n += (v.x >= 0.0f) + (v.y >= 0.0f) + (v.z >= 0.0f) + (v.w >= 0.0f);
-        }
-      } else {
-        const int per = (L + 3) / 4, lo = t * per, hi = (lo + per < L) ? lo + per : L;
-        if (mask) { for (int i = lo; i < hi; ++i) n += mask[base + i] != 0; }
-        else { for (int i = lo; i < hi; ++i) n += labels[base + i] >= 0.0f; }
-      }
-    }
-    n += __shfl_xor(n, 1, 64);
-    n += __shfl_xor(n, 2, 64);
-    if (b < B && t == 0) {
-      const int c = kOrderClasses - 1 - (n * kOrderClasses) / (L + 1);                   // 0 = longest
-      cls[b] = (uint8_t)c;
-      atomicAdd(&s_hist[c], 1);
-    }
-  }
-  __syncthreads();
-  // reserve this workgroup's slice of every class it holds lists of
-  if (tid < kOrderClasses) {
-    const int h = s_hist[tid];
-    s_cur[tid] = h ? __hip_atomic_fetch_add(&state[tid], h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-  }
-  __syncthreads();
-  if (tid == 0) {                                            // grid barrier (release our fetch-adds, acquire everyone's)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(&state[kOrderClasses], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(&state[kOrderClasses], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x)
-      __builtin_amdgcn_s_sleep(2);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-  if (tid < 64) {                                            // class bases: exclusive prefix of the totals + our slice
-    const int v = __hip_atomic_load(&state[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int u = __shfl_up(inc, d); if (tid >= d) inc += u; }
-    s_cur[tid] += inc - v;
-  }
-  __syncthreads();
-  for (int b0 = blockIdx.x * kOrderFusedLists; b0 < B; b0 += stride) {
-    const int b = b0 + tid;
-    if (tid < kOrderFusedLists && b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
-  }
-  __syncthreads();
-  if (tid == 0) {                                            // the last workgroup to leave puts the state back to zero
-    const int d = __hip_atomic_fetch_add(&state[kOrderClasses + 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == (int)gridDim.x - 1) {
-      for (int i = 0; i < kOrderStateInts; ++i) __hip_atomic_store(&state[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
 inline int block_threads_for(int P) {
   int t = P / 2;
   if (t < 64) t = 64;
@@ -1478,20 +1393,6 @@ extern "C" int tfr_metric_list_weights_f32(const float* stats, int B, float* wei
   if (B == 0) return TFR_OK;
   const int nwg = (B + 1023) / 1024 < 16 ? (B + 1023) / 1024 : 16;
   hipLaunchKernelGGL(metric_list_weights_kernel, dim3(nwg), dim3(1024), 0, (hipStream_t)stream, stats, B, weights_out);
-  return (int)hipGetLastError();
-}
-
-extern "C" int tfr_list_order_state_ints(void) { return kOrderStateInts; }
-
-extern "C" int tfr_list_order_fused_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
-                                        int32_t* workspace, int32_t* state, void* stream) {
-  if ((!labels && !mask) || !order_out || !workspace || !state || B < 0 || L <= 0) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
-  if (B == 0) return TFR_OK;
-  int nblk = (B + kOrderFusedLists - 1) / kOrderFusedLists;
-  if (nblk > 1024) nblk = 1024;                              // persistent: every workgroup resident (4 per CU)
-  hipLaunchKernelGGL(list_order_fused_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, labels, mask, B, L,
-                     (int*)order_out, reinterpret_cast<uint8_t*>(workspace), (int*)state);
   return (int)hipGetLastError();
 }
 

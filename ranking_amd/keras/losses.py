@@ -12,6 +12,7 @@ building an autograd graph -- the path a throughput-minded training loop (and
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -180,6 +181,7 @@ class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
 
 
 # ------------------------------------------------------------------- helpers
+_LOSS_SUM_FUSED = bool(int(os.environ.get('TFR_LOSS_SUM_FUSED', '1')))
 _CONST_CACHE = _ops.DeviceConstCache(64)        # graph-safe: entries a hipGraph capture has read are never evicted
 
 
@@ -504,6 +506,9 @@ class ApproxNDCGLoss(_ListwiseLoss):
         # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`.
         # The reduced scalar sum_b loss_b * list_scale_b comes out of the same launch (a fixed-order sum by the last
         # workgroup to finish its forward pass): no reduction launch.
+        if not _LOSS_SUM_FUSED:                                # (developer A/B: the reduction as its own launch, rounds 1-3)
+            loss, _, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale, self._temperature, 0, True)
+            return _ops.list_dot(loss, list_scale), dlogits
         _, _, dlogits, total = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,
                                                 self._temperature, 0, True, want_sum=True)
         return total, dlogits

@@ -63,13 +63,44 @@ for what in "$@"; do
       timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_distributed.py tests/test_gpu_tower.py -q -m gpu -k "not baseline_rows" > $OUT/newtests2.log 2>&1; echo "newtests2 rc=$?"; tail -n 15 $OUT/newtests2.log ;;
     headline_ab)
       H="--workload approx_ndcg --also none --no-cpu-baseline --busy-seconds 0 --steps 200 --warmup 20"
-      for v in "" "TFR_APPROX_PAIR_RCP=0" "TFR_ORDER_FUSED=0" "TFR_APPROX_PAIR_RCP=0 TFR_ORDER_FUSED=0"; do
+      for v in "" "TFR_LOSS_SUM_FUSED=0" "TFR_APPROX_PAIR_RCP=0 TFR_LOSS_SUM_FUSED=0"; do
         env $v timeout 200 python3 bench.py $H > $OUT/h_$(echo $v | tr ' =' '__').out 2> $OUT/h.err; echo "[$v] rc=$?"; python tools/bench_summary.py $OUT/h_$(echo $v | tr ' =' '__').out | tail -n 1; tail -n 1 $OUT/h.err | cut -c1-200
       done ;;
     sr_probe)
       timeout 300 python3 tools/tower_error_probe.py 51200 819200 > $OUT/tower_probe_sr.txt 2>&1; echo "probe SR rc=$?"; grep -v "biases\|out_" $OUT/tower_probe_sr.txt | tail -n 22
       timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_tower.py -x -q -m gpu > $OUT/t_full.log 2>&1; echo "full-size+tower tests rc=$?"; tail -n 25 $OUT/t_full.log
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel" > $OUT/t_approx.log 2>&1; echo "approx parity tests rc=$?"; tail -n 12 $OUT/t_approx.log ;;
+    approx_tests)
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel or keras_loss" > $OUT/t_approx.log 2>&1; echo "approx parity tests rc=$?"; tail -n 12 $OUT/t_approx.log ;;
+    softmax_ab)
+      for v in "TFR_SOFTMAX_LPW=1" "TFR_SOFTMAX_LPW=2"; do
+        for w in softmax_hbm softmax; do
+          env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/sm_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/sm.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/sm_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
+        done
+        env $v timeout 300 python3 bench.py --workload softmax --batch 16384 --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/sm16k_$(echo $v | tr ' =' '__').out 2> $OUT/sm.err; echo "[$v] softmax B=16384 rc=$?"; python tools/bench_summary.py $OUT/sm16k_$(echo $v | tr ' =' '__').out | tail -n 1
+      done
+      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
+      TFR_SOFTMAX_LPW=2 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax2.log 2>&1; echo "softmax tests LPW=2 rc=$?"; tail -n 3 $OUT/t_softmax2.log ;;
+    hbm)
+      for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
+        timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
+      done ;;
+    profiles)
+      # one consolidated visit for profiles/r04_*: bench lines, kernel-trace stats, FETCH / WRITE passes
+      for w in approx_ndcg pairwise_lambda softmax ndcg_metric softmax_hbm ndcg_metric_hbm gumbel_approx_ndcg approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/one_$w.out | tail -n 1
+      done
+      for w in approx_ndcg pairwise_lambda softmax_hbm ndcg_metric_hbm e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 5 $OUT/stats_$w.txt | cut -c1-130
+      done
+      for w in approx_ndcg pairwise_lambda softmax_hbm ndcg_metric_hbm e2e_approx_ndcg_l1000; do
+        st=20; case $w in *_hbm) st=4;; e2e_*) st=4;; esac
+        timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_fetch_$w.log 2>&1
+        timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
+        for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 6 | cut -c1-160; done
+      done
+      find $OUT -name '*.db' -size +4M -delete ;;
     final)
       # the LAST GPU action of the round: the driver command, three times, on the final tree
       for i in 1 2 3; do
