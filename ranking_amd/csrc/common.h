@@ -240,15 +240,18 @@ __device__ __forceinline__ float wave_tree_sum(float (&t)[IPL], int P) {
   // (13 tree sums per list in the NDCG metric: ~90 of them in a row): the two cross-row levels are gfx950's
   // v_permlane32_swap / v_permlane16_swap (the "source" result holds lanes [32, 64) in lanes [0, 32), resp. the odd
   // rows in the even ones), the four levels inside a 16-lane row are DPP row_shl, the broadcast is a v_readlane.
+  // (inline asm, both operands tied: with the builtin and the same value in both operands hipcc 7.2 picked the
+  // DESTINATION result where the source result was asked for -- every level added a lane to itself; tools/permlane_probe.hip.
+  // s_nop 1 = the two wait states between a VALU write of an operand and the swap.)
   float v = t[0];
   {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float o = __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+    float a = v, o = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(o));    // o: lanes [0, 32) <- v[32, 64)
     if (64 <= P) v = v + o;
   }
   {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float o = __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(u, u, false, false)[1]);
+    float a = v, o = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(o));    // o: even rows <- the odd rows of v
     if (32 <= P) v = v + o;
   }
 #define TFR_ROW_SHL(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(x)), 0x100 + (n), 0xf, 0xf, true))

@@ -81,6 +81,16 @@ for what in "$@"; do
       done
       timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
       TFR_SOFTMAX_LPW=2 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax2.log 2>&1; echo "softmax tests LPW=2 rc=$?"; tail -n 3 $OUT/t_softmax2.log ;;
+    metrics_ab)
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "ndcg or mrr or metric or approx or sort or rank" > $OUT/t_metrics.log 2>&1; echo "metric/approx tests rc=$?"; tail -n 3 $OUT/t_metrics.log
+      for v in "TFR_SOFTMAX_NT=0" "TFR_SOFTMAX_NT=1"; do
+        for w in softmax_hbm softmax; do
+          env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/nt_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/nt.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/nt_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
+        done
+      done
+      for w in ndcg_metric ndcg_metric_hbm approx_ndcg approx_ndcg_l1000 gumbel_approx_ndcg; do
+        timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 100 --warmup 10 > $OUT/m_$w.out 2> $OUT/m.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/m_$w.out | tail -n 1
+      done ;;
     hbm)
       for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
         timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
