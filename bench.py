@@ -17,8 +17,9 @@ reduction the Keras call returns).
 ranks with no data-path collective -> "scaling": "weak"; the
 end-to-end workloads (`e2e_*`) run ONE all-reduce of the flat gradient bucket per
 step and report its time separately.  Rank 0 prints the JSON line of the main workload as soon as it is measured; with
-`--also` (the default set is the BASELINE multi-GPU configs 4 and 5 plus the
-pairwise kernel north_star names) every extra workload then runs in its OWN child
+`--also` (the default set is the BASELINE multi-GPU configs 4 and 5, the pairwise
+kernel north_star names, and the two HBM-bound kernels -- Softmax, NDCG metric -- on
+a 1.3 GB cycled working set) every extra workload then runs in its OWN child
 process (own HIP context and timeout: a faulting extra costs one entry, never the
 headline) and the same line is printed once more, last, with them under "also".
 Every workload entry has `roofline` (dominant kernel, HIP events) and, at N = 1,
@@ -71,7 +72,7 @@ WORKLOADS = {
                                       'GumbelApproxNDCGLoss(S=8), 512 lists/GPU, L=50, 1 all-reduce/step',
                              lambda L: 0),
 }
-DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel')
+DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel', 'softmax_hbm', 'ndcg_metric_hbm')
 # The O(L) / sort kernels on a working set BEYOND the 256 MB Infinity Cache: `cycle` distinct batches
 # (inputs AND outputs) walked round-robin inside one replayed graph, so that every launch streams its bytes from HBM.
 # name: (base workload, B per batch, L, batches in the cycle)
@@ -229,7 +230,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         discount = _ops.rank_table(m._rank_discount_fn, L, dev)
         return dict(step=lambda: m.compute_multi(labels, logits, None, None, topns),
                     kernel=lambda: _ops.ndcg_metric(labels, logits, None, None, None, discount, topns),
-                    kernel_name='rank_metric_wave_kernel<NDCG>')
+                    kernel_name='ndcg_count_wave_kernel (ranks by counting, run-length ideal DCG, tree sums for five cut-offs)')
     if workload.startswith('e2e_'):
         return build_e2e_step(workload, labels, dropout, use_graph)
     raise ValueError(workload)

@@ -322,9 +322,12 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
   int* RKS = reinterpret_cast<int*>(XS + N + 8);           // [N]
   int* OCC = RKS + N;                                      // [N]
   float* WG = reinterpret_cast<float*>(OCC + N);           // [N] w * gain by original index (sort fallback)
-  const int lane = threadIdx.x, b = blockIdx.x;
+  float* DISC = WG + N;                                    // [N] the discount table: the gathers by rank / by sorted position
+  const int lane = threadIdx.x, b = blockIdx.x;            //     below are LDS reads, not a dependent global round trip each
   const size_t base = (size_t)b * L;
   const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { const int i = lane + 64 * r; DISC[i] = (i < L) ? discount[i] : 0.0f; }
 
   float w[IPL], g[IPL], wg[IPL], pr[IPL];
   bool m[IPL];
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
   wave_rank_by_count(XS, n, lane, RKS, OCC);
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
-    if (m[r]) { const int rk = RKS[posr[r]]; TERM[rk] = wg[r] * discount[rk]; }
+    if (m[r]) { const int rk = RKS[posr[r]]; TERM[rk] = wg[r] * DISC[rk]; }
   }
   WAVE_LDS_SYNC();
   float term[IPL], dcg[TFR_MAX_TOPN];
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
       float val = 0.0f;
 #pragma unroll
       for (int it = 0; it < kNdcgRuns; ++it) val = (it < nruns && p >= rs[it]) ? rv[it] : val;   // rs ascends
-      term[r] = (p < pos) ? val * discount[p] : 0.0f;        // beyond the metric-valid items: w * gain(0) = 0
+      term[r] = (p < pos) ? val * DISC[p] : 0.0f;        // beyond the metric-valid items: w * gain(0) = 0
     }
   } else {
     uint64_t key[IPL];
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
       const int p = lane + 64 * r;
-      term[r] = (p < L) ? WG[sort_key_index(key[r])] * discount[p] : 0.0f;
+      term[r] = (p < L) ? WG[sort_key_index(key[r])] * DISC[p] : 0.0f;
     }
   }
   for (int q = 0; q < topn.n; ++q) {
@@ -1092,7 +1095,7 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
                         int L, int P, float* metric_out, float* stats_out, hipStream_t st) {
   static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
   if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
-    constexpr size_t lds = (size_t)64 * IPL * 5 * sizeof(float) + 8 * sizeof(float);
+    constexpr size_t lds = (size_t)64 * IPL * 6 * sizeof(float) + 8 * sizeof(float);
     hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL>), dim3(B), dim3(64), lds, st, labels, predictions, weights,
                        weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
     return;

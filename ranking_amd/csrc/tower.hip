@@ -821,7 +821,7 @@ __device__ __forceinline__ f32x4 row16_sum4(f32x4 v) {
   return o;
 }
 
-enum { PF_TOUCH_A = 1, PF_TOUCH_Z = 2 };
+enum { PF_TOUCH_A = 1, PF_TOUCH_Z = 2, PF_IDLE_DMA = 4 };   // PF_IDLE_DMA (TFR_GEMM_FLAGS=4): rounds 2-3, a step with nothing to request still issued its pieces (into an idle slot)
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
@@ -906,8 +906,11 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   // a staged transform, but no register-staged copy of the tile, no ds_write_b128 pass and the same two-stage
   // run-ahead at tile boundaries as the plain form).
   // One k step = 4 blocks of 16 MFMAs; the 8 LDS-DMA pieces of the next stage go out two per block (A first).  A step
-  // that has nothing to request sends its pieces to the wave's idle epilogue slot: two inlined copies of this block
-  // -- with / without the pieces -- make the register allocator carry two sets of accumulators.
+  // that has nothing to request (the first of every tile: its stage 1 has been in flight since before the previous
+  // epilogue) skips them with a uniform branch around the two instructions -- round 4; rounds 2-3 sent them to the wave's
+  // idle epilogue slot (one 64 KB stage of L2 -> LDS traffic in eight for nothing, on the LDS pipe that bounds the loop)
+  // because two inlined COPIES of this block -- with / without the pieces -- make the register allocator carry two sets of
+  // accumulators; a branch inside the one copy does not.
   // What was measured on the way (tools/gemm_timeline.py, config-2 hidden layer, cycles per k step and SIMD): MFMAs
   // alone 2360 (128 x 16 = 2048 is the floor), + fragment reads 3130, + LDS-DMA pieces 4440 -- the three add up
   // whatever the order: all pieces at the top of the step, one or two per block, alternating between the two waves of
@@ -937,12 +940,14 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
         const int blk = kk * 2 + hn;
-        if (blk < 2) {
-          dma16_s(offA[2 * blk], ab, dst_a + (2 * blk) * dst_step);
-          dma16_s(offA[2 * blk + 1], ab, dst_a + (2 * blk + 1) * dst_step);
-        } else {
-          dma16_s(offB[2 * blk - 4], bb, dst_b + (2 * blk - 4) * dst_step);
-          dma16_s(offB[2 * blk - 3], bb, dst_b + (2 * blk - 3) * dst_step);
+        if (issue || (g.flags & PF_IDLE_DMA)) {      // (uniform; a branch around two instructions, no second copy of the block)
+          if (blk < 2) {
+            dma16_s(offA[2 * blk], ab, dst_a + (2 * blk) * dst_step);
+            dma16_s(offA[2 * blk + 1], ab, dst_a + (2 * blk + 1) * dst_step);
+          } else {
+            dma16_s(offB[2 * blk - 4], bb, dst_b + (2 * blk - 4) * dst_step);
+            dma16_s(offB[2 * blk - 3], bb, dst_b + (2 * blk - 3) * dst_step);
+          }
         }
 #pragma unroll
         for (int fp = 0; fp < 2; ++fp) {            // weight fragments two at a time (8 registers instead of 16)
