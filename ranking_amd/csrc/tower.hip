@@ -120,12 +120,27 @@ __device__ __forceinline__ void drop_pair(const Drop d, uint32_t m, uint32_t kpa
 // 128 positions per column: the share of s that survives is a per-column accident, the column sums of dz drift away from
 // zero, and every gradient that sees the MEAN of the layer input (weights / BatchNorm parameters below a ReLU) picks up an
 // error that grows like sqrt(M) against the signal (measured at M = 819 200: 3.4 % on a weight matrix, 5.4 % on a beta,
-// against 0.6 % at M = 51 200; tools/tower_error_probe.py).  Adding 16 uniform bits below the kept mantissa before the
-// truncation makes E[bf16(x)] = x whatever the lattice: the drift becomes zero-mean noise that averages out over M.
-// The dither is a fixed hash of (row, column pair): the same bits on every run and in both backward paths.
+// against 0.6 % at M = 51 200; tools/tower_error_probe.py).  Adding uniform bits below the kept mantissa before the
+// truncation makes E[bf16(x)] = x whatever the lattice: the drift becomes zero-mean noise that averages out over M
+// (0.5-0.6 % on every gradient at M = 819 200 afterwards).  The dither is a fixed function of (row, column): the same
+// bits on every run and in both backward paths.
+// Cost: the dither is 8 bits per element (centred: byte * 256 + 128 below the kept mantissa, i.e. the round-up probability
+// is the dropped fraction to 1 / 256 ulp), 64 bits per 8-column chunk from ONE two-multiply seed and two xorshift32 rounds
+// (full-rate shifts / xors) -- the first version hashed per column pair with the dropout hash (four quarter-rate multiplies
+// each) and made the bandwidth-bound apply pass issue-bound: 0.24 -> 0.31 ms at M = 512 000 (profiles/r04_all_workloads.txt).
 constexpr uint32_t kDitherSeed = 0x5bd1e995u;
-__device__ __forceinline__ uint32_t pack_bf16_sr(float a, float b, uint32_t h) {
-  const uint32_t ua = __float_as_uint(a) + (h & 0xffffu), ub = __float_as_uint(b) + (h >> 16);
+__device__ __forceinline__ uint32_t xorshift32(uint32_t x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
+// dither words of the 8-column chunk (row m, columns 8 * k8 ..): byte e of {a, b} belongs to column e
+__device__ __forceinline__ void sr_dither8(uint32_t m, uint32_t k8, uint32_t& a, uint32_t& b) {
+  a = xorshift32(m * 0x9E3779B1u + k8 * 0x85EBCA77u + kDitherSeed);
+  b = xorshift32(a);
+}
+// bf16 pair (columns e, e + 1 of the chunk, e = 0, 2, 4, 6) by stochastic rounding with the chunk's dither words
+__device__ __forceinline__ uint32_t pack_bf16_sr(float lo, float hi, uint32_t a, uint32_t b, int e) {
+  const uint32_t w = e < 4 ? a : b;
+  const uint32_t d0 = (__builtin_amdgcn_ubfe(w, (uint32_t)(8 * (e & 3)), 8u) << 8) | 0x80u;
+  const uint32_t d1 = (__builtin_amdgcn_ubfe(w, (uint32_t)(8 * (e & 3) + 8), 8u) << 8) | 0x80u;
+  const uint32_t ua = __float_as_uint(lo) + d0, ub = __float_as_uint(hi) + d1;
   return (ub & 0xffff0000u) | (ua >> 16);
 }
 
@@ -1515,12 +1530,11 @@ __global__ __launch_bounds__(256) void tower_out_bwd_kernel(
         }
       }
       if (MODE == 2 && sr) {                                   // dz: unbiased rounding (see pack_bf16_sr)
-        const uint32_t kp2 = (uint32_t)k >> 1;
+        uint32_t da, db;
+        sr_dither8((uint32_t)m, (uint32_t)k >> 3, da, db);
         *reinterpret_cast<uint4*>(dy + m * lddy + k) =
-            make_uint4(pack_bf16_sr(out[0], out[1], drop_hash(kDitherSeed, (uint32_t)m, kp2)),
-                       pack_bf16_sr(out[2], out[3], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 1u)),
-                       pack_bf16_sr(out[4], out[5], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 2u)),
-                       pack_bf16_sr(out[6], out[7], drop_hash(kDitherSeed, (uint32_t)m, kp2 + 3u)));
+            make_uint4(pack_bf16_sr(out[0], out[1], da, db, 0), pack_bf16_sr(out[2], out[3], da, db, 2),
+                       pack_bf16_sr(out[4], out[5], da, db, 4), pack_bf16_sr(out[6], out[7], da, db, 6));
       } else if (MODE != 1)
         *reinterpret_cast<uint4*>(dy + m * lddy + k) =
             make_uint4(pack_bf16(out[0], out[1]), pack_bf16(out[2], out[3]), pack_bf16(out[4], out[5]), pack_bf16(out[6], out[7]));
@@ -1587,12 +1601,14 @@ __global__ __launch_bounds__(256) void tower_bn_bwd_apply_kernel(uint16_t* __res
     const uint4 b = *reinterpret_cast<const uint4*>(z + m * ldz + k);
     const uint32_t ua[4] = {a.x, a.y, a.z, a.w}, ub[4] = {b.x, b.y, b.z, b.w};
     uint32_t o[4];
+    uint32_t da = 0, db = 0;
+    if (sr) sr_dither8((uint32_t)m, (uint32_t)k >> 3, da, db);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int k0 = k + 2 * i, k1 = k0 + 1;
       const float lo = __builtin_fmaf(c[k0], bf16_lo(ua[i]), __builtin_fmaf(c[K + k0], bf16_lo(ub[i]), c[2 * K + k0]));
       const float hi = __builtin_fmaf(c[k1], bf16_hi(ua[i]), __builtin_fmaf(c[K + k1], bf16_hi(ub[i]), c[2 * K + k1]));
-      o[i] = sr ? pack_bf16_sr(lo, hi, drop_hash(kDitherSeed, (uint32_t)m, (uint32_t)(k0 >> 1))) : pack_bf16(lo, hi);
+      o[i] = sr ? pack_bf16_sr(lo, hi, da, db, 2 * i) : pack_bf16(lo, hi);
     }
     *reinterpret_cast<uint4*>(dy + m * lddy + k) = make_uint4(o[0], o[1], o[2], o[3]);
   }

@@ -49,12 +49,14 @@ def main(tag):
     pm = ['# Round 4 PMC passes (visit %s): separate rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in\n'
           '# KiB per dispatch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads).  Columns: mean counter value per dispatch, avg ns.\n' % tag]
     for f in sorted(os.listdir(R)):
-        m = re.match(r'pmc_(fetch|write)_(.+)\.txt', f)
+        m = re.match(r'pmc_(fetch|write|sq)_(.+)\.txt', f)
         if m and not open(os.path.join(R, f)).read().startswith('Traceback'):
             body = [l for l in open(os.path.join(R, f)).read().rstrip().splitlines()
                     if not l.startswith('void at::') and 'rocclr' not in l]
-            pm.append('## rocprofv3 --pmc %s_SIZE -- python bench.py --workload %s --steps 20 --warmup 2 --no-cpu-baseline '
-                      '--also none\n%s\n' % (m.group(1).upper(), m.group(2), '\n'.join(body)))
+            what = 'SQ_* (waves, wave / busy cycles in units of 4 cycles, instruction counts)' if m.group(1) == 'sq' else m.group(1).upper() + '_SIZE'
+            how = ' --no-graph --kernel-timing none (eager launches: rocprofv3 --pmc died on the 128-launch graphs)' if m.group(2).endswith('_hbm') else ''
+            pm.append('## rocprofv3 --pmc %s -- python bench.py --workload %s --no-cpu-baseline --also none%s\n%s\n'
+                      % (what, m.group(2), how, '\n'.join(body)))
     open(os.path.join(ROOT, 'profiles', 'r04_pmc.txt'), 'w').write('\n'.join(pm))
 
     traffic = {}

@@ -123,6 +123,25 @@ PY
         for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 6 | cut -c1-160; done
       done
       find $OUT -name '*.db' -size +4M -delete ;;
+    profiles2)
+      # after the cheaper dz dither: tower tests, the e2e lines + kernel stats again, and the FETCH / WRITE passes of the
+      # *_hbm workloads launched eagerly (rocprofv3 --pmc died on their 128-launch graphs)
+      timeout 900 python -m pytest tests/test_gpu_tower.py tests/test_gpu_full_size.py -x -q -m gpu -k "not every_bench" > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 3 $OUT/t_tower.log
+      for w in e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/one_$w.out | tail -n 1
+      done
+      for w in e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 8 $OUT/stats_$w.txt | cut -c1-130
+      done
+      for w in softmax_hbm ndcg_metric_hbm; do
+        timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 2 --warmup 1 --no-graph --kernel-timing none --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_fetch_$w.log 2>&1
+        timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 2 --warmup 1 --no-graph --kernel-timing none --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
+        for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 4 | cut -c1-160; done
+      done
+      timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq_ndcg_metric -o r -- python bench.py --workload ndcg_metric --steps 20 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_sq_ndcg_metric.log 2>&1
+      python tools/rocpd_summary.py pmc $OUT/pmc_sq_ndcg_metric/r_results.db ndcg > $OUT/pmc_sq_ndcg_metric.txt 2>&1; cat $OUT/pmc_sq_ndcg_metric.txt | cut -c1-150
+      find $OUT -name '*.db' -size +4M -delete ;;
     final)
       # the LAST GPU action of the round: the driver command, three times, on the final tree
       for i in 1 2 3; do
