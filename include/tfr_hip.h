@@ -374,6 +374,18 @@ int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* 
                         const float* e_scale, const float* e_shift, const float* e_mean,
                         const float* e_rstd, const tfr_tower_dropout* pro_dropout,
                         const tfr_tower_dropout* epi_dropout, void* stream);
+/* The same, and the kernel also writes the operand it forms in registers: a_out[M, K] (pitch ldao, bf16) =
+ * prologue(A) -- activation(BatchNorm(z)) times the Dropout keep mask of the layer below -- for the weight gradient of
+ * THIS layer (dW = dz^T . prologue(A)) to read back without a prologue of its own.  Only where the persistent
+ * 256 x 256 kernel runs over full tiles: tfr_tower_gemm_writes_operand(M, N, K) != 0, a prologue, epilogue 0 / 1;
+ * TFR_EINVAL otherwise.  a_out NULL = tfr_tower_gemm_bf16. */
+int tfr_tower_gemm_writes_operand(int M, int N, int K);
+int tfr_tower_gemm_bf16_aout(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                             int M, int N, int K, int prologue, const float* a_scale, const float* a_shift,
+                             const float* bias, int epilogue, float* stats, const void* Zp, long ldz,
+                             const float* e_scale, const float* e_shift, const float* e_mean,
+                             const float* e_rstd, const tfr_tower_dropout* pro_dropout,
+                             const tfr_tower_dropout* epi_dropout, void* a_out, long ldao, void* stream);
 /* Dense in the REFERENCE's precision (keras/layers.py:26-77 builds fp32 Dense layers; model.py:755-817 trains through
  * them): C[M, N] = op(A)[M, K] . op(B)[K, N] (+ bias[N]) with fp32 operands, fp32 accumulation on the matrix cores
  * (v_mfma_f32_32x32x2_f32: a k-ordered fp32 fma chain).  Any M, N, K >= 0 and any pitches.

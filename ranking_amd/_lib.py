@@ -85,6 +85,10 @@ _SIGNATURES = {
     'tfr_tower_gemm_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_int] * 4
                             + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_long]
                             + [ctypes.c_void_p] * 7),
+    'tfr_tower_gemm_bf16_aout': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] * 3 + [ctypes.c_int] * 4
+                                 + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_long]
+                                 + [ctypes.c_void_p] * 6 + [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]),
+    'tfr_tower_gemm_writes_operand': (ctypes.c_int, [ctypes.c_int] * 3),
     'tfr_tower_gemm_stats_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_tower_reduce_scratch_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_tower_bn_finalize': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_long]

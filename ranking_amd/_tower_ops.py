@@ -212,21 +212,32 @@ def stats_rows(M: int) -> int:
     return (M + 63) // 64          # one row of partials per 64-row slab (tfr_tower_gemm_stats_rows)
 
 
+def gemm_writes_operand(M: int, N: int, K: int) -> bool:
+    """True where ``gemm(..., a_out=...)`` is served (the persistent 256 x 256 kernel over full tiles)."""
+    return bool(_lib.load().tfr_tower_gemm_writes_operand(int(M), int(N), int(K)))
+
+
 def gemm(A, B, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, bias=None, epilogue=EPI_PLAIN,
          Zp=None, e_scale=None, e_shift=None, e_mean=None, e_rstd=None, out=None, pro_dropout=None,
-         epi_dropout=None):
-    """C[M, N] = pro(A)[M, :K] . B[N, :K]^T (+ bias) as bf16; returns (C, stats_partial | None)."""
+         epi_dropout=None, a_out=None):
+    """C[M, N] = pro(A)[M, :K] . B[N, :K]^T (+ bias) as bf16; returns (C, stats_partial | None).  ``a_out`` (bf16
+    [M, K], optional): the kernel also writes pro(A), the operand it forms in registers (tfr_tower_gemm_bf16_aout)."""
     _bf16(A, 'A'); _bf16(B, 'B')
     M = A.shape[0]
     C = out if out is not None else torch.empty((M, N), dtype=torch.bfloat16, device=A.device)
     stats = None
     if (epilogue & 0xff) != EPI_PLAIN:
         stats = torch.empty((stats_rows(M), 2, N), dtype=torch.float32, device=A.device)
-    _lib.check(_lib.load().tfr_tower_gemm_bf16(
+    if a_out is not None:
+        _bf16(a_out, 'a_out')
+        if a_out.shape[0] != M or a_out.shape[1] < K:
+            raise ValueError('a_out must be a bf16 [%d, >= %d] tensor' % (M, K))
+    _lib.check(_lib.load().tfr_tower_gemm_bf16_aout(
         _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(C), C.stride(0), M, N, K, prologue,
         _ptr(a_scale), _ptr(a_shift), _ptr(bias), epilogue, _ptr(stats), _ptr(Zp),
         Zp.stride(0) if Zp is not None else 0, _ptr(e_scale), _ptr(e_shift), _ptr(e_mean), _ptr(e_rstd),
-        _dp(pro_dropout), _dp(epi_dropout), _stream()), 'tfr_tower_gemm_bf16')
+        _dp(pro_dropout), _dp(epi_dropout), _ptr(a_out), a_out.stride(0) if a_out is not None else 0, _stream()),
+        'tfr_tower_gemm_bf16_aout')
     return C, stats
 
 
@@ -389,7 +400,7 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
     return out
 
 
-_ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask', 'dropout_field'))
+_ops._guard_module(globals(), __name__, skip=('pad8', 'pad_k', 'stats_rows', 'dropout_mask', 'dropout_field', 'gemm_writes_operand'))
 
 
 # ---- fp32 Dense on the matrix cores (csrc/gemm_f32.hip): the reference's own precision (keras/layers.py:26-77) ----

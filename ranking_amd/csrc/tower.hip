@@ -166,7 +166,8 @@ struct GemmArgs {
   int flags;                           // persistent 256 x 256 kernel: PF_* bits
   int act;                             // ACT_* of PRO_AFFINE_ACT / EPI_ACT_BWD
   int row0;                            // global index of row 0 of A / C (dropout hash) when a launch covers a row range
-};
+  uint16_t* Aout; long ldao;           // nullable [M, K] bf16: the persistent kernel writes pro(A) -- the operand it forms
+};                                     // in registers -- for the weight-gradient kernel to read back (round 4)
 
 enum { PRO_NONE = 0, PRO_AFFINE = 1, PRO_AFFINE_RELU = 2, PRO_AFFINE_ACT = 3 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_RELU_BWD = 2, EPI_ACT_BWD = 3 };
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   // AGPRs; L2-warming touches two stages ahead; sched_group_barrier patterns (3 MFMAs : 1 LDS read); the same flops as
   // half as many v_mfma_f32_32x32x16_bf16.  None of these moved the step by more than 5 %.
   auto compute = [&](const unsigned char* ta, const unsigned char* tb, bool issue, const char* ab, const char* bb,
-                     uint32_t dstbuf, int kt, int m0_) __attribute__((always_inline)) {
+                     uint32_t dstbuf, int kt, int m0_, bool store_a) __attribute__((always_inline)) {
     const uint32_t dst_a = issue ? dstbuf + wave * 4096 : lds0 + P_STAGE + wave * 2048;
     const uint32_t dst_b = issue ? dstbuf + TILE2_BYTES + wave * 4096 : lds0 + P_STAGE + wave * 2048;
     const uint32_t dst_step = issue ? 1024u : 0u;
@@ -951,6 +952,16 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         for (int f = 0; f < 4; ++f)
           fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, pdrop,
                                             (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act);
+        // The transformed operand act(BN(z)) (* keep mask) exists only here, in registers.  The weight gradient of THIS
+        // layer needs exactly it (dW = dz^T . pro(A)): written out once (the wn = 0 waves of the tn = 0 tile of every
+        // M-tile; a lane holds 8 consecutive k of one row = one 16-byte store), the weight-gradient kernel reads it
+        // back WITHOUT a prologue -- with Dropout its prologue would be a hash per element of the transposed fragments,
+        // which is why that kernel fell back to the 128 x 128 register-staged form (0.56 vs 0.38 ms at M = 512 000).
+        if (store_a) {
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            *reinterpret_cast<bf16x8*>(g.Aout + (long)(m0_ + wm * 64 + f * 16 + fr) * g.ldao + k) = fa[f];
+        }
       }
 #pragma unroll
       for (int hn = 0; hn < 2; ++hn) {
@@ -1040,7 +1051,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         zq1 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((8 + (lane >> 3)) * g.ldz + (lane & 7) * 8) * 2));
       }
       compute(smem + cur * (2 * TILE2_BYTES), smem + cur * (2 * TILE2_BYTES) + TILE2_BYTES, issued, a_base(stm, skt),
-              b_base(stn, skt), lds0 + oth * (2 * TILE2_BYTES), kt, m0);
+              b_base(stn, skt), lds0 + oth * (2 * TILE2_BYTES), kt, m0, PRO != PRO_NONE && g.Aout != nullptr && tn == 0 && wn == 0);
       if (kt == 1 && refill) {                     // (rare: the n-tile changed) every wave is past the old epilogue here
         asm volatile("" ::: "memory");
         fill_epi(tn);
@@ -2018,12 +2029,19 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   return launch_gemm_v<PRO, EPI, true>(t, st);
 }
 
+// The shapes the persistent kernel serves (tfr_tower_gemm_persistent: the host asks before it passes `a_out`).
+static bool gemm_persistent_ok(int M, int N, int K, long lda, long ldb, long ldc, long ldz) {
+  static const bool persist = [] { const char* e = getenv("TFR_TOWER_PERSIST"); return !(e && *e) || atoi(e) != 0; }();
+  return persist && M >= BM2 && (N % BN2) == 0 && (K % BK) == 0 && K >= 2 * BK && K <= 1024 && lda < (1L << 21) &&
+         ldb < (1L << 21) && ldc < (1L << 21) && ldz < (1L << 21);
+}
+
 template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
-  static const bool persist = [] { const char* e = getenv("TFR_TOWER_PERSIST"); return !(e && *e) || atoi(e) != 0; }();
-  if (persist && g.M >= BM2 && (g.N % BN2) == 0 && (g.K % BK) == 0 && g.K >= 2 * BK && g.K <= 1024 &&
-      !((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.bias) && g.lda < (1L << 21) && g.ldb < (1L << 21) && g.ldc < (1L << 21) && g.ldz < (1L << 21))
-    return launch_gemm256p<PRO, EPI>(g, st);
+  const bool pers = gemm_persistent_ok(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldz) &&
+                    !((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.bias);
+  if (g.Aout && !(pers && (g.M % BM2) == 0 && PRO != PRO_NONE && EPI <= EPI_STATS)) return TFR_EINVAL;
+  if (pers) return launch_gemm256p<PRO, EPI>(g, st);
   static const bool no_gl = [] { const char* e = getenv("TFR_TOWER_NO_LDSDMA"); return e && *e && atoi(e) != 0; }();
   static const int tile = [] { const char* e = getenv("TFR_TOWER_TILE"); return (e && *e) ? atoi(e) : 256; }();
   if ((g.K % BK) == 0 && !no_gl && tile == 256 && g.N >= BN2 && g.M >= BM2 &&
@@ -2177,6 +2195,14 @@ extern "C" int tfr_tower_weight_cast_batch(const float* const* w, const int* R, 
   return count == 0 ? TFR_OK : (int)hipGetLastError();
 }
 
+extern "C" int tfr_tower_gemm_bf16_aout(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                        int M, int N, int K, int prologue, const float* a_scale,
+                                        const float* a_shift, const float* bias, int epilogue, float* stats,
+                                        const void* Zp, long ldz, const float* e_scale, const float* e_shift,
+                                        const float* e_mean, const float* e_rstd,
+                                        const tfr_tower_dropout* pro_dropout, const tfr_tower_dropout* epi_dropout,
+                                        void* a_out, long ldao, void* stream);
+
 extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                                    int M, int N, int K, int prologue, const float* a_scale,
                                    const float* a_shift, const float* bias, int epilogue, float* stats,
@@ -2184,7 +2210,24 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
                                    const float* e_mean, const float* e_rstd,
                                    const tfr_tower_dropout* pro_dropout, const tfr_tower_dropout* epi_dropout,
                                    void* stream) {
+  return tfr_tower_gemm_bf16_aout(A, lda, B, ldb, C, ldc, M, N, K, prologue, a_scale, a_shift, bias, epilogue, stats, Zp,
+                                  ldz, e_scale, e_shift, e_mean, e_rstd, pro_dropout, epi_dropout, nullptr, 0, stream);
+}
+
+// 1 when tfr_tower_gemm_bf16_aout accepts `a_out` for this shape (the persistent 256 x 256 kernel over full tiles)
+extern "C" int tfr_tower_gemm_writes_operand(int M, int N, int K) {
+  return (gemm_persistent_ok(M, N, K, K, K, N, N) && (M % BM2) == 0) ? 1 : 0;
+}
+
+extern "C" int tfr_tower_gemm_bf16_aout(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
+                                        int M, int N, int K, int prologue, const float* a_scale,
+                                        const float* a_shift, const float* bias, int epilogue, float* stats,
+                                        const void* Zp, long ldz, const float* e_scale, const float* e_shift,
+                                        const float* e_mean, const float* e_rstd,
+                                        const tfr_tower_dropout* pro_dropout, const tfr_tower_dropout* epi_dropout,
+                                        void* a_out, long ldao, void* stream) {
   if (!A || !B || !C || M < 0 || N <= 0 || K <= 0) return TFR_EINVAL;
+  if (a_out && ((ldao & 7) || ldao < K)) return TFR_EINVAL;
   if ((lda & 7) || (ldb & 7) || (ldc & 7) || (N & 7) || (K & 7) || lda < K || ldb < K || ldc < N) return TFR_EINVAL;
   int pact = 0, eact = 0;
   if (!split_mode(prologue, prologue, pact) || !split_mode(epilogue, epilogue, eact)) return TFR_EINVAL;
@@ -2203,6 +2246,7 @@ extern "C" int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long 
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.pro_drop = to_drop(pro_dropout); g.epi_drop = to_drop(epi_dropout);
   g.flags = 0; g.row0 = 0; g.act = pact ? pact : eact;
+  g.Aout = (uint16_t*)a_out; g.ldao = ldao;
   hipStream_t st = (hipStream_t)stream;
 #define TG(P, E) if (prologue == P && epilogue == E) return launch_gemm<P, E>(g, st)
   TG(0, 0); TG(0, 1); TG(0, 2); TG(1, 0); TG(1, 1); TG(1, 2); TG(2, 0); TG(2, 1); TG(2, 2);

@@ -64,6 +64,10 @@ def _pro_of(act: Optional[str]) -> int:
 
 
 _FUSED_LAST_MIN_ELEMS = 1 << 25
+# The forward GEMM of a layer >= 1 writes its transformed operand for the layer's weight gradient (tfr_tower_gemm_bf16_aout):
+# 0 never, 1 when a Dropout follows the layer below (the weight-gradient kernel would otherwise hash per element and fall
+# back to the 128 x 128 form), 2 always.  TFR_TOWER_AOUT overrides (developer A/B).
+_AOUT_MODE = int(os.environ.get('TFR_TOWER_AOUT', '1'))
 
 
 class _TowerFn(torch.autograd.Function):
@@ -129,11 +133,18 @@ class _TowerFn(torch.autograd.Function):
             specs += [(Ws[l], True, None) for l in range(1, n_h)]
         cast = T.cast_weights(specs)
         wbs, ctx.wts = cast[:n_h], [None] + cast[n_h:]
+        a_outs = [None] * n_h
         for l in range(n_h):
             n_out = Ws[l].shape[0]
             wb = wbs[l]
+            # layers >= 1 with a backward to come: the GEMM also writes the operand it forms in registers --
+            # act(BatchNorm(z)) times the keep mask -- for this layer's weight gradient (see _AOUT_MODE)
+            if (want_bwd and pro != T.PRO_NONE and (_AOUT_MODE == 2 or (_AOUT_MODE == 1 and drop is not None))
+                    and T.gemm_writes_operand(M, n_out, k_in)):
+                a_outs[l] = torch.empty((M, k_in), dtype=torch.bfloat16, device=dev)
             z, stats = T.gemm(a_in, wb, n_out, k_in, prologue=pro, a_scale=sc, a_shift=sh, bias=bs[l],
-                              epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN, pro_dropout=drop)
+                              epilogue=T.EPI_STATS if (use_bn and training) else T.EPI_PLAIN, pro_dropout=drop,
+                              a_out=a_outs[l])
             if use_bn:
                 if training:
                     sc, sh, mean, rstd = T.bn_finalize(stats, M, gammas[l], betas[l], _BN_EPS, tower.momentum,
@@ -160,6 +171,7 @@ class _TowerFn(torch.autograd.Function):
         ctx.tower, ctx.training = tower, training
         tower._last_drops = [c[5] for c in coefs]
         ctx.x0, ctx.zs, ctx.coefs, ctx.in_bn = x0, zs, coefs, in_bn
+        ctx.a_outs = a_outs
         ctx.params = params
         return logits
 
@@ -224,8 +236,12 @@ class _TowerFn(torch.autograd.Function):
             into = Ws[l].grad if (direct and k_in == Ws[l].shape[1] and Ws[l].grad.is_contiguous()) else None
             if l == 0:
                 dz0 = dz
-            g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p,
-                        accumulate_into=into)
+            if ctx.a_outs[l] is not None:                    # the forward GEMM left act(BN(z)) * mask behind: no prologue
+                g = T.wgrad(dz, ctx.a_outs[l], n_out, k_in, prologue=T.PRO_NONE, accumulate_into=into)
+                ctx.a_outs[l] = None
+            else:
+                g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p,
+                            accumulate_into=into)
             if into is None:
                 dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
             if l > 0:

@@ -177,6 +177,38 @@ def test_out_layer_bwd_and_bn_apply():
     bf16_close(got, want, 'dz')
 
 
+@pytest.mark.parametrize('pro,rate', [(2, 0.5), (2, 0.0), (1, 0.25)])
+def test_gemm_writes_its_transformed_operand(pro, rate):
+    """tfr_tower_gemm_bf16_aout: the persistent forward GEMM also writes pro(A) = act(A * scale + shift) * keep mask, the
+    operand it forms in registers, for the layer's weight gradient; C and the statistics are what they are without it."""
+    t = T()
+    M, N, K = 1024, 512, 512
+    assert t.gemm_writes_operand(M, N, K) and not t.gemm_writes_operand(M + 8, N, K) and not t.gemm_writes_operand(M, 136, K)
+    A = (rnd((M, K), 81) * 1.2).to(DEV).to(torch.bfloat16)
+    W = (rnd((N, K), 82) * 0.05).to(DEV).to(torch.bfloat16)
+    sc = (rnd((K,), 83) * 0.3 + 1.0).to(DEV); sh = rnd((K,), 84, 0.3).to(DEV)
+    bias = rnd((N,), 85, 0.1).to(DEV)
+    d = t.Dropout.make(rate, 4321) if rate > 0 else None
+    a_out = torch.full((M, K), float('nan'), dtype=torch.bfloat16, device=DEV)
+    C1, st1 = t.gemm(A, W, N, K, prologue=pro, a_scale=sc, a_shift=sh, bias=bias, epilogue=t.EPI_STATS, pro_dropout=d,
+                     a_out=a_out)
+    C0, st0 = t.gemm(A, W, N, K, prologue=pro, a_scale=sc, a_shift=sh, bias=bias, epilogue=t.EPI_STATS, pro_dropout=d)
+    assert torch.equal(C1.view(torch.int16), C0.view(torch.int16)) and torch.equal(st1, st0)
+    y = A.float() * sc + sh
+    want = torch.relu(y) if pro == 2 else y
+    if d is not None:
+        want = want * t.dropout_mask(d, M, K, DEV)
+    bf16_close(a_out, want, 'a_out')
+    # the weight gradient from the written operand = the one the prologue kernel computes
+    dz = (rnd((M, N), 86) * 0.01).to(DEV).to(torch.bfloat16)
+    g_new = t.wgrad(dz, a_out, N, K, prologue=t.PRO_NONE)
+    g_old = t.wgrad(dz, A, N, K, prologue=pro, a_scale=sc, a_shift=sh, dropout=d)
+    assert (g_new - g_old).abs().max().item() <= 2e-3 * g_old.abs().max().item() + 1e-6
+    with pytest.raises(ValueError):                           # a shape the persistent kernel does not serve
+        t.gemm(A[:1000], W, N, K, prologue=pro, a_scale=sc, a_shift=sh, bias=bias, epilogue=t.EPI_STATS,
+               a_out=a_out[:1000])
+
+
 def test_bn_bwd_apply_rounds_dz_without_bias():
     """dz = p dy + q z + r is rounded to bf16 STOCHASTICALLY (csrc/tower.hip pack_bf16_sr): dy is a bf16 lattice, the
     mean-removal terms are a fraction of a bf16 ulp at training batch sizes, and round-to-nearest drops them -- the column
