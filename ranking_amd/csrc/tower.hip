@@ -822,6 +822,10 @@ constexpr int P_EPI = P_SCALE + 2 * 1024 * 4;         // [4][256] floats: the ti
 constexpr int P_STAGE = P_EPI + 4 * 256 * 4;          // 8 waves x 2 KB
 constexpr int P_JUNK = P_STAGE + 8 * 2048;            // 8 waves x 256 B (touch destinations, never read)
 constexpr int P_LDS = P_JUNK + 8 * 256;               // 157 696 B
+// the keep bits of a stage's A tile (rate 1/2), [256 rows][2 words] = 2 KB per buffer, double buffered in space the forward
+// forms do not use: the touch slots and the three epilogue-coefficient rows of the dgrad forms (161 792 B of dynamic LDS
+// was refused by the runtime)
+constexpr int P_MASK0 = P_JUNK, P_MASK1 = P_EPI + 256 * 4;
 
 __device__ __forceinline__ void dma16_s(uint32_t voff, const void* sbase, uint32_t lds_addr) {
   // (s_nop 4: an SGPR fresh from v_readfirstlane must not be read by a VMEM instruction within 5 states)
@@ -837,15 +841,19 @@ __device__ __forceinline__ f32x4 row16_sum4(f32x4 v) {
   return o;
 }
 
-enum { PF_TOUCH_A = 1, PF_TOUCH_Z = 2, PF_IDLE_DMA = 4 };   // PF_IDLE_DMA (TFR_GEMM_FLAGS=4): rounds 2-3, a step with nothing to request still issued its pieces (into an idle slot)
+enum { PF_TOUCH_A = 1, PF_TOUCH_Z = 2, PF_IDLE_DMA = 4, PF_NO_BIT_TABLE = 8 };   // PF_IDLE_DMA (TFR_GEMM_FLAGS=4): rounds 2-3, a step with nothing to request still issued its pieces (into an idle slot)
 
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // The previous layer's BatchNorm (+ ReLU, + dropout) on one MFMA operand fragment (8 consecutive k of one row) as it
 // comes out of LDS: relu on the packed bf16 pair is a signed 16-bit max with 0 (v_pk_max_i16), the affine a v_pk_fma_f32.
-template <int PRO, bool DROP>
+// DROP == 2: the keep bits of the fragment's 8 columns come from the stage's bit table in LDS (`bits8`: bit j = column j
+// kept) and the factor 1 / (1 - rate) = 2 is already folded into sc / sh -- see the table's comment in
+// tower_gemm256p_kernel; DROP == 1: one hash per fragment (drop_run).
+template <int PRO, int DROP>       // DROP: 0 none, 1 one hash per fragment (drop_run), 2 the stage's keep-bit table
 __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, const f32x4 sc1, const f32x4 sh0, const f32x4 sh1,
-                                                 const Drop d, uint32_t m, uint32_t k, int act) {
+                                                 const Drop d, uint32_t m, uint32_t k, int act, uint32_t bits8 = 0u) {
+  constexpr bool bt = DROP == 2;
   if (PRO == PRO_NONE) return raw;
   const uint4 v = __builtin_bit_cast(uint4, raw);
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -853,23 +861,27 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
   const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
   uint32_t o[4];
   float kf[8];
-  if (DROP) drop_run<8>(d, m, k, kf);                // one hash for the fragment's 8 columns when the rate allows
+  if (DROP == 1) drop_run<8>(d, m, k, kf);           // one hash for the fragment's 8 columns when the rate allows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
     const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
     x = x * s + h;
     if (PRO == PRO_AFFINE_ACT) { x[0] = act_fwd(act, x[0]); x[1] = act_fwd(act, x[1]); }
-    if (DROP) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
+    if (DROP == 1) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
     uint32_t pk = pack_bf16(x[0], x[1]);
     if (PRO == PRO_AFFINE_RELU)
       pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
+    if (bt) {                                        // zero the dropped halves of the packed pair: 0 / -1 per bit, merged
+      const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)bits8, 2 * i, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)bits8, 2 * i + 1, 1);
+      pk &= (m0 & 0xffffu) | (m1 & 0xffff0000u);
+    }
     o[i] = pk;
   }
   return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
 }
 
-template <int PRO, int EPI, bool DROP>
+template <int PRO, int EPI, int DROP>      // DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
 __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
@@ -888,6 +900,18 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   const int nq = ((g.tiles_m - xcd + 7) >> 3) * g.tiles_n;       // this XCD's tiles: M-tiles xcd, xcd + 8, ...
   if (slot >= nq) return;
   const bool touch_z = (EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && (g.flags & PF_TOUCH_Z) != 0 && wave >= 4;
+  // Keep-bit table (round 4; rate 1/2 = the reference default, 1-bit fields: a hash word serves 32 columns of a row).
+  // Per fragment the prologue hashed once and expanded 8 keep factors (42 VALU on top of the 20 of BatchNorm + ReLU; the
+  // forward GEMM took 0.53 ms against 0.42 without Dropout at M = 512 000).  The A tile of a stage is 256 rows x 64
+  // columns = 512 hash words: every thread computes ONE per k step, a step ahead, into LDS; a fragment then costs one
+  // ds_read_b32 + a shift for its byte and 4 x (2 v_bfe_i32 + merge + and) on the packed pairs, with the factor 2 folded
+  // into the per-column scale / shift (exact).  Same bits as drop_run (the hash and its word / bit layout are unchanged).
+  constexpr bool bt = DROP == 2;                    // (the launcher: rate 1/2, a homogeneous activation)
+  auto mask_buf = [&](int mbuf) __attribute__((always_inline)) { return reinterpret_cast<uint32_t*>(smem + (mbuf ? P_MASK1 : P_MASK0)); };   // [256][2]
+  auto fill_mask = [&](int mbuf, int tm_, int kt_) __attribute__((always_inline)) {
+    mask_buf(mbuf)[tid] = drop_hash(pdrop.seed, (uint32_t)(g.row0 + tm_ * BM2 + (tid >> 1)), (uint32_t)(2 * kt_ + (tid & 1)));
+  };
+  int mcur = 0;                                      // the table buffer of the step being computed
 
   // per-lane byte offsets of the staging pieces (tile independent): piece i = rows wave * 32 + 8 i .. + 8
   uint32_t offA[4], offB[4];
@@ -949,9 +973,12 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_scale + k), sc1 = *reinterpret_cast<const f32x4*>(s_scale + k + 4);
         const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + k), sh1 = *reinterpret_cast<const f32x4*>(s_shift + k + 4);
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < 4; ++f) {
+          uint32_t bits8 = 0u;
+          if (bt) bits8 = mask_buf(mcur)[(wm * 64 + f * 16 + fr) * 2 + kk] >> (fq * 8);
           fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, pdrop,
-                                            (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act);
+                                            (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act, bits8);
+        }
         // The transformed operand act(BN(z)) (* keep mask) exists only here, in registers.  The weight gradient of THIS
         // layer needs exactly it (dW = dz^T . pro(A)): written out once (the wn = 0 waves of the tn = 0 tile of every
         // M-tile; a lane holds 8 consecutive k of one row = one 16-byte store), the weight-gradient kernel reads it
@@ -1013,8 +1040,11 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   fill_epi(tn);
   int p = 0;                                       // the buffer that holds stage 0 of the current tile
   issue_b(tn, 0, 0); issue_a(tm, 0, 0); issue_b(tn, 1, 1); issue_a(tm, 1, 1);
-  if (PRO != PRO_NONE)
-    for (int k = tid; k < g.K; k += 512) { s_scale[k] = g.a_scale[k]; s_shift[k] = g.a_shift[k]; }
+  if (PRO != PRO_NONE) {
+    const float fold = bt ? pdrop.scale : 1.0f;     // (x s + h) * 2 == x (2 s) + 2 h exactly
+    for (int k = tid; k < g.K; k += 512) { s_scale[k] = g.a_scale[k] * fold; s_shift[k] = g.a_shift[k] * fold; }
+  }
+  if (bt) fill_mask(0, tm, 0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
   while (true) {
@@ -1056,8 +1086,10 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         asm volatile("" ::: "memory");
         fill_epi(tn);
       }
+      if (bt && (!last || have_next)) fill_mask(mcur ^ 1, stm, skt);   // the table of the NEXT step (this or the next tile)
       // the pieces requested in this step must have landed (every wave's) before anyone reads them
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      mcur ^= 1;
     }
     GEMM_STAMP(2);
     const int freeb = p ^ ((nk - 1) & 1);           // the buffer of the last step: free now
@@ -2014,7 +2046,12 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   const bool drop = (PRO != PRO_NONE && g.pro_drop.thr) || ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.epi_drop.thr);
   const int nq0 = ((g.tiles_m + 7) >> 3) * g.tiles_n;
   const int nslots = nq0 < 32 ? nq0 : 32;
-  auto fn = drop ? tower_gemm256p_kernel<PRO, EPI, true> : tower_gemm256p_kernel<PRO, EPI, false>;
+  // the prologue's keep-bit table: rate 1/2 (1-bit fields), an activation that commutes with the factor 2
+  const bool table = PRO != PRO_NONE && PRO != PRO_AFFINE_ACT && g.pro_drop.thr != 0u && g.pro_drop.lge == 5u &&
+                     !(flags & PF_NO_BIT_TABLE);
+  auto fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0>
+                  : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, ((PRO == PRO_AFFINE || PRO == PRO_AFFINE_RELU) && EPI <= EPI_STATS) ? 2 : 1>
+                                                                            : tower_gemm256p_kernel<PRO, EPI, 1>);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(fn, dim3(8 * nslots), dim3(512), P_LDS, st, g);

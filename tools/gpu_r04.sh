@@ -115,6 +115,13 @@ print('    dropout_0 ms/step', d.get('dropout_0',{}).get('ms_per_step'))
 PY
         done
       done ;;
+    bt_ab)
+      timeout 900 python -m pytest tests/test_gpu_tower.py tests/test_gpu_full_size.py tests/test_gpu_groupwise.py -x -q -m gpu -k "not every_bench" > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 4 $OUT/t_tower.log
+      for v in "TFR_GEMM_FLAGS=8" ""; do
+        for w in e2e_approx_ndcg_l1000 e2e_softmax e2e_groupwise_gumbel; do
+          env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/b_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/b.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/b_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
+        done
+      done ;;
     hbm)
       for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
         timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
