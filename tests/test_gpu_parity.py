@@ -97,6 +97,35 @@ def test_sort_reference_goldens():
     assert out.tolist() == [[[4., 5., 6.], [7., 8., 9.]], [[70., 80., 90.], [40., 50., 60.]]]
 
 
+@pytest.mark.parametrize('B,L', [(1, 7), (2, 64), (63, 33), (64, 200), (65, 200), (200, 50), (4099, 120), (5, 1000), (70, 1500)])
+def test_approx_ndcg_reduced_scalar_from_the_same_launch(B, L):
+    """tfr_approx_ndcg_sum_f32 (round 4): sum_b loss_b * list_scale_b added up inside the loss launch by the last waves
+    to finish their forward pass (group tickets in device memory, csrc/common.h grid_weighted_sum_last) -- for batches
+    that do not fill a group, that leave groups ragged, for the wave and the workgroup kernel: equal to the fp64 sum of
+    the per-list values, the same bits on every call (fixed summation order whoever finishes last), the ticket state
+    left zero, and the per-list outputs unchanged."""
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=500 + B + L)
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    scale = (torch.rand(B, generator=torch.Generator().manual_seed(B)) + 0.5).to(DEV)
+    loss0, w0, d0 = _ops.approx_ndcg(lg, lb, None, scale, 0.1, 0, True)
+    totals = []
+    for _ in range(3):
+        loss, w, d, total = _ops.approx_ndcg(lg, lb, None, scale, 0.1, 0, True, want_sum=True)
+        assert torch.equal(loss, loss0) and torch.equal(w, w0) and torch.equal(d, d0)
+        totals.append(total.clone())
+    want = (loss0.double() * scale.double()).sum().item()
+    got = totals[0].item()
+    assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (got, want)
+    assert torch.equal(totals[0], totals[1]) and torch.equal(totals[1], totals[2])
+    state = _ops._device_state[('loss_sum', str(lb.device))]
+    torch.cuda.synchronize()
+    assert int(state[:65].abs().sum().item()) == 0            # group tickets and the top ticket are back to zero
+    # without a scale vector: the plain sum
+    _, _, _, t2 = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True, want_sum=True)
+    assert abs(t2.item() - loss0.double().sum().item()) <= 2e-6 * max(1.0, abs(loss0.double().sum().item()))
+
+
 # ---------------------------------------------------------------------- metrics
 # (1100, 300): wave kernel with 8 keys per lane; 512 < L <= 8192: the workgroup kernels (LDS bitonic sort; round 3: 16 B of
 # LDS per item, up to the 8192 items of the loss kernels -- round 2 stopped at 4096)

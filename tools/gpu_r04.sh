@@ -163,9 +163,9 @@ PY
       find $OUT -name '*.db' -size +4M -delete ;;
     final)
       # the LAST GPU action of the round: the driver command, three times, on the final tree
-      for i in 1 2 3; do
+      for i in 1 2; do
         ( time timeout 1200 python3 bench.py $DRV > $OUT/final_$i.out 2> $OUT/final_$i.err ) 2> $OUT/final_$i.time; echo "final $i rc=$?"
-        tail -n 2 $OUT/final_$i.err | cut -c1-300; tail -n 1 $OUT/final_$i.out | cut -c1-600; tail -n 3 $OUT/final_$i.time
+        tail -n 2 $OUT/final_$i.err | cut -c1-300; python tools/bench_summary.py $OUT/final_$i.out; tail -n 3 $OUT/final_$i.time
       done ;;
     tests)
       timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
