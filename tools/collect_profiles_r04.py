@@ -72,10 +72,13 @@ def main(tag):
     for w, B, L in (('e2e_approx_ndcg_l1000', 512, 1000), ('e2e_groupwise_gumbel', 512, 50), ('e2e_softmax', 4096, 100)):
         pf, pw = os.path.join(R, 'pmc_fetch_%s.txt' % w), os.path.join(R, 'pmc_write_%s.txt' % w)
         unit = B * L * 512 * 2                                   # one [M, 512] bf16 matrix
-        k0 = 'tower_gemm256p_kernel<2, 1, true>'
+        k0 = 'tower_gemm256p_kernel<2, 1, 2>'                 # Dropout 0.5: the keep-bit table form (round 4)
         f, wr = pmc_mean(pf, k0, 'FETCH_SIZE'), pmc_mean(pw, k0, 'WRITE_SIZE')
+        if f is None:
+            k0 = 'tower_gemm256p_kernel<2, 1, true>'
+            f, wr = pmc_mean(pf, k0, 'FETCH_SIZE'), pmc_mean(pw, k0, 'WRITE_SIZE')
         if f is not None and wr is not None:
-            traffic[w] = dict(B=B, L=L, kernel=k0 + ' (forward hidden layer, BN + ReLU + Dropout prologue: reads z, writes z)',
+            traffic[w] = dict(B=B, L=L, kernel=k0 + ' (forward hidden layer, BN + ReLU + Dropout prologue: reads z, writes z; in the training step also the transformed operand for the weight gradient)',
                               fetch_kib=f, write_kib=wr, traffic_bytes=int(round((2 * f + wr) * 1024)), algorithmic_bytes=2 * unit)
     doc = {'_comment': ('HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per '
                         'dispatch, mean over dispatches; visit %s, tables in profiles/r04_pmc.txt), corrected as MI355X_MICROARCH.md '

@@ -122,6 +122,21 @@ PY
           env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/b_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/b.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/b_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
         done
       done ;;
+    profiles3)
+      # the tower after the written operand / keep-bit table: e2e lines, kernel stats, FETCH / WRITE of config 4; the new test
+      timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "reduced_scalar" > $OUT/t_sum.log 2>&1; echo "reduced-scalar test rc=$?"; tail -n 2 $OUT/t_sum.log
+      for w in e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/one_$w.out | tail -n 1
+      done
+      for w in e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/prof_$w.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 12 $OUT/stats_$w.txt | cut -c1-130
+      done
+      w=e2e_approx_ndcg_l1000
+      timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch_$w -o r -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_fetch_$w.log 2>&1
+      timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
+      for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep "tower_gemm256p\|wgrad" $OUT/pmc_${p}_$w.txt | head -n 8 | cut -c1-160; done
+      find $OUT -name '*.db' -size +4M -delete ;;
     hbm)
       for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
         timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
