@@ -958,7 +958,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
   // AGPRs; L2-warming touches two stages ahead; sched_group_barrier patterns (3 MFMAs : 1 LDS read); the same flops as
   // half as many v_mfma_f32_32x32x16_bf16.  None of these moved the step by more than 5 %.
   auto compute = [&](const unsigned char* ta, const unsigned char* tb, bool issue, const char* ab, const char* bb,
-                     uint32_t dstbuf, int kt, int m0_, bool store_a) __attribute__((always_inline)) {
+                     uint32_t dstbuf, int kt, int m0_, bool store_a, int store_f) __attribute__((always_inline)) {
     const uint32_t dst_a = issue ? dstbuf + wave * 4096 : lds0 + P_STAGE + wave * 2048;
     const uint32_t dst_b = issue ? dstbuf + TILE2_BYTES + wave * 4096 : lds0 + P_STAGE + wave * 2048;
     const uint32_t dst_step = issue ? 1024u : 0u;
@@ -980,14 +980,19 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
                                             (uint32_t)(g.row0 + m0_ + wm * 64 + f * 16 + fr), (uint32_t)k, g.act, bits8);
         }
         // The transformed operand act(BN(z)) (* keep mask) exists only here, in registers.  The weight gradient of THIS
-        // layer needs exactly it (dW = dz^T . pro(A)): written out once (the wn = 0 waves of the tn = 0 tile of every
-        // M-tile; a lane holds 8 consecutive k of one row = one 16-byte store), the weight-gradient kernel reads it
+        // layer needs exactly it (dW = dz^T . pro(A)): written out once (a lane holds 8 consecutive k of one row = one
+        // 16-byte store), the weight-gradient kernel reads it
         // back WITHOUT a prologue -- with Dropout its prologue would be a hash per element of the transposed fragments,
         // which is why that kernel fell back to the 128 x 128 register-staged form (0.56 vs 0.38 ms at M = 512 000).
-        if (store_a) {
+        // Who stores: the SAME fragments exist in both waves of a row block (wn = 0, 1) and in every n-tile of the
+        // M-tile, and the eight waves of the workgroup meet at a barrier every k step -- eight stores on one wave in four
+        // made that wave the step's straggler.  The work is dealt out instead: wave wn takes the k half kk = wn, n-tile
+        // tn takes the fragment rows f with f mod min(tiles_n, 4) = tn: two stores per wave and k step at N = 512.
+        if (store_a && kk == wn) {
 #pragma unroll
           for (int f = 0; f < 4; ++f)
-            *reinterpret_cast<bf16x8*>(g.Aout + (long)(m0_ + wm * 64 + f * 16 + fr) * g.ldao + k) = fa[f];
+            if ((store_f >> f) & 1)
+              *reinterpret_cast<bf16x8*>(g.Aout + (long)(m0_ + wm * 64 + f * 16 + fr) * g.ldao + k) = fa[f];
         }
       }
 #pragma unroll
@@ -1054,6 +1059,12 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
     if (have_next) tile_of(qn, tmn, tnn);
     const int m0 = tm * BM2, n0 = tn * BN2;
     const long mb = (long)m0 + wm * 64;
+    int store_f = 0;                               // bit f: this n-tile writes fragment row f of the transformed operand
+    {
+      const int tdiv = g.tiles_n < 4 ? g.tiles_n : 4;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) store_f |= ((f % tdiv) == tn) ? (1 << f) : 0;
+    }
 #if (TFR_GEMM_ABLATE & 16)
     unsigned long long prof_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1081,7 +1092,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
         zq1 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((8 + (lane >> 3)) * g.ldz + (lane & 7) * 8) * 2));
       }
       compute(smem + cur * (2 * TILE2_BYTES), smem + cur * (2 * TILE2_BYTES) + TILE2_BYTES, issued, a_base(stm, skt),
-              b_base(stn, skt), lds0 + oth * (2 * TILE2_BYTES), kt, m0, PRO != PRO_NONE && g.Aout != nullptr && tn == 0 && wn == 0);
+              b_base(stn, skt), lds0 + oth * (2 * TILE2_BYTES), kt, m0, PRO != PRO_NONE && g.Aout != nullptr && tn < 4, store_f);
       if (kt == 1 && refill) {                     // (rare: the n-tile changed) every wave is past the old epilogue here
         asm volatile("" ::: "memory");
         fill_epi(tn);

@@ -177,12 +177,13 @@ def test_out_layer_bwd_and_bn_apply():
     bf16_close(got, want, 'dz')
 
 
+@pytest.mark.parametrize('N', [256, 512, 768, 1024, 1280])      # 1 .. 5 n-tiles share the stores of the operand
 @pytest.mark.parametrize('pro,rate', [(2, 0.5), (2, 0.0), (1, 0.25)])
-def test_gemm_writes_its_transformed_operand(pro, rate):
+def test_gemm_writes_its_transformed_operand(pro, rate, N):
     """tfr_tower_gemm_bf16_aout: the persistent forward GEMM also writes pro(A) = act(A * scale + shift) * keep mask, the
     operand it forms in registers, for the layer's weight gradient; C and the statistics are what they are without it."""
     t = T()
-    M, N, K = 1024, 512, 512
+    M, K = 1024, 512
     assert t.gemm_writes_operand(M, N, K) and not t.gemm_writes_operand(M + 8, N, K) and not t.gemm_writes_operand(M, 136, K)
     A = (rnd((M, K), 81) * 1.2).to(DEV).to(torch.bfloat16)
     W = (rnd((N, K), 82) * 0.05).to(DEV).to(torch.bfloat16)

@@ -137,6 +137,18 @@ PY
       timeout 300 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write_$w -o r -- python bench.py --workload $w --steps 4 --warmup 2 --no-cpu-baseline --also none --busy-seconds 0 > $OUT/pmc_write_$w.log 2>&1
       for p in fetch write; do python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep "tower_gemm256p\|wgrad" $OUT/pmc_${p}_$w.txt | head -n 8 | cut -c1-160; done
       find $OUT -name '*.db' -size +4M -delete ;;
+    aout2_ab)
+      timeout 900 python -m pytest tests/test_gpu_tower.py tests/test_gpu_full_size.py -x -q -m gpu -k "not every_bench" > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 3 $OUT/t_tower.log
+      for v in "TFR_TOWER_AOUT=0" "TFR_TOWER_AOUT=1" "TFR_TOWER_AOUT=2"; do
+        for w in e2e_approx_ndcg_l1000 e2e_softmax; do
+          env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/a_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/a.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/a_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
+          python - <<PY
+import json
+d=json.loads([l for l in open('$OUT/a_${w}_$(echo $v | tr ' =' '__').out') if l.startswith('{')][-1])
+print('    dropout_0 ms/step', d.get('dropout_0',{}).get('ms_per_step'))
+PY
+        done
+      done ;;
     hbm)
       for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
         timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
