@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
     float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
     float* __restrict__ dlogits_out, int max_runs, int metric, const int* __restrict__ order, int pair_rcp,
-    float* __restrict__ loss_sum, unsigned int* __restrict__ ticket, int B) {
+    float* __restrict__ loss_sum, unsigned int* __restrict__ ticket, int B, int fast_labels) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* X = reinterpret_cast<float*>(smem_raw);   // [Lp] compact x (pad -inf)
   float* E = X + Lp;                               // [Lp] exp(x - m)
@@ -407,6 +407,8 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   float x[IPL], g[IPL];
   bool v[IPL];
   float lmax = -INFINITY, lsum = 0.f, xmin = INFINITY, xmax = -INFINITY;
+  unsigned gbits = 0u;                               // grades present (bit l), when every cleaned label is an integer 0 .. 31
+  bool small_int = true;
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
     const int e = lane + 64 * r;
@@ -418,17 +420,73 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
       g[r] = v[r] ? lab : 0.0f;                      // cleaned label for now
       lmax = fmaxf(lmax, g[r]); lsum += g[r];
       if (v[r]) { xmin = fminf(xmin, x[r]); xmax = fmaxf(xmax, x[r]); }
+      const int li = (int)g[r];
+      const bool ok = g[r] >= 0.0f && g[r] < 32.0f && (float)li == g[r];
+      small_int = small_int && ok;
+      gbits |= ok ? (1u << li) : 0u;
     }
   }
-  lmax = wave_max_u(lmax); lsum = wave_sum_u(lsum); xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
-  const bool nonzero = lsum > 0.0f;
-  if (!nonzero) lmax = 1e-10f;
+  xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
+  // Graded relevance labels -- small non-negative integers -- are the common case (round 4): the label maximum and the
+  // sign of the label sum come out of ONE wave-wide OR of the grade bits, and the ideal DCG below needs no reduction per
+  // run.  (In-kernel stamps: the statistics and the run-length ideal DCG were 17 % + 25 % of a wave's lifetime, ten dependent
+  // DPP reduction chains for what is five grade counts.)  Anything else -- fractional, negative or huge labels, ApproxMRR
+  // (which needs the label sum itself) -- takes the general reductions.
+  const bool int_path = fast_labels && metric == TFR_APPROX_NDCG && !__ballot(!small_int);
+  unsigned present = 0u;
+  bool nonzero;
+  if (int_path) {
+    present = wave_or_u(gbits);
+    nonzero = (present >> 1) != 0u;
+    lmax = nonzero ? (float)(31 - __builtin_clz(present)) : 1e-10f;
+  } else {
+    lmax = wave_max_u(lmax); lsum = wave_sum_u(lsum);
+    nonzero = lsum > 0.0f;
+    if (!nonzero) lmax = 1e-10f;
+  }
 
   TFR_STAMP(1);
   // ---- 2. gains and normaliser.  NDCG: safe gains + inverse ideal DCG (:33-49, :109-134);
   // MRR (ApproxMRRLoss, :1606-1632): the cleaned labels themselves, normalised by their sum.
   float inv_max_dcg;
-  if (metric == TFR_APPROX_MRR) {
+  if (int_path) {
+    // gain of grade l = 2^(l - lmax) - 2^-lmax, exact (ldexp), 0 for grade 0 and for every item of a list without a
+    // relevant one (the reference's 1e-10 labels give 2^0 - 2^-1e-10 = 0 in fp32).  Ideal DCG: the sorted gains are runs
+    // of equal grades, highest first; position e of run [pos, pos + c) carries that grade's gain -- every lane looks its
+    // positions up against the (wave-uniform) run boundaries and ONE reduction adds gain(e) * discount(e).
+    const int lmi = nonzero ? 31 - __builtin_clz(present) : 0;
+    const float g0 = __builtin_amdgcn_ldexpf(1.0f, -lmi);
+    float tbl[IPL], gpos[IPL];
+    int li_[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int e = lane + 64 * r;
+      tbl[r] = (e < L) ? inv_log1p[e] : 0.0f;
+      li_[r] = (e < L) ? (int)g[r] : -1;
+      g[r] = (e < L && nonzero) ? __builtin_amdgcn_ldexpf(1.0f, li_[r] - lmi) - g0 : 0.0f;
+      gpos[r] = 0.0f;
+    }
+    int pos = 0;
+    for (unsigned rest = nonzero ? (present & ~1u) : 0u; rest != 0u;) {     // grades >= 1, highest first (scalar loop)
+      const int gq = 31 - __builtin_clz(rest);
+      rest &= ~(1u << gq);
+      const float val = __builtin_amdgcn_ldexpf(1.0f, gq - lmi) - g0;
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) c += __popcll(__ballot(li_[r] == gq));
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int e = lane + 64 * r;
+        gpos[r] = (e >= pos && e < pos + c) ? val : gpos[r];
+      }
+      pos += c;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) t = __builtin_fmaf(gpos[r], tbl[r], t);
+    const float idcg = wave_sum_u(t);
+    inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+  } else if (metric == TFR_APPROX_MRR) {
 #pragma unroll
     for (int r = 0; r < IPL; ++r) g[r] = (lane + 64 * r < L) ? (nonzero ? g[r] : 1e-10f) : 0.f;
     const float denom = nonzero ? lsum : (float)L * 1e-10f;
@@ -644,9 +702,10 @@ int launch_wave(const float* logits, const float* labels, const uint8_t* mask, c
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 1);   // 0: one reciprocal per pair everywhere (round 3)
+  static const int int_labels = env_int("TFR_APPROX_INT_LABELS", 1);   // 0: label statistics / ideal DCG by the general reductions
   hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
                      inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order,
-                     pair_rcp, loss_sum, ticket, B);
+                     pair_rcp, loss_sum, ticket, B, int_labels);
   return (int)hipGetLastError();
 }
 

@@ -290,6 +290,17 @@ __device__ __forceinline__ float wave_max_u(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_min_u(float v) { return -wave_max_u(-v); }
+// wave-wide OR on the DPP network (wave-uniform result, read from lane 63)
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) {
+  int x = (int)v;
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
 __device__ __forceinline__ float wave_sum_u(float v) {
   v += TFR_DPP_F(0.f, v, 0x111, 0xf, 0xf, true);
   v += TFR_DPP_F(0.f, v, 0x112, 0xf, 0xf, true);

@@ -149,6 +149,14 @@ print('    dropout_0 ms/step', d.get('dropout_0',{}).get('ms_per_step'))
 PY
         done
       done ;;
+    int_ab)
+      H="--workload approx_ndcg --also none --no-cpu-baseline --busy-seconds 0 --steps 200 --warmup 20"
+      for v in "TFR_APPROX_INT_LABELS=0" ""; do
+        env $v timeout 200 python3 bench.py $H > $OUT/i_$(echo $v | tr ' =' '__').out 2> $OUT/i.err; echo "[$v] rc=$?"; python tools/bench_summary.py $OUT/i_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
+    final1)
+      ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
+      tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;
     hbm)
       for w in softmax_hbm ndcg_metric_hbm softmax ndcg_metric; do
         timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/hbm_$w.out 2> $OUT/hbm_$w.err; echo "$w rc=$?"; python tools/bench_summary.py $OUT/hbm_$w.out | tail -n 1; tail -n 1 $OUT/hbm_$w.err | cut -c1-200
