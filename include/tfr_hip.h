@@ -359,6 +359,15 @@ int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, int F, int K
  * and keeps its digits when |mean| >> std. */
 int tfr_tower_input_stats_f32(const float* x, long ldx, int M, int F, const int* row_index, float* partial,
                               int n_blocks, const float* pivot, void* stream);
+/* bf16 feature ingest (the host parser's tfr_io_parse_elwc_batch_bf16; no reference counterpart -- the reference feeds
+ * fp32 tensors to a Keras model whose Dense layers run at whatever precision the policy says, keras/layers.py:26-77):
+ * the two entry points above for features that arrive as bfloat16 x_bf16[R, F] (pitch ldx in ELEMENTS).  Same row
+ * gather, zero padding to Kp, affine and statistics, every element widened exactly; without an affine the values
+ * pass through bit for bit, i.e. parse-to-bf16 + this gather == parse-to-fp32 + tfr_tower_cast_gather_f32_bf16. */
+int tfr_tower_cast_gather_bf16_bf16(const void* x_bf16, long ldx, int M, int F, int Kp, const float* scale,
+                                    const float* shift, const int* row_index, void* out_bf16, void* stream);
+int tfr_tower_input_stats_bf16(const void* x_bf16, long ldx, int M, int F, const int* row_index, float* partial,
+                               int n_blocks, const float* pivot, void* stream);
 /* fp32 w[R, C] -> bf16 [R, pitch] or (transpose) bf16 [C, pitch]: the per-step operand copy of a
  * Dense kernel (fp32 master weights stay with the optimizer). */
 int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch, void* out_bf16,

@@ -71,6 +71,22 @@ int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengt
                             int32_t n_context, float* example_out, float* context_out,
                             int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads);
 
+/* The same parse with the example features rounded to bfloat16 (round to nearest even, NaN preserved: bit for bit the
+ * rounding of the scorer's input cast, tfr_tower_cast_gather_f32_bf16): example_out_bf16 [B, list_size, sum(widths)]
+ * uint16.  The first hidden layer multiplies bf16 operands anyway; shipping them halves the bytes of the pinned
+ * buffer and of the host link (tfr_tower_cast_gather_bf16_bf16 takes them on the device).  Context features, sizes
+ * and the mask as above.  f32_columns [n_f32_columns] (nullable with 0): columns of the concatenated example
+ * features (labels, real-valued targets) that are ALSO written unrounded to f32_out [B, list_size, n_f32_columns]. */
+int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                 int32_t list_size, const tfr_io_feature_spec* example_specs,
+                                 int32_t n_example, const tfr_io_feature_spec* context_specs,
+                                 int32_t n_context, uint16_t* example_out_bf16, float* context_out,
+                                 int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
+                                 const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out);
+
+/* fp32 -> bfloat16 of n values with that rounding (labels, LibSVM features, any staged array). */
+void tfr_io_f32_to_bf16(const float* src, uint16_t* dst, size_t n);
+
 /* Process-wide totals of tf.Example messages (examples and contexts) decoded so far by tfr_io_parse_elwc_batch: by
  * replaying the previous example's byte structure (identical unmasked bytes: defaults + payload copies) and by the
  * generic protobuf walk.  Observability only -- the two paths return the same rows.  Either pointer may be NULL. */

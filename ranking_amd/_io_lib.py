@@ -32,6 +32,10 @@ _SIGNATURES = {
     'tfr_io_elwc_max_list_size': (ctypes.c_int64, [_P, _P, ctypes.c_int32]),
     'tfr_io_parse_elwc_batch': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _P,
                                                ctypes.c_int32, _P, _P, _P, _P, ctypes.c_int32]),
+    'tfr_io_parse_elwc_batch_bf16': (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _P,
+                                                    ctypes.c_int32, _P, _P, _P, _P, ctypes.c_int32, _P,
+                                                    ctypes.c_int32, _P]),
+    'tfr_io_f32_to_bf16': (None, [_P, _P, ctypes.c_size_t]),
     'tfr_io_parse_counters': (None, [_P, _P]),
     'tfr_io_libsvm_load': (ctypes.c_int64, [_P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
 }

@@ -79,6 +79,10 @@ _SIGNATURES = {
                                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_cast_gather_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                                        + [ctypes.c_void_p] * 5),
+    'tfr_tower_input_stats_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    'tfr_tower_cast_gather_bf16_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
+                                        + [ctypes.c_void_p] * 5),
     'tfr_tower_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                                 + [ctypes.c_void_p] * 4),
     'tfr_tower_weight_cast': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p] * 2),

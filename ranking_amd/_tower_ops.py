@@ -134,9 +134,13 @@ def flatten_row_index(mask: torch.Tensor) -> torch.Tensor:
 def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
               row_index: Optional[torch.Tensor] = None, width: Optional[int] = None):
     """fp32 [R, F] -> bf16 [M, pad8(F)] (zero padded), optional per-column affine; with ``row_index`` (int32 [M])
-    row m of the result is row ``row_index[m]`` of ``x`` (FlattenList's gather fused into the cast)."""
+    row m of the result is row ``row_index[m]`` of ``x`` (FlattenList's gather fused into the cast).  A bfloat16 ``x``
+    (bf16 feature ingest, ``data.parse_from_example_list(example_dtype=torch.bfloat16)``) is gathered and padded as it
+    is: no fp32 copy of the features exists on the device."""
     require_device(x, 'x')
-    x = x.to(torch.float32)
+    from_bf16 = x.dtype == torch.bfloat16
+    if not from_bf16:
+        x = x.to(torch.float32)
     if x.stride(1) != 1:
         x = x.contiguous()
     F = x.shape[1]
@@ -147,9 +151,9 @@ def cast_rows(x: torch.Tensor, scale: Optional[torch.Tensor] = None, shift: Opti
         M = x.shape[0]
     Kp = width if width is not None else pad8(F)
     out = torch.empty((M, Kp), dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().tfr_tower_cast_gather_f32_bf16(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
-                                                          _ptr(row_index), _ptr(out), _stream()),
-               'tfr_tower_cast_gather_f32_bf16')
+    entry = 'tfr_tower_cast_gather_bf16_bf16' if from_bf16 else 'tfr_tower_cast_gather_f32_bf16'
+    _lib.check(getattr(_lib.load(), entry)(_ptr(x), x.stride(0), M, F, Kp, _ptr(scale), _ptr(shift),
+                                           _ptr(row_index), _ptr(out), _stream()), entry)
     return out
 
 
@@ -157,9 +161,12 @@ def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blo
                 pivot: Optional[torch.Tensor] = None):
     """Per-column partial sums [T, 2, F] (sum x, sum x^2) of the fp32 features (rows gathered through
     ``row_index``): the batch statistics of create_tower's input BatchNormalization, in bn_finalize's format.
-    ``pivot`` [F]: sums of ``x - pivot`` (the variance keeps its digits when |mean| >> std; add it back to the mean)."""
+    ``pivot`` [F]: sums of ``x - pivot`` (the variance keeps its digits when |mean| >> std; add it back to the mean).
+    bfloat16 features (bf16 ingest) are read as they are."""
     require_device(x, 'x')
-    x = x.to(torch.float32)
+    from_bf16 = x.dtype == torch.bfloat16
+    if not from_bf16:
+        x = x.to(torch.float32)
     if x.stride(1) != 1:
         x = x.contiguous()
     if row_index is not None:
@@ -172,8 +179,9 @@ def input_stats(x: torch.Tensor, row_index: Optional[torch.Tensor] = None, n_blo
     partial = torch.empty((T, 2, F), dtype=torch.float32, device=x.device)
     if pivot is not None:
         pivot = pivot.to(torch.float32).contiguous()
-    _lib.check(_lib.load().tfr_tower_input_stats_f32(_ptr(x), x.stride(0), M, F, _ptr(row_index), _ptr(partial), T,
-                                                     _ptr(pivot), _stream()), 'tfr_tower_input_stats_f32')
+    entry = 'tfr_tower_input_stats_bf16' if from_bf16 else 'tfr_tower_input_stats_f32'
+    _lib.check(getattr(_lib.load(), entry)(_ptr(x), x.stride(0), M, F, _ptr(row_index), _ptr(partial), T,
+                                           _ptr(pivot), _stream()), entry)
     return partial, M
 
 

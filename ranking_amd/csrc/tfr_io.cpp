@@ -489,28 +489,62 @@ extern "C" void tfr_io_parse_counters(uint64_t* replayed, uint64_t* walked) {
   if (walked) *walked = g_examples_walked.load(std::memory_order_relaxed);
 }
 
-extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
-                                       int32_t list_size, const tfr_io_feature_spec* example_specs,
-                                       int32_t n_example, const tfr_io_feature_spec* context_specs,
-                                       int32_t n_context, float* example_out, float* context_out,
-                                       int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads) {
-  if (B < 0 || list_size <= 0 || n_example <= 0 || !example_specs || !example_out || n_context < 0) return TFR_IO_EINVAL;
+// fp32 -> bf16, round to nearest even; NaN stays NaN (quiet bit set) -- bit for bit what v_cvt_pk_bf16_f32 and
+// torch's .to(bfloat16) produce, so features rounded here equal features rounded by the scorer's input cast.
+static inline uint16_t bf16_rne(uint32_t u) {              // branch-free: the loop below vectorises
+  const uint32_t rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  const uint32_t quiet = (u >> 16) | 0x0040u;
+  return (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? quiet : rounded);
+}
+
+// one clone per vector ISA, picked at load time (the parser's other loops are byte walks: nothing to gain there)
+__attribute__((target_clones("arch=skylake-avx512", "avx2", "default"), optimize("O3")))
+void f32_to_bf16_loop(const uint32_t* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+  for (size_t i = 0; i < n; ++i) dst[i] = bf16_rne(src[i]);
+}
+
+extern "C" void tfr_io_f32_to_bf16(const float* src, uint16_t* dst, size_t n) {
+  f32_to_bf16_loop(reinterpret_cast<const uint32_t*>(src), dst, n);
+}
+
+// The batch parser behind both entry points.  example_bf16 != nullptr: every record is decoded into a per-thread
+// fp32 image of one list (list_size x total width: cache resident) and leaves it rounded to bf16 -- half the bytes
+// for the pinned buffer and the host link; context features stay fp32 (a few values per list).
+static int parse_elwc_batch_impl(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                 int32_t list_size, const tfr_io_feature_spec* example_specs,
+                                 int32_t n_example, const tfr_io_feature_spec* context_specs,
+                                 int32_t n_context, float* example_out, uint16_t* example_bf16, float* context_out,
+                                 int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
+                                 const int32_t* f32_columns = nullptr, int32_t n_f32_columns = 0,
+                                 float* f32_out = nullptr) {
+  if (B < 0 || list_size <= 0 || n_example <= 0 || !example_specs || (!example_out && !example_bf16) || n_context < 0)
+    return TFR_IO_EINVAL;
   if (B > 0 && (!records || !lengths)) return TFR_IO_EINVAL;
   if (n_context > 0 && (!context_specs || !context_out)) return TFR_IO_EINVAL;
   for (int i = 0; i < n_example; ++i) if (!example_specs[i].name || example_specs[i].width < 1) return TFR_IO_EINVAL;
   for (int i = 0; i < n_context; ++i) if (!context_specs[i].name || context_specs[i].width < 1) return TFR_IO_EINVAL;
   const SpecTable ex(example_specs, n_example);
   const SpecTable cx(context_specs, n_context);
+  if (n_f32_columns < 0 || (n_f32_columns > 0 && (!f32_columns || !f32_out || !example_bf16))) return TFR_IO_EINVAL;
+  for (int i = 0; i < n_f32_columns; ++i) if (f32_columns[i] < 0 || f32_columns[i] >= ex.total) return TFR_IO_EINVAL;
   std::atomic<int> err{0};
   auto work = [&](int lo, int hi) {
     Hints hints;
+    const size_t per_list = (size_t)list_size * ex.total;
+    std::vector<float> image(example_bf16 ? per_list : 0);
     for (int b = lo; b < hi && err.load(std::memory_order_relaxed) == 0; ++b) {
-      const int rc = decode_elwc(records[b], (size_t)lengths[b], list_size, ex, n_context ? &cx : nullptr,
-                                 example_out + (size_t)b * list_size * ex.total,
+      float* dst = example_bf16 ? image.data() : example_out + (size_t)b * per_list;
+      const int rc = decode_elwc(records[b], (size_t)lengths[b], list_size, ex, n_context ? &cx : nullptr, dst,
                                  n_context ? context_out + (size_t)b * cx.total : nullptr,
                                  sizes_out ? sizes_out + b : nullptr,
                                  mask_out ? mask_out + (size_t)b * list_size : nullptr, hints);
       if (rc < 0) { int z = 0; err.compare_exchange_strong(z, rc); }
+      else if (example_bf16) {
+        tfr_io_f32_to_bf16(dst, example_bf16 + (size_t)b * per_list, per_list);
+        float* side = f32_out + (size_t)b * list_size * n_f32_columns;        // labels and the like: unrounded
+        for (int i = 0; i < list_size && n_f32_columns > 0; ++i)
+          for (int c = 0; c < n_f32_columns; ++c) side[(size_t)i * n_f32_columns + c] = dst[(size_t)i * ex.total + f32_columns[c]];
+      }
     }
     g_examples_replayed.fetch_add(hints.example_tpl.replayed + hints.context_tpl.replayed, std::memory_order_relaxed);
     g_examples_walked.fetch_add(hints.example_tpl.walked + hints.context_tpl.walked, std::memory_order_relaxed);
@@ -525,6 +559,28 @@ extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint
     for (auto& th : pool) th.join();
   }
   return err.load();
+}
+
+extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                       int32_t list_size, const tfr_io_feature_spec* example_specs,
+                                       int32_t n_example, const tfr_io_feature_spec* context_specs,
+                                       int32_t n_context, float* example_out, float* context_out,
+                                       int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads) {
+  if (!example_out) return TFR_IO_EINVAL;
+  return parse_elwc_batch_impl(records, lengths, B, list_size, example_specs, n_example, context_specs, n_context,
+                               example_out, nullptr, context_out, sizes_out, mask_out, num_threads);
+}
+
+extern "C" int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                            int32_t list_size, const tfr_io_feature_spec* example_specs,
+                                            int32_t n_example, const tfr_io_feature_spec* context_specs,
+                                            int32_t n_context, uint16_t* example_out_bf16, float* context_out,
+                                            int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
+                                            const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out) {
+  if (!example_out_bf16) return TFR_IO_EINVAL;
+  return parse_elwc_batch_impl(records, lengths, B, list_size, example_specs, n_example, context_specs, n_context,
+                               nullptr, example_out_bf16, context_out, sizes_out, mask_out, num_threads, f32_columns,
+                               n_f32_columns, f32_out);
 }
 
 extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t list_size, int32_t num_features,

@@ -1214,8 +1214,13 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 }
 
 // ------------------------------------------------------------------------------------
-// fp32 [M, F] -> bf16 [M, Kp] (zero padded columns), optional per-column affine (input BN).
-__global__ void tower_cast_kernel(const float* __restrict__ x, long ldx, int M, int F, int Kp,
+// fp32 [M, F] -> bf16 [M, Kp] (zero padded columns), optional per-column affine (input BN).  TIn = uint16_t: the
+// features arrive as bf16 already (the host parser's bf16 ingest) -- the same gather, padding and
+// affine, the element widened exactly; without an affine the values pass through bit for bit.
+__device__ __forceinline__ float feat_f32(float v) { return v; }
+__device__ __forceinline__ float feat_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+template <typename TIn>
+__global__ void tower_cast_kernel(const TIn* __restrict__ x, long ldx, int M, int F, int Kp,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                   const int* __restrict__ row_index, uint16_t* __restrict__ out) {
   const long chunks_per_row = Kp / 8;
@@ -1227,7 +1232,7 @@ __global__ void tower_cast_kernel(const float* __restrict__ x, long ldx, int M, 
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = (k + e < F) ? x[ms * ldx + k + e] : 0.f;
+      float t = (k + e < F) ? feat_f32(x[ms * ldx + k + e]) : 0.f;
       if (scale && k + e < F) t = __builtin_fmaf(t, scale[k + e], shift[k + e]);
       v[e] = t;
     }
@@ -2166,7 +2171,8 @@ extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, in
 // input_batch_norm (keras/layers.py:57-60: BatchNormalization on the raw features): per-column partial sums
 // (sum x, sum x^2) of the fp32 input, rows gathered like the cast does; partial[T][2][F] feeds tfr_tower_bn_finalize,
 // whose scale / shift the cast kernel then applies.
-__global__ __launch_bounds__(256) void tower_input_stats_kernel(const float* __restrict__ x, long ldx, int M, int F,
+template <typename TIn>
+__global__ __launch_bounds__(256) void tower_input_stats_kernel(const TIn* __restrict__ x, long ldx, int M, int F,
                                                                 const int* __restrict__ row_index,
                                                                 float* __restrict__ partial, int rows_per_block,
                                                                 const float* __restrict__ pivot) {
@@ -2180,7 +2186,7 @@ __global__ __launch_bounds__(256) void tower_input_stats_kernel(const float* __r
     const float pv = pivot ? pivot[c] : 0.0f;
     for (long m = mb; m < me; ++m) {
       const long ms = row_index ? (long)row_index[m] : m;
-      const float v = x[ms * ldx + c] - pv;
+      const float v = feat_f32(x[ms * ldx + c]) - pv;
       s1 += v; s2 = __builtin_fmaf(v, v, s2);
     }
     partial[((long)blockIdx.x * 2) * F + c] = s1;
@@ -2192,8 +2198,17 @@ extern "C" int tfr_tower_input_stats_f32(const float* x, long ldx, int M, int F,
                                          int n_blocks, const float* pivot, void* stream) {
   if (!x || !partial || M <= 0 || F <= 0 || n_blocks < 1 || ldx < F) return TFR_EINVAL;
   const int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
-  hipLaunchKernelGGL(tower_input_stats_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, F, row_index,
-                     partial, rows, pivot);
+  hipLaunchKernelGGL(tower_input_stats_kernel<float>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, M, F,
+                     row_index, partial, rows, pivot);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_input_stats_bf16(const void* x_bf16, long ldx, int M, int F, const int* row_index,
+                                          float* partial, int n_blocks, const float* pivot, void* stream) {
+  if (!x_bf16 || !partial || M <= 0 || F <= 0 || n_blocks < 1 || ldx < F) return TFR_EINVAL;
+  const int rows = (int)(((long)M + n_blocks - 1) / n_blocks);
+  hipLaunchKernelGGL(tower_input_stats_kernel<uint16_t>, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)x_bf16, ldx, M, F, row_index, partial, rows, pivot);
   return (int)hipGetLastError();
 }
 
@@ -2202,8 +2217,20 @@ extern "C" int tfr_tower_cast_gather_f32_bf16(const float* x, long ldx, int M, i
                                               void* stream) {
   if (!x || !out_bf16 || M < 0 || F <= 0 || Kp < F || (Kp & 7)) return TFR_EINVAL;
   if (M == 0) return TFR_OK;
-  hipLaunchKernelGGL(tower_cast_kernel, dim3(grid_for((long)M * (Kp / 8), 256)), dim3(256), 0,
+  hipLaunchKernelGGL(tower_cast_kernel<float>, dim3(grid_for((long)M * (Kp / 8), 256)), dim3(256), 0,
                      (hipStream_t)stream, x, ldx, M, F, Kp, scale, shift, row_index, (uint16_t*)out_bf16);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_cast_gather_bf16_bf16(const void* x_bf16, long ldx, int M, int F, int Kp, const float* scale,
+                                               const float* shift, const int* row_index, void* out_bf16,
+                                               void* stream) {
+  if (!x_bf16 || !out_bf16 || M < 0 || F <= 0 || Kp < F || (Kp & 7) || ldx < F) return TFR_EINVAL;
+  if ((scale == nullptr) != (shift == nullptr)) return TFR_EINVAL;
+  if (M == 0) return TFR_OK;
+  hipLaunchKernelGGL(tower_cast_kernel<uint16_t>, dim3(grid_for((long)M * (Kp / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint16_t*)x_bf16, ldx, M, F, Kp, scale, shift, row_index,
+                     (uint16_t*)out_bf16);
   return (int)hipGetLastError();
 }
 

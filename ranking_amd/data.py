@@ -106,11 +106,33 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
                             example_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
                             size_feature_name: Optional[str] = None, mask_feature_name: Optional[str] = None,
                             shuffle_examples: bool = False, seed: Optional[int] = None,
-                            num_threads: int = 0) -> Dict[str, torch.Tensor]:
+                            num_threads: int = 0, example_dtype=torch.float32,
+                            float32_features: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
     """data.py:391-540: a batch of serialized ELWC protos -> feature map.  Example features are
-    ``[B, list_size, width]`` (fp32; int64 features are converted), context features ``[B, width]``."""
+    ``[B, list_size, width]`` (fp32; int64 features are converted), context features ``[B, width]``.
+
+    ``example_dtype=torch.bfloat16`` (not in the reference): the example features leave the parser rounded to bfloat16
+    (``tfr_io_parse_elwc_batch_bf16``: round to nearest even, the rounding of the scorer's own input cast) -- half the
+    bytes to pin and to send over the host link, and ``FusedTower`` gathers them as they are
+    (``tfr_tower_cast_gather_bf16_bf16``).  Every example feature must then be a float feature; the ones named in
+    ``float32_features`` (labels, real-valued targets: anything that needs more than bfloat16's 8 significant bits) come
+    back unrounded as float32 from the same pass."""
     if not example_feature_spec:
         raise ValueError('example_feature_spec {} must not be empty.'.format(example_feature_spec))
+    if example_dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError('example_dtype must be torch.float32 or torch.bfloat16, got %r' % (example_dtype,))
+    as_bf16 = example_dtype == torch.bfloat16
+    float32_features = tuple(float32_features)
+    for name in float32_features:
+        if name not in example_feature_spec:
+            raise ValueError('float32_features names %r, which is not an example feature' % name)
+    if as_bf16:
+        for name, spec in example_feature_spec.items():
+            if name in float32_features:
+                continue
+            if spec.dtype not in (None, torch.float32, torch.bfloat16):
+                raise ValueError('example_dtype=bfloat16: feature %r is declared %r; only float features can be '
+                                 'shipped as bfloat16' % (name, spec.dtype))
     lib = _io_lib.load()
     serialized = list(serialized)
     B = len(serialized)
@@ -129,29 +151,55 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
     cx_names, cx_arr, _k2 = _spec_array(context_feature_spec or {})
     ex_w = [_spec_width(example_feature_spec[n]) for n in ex_names]
     cx_w = [_spec_width(context_feature_spec[n]) for n in cx_names]
-    ex_out = np.empty((B, list_size, sum(ex_w)), dtype=np.float32)
+    if as_bf16:
+        ex_t = torch.empty((B, list_size, sum(ex_w)), dtype=torch.bfloat16)
+        ex_ptr = ex_t.data_ptr()
+    else:
+        ex_out = np.empty((B, list_size, sum(ex_w)), dtype=np.float32)
+        ex_ptr = ex_out.ctypes.data
     cx_out = np.empty((B, max(sum(cx_w), 1)), dtype=np.float32)
     sizes = np.zeros(B, dtype=np.int32)
     mask = np.zeros((B, list_size), dtype=np.uint8)
     if num_threads <= 0:
         num_threads = min(16, os.cpu_count() or 1) if B >= 64 else 1
-    _io_lib.check(lib.tfr_io_parse_elwc_batch(
-        ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
-        ex_out.ctypes.data, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
-        num_threads), 'tfr_io_parse_elwc_batch')
-    ex_t = torch.from_numpy(ex_out)
+    if as_bf16:
+        offs = dict(zip(ex_names, np.cumsum([0] + ex_w[:-1]).tolist()))
+        side_cols = [offs[n] + j for n in float32_features for j in range(_spec_width(example_feature_spec[n]))]
+        cols = np.asarray(side_cols, dtype=np.int32)
+        side = np.empty((B, list_size, max(len(side_cols), 1)), dtype=np.float32)
+        _io_lib.check(lib.tfr_io_parse_elwc_batch_bf16(
+            ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
+            ex_ptr, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data, num_threads,
+            cols.ctypes.data if side_cols else None, len(side_cols), side.ctypes.data if side_cols else None),
+            'tfr_io_parse_elwc_batch_bf16')
+        side_t = torch.from_numpy(side)
+    else:
+        _io_lib.check(lib.tfr_io_parse_elwc_batch(
+            ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
+            ex_ptr, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
+            num_threads), 'tfr_io_parse_elwc_batch')
+        ex_t = torch.from_numpy(ex_out)
     if shuffle_examples:
         from . import utils
         is_valid = torch.from_numpy(mask.astype(bool))
         idx = utils.shuffle_valid_indices(is_valid, seed=seed)[:, :out_list_size]
         ex_t = torch.gather(ex_t, 1, idx.unsqueeze(-1).expand(-1, -1, ex_t.shape[2]))
+        if as_bf16:
+            side_t = torch.gather(side_t, 1, idx.unsqueeze(-1).expand(-1, -1, side_t.shape[2]))
         mask = mask[:, :out_list_size]                     # = sequence_mask(sizes, list_size), data.py:206
     features: Dict[str, torch.Tensor] = {}
-    off = 0
+    off = soff = 0
     for name, w in zip(ex_names, ex_w):
         spec = example_feature_spec[name]
-        t = ex_t[:, :, off:off + w]
-        features[name] = t.to(spec.dtype) if spec.dtype not in (None, torch.float32) else t
+        if as_bf16 and name in float32_features:
+            t = side_t[:, :, soff:soff + w]
+            soff += w
+            features[name] = t.to(spec.dtype) if spec.dtype not in (None, torch.float32) else t
+        elif as_bf16:
+            features[name] = ex_t[:, :, off:off + w]
+        else:
+            t = ex_t[:, :, off:off + w]
+            features[name] = t.to(spec.dtype) if spec.dtype not in (None, torch.float32) else t
         off += w
     off = 0
     cx_t = torch.from_numpy(cx_out)
@@ -168,8 +216,9 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
 
 
 def make_parsing_fn(data_format, list_size=None, context_feature_spec=None, example_feature_spec=None,
-                    size_feature_name=None, mask_feature_name=None, shuffle_examples=False, seed=None):
-    """data.py:857-911."""
+                    size_feature_name=None, mask_feature_name=None, shuffle_examples=False, seed=None,
+                    example_dtype=torch.float32, float32_features=()):
+    """data.py:857-911.  ``example_dtype``: see ``parse_from_example_list``."""
     if data_format != ELWC:
         raise ValueError('Format {} is not supported: the native reader covers example_list_with_context '
                          '(SURVEY.md 8f)'.format(data_format))
@@ -178,7 +227,8 @@ def make_parsing_fn(data_format, list_size=None, context_feature_spec=None, exam
         return parse_from_example_list(serialized, list_size=list_size, context_feature_spec=context_feature_spec,
                                        example_feature_spec=example_feature_spec,
                                        size_feature_name=size_feature_name, mask_feature_name=mask_feature_name,
-                                       shuffle_examples=shuffle_examples, seed=seed)
+                                       shuffle_examples=shuffle_examples, seed=seed, example_dtype=example_dtype,
+                                       float32_features=float32_features)
     return _fn
 
 
@@ -385,11 +435,12 @@ def _ranking_batches(file_pattern, parsing_fn, batch_size, num_epochs, shuffle, 
 
 def build_ranking_dataset(file_pattern, data_format, batch_size, context_feature_spec, example_feature_spec,
                           list_size=None, size_feature_name=None, mask_feature_name=None, shuffle_examples=False,
-                          seed=None, **kwargs):
-    """data.py:1020-1068."""
+                          seed=None, example_dtype=torch.float32, float32_features=(), **kwargs):
+    """data.py:1020-1068.  ``example_dtype``: see ``parse_from_example_list``."""
     parsing_fn = make_parsing_fn(data_format, list_size, context_feature_spec, example_feature_spec,
                                  size_feature_name=size_feature_name, mask_feature_name=mask_feature_name,
-                                 shuffle_examples=shuffle_examples, seed=seed)
+                                 shuffle_examples=shuffle_examples, seed=seed, example_dtype=example_dtype,
+                                 float32_features=float32_features)
     return build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, **kwargs)
 
 

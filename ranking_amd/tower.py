@@ -109,10 +109,12 @@ class _TowerFn(torch.autograd.Function):
             in_bn = (in_sc, in_sh)
             ctx.in_stats = (in_mean, in_rstd, x)           # backward: xhat from the fp32 features, not from the bf16 copy
             x0 = T.cast_rows(x, scale=in_sc, shift=in_sh, row_index=row_index, width=T.pad_k(x.shape[1]))
-        elif row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0):
+        elif row_index is not None or not (x.dtype == torch.bfloat16 and x.shape[1] == T.pad_k(x.shape[1])):
+            # fp32 features, bf16-ingested features at their own width (data.parse_from_example_list(example_dtype=
+            # bfloat16)), or a row gather: one launch writes the bf16 operand at the k-step pitch
             x0 = T.cast_rows(x, row_index=row_index, width=T.pad_k(x.shape[1]))
         else:
-            x0 = x
+            x0 = x                                         # already staged (the groupwise gather writes this layout)
         M = x0.shape[0]
         a_in, pro, sc, sh, drop = x0, T.PRO_NONE, None, None, None
         zs, coefs = [], []
@@ -396,8 +398,9 @@ class FusedTower(nn.Module):
         if self.use_batch_norm:
             params += list(self.gammas) + list(self.betas)
         if self.input_batch_norm:
-            if x.dtype != torch.float32 or x.shape[1] != self.input_dim:
-                raise ValueError('input_batch_norm needs the raw fp32 [M, %d] features' % self.input_dim)
+            if x.dtype not in (torch.float32, torch.bfloat16) or x.shape[1] != self.input_dim:
+                raise ValueError('input_batch_norm needs the raw fp32 (or bf16-ingested) [M, %d] features'
+                                 % self.input_dim)
             params += [self.gamma_in, self.beta_in]
         params += [self.out_weight, self.out_bias]
         out = _TowerFn.apply(x, self, self.training, row_index, *params)

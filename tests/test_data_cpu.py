@@ -539,3 +539,107 @@ def test_prefetcher_moves_the_slices_of_one_array_with_one_copy(monkeypatch):
     assert got[0]['a'].untyped_storage().data_ptr() == got[0]['b'].untyped_storage().data_ptr()
     assert torch.equal(got[0]['n'], lone) and torch.equal(got[1], lone) and got[0]['name'] == 'x'
     assert torch.equal(got[0]['tiny'], big[3:5])
+
+
+def test_bf16_rounding_of_the_parser_is_torchs_and_the_devices():
+    """tfr_io_f32_to_bf16: round to nearest even with NaN kept -- bit for bit torch's .to(bfloat16) (and
+    v_cvt_pk_bf16_f32, which the GPU test of the ingest path checks) on ties, subnormals, the overflow to infinity,
+    signed zeros, infinities and NaNs."""
+    lib = _io_lib.load()
+    rng = np.random.RandomState(5)
+    bits = rng.randint(0, 2 ** 32, size=200000, dtype=np.uint64).astype(np.uint32)
+    special = np.asarray([0x00000000, 0x80000000, 0x3f800000, 0x3f808000, 0x3f818000, 0x3f807fff, 0x3f808001,
+                          0x7f7fffff, 0x7f7f8000, 0x7f7f7fff, 0xff7fffff, 0x7f800000, 0xff800000, 0x7fc00000,
+                          0x7f800001, 0xffc12345, 0x00000001, 0x00008000, 0x00018000, 0x007fffff, 0x807fffff],
+                         dtype=np.uint32)
+    src = np.concatenate([bits, special]).view(np.float32)
+    dst = np.empty(src.shape, dtype=np.uint16)
+    lib.tfr_io_f32_to_bf16(src.ctypes.data, dst.ctypes.data, src.size)
+    want = torch.from_numpy(src.copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+    nan = np.isnan(src)
+    assert np.array_equal(dst[~nan], want[~nan])
+    got_nan = dst[nan]
+    assert np.all((got_nan & 0x7f80) == 0x7f80) and np.all((got_nan & 0x007f) != 0)       # still NaN
+    assert np.array_equal(got_nan & 0x8000, (src.view(np.uint32)[nan] >> 16).astype(np.uint16) & 0x8000)
+
+
+def test_bf16_parse_equals_the_rounded_fp32_parse():
+    """example_dtype=bfloat16 (tfr_io_parse_elwc_batch_bf16) == the fp32 parse rounded afterwards, for every path of
+    the parser (template replay and generic walk, packed and unpacked lists, defaults, padding, truncation, threads);
+    float32_features come back unrounded; sizes / mask / context features are untouched."""
+    names, widths, records = _template_batch(3)
+    spec = {n: data.FixedLenFeature([widths[n]], F32, -2.5 if n == 'lab' else 0.1) for n in names if n != 'cnt'}
+    cspec = {'q': data.FixedLenFeature([1], F32, 0.0)}
+    recs = [r for r, _, _ in records]
+    for list_size in (None, 5, 16):
+        for threads in (1, 3):
+            ref = data.parse_from_example_list(recs, list_size=list_size, context_feature_spec=cspec,
+                                               example_feature_spec=spec, size_feature_name='n',
+                                               mask_feature_name='m', num_threads=threads)
+            got = data.parse_from_example_list(recs, list_size=list_size, context_feature_spec=cspec,
+                                               example_feature_spec=spec, size_feature_name='n',
+                                               mask_feature_name='m', num_threads=threads,
+                                               example_dtype=torch.bfloat16, float32_features=('lab',))
+            assert set(got) == set(ref)
+            for k in spec:
+                if k == 'lab':
+                    assert got[k].dtype == torch.float32 and torch.equal(got[k].view(torch.int32), ref[k].view(torch.int32))
+                else:
+                    assert got[k].dtype == torch.bfloat16 and got[k].shape == ref[k].shape
+                    assert torch.equal(got[k].view(torch.int16), ref[k].to(torch.bfloat16).view(torch.int16)), k
+            for k in ('q', 'n', 'm'):
+                assert torch.equal(got[k], ref[k])
+    # all features as bf16 (no side columns), through make_parsing_fn
+    fn = data.make_parsing_fn(data.ELWC, list_size=7, example_feature_spec=spec, example_dtype=torch.bfloat16)
+    ref = data.make_parsing_fn(data.ELWC, list_size=7, example_feature_spec=spec)(recs)
+    got = fn(recs)
+    for k in spec:
+        assert torch.equal(got[k].view(torch.int16), ref[k].to(torch.bfloat16).view(torch.int16))
+
+
+def test_bf16_parse_argument_errors_and_shuffle():
+    names, widths, records = _template_batch(4)
+    recs = [r for r, _, _ in records]
+    spec = {'1': data.FixedLenFeature([1], F32, 0.0), 'cnt': data.FixedLenFeature([1], torch.int64, 0)}
+    with pytest.raises(ValueError, match='only float features'):
+        data.parse_from_example_list(recs, example_feature_spec=spec, example_dtype=torch.bfloat16)
+    with pytest.raises(ValueError, match='not an example feature'):
+        data.parse_from_example_list(recs, example_feature_spec=spec, float32_features=('nope',))
+    with pytest.raises(ValueError, match='example_dtype'):
+        data.parse_from_example_list(recs, example_feature_spec=spec, example_dtype=torch.float16)
+    # an int64 feature may ride along as a float32 side feature
+    got = data.parse_from_example_list(recs, example_feature_spec=spec, example_dtype=torch.bfloat16,
+                                       float32_features=('cnt',))
+    ref = data.parse_from_example_list(recs, example_feature_spec=spec)
+    assert got['cnt'].dtype == torch.int64 and torch.equal(got['cnt'], ref['cnt'])
+    # shuffle_examples permutes the bf16 features and the side features with the same permutation
+    spec2 = {'1': data.FixedLenFeature([1], F32, 0.0), 'lab': data.FixedLenFeature([1], F32, -1.0)}
+    # (the op seed's stream advances from call to call like TF's: compare the PAIRS against the unshuffled parse)
+    a = data.parse_from_example_list(recs, example_feature_spec=spec2, mask_feature_name='m')
+    b = data.parse_from_example_list(recs, list_size=6, example_feature_spec=spec2, shuffle_examples=True, seed=9,
+                                     example_dtype=torch.bfloat16, float32_features=('lab',), mask_feature_name='m')
+    assert b['1'].shape == (len(recs), 6, 1) and b['lab'].shape == (len(recs), 6, 1)
+    moved = 0
+    for r in range(len(recs)):
+        n = int(a['m'][r].sum())
+        pairs = [(a['1'][r, j, 0].to(torch.bfloat16).view(torch.int16).item(), a['lab'][r, j, 0].view(torch.int32).item())
+                 for j in range(n)]
+        for i in range(min(n, 6)):
+            assert b['m'][r, i]
+            pair = (b['1'][r, i, 0].view(torch.int16).item(), b['lab'][r, i, 0].view(torch.int32).item())
+            assert pair in pairs
+            moved += pair != pairs[i]
+    assert moved > 0
+    # the C entry refuses inconsistent side-column arguments
+    lib = _io_lib.load()
+    ex_names, ex_arr, _keep = data._spec_array(spec2)
+    ptrs, lens = data._record_arrays(recs)
+    out = np.empty((len(recs), 4, 2), dtype=np.uint16)
+    cols = np.asarray([5], dtype=np.int32)
+    side = np.empty((len(recs), 4, 1), dtype=np.float32)
+    rc = lib.tfr_io_parse_elwc_batch_bf16(ptrs, lens.ctypes.data, len(recs), 4, ex_arr, 2, None, 0, out.ctypes.data,
+                                          None, None, None, 1, cols.ctypes.data, 1, side.ctypes.data)
+    assert rc == -1
+    rc = lib.tfr_io_parse_elwc_batch_bf16(ptrs, lens.ctypes.data, len(recs), 4, ex_arr, 2, None, 0, None,
+                                          None, None, None, 1, None, 0, None)
+    assert rc == -1

@@ -708,3 +708,77 @@ def test_prefetcher_stages_batches_on_the_gpu_through_a_copy_stream():
         assert y.tolist() == [i, i + 1, i + 2, i + 3]
         seen += 1
     assert seen == 6
+
+
+# ---- bf16 feature ingest (data.parse_from_example_list(example_dtype=bfloat16)) ----
+def test_bf16_ingest_gather_equals_the_fp32_gather():
+    """Features rounded to bf16 on the HOST (libtfr_io.so's tfr_io_f32_to_bf16, what the bf16 parse writes) and gathered by
+    tfr_tower_cast_gather_bf16_bf16 are bit for bit what tfr_tower_cast_gather_f32_bf16 makes of the fp32 features:
+    random bit patterns (ties, subnormals, overflow to infinity, infinities; NaNs stay NaN), FlattenList's row gather,
+    the padding to the k step; with an affine both entry points see the same widened values."""
+    import numpy as np
+    from ranking_amd import _io_lib
+    R, F, M = 700, 136, 1500
+    rng = np.random.RandomState(11)
+    bits = rng.randint(0, 2 ** 32, size=R * F, dtype=np.uint64).astype(np.uint32)
+    bits[:8] = [0x3f808000, 0x3f818000, 0x7f7fffff, 0x7f7f8000, 0x00018000, 0x80000000, 0x7f800000, 0xff800000]
+    src = bits.view(np.float32).reshape(R, F)
+    host = np.empty((R, F), dtype=np.uint16)
+    _io_lib.load().tfr_io_f32_to_bf16(src.ctypes.data, host.ctypes.data, src.size)
+    xb = torch.from_numpy(host.view(np.int16)).view(torch.bfloat16).to(DEV)
+    x = torch.from_numpy(src.copy()).to(DEV)
+    rows = torch.from_numpy(rng.randint(0, R, size=M).astype(np.int32)).to(DEV)
+    ops = T()
+    for ri in (None, rows):
+        for width in (None, ops.pad_k(F)):
+            a = ops.cast_rows(x, row_index=ri, width=width)
+            b = ops.cast_rows(xb, row_index=ri, width=width)
+            assert a.shape == b.shape and b.dtype == torch.bfloat16
+            nan = torch.isnan(a.float())
+            assert torch.equal(nan, torch.isnan(b.float()))
+            assert torch.equal(a.view(torch.int16)[~nan], b.view(torch.int16)[~nan])
+    # finite features with an affine (input BatchNormalization folded into the cast) and the column statistics
+    xf = rnd((R, F), 12, 3.0).to(DEV) + 5.0
+    xfb = xf.to(torch.bfloat16)
+    sc, sh = rnd((F,), 13).to(DEV), rnd((F,), 14).to(DEV)
+    a = ops.cast_rows(xfb.float(), scale=sc, shift=sh, row_index=rows, width=ops.pad_k(F))
+    b = ops.cast_rows(xfb, scale=sc, shift=sh, row_index=rows, width=ops.pad_k(F))
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert torch.equal(ops.cast_rows(xf), xfb)                               # device rounding == torch rounding
+    piv = xfb[0].float()
+    (pa, na), (pb, nb) = ops.input_stats(xfb.float(), row_index=rows, pivot=piv), ops.input_stats(xfb, row_index=rows, pivot=piv)
+    assert na == nb == M and torch.equal(pa, pb)
+    (pa, _), (pb, _) = ops.input_stats(xfb.float()), ops.input_stats(xfb)
+    assert torch.equal(pa, pb)
+
+
+@pytest.mark.parametrize('in_bn', [False, True])
+@pytest.mark.parametrize('gather', [False, True])
+def test_bf16_ingested_features_train_the_tower_like_their_fp32_widening(in_bn, gather):
+    """FusedTower on bf16-ingested [R, 136] features == FusedTower on the same values widened to fp32: logits and every
+    parameter gradient bit for bit (the bf16 path reads the features as they are, no fp32 copy on the device)."""
+    from ranking_amd.tower import FusedTower
+    R, F = 900, 136
+    torch.manual_seed(3)
+    tower = FusedTower(F, [128, 64], 1, activation='relu', use_batch_norm=True, input_batch_norm=in_bn).to(DEV)
+    tower.train()
+    xb = (rnd((R, F), 20, 2.0) + 1.0).to(torch.bfloat16).to(DEV)
+    rows = torch.randint(0, R, (1300,), generator=torch.Generator().manual_seed(4)).to(torch.int32).to(DEV) if gather else None
+    M = 1300 if gather else R
+    up = rnd((M, 1), 21).to(DEV)
+    bufs = {n: b.clone() for n, b in tower.named_buffers()}
+    outs = []
+    for x in (xb.float(), xb):
+        for n, b in tower.named_buffers():
+            b.copy_(bufs[n])
+        tower.zero_grad(set_to_none=True)
+        out = tower(x, row_index=rows)
+        out.backward(up)
+        outs.append((out.detach().clone(), [p.grad.clone() for p in tower.parameters()],
+                     [b.clone() for _, b in tower.named_buffers()]))
+    (o32, g32, b32), (o16, g16, b16) = outs
+    assert torch.equal(o32, o16)
+    for a, b in zip(g32, g16):
+        assert torch.equal(a, b)
+    for a, b in zip(b32, b16):
+        assert torch.equal(a, b)

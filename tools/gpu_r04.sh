@@ -154,6 +154,10 @@ PY
       for v in "TFR_APPROX_INT_LABELS=0" ""; do
         env $v timeout 200 python3 bench.py $H > $OUT/i_$(echo $v | tr ' =' '__').out 2> $OUT/i.err; echo "[$v] rc=$?"; python tools/bench_summary.py $OUT/i_$(echo $v | tr ' =' '__').out | tail -n 1
       done ;;
+    ingest)
+      # bf16 feature ingest: the new tower tests (and the tower suite they sit in), then the host-fed step, fp32 vs bf16 features
+      timeout 400 python -m pytest tests/test_gpu_tower.py -x -q -m gpu > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 6 $OUT/t_tower.log
+      timeout 200 python tools/ingest_bench.py > $OUT/ingest.txt 2> $OUT/ingest.err; echo "ingest bench rc=$?"; cat $OUT/ingest.txt; tail -n 2 $OUT/ingest.err | cut -c1-300 ;;
     final1)
       ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
       tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;

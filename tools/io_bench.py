@@ -1,6 +1,7 @@
 """Host throughput of libtfr_io.so's ELWC parser (no GPU): lists/s and MB/s per thread count.
    Layouts: 'wide'  = one float feature of width 136 per example (packed),
             'scalar' = 136 scalar float features "1".."136" per example (the reference's examples/data layout).
+   Every line twice: fp32 example features, and bf16 features with the label kept fp32 (bf16 ingest).
    usage: python tools/io_bench.py [--lists 256] [--list-size 100]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -45,13 +46,15 @@ def main():
             for k in range(a.features):
                 spec[str(k + 1)] = rd.FixedLenFeature([1], torch.float32, default_value=0.0)
         for th in (1, 2, 4, 8):
-            best = 1e9
-            for _ in range(a.reps):
-                t0 = time.perf_counter()
-                rd.parse_from_example_list(recs, list_size=a.list_size, example_feature_spec=spec, num_threads=th)
-                best = min(best, time.perf_counter() - t0)
-            print('%-6s threads=%d  %8.0f lists/s  %8.1f MB/s  (%d lists, %.1f MB)' % (
-                layout, th, a.lists / best, nbytes / best / 1e6, a.lists, nbytes / 1e6))
+            for tag, kw in (('fp32', {}), ('bf16', {'example_dtype': torch.bfloat16, 'float32_features': ('label',)})):
+                best = 1e9
+                for _ in range(a.reps):
+                    t0 = time.perf_counter()
+                    rd.parse_from_example_list(recs, list_size=a.list_size, example_feature_spec=spec, num_threads=th,
+                                               **kw)
+                    best = min(best, time.perf_counter() - t0)
+                print('%-6s %s threads=%d  %8.0f lists/s  %8.1f MB/s  (%d lists, %.1f MB)' % (
+                    layout, tag, th, a.lists / best, nbytes / best / 1e6, a.lists, nbytes / 1e6))
 
 
 if __name__ == '__main__':
