@@ -213,7 +213,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
                     kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True),
-                    kernel_name='softmax_wave_kernel')
+                    kernel_name='softmax_stream_kernel' if B > 8192 else 'softmax_wave_kernel')
     if workload == 'gumbel_approx_ndcg':
         loss = K.GumbelApproxNDCGLoss(seed=1)
         S = 8

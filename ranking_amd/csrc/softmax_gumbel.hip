@@ -415,6 +415,128 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
   }
 }
 
+// Streaming form of the same kernel for LARGE batches of the plain case (round 4, TFR_SOFTMAX_STREAM: no mask array,
+// no per-item weights (per-list ones: LW), gradient requested, more than 4 * kSmStreamGroups lists): at most kSmStreamGroups workgroups; a
+// wavefront walks the lists w, w + W, w + 2 W, ... with the label / logit loads of its next D lists in flight (a slot
+// is re-loaded as soon as its values are consumed), so that every resident wave has loads in flight while it reduces
+// and a launch of 65 536 lists dispatches 2 048 workgroups instead of 16 384.  gfx950 counts loads AND stores on one in-order counter
+// (vmcnt), so the overlap only exists if the compiler can count the memory operations between a load and its first
+// use: every load and store below is unconditional (out-of-range slots re-read / re-write item 0 of the list with
+// item 0's value; a wave past the end re-reads its last list) -- no branch around a memory instruction.  Same
+// arithmetic, in the same order, as softmax_wave_kernel: bit-identical results (tests/test_gpu_parity.py).
+constexpr int kSmStreamGroups = 2048;               // 8 workgroups of 4 waves per CU
+
+template <int IPL, bool NT, int D, bool LW>
+__global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int B) {
+  const int lane = threadIdx.x & 63;
+  const int W = gridDim.x * 4;
+  int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // (the grid never exceeds the lists: b < B)
+  const int L = a.L;
+  const float inv_t = 1.0f / a.temperature;
+  int off[IPL];
+  bool in[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { const int i = lane + 64 * r; in[r] = i < L; off[r] = in[r] ? i : 0; }
+  // D lists in flight per wave: slot d holds list b + d W (a list past the end re-reads the wave's first one)
+  float lab[D][IPL], x[D][IPL], wl[D];                   // (LW: one weight per list, item_weights[b])
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int bl = (b + d * W < B) ? b + d * W : b;
+    wl[d] = LW ? a.item_weights[bl] : 1.0f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const float* pl = a.labels + (size_t)bl * L + off[r];
+      const float* px = a.logits + (size_t)bl * L + off[r];
+      lab[d][r] = NT ? __builtin_nontemporal_load(pl) : *pl;
+      x[d][r] = NT ? __builtin_nontemporal_load(px) : *px;
+    }
+  }
+  auto one_list = [&](const int d, const int cur, const bool reload) {
+      float z[IPL], y[IPL];
+      bool mv[IPL];
+      float lsum = 0.f, zmax = -INFINITY;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {                      // selects, no branches (see above); x + 0 and max(x, -inf) are x
+        mv[r] = in[r] && lab[d][r] >= 0.0f;
+        z[r] = mv[r] ? x[d][r] * inv_t : (in[r] ? kLogEps10 : -INFINITY);
+        y[r] = mv[r] ? lab[d][r] : 0.0f;
+        if (LW) y[r] *= wl[d];
+        lsum += y[r];
+        zmax = fmaxf(zmax, z[r]);
+      }
+      if (reload) {                                        // the slot is free: the list D W further on
+        const int bl = (cur + D * W < B) ? cur + D * W : cur;
+        if (LW) wl[d] = a.item_weights[bl];
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const float* pl = a.labels + (size_t)bl * L + off[r];
+          const float* px = a.logits + (size_t)bl * L + off[r];
+          lab[d][r] = NT ? __builtin_nontemporal_load(pl) : *pl;
+          x[d][r] = NT ? __builtin_nontemporal_load(px) : *px;
+        }
+      }
+      lsum = wave_sum_u(lsum);
+      zmax = wave_max_u(zmax);
+      const bool nonzero = lsum > 0.0f;
+      float psum = 0.f, esum = 0.f, e[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        float yy = nonzero ? y[r] : 1e-10f;
+        yy = (in[r] && mv[r]) ? yy : 0.0f;
+        y[r] = yy;
+        psum += yy;
+        e[r] = in[r] ? __builtin_amdgcn_exp2f((z[r] - zmax) * 1.44269504088896340736f) : 0.0f;
+        esum += e[r];
+      }
+      psum = wave_sum_u(psum);
+      esum = wave_sum_u(esum);
+      const float lse = logf(esum);
+      const float inv_p = (psum != 0.0f) ? 1.0f / psum : 0.0f;            // divide_no_nan
+      const float inv_e = 1.0f / esum;
+      float loss = 0.f, ptot = 0.f, pt = 0.f;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const float p = y[r] * inv_p;                      // (0 in an out-of-range slot; e is 0 there too)
+        loss += in[r] ? p * (lse - (z[r] - zmax)) : 0.0f;
+        ptot += p;
+        pt += p * (e[r] * inv_e);
+        y[r] = p;
+      }
+      loss = wave_sum_u(loss);
+      ptot = wave_sum_u(ptot);
+      if (a.poly_eps != 0.0f) {
+        pt = wave_sum_u(pt);
+        loss += a.poly_eps * (1.0f - pt);
+      }
+      a.loss[cur] = loss; a.weight[cur] = lsum;            // (every lane, one address, one value)
+      float g[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const float sm = e[r] * inv_e;
+        float dd = ptot * sm - y[r];
+        if (a.poly_eps != 0.0f) dd -= a.poly_eps * sm * (y[r] - pt);
+        g[r] = mv[r] ? (lsum * inv_t) * dd : 0.0f;
+      }
+      const float g_first = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g[0])));
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const float v = in[r] ? g[r] : g_first;            // an out-of-range slot re-writes item 0 with item 0's value
+        float* pd = a.dlogits + (size_t)cur * L + off[r];
+        if (NT) __builtin_nontemporal_store(v, pd); else *pd = v;
+      }
+  };
+  // the main loop has no exit inside its body (all D lists exist): straight-line code, exact vmcnt counts, nothing drains
+  for (; b + (D - 1) * W < B; b += D * W) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) one_list(d, b + d * W, true);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {                          // the last fewer-than-D lists of this wave
+    if (b + d * W >= B) return;
+    one_list(d, b + d * W, false);
+  }
+}
+
 }  // namespace
 
 extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
@@ -457,6 +579,21 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
     hipStream_t st = (hipStream_t)stream;
     static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
     const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
+    static const int env_stream = [] { const char* e = getenv("TFR_SOFTMAX_STREAM"); return (e && *e) ? atoi(e) : 1; }();
+    static const int env_groups = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_GROUPS"); return (e && *e) ? atoi(e) : kSmStreamGroups; }();
+    if (env_stream && !mask && (!item_weights || weights_per_list) && dlogits_out && L <= 256 &&
+        (B + 3) / 4 > env_groups && env_groups >= 1) {
+      static const int env_depth = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_DEPTH"); return (e && *e) ? atoi(e) : 2; }();
+#define SMK(I, N, D, W) hipLaunchKernelGGL((softmax_stream_kernel<I, N, D, W>), dim3(env_groups), dim3(256), 0, st, a, B)
+#define SMS(I, D) do { if (item_weights) { if (nt) SMK(I, true, D, true); else SMK(I, false, D, true); } \
+                       else { if (nt) SMK(I, true, D, false); else SMK(I, false, D, false); } } while (0)
+#define SMD(I) do { if (env_depth >= 4) SMS(I, 4); else if (env_depth >= 2) SMS(I, 2); else SMS(I, 1); } while (0)
+      if (L <= 64) SMD(1); else if (L <= 128) SMD(2); else SMD(4);
+#undef SMD
+#undef SMS
+#undef SMK
+      return (int)hipGetLastError();
+    }
 #define SMW(I) do { if (nt) hipLaunchKernelGGL((softmax_wave_kernel<I, true>), dim3((B + 3) / 4), dim3(256), 0, st, a, B); \
                     else hipLaunchKernelGGL((softmax_wave_kernel<I, false>), dim3((B + 3) / 4), dim3(256), 0, st, a, B); } while (0)
     if (L <= 64) SMW(1); else if (L <= 128) SMW(2); else if (L <= 256) SMW(4); else if (L <= 512) SMW(8); else SMW(16);

@@ -1885,7 +1885,8 @@ def test_lambdarank_fast_path_randomised_against_the_general_kernel(seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('B,L', [(2100, 50), (2049, 200), (8300, 100), (8193, 256), (16384, 200)])
+@pytest.mark.parametrize('B,L', [(2100, 50), (2049, 200), (8300, 100), (8193, 256), (16384, 200), (8193, 37), (9001, 64),
+                                 (20011, 129)])
 @pytest.mark.parametrize('wkind', ['none', 'list', 'item'])
 def test_softmax_large_batches_against_the_c_arbiter(B, L, wkind):
     """Large softmax batches (the sizes bench.py times, ragged tails): every per-list loss, weight and gradient row
@@ -1908,6 +1909,30 @@ def test_softmax_large_batches_against_the_c_arbiter(B, L, wkind):
     l1, w1, g1 = _ops.softmax_loss(d(logits[:n]), d(labels[:n]), None, d(None if w is None else w[:n]), temperature=0.7,
                                    want_grad=True)
     assert torch.equal(loss[:n], l1) and torch.equal(weight[:n], w1) and torch.equal(grad[:n], g1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,L', [(8193, 100), (70001, 100), (12345, 200), (9000, 1), (8500, 65)])
+@pytest.mark.parametrize('eps', [0.0, 1.5])
+@pytest.mark.parametrize('list_weights', [False, True])
+def test_softmax_streaming_kernel_is_the_per_list_kernel(B, L, eps, list_weights):
+    """More than 8192 lists of the plain case take softmax_stream_kernel (a wave walks several lists with the next
+    list's loads in flight; out-of-range slots re-read / re-write item 0): every loss, weight and gradient bit for bit
+    what softmax_wave_kernel gives for the same rows in batches it serves, last wave / last list included."""
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=77 + L)
+    labels[0] = -1.0
+    labels[B - 1] = torch.where(labels[B - 1] >= 0, torch.zeros_like(labels[B - 1]), labels[B - 1])
+    d_logits, d_labels = logits.to(DEV), labels.to(DEV)
+    w = make_weights(B, 1, seed=6).reshape(B).to(DEV) if list_weights else None
+    loss, weight, grad = _ops.softmax_loss(d_logits, d_labels, None, w, temperature=0.5, want_grad=True, poly_epsilon=eps)
+    assert torch.isfinite(loss).all() and torch.isfinite(grad).all()
+    for lo in list(range(0, B, 8000)):
+        hi = min(B, lo + 8000)
+        l1, w1, g1 = _ops.softmax_loss(d_logits[lo:hi].contiguous(), d_labels[lo:hi].contiguous(), None,
+                                       None if w is None else w[lo:hi].contiguous(), temperature=0.5,
+                                       want_grad=True, poly_epsilon=eps)
+        assert torch.equal(loss[lo:hi], l1) and torch.equal(weight[lo:hi], w1) and torch.equal(grad[lo:hi], g1), (lo, hi)
 
 
 def test_metrics_of_lists_without_items_are_zero():

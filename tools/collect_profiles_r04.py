@@ -62,7 +62,7 @@ def main(tag):
     traffic = {}
     for w, sub, B, L, alg in (('approx_ndcg', 'approx_ndcg_wave_kernel', 16384, 200, (12 * 200 + 12) * 16384),
                               ('pairwise_lambda', 'lambdarank_group_kernel', 4096, 200, (12 * 200 + 12) * 4096),
-                              ('softmax_hbm', 'softmax_wave_kernel', 65536, 100, (12 * 100 + 12) * 65536),
+                              ('softmax_hbm', 'softmax_stream_kernel', 65536, 100, (12 * 100 + 12) * 65536),
                               ('ndcg_metric_hbm', 'ndcg_count_wave_kernel', 16384, 200, (8 * 200 + 24) * 16384)):
         f = pmc_mean(os.path.join(R, 'pmc_fetch_%s.txt' % w), sub, 'FETCH_SIZE')
         wr = pmc_mean(os.path.join(R, 'pmc_write_%s.txt' % w), sub, 'WRITE_SIZE')

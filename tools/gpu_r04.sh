@@ -158,6 +158,20 @@ PY
       # bf16 feature ingest: the new tower tests (and the tower suite they sit in), then the host-fed step, fp32 vs bf16 features
       timeout 400 python -m pytest tests/test_gpu_tower.py -x -q -m gpu > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 6 $OUT/t_tower.log
       timeout 200 python tools/ingest_bench.py > $OUT/ingest.txt 2> $OUT/ingest.err; echo "ingest bench rc=$?"; cat $OUT/ingest.txt; tail -n 2 $OUT/ingest.err | cut -c1-300 ;;
+    stream_ab)
+      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
+      for v in "TFR_SOFTMAX_STREAM=0" "TFR_SOFTMAX_STREAM_DEPTH=1" "TFR_SOFTMAX_STREAM_DEPTH=2" "TFR_SOFTMAX_STREAM_DEPTH=4" "TFR_SOFTMAX_STREAM_DEPTH=8"; do
+        env $v timeout 300 python3 bench.py --workload softmax_hbm --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/st_hbm_$(echo $v | tr ' =' '__').out 2> $OUT/st.err; echo "[$v] softmax_hbm rc=$?"; python tools/bench_summary.py $OUT/st_hbm_$(echo $v | tr ' =' '__').out | tail -n 1
+        env $v timeout 300 python3 bench.py --workload softmax --batch 16384 --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/st16k_$(echo $v | tr ' =' '__').out 2> $OUT/st.err; echo "[$v] softmax B=16384 rc=$?"; python tools/bench_summary.py $OUT/st16k_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
+    stream_groups)
+      for v in "TFR_SOFTMAX_STREAM_GROUPS=512" "TFR_SOFTMAX_STREAM_GROUPS=1024" "TFR_SOFTMAX_STREAM_GROUPS=1536" "TFR_SOFTMAX_STREAM_GROUPS=2048" "TFR_SOFTMAX_STREAM_GROUPS=3072" "TFR_SOFTMAX_STREAM_GROUPS=4096"; do
+        env $v timeout 300 python3 bench.py --workload softmax_hbm --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/sg_$(echo $v | tr ' =' '__').out 2> $OUT/sg.err; echo "[$v] softmax_hbm rc=$?"; python tools/bench_summary.py $OUT/sg_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
+    softmax_final)
+      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py tests/test_gpu_e2e_parity.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
+      timeout 300 python -m pytest tests/test_gpu_full_size.py -x -q -m gpu -k "every_bench_workload" > $OUT/t_workloads.log 2>&1; echo "bench workloads test rc=$?"; tail -n 2 $OUT/t_workloads.log
+      timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/smoke.log ;;
     final1)
       ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
       tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;
