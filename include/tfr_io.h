@@ -32,6 +32,12 @@ extern "C" {
 #define TFR_IO_ECRC (-3)
 #define TFR_IO_ESHAPE (-4)
 #define TFR_IO_ETYPE (-5)
+#define TFR_IO_EMISSING (-6)   /* ExampleInExample without its `serialized_context` feature */
+
+/* Record formats of python/data.py:45-47 (the numeric FixedLenFeature subset of each). */
+#define TFR_IO_FORMAT_ELWC 0   /* ExampleListWithContext                                    (data.py:59-96, 383-540)  */
+#define TFR_IO_FORMAT_EIE 1    /* ExampleInExample: serialized_context / serialized_examples (data.py:133-380)         */
+#define TFR_IO_FORMAT_SEQ 2    /* tf.SequenceExample: context + one feature_list per feature (data.py:572-855)         */
 
 int tfr_io_abi_version(void);
 
@@ -83,6 +89,25 @@ int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const uint64_t* 
                                  int32_t n_context, uint16_t* example_out_bf16, float* context_out,
                                  int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
                                  const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out);
+
+/* The batch parser for any of the three record formats: the arguments of tfr_io_parse_elwc_batch /
+ * tfr_io_parse_elwc_batch_bf16 with `format` in front; exactly one of example_out (fp32) and example_out_bf16 is
+ * non-NULL (f32_columns / f32_out only with the latter).  ExampleInExample: examples and context are the serialized
+ * tf.Examples inside the two bytes features of the outer tf.Example; a record without `serialized_context` is
+ * TFR_IO_EMISSING, more than one context TFR_IO_ESHAPE.  SequenceExample: every named example feature is a
+ * FixedLenSequenceFeature(allow_missing=True) of the reference's parser -- a missing feature_list has no frames, a
+ * frame must hold exactly `width` values (an empty frame is TFR_IO_ESHAPE, also among the frames truncation drops),
+ * positions past a feature's own frames take its default, sizes_out = the longest named feature_list. */
+int tfr_io_parse_batch(int32_t format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                       int32_t list_size, const tfr_io_feature_spec* example_specs, int32_t n_example,
+                       const tfr_io_feature_spec* context_specs, int32_t n_context, float* example_out,
+                       uint16_t* example_out_bf16, float* context_out, int32_t* sizes_out, uint8_t* mask_out,
+                       int32_t num_threads, const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out);
+
+/* list_size=None for any format: the largest number of examples (ELWC, EIE) / the longest feature_list among the named
+ * example features (SequenceExample; example_specs is only read for that format) over the records. */
+int64_t tfr_io_max_list_size(int32_t format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                             const tfr_io_feature_spec* example_specs, int32_t n_example);
 
 /* fp32 -> bfloat16 of n values with that rounding (labels, LibSVM features, any staged array). */
 void tfr_io_f32_to_bf16(const float* src, uint16_t* dst, size_t n);

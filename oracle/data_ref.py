@@ -167,6 +167,50 @@ def parse_from_example_list(serialized, list_size, example_spec, context_spec=No
     decoded = [decode_elwc(s) for s in serialized]
     if not list_size:
         list_size = max([len(e) for _, e in decoded] + [1])
+    return _pad_parse(decoded, list_size, example_spec, context_spec)
+
+
+def decode_eie(buf):
+    """ExampleInExample (data.py:136-151): a tf.Example whose bytes feature `serialized_context` holds one serialized
+    tf.Example and whose bytes feature `serialized_examples` holds one per item -> (context dict, [example dicts]).
+    `serialized_context` is a FixedLenFeature([1], string) there: a record without it is an error."""
+    outer = decode_example(buf)
+    ctx = outer.get('serialized_context', ('none', []))
+    if ctx[0] != 'bytes' or len(ctx[1]) != 1:
+        raise ValueError('serialized_context must hold exactly one serialized tf.Example')
+    exs = outer.get('serialized_examples', ('bytes', []))
+    if exs[0] not in ('bytes', 'none'):
+        raise ValueError('serialized_examples must be a bytes_list')
+    return decode_example(bytes(ctx[1][0])), [decode_example(bytes(e)) for e in exs[1]]
+
+
+def decode_seq(buf):
+    """tf.SequenceExample { Features context = 1; FeatureLists feature_lists = 2 } with FeatureLists { map<string,
+    FeatureList> feature_list = 1 }, FeatureList { repeated Feature feature = 1 } -> (context dict, {name: [frames]}),
+    a frame = (kind, values)."""
+    ctx, lists = {}, {}
+    for field, wire, v in _fields(buf):
+        if wire != 2:
+            continue
+        if field == 1:
+            ctx.update(decode_example(_ld(1, bytes(v))))          # Features == the payload of Example.features
+        elif field == 2:
+            for f2, w2, entry in _fields(v):
+                if f2 != 1 or w2 != 2:
+                    continue
+                key, val = None, b''
+                for f3, w3, x in _fields(entry):
+                    if f3 == 1:
+                        key = bytes(x).decode('utf-8')
+                    elif f3 == 2:
+                        val = x
+                if key is None:
+                    continue
+                lists[key] = [decode_feature(x) for f4, w4, x in _fields(val) if f4 == 1 and w4 == 2]
+    return ctx, lists
+
+
+def _pad_parse(decoded, list_size, example_spec, context_spec):
     feats = {k: [] for k in example_spec}
     ctxs = {k: [] for k in (context_spec or {})}
     sizes, mask = [], []
@@ -181,6 +225,56 @@ def parse_from_example_list(serialized, list_size, example_spec, context_spec=No
                     vals = [d] * w
                 assert len(vals) == w, (k, len(vals), w)
                 rows.append([float(x) for x in vals])
+            feats[k].append(rows)
+        for k, (w, d) in (context_spec or {}).items():
+            vals = ctx.get(k, ('none', []))[1]
+            if len(vals) == 0:
+                vals = [d] * w
+            ctxs[k].append([float(x) for x in vals])
+    return feats, ctxs, sizes, mask
+
+
+def parse_from_example_in_example(serialized, list_size, example_spec, context_spec=None):
+    """data.py:133-208, 211-380 for numeric FixedLenFeature specs: same outputs as parse_from_example_list."""
+    decoded = [decode_eie(s) for s in serialized]
+    if not list_size:
+        list_size = max([len(e) for _, e in decoded] + [1])
+    return _pad_parse(decoded, list_size, example_spec, context_spec)
+
+
+def parse_from_sequence_example(serialized, list_size, example_spec, context_spec=None):
+    """data.py:572-710 for numeric FixedLenFeature specs {name: (width, default)}: every named example feature is
+    parsed as a FixedLenSequenceFeature(allow_missing=True) -- a missing feature_list has no frames, a frame must carry
+    exactly `width` values (an empty frame is an error, data_test.py:793-819) -- frames beyond a feature's own count
+    take its default (:620-633, pad_fn :680-684), the list is truncated / padded to list_size (None: the longest
+    feature list of the batch, :636-642), sizes = max over the named features (:701-702)."""
+    decoded = [decode_seq(s) for s in serialized]
+    counts = [[len(lists.get(k, [])) for k in example_spec] for _, lists in decoded]
+    if not list_size:
+        list_size = max([max(c + [0]) for c in counts] + [1])
+    feats = {k: [] for k in example_spec}
+    ctxs = {k: [] for k in (context_spec or {})}
+    sizes, mask = [], []
+    for (ctx, lists), cnt in zip(decoded, counts):
+        n = max(cnt + [0])
+        sizes.append(n)
+        mask.append([i < n for i in range(list_size)])
+        for k, (w, d) in example_spec.items():
+            frames = lists.get(k, [])
+            rows = []
+            for i in range(list_size):
+                if i < len(frames):
+                    kind, vals = frames[i]
+                    if kind == 'bytes' and len(vals):
+                        raise TypeError('feature %s: bytes_list where a numeric frame is expected' % k)
+                    if len(vals) != w:
+                        raise ValueError('feature %s, frame %d: %d values, expected %d' % (k, i, len(vals), w))
+                    rows.append([float(x) for x in vals])
+                else:
+                    rows.append([float(d)] * w)
+            for i in range(list_size, len(frames)):               # (TF validates the frames it truncates as well)
+                if len(frames[i][1]) != w:
+                    raise ValueError('feature %s, frame %d: %d values, expected %d' % (k, i, len(frames[i][1]), w))
             feats[k].append(rows)
         for k, (w, d) in (context_spec or {}).items():
             vals = ctx.get(k, ('none', []))[1]
@@ -237,6 +331,29 @@ def encode_elwc(context, examples, packed=True):
     out = b''.join(_ld(1, encode_example(e, packed)) for e in examples)
     if context is not None:
         out += _ld(2, encode_example(context, packed))
+    return out
+
+
+def encode_eie(context, examples, packed=True):
+    """data_test.py:568-577: the outer tf.Example with the two bytes features."""
+    feats = {'serialized_context': ('bytes', [encode_example(context or {}, packed)]),
+             'serialized_examples': ('bytes', [encode_example(e, packed) for e in examples])}
+    return encode_example(feats, packed)
+
+
+def encode_seq(context, feature_lists, packed=True):
+    """{name: (kind, values)} context + {name: [(kind, values) per frame]} -> serialized tf.SequenceExample.
+    A frame given as None is an empty Feature (no kind set)."""
+    out = b''
+    if context is not None:
+        entries = b''.join(_ld(1, _ld(1, k.encode('utf-8')) + _ld(2, encode_feature(kind, vals, packed)))
+                           for k, (kind, vals) in context.items())
+        out += _ld(1, entries)
+    lists = b''
+    for k, frames in feature_lists.items():
+        fl = b''.join(_ld(1, b'' if fr is None else encode_feature(fr[0], fr[1], packed)) for fr in frames)
+        lists += _ld(1, _ld(1, k.encode('utf-8')) + _ld(2, fl))
+    out += _ld(2, lists)
     return out
 
 

@@ -36,6 +36,9 @@ _SIGNATURES = {
                                                     ctypes.c_int32, _P, _P, _P, _P, ctypes.c_int32, _P,
                                                     ctypes.c_int32, _P]),
     'tfr_io_f32_to_bf16': (None, [_P, _P, ctypes.c_size_t]),
+    'tfr_io_parse_batch': (ctypes.c_int, [ctypes.c_int32, _P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, _P,
+                                          ctypes.c_int32, _P, _P, _P, _P, _P, ctypes.c_int32, _P, ctypes.c_int32, _P]),
+    'tfr_io_max_list_size': (ctypes.c_int64, [ctypes.c_int32, _P, _P, ctypes.c_int32, _P, ctypes.c_int32]),
     'tfr_io_parse_counters': (None, [_P, _P]),
     'tfr_io_libsvm_load': (ctypes.c_int64, [_P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
 }
@@ -43,7 +46,9 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 ERRORS = {-1: 'invalid argument', -2: 'truncated or malformed record / protobuf', -3: 'checksum mismatch',
           -4: 'a feature is present with a length different from its spec',
-          -5: 'a numeric feature spec matched a bytes_list feature'}
+          -5: 'a numeric feature spec matched a bytes_list feature',
+          -6: 'an ExampleInExample record without its serialized_context feature'}
+FORMAT_ELWC, FORMAT_EIE, FORMAT_SEQ = 0, 1, 2
 
 
 class TfrIoError(RuntimeError):
@@ -112,6 +117,6 @@ def check(code: int, what: str) -> int:
     if code >= 0:
         return code
     msg = '%s: %s (code %d)' % (what, ERRORS.get(int(code), 'error'), code)
-    if code in (-1, -4, -5):
+    if code in (-1, -4, -5, -6):
         raise ValueError(msg)
     raise TfrIoError(msg)

@@ -439,6 +439,222 @@ int count_examples(const uint8_t* b, size_t n) {
   return r.ok ? count : TFR_IO_ECORRUPT;
 }
 
+// ---- ExampleInExample (data.py:136-151, 211-380): a tf.Example with two bytes features, `serialized_context` (exactly
+// one serialized tf.Example: FixedLenFeature([1], string) in the reference, a record without it is an error there and
+// TFR_IO_EMISSING here) and `serialized_examples` (one serialized tf.Example per item; "" is an example of defaults).
+// Walks the outer map; `on_context` / `on_example` receive the byte ranges.  Returns 0 or a negative TFR_IO_E*.
+template <typename FC, typename FE>
+int walk_eie(const uint8_t* b, size_t n, FC&& on_context, FE&& on_example) {
+  bool ctx_seen = false;
+  Reader r(b, n);
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    if ((tag >> 3) != 1 || (tag & 7) != 2) { r.skip((uint32_t)(tag & 7)); continue; }
+    const uint8_t* fb; size_t fn;
+    if (!r.bytes(fb, fn)) return TFR_IO_ECORRUPT;
+    Reader f(fb, fn);                                     // Features
+    while (!f.done()) {
+      const uint64_t t2 = f.varint();
+      if (!f.ok) return TFR_IO_ECORRUPT;
+      if ((t2 >> 3) != 1 || (t2 & 7) != 2) { f.skip((uint32_t)(t2 & 7)); continue; }
+      const uint8_t* eb; size_t en;
+      if (!f.bytes(eb, en)) return TFR_IO_ECORRUPT;
+      Reader e(eb, en);                                   // map entry { key = 1; value = 2; }
+      std::string_view key; const uint8_t* vb = nullptr; size_t vn = 0;
+      while (!e.done()) {
+        const uint64_t t3 = e.varint();
+        if (!e.ok) return TFR_IO_ECORRUPT;
+        const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+        if (w3 != 2) { e.skip(w3); continue; }
+        const uint8_t* xb; size_t xn;
+        if (!e.bytes(xb, xn)) return TFR_IO_ECORRUPT;
+        if (f3 == 1) key = std::string_view(reinterpret_cast<const char*>(xb), xn);
+        else if (f3 == 2) { vb = xb; vn = xn; }
+      }
+      if (!e.ok) return TFR_IO_ECORRUPT;
+      const bool is_ctx = key == "serialized_context", is_ex = key == "serialized_examples";
+      if ((!is_ctx && !is_ex) || vb == nullptr) continue;
+      Reader v(vb, vn);                                   // Feature: bytes_list = 1
+      int n_ctx = 0;
+      while (!v.done()) {
+        const uint64_t t4 = v.varint();
+        if (!v.ok) return TFR_IO_ECORRUPT;
+        const uint32_t f4 = (uint32_t)(t4 >> 3), w4 = (uint32_t)(t4 & 7);
+        if (w4 != 2) { v.skip(w4); continue; }
+        const uint8_t* lb; size_t ln;
+        if (!v.bytes(lb, ln)) return TFR_IO_ECORRUPT;
+        if (f4 != 1) { if (ln > 0) return TFR_IO_ETYPE; continue; }       // a float / int64 list under these keys
+        Reader l(lb, ln);                                 // BytesList { repeated bytes value = 1; }
+        while (!l.done()) {
+          const uint64_t t5 = l.varint();
+          if (!l.ok) return TFR_IO_ECORRUPT;
+          if ((t5 >> 3) != 1 || (t5 & 7) != 2) { l.skip((uint32_t)(t5 & 7)); continue; }
+          const uint8_t* sb; size_t sn;
+          if (!l.bytes(sb, sn)) return TFR_IO_ECORRUPT;
+          int rc = 0;
+          if (is_ctx) { if (++n_ctx > 1) return TFR_IO_ESHAPE; ctx_seen = true; rc = on_context(sb, sn); }
+          else rc = on_example(sb, sn);
+          if (rc < 0) return rc;
+        }
+        if (!l.ok) return TFR_IO_ECORRUPT;
+      }
+      if (!v.ok) return TFR_IO_ECORRUPT;
+    }
+    if (!f.ok) return TFR_IO_ECORRUPT;
+  }
+  if (!r.ok) return TFR_IO_ECORRUPT;
+  return ctx_seen ? 0 : TFR_IO_EMISSING;
+}
+
+int decode_eie(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, const SpecTable* ctx,
+               float* example_rows, float* context_row, int32_t* size_out, uint8_t* mask_row, Hints& hints) {
+  int count = 0;
+  if (ctx && context_row) ctx->fill_defaults(context_row);
+  const int rc = walk_eie(
+      b, n,
+      [&](const uint8_t* sb, size_t sn) {
+        return (ctx && context_row) ? decode_example(sb, sn, *ctx, context_row, hints.context, hints.context_tpl) : 0;
+      },
+      [&](const uint8_t* sb, size_t sn) {
+        int r2 = 0;
+        if (count < list_size)
+          r2 = decode_example(sb, sn, ex, example_rows + (size_t)count * ex.total, hints.example, hints.example_tpl);
+        ++count;
+        return r2;
+      });
+  if (rc < 0) return rc;
+  for (int i = std::min(count, list_size); i < list_size; ++i) ex.fill_defaults(example_rows + (size_t)i * ex.total);
+  if (size_out) *size_out = count;
+  if (mask_row)
+    for (int i = 0; i < list_size; ++i) mask_row[i] = i < count ? 1 : 0;
+  return 0;
+}
+
+int count_eie(const uint8_t* b, size_t n) {
+  int count = 0;
+  const int rc = walk_eie(b, n, [](const uint8_t*, size_t) { return 0; }, [&](const uint8_t*, size_t) { ++count; return 0; });
+  return rc < 0 ? rc : count;
+}
+
+// ---- tf.SequenceExample (data.py:572-710): { Features context = 1; FeatureLists feature_lists = 2; },
+// FeatureLists { map<string, FeatureList> feature_list = 1; }, FeatureList { repeated Feature feature = 1; }.
+// Every named example feature is a FixedLenSequenceFeature(allow_missing=True) there: a missing feature_list has no
+// frames; frame t of feature k is example t's value of k and must carry exactly `width` values (an empty frame is an
+// error, data_test.py:793-819) -- also in the frames the truncation drops; positions past a feature's own frames take
+// its default; sizes = the longest named feature list.  `frames_out` (nullable): only count (the list-size query).
+int decode_seq(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, const SpecTable* ctx,
+               float* example_rows, float* context_row, int32_t* size_out, uint8_t* mask_row, Hints& hints,
+               bool count_only) {
+  int longest = 0;
+  if (!count_only) {
+    for (int i = 0; i < list_size; ++i) ex.fill_defaults(example_rows + (size_t)i * ex.total);
+    if (ctx && context_row) ctx->fill_defaults(context_row);
+  }
+  std::vector<float> scratch;
+  std::vector<int> frames_of(ex.width.size(), -1);        // a repeated map key: the later entry wins (protobuf maps)
+  Reader r(b, n);
+  while (!r.done()) {
+    const uint64_t tag = r.varint();
+    if (!r.ok) return TFR_IO_ECORRUPT;
+    const uint32_t field = (uint32_t)(tag >> 3), wire = (uint32_t)(tag & 7);
+    if (wire != 2 || (field != 1 && field != 2)) { r.skip(wire); continue; }
+    const uint8_t* pb; size_t pn;
+    if (!r.bytes(pb, pn)) return TFR_IO_ECORRUPT;
+    if (field == 1) {                                     // context: a Features message = the payload of Example.features
+      if (count_only || !ctx || !context_row) continue;
+      // decode_example expects Example { features = 1 }: walk the Features payload with the same entry decoder by
+      // re-framing is a copy; instead parse the map entries here (contexts are a handful of values per list)
+      Reader f(pb, pn);
+      size_t pos = 0;
+      while (!f.done()) {
+        const uint64_t t2 = f.varint();
+        if (!f.ok) return TFR_IO_ECORRUPT;
+        if ((t2 >> 3) != 1 || (t2 & 7) != 2) { f.skip((uint32_t)(t2 & 7)); continue; }
+        const uint8_t* eb; size_t en;
+        if (!f.bytes(eb, en)) return TFR_IO_ECORRUPT;
+        Reader e(eb, en);
+        std::string_view key; const uint8_t* vb = nullptr; size_t vn = 0;
+        while (!e.done()) {
+          const uint64_t t3 = e.varint();
+          if (!e.ok) return TFR_IO_ECORRUPT;
+          const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+          if (w3 != 2) { e.skip(w3); continue; }
+          const uint8_t* xb; size_t xn;
+          if (!e.bytes(xb, xn)) return TFR_IO_ECORRUPT;
+          if (f3 == 1) key = std::string_view(reinterpret_cast<const char*>(xb), xn);
+          else if (f3 == 2) { vb = xb; vn = xn; }
+        }
+        if (!e.ok) return TFR_IO_ECORRUPT;
+        const int s = ctx->lookup(key, pos++, hints.context);
+        if (s < 0 || vb == nullptr) continue;
+        int payload_at = -1;
+        const int rc = decode_feature(vb, vn, ctx->width[s], context_row + ctx->offset[s], &payload_at);
+        if (rc < 0) return rc;
+        if (rc == 1)
+          for (int k = 0; k < ctx->width[s]; ++k) context_row[ctx->offset[s] + k] = ctx->dflt[s];
+      }
+      if (!f.ok) return TFR_IO_ECORRUPT;
+      continue;
+    }
+    Reader fl(pb, pn);                                    // FeatureLists
+    size_t pos = 0;
+    while (!fl.done()) {
+      const uint64_t t2 = fl.varint();
+      if (!fl.ok) return TFR_IO_ECORRUPT;
+      if ((t2 >> 3) != 1 || (t2 & 7) != 2) { fl.skip((uint32_t)(t2 & 7)); continue; }
+      const uint8_t* eb; size_t en;
+      if (!fl.bytes(eb, en)) return TFR_IO_ECORRUPT;
+      Reader e(eb, en);                                   // map entry { key = 1; FeatureList value = 2; }
+      std::string_view key; const uint8_t* vb = nullptr; size_t vn = 0;
+      while (!e.done()) {
+        const uint64_t t3 = e.varint();
+        if (!e.ok) return TFR_IO_ECORRUPT;
+        const uint32_t f3 = (uint32_t)(t3 >> 3), w3 = (uint32_t)(t3 & 7);
+        if (w3 != 2) { e.skip(w3); continue; }
+        const uint8_t* xb; size_t xn;
+        if (!e.bytes(xb, xn)) return TFR_IO_ECORRUPT;
+        if (f3 == 1) key = std::string_view(reinterpret_cast<const char*>(xb), xn);
+        else if (f3 == 2) { vb = xb; vn = xn; }
+      }
+      if (!e.ok) return TFR_IO_ECORRUPT;
+      const int s = ex.lookup(key, pos++, hints.example);
+      if (s < 0) continue;
+      const int w = ex.width[s];
+      if ((int)scratch.size() < w) scratch.resize(w);
+      if (frames_of[s] >= 0 && !count_only)
+        for (int i = 0; i < list_size; ++i)
+          for (int k = 0; k < w; ++k) example_rows[(size_t)i * ex.total + ex.offset[s] + k] = ex.dflt[s];
+      int frame = 0;
+      Reader v(vb, vn);                                   // FeatureList { repeated Feature feature = 1; }
+      while (vb != nullptr && !v.done()) {
+        const uint64_t t4 = v.varint();
+        if (!v.ok) return TFR_IO_ECORRUPT;
+        if ((t4 >> 3) != 1 || (t4 & 7) != 2) { v.skip((uint32_t)(t4 & 7)); continue; }
+        const uint8_t* xb; size_t xn;
+        if (!v.bytes(xb, xn)) return TFR_IO_ECORRUPT;
+        if (!count_only) {
+          float* dst = frame < list_size ? example_rows + (size_t)frame * ex.total + ex.offset[s] : scratch.data();
+          int payload_at = -1;
+          const int rc = decode_feature(xb, xn, w, dst, &payload_at);
+          if (rc < 0) return rc;
+          if (rc == 1) return TFR_IO_ESHAPE;              // an empty frame: "values size: 0 but output shape: [w]"
+        }
+        ++frame;
+      }
+      if (vb != nullptr && !v.ok) return TFR_IO_ECORRUPT;
+      frames_of[s] = frame;
+    }
+    if (!fl.ok) return TFR_IO_ECORRUPT;
+  }
+  if (!r.ok) return TFR_IO_ECORRUPT;
+  for (int c : frames_of) longest = std::max(longest, c);
+  if (size_out) *size_out = longest;
+  if (mask_row && !count_only)
+    for (int i = 0; i < list_size; ++i) mask_row[i] = i < longest ? 1 : 0;
+  return count_only ? longest : 0;
+}
+
 }  // namespace
 
 extern "C" int tfr_io_abi_version(void) { return 1; }
@@ -510,7 +726,7 @@ extern "C" void tfr_io_f32_to_bf16(const float* src, uint16_t* dst, size_t n) {
 // The batch parser behind both entry points.  example_bf16 != nullptr: every record is decoded into a per-thread
 // fp32 image of one list (list_size x total width: cache resident) and leaves it rounded to bf16 -- half the bytes
 // for the pinned buffer and the host link; context features stay fp32 (a few values per list).
-static int parse_elwc_batch_impl(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+static int parse_batch_impl(int format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
                                  int32_t list_size, const tfr_io_feature_spec* example_specs,
                                  int32_t n_example, const tfr_io_feature_spec* context_specs,
                                  int32_t n_context, float* example_out, uint16_t* example_bf16, float* context_out,
@@ -519,6 +735,7 @@ static int parse_elwc_batch_impl(const uint8_t* const* records, const uint64_t* 
                                  float* f32_out = nullptr) {
   if (B < 0 || list_size <= 0 || n_example <= 0 || !example_specs || (!example_out && !example_bf16) || n_context < 0)
     return TFR_IO_EINVAL;
+  if (format != TFR_IO_FORMAT_ELWC && format != TFR_IO_FORMAT_EIE && format != TFR_IO_FORMAT_SEQ) return TFR_IO_EINVAL;
   if (B > 0 && (!records || !lengths)) return TFR_IO_EINVAL;
   if (n_context > 0 && (!context_specs || !context_out)) return TFR_IO_EINVAL;
   for (int i = 0; i < n_example; ++i) if (!example_specs[i].name || example_specs[i].width < 1) return TFR_IO_EINVAL;
@@ -534,10 +751,14 @@ static int parse_elwc_batch_impl(const uint8_t* const* records, const uint64_t* 
     std::vector<float> image(example_bf16 ? per_list : 0);
     for (int b = lo; b < hi && err.load(std::memory_order_relaxed) == 0; ++b) {
       float* dst = example_bf16 ? image.data() : example_out + (size_t)b * per_list;
-      const int rc = decode_elwc(records[b], (size_t)lengths[b], list_size, ex, n_context ? &cx : nullptr, dst,
-                                 n_context ? context_out + (size_t)b * cx.total : nullptr,
-                                 sizes_out ? sizes_out + b : nullptr,
-                                 mask_out ? mask_out + (size_t)b * list_size : nullptr, hints);
+      float* crow = n_context ? context_out + (size_t)b * cx.total : nullptr;
+      int32_t* srow = sizes_out ? sizes_out + b : nullptr;
+      uint8_t* mrow = mask_out ? mask_out + (size_t)b * list_size : nullptr;
+      const SpecTable* cxp = n_context ? &cx : nullptr;
+      const uint8_t* rec = records[b]; const size_t len = (size_t)lengths[b];
+      const int rc = format == TFR_IO_FORMAT_ELWC ? decode_elwc(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
+                   : format == TFR_IO_FORMAT_EIE  ? decode_eie(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
+                                                  : decode_seq(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints, false);
       if (rc < 0) { int z = 0; err.compare_exchange_strong(z, rc); }
       else if (example_bf16) {
         tfr_io_f32_to_bf16(dst, example_bf16 + (size_t)b * per_list, per_list);
@@ -567,8 +788,8 @@ extern "C" int tfr_io_parse_elwc_batch(const uint8_t* const* records, const uint
                                        int32_t n_context, float* example_out, float* context_out,
                                        int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads) {
   if (!example_out) return TFR_IO_EINVAL;
-  return parse_elwc_batch_impl(records, lengths, B, list_size, example_specs, n_example, context_specs, n_context,
-                               example_out, nullptr, context_out, sizes_out, mask_out, num_threads);
+  return parse_batch_impl(TFR_IO_FORMAT_ELWC, records, lengths, B, list_size, example_specs, n_example, context_specs,
+                          n_context, example_out, nullptr, context_out, sizes_out, mask_out, num_threads);
 }
 
 extern "C" int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const uint64_t* lengths, int32_t B,
@@ -578,9 +799,49 @@ extern "C" int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const
                                             int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
                                             const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out) {
   if (!example_out_bf16) return TFR_IO_EINVAL;
-  return parse_elwc_batch_impl(records, lengths, B, list_size, example_specs, n_example, context_specs, n_context,
-                               nullptr, example_out_bf16, context_out, sizes_out, mask_out, num_threads, f32_columns,
-                               n_f32_columns, f32_out);
+  return parse_batch_impl(TFR_IO_FORMAT_ELWC, records, lengths, B, list_size, example_specs, n_example, context_specs,
+                          n_context, nullptr, example_out_bf16, context_out, sizes_out, mask_out, num_threads, f32_columns,
+                          n_f32_columns, f32_out);
+}
+
+extern "C" int tfr_io_parse_batch(int32_t format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                  int32_t list_size, const tfr_io_feature_spec* example_specs, int32_t n_example,
+                                  const tfr_io_feature_spec* context_specs, int32_t n_context, float* example_out,
+                                  uint16_t* example_out_bf16, float* context_out, int32_t* sizes_out, uint8_t* mask_out,
+                                  int32_t num_threads, const int32_t* f32_columns, int32_t n_f32_columns,
+                                  float* f32_out) {
+  if ((example_out == nullptr) == (example_out_bf16 == nullptr)) return TFR_IO_EINVAL;    // exactly one of the two
+  return parse_batch_impl(format, records, lengths, B, list_size, example_specs, n_example, context_specs, n_context,
+                          example_out, example_out_bf16, context_out, sizes_out, mask_out, num_threads, f32_columns,
+                          n_f32_columns, f32_out);
+}
+
+extern "C" int64_t tfr_io_max_list_size(int32_t format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
+                                        const tfr_io_feature_spec* example_specs, int32_t n_example) {
+  if (B < 0 || (B > 0 && (!records || !lengths))) return TFR_IO_EINVAL;
+  if (format == TFR_IO_FORMAT_ELWC) return tfr_io_elwc_max_list_size(records, lengths, B);
+  if (format != TFR_IO_FORMAT_EIE && format != TFR_IO_FORMAT_SEQ) return TFR_IO_EINVAL;
+  if (format == TFR_IO_FORMAT_SEQ) {
+    if (n_example <= 0 || !example_specs) return TFR_IO_EINVAL;
+    for (int i = 0; i < n_example; ++i) if (!example_specs[i].name || example_specs[i].width < 1) return TFR_IO_EINVAL;
+  }
+  int64_t best = 0;
+  if (format == TFR_IO_FORMAT_EIE) {
+    for (int b = 0; b < B; ++b) {
+      const int c = count_eie(records[b], (size_t)lengths[b]);
+      if (c < 0) return c;
+      best = std::max<int64_t>(best, c);
+    }
+    return best;
+  }
+  const SpecTable ex(example_specs, n_example);
+  Hints hints;
+  for (int b = 0; b < B; ++b) {
+    const int c = decode_seq(records[b], (size_t)lengths[b], 0, ex, nullptr, nullptr, nullptr, nullptr, nullptr, hints, true);
+    if (c < 0) return c;
+    best = std::max<int64_t>(best, c);
+  }
+  return best;
 }
 
 extern "C" int64_t tfr_io_libsvm_load(const char* text, size_t nbytes, int32_t list_size, int32_t num_features,

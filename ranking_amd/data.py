@@ -1,11 +1,13 @@
 """Input side of the ranking path: mirror of the numeric-feature subset of
 ``tensorflow_ranking/python/data.py`` and of the LibSVM loader in
 ``examples/tf_ranking_libsvm.py:137-195`` on top of the native ``libtfr_io.so``
-(include/tfr_io.h): TFRecord framing with CRC-32C, ``ExampleListWithContext`` decoding,
-truncation / padding to ``list_size``, list sizes and mask.
+(include/tfr_io.h): TFRecord framing with CRC-32C, ``ExampleListWithContext`` /
+``ExampleInExample`` / ``tf.SequenceExample`` decoding, truncation / padding to ``list_size``,
+list sizes and mask.
 
 Same entry-point names and keyword arguments as the reference where they exist
-(``parse_from_example_list``, ``make_parsing_fn``, ``build_ranking_dataset``,
+(``parse_from_example_list``, ``parse_from_example_in_example``, ``parse_from_sequence_example``,
+``make_parsing_fn``, ``build_ranking_dataset``,
 ``build_ranking_dataset_with_parsing_fn``); feature specs are ``FixedLenFeature`` objects
 (numeric, with a default value).  Tensors are returned on the host (pin + copy to the GPU is
 the caller's choice); ``shuffle_examples`` permutes the valid examples of each list like
@@ -108,7 +110,54 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
                             shuffle_examples: bool = False, seed: Optional[int] = None,
                             num_threads: int = 0, example_dtype=torch.float32,
                             float32_features: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
-    """data.py:391-540: a batch of serialized ELWC protos -> feature map.  Example features are
+    """data.py:391-540: a batch of serialized ELWC protos -> feature map (see ``_parse_batch``)."""
+    return _parse_batch(_io_lib.FORMAT_ELWC, serialized, list_size, context_feature_spec, example_feature_spec,
+                        size_feature_name, mask_feature_name, shuffle_examples, seed, num_threads, example_dtype,
+                        float32_features)
+
+
+def parse_from_example_in_example(serialized: Sequence[bytes], list_size: Optional[int] = None,
+                                  context_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                                  example_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                                  size_feature_name: Optional[str] = None, mask_feature_name: Optional[str] = None,
+                                  shuffle_examples: bool = False, seed: Optional[int] = None,
+                                  num_threads: int = 0, example_dtype=torch.float32,
+                                  float32_features: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+    """data.py:211-380: a batch of serialized ExampleInExample protos -- a tf.Example whose bytes features
+    ``serialized_context`` / ``serialized_examples`` hold the context and the per-item tf.Examples -- -> feature map,
+    with the truncation / padding / sizes / mask / shuffle semantics of the ELWC parser (same parser class in the
+    reference, data.py:133-208, 383-388)."""
+    return _parse_batch(_io_lib.FORMAT_EIE, serialized, list_size, context_feature_spec, example_feature_spec,
+                        size_feature_name, mask_feature_name, shuffle_examples, seed, num_threads, example_dtype,
+                        float32_features)
+
+
+def parse_from_sequence_example(serialized: Sequence[bytes], list_size: Optional[int] = None,
+                                context_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                                example_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                                size_feature_name: Optional[str] = None, mask_feature_name: Optional[str] = None,
+                                shuffle_examples: bool = False, seed: Optional[int] = None,
+                                num_threads: int = 0, example_dtype=torch.float32,
+                                float32_features: Sequence[str] = ()) -> Dict[str, torch.Tensor]:
+    """data.py:713-855 (parser :572-710): a batch of serialized tf.SequenceExample protos -> feature map.  Frame t of
+    feature_list k is item t's value of example feature k; a missing feature_list has no frames, positions past a
+    feature's own frames take its default value, ``list_size=None`` pads to the longest feature_list of the batch, the
+    list size of a record is its longest named feature_list.  ``shuffle_examples`` raises like the reference
+    (:577-579)."""
+    if shuffle_examples:
+        raise ValueError('Shuffling examples is not supported in SequenceExample format.')
+    return _parse_batch(_io_lib.FORMAT_SEQ, serialized, list_size, context_feature_spec, example_feature_spec,
+                        size_feature_name, mask_feature_name, False, seed, num_threads, example_dtype,
+                        float32_features)
+
+
+def _parse_batch(fmt: int, serialized: Sequence[bytes], list_size: Optional[int],
+                 context_feature_spec: Optional[Dict[str, FixedLenFeature]],
+                 example_feature_spec: Optional[Dict[str, FixedLenFeature]],
+                 size_feature_name: Optional[str], mask_feature_name: Optional[str],
+                 shuffle_examples: bool, seed: Optional[int], num_threads: int, example_dtype,
+                 float32_features: Sequence[str]) -> Dict[str, torch.Tensor]:
+    """One batch through ``libtfr_io.so``'s ``tfr_io_parse_batch``.  Example features are
     ``[B, list_size, width]`` (fp32; int64 features are converted), context features ``[B, width]``.
 
     ``example_dtype=torch.bfloat16`` (not in the reference): the example features leave the parser rounded to bfloat16
@@ -138,17 +187,17 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
     B = len(serialized)
     ptrs, lens = _record_arrays(serialized)
     out_list_size = list_size
+    ex_names, ex_arr, _k1 = _spec_array(example_feature_spec)
+    cx_names, cx_arr, _k2 = _spec_array(context_feature_spec or {})
     if list_size is None or list_size <= 0 or shuffle_examples:
-        cur = max(1, int(_io_lib.check(lib.tfr_io_elwc_max_list_size(ptrs, lens.ctypes.data, B),
-                                       'tfr_io_elwc_max_list_size')))
+        cur = max(1, int(_io_lib.check(lib.tfr_io_max_list_size(fmt, ptrs, lens.ctypes.data, B, ex_arr, len(ex_names)),
+                                       'tfr_io_max_list_size')))
         if list_size is None or list_size <= 0:
             list_size = out_list_size = cur
         else:
             # data.py:164-182: the shuffle runs over ALL examples of the batch's longest list and the truncation to
             # list_size comes after it (a truncated list is a random sample, not the first list_size examples)
             list_size = max(cur, list_size)
-    ex_names, ex_arr, _k1 = _spec_array(example_feature_spec)
-    cx_names, cx_arr, _k2 = _spec_array(context_feature_spec or {})
     ex_w = [_spec_width(example_feature_spec[n]) for n in ex_names]
     cx_w = [_spec_width(context_feature_spec[n]) for n in cx_names]
     if as_bf16:
@@ -167,17 +216,17 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
         side_cols = [offs[n] + j for n in float32_features for j in range(_spec_width(example_feature_spec[n]))]
         cols = np.asarray(side_cols, dtype=np.int32)
         side = np.empty((B, list_size, max(len(side_cols), 1)), dtype=np.float32)
-        _io_lib.check(lib.tfr_io_parse_elwc_batch_bf16(
-            ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
-            ex_ptr, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data, num_threads,
-            cols.ctypes.data if side_cols else None, len(side_cols), side.ctypes.data if side_cols else None),
-            'tfr_io_parse_elwc_batch_bf16')
+        _io_lib.check(lib.tfr_io_parse_batch(
+            fmt, ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None,
+            len(cx_names), None, ex_ptr, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
+            num_threads, cols.ctypes.data if side_cols else None, len(side_cols),
+            side.ctypes.data if side_cols else None), 'tfr_io_parse_batch')
         side_t = torch.from_numpy(side)
     else:
-        _io_lib.check(lib.tfr_io_parse_elwc_batch(
-            ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None, len(cx_names),
-            ex_ptr, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
-            num_threads), 'tfr_io_parse_elwc_batch')
+        _io_lib.check(lib.tfr_io_parse_batch(
+            fmt, ptrs, lens.ctypes.data, B, list_size, ex_arr, len(ex_names), cx_arr if cx_names else None,
+            len(cx_names), ex_ptr, None, cx_out.ctypes.data if cx_names else None, sizes.ctypes.data, mask.ctypes.data,
+            num_threads, None, 0, None), 'tfr_io_parse_batch')
         ex_t = torch.from_numpy(ex_out)
     if shuffle_examples:
         from . import utils
@@ -218,13 +267,15 @@ def parse_from_example_list(serialized: Sequence[bytes], list_size: Optional[int
 def make_parsing_fn(data_format, list_size=None, context_feature_spec=None, example_feature_spec=None,
                     size_feature_name=None, mask_feature_name=None, shuffle_examples=False, seed=None,
                     example_dtype=torch.float32, float32_features=()):
-    """data.py:857-911.  ``example_dtype``: see ``parse_from_example_list``."""
-    if data_format != ELWC:
-        raise ValueError('Format {} is not supported: the native reader covers example_list_with_context '
-                         '(SURVEY.md 8f)'.format(data_format))
+    """data.py:857-911: ``example_list_with_context``, ``example_in_example`` or ``sequence_example``.
+    ``example_dtype`` / ``float32_features``: see ``_parse_batch``."""
+    parsers = {ELWC: parse_from_example_list, EIE: parse_from_example_in_example, SEQ: parse_from_sequence_example}
+    if data_format not in parsers:
+        raise ValueError('Format {} is not supported.'.format(data_format))
+    parse = parsers[data_format]
 
     def _fn(serialized):
-        return parse_from_example_list(serialized, list_size=list_size, context_feature_spec=context_feature_spec,
+        return parse(serialized, list_size=list_size, context_feature_spec=context_feature_spec,
                                        example_feature_spec=example_feature_spec,
                                        size_feature_name=size_feature_name, mask_feature_name=mask_feature_name,
                                        shuffle_examples=shuffle_examples, seed=seed, example_dtype=example_dtype,

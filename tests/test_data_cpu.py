@@ -148,7 +148,7 @@ def test_synthetic_elwc_all_encodings(tmp_path):
     with pytest.raises(_io_lib.TfrIoError):                   # truncated protobuf
         data.parse_from_example_list([records[1][:-2]], list_size=4, example_feature_spec=ex_spec)
     with pytest.raises(ValueError):
-        data.make_parsing_fn('sequence_example', example_feature_spec=ex_spec)
+        data.make_parsing_fn('tf_example_in_a_trenchcoat', example_feature_spec=ex_spec)      # data.py:911
 
 
 def test_shuffle_examples_permutes_only_valid_items():
@@ -643,3 +643,142 @@ def test_bf16_parse_argument_errors_and_shuffle():
     rc = lib.tfr_io_parse_elwc_batch_bf16(ptrs, lens.ctypes.data, len(recs), 4, ex_arr, 2, None, 0, None,
                                           None, None, None, 1, None, 0, None)
     assert rc == -1
+
+
+def _random_lists(seed, n_lists=24):
+    """Per list: a context and 0..9 examples over features a[1] float, b[3] float, c[1] int64, lab[1] float -- with
+    missing features, features the spec does not name and bytes features to skip."""
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(n_lists):
+        exs = []
+        for _ in range(int(rng.randint(0, 10))):
+            e = {}
+            if rng.rand() < 0.9:
+                e['a'] = ('float', [float(np.float32(rng.randn()))])
+            if rng.rand() < 0.9:
+                e['b'] = ('float', [float(np.float32(v)) for v in rng.randn(3)])
+            if rng.rand() < 0.8:
+                e['c'] = ('int64', [int(rng.randint(-5, 1000))])
+            e['lab'] = ('float', [float(rng.randint(0, 5))])
+            if rng.rand() < 0.3:
+                e['tok'] = ('bytes', [b'x' * int(rng.randint(0, 5)), b'yz'])
+            if rng.rand() < 0.3:
+                e['other'] = ('float', [1.0, 2.0])
+            exs.append(e)
+        ctx = {'q': ('float', [float(np.float32(rng.randn()))])} if rng.rand() < 0.8 else {}
+        if rng.rand() < 0.5:
+            ctx['n'] = ('int64', [int(rng.randint(0, 50))])
+        out.append((ctx, exs))
+    return out
+
+
+_RSPEC = {'a': (1, 0.5), 'b': (3, -2.0), 'c': (1, 7.0), 'lab': (1, -1.0)}
+_RCTX = {'q': (1, 0.25), 'n': (1, -3.0)}
+
+
+def _product_spec(spec):
+    return {k: data.FixedLenFeature([w], torch.int64 if k in ('c', 'n') else F32, d) for k, (w, d) in spec.items()}
+
+
+@pytest.mark.parametrize('fmt', ['eie', 'seq'])
+def test_eie_and_seq_parsers_equal_the_oracle_on_random_lists(fmt):
+    """tfr_io_parse_batch(EIE / SEQ) == the pure-Python restatement (oracle/data_ref.py) on random lists: packed and
+    unpacked encodings, missing / unnamed / bytes features, int64 values, padding, truncation, dynamic list size, one
+    and several threads, fp32 and bf16 example features; sizes, mask and context features included."""
+    lists = _random_lists(17 if fmt == 'eie' else 18)
+    ex_spec, cx_spec = _product_spec(_RSPEC), _product_spec(_RCTX)
+    for packed in (True, False):
+        if fmt == 'eie':
+            recs = [D.encode_eie(ctx, exs, packed) for ctx, exs in lists]
+            oracle_fn, product_fn = D.parse_from_example_in_example, data.parse_from_example_in_example
+        else:
+            recs = []
+            for ctx, exs in lists:                                # a SequenceExample: every feature_list as long as ITS values go
+                fl = {}
+                for name in ('a', 'b', 'c', 'lab', 'tok', 'other'):
+                    frames = []
+                    for e in exs:
+                        if name not in e:
+                            break                                 # (a feature_list has no holes: stop at the first gap)
+                        frames.append(e[name])
+                    if frames or name == 'lab':
+                        fl[name] = frames
+                recs.append(D.encode_seq(ctx if ctx else None, fl, packed))
+            oracle_fn, product_fn = D.parse_from_sequence_example, data.parse_from_sequence_example
+        for list_size in (None, 4, 12):
+            feats, ctxs, sizes, mask = oracle_fn(recs, list_size, _RSPEC, _RCTX)
+            for threads in (1, 3):
+                got = product_fn(recs, list_size=list_size, context_feature_spec=cx_spec, example_feature_spec=ex_spec,
+                                 size_feature_name='n_items', mask_feature_name='m', num_threads=threads)
+                for k in _RSPEC:
+                    assert got[k].tolist() == feats[k], (fmt, packed, list_size, k)
+                for k in _RCTX:
+                    assert got[k].tolist() == ctxs[k], (fmt, packed, list_size, k)
+                assert got['n_items'].tolist() == sizes and got['m'].tolist() == mask
+            fspec = {k: v for k, v in ex_spec.items() if k != 'c'}
+            ref = product_fn(recs, list_size=list_size, example_feature_spec=fspec)
+            b16 = product_fn(recs, list_size=list_size, example_feature_spec=fspec, example_dtype=torch.bfloat16,
+                             float32_features=('lab',))
+            assert torch.equal(b16['lab'], ref['lab'])
+            for k in ('a', 'b'):
+                assert torch.equal(b16[k].view(torch.int16), ref[k].to(torch.bfloat16).view(torch.int16))
+
+
+def test_eie_and_seq_error_behaviour():
+    lists = _random_lists(19, n_lists=6)
+    ex_spec = _product_spec(_RSPEC)
+    eie = [D.encode_eie(ctx, exs) for ctx, exs in lists]
+    # truncated protobufs -> TfrIoError (corrupt), never a crash
+    for cut in (1, 3, 7, 20):
+        for rec in eie:
+            if len(rec) > cut:
+                try:
+                    data.parse_from_example_in_example([rec[:-cut]], list_size=4, example_feature_spec=ex_spec)
+                except (_io_lib.TfrIoError, ValueError):
+                    pass
+    # an ExampleInExample without its context feature (FixedLenFeature([1], string) in the reference: required)
+    no_ctx = D.encode_example({'serialized_examples': ('bytes', [D.encode_example({'a': ('float', [1.0])})])})
+    with pytest.raises(ValueError, match='serialized_context'):
+        data.parse_from_example_in_example([no_ctx], list_size=2, example_feature_spec=ex_spec)
+    with pytest.raises(ValueError):
+        D.parse_from_example_in_example([no_ctx], 2, _RSPEC)
+    two_ctx = D.encode_example({'serialized_context': ('bytes', [b'', b'']), 'serialized_examples': ('bytes', [])})
+    with pytest.raises(ValueError):
+        data.parse_from_example_in_example([two_ctx], list_size=2, example_feature_spec=ex_spec)
+    # an empty serialized example is an example of defaults and counts towards the list size
+    rec = D.encode_eie({}, [{}, {'a': ('float', [2.0])}])
+    got = data.parse_from_example_in_example([rec], example_feature_spec=ex_spec, size_feature_name='n')
+    assert got['n'].tolist() == [2] and got['a'].tolist() == [[[0.5], [2.0]]] and got['lab'].tolist() == [[[-1.0], [-1.0]]]
+    # SequenceExample: a frame of the wrong width, a bytes frame under a numeric spec, a repeated key (later entry wins)
+    bad = D.encode_seq(None, {'b': [('float', [1.0, 2.0, 3.0]), ('float', [1.0])]})
+    with pytest.raises(ValueError, match='length different'):
+        data.parse_from_sequence_example([bad], example_feature_spec=ex_spec)
+    bad = D.encode_seq(None, {'a': [('bytes', [b'zz'])]})
+    with pytest.raises(ValueError, match='bytes_list'):
+        data.parse_from_sequence_example([bad], example_feature_spec=ex_spec)
+    first = D.encode_seq(None, {'a': [('float', [1.0]), ('float', [2.0]), ('float', [3.0])]})
+    second = D.encode_seq(None, {'a': [('float', [9.0])]})
+    dup = first + second                                          # concatenated messages merge: feature_lists twice
+    got = data.parse_from_sequence_example([dup], list_size=3, example_feature_spec={'a': ex_spec['a']},
+                                           size_feature_name='n')
+    feats, _, sizes, _ = D.parse_from_sequence_example([dup], 3, {'a': _RSPEC['a']})
+    assert got['a'].tolist() == feats['a'] == [[[9.0], [0.5], [0.5]]] and got['n'].tolist() == sizes == [1]
+    for cut in (1, 2, 5, 9):
+        try:
+            data.parse_from_sequence_example([first[:-cut]], list_size=3, example_feature_spec={'a': ex_spec['a']})
+        except (_io_lib.TfrIoError, ValueError):
+            pass
+    # the C entry validates its arguments
+    lib = _io_lib.load()
+    ex_names, ex_arr, _keep = data._spec_array(ex_spec)
+    ptrs, lens = data._record_arrays(eie)
+    out = np.empty((len(eie), 2, 6), dtype=np.float32)
+    args = (ptrs, lens.ctypes.data, len(eie), 2, ex_arr, len(ex_names), None, 0)
+    assert lib.tfr_io_parse_batch(7, *args, out.ctypes.data, None, None, None, None, 1, None, 0, None) == -1
+    assert lib.tfr_io_parse_batch(1, *args, None, None, None, None, None, 1, None, 0, None) == -1
+    assert lib.tfr_io_parse_batch(1, *args, out.ctypes.data, out.ctypes.data, None, None, None, 1, None, 0, None) == -1
+    assert lib.tfr_io_parse_batch(1, *args, out.ctypes.data, None, None, None, None, 1, None, 0, None) == 0
+    assert lib.tfr_io_max_list_size(9, ptrs, lens.ctypes.data, len(eie), None, 0) == -1
+    assert lib.tfr_io_max_list_size(2, ptrs, lens.ctypes.data, len(eie), None, 0) == -1
+    assert lib.tfr_io_max_list_size(1, ptrs, lens.ctypes.data, len(eie), None, 0) == max(len(e) for _, e in lists)

@@ -7,6 +7,11 @@
     and static shapes that `parse_from_example_list` must produce;
   * `examples/tf_ranking_libsvm.py:137-195` -- the LibSVM loader, hand-evaluated on a 7-line file.
 
+  * `python/data_test.py:568-577, 581-643` -- ExampleInExample: the same context / examples wrapped by
+    `_example_in_example`, the same expectations;
+  * `python/data_test.py:192-220, 716-848` -- SEQ_EXAMPLE_PROTO_1 / _2 and what `parse_from_sequence_example` makes of
+    them (values, sizes, mask, large / small list_size, the missing-frame error, a missing feature_list).
+
 Both the oracle (oracle/data_ref.py) and the product (libtfr_io.so through ranking_amd.data) are held to the same
 literals.  The string feature "unigrams" (a VarLenFeature -> SparseTensor in the reference) is outside the numeric
 subset this repository parses; it is present in the protos so that the parsers have to skip it correctly."""
@@ -186,3 +191,148 @@ def test_libsvm_loader_hand_evaluated(tmp_path):
     p.write_text(LIBSVM_TEXT)
     got_f, got_l = data.load_libsvm_data(str(p), 3, num_features=3)
     assert (got_f.numpy() == want_feats).all() and (got_l.numpy() == want_labels).all()
+
+
+# ---------------------------------------------------------------- ExampleInExample (data_test.py:568-643)
+CONTEXT_1 = {'query_length': ('int64', [3])}                     # data_test.py:95-103
+EXAMPLES_1 = [{'unigrams': ('bytes', [b'tensorflow']), 'utility': ('float', [0.0])},             # :105-132
+              {'unigrams': ('bytes', [b'learning', b'to', b'rank']), 'utility': ('float', [1.0])}]
+CONTEXT_2 = {'query_length': ('int64', [2])}                     # :134-141
+EXAMPLES_2 = [{'unigrams': ('bytes', [b'gbdt']), 'utility': ('float', [0.0])}]                  # :143-154
+EIE_SERIALIZED = [D.encode_eie(CONTEXT_1, EXAMPLES_1), D.encode_eie(CONTEXT_2, EXAMPLES_2)]
+
+
+def _eie(list_size=None, **kw):
+    feats, ctxs, sizes, mask = D.parse_from_example_in_example(EIE_SERIALIZED, list_size, {'utility': (1, -1.0)},
+                                                               {'query_length': (1, 0)})
+    oracle = {'utility': feats['utility'], 'query_length': ctxs['query_length'], _SIZE: sizes, _MASK: mask}
+    got = data.parse_from_example_in_example(EIE_SERIALIZED, list_size=list_size,
+                                             context_feature_spec=CONTEXT_FEATURE_SPEC,
+                                             example_feature_spec=EXAMPLE_FEATURE_SPEC, size_feature_name=_SIZE,
+                                             mask_feature_name=_MASK, **kw)
+    return oracle, {k: v.tolist() for k, v in got.items()}, got
+
+
+def test_parse_from_example_in_example():
+    """data_test.py:581-599."""
+    oracle, product, got = _eie()
+    assert product['query_length'] == [[3], [2]] and got['query_length'].dtype == I64
+    assert product['utility'] == [[[0.], [1.0]], [[0.], [-1.]]]
+    assert oracle['utility'] == product['utility'] and oracle['query_length'] == [[3.0], [2.0]]
+
+
+def test_parse_example_in_example_with_sizes():
+    """data_test.py:628-643."""
+    oracle, product, _ = _eie(list_size=3)
+    assert product[_SIZE] == [2, 1] == oracle[_SIZE]
+    assert product[_MASK] == [[True, True, False], [True, False, False]] == oracle[_MASK]
+    assert product['utility'] == [[[0.], [1.], [-1.]], [[0.], [-1.], [-1.]]] == oracle['utility']
+
+
+def test_parse_from_example_in_example_shuffle():
+    """data_test.py:601-626: list_size=1 with shuffle_examples keeps ONE of the two examples of list 1 (which one is
+    the TF random stream's business: SURVEY 8c) and the only example of list 2."""
+    seen = set()
+    for seed in range(8):
+        got = data.parse_from_example_in_example(EIE_SERIALIZED, list_size=1, context_feature_spec=CONTEXT_FEATURE_SPEC,
+                                                 example_feature_spec=EXAMPLE_FEATURE_SPEC, shuffle_examples=True,
+                                                 seed=seed)
+        assert tuple(got['utility'].shape) == (2, 1, 1) and got['query_length'].tolist() == [[3], [2]]
+        assert got['utility'][1].tolist() == [[0.]]
+        assert got['utility'][0].tolist() in ([[0.]], [[1.]])
+        seen.add(got['utility'][0, 0, 0].item())
+    assert seen == {0.0, 1.0}                                  # both outcomes occur over the seeds
+
+
+def test_make_parsing_fn_eie_and_seq():
+    """data_test.py:935-974."""
+    fn = data.make_parsing_fn(data.EIE, context_feature_spec=CONTEXT_FEATURE_SPEC,
+                              example_feature_spec=EXAMPLE_FEATURE_SPEC)
+    got = fn(EIE_SERIALIZED)
+    assert got['query_length'].tolist() == [[3], [2]] and got['utility'].tolist() == [[[0.], [1.0]], [[0.], [-1.]]]
+    fn = data.make_parsing_fn(data.SEQ, context_feature_spec=CONTEXT_FEATURE_SPEC,
+                              example_feature_spec=EXAMPLE_FEATURE_SPEC)
+    got = fn(SEQ_SERIALIZED)
+    assert got['query_length'].tolist() == [[3], [2]] and got['utility'].tolist() == [[[0.], [1.0]], [[0.], [-1.]]]
+    import pytest
+    with pytest.raises(ValueError, match='Format non_existing is not supported.'):             # data_test.py:976-980
+        data.make_parsing_fn('non_existing', example_feature_spec=EXAMPLE_FEATURE_SPEC)
+
+
+# ---------------------------------------------------------------- SequenceExample (data_test.py:192-220, 716-848)
+SEQ_EXAMPLE_PROTO_1 = D.encode_seq(
+    {'query_length': ('int64', [3])},
+    {'unigrams': [('bytes', [b'tensorflow']), ('bytes', [b'learning', b'to', b'rank'])],
+     'utility': [('float', [0.0]), ('float', [1.0])]})
+SEQ_EXAMPLE_PROTO_2 = D.encode_seq(
+    {'query_length': ('int64', [2])},
+    {'unigrams': [('bytes', [b'gbdt'])], 'utility': [('float', [0.0])]})
+SEQ_SERIALIZED = [SEQ_EXAMPLE_PROTO_1, SEQ_EXAMPLE_PROTO_2]
+
+
+def _seq(serialized, list_size=None, ctx=True):
+    feats, ctxs, sizes, mask = D.parse_from_sequence_example(serialized, list_size, {'utility': (1, -1.0)},
+                                                             {'query_length': (1, 0)} if ctx else None)
+    oracle = {'utility': feats['utility'], _SIZE: sizes, _MASK: mask}
+    got = data.parse_from_sequence_example(serialized, list_size=list_size,
+                                           context_feature_spec=CONTEXT_FEATURE_SPEC if ctx else None,
+                                           example_feature_spec=EXAMPLE_FEATURE_SPEC, size_feature_name=_SIZE,
+                                           mask_feature_name=_MASK)
+    product = {k: v.tolist() for k, v in got.items()}
+    for k in oracle:
+        assert oracle[k] == product[k], k
+    return product, got
+
+
+def test_parse_from_sequence_example():
+    """data_test.py:718-751: values, static shapes, sizes, mask."""
+    product, got = _seq(SEQ_SERIALIZED)
+    assert product['query_length'] == [[3], [2]]
+    assert product['utility'] == [[[0.], [1.]], [[0.], [-1.]]]
+    assert tuple(got['query_length'].shape) == (2, 1) and tuple(got['utility'].shape) == (2, 2, 1)
+    assert product[_SIZE] == [2, 1] and product[_MASK] == [[True, True], [True, False]]
+
+
+def test_parse_from_sequence_example_with_large_and_small_list_size():
+    """data_test.py:753-791."""
+    product, got = _seq([SEQ_EXAMPLE_PROTO_1], list_size=3)
+    assert product['query_length'] == [[3]] and product['utility'] == [[[0.], [1.], [-1.]]]
+    assert tuple(got['utility'].shape) == (1, 3, 1)
+    product, got = _seq([SEQ_EXAMPLE_PROTO_1], list_size=1)
+    assert product['query_length'] == [[3]] and product['utility'] == [[[0.]]]
+    assert tuple(got['utility'].shape) == (1, 1, 1) and product[_SIZE] == [2]
+
+
+def test_parse_from_sequence_example_missing_frame_exception():
+    """data_test.py:793-819: `feature { }` inside a feature_list is an error ("values size: 0 but output shape: [1]")."""
+    import pytest
+    missing_frame = D.encode_seq(None, {'utility': [('float', [0.0]), None]})
+    with pytest.raises(ValueError):
+        D.parse_from_sequence_example([missing_frame], 2, {'utility': (1, -1.0)})
+    with pytest.raises(ValueError, match='length different from its spec'):       # (tf.errors.InvalidArgumentError there)
+        data.parse_from_sequence_example([missing_frame], list_size=2, example_feature_spec=EXAMPLE_FEATURE_SPEC)
+    with pytest.raises(ValueError):                            # also when the bad frame is one the truncation drops
+        data.parse_from_sequence_example([missing_frame], list_size=1, example_feature_spec=EXAMPLE_FEATURE_SPEC)
+
+
+def test_parse_from_sequence_example_missing_feature_list():
+    """data_test.py:821-848: a spec'd feature without a feature_list is all defaults; the dynamic list size is the
+    longest list among the NAMED features."""
+    proto = D.encode_seq(None, {'utility2': [('float', [0.0])]})
+    got = data.parse_from_sequence_example([proto], list_size=2, example_feature_spec=EXAMPLE_FEATURE_SPEC)
+    assert tuple(got['utility'].shape) == (1, 2, 1) and got['utility'].tolist() == [[[-1.], [-1.]]]
+    spec2 = dict(EXAMPLE_FEATURE_SPEC, utility2=EXAMPLE_FEATURE_SPEC['utility'])
+    got0 = data.parse_from_sequence_example([proto], example_feature_spec=spec2, size_feature_name=_SIZE)
+    assert tuple(got0['utility'].shape) == (1, 1, 1) and got0['utility'].tolist() == [[[-1.]]]
+    assert got0['utility2'].tolist() == [[[0.]]] and got0[_SIZE].tolist() == [1]
+    # nothing named is present: the reference pads to max(bounding shapes) = 0 frames; here the list is one default row
+    got1 = data.parse_from_sequence_example([proto], example_feature_spec=EXAMPLE_FEATURE_SPEC, size_feature_name=_SIZE)
+    assert got1[_SIZE].tolist() == [0] and got1['utility'].tolist() == [[[-1.]]]
+
+
+def test_sequence_example_refuses_shuffle():
+    """data.py:577-579."""
+    import pytest
+    with pytest.raises(ValueError, match='Shuffling examples is not supported in SequenceExample format.'):
+        data.parse_from_sequence_example(SEQ_SERIALIZED, example_feature_spec=EXAMPLE_FEATURE_SPEC,
+                                         shuffle_examples=True)
