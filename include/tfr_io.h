@@ -38,6 +38,7 @@ extern "C" {
 #define TFR_IO_FORMAT_ELWC 0   /* ExampleListWithContext                                    (data.py:59-96, 383-540)  */
 #define TFR_IO_FORMAT_EIE 1    /* ExampleInExample: serialized_context / serialized_examples (data.py:133-380)         */
 #define TFR_IO_FORMAT_SEQ 2    /* tf.SequenceExample: context + one feature_list per feature (data.py:572-855)         */
+#define TFR_IO_FORMAT_EXAMPLE 3 /* one tf.Example = a list of ONE item carrying its context features too (data.py:1348-1395) */
 
 int tfr_io_abi_version(void);
 
@@ -90,14 +91,16 @@ int tfr_io_parse_elwc_batch_bf16(const uint8_t* const* records, const uint64_t* 
                                  int32_t* sizes_out, uint8_t* mask_out, int32_t num_threads,
                                  const int32_t* f32_columns, int32_t n_f32_columns, float* f32_out);
 
-/* The batch parser for any of the three record formats: the arguments of tfr_io_parse_elwc_batch /
+/* The batch parser for any of the record formats above: the arguments of tfr_io_parse_elwc_batch /
  * tfr_io_parse_elwc_batch_bf16 with `format` in front; exactly one of example_out (fp32) and example_out_bf16 is
  * non-NULL (f32_columns / f32_out only with the latter).  ExampleInExample: examples and context are the serialized
  * tf.Examples inside the two bytes features of the outer tf.Example; a record without `serialized_context` is
  * TFR_IO_EMISSING, more than one context TFR_IO_ESHAPE.  SequenceExample: every named example feature is a
  * FixedLenSequenceFeature(allow_missing=True) of the reference's parser -- a missing feature_list has no frames, a
  * frame must hold exactly `width` values (an empty frame is TFR_IO_ESHAPE, also among the frames truncation drops),
- * positions past a feature's own frames take its default, sizes_out = the longest named feature_list. */
+ * positions past a feature's own frames take its default, sizes_out = the longest named feature_list.
+ * TFR_IO_FORMAT_EXAMPLE: example AND context features are looked up in the one tf.Example; size 1, rows past the first
+ * are defaults. */
 int tfr_io_parse_batch(int32_t format, const uint8_t* const* records, const uint64_t* lengths, int32_t B,
                        int32_t list_size, const tfr_io_feature_spec* example_specs, int32_t n_example,
                        const tfr_io_feature_spec* context_specs, int32_t n_context, float* example_out,

@@ -48,7 +48,7 @@ ERRORS = {-1: 'invalid argument', -2: 'truncated or malformed record / protobuf'
           -4: 'a feature is present with a length different from its spec',
           -5: 'a numeric feature spec matched a bytes_list feature',
           -6: 'an ExampleInExample record without its serialized_context feature'}
-FORMAT_ELWC, FORMAT_EIE, FORMAT_SEQ = 0, 1, 2
+FORMAT_ELWC, FORMAT_EIE, FORMAT_SEQ, FORMAT_EXAMPLE = 0, 1, 2, 3
 
 
 class TfrIoError(RuntimeError):

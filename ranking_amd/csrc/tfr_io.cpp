@@ -735,7 +735,9 @@ static int parse_batch_impl(int format, const uint8_t* const* records, const uin
                                  float* f32_out = nullptr) {
   if (B < 0 || list_size <= 0 || n_example <= 0 || !example_specs || (!example_out && !example_bf16) || n_context < 0)
     return TFR_IO_EINVAL;
-  if (format != TFR_IO_FORMAT_ELWC && format != TFR_IO_FORMAT_EIE && format != TFR_IO_FORMAT_SEQ) return TFR_IO_EINVAL;
+  if (format != TFR_IO_FORMAT_ELWC && format != TFR_IO_FORMAT_EIE && format != TFR_IO_FORMAT_SEQ &&
+      format != TFR_IO_FORMAT_EXAMPLE)
+    return TFR_IO_EINVAL;
   if (B > 0 && (!records || !lengths)) return TFR_IO_EINVAL;
   if (n_context > 0 && (!context_specs || !context_out)) return TFR_IO_EINVAL;
   for (int i = 0; i < n_example; ++i) if (!example_specs[i].name || example_specs[i].width < 1) return TFR_IO_EINVAL;
@@ -756,9 +758,19 @@ static int parse_batch_impl(int format, const uint8_t* const* records, const uin
       uint8_t* mrow = mask_out ? mask_out + (size_t)b * list_size : nullptr;
       const SpecTable* cxp = n_context ? &cx : nullptr;
       const uint8_t* rec = records[b]; const size_t len = (size_t)lengths[b];
-      const int rc = format == TFR_IO_FORMAT_ELWC ? decode_elwc(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
-                   : format == TFR_IO_FORMAT_EIE  ? decode_eie(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
-                                                  : decode_seq(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints, false);
+      int rc;
+      if (format == TFR_IO_FORMAT_EXAMPLE) {
+        // one tf.Example = one list of one item that also carries the context features (data.py:1348-1395)
+        rc = decode_example(rec, len, ex, dst, hints.example, hints.example_tpl);
+        if (rc >= 0 && cxp && crow) rc = decode_example(rec, len, *cxp, crow, hints.context, hints.context_tpl);
+        for (int i = 1; i < list_size; ++i) ex.fill_defaults(dst + (size_t)i * ex.total);
+        if (srow) *srow = 1;
+        if (mrow) for (int i = 0; i < list_size; ++i) mrow[i] = i < 1 ? 1 : 0;
+      } else {
+        rc = format == TFR_IO_FORMAT_ELWC ? decode_elwc(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
+           : format == TFR_IO_FORMAT_EIE  ? decode_eie(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints)
+                                          : decode_seq(rec, len, list_size, ex, cxp, dst, crow, srow, mrow, hints, false);
+      }
       if (rc < 0) { int z = 0; err.compare_exchange_strong(z, rc); }
       else if (example_bf16) {
         tfr_io_f32_to_bf16(dst, example_bf16 + (size_t)b * per_list, per_list);
@@ -820,6 +832,7 @@ extern "C" int64_t tfr_io_max_list_size(int32_t format, const uint8_t* const* re
                                         const tfr_io_feature_spec* example_specs, int32_t n_example) {
   if (B < 0 || (B > 0 && (!records || !lengths))) return TFR_IO_EINVAL;
   if (format == TFR_IO_FORMAT_ELWC) return tfr_io_elwc_max_list_size(records, lengths, B);
+  if (format == TFR_IO_FORMAT_EXAMPLE) return B > 0 ? 1 : 0;
   if (format != TFR_IO_FORMAT_EIE && format != TFR_IO_FORMAT_SEQ) return TFR_IO_EINVAL;
   if (format == TFR_IO_FORMAT_SEQ) {
     if (n_example <= 0 || !example_specs) return TFR_IO_EINVAL;

@@ -151,6 +151,21 @@ def parse_from_sequence_example(serialized: Sequence[bytes], list_size: Optional
                         float32_features)
 
 
+def parse_from_tf_example(serialized: Sequence[bytes],
+                          context_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                          example_feature_spec: Optional[Dict[str, FixedLenFeature]] = None,
+                          size_feature_name: Optional[str] = None, mask_feature_name: Optional[str] = None,
+                          num_threads: int = 0) -> Dict[str, torch.Tensor]:
+    """data.py:1348-1395: a batch of serialized ``tf.train.Example`` protos, each ONE item together with its context
+    features (the serving signature of a ranking model) -> context features ``[B, width]``, example features
+    ``[B, 1, width]``, sizes ``[B]`` of ones (float32 like ``tf.ones``), mask ``[B, 1]`` of True."""
+    features = _parse_batch(_io_lib.FORMAT_EXAMPLE, serialized, 1, context_feature_spec, example_feature_spec,
+                            size_feature_name, mask_feature_name, False, None, num_threads, torch.float32, ())
+    if size_feature_name:
+        features[size_feature_name] = features[size_feature_name].to(torch.float32)
+    return features
+
+
 def _parse_batch(fmt: int, serialized: Sequence[bytes], list_size: Optional[int],
                  context_feature_spec: Optional[Dict[str, FixedLenFeature]],
                  example_feature_spec: Optional[Dict[str, FixedLenFeature]],

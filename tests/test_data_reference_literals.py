@@ -336,3 +336,20 @@ def test_sequence_example_refuses_shuffle():
     with pytest.raises(ValueError, match='Shuffling examples is not supported in SequenceExample format.'):
         data.parse_from_sequence_example(SEQ_SERIALIZED, example_feature_spec=EXAMPLE_FEATURE_SPEC,
                                          shuffle_examples=True)
+
+
+def test_parse_from_tf_example():
+    """data_test.py:156-190, 1266-1288: TF_EXAMPLE_PROTO_1 / _2, one item per list, context features in the same proto."""
+    protos = [D.encode_example({'query_length': ('int64', [1]), 'unigrams': ('bytes', [b'tensorflow']),
+                                'utility': ('float', [0.0])}),
+              D.encode_example({'query_length': ('int64', [3]), 'unigrams': ('bytes', [b'learning', b'to', b'rank']),
+                                'utility': ('float', [1.0])})]
+    got = data.parse_from_tf_example(protos, context_feature_spec=CONTEXT_FEATURE_SPEC,
+                                     example_feature_spec=EXAMPLE_FEATURE_SPEC, size_feature_name=_SIZE,
+                                     mask_feature_name=_MASK)
+    assert got[_SIZE].tolist() == [1, 1] and got[_SIZE].dtype == F32
+    assert got[_MASK].tolist() == [[True], [True]]
+    assert got['query_length'].tolist() == [[1], [3]] and got['utility'].tolist() == [[[0.]], [[1.]]]
+    got = data.parse_from_tf_example([D.encode_example({})], context_feature_spec=CONTEXT_FEATURE_SPEC,
+                                     example_feature_spec=EXAMPLE_FEATURE_SPEC)
+    assert got['query_length'].tolist() == [[0]] and got['utility'].tolist() == [[[-1.]]]      # the specs' defaults
