@@ -1,6 +1,10 @@
 #!/bin/bash
 # Round-4 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r04.sh <tag> <what...>
-#   what: repro | final | tests | one:<workload> | prof:<workload> | pmc:<workload>
+#   what: final (the driver's command, twice) | final1 | tests (full -m gpu suite + smoke) | repro / hunt / driver1 (the
+#         fault hunt of DESIGN 4.2) | profiles / profiles2 / profiles3 / hbm (what profiles/r04_* were made from) |
+#         one:<workload> | prof:<workload> | pmc:<workload> | same-box A/B steps of the switches in DESIGN 8:
+#         headline_ab, int_ab, metrics_ab, gemm_ab, aout_ab, aout2_ab, bt_ab, stream_ab, stream_groups | approx_tests,
+#         ingest, softmax_final (targeted test subsets)
 set -u
 TAG=${1:-r04}; shift
 OUT=gpurun_out/$TAG
@@ -31,56 +35,16 @@ for what in "$@"; do
           echo "graph $w dropout=$d rc=$?"; tail -n 2 $OUT/graph_${w}_d$d.err | cut -c1-300
         done
       done ;;
-    hunt2)
-      C="--also none --no-cpu-baseline --busy-seconds 0 --steps 20 --warmup 5"
-      for w in e2e_groupwise_gumbel e2e_approx_ndcg_l1000; do
-        for kt in none last first; do
-          timeout 300 python3 bench.py --workload $w $C --kernel-timing $kt --dropout 0 > $OUT/g_${w}_$kt.out 2> $OUT/g_${w}_$kt.err
-          echo "graph $w kernel-timing=$kt dropout=0 rc=$?"; tail -n 2 $OUT/g_${w}_$kt.err | cut -c1-200
-        done
-      done
-      for w in e2e_groupwise_gumbel e2e_approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda; do
-        PYTORCH_NO_HIP_MEMORY_CACHING=1 PYTORCH_NO_CUDA_MEMORY_CACHING=1 TFR_SYNC_EVERY_CALL=1 AMD_SERIALIZE_KERNEL=3 timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 3 --warmup 1 --no-graph --kernel-timing none > $OUT/hunt_$w.out 2> $OUT/hunt_$w.err
-        echo "hunt eager nocache $w rc=$?"; grep -v "^\[tfr\]" $OUT/hunt_$w.err | tail -n 2 | cut -c1-300; grep "^\[tfr\]" $OUT/hunt_$w.err | tail -n 3; grep -c "^\[tfr\]" $OUT/hunt_$w.err
-      done ;;
-    hunt3)
-      for e in none empty_cache gc gc_empty kernel_eager trivial_graph trivial_graph_keep kernel_graph replay_first_then_kernel_graph; do
-        timeout 200 python3 tools/fault_repro.py $e > $OUT/fr_$e.out 2> $OUT/fr_$e.err
-        echo "experiment $e rc=$? : $(tail -n 1 $OUT/fr_$e.out) | $(grep -v amdgpu.ids $OUT/fr_$e.err | tail -n 1 | cut -c1-160)"
-      done ;;
-    hunt4)
-      TAG=$TAG timeout 300 python3 tools/fault_repro.py snapshot e2e_groupwise_gumbel > $OUT/snap.out 2> $OUT/snap.err; echo "snapshot rc=$?"; tail -n 3 $OUT/snap.err | cut -c1-200; ls -la $OUT ;;
     driver1)
       ( time timeout 1200 python3 bench.py $DRV > $OUT/driver.out 2> $OUT/driver.err ) 2> $OUT/driver.time; echo "driver rc=$?"
       tail -n 3 $OUT/driver.err | cut -c1-300; python tools/bench_summary.py $OUT/driver.out; tail -n 3 $OUT/driver.time ;;
-    newtests)
-      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_distributed.py tests/test_gpu_tower.py -x -q -m gpu > $OUT/newtests.log 2>&1; echo "newtests rc=$?"; tail -n 30 $OUT/newtests.log ;;
-    probe)
-      timeout 600 python3 tools/tower_error_probe.py 51200 204800 819200 > $OUT/tower_probe.txt 2>&1; echo "probe rc=$?"; cat $OUT/tower_probe.txt | tail -n 40
-      TFR_TOWER_NO_FUSED_LAST=1 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_nofused.txt 2>&1; echo "probe nofused rc=$?"; tail -n 12 $OUT/tower_probe_nofused.txt
-      TFR_WGRAD_256=0 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_w128.txt 2>&1; echo "probe wgrad128 rc=$?"; tail -n 12 $OUT/tower_probe_w128.txt
-      TFR_TOWER_PERSIST=0 timeout 300 python3 tools/tower_error_probe.py 819200 > $OUT/tower_probe_nopersist.txt 2>&1; echo "probe nopersist rc=$?"; tail -n 12 $OUT/tower_probe_nopersist.txt
-      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_distributed.py tests/test_gpu_tower.py -q -m gpu -k "not baseline_rows" > $OUT/newtests2.log 2>&1; echo "newtests2 rc=$?"; tail -n 15 $OUT/newtests2.log ;;
     headline_ab)
       H="--workload approx_ndcg --also none --no-cpu-baseline --busy-seconds 0 --steps 200 --warmup 20"
       for v in "" "TFR_LOSS_SUM_FUSED=0" "TFR_APPROX_PAIR_RCP=0 TFR_LOSS_SUM_FUSED=0"; do
         env $v timeout 200 python3 bench.py $H > $OUT/h_$(echo $v | tr ' =' '__').out 2> $OUT/h.err; echo "[$v] rc=$?"; python tools/bench_summary.py $OUT/h_$(echo $v | tr ' =' '__').out | tail -n 1; tail -n 1 $OUT/h.err | cut -c1-200
       done ;;
-    sr_probe)
-      timeout 300 python3 tools/tower_error_probe.py 51200 819200 > $OUT/tower_probe_sr.txt 2>&1; echo "probe SR rc=$?"; grep -v "biases\|out_" $OUT/tower_probe_sr.txt | tail -n 22
-      timeout 1500 python -m pytest tests/test_gpu_full_size.py tests/test_gpu_tower.py -x -q -m gpu > $OUT/t_full.log 2>&1; echo "full-size+tower tests rc=$?"; tail -n 25 $OUT/t_full.log
-      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel" > $OUT/t_approx.log 2>&1; echo "approx parity tests rc=$?"; tail -n 12 $OUT/t_approx.log ;;
     approx_tests)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel or keras_loss" > $OUT/t_approx.log 2>&1; echo "approx parity tests rc=$?"; tail -n 12 $OUT/t_approx.log ;;
-    softmax_ab)
-      for v in "TFR_SOFTMAX_LPW=1" "TFR_SOFTMAX_LPW=2"; do
-        for w in softmax_hbm softmax; do
-          env $v timeout 300 python3 bench.py --workload $w --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/sm_${w}_$(echo $v | tr ' =' '__').out 2> $OUT/sm.err; echo "[$v] $w rc=$?"; python tools/bench_summary.py $OUT/sm_${w}_$(echo $v | tr ' =' '__').out | tail -n 1
-        done
-        env $v timeout 300 python3 bench.py --workload softmax --batch 16384 --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/sm16k_$(echo $v | tr ' =' '__').out 2> $OUT/sm.err; echo "[$v] softmax B=16384 rc=$?"; python tools/bench_summary.py $OUT/sm16k_$(echo $v | tr ' =' '__').out | tail -n 1
-      done
-      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
-      TFR_SOFTMAX_LPW=2 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax" > $OUT/t_softmax2.log 2>&1; echo "softmax tests LPW=2 rc=$?"; tail -n 3 $OUT/t_softmax2.log ;;
     metrics_ab)
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "ndcg or mrr or metric or approx or sort or rank" > $OUT/t_metrics.log 2>&1; echo "metric/approx tests rc=$?"; tail -n 3 $OUT/t_metrics.log
       for v in "TFR_SOFTMAX_NT=0" "TFR_SOFTMAX_NT=1"; do
