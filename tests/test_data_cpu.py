@@ -782,3 +782,27 @@ def test_eie_and_seq_error_behaviour():
     assert lib.tfr_io_max_list_size(9, ptrs, lens.ctypes.data, len(eie), None, 0) == -1
     assert lib.tfr_io_max_list_size(2, ptrs, lens.ctypes.data, len(eie), None, 0) == -1
     assert lib.tfr_io_max_list_size(1, ptrs, lens.ctypes.data, len(eie), None, 0) == max(len(e) for _, e in lists)
+
+
+def test_parsers_survive_the_sanitizer_fuzzer(tmp_path):
+    """tools/io_fuzz.cpp: libtfr_io's source built under -fsanitize=address,undefined and fed valid records of the four
+    formats (and LibSVM text, TFRecord framing) with random truncations, bit flips, splices and deletions.  Any error code
+    is fine; an out-of-bounds access or undefined behaviour aborts the fuzzer."""
+    import shutil
+    import subprocess
+    cxx = shutil.which('g++')
+    if cxx is None:
+        pytest.skip('no g++')
+    exe = str(tmp_path / 'io_fuzz')
+    build = subprocess.run([cxx, '-O1', '-g', '-std=c++17', '-fsanitize=address,undefined', '-fno-sanitize-recover=all',
+                            '-pthread', '-I', os.path.join(ROOT, 'include'), os.path.join(ROOT, 'tools', 'io_fuzz.cpp'),
+                            os.path.join(ROOT, 'ranking_amd', 'csrc', 'tfr_io.cpp'), '-o', exe],
+                           capture_output=True, text=True)
+    if build.returncode != 0 and ('asan' in build.stderr or 'ubsan' in build.stderr or 'sanitize' in build.stderr):
+        pytest.skip('this toolchain has no sanitizer runtime: %s' % build.stderr[-200:])
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([exe, '15000', '11'], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, (run.stdout[-500:], run.stderr[-3000:])
+    assert 'io_fuzz: 15000 rounds' in run.stdout
+    parsed = int(run.stdout.split('rounds,')[1].split('batches parsed')[0])
+    assert parsed > 1000                                         # the fuzzer does reach the accepting paths
