@@ -381,6 +381,109 @@ __device__ __forceinline__ void wave_rank_by_count(const float* XS, int n, int l
   WAVE_LDS_SYNC();
 }
 
+// inclusive prefix sum over the 64 lanes on the DPP network (the steps of wave_sum_u, every lane keeps its prefix)
+__device__ __forceinline__ int wave_scan_incl_i(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return x;
+}
+
+// The ranks of wave_rank_by_count (same result, integer for integer) from a 64-bucket partition of the score range
+// instead of all n^2 / 64 compares per lane (round 4): bucket(x) = min(63, int((max - x) * 64 / (max - min))) is monotone
+// (a higher score never lands in a later bucket, equal scores share one), so rank = (items in earlier buckets) + (items
+// of the OWN bucket with a higher score) -- a histogram (LDS atomics), one wave scan, a scatter into bucket order and a
+// scan of at most `hmax` = the fullest bucket's entries per item.  The scan needs no bound check: whatever follows a
+// bucket in BX belongs to later buckets (strictly lower scores) or to the -inf padding, and never counts.  Ties leave
+// equal counts exactly like the counting sweep, and the same occupancy fix-up orders them by compact index.
+// Declines (returns false, wave-uniform; nothing written that the caller reads) when the range is empty / not finite or
+// a bucket holds more than kRankBucketMax items (heavy ties, an outlier that squeezes the rest into one bucket): the
+// caller then runs wave_rank_by_count.  n <= 64 * NC; BX: n + kRankBucketMax floats, HB: 192 ints, OCC: n ints of scratch.
+constexpr int kRankBucketMax = 32;
+template <int NC>
+__device__ __forceinline__ bool wave_rank_by_bucket(const float* XS, int n, int lane, int* RKS, int* OCC, float* BX,
+                                                    int* HB) {
+  float x[NC];
+  bool in[NC];
+  float mn = INFINITY, mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int p = lane + 64 * k;
+    in[k] = p < n;
+    x[k] = in[k] ? XS[p] : 0.0f;
+    if (in[k]) { mn = fminf(mn, x[k]); mx = fmaxf(mx, x[k]); }
+  }
+  mn = wave_min_u(mn); mx = wave_max_u(mx);
+  const float range = mx - mn;
+  const float scale = 64.0f / range;
+  if (!(range > 0.0f) || !(range < INFINITY) || !(scale < INFINITY)) return false;
+  int* H = HB; int* FILL = HB + 64; int* START = HB + 128;
+  H[lane] = 0; FILL[lane] = 0;
+  for (int p = lane; p < n; p += 64) OCC[p] = 0;
+  for (int p = n + lane; p < n + kRankBucketMax; p += 64) BX[p] = -INFINITY;
+  WAVE_LDS_SYNC();
+  int bk[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    int bi = (int)(in[k] ? (mx - x[k]) * scale : 0.0f);      // (mx >= x: in [0, 64])
+    bi = bi > 63 ? 63 : bi;
+    bk[k] = bi;
+    if (in[k]) atomicAdd(&H[bi], 1);
+  }
+  WAVE_LDS_SYNC();
+  const int h = H[lane];
+  const int hmax = (int)wave_max_u((float)h);               // (<= 512: exact in fp32)
+  if (hmax > kRankBucketMax) return false;
+  START[lane] = wave_scan_incl_i(h) - h;
+  WAVE_LDS_SYNC();
+  int st[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    st[k] = 0;
+    if (in[k]) {
+      st[k] = START[bk[k]];
+      const int slot = atomicAdd(&FILL[bk[k]], 1);           // (any order inside a bucket: the scan below compares values)
+      BX[st[k] + slot] = x[k];
+    }
+  }
+  WAVE_LDS_SYNC();
+  int cnt[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) cnt[k] = st[k];
+  for (int j = 0; j < hmax; j += 4) {                        // (uniform trip count; reads past a bucket never count)
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      const float* q = BX + st[k] + j;                        // st + j + 3 < n + kRankBucketMax
+      const float a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+      cnt[k] += (a0 > x[k]) ? 1 : 0; cnt[k] += (a1 > x[k]) ? 1 : 0;
+      cnt[k] += (a2 > x[k]) ? 1 : 0; cnt[k] += (a3 > x[k]) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    const int p = lane + 64 * k;
+    if (in[k]) { RKS[p] = cnt[k]; atomicAdd(&OCC[cnt[k]], 1); }
+  }
+  WAVE_LDS_SYNC();
+  for (int q0 = 0; q0 < n; q0 += 64) {                        // ties: the fix-up of wave_rank_by_count
+    const int p = q0 + lane;
+    const bool tie = p < n && OCC[RKS[p]] > 1;
+    if (__ballot(tie)) {
+      if (tie) {
+        const float xi = XS[p];
+        int c = RKS[p];
+        for (int j = 0; j < p; ++j) c += (XS[j] == xi) ? 1 : 0;
+        RKS[p] = c;
+      }
+    }
+  }
+  WAVE_LDS_SYNC();
+  return true;
+}
+
 // out[0] = sum_i vec[i] * w[i] (w nullable) over the B per-list values of a launch, without a launch of its own: the
 // scalar a reduced loss returns.  Called by ONE wavefront of every workgroup; lane 0 stores the workgroup's own entry
 // vec[b] = value HERE.  Two levels, both in a FIXED order whoever computes them (the result does not depend on the order

@@ -309,7 +309,9 @@ __global__ __launch_bounds__(64) void rank_metric_wave_kernel(
 // result is bit-identical to rank_metric_wave_kernel<0> (and to the oracle).
 constexpr int kNdcgRuns = 8;
 
-template <int IPL>
+// BUCKET (round 4, TFR_NDCG_BUCKET): the ranks from wave_rank_by_bucket (64-bucket partition of the score range, same
+// integers) with the counting sweep as the fallback for lists it declines.
+template <int IPL, bool BUCKET>
 __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
     const float* __restrict__ labels, const float* __restrict__ predictions, const float* __restrict__ weights,
     int weights_per_list, const uint8_t* __restrict__ mask, const float* __restrict__ gains,
@@ -323,6 +325,8 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
   int* OCC = RKS + N;                                      // [N]
   float* WG = reinterpret_cast<float*>(OCC + N);           // [N] w * gain by original index (sort fallback)
   float* DISC = WG + N;                                    // [N] the discount table: the gathers by rank / by sorted position
+  float* BX = DISC + N;                                    // BUCKET: [N + kRankBucketMax] scores in bucket order, then
+  int* HB = reinterpret_cast<int*>(BX + N + kRankBucketMax);   //     [192] histogram / fill counters / bucket starts
   const int lane = threadIdx.x, b = blockIdx.x;            //     below are LDS reads, not a dependent global round trip each
   const size_t base = (size_t)b * L;
   const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
 
   // ---- DCG: rank of every metric-valid item among them (prediction descending, ties by index); the masked items
   // follow in the sorted order and carry w * gain = 0: their terms are the zeros TERM starts from.
-  wave_rank_by_count(XS, n, lane, RKS, OCC);
+  if (!BUCKET || !wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, BX, HB)) wave_rank_by_count(XS, n, lane, RKS, OCC);
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
     if (m[r]) { const int rk = RKS[posr[r]]; TERM[rk] = wg[r] * DISC[rk]; }
@@ -1096,7 +1100,14 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
   static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
   if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
     constexpr size_t lds = (size_t)64 * IPL * 6 * sizeof(float) + 8 * sizeof(float);
-    hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL>), dim3(B), dim3(64), lds, st, labels, predictions, weights,
+    static const int env_bucket = [] { const char* e = getenv("TFR_NDCG_BUCKET"); return (e && *e) ? atoi(e) : 0; }();
+    if (env_bucket) {
+      constexpr size_t lds_b = lds + (size_t)(64 * IPL + kRankBucketMax + 192) * sizeof(float);
+      hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL, true>), dim3(B), dim3(64), lds_b, st, labels, predictions, weights,
+                         weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
+      return;
+    }
+    hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL, false>), dim3(B), dim3(64), lds, st, labels, predictions, weights,
                        weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
     return;
   }

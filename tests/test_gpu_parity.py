@@ -153,6 +153,36 @@ def test_ndcg_mrr_bit_exact(B, L, weighted):
     assert_loss_close(got_w, want_w, 1e-6, 'mrr list weights')
 
 
+@pytest.mark.parametrize('L', [2, 5, 64, 200, 512])
+@pytest.mark.parametrize('kind', ['few_ties', 'many_ties', 'outlier', 'constant', 'tiny_range'])
+def test_ndcg_bit_exact_with_tied_and_squeezed_predictions(L, kind):
+    """The rank step of the NDCG kernel (counting sweep; with TFR_NDCG_BUCKET=1 the 64-bucket partition with the sweep as
+    its fallback) on the score sets that stress it: a few ties inside buckets, ties everywhere (a bucket overflows: the
+    partition declines), one outlier that squeezes every other score into one bucket, constant scores, a range of a few
+    ulps.  NDCG@{1,3,5,10,all} bit-exact against the oracle, ties by index."""
+    B = 300
+    labels, preds = make_batch(B, L, seed=400 + L)
+    if kind == 'few_ties':
+        preds = torch.round(preds * 40) / 40
+    elif kind == 'many_ties':
+        preds = torch.round(preds)
+    elif kind == 'outlier':
+        preds = preds * 1e-3
+        preds[:, 0] = 1e6
+    elif kind == 'constant':
+        preds = torch.full_like(preds, 0.25)
+        preds[::2] = 0.0                                         # (and the -0 / +0 case of float_to_ordered)
+        preds[::4, ::2] = -0.0
+    else:
+        preds = 1.0 + torch.randint(0, 4, preds.shape).float() * 2 ** -23
+    mi = ra().metrics_impl
+    topns = [1, 3, 5, 10, None]
+    got, _ = mi.NDCGMetric(None, None).compute_multi(labels.to(DEV), preds.to(DEV), None, None, topns)
+    for q, k in enumerate(topns):
+        want, _ = R.NDCGMetric(topn=k).compute(labels, preds, None)
+        assert torch.equal(got[q].cpu(), want.reshape(-1)), (kind, L, k, (got[q].cpu() - want.reshape(-1)).abs().max())
+
+
 def test_metric_reference_goldens():
     km = ra().keras.metrics
     t = lambda x: torch.tensor(x, device=DEV)

@@ -136,6 +136,11 @@ PY
       timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py tests/test_gpu_e2e_parity.py -x -q -m gpu -k "softmax" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 3 $OUT/t_softmax.log
       timeout 300 python -m pytest tests/test_gpu_full_size.py -x -q -m gpu -k "every_bench_workload" > $OUT/t_workloads.log 2>&1; echo "bench workloads test rc=$?"; tail -n 2 $OUT/t_workloads.log
       timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $OUT/smoke.log ;;
+    bucket_ab)
+      TFR_NDCG_BUCKET=1 timeout 300 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "ndcg_mrr_bit_exact or tied_and_squeezed or metric_reference_goldens or ndcg_at_10_bit_exact" > $OUT/t_bucket.log 2>&1; echo "ndcg tests (bucket ranks) rc=$?"; tail -n 4 $OUT/t_bucket.log
+      for v in "TFR_NDCG_BUCKET=0" "TFR_NDCG_BUCKET=1"; do
+        env $v timeout 100 python3 bench.py --workload ndcg_metric --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/nb_$(echo $v | tr ' =' '__').out 2> $OUT/nb.err; echo "[$v] ndcg_metric rc=$?"; python tools/bench_summary.py $OUT/nb_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
     final1)
       ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
       tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;
