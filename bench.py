@@ -230,7 +230,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         discount = _ops.rank_table(m._rank_discount_fn, L, dev)
         return dict(step=lambda: m.compute_multi(labels, logits, None, None, topns),
                     kernel=lambda: _ops.ndcg_metric(labels, logits, None, None, None, discount, topns),
-                    kernel_name='ndcg_count_wave_kernel (ranks by counting, run-length ideal DCG, tree sums for five cut-offs)')
+                    kernel_name='ndcg_count_wave_kernel (ranks from a 64-bucket partition of the scores, run-length ideal DCG, tree sums for five cut-offs)')
     if workload.startswith('e2e_'):
         return build_e2e_step(workload, labels, dropout, use_graph)
     raise ValueError(workload)

@@ -1100,7 +1100,7 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
   static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
   if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
     constexpr size_t lds = (size_t)64 * IPL * 6 * sizeof(float) + 8 * sizeof(float);
-    static const int env_bucket = [] { const char* e = getenv("TFR_NDCG_BUCKET"); return (e && *e) ? atoi(e) : 0; }();
+    static const int env_bucket = [] { const char* e = getenv("TFR_NDCG_BUCKET"); return (e && *e) ? atoi(e) : 1; }();
     if (env_bucket) {
       constexpr size_t lds_b = lds + (size_t)(64 * IPL + kRankBucketMax + 192) * sizeof(float);
       hipLaunchKernelGGL((ndcg_count_wave_kernel<IPL, true>), dim3(B), dim3(64), lds_b, st, labels, predictions, weights,
