@@ -279,7 +279,10 @@ __device__ __forceinline__ void grp_lo_sweep(const float2* recL, const float* WS
   accG2 = __builtin_fmaf(dG, ag, accG2);
 }
 
-template <int IPL, bool AUX, bool ITEMW>
+// BKT (round 4, written after the GPU budget was spent: TFR_LAMBDARANK_BUCKET=1, off until it has run the pairwise
+// suites): the builder takes its ranks from wave_rank_by_bucket (the NDCG metric kernel's rank step since round 4:
+// same integers, ~1/5 of the instructions for 200 items) with the counting sweep as the fallback.
+template <int IPL, bool AUX, bool ITEMW, bool BKT = false>
 __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp,
                                                                 const int G) {
   // G lists per workgroup, blockDim.x / 64 >= G wavefronts: waves 0 .. G-1 each BUILD one list's LDS image, then every
@@ -407,7 +410,12 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
 
       // 1b. ranks by counting (score descending, ties by index) (:483-500).
       int rk[IPL];
-      wave_rank_by_count(XS, n, lane, RKS, OCC);         // (common.h: all row chunks against each float4 of columns at once)
+      // (BKT scratch: bucket-ordered scores behind XS inside recH -- 2 LpS floats, XS takes Lp + 8 of them, n + 32 <=
+      //  Lp + 24 -- and the 192 counters in GS, which the records phase writes later; lists with LpS < 192 are short
+      //  enough for the sweep)
+      if (!BKT || LpS < 192 ||
+          !wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, XS + Lp + 8, reinterpret_cast<int*>(GS)))
+        wave_rank_by_count(XS, n, lane, RKS, OCC);       // (common.h: all row chunks against each float4 of columns at once)
 #pragma unroll
       for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
       WAVE_LDS_SYNC();                                                       // the scratch is rewritten below

@@ -1026,6 +1026,20 @@ int launch_grp(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, hipStre
   return (int)hipGetLastError();
 }
 
+// The same launch with the builder's ranks from wave_rank_by_bucket (plain case only: no aux outputs, no item weights).
+template <int IPL>
+int launch_grp_bucket(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lambdarank_group_kernel<IPL, false, false, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int N = (B + G - 1) / G;
+  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, false, false, true>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R,
+                     grp_lp(a.L), G);
+  return (int)hipGetLastError();
+}
+
 template <int IPL>
 int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
   static const int env_s = env_int("TFR_PAIRWISE_WAVES_PER_LIST", 0);
@@ -1051,6 +1065,8 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
     size_t glds = 0;
     if (env_grp && B >= env_grp_min && grp_geometry(B, a.L, iw, gG, gWt, gR, glds)) {
       // G lists per workgroup, barrier-free build / sweep, conflict-free rank-difference gather (lambdarank_group.h)
+      static const int env_bkt = env_int("TFR_LAMBDARANK_BUCKET", 0);
+      if (env_bkt && !aux && !iw) return launch_grp_bucket<IPL>(a, B, gG, gWt, gR, glds, stream);
       if (aux) return iw ? launch_grp<IPL, true, true>(a, B, gG, gWt, gR, glds, stream)
                          : launch_grp<IPL, true, false>(a, B, gG, gWt, gR, glds, stream);
       return iw ? launch_grp<IPL, false, true>(a, B, gG, gWt, gR, glds, stream)

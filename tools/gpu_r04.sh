@@ -141,6 +141,12 @@ PY
       for v in "TFR_NDCG_BUCKET=0" "TFR_NDCG_BUCKET=1"; do
         env $v timeout 100 python3 bench.py --workload ndcg_metric --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/nb_$(echo $v | tr ' =' '__').out 2> $OUT/nb.err; echo "[$v] ndcg_metric rc=$?"; python tools/bench_summary.py $OUT/nb_$(echo $v | tr ' =' '__').out | tail -n 1
       done ;;
+    lbucket_ab)
+      # NOT YET RUN (written after the round-4 budget was spent): the LambdaRank builder's ranks from the bucket partition
+      TFR_LAMBDARANK_BUCKET=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "pairwise or lambda" > $OUT/t_lbucket.log 2>&1; echo "pairwise tests (bucket ranks) rc=$?"; tail -n 4 $OUT/t_lbucket.log
+      for v in "TFR_LAMBDARANK_BUCKET=0" "TFR_LAMBDARANK_BUCKET=1"; do
+        env $v timeout 100 python3 bench.py --workload pairwise_lambda --also none --no-cpu-baseline --busy-seconds 0 --steps 100 --warmup 10 > $OUT/lb_$(echo $v | tr ' =' '__').out 2> $OUT/lb.err; echo "[$v] pairwise_lambda rc=$?"; python tools/bench_summary.py $OUT/lb_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
     final1)
       ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
       tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;
