@@ -141,6 +141,14 @@ PY
       for v in "TFR_NDCG_BUCKET=0" "TFR_NDCG_BUCKET=1"; do
         env $v timeout 100 python3 bench.py --workload ndcg_metric --also none --no-cpu-baseline --busy-seconds 0 --steps 50 --warmup 5 > $OUT/nb_$(echo $v | tr ' =' '__').out 2> $OUT/nb.err; echo "[$v] ndcg_metric rc=$?"; python tools/bench_summary.py $OUT/nb_$(echo $v | tr ' =' '__').out | tail -n 1
       done ;;
+    lbucket_quick)
+      # bit-identity of the bucket-rank builder against the (validated) counting builder, then the A/B -- about 25 s
+      TFR_LAMBDARANK_BUCKET=0 timeout 60 python tools/lbucket_check.py $OUT a > $OUT/lbq.log 2>&1
+      TFR_LAMBDARANK_BUCKET=1 timeout 60 python tools/lbucket_check.py $OUT b >> $OUT/lbq.log 2>&1
+      timeout 30 python tools/lbucket_check.py $OUT compare >> $OUT/lbq.log 2>&1; echo "lbucket_check rc=$?"; tail -n 8 $OUT/lbq.log | cut -c1-200
+      for v in "TFR_LAMBDARANK_BUCKET=0" "TFR_LAMBDARANK_BUCKET=1"; do
+        env $v timeout 60 python3 bench.py --workload pairwise_lambda --also none --no-cpu-baseline --busy-seconds 0 --steps 100 --warmup 10 > $OUT/lb_$(echo $v | tr ' =' '__').out 2> $OUT/lb.err; echo "[$v] pairwise_lambda rc=$?"; python tools/bench_summary.py $OUT/lb_$(echo $v | tr ' =' '__').out | tail -n 1
+      done ;;
     lbucket_ab)
       # NOT YET RUN (written after the round-4 budget was spent): the LambdaRank builder's ranks from the bucket partition
       TFR_LAMBDARANK_BUCKET=1 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "pairwise or lambda" > $OUT/t_lbucket.log 2>&1; echo "pairwise tests (bucket ranks) rc=$?"; tail -n 4 $OUT/t_lbucket.log
