@@ -1065,7 +1065,7 @@ int launch_pw_wave(const PwArgs& a, int B, hipStream_t stream) {
     size_t glds = 0;
     if (env_grp && B >= env_grp_min && grp_geometry(B, a.L, iw, gG, gWt, gR, glds)) {
       // G lists per workgroup, barrier-free build / sweep, conflict-free rank-difference gather (lambdarank_group.h)
-      static const int env_bkt = env_int("TFR_LAMBDARANK_BUCKET", 0);
+      static const int env_bkt = env_int("TFR_LAMBDARANK_BUCKET", 1);
       if (env_bkt && !aux && !iw) return launch_grp_bucket<IPL>(a, B, gG, gWt, gR, glds, stream);
       if (aux) return iw ? launch_grp<IPL, true, true>(a, B, gG, gWt, gR, glds, stream)
                          : launch_grp<IPL, true, false>(a, B, gG, gWt, gR, glds, stream);
