@@ -410,3 +410,70 @@ def test_utils_reference_literals():
     assert pk('a') == {'a': 1.0} and pk('a :0.9') == {'a': 0.9} and pk('a,b') == {'a': 1., 'b': 1.}
     assert pk('a, b') == {'a': 1., 'b': 1.} and pk('a, b: 2.') == {'a': 1., 'b': 2.}
     assert pk('a:0.1,b:0.9') == {'a': 0.1, 'b': 0.9} and pk('a:0.1, b : 0.9') == {'a': 0.1, 'b': 0.9}
+
+
+def test_bucket_rank_algorithm_equals_the_counting_ranks():
+    """The algorithm of csrc/common.h: wave_rank_by_bucket restated in numpy (fp32 like the kernel): a 64-bucket partition
+    of the score range is monotone, so rank = items in earlier buckets + higher scores inside the own bucket; the scan of
+    `hmax` entries needs no bound check (what follows a bucket scores lower, then the -inf padding); ties keep equal
+    counts and the occupancy fix-up orders them by index; the partition declines on an empty / non-finite range or a
+    bucket above 32 items.  Held against the definition (score descending, ties by index) on the score sets that stress
+    it; the HIP code itself is checked on the GPU (bit-exact NDCG, bit-identical LambdaRank outputs)."""
+    import numpy as np
+    rng = np.random.RandomState(0)
+    T = 32
+
+    def reference(x):
+        n = len(x)
+        return np.asarray([sum((x[j] > x[i]) or (x[j] == x[i] and j < i) for j in range(n)) for i in range(n)])
+
+    def bucket_ranks(x):
+        x = np.asarray(x, np.float32)
+        n = len(x)
+        if n == 0:
+            return None
+        mn, mx = x.min(), x.max()
+        with np.errstate(all='ignore'):
+            span = np.float32(mx - mn)
+            scale = np.float32(64.0) / span
+        if not (span > 0) or not np.isfinite(span) or not np.isfinite(scale):
+            return None
+        b = np.minimum(63, ((mx - x) * scale).astype(np.int32))
+        assert all(b[i] <= b[j] for i in range(n) for j in range(n) if x[i] > x[j])      # monotone
+        hist = np.bincount(b, minlength=64)
+        if hist.max() > T:
+            return None
+        start = np.concatenate([[0], np.cumsum(hist)[:-1]])
+        fill = np.zeros(64, int)
+        bx = np.full(n + T, -np.inf, np.float32)
+        for p in rng.permutation(n):                              # the order of the LDS atomics is arbitrary
+            bx[start[b[p]] + fill[b[p]]] = x[p]
+            fill[b[p]] += 1
+        hmax = int(hist.max())
+        cnt = np.asarray([start[b[p]] + sum(bx[start[b[p]] + j] > x[p] for j in range(-(-hmax // 4) * 4))
+                          for p in range(n)])
+        occ = np.bincount(cnt, minlength=n)
+        return np.asarray([cnt[p] + (sum(x[j] == x[p] for j in range(p)) if occ[cnt[p]] > 1 else 0) for p in range(n)])
+
+    declined = ranked = 0
+    for trial in range(400):
+        n = int(rng.randint(1, 200))
+        kind = trial % 5
+        if kind == 0:
+            x = rng.randn(n)
+        elif kind == 1:
+            x = rng.rand(n)
+        elif kind == 2:
+            x = np.round(rng.randn(n) * 3) / 3                   # heavy ties
+        elif kind == 3:
+            x = np.concatenate([rng.randn(n - 1) * 1e-3, [1e6]]) if n > 1 else rng.randn(n)      # an outlier
+        else:
+            x = rng.randn(n) * rng.choice([1e-30, 1.0, 1e30])
+        x = x.astype(np.float32)
+        got = bucket_ranks(x)
+        if got is None:
+            declined += 1
+            continue
+        ranked += 1
+        assert np.array_equal(got, reference(x)), (trial, n, kind)
+    assert ranked > 150 and declined > 20                          # both outcomes are exercised
