@@ -45,8 +45,10 @@ class DNNScorer(UnivariateScorer):
         """keras/model.py:712-777.  With the fused tower and one dense example feature the flatten step's
         circular-padding gather (a full copy of the [B, L, F] tensor) is folded into the tower's input cast."""
         from ..tower import FusedTower
+        _feed = (torch.float32, torch.bfloat16)               # (bf16: features the parser already rounded, data.py)
         if not context_features and len(example_features) > 1 and all(
-                torch.is_tensor(v) and v.dim() >= 2 and v.dtype == torch.float32 for v in example_features.values()):
+                torch.is_tensor(v) and v.dim() >= 2 and v.dtype in _feed for v in example_features.values()) and len(
+                {v.dtype for v in example_features.values()}) == 1:
             # Many per-column features (the reference's data: "1".."136"): concatenate ONCE, in the order
             # _score_flattened concatenates the flattened columns (:803-813) -- the flatten gather uses one index for
             # every feature, so flatten(concat) == concat(flatten) -- instead of one gather per feature and a concat.
@@ -55,7 +57,7 @@ class DNNScorer(UnivariateScorer):
                  for k in sorted(example_features)], dim=2)}
         if (isinstance(self._tower, FusedTower) and not context_features and len(example_features) == 1):
             (x,) = example_features.values()
-            if torch.is_tensor(x) and x.dim() == 3 and x.dtype == torch.float32:
+            if torch.is_tensor(x) and x.dim() == 3 and x.dtype in _feed:
                 mask = torch.as_tensor(mask, device=x.device).to(torch.bool)
                 b, l = mask.shape
                 if l <= 4096 and b * l < 2 ** 31:

@@ -105,7 +105,12 @@ class SimpleDatasetBuilder(AbstractDatasetBuilder):
     """keras/pipeline.py:1026-1117 over ELWC TFRecords (``ranking_amd.data``)."""
 
     def __init__(self, context_feature_spec, example_feature_spec, mask_feature_name, label_spec,
-                 hparams: DatasetHparams, sample_weight_spec=None):
+                 hparams: DatasetHparams, sample_weight_spec=None, data_format=data_lib.ELWC,
+                 example_dtype=torch.float32):
+        """``data_format``: any key of ``data.make_parsing_fn``.  ``example_dtype=torch.bfloat16``: the example features
+        are parsed, pinned and shipped as bfloat16 (label and sample weight stay float32; ``data._parse_batch``)."""
+        self._data_format = data_format
+        self._example_dtype = example_dtype
         self._context_feature_spec = context_feature_spec or {}
         self._example_feature_spec = example_feature_spec
         self._mask_feature_name = mask_feature_name
@@ -127,10 +132,14 @@ class SimpleDatasetBuilder(AbstractDatasetBuilder):
         spec[self._label_spec[0]] = self._label_spec[1]
         if self._sample_weight_spec:
             spec[self._sample_weight_spec[0]] = self._sample_weight_spec[1]
+        keep32 = ()
+        if self._example_dtype == torch.bfloat16:
+            keep32 = (self._label_spec[0],) + ((self._sample_weight_spec[0],) if self._sample_weight_spec else ())
         ds = data_lib.build_ranking_dataset(
-            file_pattern, data_lib.ELWC, batch_size, self._context_feature_spec, spec, list_size=list_size,
-            mask_feature_name=self._mask_feature_name, shuffle=randomize_input, num_epochs=num_epochs,
-            drop_final_batch=randomize_input, shard=shard)
+            file_pattern, self._data_format, batch_size, self._context_feature_spec, spec, list_size=list_size,
+            mask_feature_name=self._mask_feature_name, shuffle=randomize_input,
+            num_epochs=num_epochs, drop_final_batch=randomize_input, shard=shard, example_dtype=self._example_dtype,
+            float32_features=keep32)
         return (self._features_and_labels(f) for f in ds)
 
     def build_train_dataset(self):

@@ -806,3 +806,48 @@ def test_parsers_survive_the_sanitizer_fuzzer(tmp_path):
     assert 'io_fuzz: 15000 rounds' in run.stdout
     parsed = int(run.stdout.split('rounds,')[1].split('batches parsed')[0])
     assert parsed > 1000                                         # the fuzzer does reach the accepting paths
+
+
+def test_simple_dataset_builder_formats_and_bf16_features(tmp_path):
+    """keras.pipeline.SimpleDatasetBuilder(data_format=..., example_dtype=bfloat16): the example features arrive as
+    bfloat16 (rounded like the fp32 parse rounds afterwards), label and sample weight stay float32; the three list
+    formats give the same batches for the same lists (host only)."""
+    import ranking_amd as tfr
+    P = tfr.keras.pipeline
+    rng = np.random.RandomState(3)
+    lists = []
+    for _ in range(12):
+        n = int(rng.randint(2, 7))
+        lists.append([{'x': ('float', [float(np.float32(v)) for v in rng.randn(4)]),
+                       'utility': ('float', [float(rng.randint(0, 5))]), 'w': ('float', [float(np.float32(rng.rand()))])}
+                      for _ in range(n)])
+    files = {}
+    for fmt, enc in ((data.ELWC, lambda exs: D.encode_elwc(None, exs)), (data.EIE, lambda exs: D.encode_eie({}, exs)),
+                     (data.SEQ, lambda exs: D.encode_seq(None, {k: [e[k] for e in exs] for k in ('x', 'utility', 'w')}))):
+        path = str(tmp_path / ('%s.tfrecord' % fmt))
+        data.write_tfrecord(path, [enc(exs) for exs in lists])
+        files[fmt] = path
+    ex_spec = {'x': data.FixedLenFeature([4], F32, 0.0)}
+    label_spec = ('utility', data.FixedLenFeature([1], F32, -1.0))
+    weight_spec = ('w', data.FixedLenFeature([1], F32, 1.0))
+    batches = {}
+    for fmt in files:
+        for dt in (torch.float32, torch.bfloat16):
+            h = P.DatasetHparams(train_input_pattern=files[fmt], valid_input_pattern=files[fmt], train_batch_size=4,
+                                 valid_batch_size=4, list_size=6)
+            db = P.SimpleDatasetBuilder({}, ex_spec, 'mask', label_spec, h, sample_weight_spec=weight_spec,
+                                        data_format=fmt, example_dtype=dt)
+            import itertools
+            out = list(itertools.islice(db.build_valid_dataset(), 3))          # (the dataset repeats: num_epochs=None)
+            assert len(out) == 3
+            for feats, label, weight in out:
+                assert feats['x'].dtype == dt and label.dtype == torch.float32 and weight.dtype == torch.float32
+                assert tuple(feats['x'].shape) == (4, 6, 4) and tuple(label.shape) == (4, 6)
+            batches[(fmt, dt)] = out
+    ref = batches[(data.ELWC, torch.float32)]
+    for key, out in batches.items():
+        for (fa, la, wa), (fb, lb, wb) in zip(ref, out):
+            assert torch.equal(la, lb) and torch.equal(wa, wb) and torch.equal(fa['mask'], fb['mask']), key
+            want = fa['x'] if key[1] == torch.float32 else fa['x'].to(torch.bfloat16)
+            assert torch.equal(want.view(torch.int32 if key[1] == torch.float32 else torch.int16),
+                               fb['x'].view(torch.int32 if key[1] == torch.float32 else torch.int16)), key

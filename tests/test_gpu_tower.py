@@ -782,3 +782,25 @@ def test_bf16_ingested_features_train_the_tower_like_their_fp32_widening(in_bn, 
         assert torch.equal(a, b)
     for a, b in zip(b32, b16):
         assert torch.equal(a, b)
+
+
+def test_dnn_scorer_on_bf16_ingested_features():
+    """DNNScorer takes the example features as the bf16 parse delivers them (one feature or several per-column ones,
+    FlattenList's gather fused into the cast): the logits equal those of the same values widened to fp32, bit for bit."""
+    from ranking_amd.keras.model import DNNScorer
+    torch.manual_seed(5)
+    B, L, F = 33, 12, 24
+    xb = rnd((B, L, F), 90).to(torch.bfloat16).to(DEV)
+    n_valid = torch.randint(1, L + 1, (B,), generator=torch.Generator().manual_seed(2))
+    mask = (torch.arange(L).unsqueeze(0) < n_valid.unsqueeze(1)).to(DEV)
+    scorer = DNNScorer(input_dim=F, hidden_layer_dims=[64, 32], activation=torch.relu, use_batch_norm=True,
+                       dropout=0.0, compute_dtype=torch.bfloat16).to(DEV)
+    scorer.eval()
+    with torch.no_grad():
+        want = scorer({}, {'f': xb.float()}, mask)
+        got = scorer({}, {'f': xb}, mask)
+        assert got.dtype == torch.float32 and torch.equal(got, want)
+        cols16 = {'%02d' % k: xb[:, :, k:k + 1] for k in range(F)}               # one feature per column, sorted names
+        cols32 = {k: v.float() for k, v in cols16.items()}
+        assert torch.equal(scorer({}, cols16, mask), scorer({}, cols32, mask))
+        assert torch.equal(scorer({}, cols16, mask), want)
