@@ -510,6 +510,18 @@ def build_ranking_dataset(file_pattern, data_format, batch_size, context_feature
     return build_ranking_dataset_with_parsing_fn(file_pattern, parsing_fn, batch_size, **kwargs)
 
 
+def read_batched_sequence_example_dataset(file_pattern, batch_size, list_size, context_feature_spec, example_feature_spec,
+                                          reader=None, reader_args=None, num_epochs=None, shuffle=True,
+                                          shuffle_buffer_size=1000, shuffle_seed=None, prefetch_buffer_size=32,
+                                          reader_num_threads=10, sloppy_ordering=True, drop_final_batch=False):
+    """data.py:1149-1311: ``build_ranking_dataset`` on ``tf.SequenceExample`` records."""
+    return build_ranking_dataset(
+        file_pattern, SEQ, batch_size, context_feature_spec, example_feature_spec, list_size=list_size, reader=reader,
+        reader_args=reader_args, num_epochs=num_epochs, shuffle=shuffle, shuffle_buffer_size=shuffle_buffer_size,
+        shuffle_seed=shuffle_seed, prefetch_buffer_size=prefetch_buffer_size, reader_num_threads=reader_num_threads,
+        sloppy_ordering=sloppy_ordering, drop_final_batch=drop_final_batch)
+
+
 def load_libsvm_data(path: str, list_size: int, num_features: int = 136) -> Tuple[torch.Tensor, torch.Tensor]:
     """examples/tf_ranking_libsvm.py:137-195: (features [Q, list_size, num_features] fp32,
     labels [Q, list_size] fp32 with -1 padding); feature k of the reference's per-name map is

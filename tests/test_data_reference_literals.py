@@ -353,3 +353,15 @@ def test_parse_from_tf_example():
     got = data.parse_from_tf_example([D.encode_example({})], context_feature_spec=CONTEXT_FEATURE_SPEC,
                                      example_feature_spec=EXAMPLE_FEATURE_SPEC)
     assert got['query_length'].tolist() == [[0]] and got['utility'].tolist() == [[[-1.]]]      # the specs' defaults
+
+
+def test_read_batched_sequence_example_dataset(tmp_path):
+    """data_test.py:1148-1186: the two SequenceExamples written to a TFRecord file and read back in one batch of two."""
+    path = str(tmp_path / 'seq.tfrecord')
+    data.write_tfrecord(path, SEQ_SERIALIZED)
+    ds = data.read_batched_sequence_example_dataset(path, 2, 2, CONTEXT_FEATURE_SPEC, EXAMPLE_FEATURE_SPEC,
+                                                    num_epochs=1, shuffle=False, prefetch_buffer_size=None)
+    batches = list(ds)
+    assert len(batches) == 1
+    got = batches[0]
+    assert got['query_length'].tolist() == [[3], [2]] and got['utility'].tolist() == [[[0.], [1.0]], [[0.], [-1.]]]
