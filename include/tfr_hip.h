@@ -62,6 +62,10 @@ extern "C" {
 #define TFR_LAMBDA_PRECISION 5 /* losses_impl.py:410-454 PrecisionLambdaWeight: `gains` = positive_fn(labels)
                                   as 0/1 floats (TFR_GAIN_CUSTOM), topn mandatory */
 
+/* Version of this header's ABI.  2 (round 5): the `*_sum_f32` entry points below; `tfr_tower_dropout` carries the device
+ * pointer `step` since round 4 (24 bytes, was 12 -- a caller built against version 1 passes a short struct).  A binding
+ * must check the value at load time (ranking_amd/_lib.py does). */
+#define TFR_HIP_ABI_VERSION 2
 int tfr_hip_abi_version(void);
 
 /* utils.sort_by_scores / utils.sorted_ranks / losses_impl._compute_ranks
@@ -167,6 +171,44 @@ int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint
                             float temperature, int lanes_per_row, float* loss_out, float* weight_out,
                             float* dlogits_out, const int32_t* list_order, float* loss_sum_out,
                             uint32_t* ticket, void* stream);
+
+/* The same reduced scalar from the other loss launches (round 5; `ticket` as above, zero before the first launch, left zero,
+ * one per stream in flight; every output of the plain entry point is still written, bit for bit the same):
+ *   tfr_softmax_loss_sum_f32        sum_b loss_out[b] * weight_out[b]   (keras/losses.py:824-832); `sum_scratch` = B floats
+ *                                   of device scratch (the per-contributor products; the streaming form adds up one
+ *                                   partial per wavefront, in the order the wavefront walks its lists)
+ *   tfr_pairwise_loss_sum_f32       sum_b list_loss_out[b] (list_loss_out must be given: its entries are what is added up)
+ *   tfr_list_mle_sum_f32 / tfr_unique_softmax_sum_f32    sum_b loss_out[b] * list_scale[b] (list_scale NULL: plain sum)
+ *   tfr_pointwise_loss_sum_f32      sum_b list_loss_out[b]
+ * Summation order: fixed by (B, launch geometry), independent of which workgroup finishes last: the same bits on every
+ * run.  B == 0: loss_sum_out[0] = 0. */
+int tfr_softmax_loss_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                             const float* item_weights, int weights_per_list, int lambda_kind,
+                             int topn, int normalized, int gain_kind, const float* gains,
+                             const float* discount, int B, int L, float temperature, float poly_epsilon,
+                             float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
+                             float* sum_scratch, uint32_t* ticket, void* stream);
+int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
+                              const float* item_weights, const float* list_weights,
+                              int lambda_kind, int topn, float smooth_fraction,
+                              int normalized, int gain_kind, const float* gains,
+                              const float* discount, int B, int L, float temperature,
+                              float* row_loss_out, float* row_weight_out, float* nnz_out,
+                              float* dlogits_out, const int32_t* list_order, float* list_loss_out,
+                              float* loss_sum_out, uint32_t* ticket, void* stream);
+int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                         const float* pos_weight, const float* list_scale, int B, int L,
+                         float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
+                         uint32_t* ticket, void* stream);
+int tfr_unique_softmax_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                               const float* list_scale, int B, int L, float temperature,
+                               float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                               void* stream);
+int tfr_pointwise_loss_sum_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                               const float* item_weights, const float* list_weights, int B, int L,
+                               float temperature, float* list_loss_out, float* list_weight_out,
+                               float* list_nnz_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                               void* stream);
 
 /* Longest-first launch order for the O(n^2) loss kernels (their `list_order` argument, nullable):
  * order_out[B] = list indices by decreasing number of valid items (64 length classes; arbitrary

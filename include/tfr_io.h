@@ -40,6 +40,9 @@ extern "C" {
 #define TFR_IO_FORMAT_SEQ 2    /* tf.SequenceExample: context + one feature_list per feature (data.py:572-855)         */
 #define TFR_IO_FORMAT_EXAMPLE 3 /* one tf.Example = a list of ONE item carrying its context features too (data.py:1348-1395) */
 
+/* 2 (round 5 bookkeeping of round 4's additions): the EIE / SequenceExample / single-Example formats, the bf16 batch
+ * entry points and TFR_IO_EMISSING.  A binding checks the value at load time (ranking_amd/_io_lib.py does). */
+#define TFR_IO_ABI_VERSION 2
 int tfr_io_abi_version(void);
 
 /* CRC-32C (Castagnoli) and TFRecord's masked form ((crc >> 15 | crc << 17) + 0xa282ead8). */

@@ -43,6 +43,7 @@ _SIGNATURES = {
     'tfr_io_libsvm_load': (ctypes.c_int64, [_P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 2                        # = TFR_IO_ABI_VERSION of include/tfr_io.h
 
 ERRORS = {-1: 'invalid argument', -2: 'truncated or malformed record / protobuf', -3: 'checksum mismatch',
           -4: 'a feature is present with a length different from its spec',
@@ -109,6 +110,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    got = lib.tfr_io_abi_version()
+    if got != ABI_VERSION:
+        raise TfrIoError('%s reports ABI version %d, this binding was written against %d (include/tfr_io.h '
+                         'TFR_IO_ABI_VERSION): rebuild it' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -125,6 +125,18 @@ _SIGNATURES = {
                              + [ctypes.c_void_p] * 3),
     'tfr_tower_colsum_rows': (ctypes.c_int, [ctypes.c_int]),
     'tfr_list_dot_f32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 2),
+    # the reduced scalar from the loss launch itself (round 5): the plain entry point's arguments + sum / scratch / ticket
+    'tfr_softmax_loss_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
+                                 + [ctypes.c_int] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 7),
+    'tfr_pairwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
+                                  + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
+                                  + [ctypes.c_float] + [ctypes.c_void_p] * 9),
+    'tfr_list_mle_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                             + [ctypes.c_void_p] * 5),
+    'tfr_unique_softmax_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
+                                   + [ctypes.c_void_p] * 5),
+    'tfr_pointwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
+                                   + [ctypes.c_float] + [ctypes.c_void_p] * 7),
     # groupwise scoring (groupwise.hip)
     'tfr_group_indices_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_group_gather_cast_f32_bf16': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
@@ -135,6 +147,7 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+ABI_VERSION = 2                        # = TFR_HIP_ABI_VERSION of include/tfr_hip.h (tests/test_host_logic.py compares them)
 
 
 class TfrHipError(RuntimeError):
@@ -301,6 +314,10 @@ def load():
             raise TfrHipError('%s does not export %s' % (LIB_PATH, name))
         fn.restype = res
         fn.argtypes = args
+    got = lib.tfr_hip_abi_version()
+    if got != ABI_VERSION:            # a stale / foreign libtfr_hip.so: struct layouts and argument lists may differ
+        raise TfrHipError('%s reports ABI version %d, this binding was written against %d (include/tfr_hip.h '
+                          'TFR_HIP_ABI_VERSION): rebuild it (__graft_entry__.build())' % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

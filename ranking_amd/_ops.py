@@ -269,18 +269,36 @@ _device_state: Dict[Tuple, torch.Tensor] = {}
 
 def _zero_state(kind: str, n_ints: int, device) -> torch.Tensor:
     """A persistent zero-initialised int32 scratch of a kernel that synchronises its workgroups through device memory
-    (grid barrier / last-workgroup ticket) and leaves it zero: one per (kind, device), never freed -- a captured hipGraph
-    holds its address.  The launches that use it must be stream-ordered per device (they are: the loss kernels run on the
-    training stream).  It cannot be created inside a stream capture (its storage would belong to the graph's pool and
-    the zero fill would become a node of the graph): run the step once eagerly first, as every capture does anyway."""
-    key = (kind, str(device))
+    (last-workgroup tickets) and leaves it zero; never freed -- a captured hipGraph holds its address.  tfr_hip.h asks for
+    one per stream in flight: eager launches get one per (kind, device, current stream), so two streams never
+    share tickets.  Launches recorded by a stream capture run wherever the graph is replayed; they share one state per
+    (kind, device), created at the first eager call (every capture is preceded by an eager run of the step): graphs that
+    contain the same loss kind must be replayed in stream order on a device, as training steps are.  A capture with no
+    eager run before it gets a private state from the graph's own pool (the zero fill becomes a node of the graph)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    graph_key = (kind, str(device))
+    if capturing:
+        t = _device_state.get(graph_key)
+        return t if t is not None else torch.zeros(n_ints, dtype=torch.int32, device=device)
+    if graph_key not in _device_state:
+        _device_state[graph_key] = torch.zeros(n_ints, dtype=torch.int32, device=device)
+    key = (kind, str(device), int(torch.cuda.current_stream(device).cuda_stream))
     t = _device_state.get(key)
     if t is None:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError('the %s scratch must exist before a stream capture: run the step once eagerly first' % kind)
         t = torch.zeros(n_ints, dtype=torch.int32, device=device)
         _device_state[key] = t
     return t
+
+
+def _sum_outputs(device):
+    """(0-d result, ticket state) of a `*_sum_f32` launch.  Eagerly the result starts as NaN: if the last-arriver logic ever
+    misfired (ticket state left dirty by an aborted launch) the reduced loss is loudly wrong instead of silently stale;
+    inside a capture it is plain graph-pool memory (a fill would be one more node in every replay)."""
+    if torch.cuda.is_current_stream_capturing():
+        total = torch.empty((), dtype=torch.float32, device=device)
+    else:
+        total = torch.full((), float('nan'), dtype=torch.float32, device=device)
+    return total, _zero_state('loss_sum', int(_lib.load().tfr_grid_sum_state_ints()), device)
 
 
 def list_order(labels, mask=None):
@@ -323,8 +341,7 @@ def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lan
     weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
     if want_sum:
-        total = torch.empty((), dtype=torch.float32, device=logits.device)
-        ticket = _zero_state('loss_sum', int(_lib.load().tfr_grid_sum_state_ints()), logits.device)
+        total, ticket = _sum_outputs(logits.device)
         rc = _lib.load().tfr_approx_ndcg_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                                  _ptr(list_scale), B, L, float(temperature), int(lanes_per_row),
                                                  _ptr(loss), _ptr(weight), _ptr(dlogits),
@@ -355,26 +372,43 @@ def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want
     return loss, weight, dlogits
 
 
-def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temperature=1.0, want_grad=True):
+def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temperature=1.0, want_grad=True,
+             want_sum=False):
+    """want_sum=True (here and in the other losses below): one more result, the 0-d reduced scalar of the launch
+    (sum_b loss_b * list_scale_b) from the `*_sum_f32` entry point -- no reduction launch."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale'); pos_weight = _f32(pos_weight, 'pos_weight')
     B, L = logits.shape
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    if want_sum:
+        total, ticket = _sum_outputs(logits.device)
+        rc = _lib.load().tfr_list_mle_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
+                                              B, L, float(temperature), _ptr(loss), _ptr(dlogits), _ptr(total),
+                                              _ptr(ticket), _stream())
+        _lib.check(rc, 'tfr_list_mle_sum_f32')
+        return loss, dlogits, total
     rc = _lib.load().tfr_list_mle_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
                                       B, L, float(temperature), _ptr(loss), _ptr(dlogits), _stream())
     _lib.check(rc, 'tfr_list_mle_f32')
     return loss, dlogits
 
 
-def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, want_grad=True):
+def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, want_grad=True, want_sum=False):
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale')
     B, L = logits.shape
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    if want_sum:
+        total, ticket = _sum_outputs(logits.device)
+        rc = _lib.load().tfr_unique_softmax_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
+                                                    float(temperature), _ptr(loss), _ptr(dlogits), _ptr(total),
+                                                    _ptr(ticket), _stream())
+        _lib.check(rc, 'tfr_unique_softmax_sum_f32')
+        return loss, dlogits, total
     rc = _lib.load().tfr_unique_softmax_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
                                             float(temperature), _ptr(loss), _ptr(dlogits), _stream())
     _lib.check(rc, 'tfr_unique_softmax_f32')
@@ -385,8 +419,8 @@ POINT_SIGMOID_CE, POINT_MSE = 0, 1
 
 
 def pointwise_loss(kind, logits, labels, mask=None, item_weights=None, list_weights=None, temperature=1.0,
-                   want_grad=True):
-    """tfr_pointwise_loss_f32 -> (list_loss [B], list_weight [B], list_nnz [B], dlogits [B, L])."""
+                   want_grad=True, want_sum=False):
+    """tfr_pointwise_loss_f32 -> (list_loss [B], list_weight [B], list_nnz [B], dlogits [B, L]) (+ 0-d sum of list_loss)."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); item_weights = _f32(item_weights, 'item_weights')
@@ -397,6 +431,13 @@ def pointwise_loss(kind, logits, labels, mask=None, item_weights=None, list_weig
     weight = torch.empty((B,), dtype=torch.float32, device=dev)
     nnz = torch.empty((B,), dtype=torch.float32, device=dev)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
+    if want_sum:
+        total, ticket = _sum_outputs(dev)
+        rc = _lib.load().tfr_pointwise_loss_sum_f32(int(kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights),
+                                                    _ptr(list_weights), B, L, float(temperature), _ptr(loss), _ptr(weight),
+                                                    _ptr(nnz), _ptr(dlogits), _ptr(total), _ptr(ticket), _stream())
+        _lib.check(rc, 'tfr_pointwise_loss_sum_f32')
+        return loss, weight, nnz, dlogits, total
     rc = _lib.load().tfr_pointwise_loss_f32(int(kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights),
                                             _ptr(list_weights), B, L, float(temperature), _ptr(loss), _ptr(weight),
                                             _ptr(nnz), _ptr(dlogits), _stream())
@@ -443,7 +484,8 @@ def neural_sort_loss(kind, logits, labels, mask=None, list_scale=None, temperatu
 def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights=None,
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
-                      want_grad=True, want_rows=True, want_aux=True, loss_kind=0, balance=None, want_list=False):
+                      want_grad=True, want_rows=True, want_aux=True, loss_kind=0, balance=None, want_list=False,
+                      want_sum=False):
     """loss_kind: PAIR_LOGISTIC / PAIR_HINGE / PAIR_SOFT_ZERO_ONE.  want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
     SUM_BY_NONZERO_WEIGHTS reductions and compute_per_list need them): a leaner kernel variant.  want_list=True
     returns the per-list loss sums [B] in place of the [B, L] row losses (5-tuple: rows, weights, nnz, dlogits, list)."""
@@ -458,7 +500,17 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
     row_weight = torch.empty((B, L), dtype=torch.float32, device=dev) if (want_rows and want_aux) else None
     nnz = torch.empty((B,), dtype=torch.float32, device=dev) if want_aux else None
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
-    list_loss = torch.empty((B,), dtype=torch.float32, device=dev) if want_list else None
+    list_loss = torch.empty((B,), dtype=torch.float32, device=dev) if (want_list or want_sum) else None
+    if want_sum:                                   # (6-tuple: ..., list_loss, 0-d sum of list_loss)
+        total, ticket = _sum_outputs(dev)
+        rc = _lib.load().tfr_pairwise_loss_sum_f32(
+            int(loss_kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
+            int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
+            _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
+            _ptr(nnz), _ptr(dlogits), _ptr(_auto_order(labels, mask, balance, 128)), _ptr(list_loss), _ptr(total),
+            _ptr(ticket), _stream())
+        _lib.check(rc, 'tfr_pairwise_loss_sum_f32')
+        return row_loss, row_weight, nnz, dlogits, list_loss, total
     rc = _lib.load().tfr_pairwise_loss_f32(
         int(loss_kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
         int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
@@ -472,8 +524,9 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
 
 def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NONE, topn=0,
                  normalized=False, gain_kind=GAIN_IDENTITY, gains=None, discount=None,
-                 temperature=1.0, want_grad=True, poly_epsilon=0.0):
-    """poly_epsilon != 0: PolyOneSoftmaxLoss (loss += epsilon * (1 - sum p softmax))."""
+                 temperature=1.0, want_grad=True, poly_epsilon=0.0, want_sum=False):
+    """poly_epsilon != 0: PolyOneSoftmaxLoss (loss += epsilon * (1 - sum p softmax)).  want_sum=True: a fourth result,
+    the 0-d sum_b loss_b * weight_b from the same launch (tfr_softmax_loss_sum_f32)."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
@@ -483,6 +536,16 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
     loss = torch.empty((B,), dtype=torch.float32, device=dev)
     weight = torch.empty((B,), dtype=torch.float32, device=dev)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
+    if want_sum:
+        total, ticket = _sum_outputs(dev)
+        scratch = torch.empty((max(B, 1),), dtype=torch.float32, device=dev)
+        rc = _lib.load().tfr_softmax_loss_sum_f32(
+            _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),
+            int(bool(normalized)), int(gain_kind), _ptr(gains), _ptr(discount), B, L, float(temperature),
+            float(poly_epsilon), _ptr(loss), _ptr(weight), _ptr(dlogits), _ptr(total), _ptr(scratch), _ptr(ticket),
+            _stream())
+        _lib.check(rc, 'tfr_softmax_loss_sum_f32')
+        return loss, weight, dlogits, total
     rc = _lib.load().tfr_poly1_softmax_loss_f32(
         _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),
         int(bool(normalized)), int(gain_kind), _ptr(gains), _ptr(discount), B, L, float(temperature),

@@ -511,6 +511,12 @@ __device__ __forceinline__ void grid_weighted_sum_last(float* vec, int b, float 
   }
   t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
   if ((int)t != cnt - 1) return;
+  // The loads below are ordered after the ticket by (a) the control dependency on its RETURNED value and (b) this
+  // compiler barrier (nothing may be hoisted above the RMW).  Hardware assumption, stated: on gfx950 an agent-scope
+  // atomic load (global_load ... sc1) is served at the coherence point, so once the ticket RMW -- performed there too,
+  // after every contributor's written-through store was acknowledged (its s_waitcnt vmcnt(0)) -- has returned, the
+  // entries are visible; `w` is only ever a kernel INPUT (never written by the launch), so its plain loads need no order.
+  asm volatile("" ::: "memory");
   float acc = 0.f;
   for (int q = lane; q < cnt; q += 64) {
     const int i = j + kGridSumGroups * q;
@@ -527,6 +533,7 @@ __device__ __forceinline__ void grid_weighted_sum_last(float* vec, int b, float 
   }
   t2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)t2);
   if ((int)t2 != groups - 1) return;
+  asm volatile("" ::: "memory");
   float p = (lane < groups) ? __hip_atomic_load(reinterpret_cast<float*>(st + kGridSumGroups + 1 + lane), __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
   p = wave_sum_u(p);
@@ -534,6 +541,14 @@ __device__ __forceinline__ void grid_weighted_sum_last(float* vec, int b, float 
     out[0] = p;
     __hip_atomic_store(st + kGridSumGroups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// The same reduction for any launch (round 5): `vec` is a scratch of >= n floats, entry idx = one contributor's value (a
+// list, or a wavefront's own fixed-order partial over the lists it walked), n contributors in total, every one of them
+// calls this exactly once with its whole wavefront converged.  out == nullptr: no sum requested.
+struct GridSum { float* out; float* vec; unsigned int* st; int n; };
+__device__ __forceinline__ void grid_sum_contribute(const GridSum& s, int idx, float value, int lane) {
+  grid_weighted_sum_last(s.vec, idx, value, nullptr, s.n, s.out, s.st, lane);
 }
 
 // sum_p sorted_desc(g)[p] * table[p] for NON-NEGATIVE g (element e = lane + 64*r, zero beyond

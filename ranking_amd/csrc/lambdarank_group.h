@@ -540,10 +540,11 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
         H->n = n; H->np = ppos; H->nseg = nseg; H->flags = (fast ? 1 : 0) | (tail ? 2 : 0);
         H->npass = npass; H->lw = lw;
         if (npass == 0) {                                     // no valid item: nothing to sweep, the sums are zero
-          if (a.list_loss) a.list_loss[b] = 0.f;
+          if (a.list_loss && !a.sum.out) a.list_loss[b] = 0.f;
           if (AUX && a.nnz) a.nnz[b] = 0.f;
         }
       }
+      if (npass == 0 && a.sum.out) grid_sum_contribute(a.sum, b, 0.f, lane);       // (wave-uniform: the list still counts as one entry)
     }
     // publish: release at workgroup scope (every LDS store above is ordered before the flag; the sweepers acquire it)
     WAVE_LDS_SYNC();
@@ -705,9 +706,15 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
         int done = 0;
         if (lane == 0) done = atomicAdd(&H->done_pass, 1);
         done = __builtin_amdgcn_readfirstlane(done);
-        if (done + 1 == npass && lane == 0) {
-          if (want_list) { float t = 0.f; for (int p2 = 0; p2 < npass; ++p2) t += H->pass_loss[p2]; a.list_loss[lb] = t; }
-          if (want_nnz) { float t = 0.f; for (int p2 = 0; p2 < npass; ++p2) t += H->pass_nnz[p2]; a.nnz[lb] = t; }
+        if (done + 1 == npass) {                              // (wave-uniform)
+          float tl = 0.f;
+          if (want_list) { for (int p2 = 0; p2 < npass; ++p2) tl += H->pass_loss[p2]; }      // every lane: the same sum, in pass order
+          if (lane == 0) {
+            if (want_list && !a.sum.out) a.list_loss[lb] = tl;
+            if (want_nnz) { float t = 0.f; for (int p2 = 0; p2 < npass; ++p2) t += H->pass_nnz[p2]; a.nnz[lb] = t; }
+          }
+          // the reduced scalar of the launch (round 5): the helper stores list_loss[lb] itself, written through
+          if (want_list && a.sum.out) grid_sum_contribute(a.sum, lb, tl, lane);
         }
       }
     }

@@ -22,7 +22,7 @@ template <int IPL>
 __global__ __launch_bounds__(64) void list_mle_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int L, float temperature,
-    float* __restrict__ loss_out, float* __restrict__ dlogits_out) {
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* XS = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] logits by original index
   const int lane = threadIdx.x, b = blockIdx.x;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64) void list_mle_wave_kernel(
     if (lane + 64 * r < L) term += w[r] * (logf(S[r]) - xs[r]);
   const float loss = wave_sum_u(term);
   if (lane == 0) loss_out[b] = loss;
+  if (sum.out) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, lane);   // sum_b loss_b * list_scale_b
   if (!dlogits_out) return;
 
   // C_p = sum_{q <= p} w_q / S_q : forward inclusive scan;  grad_p = e_p * C_p - w_p
@@ -167,7 +168,7 @@ template <int IPL>
 __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ list_scale, int L, float temperature, float* __restrict__ loss_out,
-    float* __restrict__ dlogits_out) {
+    float* __restrict__ dlogits_out, const GridSum sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* XS = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] logits by original index
   float* LB = XS + 64 * IPL;                               // [64 * IPL] labels by original index
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(64) void unique_softmax_wave_kernel(
   }
   const float loss = wave_sum_u(term);
   if (lane == 0) loss_out[b] = loss;
+  if (sum.out) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, lane);
   if (!dlogits_out) return;
   // exclusive prefix of c = g / D in sorted order -> PRE[p] = sum_{q < p} c_q
   carry = 0.f;
@@ -444,7 +446,7 @@ struct ScanMinI { __device__ int operator()(int a, int b) const { return a < b ?
 __global__ __launch_bounds__(1024) void list_mle_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int L, int P, float temperature,
-    float* __restrict__ loss_out, float* __restrict__ dlogits_out) {
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(1024) void list_mle_block_kernel(
   }
   const float loss = block_sum(term, red);
   if (tid == 0) loss_out[b] = loss;
+  if (sum.out && tid < 64) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, tid);
   if (!dlogits_out) return;
   __syncthreads();
   block_scan_inclusive(CA, XS, P, ScanAdd());                     // C_p = sum_{q <= p} w_q / S_q
@@ -502,7 +505,7 @@ __global__ __launch_bounds__(1024) void list_mle_block_kernel(
 __global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ list_scale, int L, int P, float temperature, float* __restrict__ loss_out,
-    float* __restrict__ dlogits_out) {
+    float* __restrict__ dlogits_out, const GridSum sum) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
@@ -568,6 +571,7 @@ __global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
   }
   const float loss = block_sum(term, red);
   if (tid == 0) loss_out[b] = loss;
+  if (sum.out && tid < 64) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, tid);
   if (!dlogits_out) return;
   __syncthreads();
   block_scan_inclusive(CA, SB, P, ScanAdd());                     // inclusive prefix of g / D
@@ -684,12 +688,14 @@ __global__ __launch_bounds__(1024) void circle_block_kernel(
 
 }  // namespace
 
-extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
-                                const float* pos_weight, const float* list_scale, int B, int L,
-                                float temperature, float* loss_out, float* dlogits_out, void* stream) {
+static int list_mle_dispatch(const float* logits, const float* labels, const uint8_t* mask,
+                             const float* pos_weight, const float* list_scale, int B, int L,
+                             float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                             void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 24 B of LDS per item in the workgroup kernel
-  if (B == 0) return TFR_OK;
+  if (B == 0) return loss_sum_out ? (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream) : TFR_OK;
+  const GridSum sum = {loss_sum_out, loss_out, ticket, B};
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
     const int P = pow2_ceil(L);
@@ -697,21 +703,38 @@ extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_mle_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(list_mle_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, pos_weight, list_scale, L, P,
-                       temperature, loss_out, dlogits_out);
+                       temperature, loss_out, dlogits_out, sum);
     return (int)hipGetLastError();
   }
-#define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out)
+#define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out, sum)
   if (L <= 64) LM(1); else if (L <= 128) LM(2); else if (L <= 256) LM(4); else if (L <= 512) LM(8); else LM(16);
 #undef LM
   return (int)hipGetLastError();
 }
 
-extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
-                                      const float* list_scale, int B, int L, float temperature,
-                                      float* loss_out, float* dlogits_out, void* stream) {
+extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                const float* pos_weight, const float* list_scale, int B, int L,
+                                float temperature, float* loss_out, float* dlogits_out, void* stream) {
+  return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out, nullptr,
+                           nullptr, stream);
+}
+
+extern "C" int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                    const float* pos_weight, const float* list_scale, int B, int L,
+                                    float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
+                                    uint32_t* ticket, void* stream) {
+  if (!loss_sum_out || !ticket) return TFR_EINVAL;
+  return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out,
+                           loss_sum_out, ticket, stream);
+}
+
+static int unique_softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
+                                   const float* list_scale, int B, int L, float temperature,
+                                   float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 36 B of LDS per item in the workgroup kernel
-  if (B == 0) return TFR_OK;
+  if (B == 0) return loss_sum_out ? (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream) : TFR_OK;
+  const GridSum sum = {loss_sum_out, loss_out, ticket, B};
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
     const int P = pow2_ceil(L);
@@ -719,13 +742,29 @@ extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, 
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unique_softmax_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(unique_softmax_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, list_scale, L, P,
-                       temperature, loss_out, dlogits_out);
+                       temperature, loss_out, dlogits_out, sum);
     return (int)hipGetLastError();
   }
-#define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out)
+#define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out, sum)
   if (L <= 64) US(1); else if (L <= 128) US(2); else if (L <= 256) US(4); else if (L <= 512) US(8); else US(16);
 #undef US
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                      const float* list_scale, int B, int L, float temperature,
+                                      float* loss_out, float* dlogits_out, void* stream) {
+  return unique_softmax_dispatch(logits, labels, mask, list_scale, B, L, temperature, loss_out, dlogits_out, nullptr, nullptr,
+                                 stream);
+}
+
+extern "C" int tfr_unique_softmax_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* list_scale, int B, int L, float temperature,
+                                          float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                                          void* stream) {
+  if (!loss_sum_out || !ticket) return TFR_EINVAL;
+  return unique_softmax_dispatch(logits, labels, mask, list_scale, B, L, temperature, loss_out, dlogits_out, loss_sum_out,
+                                 ticket, stream);
 }
 
 extern "C" int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,

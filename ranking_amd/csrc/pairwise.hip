@@ -35,6 +35,7 @@ struct PwArgs {
   float* row_loss; float* row_weight; float* nnz; float* dlogits;
   float* list_loss;                      // nullable [B]: sum of the row losses of a list
   const int* order;                      // longest-first launch order (nullable)
+  GridSum sum;                           // round 5: sum_b list_loss[b] from the same launch (tfr_pairwise_loss_sum_f32); out == NULL: off
 };
 
 __host__ __device__ inline size_t pw_wave_lds(int Lp) { return (size_t)Lp * (16 + 8 + 4 + 4 + 4) + 16; }
@@ -354,6 +355,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
   if (a.list_loss) {
     list_local = block_sum(list_local, red);
     if (tid == 0) a.list_loss[b] = list_local;
+    if (a.sum.out && tid < 64) grid_sum_contribute(a.sum, b, list_local, tid);     // wave 0; the value is block-uniform
   }
 }
 
@@ -424,6 +426,7 @@ __device__ __forceinline__ void pw_finish(const PwArgs& a, int b, int lane, int 
       if (AUX && a.nnz) a.nnz[b] = nz;
       if (want_list) a.list_loss[b] = ls;
     }
+    if (want_list && a.sum.out) grid_sum_contribute(a.sum, b, ls, lane);
     return;
   }
   if (lane == 0) { slots[wave] = nz; slots[S + wave] = ls; }
@@ -433,6 +436,11 @@ __device__ __forceinline__ void pw_finish(const PwArgs& a, int b, int lane, int 
     for (int w2 = 0; w2 < S; ++w2) { t += slots[w2]; u += slots[S + w2]; }
     if (AUX && a.nnz) a.nnz[b] = t;
     if (want_list) a.list_loss[b] = u;
+  }
+  if (want_list && a.sum.out && wave == 0) {                  // the same sum, in the same order, in every lane of wave 0
+    float u = 0.f;
+    for (int w2 = 0; w2 < S; ++w2) u += slots[S + w2];
+    grid_sum_contribute(a.sum, b, u, lane);
   }
 }
 
@@ -1115,8 +1123,10 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          int normalized, int gain_kind, const float* gains,
                                          const float* discount, int B, int L, float temperature,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
-                                         float* dlogits_out, const int* order, float* list_loss_out, void* stream) {
+                                         float* dlogits_out, const int* order, float* list_loss_out, void* stream,
+                                         float* loss_sum_out = nullptr, uint32_t* ticket = nullptr) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
+  if (loss_sum_out && (!list_loss_out || !ticket)) return TFR_EINVAL;       // the per-list sums are the entries that are added up
   if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_MSE) return TFR_EINVAL;
   if (lambda_kind < TFR_LAMBDA_NONE || lambda_kind > TFR_LAMBDA_PRECISION) return TFR_EINVAL;
   // DCGLambdaWeightV2 / YetiDCGLambdaWeight / PrecisionLambdaWeight run as sub-kinds of the generic DCG path
@@ -1133,7 +1143,11 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
     if (!(smooth_fraction >= 0.0f && smooth_fraction <= 1.0f)) return TFR_EINVAL;   // :329-331
   }
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
-  if (B == 0) return TFR_OK;
+  if (B == 0) {
+    if (loss_sum_out) return (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream);
+    return TFR_OK;
+  }
+  const GridSum gsum = {loss_sum_out, list_loss_out, ticket, B};
   static const int env_threads = env_int("TFR_PAIRWISE_THREADS", 0);
   static const int env_lanes = env_int("TFR_PAIRWISE_LANES", 0);
   static const int env_wave = env_int("TFR_PAIRWISE_WAVE", 1);
@@ -1147,7 +1161,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
     const int c2 = (2 * C > 4) ? 2 * C : 4;
     w.discount = discount; w.L = L; w.Lp = ((L + c2 - 1) / c2) * c2 + 4; w.P = 0;
     w.temperature = temperature; w.C = C; w.kind = kind; w.row_loss = row_loss_out; w.row_weight = row_weight_out;
-    w.nnz = nnz_out; w.dlogits = dlogits_out; w.order = order; w.list_loss = list_loss_out;
+    w.nnz = nnz_out; w.dlogits = dlogits_out; w.order = order; w.list_loss = list_loss_out; w.sum = gsum;
     hipStream_t st = (hipStream_t)stream;
     if (L <= 64) return launch_pw_wave<1>(w, B, st);
     if (L <= 128) return launch_pw_wave<2>(w, B, st);
@@ -1161,7 +1175,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   a.smooth = smooth_fraction; a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains;
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
   a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
-  a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order; a.list_loss = list_loss_out;
+  a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order; a.list_loss = list_loss_out; a.sum = gsum;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
   const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
@@ -1208,6 +1222,21 @@ extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const f
   return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
                            row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream);
+}
+
+extern "C" int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
+                                         const float* item_weights, const float* list_weights,
+                                         int lambda_kind, int topn, float smooth_fraction,
+                                         int normalized, int gain_kind, const float* gains,
+                                         const float* discount, int B, int L, float temperature,
+                                         float* row_loss_out, float* row_weight_out, float* nnz_out,
+                                         float* dlogits_out, const int32_t* list_order, float* list_loss_out,
+                                         float* loss_sum_out, uint32_t* ticket, void* stream) {
+  if (!loss_sum_out || !ticket || !list_loss_out) return TFR_EINVAL;
+  return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
+                           smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream,
+                           loss_sum_out, ticket);
 }
 
 #ifdef TFR_PROFILE_STAMPS

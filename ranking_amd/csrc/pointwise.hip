@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void pointwise_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ item_weights, const float* __restrict__ list_weights, int B, int L, float temperature,
     float* __restrict__ list_loss, float* __restrict__ list_weight, float* __restrict__ list_nnz,
-    float* __restrict__ dlogits) {
+    float* __restrict__ dlogits, const GridSum sum) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void pointwise_wave_kernel(
     if (list_weight) list_weight[b] = sw;
     if (list_nnz) list_nnz[b] = nz;
   }
+  if (sum.out) grid_sum_contribute(sum, b, sl, lane);        // sum_b list_loss[b] from the same launch (round 5)
 }
 
 // out[0] = sum_i x_i * w_i (w nullable: plain sum) over n <= 65536 values: the scalar reduction of a per-list loss
@@ -122,20 +123,39 @@ __global__ __launch_bounds__(1024) void list_dot_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int tfr_pointwise_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
-                                      const float* item_weights, const float* list_weights, int B, int L,
-                                      float temperature, float* list_loss_out, float* list_weight_out,
-                                      float* list_nnz_out, float* dlogits_out, void* stream) {
+static int pointwise_dispatch(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                              const float* item_weights, const float* list_weights, int B, int L,
+                              float temperature, float* list_loss_out, float* list_weight_out,
+                              float* list_nnz_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket, void* stream) {
   if (!logits || !labels || !list_loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (kind != TFR_POINT_SIGMOID_CE && kind != TFR_POINT_MSE) return TFR_EINVAL;
-  if (B == 0) return TFR_OK;
+  if (B == 0) return loss_sum_out ? (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream) : TFR_OK;
+  const GridSum sum = {loss_sum_out, list_loss_out, ticket, B};
   hipStream_t st = (hipStream_t)stream;
-#define PW(K, I) hipLaunchKernelGGL((pointwise_wave_kernel<K, I>), dim3((B + 3) / 4), dim3(256), 0, st, logits, labels, mask, item_weights, list_weights, B, L, temperature, list_loss_out, list_weight_out, list_nnz_out, dlogits_out)
+#define PW(K, I) hipLaunchKernelGGL((pointwise_wave_kernel<K, I>), dim3((B + 3) / 4), dim3(256), 0, st, logits, labels, mask, item_weights, list_weights, B, L, temperature, list_loss_out, list_weight_out, list_nnz_out, dlogits_out, sum)
 #define PW_K(K) do { if (L <= 64) PW(K, 1); else if (L <= 128) PW(K, 2); else if (L <= 256) PW(K, 4); else if (L <= 512) PW(K, 8); else if (L <= 1024) PW(K, 16); else PW(K, 0); } while (0)
   if (kind == TFR_POINT_SIGMOID_CE) PW_K(TFR_POINT_SIGMOID_CE); else PW_K(TFR_POINT_MSE);
 #undef PW_K
 #undef PW
   return (int)hipGetLastError();
+}
+
+extern "C" int tfr_pointwise_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                                      const float* item_weights, const float* list_weights, int B, int L,
+                                      float temperature, float* list_loss_out, float* list_weight_out,
+                                      float* list_nnz_out, float* dlogits_out, void* stream) {
+  return pointwise_dispatch(kind, logits, labels, mask, item_weights, list_weights, B, L, temperature, list_loss_out,
+                            list_weight_out, list_nnz_out, dlogits_out, nullptr, nullptr, stream);
+}
+
+extern "C" int tfr_pointwise_loss_sum_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* item_weights, const float* list_weights, int B, int L,
+                                          float temperature, float* list_loss_out, float* list_weight_out,
+                                          float* list_nnz_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                                          void* stream) {
+  if (!loss_sum_out || !ticket) return TFR_EINVAL;
+  return pointwise_dispatch(kind, logits, labels, mask, item_weights, list_weights, B, L, temperature, list_loss_out,
+                            list_weight_out, list_nnz_out, dlogits_out, loss_sum_out, ticket, stream);
 }
 
 extern "C" int tfr_list_dot_f32(const float* x, const float* w, int n, float* out, void* stream) {

@@ -23,6 +23,7 @@ struct SmArgs {
   const float* gains; const float* discount; int L; int Lp; int P; float temperature;
   float* loss; float* weight; float* dlogits;
   float poly_eps;                 // PolyOneSoftmaxLoss (losses_impl.py:1200-1247): loss += eps * (1 - sum_i p_i softmax_i)
+  GridSum sum;                    // round 5: sum_b loss_b * weight_b from the same launch (tfr_softmax_loss_sum_f32); out == NULL: off
 };
 
 __global__ void softmax_loss_kernel(const SmArgs a) {
@@ -129,6 +130,7 @@ __global__ void softmax_loss_kernel(const SmArgs a) {
     loss += a.poly_eps * (1.0f - pt);
   }
   if (tid == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
+  if (a.sum.out && tid < 64) grid_sum_contribute(a.sum, b, loss * lsum, tid);      // (wave 0, converged; values are block-uniform)
   if (!a.dlogits) return;
   // ---- backward: d(weight * loss)/d logits_k = (w/T) (sum_p * softmax_k - p_k), valid k;
   // poly-1 adds  -eps * softmax_k * (p_k - pt).
@@ -398,6 +400,7 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
     loss += a.poly_eps * (1.0f - pt);
   }
   if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
+  if (a.sum.out) grid_sum_contribute(a.sum, b, loss * lsum, lane);     // one contributor per list
   if (!a.dlogits) return;
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
@@ -431,6 +434,8 @@ __global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int
   const int lane = threadIdx.x & 63;
   const int W = gridDim.x * 4;
   int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));     // (the grid never exceeds the lists: b < B)
+  const int wave_id = b;
+  float wsum = 0.f;                                      // sum of loss * weight over this wave's lists, in the order it walks them
   const int L = a.L;
   const float inv_t = 1.0f / a.temperature;
   int off[IPL];
@@ -509,6 +514,7 @@ __global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int
         loss += a.poly_eps * (1.0f - pt);
       }
       a.loss[cur] = loss; a.weight[cur] = lsum;            // (every lane, one address, one value)
+      wsum = __builtin_fmaf(loss, lsum, wsum);
       float g[IPL];
 #pragma unroll
       for (int r = 0; r < IPL; ++r) {
@@ -532,9 +538,11 @@ __global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int
   }
 #pragma unroll
   for (int d = 0; d < D; ++d) {                          // the last fewer-than-D lists of this wave
-    if (b + d * W >= B) return;
-    one_list(d, b + d * W, false);
+    if (b + d * W < B) one_list(d, b + d * W, false);
   }
+  // one contributor per WAVE (W of them; the walk order of a wave is fixed by the grid, so the sum is reproducible for a
+  // given launch geometry): a ticket per list would put two dependent memory round trips into every trip of the stream
+  if (a.sum.out) grid_sum_contribute(a.sum, wave_id, wsum, lane);
 }
 
 }  // namespace
@@ -544,6 +552,12 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
                                           int topn, int normalized, int gain_kind, const float* gains,
                                           const float* discount, int B, int L, float temperature, float epsilon,
                                           float* loss_out, float* weight_out, float* dlogits_out, void* stream);
+static int softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
+                            const float* item_weights, int weights_per_list, int lambda_kind,
+                            int topn, int normalized, int gain_kind, const float* gains,
+                            const float* discount, int B, int L, float temperature, float epsilon,
+                            float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
+                            float* sum_scratch, uint32_t* ticket, void* stream);
 
 extern "C" int tfr_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                                     const float* item_weights, int weights_per_list, int lambda_kind,
@@ -561,14 +575,41 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
                                           int topn, int normalized, int gain_kind, const float* gains,
                                           const float* discount, int B, int L, float temperature, float epsilon,
                                           float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
+  return softmax_dispatch(logits, labels, mask, item_weights, weights_per_list, lambda_kind, topn, normalized, gain_kind,
+                          gains, discount, B, L, temperature, epsilon, loss_out, weight_out, dlogits_out, nullptr, nullptr,
+                          nullptr, stream);
+}
+
+extern "C" int tfr_softmax_loss_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                        const float* item_weights, int weights_per_list, int lambda_kind,
+                                        int topn, int normalized, int gain_kind, const float* gains,
+                                        const float* discount, int B, int L, float temperature, float epsilon,
+                                        float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
+                                        float* sum_scratch, uint32_t* ticket, void* stream) {
+  if (!loss_sum_out || !sum_scratch || !ticket) return TFR_EINVAL;
+  return softmax_dispatch(logits, labels, mask, item_weights, weights_per_list, lambda_kind, topn, normalized, gain_kind,
+                          gains, discount, B, L, temperature, epsilon, loss_out, weight_out, dlogits_out, loss_sum_out,
+                          sum_scratch, ticket, stream);
+}
+
+static int softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
+                            const float* item_weights, int weights_per_list, int lambda_kind,
+                            int topn, int normalized, int gain_kind, const float* gains,
+                            const float* discount, int B, int L, float temperature, float epsilon,
+                            float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
+                            float* sum_scratch, uint32_t* ticket, void* stream) {
   if (!logits || !labels || !loss_out || !weight_out || B < 0 || L <= 0 || !(temperature > 0.0f))
     return TFR_EINVAL;
   if (lambda_kind != TFR_LAMBDA_NONE && lambda_kind != TFR_LAMBDA_DCG) return TFR_EINVAL;
   if (lambda_kind == TFR_LAMBDA_DCG && (!discount || (gain_kind == TFR_GAIN_CUSTOM && !gains)))
     return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
-  if (B == 0) return TFR_OK;
+  if (B == 0) {
+    if (loss_sum_out) return (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream);
+    return TFR_OK;
+  }
   SmArgs a;
+  a.sum.out = loss_sum_out; a.sum.vec = sum_scratch; a.sum.st = ticket; a.sum.n = B;      // one contributor per list ...
   a.logits = logits; a.labels = labels; a.mask = mask; a.item_weights = item_weights;
   a.weights_per_list = weights_per_list; a.lambda_kind = lambda_kind; a.topn = topn;
   a.normalized = normalized; a.gain_kind = gain_kind; a.gains = gains; a.discount = discount;
@@ -584,6 +625,7 @@ extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labe
     if (env_stream && !mask && (!item_weights || weights_per_list) && dlogits_out && L <= 256 &&
         (B + 3) / 4 > env_groups && env_groups >= 1) {
       static const int env_depth = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_DEPTH"); return (e && *e) ? atoi(e) : 2; }();
+      a.sum.n = env_groups * 4;                                     // ... per wave in the streaming form
 #define SMK(I, N, D, W) hipLaunchKernelGGL((softmax_stream_kernel<I, N, D, W>), dim3(env_groups), dim3(256), 0, st, a, B)
 #define SMS(I, D) do { if (item_weights) { if (nt) SMK(I, true, D, true); else SMK(I, false, D, true); } \
                        else { if (nt) SMK(I, true, D, false); else SMK(I, false, D, false); } } while (0)

@@ -1259,7 +1259,7 @@ inline int block_threads_for(int P) {
 
 }  // namespace
 
-extern "C" int tfr_hip_abi_version(void) { return 1; }
+extern "C" int tfr_hip_abi_version(void) { return TFR_HIP_ABI_VERSION; }
 
 extern "C" int tfr_sort_ranks_f32(const float* scores, const float* labels, const uint8_t* mask,
                                   const int32_t* tiebreak, int B, int L, int32_t* ranks_out,

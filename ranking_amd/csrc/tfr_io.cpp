@@ -657,7 +657,7 @@ int decode_seq(const uint8_t* b, size_t n, int list_size, const SpecTable& ex, c
 
 }  // namespace
 
-extern "C" int tfr_io_abi_version(void) { return 1; }
+extern "C" int tfr_io_abi_version(void) { return TFR_IO_ABI_VERSION; }
 
 extern "C" uint32_t tfr_io_crc32c(const uint8_t* data, size_t n) { return crc32c(data, n); }
 extern "C" uint32_t tfr_io_crc32c_portable(const uint8_t* data, size_t n) { return crc32c_sliced(data, n); }
@@ -714,7 +714,11 @@ static inline uint16_t bf16_rne(uint32_t u) {              // branch-free: the l
 }
 
 // one clone per vector ISA, picked at load time (the parser's other loops are byte walks: nothing to gain there)
+// (x86-64 GCC only: target_clones needs ifunc support and `optimize` is a GCC attribute -- any other host compiler /
+// architecture takes the plain loop at the translation unit's optimisation level)
+#if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__) && defined(__gnu_linux__)
 __attribute__((target_clones("arch=skylake-avx512", "avx2", "default"), optimize("O3")))
+#endif
 void f32_to_bf16_loop(const uint32_t* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
   for (size_t i = 0; i < n; ++i) dst[i] = bf16_rne(src[i]);
 }

@@ -333,10 +333,17 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
                 item_w = sample_weight
             else:
                 list_w = list_w * torch.broadcast_to(sample_weight.reshape(-1), (b,))
-        _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
+        if not _LOSS_SUM_FUSED:
+            _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
+                y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
+                want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind, **lam)
+            return _ops.list_dot(list_loss), dlogits       # [B] per-list sums: nothing [B, L]-sized for the loss
+        # the reduced scalar out of the same launch (round 5: every loss, not only ApproxNDCG)
+        _, _, _, dlogits, _, total = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-            want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind, **lam)
-        return _ops.list_dot(list_loss), dlogits           # [B] per-list sums: nothing [B, L]-sized for the loss
+            want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind,
+            want_sum=True, **lam)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()
@@ -429,10 +436,15 @@ class SoftmaxLoss(_ListwiseLoss):
         scale = self._scale(b)
         w = _const_vector(b, scale, y_pred.device) if sample_weight is None else sample_weight * scale
         lam = self._loss._lambda_args(y_true, y_pred, mask)      # only a DCGLambdaWeight is active, like __call__
-        loss, weight, dlogits = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
-                                                  temperature=self._temperature, want_grad=True,
-                                                  poly_epsilon=self._loss._poly_epsilon, **lam)
-        return _ops.list_dot(loss, weight), dlogits
+        if not _LOSS_SUM_FUSED:
+            loss, weight, dlogits = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
+                                                      temperature=self._temperature, want_grad=True,
+                                                      poly_epsilon=self._loss._poly_epsilon, **lam)
+            return _ops.list_dot(loss, weight), dlogits
+        _, _, dlogits, total = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
+                                                 temperature=self._temperature, want_grad=True,
+                                                 poly_epsilon=self._loss._poly_epsilon, want_sum=True, **lam)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()
@@ -535,8 +547,12 @@ class UniqueSoftmaxLoss(ApproxNDCGLoss):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
-        loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
-        return _ops.list_dot(loss, list_scale), dlogits
+        if not _LOSS_SUM_FUSED:
+            loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
+            return _ops.list_dot(loss, list_scale), dlogits
+        _, dlogits, total = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True,
+                                                want_sum=True)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()
@@ -560,8 +576,12 @@ class ListMLELoss(ApproxNDCGLoss):
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         pw = self._loss._pos_weight(y_pred.shape[1], y_pred.device)
-        loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
-        return _ops.list_dot(loss, list_scale), dlogits
+        if not _LOSS_SUM_FUSED:
+            loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
+            return _ops.list_dot(loss, list_scale), dlogits
+        _, dlogits, total = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True,
+                                          want_sum=True)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()
@@ -690,9 +710,13 @@ class _PointwiseLoss(_RankingLoss):
         scale = self._scale(b * l)
         item_w, list_w = self._weights_args(sample_weight, b, l, y_pred.device)
         list_w = _const_vector(b, scale, y_pred.device) if list_w is None else list_w * scale
-        loss, _, _, dlogits = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w, list_w,
-                                                  self._loss._temperature, True)
-        return _ops.list_dot(loss), dlogits
+        if not _LOSS_SUM_FUSED:
+            loss, _, _, dlogits = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w,
+                                                      list_w, self._loss._temperature, True)
+            return _ops.list_dot(loss), dlogits
+        _, _, _, dlogits, total = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w,
+                                                      list_w, self._loss._temperature, True, want_sum=True)
+        return total, dlogits
 
 
 @utils.register_keras_serializable()

@@ -28,7 +28,7 @@ def test_io_header_and_library_agree():
     for n in names:
         assert hasattr(lib, n), n
     assert names == sorted(_io_lib.EXPORTED_SYMBOLS)
-    assert lib.tfr_io_abi_version() >= 1
+    assert lib.tfr_io_abi_version() == _io_lib.ABI_VERSION == 2
 
 
 def test_crc32c_known_answers():

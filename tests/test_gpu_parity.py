@@ -118,12 +118,132 @@ def test_approx_ndcg_reduced_scalar_from_the_same_launch(B, L):
     got = totals[0].item()
     assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (got, want)
     assert torch.equal(totals[0], totals[1]) and torch.equal(totals[1], totals[2])
-    state = _ops._device_state[('loss_sum', str(lb.device))]
     torch.cuda.synchronize()
-    assert int(state[:65].abs().sum().item()) == 0            # group tickets and the top ticket are back to zero
+    _assert_tickets_zero()
     # without a scale vector: the plain sum
     _, _, _, t2 = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True, want_sum=True)
     assert abs(t2.item() - loss0.double().sum().item()) <= 2e-6 * max(1.0, abs(loss0.double().sum().item()))
+
+
+def _assert_tickets_zero():
+    """every ticket state of the process (one per stream that launched eagerly + the shared one of captured launches):
+    group tickets and the top ticket are back to zero after a launch"""
+    from ranking_amd import _ops
+    states = [t for k, t in _ops._device_state.items() if k[0] == 'loss_sum']
+    assert states
+    for t in states:
+        assert int(t[:65].abs().sum().item()) == 0
+
+
+def _sum_case(name, B, L):
+    """(plain call -> outputs, sum call -> outputs + total, fp64 reference of the total from the plain outputs)"""
+    from ranking_amd import _ops
+    from ranking_amd.keras import losses as K
+    from ranking_amd import losses_impl
+    labels, logits = make_batch(B, L, seed=900 + B + L)
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    g = torch.Generator().manual_seed(B + L)
+    scale = (torch.rand(B, generator=g) + 0.5).to(DEV)
+    if name == 'softmax':
+        run = lambda s: _ops.softmax_loss(lg, lb, None, scale, temperature=1.0, want_grad=True, want_sum=s)
+        ref = lambda o: (o[0].double() * o[1].double()).sum().item()
+    elif name == 'softmax_lambda':            # DCGLambdaWeight.individual_weights: the workgroup kernel
+        lam = dict(lambda_kind=_ops.LAMBDA_DCG, normalized=True, gain_kind=_ops.GAIN_POW2M1,
+                   discount=_ops.rank_table(lambda r: 1.0 / torch.log1p(r), L, DEV))
+        run = lambda s: _ops.softmax_loss(lg, lb, None, scale, temperature=1.0, want_grad=True, want_sum=s, **lam)
+        ref = lambda o: (o[0].double() * o[1].double()).sum().item()
+    elif name in ('pairwise_lambda', 'pairwise_plain', 'pairwise_topn'):
+        lw = K.NDCGLambdaWeight(topn=5 if name == 'pairwise_topn' else None) if name != 'pairwise_plain' else None
+        lam = losses_impl._lambda_kernel_args(lw, lb, L, lg.device)
+        run = lambda s: _ops.pairwise_logistic(lg, lb, None, None, scale, temperature=1.0, want_grad=True, want_rows=False,
+                                               want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC,
+                                               want_sum=s, **lam)
+        ref = lambda o: o[4].double().sum().item()
+    elif name == 'list_mle':
+        run = lambda s: _ops.list_mle(lg, lb, None, None, scale, 1.0, True, want_sum=s)
+        ref = lambda o: (o[0].double() * scale.double()).sum().item()
+    elif name == 'unique_softmax':
+        run = lambda s: _ops.unique_softmax(lg, lb, None, scale, 1.0, True, want_sum=s)
+        ref = lambda o: (o[0].double() * scale.double()).sum().item()
+    elif name == 'pointwise':
+        run = lambda s: _ops.pointwise_loss(_ops.POINT_SIGMOID_CE, lg, lb, None, None, scale, 1.0, True, want_sum=s)
+        ref = lambda o: o[0].double().sum().item()
+    else:
+        raise ValueError(name)
+    return run, ref
+
+
+# every kernel family that carries the in-launch sum: softmax wave / streaming (B > 8192) / workgroup (lambda) kernels,
+# LambdaRank group kernel (B >= 512), lean + generic wave kernels, the workgroup pairwise kernel (L > 256), ListMLE and
+# UniqueSoftmax wave (L <= 1024) and workgroup kernels, the pointwise kernel; batches that leave ticket groups ragged
+@pytest.mark.parametrize('name,B,L', [
+    ('softmax', 1, 5), ('softmax', 70, 100), ('softmax', 4099, 100), ('softmax', 20011, 129), ('softmax', 9000, 40),
+    ('softmax', 3, 1500), ('softmax_lambda', 67, 120),
+    ('pairwise_lambda', 4096, 200), ('pairwise_lambda', 700, 130), ('pairwise_lambda', 65, 200), ('pairwise_lambda', 3, 7),
+    ('pairwise_plain', 130, 60), ('pairwise_topn', 130, 60), ('pairwise_lambda', 5, 300),
+    ('list_mle', 131, 70), ('list_mle', 3, 1100), ('unique_softmax', 131, 70), ('unique_softmax', 3, 1100),
+    ('pointwise', 257, 32), ('pointwise', 5, 1200),
+])
+def test_reduced_scalar_from_the_loss_launch(name, B, L):
+    """tfr_*_sum_f32 (round 5): the reduced scalar of every loss comes out of the loss launch (no tfr_list_dot_f32
+    launch): equal to the fp64 sum of the per-list values, the same bits on every call, every other output unchanged bit
+    for bit, ticket state left zero."""
+    run, ref = _sum_case(name, B, L)
+    plain = run(False)
+    want = ref(plain)
+    totals = []
+    for _ in range(3):
+        out = run(True)
+        for a, b in zip(plain, out[:len(plain)]):
+            assert (a is None and b is None) or torch.equal(a, b)
+        totals.append(out[-1].clone())
+    got = totals[0].item()
+    record_margin('reduced scalar %s B=%d L=%d' % (name, B, L), abs(got - want), 2e-6 * max(1.0, abs(want)))
+    assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (name, got, want)
+    assert torch.equal(totals[0], totals[1]) and torch.equal(totals[1], totals[2])
+    torch.cuda.synchronize()
+    _assert_tickets_zero()
+
+
+def test_reduced_scalar_stress_across_streams():
+    """(a) a batch far beyond one ticket group (16 384 + 37 lists spread over all XCDs), 20 launches, the same
+    bits every time and the fp64 sum within 2e-6; (b) two streams launching the same loss concurrently each use their OWN
+    ticket state (one per stream in flight) and both get their own correct totals."""
+    from ranking_amd import _ops
+    B, L = 16384 + 37, 200
+    labels, logits = make_batch(B, L, seed=77)
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    scale = (torch.rand(B, generator=torch.Generator().manual_seed(3)) + 0.5).to(DEV)
+    loss0, _, _ = _ops.approx_ndcg(lg, lb, None, scale, 0.1, 0, True)
+    want = (loss0.double() * scale.double()).sum().item()
+    first = None
+    for _ in range(20):
+        total = _ops.approx_ndcg(lg, lb, None, scale, 0.1, 0, True, want_sum=True)[3]
+        first = total.clone() if first is None else first
+        assert torch.equal(total, first)
+    assert abs(first.item() - want) <= 2e-6 * max(1.0, abs(want))
+    # two streams, interleaved launches of two different batches
+    lb2, lg2 = make_batch(4096, 100, seed=78)
+    lb2, lg2 = lb2.to(DEV), lg2.to(DEV)
+    w2 = torch.full((4096,), 1.0 / 4096, device=DEV)
+    p2 = _ops.softmax_loss(lg2, lb2, None, w2, want_grad=True)
+    want2 = (p2[0].double() * p2[1].double()).sum().item()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    r1, r2 = [], []
+    for _ in range(10):
+        with torch.cuda.stream(s1):
+            r1.append(_ops.approx_ndcg(lg, lb, None, scale, 0.1, 0, True, want_sum=True)[3])
+        with torch.cuda.stream(s2):
+            r2.append(_ops.softmax_loss(lg2, lb2, None, w2, want_grad=True, want_sum=True)[3])
+    torch.cuda.synchronize()
+    keys = [k for k in _ops._device_state if k[0] == 'loss_sum' and len(k) == 3]
+    assert len({k[2] for k in keys}) >= 2                     # one ticket state per launching stream
+    for t in r1:
+        assert torch.equal(t, first)
+    for t in r2:
+        assert abs(t.item() - want2) <= 2e-6 * max(1.0, abs(want2)) and torch.equal(t, r2[0])
+    _assert_tickets_zero()
 
 
 # ---------------------------------------------------------------------- metrics

@@ -26,7 +26,10 @@ def test_header_and_library_agree():
     for n in names:
         assert hasattr(lib, n), 'libtfr_hip.so does not export %s' % n
     assert sorted(_lib.EXPORTED_SYMBOLS) == names
-    assert lib.tfr_hip_abi_version() >= 1
+    # one version number in three places: the header's constant, what the library was compiled with, what the binding expects
+    hdr = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
+    want = int(re.search(r'#define\s+TFR_HIP_ABI_VERSION\s+(\d+)', hdr).group(1))
+    assert lib.tfr_hip_abi_version() == want == _lib.ABI_VERSION
 
 
 def test_library_is_in_tree_and_for_gfx950():
@@ -67,6 +70,15 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     # B == 0 is a no-op
     assert lib.tfr_softmax_loss_f32(one, one, None, None, 0, 0, 0, 0, 0, None, None, 0, 8, 1.0, one, one,
                                     None, None) == 0
+    # the reduced-scalar entry points (round 5) need their sum / ticket (/ scratch) buffers
+    assert lib.tfr_softmax_loss_sum_f32(one, one, None, None, 0, 0, 0, 0, 0, None, None, 1, 8, 1.0, 0.0, one, one,
+                                        None, None, one, one, None) == -1
+    assert lib.tfr_pairwise_loss_sum_f32(0, one, one, None, None, None, 0, 0, 0.0, 0, 0, None, None, 1, 8, 1.0,
+                                         None, None, None, None, None, None, one, one, None) == -1     # no list_loss_out
+    assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, None) == -1
+    assert lib.tfr_unique_softmax_sum_f32(one, one, None, None, 1, 8, 1.0, one, None, None, one, None) == -1
+    assert lib.tfr_pointwise_loss_sum_f32(0, one, one, None, None, None, 1, 8, 1.0, one, None, None, None, None, one,
+                                          None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, 'x')
     with pytest.raises(ValueError):
