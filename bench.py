@@ -17,13 +17,15 @@ reduction the Keras call returns).
 ranks with no data-path collective -> "scaling": "weak"; the
 end-to-end workloads (`e2e_*`) run ONE all-reduce of the flat gradient bucket per
 step and report its time separately.  Rank 0 prints the JSON line of the main workload as soon as it is measured; with
-`--also` (the default set is the BASELINE multi-GPU configs 4 and 5, the pairwise
-kernel north_star names, and the two HBM-bound kernels -- Softmax, NDCG metric -- on
-a 1.3 GB cycled working set) every extra workload then runs in its OWN child
+`--also` (the default set at N = 1 is every other BASELINE configuration -- 2 and 3 end to end, the pairwise
+kernel north_star names, the per-GPU shards of the multi-GPU configs 4 and 5 -- and the two HBM-bound kernels
+-- Softmax, NDCG metric -- on a 1.3 GB cycled working set; at N > 1 the end-to-end workloads, whose step contains
+the all-reduce, first) every extra workload then runs in its OWN child
 process (own HIP context and timeout: a faulting extra costs one entry, never the
 headline) and the same line is printed once more, last, with them under "also".
-Every workload entry has `roofline` (dominant kernel, HIP events) and, at N = 1,
-`cpu_baseline` (the oracle on a bounded sample on the host cores).
+Every workload entry has `roofline` (dominant kernel, HIP events), `steady_state` (the same step replayed for
+seconds after the timed steps: 10 s for the main workload, which also makes the GPU phase visible to a utilisation
+sampler) and, at N = 1, `cpu_baseline` (the oracle on a bounded sample on the host cores).
 """
 from __future__ import annotations
 
@@ -43,7 +45,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense bf16 MFMA peak (2.5 PFLOP/s)
-TRAFFIC_FILES = ('profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json')     # newest first
+TRAFFIC_FILES = ('profiles/r05_traffic.json', 'profiles/r04_traffic.json', 'profiles/r03_traffic.json', 'profiles/r02_traffic.json', 'profiles/r01_traffic.json')     # newest first
 
 WORKLOADS = {
     # name: (B per GPU, L, description, algorithmic HBM bytes per list -- SURVEY.md 8d)
@@ -72,7 +74,14 @@ WORKLOADS = {
                                       'GumbelApproxNDCGLoss(S=8), 512 lists/GPU, L=50, 1 all-reduce/step',
                              lambda L: 0),
 }
-DEFAULT_ALSO = ('pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel', 'softmax_hbm', 'ndcg_metric_hbm')
+# N = 1: every BASELINE single-GPU configuration (2 = e2e_softmax, 3 = pairwise_lambda loss-only and end to end), the
+# multi-GPU configurations' per-GPU shards (4, 5) and the two HBM-bound kernels.  N > 1: the workloads whose step contains
+# the all-reduce FIRST (config 4 is the curve north_star asks for), then the loss-only pairwise kernel; the *_hbm lines
+# do not depend on N and are left to the N = 1 run.
+DEFAULT_ALSO = ('pairwise_lambda', 'e2e_softmax', 'e2e_pairwise_lambda', 'e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel',
+                'softmax_hbm', 'ndcg_metric_hbm')
+DEFAULT_ALSO_MULTI = ('e2e_approx_ndcg_l1000', 'e2e_groupwise_gumbel', 'e2e_softmax', 'pairwise_lambda')
+CHILD_BUSY_SECONDS = 1.5       # every extra replays its step this long after its timed steps: `steady_state` of each line
 # The O(L) / sort kernels on a working set BEYOND the 256 MB Infinity Cache: `cycle` distinct batches
 # (inputs AND outputs) walked round-robin inside one replayed graph, so that every launch streams its bytes from HBM.
 # name: (base workload, B per batch, L, batches in the cycle)
@@ -179,6 +188,18 @@ def make_inputs(B, L, seed, device):
     return labels.to(device), logits.to(device)
 
 
+def make_inputs_on_device(B, L, seed, device):
+    """The same distribution as make_batch (valid length U{ceil(L/2)..L}, labels randint{0..4} with -1
+    padding, logits N(0,1)) drawn by the device generator: the 15 / 47 extra batches of the *_hbm working sets, which
+    only exist to push the working set past the Infinity Cache (host generation of 1.3 GB cost the child a minute)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    n_valid = torch.randint((L + 1) // 2, L + 1, (B, 1), generator=g, device=device)
+    labels = torch.randint(0, 5, (B, L), generator=g, device=device).to(torch.float32)
+    labels = torch.where(torch.arange(L, device=device)[None, :] < n_valid, labels, torch.full_like(labels, -1.0))
+    logits = torch.randn((B, L), generator=g, device=device)
+    return labels, logits
+
+
 def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
     """Returns a dict: step (callable), kernel (callable launching only the dominant kernel, or None),
     kernel_name, and for the e2e workloads `all_reduce` (callable: the step's collective alone)."""
@@ -205,14 +226,15 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
                     kernel=lambda: _ops.pairwise_logistic(                 # exactly the launch of loss_and_grad
                         logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_rows=False,
-                        want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC,
+                        want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC, want_sum=True,
                         balance=order if order is not None else False, **lam),
                     kernel_name=('lambdarank_group_kernel' if B >= 512 else 'pairwise_lean_kernel') if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()
         w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
-                    kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True),
+                    kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True,
+                                                     want_sum=True),          # exactly the launch of loss_and_grad
                     kernel_name='softmax_stream_kernel' if B > 8192 else 'softmax_wave_kernel')
     if workload == 'gumbel_approx_ndcg':
         loss = K.GumbelApproxNDCGLoss(seed=1)
@@ -656,7 +678,7 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
     cycle = 1
     if name in HBM_VARIANTS:
         base, _, _, cycle = HBM_VARIANTS[name]
-        batches = [(labels, logits)] + [make_inputs(B, L, seed=1000 + 17 * i + rank, device=dev) for i in range(1, cycle)]
+        batches = [(labels, logits)] + [make_inputs_on_device(B, L, 1000 + 17 * i + rank, dev) for i in range(1, cycle)]
         infos = [build_step(base, lb, lg, 0.0, args.graph) for lb, lg in batches]
         info = dict(infos[0], step=lambda: [i['step']() for i in infos][-1], kernel=lambda: [i['kernel']() for i in infos],
                     keep_alive=(batches, infos))
@@ -847,7 +869,7 @@ def child_command(workload, args, n_gpus, steps, warmup, port=None):
     """The command line that measures ONE extra workload in its own process (at N > 1: its own N ranks under
     torch.distributed.run on a fresh port)."""
     tail = ['--gpus', str(n_gpus), '--workload', workload, '--also', 'none', '--steps', str(steps), '--warmup',
-            str(warmup), '--busy-seconds', '0', '--cpu-budget', '4']
+            str(warmup), '--busy-seconds', str(CHILD_BUSY_SECONDS), '--cpu-budget', '3']
     if args.no_cpu_baseline:
         tail.append('--no-cpu-baseline')
     if not args.graph:
@@ -914,13 +936,13 @@ def main(argv=None):
                          % ','.join(DEFAULT_ALSO))
     ap.add_argument('--batch', type=int, default=0, help='lists per GPU per step (0 = workload default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-budget', type=float, default=12.0, help='seconds of host time for the CPU-baseline sample')
+    ap.add_argument('--cpu-budget', type=float, default=8.0, help='seconds of host time for the CPU-baseline sample')
     ap.add_argument('--no-graph', dest='graph', action='store_false', default=True,
                     help='launch eagerly instead of replaying the step from hipGraphs')
     ap.add_argument('--dropout', type=float, default=None,
                     help='e2e workloads: Dropout rate of the scorer tower (default: the reference default 0.5 -- '
                          'keras/layers.py:32, examples/tf_ranking_libsvm.py:86 -- with the dropout-free step reported beside it)')
-    ap.add_argument('--busy-seconds', type=float, default=2.5,
+    ap.add_argument('--busy-seconds', type=float, default=10.0,
                     help='after the timed steps of the main workload, keep replaying the step for this long (not counted): '
                          'makes the GPU phase visible to a utilisation sampler; 0 to disable')
     ap.add_argument('--kernel-timing', choices=('first', 'last', 'none'), default='first',
@@ -960,7 +982,7 @@ def main(argv=None):
         dist.barrier()
 
     result = run_workload(args.workload, args, dist, rank, world, dev, args.steps, args.warmup, args.cpu_budget)
-    also = DEFAULT_ALSO if (args.also is None and args.workload == 'approx_ndcg') else tuple(
+    also = (DEFAULT_ALSO if world == 1 else DEFAULT_ALSO_MULTI) if (args.also is None and args.workload == 'approx_ndcg') else tuple(
         w for w in (args.also or '').split(',') if w and w != 'none')
     for w in also:
         if w not in WORKLOADS:

@@ -467,6 +467,240 @@ __global__ __launch_bounds__(64) void ndcg_count_wave_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// NDCG@{k...} "lean" form (round 5) for the common case: built-in gain, validity from the labels, no per-item weights,
+// list_size <= 256.  Same results, bit for bit, as ndcg_count_wave_kernel / rank_metric_wave_kernel<0> / the oracle (the
+// terms are the same products, summed with the same tree_sum pairing); what changed is the instruction count -- the
+// counters of round 4 (profiles/r04_pmc.txt) put the kernel at 2 100 VALU + 700 SALU instructions per 200-item list, of
+// which ~1 000 were the THIRTEEN tree sums of a list (five cut-offs x (DCG + ideal DCG) + three statistics, ~80
+// instructions each with their cut-off select chain, kernarg loads and run-time P tests), ~200 the ideal-DCG run rounds
+// (a seven-step DPP maximum per distinct label value) and the load phase waited for every global load on its own:
+//  * cut-offs k <= 16 (NDCG@1/3/5/10) need only positions 0..15: tree_sum over P >= 16 values that are zero beyond k
+//    IS the 16-wide tree over the first 16 (x + 0.0f is exact), and four of those run at once, one per 16-lane DPP row,
+//    in FOUR v_add_f32_dpp (row_shl 8, 4, 2, 1 = the pairs (i, i + 8), (i, i + 4), ... of block_tree_sum);
+//  * without weights the statistics are one tree sum (sum w = list_size exactly, sum w g = sum g);
+//  * graded relevance = small integers: the distinct label values come from ONE wave-wide OR of (1 << label), the run
+//    lengths from ballots, the value of a sorted position from a compare / select per (run, register);
+//  * P = 64 * IPL at compile time for lists beyond 64 items: no run-time level tests in the tree sums;
+//  * four lists (wavefronts) per workgroup share the discount table in LDS, and a wavefront walks lists b, b + W, ...
+//    with the NEXT list's labels / predictions requested before the current one is processed (unconditional loads: an
+//    out-of-range lane re-reads item 0), so no load is waited for where it is issued.
+// Lists whose labels are not small non-negative integers take the generic gain and a run-by-run scatter of the ideal
+// terms (any number of distinct values).  Per-item weights, a mask array, custom gains, list_size > 256: the kernels above.
+struct NdcgCut {
+  unsigned small_k, small_q;      // up to four cut-offs <= 16, one per byte (0 = slot unused) / their rows in metric_out
+  int n_large, large_k[TFR_MAX_TOPN], large_q[TFR_MAX_TOPN];     // the others (k = min(topn, list_size))
+};
+
+__device__ __forceinline__ float row16_tree(float v) {        // lane 16 q: tree_sum of the 16 values of DPP row q
+#define TFR_ROW_SHL(x, n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(x)), 0x100 + (n), 0xf, 0xf, true))
+  v = v + TFR_ROW_SHL(v, 8);
+  v = v + TFR_ROW_SHL(v, 4);
+  v = v + TFR_ROW_SHL(v, 2);
+  v = v + TFR_ROW_SHL(v, 1);
+#undef TFR_ROW_SHL
+  return v;
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) void ndcg_lean_kernel(
+    const float* __restrict__ labels, const float* __restrict__ predictions, const float* __restrict__ list_weights,
+    const float* __restrict__ discount, const NdcgCut cut, const int B, const int L, const int Prt,
+    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  constexpr int N = 64 * IPL;
+  constexpr int kPerWave = 5 * N + 8 + kRankBucketMax + 192;      // 32-bit words of LDS per wavefront
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* DISC = reinterpret_cast<float*>(smem_raw);                 // [N] shared by the four waves
+  float* TERM = DISC + N + wave * kPerWave;                         // [N] w * gain * discount by sorted position
+  float* XS = TERM + N;                                             // [N + 8] compact predictions (pad -inf) / generic ideal terms
+  int* RKS = reinterpret_cast<int*>(XS + N + 8);                    // [N]
+  int* OCC = RKS + N;                                               // [N]
+  float* BX = reinterpret_cast<float*>(OCC + N);                    // [N + kRankBucketMax]
+  int* HB = reinterpret_cast<int*>(BX + N + kRankBucketMax);        // [192]
+  for (int i = threadIdx.x; i < N; i += 256) DISC[i] = (i < L) ? discount[i] : 0.0f;
+  __syncthreads();
+  const int P = (IPL >= 2) ? N : Prt;                               // tree_sum width: pow2_ceil(L) (= N beyond 64 items)
+  float disc[IPL];
+  int off[IPL];
+  bool in[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { const int i = lane + 64 * r; in[r] = i < L; off[r] = in[r] ? i : 0; disc[r] = DISC[i]; }
+  const int W = gridDim.x * 4;
+  int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const int j16 = lane & 15, q16 = lane >> 4;
+  const int kq = (int)((cut.small_k >> (8 * q16)) & 0xffu), oq = (int)((cut.small_q >> (8 * q16)) & 0xffu);
+
+  float lab_n[IPL], pr_n[IPL], wl_n = 1.0f;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { lab_n[r] = labels[(size_t)b * L + off[r]]; pr_n[r] = predictions[(size_t)b * L + off[r]]; }
+  if (list_weights) wl_n = list_weights[b];
+
+  for (; b < B; b += W) {
+    float lab[IPL], pr[IPL];
+    const float wl = wl_n;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) { lab[r] = lab_n[r]; pr[r] = pr_n[r]; }
+    {                                                               // the next list of this wave (the last one re-reads itself)
+      const int bn = (b + W < B) ? b + W : b;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) { lab_n[r] = labels[(size_t)bn * L + off[r]]; pr_n[r] = predictions[(size_t)bn * L + off[r]]; }
+      if (list_weights) wl_n = list_weights[bn];
+    }
+    // ---- _prepare_and_validate_params (metrics_impl.py:228-266): valid = label >= 0 and weight > 0
+    const bool wpos = wl > 0.0f;
+    bool m[IPL];
+    float labm[IPL], g[IPL], wg[IPL];
+    bool okint = true;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      m[r] = in[r] && (lab[r] >= 0.0f) && wpos;
+      labm[r] = m[r] ? lab[r] : -1.0f;
+      okint = okint && (!m[r] || (lab[r] < 31.0f && lab[r] == rintf(lab[r])));
+    }
+    const bool small_int = __ballot(!okint) == 0ull;                // wave-uniform
+    unsigned present = 0u;
+    if (small_int) {
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) {
+        const int e = m[r] ? (int)lab[r] : 0;
+        g[r] = __builtin_amdgcn_ldexpf(1.0f, e) - 1.0f;              // 2^l - 1, exact (gain_pow2m1's integer branch)
+        present |= m[r] ? (1u << e) : 0u;
+      }
+      present = wave_or_u(present);
+    } else {
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) g[r] = gain_pow2m1(m[r] ? lab[r] : 0.0f);
+    }
+    int posr[IPL];
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      wg[r] = in[r] ? wl * g[r] : 0.0f;                             // (1.0f * g is g: the unweighted products are the gains)
+      const unsigned long long bal = __ballot(m[r]);
+      posr[r] = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+      if (m[r]) XS[posr[r]] = pr[r] + 0.0f;                          // -0 -> +0 like float_to_ordered
+      n += __popcll(bal);
+    }
+    // ---- per-list weight statistics (tree_sum over the original index)
+    {
+      float t[IPL];
+      float s_w, s_g, s_wg;
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) t[r] = in[r] ? g[r] : 0.0f;
+      s_g = wave_tree_sum<IPL>(t, P);
+      if (list_weights) {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) t[r] = in[r] ? wl : 0.0f;
+        s_w = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) t[r] = wg[r];
+        s_wg = wave_tree_sum<IPL>(t, P);
+      } else {
+        s_w = (float)L;                                             // L ones: exact in any order
+        s_wg = s_g;                                                 // w = 1
+      }
+      if (lane == 0) {
+        stats_out[(size_t)b * 3 + 0] = s_w;
+        stats_out[(size_t)b * 3 + 1] = s_g;
+        stats_out[(size_t)b * 3 + 2] = s_wg;
+      }
+    }
+    {
+      const int n4 = (n + 3) >> 2;
+      for (int p = n + lane; p < n4 * 4 + 4 && p < N + 8; p += 64) XS[p] = -INFINITY;
+    }
+    WAVE_LDS_SYNC();
+    // ---- DCG: rank of every valid item (prediction descending, ties by index); its term goes to its sorted position.
+    // The ranks 0 .. n - 1 are a permutation: every position below n is written, the ones beyond are never read.
+    if (!wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, BX, HB)) wave_rank_by_count(XS, n, lane, RKS, OCC);
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      if (m[r]) { const int rk = RKS[posr[r]]; TERM[rk] = wg[r] * DISC[rk]; }
+    }
+    WAVE_LDS_SYNC();
+    float term[IPL], termi[IPL];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) term[r] = (lane + 64 * r < n) ? TERM[lane + 64 * r] : 0.0f;
+    const float dsm = (j16 < kq && j16 < n) ? TERM[j16] : 0.0f;     // the cut-offs <= 16: row q16 holds positions 0 .. 15
+
+    // ---- ideal DCG terms: the weighted gains of the valid items in descending order = runs of equal values
+    if (small_int) {
+      float val[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) val[r] = 0.0f;
+      int pos = 0;
+      unsigned bits = present & ~1u;                                // grade 0 has gain 0: its run contributes zeros
+      while (bits) {                                                // (wave-uniform; one trip per distinct grade >= 1)
+        const int gb = 31 - __builtin_clz(bits);
+        bits &= ~(1u << gb);
+        const float gv = (float)gb;
+        const float v = wl * (__builtin_amdgcn_ldexpf(1.0f, gb) - 1.0f);      // the same product as the items' wg
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          c += __popcll(__ballot(labm[r] == gv));
+          val[r] = (lane + 64 * r >= pos) ? v : val[r];
+        }
+        pos += c;
+      }
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) termi[r] = (lane + 64 * r >= pos) ? 0.0f : val[r] * disc[r];
+    } else {
+      // any label values: repeatedly take the largest remaining w * gain; its items go to the next sorted positions
+      // (equal values: any order among them gives the same terms).  XS is free again: the ranks are done.
+      float rem[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) rem[r] = m[r] ? wg[r] : -INFINITY;
+      int pos = 0;
+      for (int it = 0; it <= N; ++it) {                             // (every trip retires >= 1 item: the bound is never reached)
+        float mx = rem[0];
+#pragma unroll
+        for (int r = 1; r < IPL; ++r) mx = fmaxf(mx, rem[r]);
+        const float v = wave_max_u(mx);
+        if (!(v > -INFINITY)) break;
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const bool hit = rem[r] == v;
+          const unsigned long long bal = __ballot(hit);
+          if (hit) {
+            const int sp = pos + c + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            XS[sp] = v * DISC[sp];
+            rem[r] = -INFINITY;
+          }
+          c += __popcll(bal);
+        }
+        pos += c;
+      }
+      WAVE_LDS_SYNC();
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) termi[r] = (lane + 64 * r < pos) ? XS[lane + 64 * r] : 0.0f;
+    }
+    // ---- the cut-offs <= 16, four at a time (one per DPP row)
+    if (cut.small_k) {
+      const float ti = __shfl(termi[0], j16, 64);
+      const float ism = (j16 < kq) ? ti : 0.0f;
+      const float dsum = row16_tree(dsm), isum = row16_tree(ism);
+      if (j16 == 0 && kq > 0) metric_out[(size_t)oq * B + b] = (isum != 0.0f) ? (dsum / isum) : 0.0f;   // divide_no_nan
+    }
+    // ---- the others (k = list_size: NDCG over the whole list)
+    for (int ql = 0; ql < cut.n_large; ++ql) {
+      const int k = cut.large_k[ql];
+      float t[IPL];
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? term[r] : 0.0f;
+      const float dcg = wave_tree_sum<IPL>(t, P);
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) t[r] = (lane + 64 * r < k) ? termi[r] : 0.0f;
+      const float idcg = wave_tree_sum<IPL>(t, P);
+      if (lane == 0) metric_out[(size_t)cut.large_q[ql] * B + b] = (idcg != 0.0f) ? (dcg / idcg) : 0.0f;
+    }
+    WAVE_LDS_SYNC();                                                // TERM / XS are rewritten by the next list
+  }
+}
+
 // The other sort-based metrics of metrics_impl.py on the same wave-per-list machinery
 // (kind is wave-uniform at run time):
 //   TFR_METRIC_DCG       :673-705  sum_{p<k} w gain disc(p)   (divided by the list weight by the caller)
@@ -1098,6 +1332,28 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
                         const uint8_t* mask, const float* gains, const float* discount, const TopN& tn, int B,
                         int L, int P, float* metric_out, float* stats_out, hipStream_t st) {
   static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
+  static const int env_lean = [] { const char* e = getenv("TFR_NDCG_LEAN"); return (e && *e) ? atoi(e) : 1; }();
+  if (KIND == 0 && IPL <= 4 && env_lean && env_count && !gains && !mask && (!weights || weights_per_list)) {
+    // the lean form (round 5): cut-offs <= 16 packed four to a launch pass, the rest through full tree sums
+    NdcgCut cut;
+    cut.small_k = 0u; cut.small_q = 0u; cut.n_large = 0;
+    int ns = 0;
+    for (int q = 0; q < tn.n; ++q) {
+      const int k = (tn.k[q] <= 0 || tn.k[q] > L) ? L : tn.k[q];
+      if (k <= 16 && ns < 4) { cut.small_k |= (unsigned)k << (8 * ns); cut.small_q |= (unsigned)q << (8 * ns); ++ns; }
+      else { cut.large_k[cut.n_large] = k; cut.large_q[cut.n_large] = q; ++cut.n_large; }
+    }
+    for (int q = cut.n_large; q < TFR_MAX_TOPN; ++q) { cut.large_k[q] = 0; cut.large_q[q] = 0; }
+    constexpr int N = 64 * IPL;
+    constexpr size_t lds = (size_t)(N + 4 * (5 * N + 8 + kRankBucketMax + 192)) * sizeof(float);
+    // a wavefront walks `per` lists: enough wavefronts to fill the chip's LDS once (six workgroups of four per CU)
+    static const int env_waves = [] { const char* e = getenv("TFR_NDCG_LEAN_WAVES"); return (e && *e) ? atoi(e) : 256 * 24; }();
+    const int per = (B + env_waves - 1) / env_waves;
+    const int waves = (B + per - 1) / per;
+    hipLaunchKernelGGL((ndcg_lean_kernel<IPL>), dim3((waves + 3) / 4), dim3(256), lds, st, labels, predictions, weights,
+                       discount, cut, B, L, P, metric_out, stats_out);
+    return;
+  }
   if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
     constexpr size_t lds = (size_t)64 * IPL * 6 * sizeof(float) + 8 * sizeof(float);
     static const int env_bucket = [] { const char* e = getenv("TFR_NDCG_BUCKET"); return (e && *e) ? atoi(e) : 1; }();

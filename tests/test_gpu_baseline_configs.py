@@ -61,11 +61,11 @@ def _check(name, got_loss, got_grad, want_loss64, want_grad64, o32_loss, o32_gra
     gs = g.abs().max().item()
     g_k = (got_grad.detach().cpu().double() - g).abs().max().item() / gs
     g_o = (o32_grad.double() - g[::stride]).abs().max().item() / gs if o32_grad is not None else float('nan')
-    record_margin('%s: per-list loss, kernel vs fp64' % name, e_k, loss_bar)
-    record_margin('%s: gradient / max|g|, kernel vs fp64' % name, g_k, grad_bar)
+    record_margin('%s: per-list loss, kernel vs fp64' % name, e_k, loss_bar, pin=True)
+    record_margin('%s: gradient / max|g|, kernel vs fp64' % name, g_k, grad_bar, pin=True)
     if o32_loss is not None:
-        record_margin('%s: per-list loss, fp32 ORACLE vs fp64 (context)' % name, e_o, loss_bar)
-        record_margin('%s: gradient / max|g|, fp32 ORACLE vs fp64 (context)' % name, g_o, grad_bar)
+        record_margin('%s: per-list loss, fp32 ORACLE vs fp64 (context)' % name, e_o, loss_bar, pin=True)
+        record_margin('%s: gradient / max|g|, fp32 ORACLE vs fp64 (context)' % name, g_o, grad_bar, pin=True)
     print('\n[%s] loss: kernel %.3e, fp32 oracle %.3e (bar %.0e) | grad/max|g|: kernel %.3e, fp32 oracle %.3e (bar %.0e)'
           % (name, e_k, e_o, loss_bar, g_k, g_o, grad_bar))
     return e_k, e_o, g_k, g_o
@@ -165,6 +165,6 @@ def test_ndcg_at_10_bit_exact_on_the_whole_headline_batch():
     w_ndcg, w_mrr = c.ndcg_mrr(logits.numpy(), labels.numpy(), topn=10)
     e_n = float(np.abs(ndcg.cpu().double().numpy().reshape(-1) - w_ndcg.reshape(-1)).max())
     e_m = float(np.abs(mrr.cpu().double().numpy().reshape(-1) - w_mrr.reshape(-1)).max())
-    record_margin('headline NDCG@10 (16384 lists) vs fp64 C', e_n, 5e-6)
-    record_margin('headline MRR@10 (16384 lists) vs fp64 C', e_m, 1e-6)
+    record_margin('headline NDCG@10 (16384 lists) vs fp64 C', e_n, 5e-6, pin=True)
+    record_margin('headline MRR@10 (16384 lists) vs fp64 C', e_m, 1e-6, pin=True)
     assert e_n <= 5e-6 and e_m <= 1e-6, (e_n, e_m)

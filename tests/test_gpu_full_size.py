@@ -45,7 +45,7 @@ def _masks(tower, M, rate):
 def _compare(tag, got, want, g_got, g_want, names):
     scale = max(1.0, want.abs().max().item())
     err = (got - want).abs().max().item() / scale
-    record_margin('full-size fused tower logits vs bf16-aware fp32 replica (%s)' % tag, err, 3e-2)
+    record_margin('full-size fused tower logits vs bf16-aware fp32 replica (%s)' % tag, err, 3e-2, pin=True)
     assert torch.isfinite(got).all()
     assert err <= 3e-2, (tag, err)
     gscale = max(b.abs().max().item() for b in g_want)
@@ -54,7 +54,7 @@ def _compare(tag, got, want, g_got, g_want, names):
         rel = (a - b).norm().item() / (b.norm().item() + 1e-6 * b.numel() ** 0.5)
         mx = (a - b).abs().max().item() / gscale
         record_margin('full-size fused tower gradients (%s): min(rel / 3e-2, max-norm / 2e-2)' % tag,
-                      min(rel / 3e-2, mx / 2e-2), 1.0)
+                      min(rel / 3e-2, mx / 2e-2), 1.0, pin=True)
         assert rel <= 3e-2 or mx <= 2e-2, (tag, n, rel, mx)
 
 

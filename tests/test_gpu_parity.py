@@ -303,6 +303,51 @@ def test_ndcg_bit_exact_with_tied_and_squeezed_predictions(L, kind):
         assert torch.equal(got[q].cpu(), want.reshape(-1)), (kind, L, k, (got[q].cpu() - want.reshape(-1)).abs().max())
 
 
+@pytest.mark.parametrize('B,L', [(1, 1), (3, 2), (5, 5), (9, 17), (70, 64), (70, 65), (33, 128), (33, 129), (600, 200),
+                                 (257, 256), (30011, 200)])
+@pytest.mark.parametrize('case', ['plain', 'list_weights', 'float_labels', 'many_values', 'big_labels', 'topn_mix'])
+def test_ndcg_lean_kernel_bit_exact(B, L, case):
+    """ndcg_lean_kernel (round 5: packed cut-offs <= 16, integer-grade runs, persistent four-list workgroups) against the
+    oracle, bit for bit, on every branch of it: no weights / per-list weights (zero and negative ones mask the list),
+    non-integer labels (generic gain + scattered ideal terms), more distinct label values than the old kernel's run
+    table held, labels at and beyond the small-integer limit (30, 31, 40), five and more cut-offs <= 16 (the fifth takes
+    the full tree sum), a batch that makes every wavefront walk several lists."""
+    if B > 10000 and case not in ('plain', 'list_weights'):
+        pytest.skip('the long walk is covered by the plain / weighted cases')
+    labels, preds = make_batch(B, L, seed=2100 + B + L)
+    g = torch.Generator().manual_seed(B * 7 + L)
+    w = None
+    topns = [1, 3, 5, 10, None]
+    valid = labels >= 0
+    if case == 'list_weights':
+        w = torch.rand((B, 1), generator=g) + 0.25
+        w[::5] = 0.0
+        if B > 3:
+            w[3] = -1.0
+    elif case == 'float_labels':
+        labels = torch.where(valid, labels + torch.rand(labels.shape, generator=g) * (torch.arange(B)[:, None] % 2), labels)
+    elif case == 'many_values':
+        labels = torch.where(valid, torch.randint(0, 25, labels.shape, generator=g).float(), labels)
+    elif case == 'big_labels':
+        big = torch.tensor([30.0, 31.0, 40.0, 7.0])[torch.arange(B) % 4][:, None].expand(B, L)
+        labels = torch.where(valid & (torch.rand(labels.shape, generator=g) < 0.1), big, labels)
+    elif case == 'topn_mix':
+        topns = [16, 2, 17, 4, 5, 3, None, 1]
+    mi = ra().metrics_impl
+    wd = None if w is None else w.to(DEV)
+    got, got_w = mi.NDCGMetric(None, None).compute_multi(labels.to(DEV), preds.to(DEV), wd, None, topns)
+    for q, k in enumerate(topns):
+        want, want_w = R.NDCGMetric(topn=k).compute(labels, preds, w)
+        assert torch.equal(got[q].cpu(), want.reshape(-1)), '%s NDCG@%s not bit-exact: max diff %g at %d' % (
+            case, k, (got[q].cpu() - want.reshape(-1)).abs().max(), int((got[q].cpu() - want.reshape(-1)).abs().argmax()))
+    assert_loss_close(got_w, want_w, 1e-6, 'ndcg lean list weights')
+    # one cut-off at a time (the Keras metric objects): only a packed row / only the full tree sum
+    for k in (10, None):
+        one, _ = mi.NDCGMetric(None, k).compute(labels.to(DEV), preds.to(DEV), wd)
+        want, _ = R.NDCGMetric(topn=k).compute(labels, preds, w)
+        assert torch.equal(one.cpu().reshape(-1), want.reshape(-1)), (case, k)
+
+
 def test_metric_reference_goldens():
     km = ra().keras.metrics
     t = lambda x: torch.tensor(x, device=DEV)

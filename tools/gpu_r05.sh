@@ -1,0 +1,107 @@
+#!/bin/bash
+# Round-5 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r05.sh <tag> <what...>
+#   what: tests (full -m gpu suite + smoke) | sums_ab (TFR_LOSS_SUM_FUSED 0 / 1 on the softmax and LambdaRank steps) |
+#         ndcg_ab (TFR_NDCG_LEAN 0 / 1 and the persistent-grid size) | gemm_ab (tower GEMM variants: tools/tower_bench.py +
+#         the e2e steps) | lrank_ab (LambdaRank switches) | one:<workload> | prof:<workload> | pmc:<workload> |
+#         profiles (everything profiles/r05_* is made from: bench lines, rocprofv3 kernel-trace stats, FETCH / WRITE / SQ
+#         passes of every dominant kernel, on the tree as it is) | final (the driver's command) | multi (N = 2 if two
+#         devices are visible: bench.py --gpus 2 and the RCCL test)
+set -u
+TAG=${1:-r05}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+DRV="--gpus 1 --steps 20 --warmup 5"
+ONE="--also none --no-cpu-baseline --busy-seconds 0"
+brief() { python tools/bench_summary.py "$1" 2>/dev/null | tail -n 1 || tail -c 400 "$1"; }
+ab() {   # ab <label> <workload> <steps> <env assignments...>: one bench line under an environment
+  local label=$1 w=$2 st=$3; shift 3
+  local f=$OUT/ab_${w}_$(echo "$label" | tr ' =/' '___').out
+  env "$@" timeout 300 python3 bench.py --workload $w $ONE --steps $st --warmup 10 > $f 2> $OUT/ab.err
+  echo "[$label] $w rc=$?"; brief $f; tail -n 1 $OUT/ab.err | cut -c1-200
+}
+for what in "$@"; do
+  case $what in
+    tests)
+      timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+      tail -n 30 $OUT/pytest_gpu.log | cut -c1-200
+      timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log ;;
+    tests_changed)
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "reduced_scalar or ndcg or softmax or pairwise or lambda or list_mle or unique or pointwise or keras or metric or sigmoid" > $OUT/t_changed.log 2>&1; echo "changed-area tests rc=$?"; tail -n 12 $OUT/t_changed.log | cut -c1-200 ;;
+    sums_ab)
+      for v in 0 1; do
+        ab "fused=$v" softmax_hbm 50 TFR_LOSS_SUM_FUSED=$v
+        ab "fused=$v" softmax 200 TFR_LOSS_SUM_FUSED=$v
+        ab "fused=$v" pairwise_lambda 200 TFR_LOSS_SUM_FUSED=$v
+      done ;;
+    ndcg_ab)
+      for v in 0 1; do
+        ab "lean=$v" ndcg_metric_hbm 20 TFR_NDCG_LEAN=$v
+        ab "lean=$v" ndcg_metric 200 TFR_NDCG_LEAN=$v
+      done
+      for n in 2048 4096 8192 16384; do ab "lean waves=$n" ndcg_metric_hbm 20 TFR_NDCG_LEAN_WAVES=$n; done ;;
+    gemm_ab)
+      timeout 900 python -m pytest tests/test_gpu_tower.py tests/test_gpu_full_size.py -x -q -m gpu -k "not every_bench" > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 4 $OUT/t_tower.log | cut -c1-200
+      timeout 600 python tools/tower_bench.py > $OUT/tower_bench.txt 2> $OUT/tower_bench.err; echo "tower_bench rc=$?"; cat $OUT/tower_bench.txt | cut -c1-200; tail -n 2 $OUT/tower_bench.err | cut -c1-200
+      for v in ${GEMM_VARIANTS:-"TFR_GEMM_PP=0" "TFR_GEMM_PP=1"}; do
+        for w in e2e_approx_ndcg_l1000 e2e_softmax; do ab "$v" $w 50 $v; done
+      done ;;
+    lrank_ab)
+      for v in ${LRANK_VARIANTS:-"TFR_LAMBDARANK_LO16=0" "TFR_LAMBDARANK_LO16=1"}; do ab "$v" pairwise_lambda 200 $v; done ;;
+    one:*)
+      w=${what#one:}
+      timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
+      echo "$w rc=$?"; tail -n 2 $OUT/one_$w.err | cut -c1-300; brief $OUT/one_$w.out ;;
+    prof:*)
+      w=${what#prof:}
+      timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 $ONE > $OUT/prof_$w.log 2>&1
+      python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1
+      head -n 14 $OUT/stats_$w.txt | cut -c1-130; find $OUT -name '*.db' -size +4M -delete ;;
+    pmc:*)
+      w=${what#pmc:}
+      eager=""; st=20; case $w in *_hbm) eager="--no-graph --kernel-timing none"; st=2;; e2e_*) st=4;; esac
+      for c in FETCH_SIZE WRITE_SIZE; do
+        p=$(echo $c | cut -d_ -f1 | tr A-Z a-z)
+        timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_${p}_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 $eager $ONE > $OUT/pmc_${p}_$w.log 2>&1
+        python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 6 | cut -c1-160
+      done
+      timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 $eager $ONE > $OUT/pmc_sq_$w.log 2>&1
+      python tools/rocpd_summary.py pmc $OUT/pmc_sq_$w/r_results.db > $OUT/pmc_sq_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_sq_$w.txt | head -n 12 | cut -c1-160
+      find $OUT -name '*.db' -size +4M -delete ;;
+    profiles)
+      # ONE consolidated visit on the final tree: every bench line, kernel-trace stats of every dominant kernel, FETCH / WRITE /
+      # SQ passes -- what profiles/r05_all_workloads.txt, r05_pmc.txt and r05_traffic.json are assembled from
+      for w in approx_ndcg pairwise_lambda softmax ndcg_metric softmax_hbm ndcg_metric_hbm gumbel_approx_ndcg approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 300 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err; echo "$w rc=$?"; brief $OUT/one_$w.out
+      done
+      for w in approx_ndcg pairwise_lambda softmax_hbm ndcg_metric_hbm e2e_softmax e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
+        timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 $ONE > $OUT/prof_$w.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 5 $OUT/stats_$w.txt | cut -c1-130
+      done
+      for w in approx_ndcg pairwise_lambda softmax_hbm ndcg_metric_hbm e2e_approx_ndcg_l1000; do
+        eager=""; st=20; case $w in *_hbm) eager="--no-graph --kernel-timing none"; st=2;; e2e_*) st=4;; esac
+        for c in FETCH_SIZE WRITE_SIZE; do
+          p=$(echo $c | cut -d_ -f1 | tr A-Z a-z)
+          timeout 300 rocprofv3 --pmc $c -d $OUT/pmc_${p}_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 $eager $ONE > $OUT/pmc_${p}_$w.log 2>&1
+          python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 4 | cut -c1-160
+        done
+      done
+      for w in softmax_hbm ndcg_metric_hbm pairwise_lambda; do
+        eager=""; st=20; case $w in *_hbm) eager="--no-graph --kernel-timing none"; st=2;; esac
+        timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 $eager $ONE > $OUT/pmc_sq_$w.log 2>&1
+        python tools/rocpd_summary.py pmc $OUT/pmc_sq_$w/r_results.db > $OUT/pmc_sq_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_sq_$w.txt | head -n 10 | cut -c1-160
+      done
+      find $OUT -name '*.db' -size +4M -delete ;;
+    final)
+      ( time timeout 1200 python3 bench.py $DRV > $OUT/final_1.out 2> $OUT/final_1.err ) 2> $OUT/final_1.time; echo "final rc=$?"
+      tail -n 2 $OUT/final_1.err | cut -c1-300; python tools/bench_summary.py $OUT/final_1.out; tail -n 3 $OUT/final_1.time ;;
+    multi)
+      n=$(python -c "import torch; print(torch.cuda.device_count())")
+      echo "devices visible: $n"
+      if [ "$n" -ge 2 ]; then
+        timeout 600 python -m pytest tests/test_gpu_distributed.py -x -q -m gpu > $OUT/t_dist.log 2>&1; echo "RCCL test rc=$?"; tail -n 3 $OUT/t_dist.log
+        timeout 900 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/multi2.out 2> $OUT/multi2.err; echo "bench --gpus 2 rc=$?"; python tools/bench_summary.py $OUT/multi2.out; tail -n 2 $OUT/multi2.err | cut -c1-300
+      fi ;;
+    *) echo "unknown step $what" ;;
+  esac
+done
