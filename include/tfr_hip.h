@@ -176,7 +176,13 @@ int tfr_approx_ndcg_sum_f32(const float* logits, const float* labels, const uint
  * one per stream in flight; every output of the plain entry point is still written, bit for bit the same):
  *   tfr_softmax_loss_sum_f32        sum_b loss_out[b] * weight_out[b]   (keras/losses.py:824-832); `sum_scratch` = B floats
  *                                   of device scratch (the per-contributor products; the streaming form adds up one
- *                                   partial per wavefront, in the order the wavefront walks its lists)
+ *                                   partial per wavefront, in the order the wavefront walks its lists).
+ *                                   PARTIALS MODE: loss_sum_out == NULL and ticket == NULL -- the launch only leaves the
+ *                                   n = tfr_softmax_sum_contributors(...) per-contributor values in sum_scratch[0 .. n) and
+ *                                   the caller adds them with tfr_list_dot_f32(sum_scratch, NULL, n): no device-memory
+ *                                   tickets at the end of a 5-25 us kernel (measured: the ticket chain is five dependent
+ *                                   memory round trips, +16 us behind a softmax launch -- DESIGN 4), and a reduction over
+ *                                   8 192 values instead of 2 x 65 536.
  *   tfr_pairwise_loss_sum_f32       sum_b list_loss_out[b] (list_loss_out must be given: its entries are what is added up)
  *   tfr_list_mle_sum_f32 / tfr_unique_softmax_sum_f32    sum_b loss_out[b] * list_scale[b] (list_scale NULL: plain sum)
  *   tfr_pointwise_loss_sum_f32      sum_b list_loss_out[b]
@@ -188,6 +194,7 @@ int tfr_softmax_loss_sum_f32(const float* logits, const float* labels, const uin
                              const float* discount, int B, int L, float temperature, float poly_epsilon,
                              float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
                              float* sum_scratch, uint32_t* ticket, void* stream);
+int tfr_softmax_sum_contributors(int B, int L, int has_mask, int per_item_weights, int lambda_kind, int want_grad);
 int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                               const float* item_weights, const float* list_weights,
                               int lambda_kind, int topn, float smooth_fraction,

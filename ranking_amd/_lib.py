@@ -128,6 +128,7 @@ _SIGNATURES = {
     # the reduced scalar from the loss launch itself (round 5): the plain entry point's arguments + sum / scratch / ticket
     'tfr_softmax_loss_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                                  + [ctypes.c_int] * 2 + [ctypes.c_float] * 2 + [ctypes.c_void_p] * 7),
+    'tfr_softmax_sum_contributors': (ctypes.c_int, [ctypes.c_int] * 6),
     'tfr_pairwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 9),

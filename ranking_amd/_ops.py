@@ -526,7 +526,8 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
                  normalized=False, gain_kind=GAIN_IDENTITY, gains=None, discount=None,
                  temperature=1.0, want_grad=True, poly_epsilon=0.0, want_sum=False):
     """poly_epsilon != 0: PolyOneSoftmaxLoss (loss += epsilon * (1 - sum p softmax)).  want_sum=True: a fourth result,
-    the 0-d sum_b loss_b * weight_b from the same launch (tfr_softmax_loss_sum_f32)."""
+    the 0-d sum_b loss_b * weight_b from the same launch (tfr_softmax_loss_sum_f32); want_sum='partials': the launch
+    leaves per-contributor partial sums and ONE short tfr_list_dot_f32 adds them (the default of SoftmaxLoss.loss_and_grad)."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); gains = _f32(gains, 'gains'); discount = _f32(discount, 'discount')
@@ -537,14 +538,25 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
     weight = torch.empty((B,), dtype=torch.float32, device=dev)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=dev) if want_grad else None
     if want_sum:
-        total, ticket = _sum_outputs(dev)
         scratch = torch.empty((max(B, 1),), dtype=torch.float32, device=dev)
+        if want_sum == 'partials':
+            # the launch leaves one value per contributor (a list, or a wavefront of the streaming form: 8 192 of them for
+            # any batch); one short tfr_list_dot_f32 adds them -- no ticket chain behind a 5-25 us kernel
+            total, ticket = None, None
+        else:
+            total, ticket = _sum_outputs(dev)
         rc = _lib.load().tfr_softmax_loss_sum_f32(
             _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),
             int(bool(normalized)), int(gain_kind), _ptr(gains), _ptr(discount), B, L, float(temperature),
             float(poly_epsilon), _ptr(loss), _ptr(weight), _ptr(dlogits), _ptr(total), _ptr(scratch), _ptr(ticket),
             _stream())
         _lib.check(rc, 'tfr_softmax_loss_sum_f32')
+        if total is None:
+            n = _lib.load().tfr_softmax_sum_contributors(B, L, int(mask is not None), int(w is not None and not per_list),
+                                                         int(lambda_kind), int(want_grad))
+            if n < 0:
+                _lib.check(n, 'tfr_softmax_sum_contributors')
+            total = list_dot(scratch[:n]) if n > 0 else torch.zeros((), dtype=torch.float32, device=dev)
         return loss, weight, dlogits, total
     rc = _lib.load().tfr_poly1_softmax_loss_f32(
         _ptr(logits), _ptr(labels), _ptr(mask), _ptr(w), per_list, int(lambda_kind), int(topn or 0),

@@ -130,7 +130,8 @@ __global__ void softmax_loss_kernel(const SmArgs a) {
     loss += a.poly_eps * (1.0f - pt);
   }
   if (tid == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
-  if (a.sum.out && tid < 64) grid_sum_contribute(a.sum, b, loss * lsum, tid);      // (wave 0, converged; values are block-uniform)
+  if (a.sum.out) { if (tid < 64) grid_sum_contribute(a.sum, b, loss * lsum, tid); }    // (wave 0, converged; values are block-uniform)
+  else if (a.sum.vec && tid == 0) a.sum.vec[b] = loss * lsum;                          // partials mode: the product, for a short tfr_list_dot_f32
   if (!a.dlogits) return;
   // ---- backward: d(weight * loss)/d logits_k = (w/T) (sum_p * softmax_k - p_k), valid k;
   // poly-1 adds  -eps * softmax_k * (p_k - pt).
@@ -401,6 +402,7 @@ __global__ __launch_bounds__(256) void softmax_wave_kernel(const SmArgs a, int B
   }
   if (lane == 0) { a.loss[b] = loss; a.weight[b] = lsum; }
   if (a.sum.out) grid_sum_contribute(a.sum, b, loss * lsum, lane);     // one contributor per list
+  else if (a.sum.vec && lane == 0) a.sum.vec[b] = loss * lsum;
   if (!a.dlogits) return;
 #pragma unroll
   for (int r = 0; r < IPL; ++r) {
@@ -543,6 +545,7 @@ __global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int
   // one contributor per WAVE (W of them; the walk order of a wave is fixed by the grid, so the sum is reproducible for a
   // given launch geometry): a ticket per list would put two dependent memory round trips into every trip of the stream
   if (a.sum.out) grid_sum_contribute(a.sum, wave_id, wsum, lane);
+  else if (a.sum.vec && lane == 0) a.sum.vec[wave_id] = wsum;     // partials mode (the default): W values for tfr_list_dot_f32 instead of 2 B
 }
 
 }  // namespace
@@ -586,10 +589,28 @@ extern "C" int tfr_softmax_loss_sum_f32(const float* logits, const float* labels
                                         const float* discount, int B, int L, float temperature, float epsilon,
                                         float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
                                         float* sum_scratch, uint32_t* ticket, void* stream) {
-  if (!loss_sum_out || !sum_scratch || !ticket) return TFR_EINVAL;
+  if (!sum_scratch || (loss_sum_out != nullptr) != (ticket != nullptr)) return TFR_EINVAL;
   return softmax_dispatch(logits, labels, mask, item_weights, weights_per_list, lambda_kind, topn, normalized, gain_kind,
                           gains, discount, B, L, temperature, epsilon, loss_out, weight_out, dlogits_out, loss_sum_out,
                           sum_scratch, ticket, stream);
+}
+
+// streaming form: plain case, gradient requested, more lists than four per workgroup of the persistent grid
+static int sm_stream_groups() {
+  static const int env_groups = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_GROUPS"); return (e && *e) ? atoi(e) : kSmStreamGroups; }();
+  return env_groups;
+}
+static bool sm_streams(int B, int L, bool has_mask, bool per_item_weights, int lambda_kind, bool want_grad) {
+  static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
+  static const int env_stream = [] { const char* e = getenv("TFR_SOFTMAX_STREAM"); return (e && *e) ? atoi(e) : 1; }();
+  const int groups = sm_stream_groups();
+  return env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 256 && env_stream && !has_mask && !per_item_weights && want_grad &&
+         (B + 3) / 4 > groups && groups >= 1;
+}
+
+extern "C" int tfr_softmax_sum_contributors(int B, int L, int has_mask, int per_item_weights, int lambda_kind, int want_grad) {
+  if (B < 0 || L <= 0) return TFR_EINVAL;
+  return sm_streams(B, L, has_mask != 0, per_item_weights != 0, lambda_kind, want_grad != 0) ? 4 * sm_stream_groups() : B;
 }
 
 static int softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
@@ -620,10 +641,8 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
     hipStream_t st = (hipStream_t)stream;
     static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
     const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
-    static const int env_stream = [] { const char* e = getenv("TFR_SOFTMAX_STREAM"); return (e && *e) ? atoi(e) : 1; }();
-    static const int env_groups = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_GROUPS"); return (e && *e) ? atoi(e) : kSmStreamGroups; }();
-    if (env_stream && !mask && (!item_weights || weights_per_list) && dlogits_out && L <= 256 &&
-        (B + 3) / 4 > env_groups && env_groups >= 1) {
+    const int env_groups = sm_stream_groups();
+    if (sm_streams(B, L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
       static const int env_depth = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_DEPTH"); return (e && *e) ? atoi(e) : 2; }();
       a.sum.n = env_groups * 4;                                     // ... per wave in the streaming form
 #define SMK(I, N, D, W) hipLaunchKernelGGL((softmax_stream_kernel<I, N, D, W>), dim3(env_groups), dim3(256), 0, st, a, B)

@@ -1346,8 +1346,11 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
     for (int q = cut.n_large; q < TFR_MAX_TOPN; ++q) { cut.large_k[q] = 0; cut.large_q[q] = 0; }
     constexpr int N = 64 * IPL;
     constexpr size_t lds = (size_t)(N + 4 * (5 * N + 8 + kRankBucketMax + 192)) * sizeof(float);
-    // a wavefront walks `per` lists: enough wavefronts to fill the chip's LDS once (six workgroups of four per CU)
-    static const int env_waves = [] { const char* e = getenv("TFR_NDCG_LEAN_WAVES"); return (e && *e) ? atoi(e) : 256 * 24; }();
+    // a wavefront walks `per` lists.  Measured (B = 16 384, L = 200, 1.3 GB working set, profiles/r05_ndcg_ab.txt): 2 048
+    // wavefronts 42.5 us, 4 096 28.9, 6 144 (one resident round) 31.9, 8 192 27.4, 16 384 (one list per wavefront) 26.6 --
+    // the dispatcher balances short and long lists better than a static walk, so a wavefront only walks several lists in
+    // batches beyond 65 536 lists
+    static const int env_waves = [] { const char* e = getenv("TFR_NDCG_LEAN_WAVES"); return (e && *e) ? atoi(e) : 65536; }();
     const int per = (B + env_waves - 1) / env_waves;
     const int waves = (B + per - 1) / per;
     hipLaunchKernelGGL((ndcg_lean_kernel<IPL>), dim3((waves + 3) / 4), dim3(256), lds, st, labels, predictions, weights,

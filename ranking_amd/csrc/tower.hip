@@ -881,7 +881,26 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
   return __builtin_bit_cast(bf16x8, make_uint4(o[0], o[1], o[2], o[3]));
 }
 
-template <int PRO, int EPI, int DROP>      // DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
+// PP (round 5, TFR_GEMM_PP): the k loop as a two-group PING-PONG.  The single-phase loop below it costs 4 440 cycles per k
+// step against 2 048 of MFMA because the two wavefronts of a SIMD do the same thing at the same time: both wait for their
+// fragment reads, both queue their MFMAs, and MFMA issue, LDS-read return and LDS-DMA issue add up.  Here the
+// waves of n-half 1 (waves 4-7: the OTHER wavefront of every SIMD) run one phase behind those of n-half 0, and a k step is
+// four phases separated by workgroup barriers:   LOAD(kk) = the 12 fragment reads of a 32-wide k half (+ the prologue's
+// BatchNorm / ReLU / Dropout on them, + this group's LDS-DMA pieces of the next stage)   |   MMA(kk) = its 32 MFMAs under
+// s_setprio(1), from registers only.  While one group of a SIMD is in MMA the other is in LOAD: the matrix pipe is fed by
+// one wave while the other wave's LDS reads and VALU prologue run beside it.
+//   group 0:        L00 | M00 | L01 | M01 | L10 | ...  | M(n-1,1) | epilogue
+//   group 1:  (b) |     L00 | M00 | L01 | M01 | ...  | L(n-1,1) | M(n-1,1), epilogue      (b = one extra barrier per tile, the
+//                                                                                           last barrier of the tile left out)
+// Hazards, by barrier count (group 1's j-th barrier of a k step is the workgroup's (4 s + j + 1)-th, group 0's the (4 s + j)-th):
+//  * the stage of step s + 1 is requested during step s into the other buffer, whose last reader (group 1's L(s-1,1)) finished
+//    before barrier 4 s; group 0 asks for its pieces in L(s,0) / L(s,1), group 1 for all of its pieces in L(s,0) (three phases
+//    ahead of its wait), and both wait vmcnt(0) before barrier 4 s + 4 -- group 0 after M(s,1), group 1 after L(s,1) -- which is
+//    the barrier group 0's L(s+1,0) starts behind;
+//  * every LOAD phase drains its LDS reads / writes (lgkmcnt(0)) before its closing barrier: no buffer is re-staged under a read;
+//  * the keep-bit table of step s + 1 is written in L(s,0) by both groups, i.e. before barrier 4 s + 2, and read after 4 s + 4;
+//  * at the end of a tile both groups pass barrier 4 n together and run their (barrier-free) epilogues side by side.
+template <int PRO, int EPI, int DROP, bool PP = false>      // DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
 __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
@@ -1076,6 +1095,94 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 zq0 = make_uint4(0, 0, 0, 0), zq1 = zq0;
+    if constexpr (PP) {
+      bf16x8 fa[4], fb[8];
+      if (wn == 1) __builtin_amdgcn_s_barrier();      // the stagger of this tile (see the kernel's comment)
+#pragma unroll 1
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = p ^ (kt & 1), oth = cur ^ 1;
+        const bool last = kt + 1 == nk;
+        const bool issued = kt != 0 && (!last || have_next);
+        const int stm = last ? tmn : tm, stn = last ? tnn : tn, skt = last ? 0 : kt + 1;
+        if (touch_z && kt < 4)
+          touch4_s(offTZ, reinterpret_cast<const char*>(g.Zp) + ((long)m0 * g.ldz + n0 + kt * 64) * 2, junk);
+        if ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && last) {            // first Zp chunk of the epilogue
+          const char* zb = reinterpret_cast<const char*>(g.Zp) + (mb * g.ldz + n0 + wn * 128) * 2;
+          zq0 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((lane >> 3) * g.ldz + (lane & 7) * 8) * 2));
+          zq1 = *reinterpret_cast<const uint4*>(zb + (uint32_t)(((8 + (lane >> 3)) * g.ldz + (lane & 7) * 8) * 2));
+        }
+        const unsigned char* ta = smem + cur * (2 * TILE2_BYTES);
+        const unsigned char* tb = ta + TILE2_BYTES;
+        const char* ab = a_base(stm, skt);
+        const char* bb = b_base(stn, skt);
+        const uint32_t dst_a = lds0 + oth * (2 * TILE2_BYTES) + wave * 4096, dst_b = dst_a + TILE2_BYTES;
+        const bool store_a = PRO != PRO_NONE && g.Aout != nullptr && tn < 4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          // ---------------- LOAD(kt, kk)
+          if (issued) {                                 // (uniform) this wave's eight pieces of the next stage
+            if (wn == 1) {
+              if (kk == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16_s(offA[i], ab, dst_a + i * 1024);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dma16_s(offB[i], bb, dst_b + i * 1024);
+              }
+            } else if (kk == 0) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dma16_s(offA[i], ab, dst_a + i * 1024);
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) dma16_s(offB[i], bb, dst_b + i * 1024);
+            }
+          }
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            fa[f] = *reinterpret_cast<const bf16x8*>(ta + swz(wm * 64 + f * 16 + fr, kk * 4 + fq));    // activations
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            fb[j] = *reinterpret_cast<const bf16x8*>(tb + swz(wn * 128 + j * 16 + fr, kk * 4 + fq));   // weights
+          if (PRO != PRO_NONE) {
+            const int k = kt * BK + kk * 32 + fq * 8;
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_scale + k), sc1 = *reinterpret_cast<const f32x4*>(s_scale + k + 4);
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + k), sh1 = *reinterpret_cast<const f32x4*>(s_shift + k + 4);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+              uint32_t bits8 = 0u;
+              if (bt) bits8 = mask_buf(mcur)[(wm * 64 + f * 16 + fr) * 2 + kk] >> (fq * 8);
+              fa[f] = transform_frag<PRO, DROP>(fa[f], sc0, sc1, sh0, sh1, pdrop,
+                                                (uint32_t)(g.row0 + m0 + wm * 64 + f * 16 + fr), (uint32_t)k, g.act, bits8);
+            }
+            if (store_a && kk == wn) {                // (who stores what: see `compute` above)
+#pragma unroll
+              for (int f = 0; f < 4; ++f)
+                if ((store_f >> f) & 1)
+                  *reinterpret_cast<bf16x8*>(g.Aout + (long)(m0 + wm * 64 + f * 16 + fr) * g.ldao + k) = fa[f];
+            }
+          }
+          if (bt && kk == 0 && (!last || have_next)) fill_mask(mcur ^ 1, stm, skt);   // the table of the NEXT step
+          if (kk == 0 && kt == 1 && refill) fill_epi(tn);      // (rare: the n-tile changed; every wave is past the old epilogue)
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == 1 && wn == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          // ---------------- MMA(kt, kk): registers only
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+              acc[j][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[fm], acc[j][fm], 0, 0, 0);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk == 1 && wn == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (!(kk == 1 && wn == 1 && last)) __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        mcur ^= 1;
+      }
+    } else {
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = p ^ (kt & 1), oth = cur ^ 1;
@@ -1101,6 +1208,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
       // the pieces requested in this step must have landed (every wave's) before anyone reads them
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       mcur ^= 1;
+    }
     }
     GEMM_STAMP(2);
     const int freeb = p ^ ((nk - 1) & 1);           // the buffer of the last step: free now
@@ -2068,6 +2176,16 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   auto fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0>
                   : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, ((PRO == PRO_AFFINE || PRO == PRO_AFFINE_RELU) && EPI <= EPI_STATS) ? 2 : 1>
                                                                             : tower_gemm256p_kernel<PRO, EPI, 1>);
+  // the two-group ping-pong k loop (round 5; TFR_GEMM_PP=0: the single-phase loop of rounds 2-4), compiled for the forms a
+  // BatchNorm + ReLU tower runs: hidden-layer forward (2, 1), its dgrad (0, 2), layer 1 / plain products (0, 1), (0, 0)
+  static const int env_pp = [] { const char* e = getenv("TFR_GEMM_PP"); return (e && *e) ? atoi(e) : 1; }();
+  constexpr bool pp_form = (PRO == PRO_AFFINE_RELU && EPI == EPI_STATS) || (PRO == PRO_NONE && EPI <= EPI_RELU_BWD);
+  if constexpr (pp_form) {
+    if (env_pp)
+      fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0, true>
+                 : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, (PRO == PRO_AFFINE_RELU && EPI <= EPI_STATS) ? 2 : 1, true>
+                                                : tower_gemm256p_kernel<PRO, EPI, 1, true>);
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(fn, dim3(8 * nslots), dim3(512), P_LDS, st, g);

@@ -181,7 +181,16 @@ class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
 
 
 # ------------------------------------------------------------------- helpers
-_LOSS_SUM_FUSED = bool(int(os.environ.get('TFR_LOSS_SUM_FUSED', '1')))
+# The reduced scalar of loss_and_grad (TFR_LOSS_SUM_FUSED): 0 = a tfr_list_dot_f32 launch behind every loss launch (rounds
+# 1-3); 1 (default) = ApproxNDCG / GumbelApproxNDCG take it from the loss launch (its ticket chain hides behind the backward
+# sweeps: -4 us of a 136 us step), Softmax leaves per-wavefront partials and adds 8 192 of them instead of 2 x 65 536 values
+# (-8 us of a 36 us launch), the other losses keep the reduction launch; 2 = every loss takes it from its own launch
+# (tfr_*_sum_f32) -- measured SLOWER behind short kernels (round 5, profiles/r05_sum_ab.txt: the last wavefront's store ->
+# ticket -> group sum -> ticket -> final sum is five dependent device-memory round trips, +16 us behind a 5-25 us softmax
+# launch, +2.6 us behind the 48 us LambdaRank kernel, against 3.5-11.6 us for the reduction launch it replaces).
+_LOSS_SUM_MODE = int(os.environ.get('TFR_LOSS_SUM_FUSED', '1'))
+_LOSS_SUM_FUSED = _LOSS_SUM_MODE >= 1                  # ApproxNDCG family
+_LOSS_SUM_ALL = _LOSS_SUM_MODE >= 2                    # every loss
 _CONST_CACHE = _ops.DeviceConstCache(64)        # graph-safe: entries a hipGraph capture has read are never evicted
 
 
@@ -333,7 +342,7 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
                 item_w = sample_weight
             else:
                 list_w = list_w * torch.broadcast_to(sample_weight.reshape(-1), (b,))
-        if not _LOSS_SUM_FUSED:
+        if not _LOSS_SUM_ALL:
             _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
                 y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
                 want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind, **lam)
@@ -443,7 +452,8 @@ class SoftmaxLoss(_ListwiseLoss):
             return _ops.list_dot(loss, weight), dlogits
         _, _, dlogits, total = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
                                                  temperature=self._temperature, want_grad=True,
-                                                 poly_epsilon=self._loss._poly_epsilon, want_sum=True, **lam)
+                                                 poly_epsilon=self._loss._poly_epsilon,
+                                                 want_sum=True if _LOSS_SUM_ALL else 'partials', **lam)
         return total, dlogits
 
 
@@ -547,7 +557,7 @@ class UniqueSoftmaxLoss(ApproxNDCGLoss):
             list_scale = (sw.reshape(b) * scale).contiguous()
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
-        if not _LOSS_SUM_FUSED:
+        if not _LOSS_SUM_ALL:
             loss, dlogits = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True)
             return _ops.list_dot(loss, list_scale), dlogits
         _, dlogits, total = _ops.unique_softmax(y_pred.detach(), y_true, mask, list_scale, self._temperature, True,
@@ -576,7 +586,7 @@ class ListMLELoss(ApproxNDCGLoss):
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         pw = self._loss._pos_weight(y_pred.shape[1], y_pred.device)
-        if not _LOSS_SUM_FUSED:
+        if not _LOSS_SUM_ALL:
             loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
             return _ops.list_dot(loss, list_scale), dlogits
         _, dlogits, total = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True,
@@ -710,7 +720,7 @@ class _PointwiseLoss(_RankingLoss):
         scale = self._scale(b * l)
         item_w, list_w = self._weights_args(sample_weight, b, l, y_pred.device)
         list_w = _const_vector(b, scale, y_pred.device) if list_w is None else list_w * scale
-        if not _LOSS_SUM_FUSED:
+        if not _LOSS_SUM_ALL:
             loss, _, _, dlogits = _ops.pointwise_loss(self._loss._fused_kind, y_pred.detach(), y_true, mask, item_w,
                                                       list_w, self._loss._temperature, True)
             return _ops.list_dot(loss), dlogits

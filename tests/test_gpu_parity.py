@@ -144,7 +144,10 @@ def _sum_case(name, B, L):
     lb, lg = labels.to(DEV), logits.to(DEV)
     g = torch.Generator().manual_seed(B + L)
     scale = (torch.rand(B, generator=g) + 0.5).to(DEV)
-    if name == 'softmax':
+    if name == 'softmax_partials':           # the default of SoftmaxLoss.loss_and_grad: per-contributor partials + one short dot
+        run = lambda s: _ops.softmax_loss(lg, lb, None, scale, temperature=1.0, want_grad=True, want_sum='partials' if s else False)
+        ref = lambda o: (o[0].double() * o[1].double()).sum().item()
+    elif name == 'softmax':
         run = lambda s: _ops.softmax_loss(lg, lb, None, scale, temperature=1.0, want_grad=True, want_sum=s)
         ref = lambda o: (o[0].double() * o[1].double()).sum().item()
     elif name == 'softmax_lambda':            # DCGLambdaWeight.individual_weights: the workgroup kernel
@@ -179,6 +182,7 @@ def _sum_case(name, B, L):
 @pytest.mark.parametrize('name,B,L', [
     ('softmax', 1, 5), ('softmax', 70, 100), ('softmax', 4099, 100), ('softmax', 20011, 129), ('softmax', 9000, 40),
     ('softmax', 3, 1500), ('softmax_lambda', 67, 120),
+    ('softmax_partials', 70, 100), ('softmax_partials', 20011, 129), ('softmax_partials', 3, 1500),
     ('pairwise_lambda', 4096, 200), ('pairwise_lambda', 700, 130), ('pairwise_lambda', 65, 200), ('pairwise_lambda', 3, 7),
     ('pairwise_plain', 130, 60), ('pairwise_topn', 130, 60), ('pairwise_lambda', 5, 300),
     ('list_mle', 131, 70), ('list_mle', 3, 1100), ('unique_softmax', 131, 70), ('unique_softmax', 3, 1100),
@@ -338,6 +342,9 @@ def test_ndcg_lean_kernel_bit_exact(B, L, case):
     got, got_w = mi.NDCGMetric(None, None).compute_multi(labels.to(DEV), preds.to(DEV), wd, None, topns)
     for q, k in enumerate(topns):
         want, want_w = R.NDCGMetric(topn=k).compute(labels, preds, w)
+        if case == 'float_labels':               # 2^l of a non-integer label: the device's exp2 and torch's pow differ by an ulp
+            assert_loss_close(got[q], want.reshape(-1), 1e-6, 'ndcg lean, non-integer labels')
+            continue
         assert torch.equal(got[q].cpu(), want.reshape(-1)), '%s NDCG@%s not bit-exact: max diff %g at %d' % (
             case, k, (got[q].cpu() - want.reshape(-1)).abs().max(), int((got[q].cpu() - want.reshape(-1)).abs().argmax()))
     assert_loss_close(got_w, want_w, 1e-6, 'ndcg lean list weights')
@@ -345,7 +352,10 @@ def test_ndcg_lean_kernel_bit_exact(B, L, case):
     for k in (10, None):
         one, _ = mi.NDCGMetric(None, k).compute(labels.to(DEV), preds.to(DEV), wd)
         want, _ = R.NDCGMetric(topn=k).compute(labels, preds, w)
-        assert torch.equal(one.cpu().reshape(-1), want.reshape(-1)), (case, k)
+        if case == 'float_labels':
+            assert_loss_close(one.reshape(-1), want.reshape(-1), 1e-6, 'ndcg lean, non-integer labels')
+        else:
+            assert torch.equal(one.cpu().reshape(-1), want.reshape(-1)), (case, k)
 
 
 def test_metric_reference_goldens():
