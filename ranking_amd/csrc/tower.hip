@@ -900,7 +900,7 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
 //  * every LOAD phase drains its LDS reads / writes (lgkmcnt(0)) before its closing barrier: no buffer is re-staged under a read;
 //  * the keep-bit table of step s + 1 is written in L(s,0) by both groups, i.e. before barrier 4 s + 2, and read after 4 s + 4;
 //  * at the end of a tile both groups pass barrier 4 n together and run their (barrier-free) epilogues side by side.
-template <int PRO, int EPI, int DROP, bool PP = false>      // DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
+template <int PRO, int EPI, int DROP, int PP = 0>      // PP: 0 single-phase loop, 1 ping-pong with the LDS-DMA pieces in the LOAD phases, 2 with the pieces among the MFMAs of MMA(kt, 0); DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
 __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
@@ -1095,7 +1095,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
       for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     uint4 zq0 = make_uint4(0, 0, 0, 0), zq1 = zq0;
-    if constexpr (PP) {
+    if constexpr (PP != 0) {
       bf16x8 fa[4], fb[8];
       if (wn == 1) __builtin_amdgcn_s_barrier();      // the stagger of this tile (see the kernel's comment)
 #pragma unroll 1
@@ -1120,7 +1120,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
           // ---------------- LOAD(kt, kk)
-          if (issued) {                                 // (uniform) this wave's eight pieces of the next stage
+          if (PP == 1 && issued) {                      // (uniform) this wave's eight pieces of the next stage
             if (wn == 1) {
               if (kk == 0) {
 #pragma unroll
@@ -1170,10 +1170,19 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
           // ---------------- MMA(kt, kk): registers only
           __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
+          for (int j = 0; j < 8; ++j) {
 #pragma unroll
             for (int fm = 0; fm < 4; ++fm)
               acc[j][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[fm], acc[j][fm], 0, 0, 0);
+            // PP == 2: the eight pieces of the next stage go out among the MFMAs of MMA(kt, 0), one per four MFMAs -- where
+            // an LDS-DMA instruction is cheapest (MI355X_MICROARCH.md: ~60 cycles among bare MFMAs against 100-185 inside a
+            // phase that also carries fragment reads); both groups wait for them before barrier 4 s + 4 (group 1 has its
+            // L(s,1) phase in between, group 0 its L(s,1) and M(s,1))
+            if (PP == 2 && kk == 0 && issued) {
+              if (j < 4) dma16_s(offA[j], ab, dst_a + j * 1024);
+              else dma16_s(offB[j - 4], bb, dst_b + (j - 4) * 1024);
+            }
+          }
           __builtin_amdgcn_s_setprio(0);
           __builtin_amdgcn_sched_barrier(0);
           if (kk == 1 && wn == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2176,15 +2185,20 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   auto fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0>
                   : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, ((PRO == PRO_AFFINE || PRO == PRO_AFFINE_RELU) && EPI <= EPI_STATS) ? 2 : 1>
                                                                             : tower_gemm256p_kernel<PRO, EPI, 1>);
-  // the two-group ping-pong k loop (round 5; TFR_GEMM_PP=0: the single-phase loop of rounds 2-4), compiled for the forms a
+  // the two-group ping-pong k loop (round 5; TFR_GEMM_PP=1 / 2; default 0 = the single-phase loop of rounds 2-4: measured
+  // equal within 2 % -- profiles/r05_gemm_pp.txt), compiled for the forms a
   // BatchNorm + ReLU tower runs: hidden-layer forward (2, 1), its dgrad (0, 2), layer 1 / plain products (0, 1), (0, 0)
-  static const int env_pp = [] { const char* e = getenv("TFR_GEMM_PP"); return (e && *e) ? atoi(e) : 1; }();
+  static const int env_pp = [] { const char* e = getenv("TFR_GEMM_PP"); return (e && *e) ? atoi(e) : 0; }();
   constexpr bool pp_form = (PRO == PRO_AFFINE_RELU && EPI == EPI_STATS) || (PRO == PRO_NONE && EPI <= EPI_RELU_BWD);
   if constexpr (pp_form) {
-    if (env_pp)
-      fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0, true>
-                 : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, (PRO == PRO_AFFINE_RELU && EPI <= EPI_STATS) ? 2 : 1, true>
-                                                : tower_gemm256p_kernel<PRO, EPI, 1, true>);
+    if (env_pp == 1)
+      fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0, 1>
+                 : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, (PRO == PRO_AFFINE_RELU && EPI <= EPI_STATS) ? 2 : 1, 1>
+                                                : tower_gemm256p_kernel<PRO, EPI, 1, 1>);
+    else if (env_pp == 2)
+      fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0, 2>
+                 : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, (PRO == PRO_AFFINE_RELU && EPI <= EPI_STATS) ? 2 : 1, 2>
+                                                : tower_gemm256p_kernel<PRO, EPI, 1, 2>);
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS);
   if (e != hipSuccess) return (int)e;

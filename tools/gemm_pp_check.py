@@ -88,15 +88,18 @@ def run(out_dir, tag):
 
 
 def compare(out_dir):
-    a = json.load(open(os.path.join(out_dir, 'gemm_pp_a.json')))
-    b = json.load(open(os.path.join(out_dir, 'gemm_pp_b.json')))
+    runs = []
+    for tag in 'abcdef':
+        f = os.path.join(out_dir, 'gemm_pp_%s.json' % tag)
+        if os.path.exists(f):
+            runs.append(json.load(open(f)))
     ok = True
-    print('form                       PP=%s ms   PP=%s ms   ratio   bits' % (a['pp'], b['pp']))
-    for k in a['forms']:
-        fa, fb = a['forms'][k], b['forms'][k]
-        same = all(f == fa['fingerprints'][0] for f in fa['fingerprints'] + fb['fingerprints'])
+    print('%-26s' % 'form' + ''.join('  PP=%-9s' % r['pp'] for r in runs) + '  bits')
+    for k in runs[0]['forms']:
+        fps = [f for r in runs for f in r['forms'][k]['fingerprints']]
+        same = all(f == fps[0] for f in fps)
         ok = ok and same
-        print('%-26s %8.3f   %8.3f   %5.2f   %s' % (k, fa['ms'], fb['ms'], fa['ms'] / fb['ms'], 'identical' if same else 'DIFFERENT'))
+        print('%-26s' % k + ''.join('  %8.3f ms' % r['forms'][k]['ms'] for r in runs) + '  ' + ('identical' if same else 'DIFFERENT'))
     print('ALL IDENTICAL' if ok else 'MISMATCH')
     return 0 if ok else 1
 

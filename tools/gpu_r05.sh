@@ -43,13 +43,23 @@ for what in "$@"; do
     gemm_ab)
       # the two k-loop forms of the persistent tower GEMM: bit-identity + timing (each form in its own process), then the
       # tower parity suites under the default form, then the end-to-end steps under both
-      TFR_GEMM_PP=0 timeout 200 python tools/gemm_pp_check.py $OUT a > $OUT/gemm_pp_a.txt 2>&1; echo "gemm_pp_check PP=0 rc=$?"; tail -n 11 $OUT/gemm_pp_a.txt | cut -c1-160
-      TFR_GEMM_PP=1 timeout 200 python tools/gemm_pp_check.py $OUT b > $OUT/gemm_pp_b.txt 2>&1; echo "gemm_pp_check PP=1 rc=$?"; tail -n 11 $OUT/gemm_pp_b.txt | cut -c1-160
+      i=0
+      for v in ${GEMM_PP_MODES:-0 1 2}; do
+        tag=$(echo abcdef | cut -c$((i+1))); i=$((i+1))
+        TFR_GEMM_PP=$v timeout 200 python tools/gemm_pp_check.py $OUT $tag > $OUT/gemm_pp_$tag.txt 2>&1; echo "gemm_pp_check PP=$v rc=$?"; tail -n 11 $OUT/gemm_pp_$tag.txt | cut -c1-160
+      done
       timeout 60 python tools/gemm_pp_check.py $OUT compare > $OUT/gemm_pp_compare.txt 2>&1; echo "compare rc=$?"; cat $OUT/gemm_pp_compare.txt | cut -c1-160
       timeout 900 python -m pytest tests/test_gpu_tower.py tests/test_gpu_full_size.py tests/test_gpu_groupwise.py tests/test_gpu_e2e_parity.py -x -q -m gpu -k "not every_bench" > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 4 $OUT/t_tower.log | cut -c1-200
-      for v in ${GEMM_VARIANTS:-"TFR_GEMM_PP=0" "TFR_GEMM_PP=1"}; do
-        for w in e2e_approx_ndcg_l1000 e2e_softmax e2e_groupwise_gumbel; do ab "$v" $w 50 $v; done
+      for v in ${GEMM_VARIANTS:-"TFR_GEMM_PP=0" "TFR_GEMM_PP=2"}; do
+        for w in e2e_approx_ndcg_l1000 e2e_softmax; do ab "$v" $w 50 $v; done
       done ;;
+    gemm_quick)
+      i=0
+      for v in ${GEMM_PP_MODES:-0 2}; do
+        tag=$(echo abcdef | cut -c$((i+1))); i=$((i+1))
+        TFR_GEMM_PP=$v timeout 200 python tools/gemm_pp_check.py $OUT $tag > $OUT/gemm_pp_$tag.txt 2>&1; echo "gemm_pp_check PP=$v rc=$?"; tail -n 11 $OUT/gemm_pp_$tag.txt | cut -c1-160
+      done
+      timeout 60 python tools/gemm_pp_check.py $OUT compare > $OUT/gemm_pp_compare.txt 2>&1; echo "compare rc=$?"; cat $OUT/gemm_pp_compare.txt | cut -c1-160 ;;
     lrank_ab)
       for v in ${LRANK_VARIANTS:-"TFR_LAMBDARANK_LO16=0" "TFR_LAMBDARANK_LO16=1"}; do ab "$v" pairwise_lambda 200 $v; done ;;
     one:*)
