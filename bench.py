@@ -235,7 +235,7 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
                     kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True,
                                                      want_sum=True),          # exactly the launch of loss_and_grad
-                    kernel_name='softmax_stream_kernel' if B > 8192 else 'softmax_wave_kernel')
+                    kernel_name='softmax_pack_kernel (two lists per wavefront, persistent)')
     if workload == 'gumbel_approx_ndcg':
         loss = K.GumbelApproxNDCGLoss(seed=1)
         S = 8

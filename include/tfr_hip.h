@@ -194,7 +194,8 @@ int tfr_softmax_loss_sum_f32(const float* logits, const float* labels, const uin
                              const float* discount, int B, int L, float temperature, float poly_epsilon,
                              float* loss_out, float* weight_out, float* dlogits_out, float* loss_sum_out,
                              float* sum_scratch, uint32_t* ticket, void* stream);
-int tfr_softmax_sum_contributors(int B, int L, int has_mask, int per_item_weights, int lambda_kind, int want_grad);
+/* has_weights: 0 = none; 1 = one per list; 2 = one per item */
+int tfr_softmax_sum_contributors(int B, int L, int has_mask, int has_weights, int lambda_kind, int want_grad);
 int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                               const float* item_weights, const float* list_weights,
                               int lambda_kind, int topn, float smooth_fraction,

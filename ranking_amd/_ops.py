@@ -552,7 +552,8 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
             _stream())
         _lib.check(rc, 'tfr_softmax_loss_sum_f32')
         if total is None:
-            n = _lib.load().tfr_softmax_sum_contributors(B, L, int(mask is not None), int(w is not None and not per_list),
+            n = _lib.load().tfr_softmax_sum_contributors(B, L, int(mask is not None),
+                                                         0 if w is None else (1 if per_list else 2),
                                                          int(lambda_kind), int(want_grad))
             if n < 0:
                 _lib.check(n, 'tfr_softmax_sum_contributors')

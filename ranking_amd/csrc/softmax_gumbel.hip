@@ -548,6 +548,174 @@ __global__ __launch_bounds__(256) void softmax_stream_kernel(const SmArgs a, int
   else if (a.sum.vec && lane == 0) a.sum.vec[wave_id] = wsum;     // partials mode (the default): W values for tfr_list_dot_f32 instead of 2 B
 }
 
+// Packed form (round 5) of the plain case WITHOUT weights: 64 / LG lists side by side in one wavefront (LG = 32 or 16 lanes per
+// list, IPL items per lane).  Why: the streaming kernel above moves 79 MB in 24.8 us (3.2 TB/s, 40 % of 8 TB/s) and is flat in
+// lists in flight and in workgroups -- it is bound by instruction issue, not by bytes in flight: a 100-item list occupies a
+// whole wavefront (100 of 128 item slots) through six wave-wide reductions of ~13 DPP / readlane instructions each plus ~60
+// element-wise instructions, ~200 instructions per list = 12 800 per SIMD for 65 536 lists.  Two lists per wavefront halve both
+// parts (every vector instruction serves two lists; a 32-lane reduction is the same DPP steps with the last cross-row step
+// dropped), four lists per wavefront for list_size <= 64 quarter them.  A wavefront reads / writes the rows of its lists as ONE
+// contiguous run of memory (lists g S .. g S + S - 1 are adjacent rows).
+// The reductions of a list run over its own LG lanes only, in an order that does not depend on the lane group or on the batch:
+// a row's results are the same bits whatever surrounds it.  (They are NOT the bits of softmax_wave_kernel -- another
+// summation order, both within a few ulp of the fp64 arbiter; every plain unweighted batch takes this kernel, so there is no
+// mixing.)  Persistent like the streaming form: a wavefront walks groups w, w + W, ... with the next group's loads in flight.
+template <int LG> struct SegOps;
+template <> struct SegOps<32> {      // totals of lanes [0, 32) and [32, 64), returned to every lane of the segment
+  static __device__ __forceinline__ float sum(float v, bool hi) {
+    v += TFR_DPP_F(0.f, v, 0x111, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x112, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x114, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x118, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x142, 0xa, 0xf, false);                   // row_bcast:15 into rows 1 and 3
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return hi ? b : a;
+  }
+  static __device__ __forceinline__ float max(float v, bool hi) {
+    const float ninf = -INFINITY;
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x111, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x112, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x114, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x118, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x142, 0xa, 0xf, false));
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    return hi ? b : a;
+  }
+};
+template <> struct SegOps<16> {      // totals of the four 16-lane rows
+  static __device__ __forceinline__ float pick(float v, int seg) {
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 31));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 47));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+    const float lo = (seg & 1) ? r1 : r0, hi = (seg & 1) ? r3 : r2;
+    return (seg & 2) ? hi : lo;
+  }
+  static __device__ __forceinline__ float sum(float v, int seg) {
+    v += TFR_DPP_F(0.f, v, 0x111, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x112, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x114, 0xf, 0xf, true);
+    v += TFR_DPP_F(0.f, v, 0x118, 0xf, 0xf, true);
+    return pick(v, seg);
+  }
+  static __device__ __forceinline__ float max(float v, int seg) {
+    const float ninf = -INFINITY;
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x111, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x112, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x114, 0xf, 0xf, false));
+    v = fmaxf(v, TFR_DPP_F(ninf, v, 0x118, 0xf, 0xf, false));
+    return pick(v, seg);
+  }
+};
+
+template <int LG, int IPL, bool NT, bool LW>
+__global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B) {
+  constexpr int S = 64 / LG;                              // lists per wavefront
+  const int lane = threadIdx.x & 63;
+  const int seg = lane / LG, sl = lane % LG;
+  const int W = gridDim.x * 4;
+  const int G = (B + S - 1) / S;                          // groups of S adjacent lists
+  int g = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));    // (the grid never exceeds the groups)
+  const int wave_id = g;
+  const int L = a.L;
+  const float inv_t = 1.0f / a.temperature;
+  int off[IPL];
+  bool in[IPL];
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) { const int i = sl + LG * r; in[r] = i < L; off[r] = in[r] ? i : 0; }
+  float lab_n[IPL], x_n[IPL], wl_n = 1.0f;                // (LW: one weight per list, item_weights[b])
+  auto fetch = [&](int gg) {
+    int bl = gg * S + seg;
+    bl = bl < B ? bl : B - 1;                              // an absent list of the last group re-reads the last list
+    if (LW) wl_n = a.item_weights[bl];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const float* pl = a.labels + (size_t)bl * L + off[r];
+      const float* px = a.logits + (size_t)bl * L + off[r];
+      lab_n[r] = NT ? __builtin_nontemporal_load(pl) : *pl;
+      x_n[r] = NT ? __builtin_nontemporal_load(px) : *px;
+    }
+  };
+  float wacc = 0.f;                                       // lanes with sl == 0: sum of loss * weight over the lists of that lane group
+  if (g < G) fetch(g);
+  for (; g < G; g += W) {
+    float lab[IPL], x[IPL];
+    const float wl = wl_n;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) { lab[r] = lab_n[r]; x[r] = x_n[r]; }
+    fetch(g + W < G ? g + W : g);                         // the next group of this wavefront (the last one re-reads itself)
+    const int b = g * S + seg;
+    const bool have = b < B;
+    float z[IPL], y[IPL], e[IPL];
+    bool mv[IPL];
+    float lsum = 0.f, zmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      mv[r] = in[r] && lab[r] >= 0.0f;
+      z[r] = mv[r] ? x[r] * inv_t : (in[r] ? kLogEps10 : -INFINITY);
+      y[r] = mv[r] ? lab[r] : 0.0f;
+      if (LW) y[r] *= wl;
+      lsum += y[r];
+      zmax = fmaxf(zmax, z[r]);
+    }
+    const auto sg = [&](float v) { if constexpr (LG == 32) return SegOps<32>::sum(v, seg != 0); else return SegOps<16>::sum(v, seg); };
+    const auto mg = [&](float v) { if constexpr (LG == 32) return SegOps<32>::max(v, seg != 0); else return SegOps<16>::max(v, seg); };
+    lsum = sg(lsum);
+    zmax = mg(zmax);
+    const bool nonzero = lsum > 0.0f;
+    float psum = 0.f, esum = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      float yy = nonzero ? y[r] : 1e-10f;
+      yy = mv[r] ? yy : 0.0f;
+      y[r] = yy;
+      psum += yy;
+      e[r] = in[r] ? __builtin_amdgcn_exp2f((z[r] - zmax) * 1.44269504088896340736f) : 0.0f;
+      esum += e[r];
+    }
+    psum = sg(psum);
+    esum = sg(esum);
+    const float lse = logf(esum);
+    const float inv_p = (psum != 0.0f) ? 1.0f / psum : 0.0f;            // divide_no_nan
+    const float inv_e = 1.0f / esum;
+    float loss = 0.f, ptot = 0.f, pt = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const float p = y[r] * inv_p;
+      loss += in[r] ? p * (lse - (z[r] - zmax)) : 0.0f;
+      ptot += p;
+      pt += p * (e[r] * inv_e);
+      y[r] = p;
+    }
+    loss = sg(loss);
+    ptot = sg(ptot);
+    if (a.poly_eps != 0.0f) {
+      pt = sg(pt);
+      loss += a.poly_eps * (1.0f - pt);
+    }
+    if (have && sl == 0) { a.loss[b] = loss; a.weight[b] = lsum; wacc = __builtin_fmaf(loss, lsum, wacc); }
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const float sm = e[r] * inv_e;
+      float dd = ptot * sm - y[r];
+      if (a.poly_eps != 0.0f) dd -= a.poly_eps * sm * (y[r] - pt);
+      const float gv = mv[r] ? (lsum * inv_t) * dd : 0.0f;
+      if (have && in[r]) {
+        float* pd = a.dlogits + (size_t)b * L + off[r];
+        if (NT) __builtin_nontemporal_store(gv, pd); else *pd = gv;
+      }
+    }
+  }
+  // one contributor per wavefront (see softmax_stream_kernel): its lane groups' sums added in lane order
+  if (a.sum.out || a.sum.vec) {
+    const float wsum = wave_sum_u(wacc);
+    if (a.sum.out) grid_sum_contribute(a.sum, wave_id, wsum, lane);
+    else if (lane == 0) a.sum.vec[wave_id] = wsum;
+  }
+}
+
 }  // namespace
 
 extern "C" int tfr_poly1_softmax_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
@@ -608,9 +776,26 @@ static bool sm_streams(int B, int L, bool has_mask, bool per_item_weights, int l
          (B + 3) / 4 > groups && groups >= 1;
 }
 
-extern "C" int tfr_softmax_sum_contributors(int B, int L, int has_mask, int per_item_weights, int lambda_kind, int want_grad) {
+// packed form: plain case (no per-item weights), list_size <= 256; lanes per list / items per lane by list size
+static bool sm_packs(int L, bool has_mask, bool has_weights, int lambda_kind, bool want_grad) {
+  static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
+  static const int env_pack = [] { const char* e = getenv("TFR_SOFTMAX_PACK"); return (e && *e) ? atoi(e) : 1; }();
+  return env_wave && env_pack && lambda_kind == TFR_LAMBDA_NONE && L <= 256 && !has_mask && !has_weights && want_grad;
+}
+static int sm_pack_lists_per_wave(int L) { return L <= 64 ? 4 : 2; }
+static int sm_pack_grid(int B, int L) {
+  const int S = sm_pack_lists_per_wave(L);
+  const int groups = (B + S - 1) / S;
+  const int wg = (groups + 3) / 4;
+  return wg < sm_stream_groups() ? wg : sm_stream_groups();
+}
+
+// has_weights: 0 none, 1 per list, 2 per item
+extern "C" int tfr_softmax_sum_contributors(int B, int L, int has_mask, int has_weights, int lambda_kind, int want_grad) {
   if (B < 0 || L <= 0) return TFR_EINVAL;
-  return sm_streams(B, L, has_mask != 0, per_item_weights != 0, lambda_kind, want_grad != 0) ? 4 * sm_stream_groups() : B;
+  if (B == 0) return 0;
+  if (sm_packs(L, has_mask != 0, has_weights == 2, lambda_kind, want_grad != 0)) return 4 * sm_pack_grid(B, L);
+  return sm_streams(B, L, has_mask != 0, has_weights == 2, lambda_kind, want_grad != 0) ? 4 * sm_stream_groups() : B;
 }
 
 static int softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
@@ -642,6 +827,18 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
     static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
     const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
     const int env_groups = sm_stream_groups();
+    if (sm_packs(L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
+      const int grid = sm_pack_grid(B, L);
+      a.sum.n = grid * 4;                                           // one contributor per wavefront
+#define SPK2(G_, I_, N_) do { if (item_weights) hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, true>), dim3(grid), dim3(256), 0, st, a, B); \
+                             else hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, false>), dim3(grid), dim3(256), 0, st, a, B); } while (0)
+#define SPK(G_, I_) do { if (nt) SPK2(G_, I_, true); else SPK2(G_, I_, false); } while (0)
+      if (L <= 16) SPK(16, 1); else if (L <= 32) SPK(16, 2); else if (L <= 64) SPK(16, 4);
+      else if (L <= 128) SPK(32, 4); else SPK(32, 8);
+#undef SPK
+#undef SPK2
+      return (int)hipGetLastError();
+    }
     if (sm_streams(B, L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
       static const int env_depth = [] { const char* e = getenv("TFR_SOFTMAX_STREAM_DEPTH"); return (e && *e) ? atoi(e) : 2; }();
       a.sum.n = env_groups * 4;                                     // ... per wave in the streaming form

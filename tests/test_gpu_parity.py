@@ -2121,9 +2121,10 @@ def test_softmax_large_batches_against_the_c_arbiter(B, L, wkind):
 @pytest.mark.parametrize('eps', [0.0, 1.5])
 @pytest.mark.parametrize('list_weights', [False, True])
 def test_softmax_streaming_kernel_is_the_per_list_kernel(B, L, eps, list_weights):
-    """More than 8192 lists of the plain case take softmax_stream_kernel (a wave walks several lists with the next
-    list's loads in flight; out-of-range slots re-read / re-write item 0): every loss, weight and gradient bit for bit
-    what softmax_wave_kernel gives for the same rows in batches it serves, last wave / last list included."""
+    """The persistent forms of the plain case (round 5: softmax_pack_kernel, two / four lists per wavefront, a wavefront
+    walks several groups with the next group's loads in flight; round 4: softmax_stream_kernel) give every row the same
+    bits whatever batch surrounds it: a large batch against the same rows in 8000-list batches, last wave / last group /
+    odd list count included."""
     from ranking_amd import _ops
     labels, logits = make_batch(B, L, seed=77 + L)
     labels[0] = -1.0
