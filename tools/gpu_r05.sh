@@ -34,6 +34,14 @@ for what in "$@"; do
         ab "fused=$v" softmax 200 TFR_LOSS_SUM_FUSED=$v
         ab "fused=$v" pairwise_lambda 200 TFR_LOSS_SUM_FUSED=$v
       done ;;
+    softmax_ab)
+      for v in 0 1; do
+        ab "pack=$v" softmax_hbm 50 TFR_SOFTMAX_PACK=$v
+        ab "pack=$v" softmax 200 TFR_SOFTMAX_PACK=$v
+      done
+      ab "pack=1 list_dot" softmax_hbm 50 TFR_LOSS_SUM_FUSED=0
+      ab "pack=1 groups=4096" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=4096
+      ab "pack=1 groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024 ;;
     ndcg_ab)
       for v in 0 1; do
         ab "lean=$v" ndcg_metric_hbm 20 TFR_NDCG_LEAN=$v
