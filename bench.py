@@ -226,16 +226,15 @@ def build_step(workload, labels, logits, dropout=0.0, use_graph=False):
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
                     kernel=lambda: _ops.pairwise_logistic(                 # exactly the launch of loss_and_grad
                         logits, labels, None, None, list_w, temperature=1.0, want_grad=True, want_rows=False,
-                        want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC, want_sum=True,
+                        want_aux=False, want_list=True, loss_kind=_ops.PAIR_LOGISTIC,
                         balance=order if order is not None else False, **lam),
                     kernel_name=('lambdarank_group_kernel' if B >= 512 else 'pairwise_lean_kernel') if L <= 256 else 'pairwise_logistic_kernel')
     if workload == 'softmax':
         loss = K.SoftmaxLoss()
         w = torch.full((B,), 1.0 / B, dtype=torch.float32, device=dev)
         return dict(step=lambda: loss.loss_and_grad(labels, logits),
-                    kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True,
-                                                     want_sum=True),          # exactly the launch of loss_and_grad
-                    kernel_name='softmax_pack_kernel (two lists per wavefront, persistent)')
+                    kernel=lambda: _ops.softmax_loss(logits, labels, None, w, temperature=1.0, want_grad=True),
+                    kernel_name='softmax_pack_kernel (two lists per wavefront, persistent)' if B >= 8192 else 'softmax_wave_kernel')
     if workload == 'gumbel_approx_ndcg':
         loss = K.GumbelApproxNDCGLoss(seed=1)
         S = 8

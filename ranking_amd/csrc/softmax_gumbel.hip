@@ -610,7 +610,7 @@ template <> struct SegOps<16> {      // totals of the four 16-lane rows
   }
 };
 
-template <int LG, int IPL, bool NT, bool LW>
+template <int LG, int IPL, bool NT, bool LW, int D>      // D groups of lists in flight per wavefront (TFR_SOFTMAX_PACK_DEPTH)
 __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B) {
   constexpr int S = 64 / LG;                              // lists per wavefront
   const int lane = threadIdx.x & 63;
@@ -625,27 +625,30 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
   bool in[IPL];
 #pragma unroll
   for (int r = 0; r < IPL; ++r) { const int i = sl + LG * r; in[r] = i < L; off[r] = in[r] ? i : 0; }
-  float lab_n[IPL], x_n[IPL], wl_n = 1.0f;                // (LW: one weight per list, item_weights[b])
-  auto fetch = [&](int gg) {
+  float lab_n[D][IPL], x_n[D][IPL], wl_n[D];              // (LW: one weight per list, item_weights[b])
+  auto fetch = [&](const int d, int gg) {
+    gg = gg < G ? gg : (wave_id < G ? wave_id : 0);        // a group past the end re-reads the wavefront's first one
     int bl = gg * S + seg;
     bl = bl < B ? bl : B - 1;                              // an absent list of the last group re-reads the last list
-    if (LW) wl_n = a.item_weights[bl];
+    wl_n[d] = LW ? a.item_weights[bl] : 1.0f;
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
       const float* pl = a.labels + (size_t)bl * L + off[r];
       const float* px = a.logits + (size_t)bl * L + off[r];
-      lab_n[r] = NT ? __builtin_nontemporal_load(pl) : *pl;
-      x_n[r] = NT ? __builtin_nontemporal_load(px) : *px;
+      lab_n[d][r] = NT ? __builtin_nontemporal_load(pl) : *pl;
+      x_n[d][r] = NT ? __builtin_nontemporal_load(px) : *px;
     }
   };
   float wacc = 0.f;                                       // lanes with sl == 0: sum of loss * weight over the lists of that lane group
-  if (g < G) fetch(g);
-  for (; g < G; g += W) {
-    float lab[IPL], x[IPL];
-    const float wl = wl_n;
+  // (up to three wavefronts of the last workgroup have no group: they fall through both loops and contribute a zero sum)
 #pragma unroll
-    for (int r = 0; r < IPL; ++r) { lab[r] = lab_n[r]; x[r] = x_n[r]; }
-    fetch(g + W < G ? g + W : g);                         // the next group of this wavefront (the last one re-reads itself)
+  for (int d = 0; d < D; ++d) fetch(d, g + d * W);
+  auto one_group = [&](const int d, const int g, const bool reload) {
+    float lab[IPL], x[IPL];
+    const float wl = wl_n[d];
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) { lab[r] = lab_n[d][r]; x[r] = x_n[d][r]; }
+    if (reload) fetch(d, g + D * W);                      // the slot is free: the group D W further on
     const int b = g * S + seg;
     const bool have = b < B;
     float z[IPL], y[IPL], e[IPL];
@@ -707,6 +710,14 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
         if (NT) __builtin_nontemporal_store(gv, pd); else *pd = gv;
       }
     }
+  };
+  for (; g + (D - 1) * W < G; g += D * W) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) one_group(d, g + d * W, true);
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) {                           // the last fewer-than-D groups of this wavefront
+    if (g + d * W < G) one_group(d, g + d * W, false);
   }
   // one contributor per wavefront (see softmax_stream_kernel): its lane groups' sums added in lane order
   if (a.sum.out || a.sum.vec) {
@@ -777,12 +788,16 @@ static bool sm_streams(int B, int L, bool has_mask, bool per_item_weights, int l
 }
 
 // packed form: plain case (no per-item weights), list_size <= 256; lanes per list / items per lane by list size
-static bool sm_packs(int L, bool has_mask, bool has_weights, int lambda_kind, bool want_grad) {
+static int sm_pack_lists_per_wave(int L) { return L <= 64 ? 4 : 2; }
+// (from 4 096 wavefronts' worth of lists on: below that the one-list-per-wavefront kernel has more wavefronts to hide latency
+// behind -- B = 4 096, L = 100: 12.4 us per step against 13.3 packed; B = 65 536: 24.9 -> 22 us per launch, profiles/r05_softmax_ab.txt)
+static bool sm_packs(int B, int L, bool has_mask, bool has_weights, int lambda_kind, bool want_grad) {
   static const int env_wave = [] { const char* e = getenv("TFR_SOFTMAX_WAVE"); return (e && *e) ? atoi(e) : 1; }();
   static const int env_pack = [] { const char* e = getenv("TFR_SOFTMAX_PACK"); return (e && *e) ? atoi(e) : 1; }();
-  return env_wave && env_pack && lambda_kind == TFR_LAMBDA_NONE && L <= 256 && !has_mask && !has_weights && want_grad;
+  static const int env_min = [] { const char* e = getenv("TFR_SOFTMAX_PACK_MIN_WAVES"); return (e && *e) ? atoi(e) : 4096; }();
+  return env_wave && env_pack && lambda_kind == TFR_LAMBDA_NONE && L <= 256 && !has_mask && !has_weights && want_grad &&
+         (B + sm_pack_lists_per_wave(L) - 1) / sm_pack_lists_per_wave(L) >= env_min;
 }
-static int sm_pack_lists_per_wave(int L) { return L <= 64 ? 4 : 2; }
 static int sm_pack_grid(int B, int L) {
   const int S = sm_pack_lists_per_wave(L);
   const int groups = (B + S - 1) / S;
@@ -794,7 +809,7 @@ static int sm_pack_grid(int B, int L) {
 extern "C" int tfr_softmax_sum_contributors(int B, int L, int has_mask, int has_weights, int lambda_kind, int want_grad) {
   if (B < 0 || L <= 0) return TFR_EINVAL;
   if (B == 0) return 0;
-  if (sm_packs(L, has_mask != 0, has_weights == 2, lambda_kind, want_grad != 0)) return 4 * sm_pack_grid(B, L);
+  if (sm_packs(B, L, has_mask != 0, has_weights == 2, lambda_kind, want_grad != 0)) return 4 * sm_pack_grid(B, L);
   return sm_streams(B, L, has_mask != 0, has_weights == 2, lambda_kind, want_grad != 0) ? 4 * sm_stream_groups() : B;
 }
 
@@ -827,16 +842,19 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
     static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
     const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
     const int env_groups = sm_stream_groups();
-    if (sm_packs(L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
+    if (sm_packs(B, L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
       const int grid = sm_pack_grid(B, L);
       a.sum.n = grid * 4;                                           // one contributor per wavefront
-#define SPK2(G_, I_, N_) do { if (item_weights) hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, true>), dim3(grid), dim3(256), 0, st, a, B); \
-                             else hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, false>), dim3(grid), dim3(256), 0, st, a, B); } while (0)
+      static const int env_pdepth = [] { const char* e = getenv("TFR_SOFTMAX_PACK_DEPTH"); return (e && *e) ? atoi(e) : 1; }();
+#define SPK3(G_, I_, N_, W_) do { if (env_pdepth >= 2) hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, W_, 2>), dim3(grid), dim3(256), 0, st, a, B); \
+                                 else hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, W_, 1>), dim3(grid), dim3(256), 0, st, a, B); } while (0)
+#define SPK2(G_, I_, N_) do { if (item_weights) SPK3(G_, I_, N_, true); else SPK3(G_, I_, N_, false); } while (0)
 #define SPK(G_, I_) do { if (nt) SPK2(G_, I_, true); else SPK2(G_, I_, false); } while (0)
       if (L <= 16) SPK(16, 1); else if (L <= 32) SPK(16, 2); else if (L <= 64) SPK(16, 4);
       else if (L <= 128) SPK(32, 4); else SPK(32, 8);
 #undef SPK
 #undef SPK2
+#undef SPK3
       return (int)hipGetLastError();
     }
     if (sm_streams(B, L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {

@@ -2089,6 +2089,22 @@ def test_lambdarank_fast_path_randomised_against_the_general_kernel(seed):
     assert_grad_close(xa.grad, xb.grad, 1e-5, what='grad')
 
 
+def _softmax_form(B, L, per_item):
+    """which kernel form a plain softmax batch takes, told by its number of sum contributors: B = one per list (per-list
+    kernels), otherwise a persistent form (packed: 4 x ceil(groups / 4) up to 8192; streaming: 8192)"""
+    from ranking_amd import _lib
+    n = _lib.load().tfr_softmax_sum_contributors(B, L, 0, 2 if per_item else 0, 0, 1)
+    packed_groups = (B + (4 if L <= 64 else 2) - 1) // (4 if L <= 64 else 2)
+    if n == B:
+        return 'per-list'
+    return 'packed' if (not per_item and L <= 256 and packed_groups >= 4096) else 'streaming'
+
+
+def _softmax_same_form(B1, B2, L, per_item):
+    f1, f2 = _softmax_form(B1, L, per_item), _softmax_form(B2, L, per_item)
+    return f1 == f2 or {f1, f2} == {'per-list', 'streaming'}      # (the streaming form is bit for bit the per-list kernel)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('B,L', [(2100, 50), (2049, 200), (8300, 100), (8193, 256), (16384, 200), (8193, 37), (9001, 64),
                                  (20011, 129)])
@@ -2113,7 +2129,12 @@ def test_softmax_large_batches_against_the_c_arbiter(B, L, wkind):
     n = 1000                                                  # a row does not depend on the batch around it
     l1, w1, g1 = _ops.softmax_loss(d(logits[:n]), d(labels[:n]), None, d(None if w is None else w[:n]), temperature=0.7,
                                    want_grad=True)
-    assert torch.equal(loss[:n], l1) and torch.equal(weight[:n], w1) and torch.equal(grad[:n], g1)
+    if _softmax_same_form(B, n, L, wkind == 'item'):
+        assert torch.equal(loss[:n], l1) and torch.equal(weight[:n], w1) and torch.equal(grad[:n], g1)
+    else:     # the packed form (two / four lists per wavefront) adds a list's items in another order than the per-list kernel
+        assert_loss_close(loss[:n], l1, 2e-6, what='softmax rows, packed vs per-list kernel')
+        assert_loss_close(weight[:n], w1, 1e-6, what='softmax row weights, packed vs per-list kernel')
+        assert_grad_close(grad[:n], g1, 2e-6, what='softmax rows, packed vs per-list kernel')
 
 
 @pytest.mark.gpu
@@ -2133,12 +2154,18 @@ def test_softmax_streaming_kernel_is_the_per_list_kernel(B, L, eps, list_weights
     w = make_weights(B, 1, seed=6).reshape(B).to(DEV) if list_weights else None
     loss, weight, grad = _ops.softmax_loss(d_logits, d_labels, None, w, temperature=0.5, want_grad=True, poly_epsilon=eps)
     assert torch.isfinite(loss).all() and torch.isfinite(grad).all()
-    for lo in list(range(0, B, 8000)):
-        hi = min(B, lo + 8000)
-        l1, w1, g1 = _ops.softmax_loss(d_logits[lo:hi].contiguous(), d_labels[lo:hi].contiguous(), None,
-                                       None if w is None else w[lo:hi].contiguous(), temperature=0.5,
-                                       want_grad=True, poly_epsilon=eps)
-        assert torch.equal(loss[lo:hi], l1) and torch.equal(weight[lo:hi], w1) and torch.equal(grad[lo:hi], g1), (lo, hi)
+    for chunk in (8000, 16384):                                # 8000 lists: a per-list-kernel batch; 16384: a packed one (L > 64)
+        for lo in list(range(0, B, chunk)):
+            hi = min(B, lo + chunk)
+            l1, w1, g1 = _ops.softmax_loss(d_logits[lo:hi].contiguous(), d_labels[lo:hi].contiguous(), None,
+                                           None if w is None else w[lo:hi].contiguous(), temperature=0.5,
+                                           want_grad=True, poly_epsilon=eps)
+            if _softmax_same_form(B, hi - lo, L, False):
+                assert torch.equal(loss[lo:hi], l1) and torch.equal(weight[lo:hi], w1) and torch.equal(grad[lo:hi], g1), (lo, hi)
+            else:
+                assert_loss_close(loss[lo:hi], l1, 2e-6, what='softmax rows, packed vs per-list kernel')
+                assert_loss_close(weight[lo:hi], w1, 1e-6, what='softmax row weights, packed vs per-list kernel')
+                assert_grad_close(grad[lo:hi], g1, 2e-6, what='softmax rows, packed vs per-list kernel')
 
 
 def test_metrics_of_lists_without_items_are_zero():

@@ -39,9 +39,11 @@ for what in "$@"; do
         ab "pack=$v" softmax_hbm 50 TFR_SOFTMAX_PACK=$v
         ab "pack=$v" softmax 200 TFR_SOFTMAX_PACK=$v
       done
-      ab "pack=1 list_dot" softmax_hbm 50 TFR_LOSS_SUM_FUSED=0
-      ab "pack=1 groups=4096" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=4096
-      ab "pack=1 groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024 ;;
+      ab "pack=1 depth=2" softmax_hbm 50 TFR_SOFTMAX_PACK_DEPTH=2
+      ab "pack=1 depth=2 groups=1024" softmax_hbm 50 TFR_SOFTMAX_PACK_DEPTH=2 TFR_SOFTMAX_STREAM_GROUPS=1024
+      ab "pack=1 groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024
+      ab "pack=1 groups=512" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=512
+      rocprofv3 -L 2>/dev/null | grep -o "TCP_[A-Z_0-9]*\|TA_[A-Z_0-9]*\|TCC_[A-Z_0-9]*\|SQ_[A-Z_0-9]*" | sort -u > $OUT/counters.txt; wc -l $OUT/counters.txt ;;
     ndcg_ab)
       for v in 0 1; do
         ab "lean=$v" ndcg_metric_hbm 20 TFR_NDCG_LEAN=$v
