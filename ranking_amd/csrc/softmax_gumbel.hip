@@ -680,9 +680,11 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
     }
     psum = sg(psum);
     esum = sg(esum);
-    const float lse = logf(esum);
-    const float inv_p = (psum != 0.0f) ? 1.0f / psum : 0.0f;            // divide_no_nan
-    const float inv_e = 1.0f / esum;
+    // single-instruction log / reciprocals (1 ulp each: the loss and the gradient stay within a few 1e-7 of the fp64
+    // arbiter; the libm logf and two IEEE divisions were ~35 of the ~300 vector instructions of a group)
+    const float lse = __builtin_amdgcn_logf(esum) * 0.69314718055994530942f;
+    const float inv_p = (psum != 0.0f) ? __builtin_amdgcn_rcpf(psum) : 0.0f;      // divide_no_nan
+    const float inv_e = __builtin_amdgcn_rcpf(esum);
     float loss = 0.f, ptot = 0.f, pt = 0.f;
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
@@ -788,7 +790,13 @@ static bool sm_streams(int B, int L, bool has_mask, bool per_item_weights, int l
 }
 
 // packed form: plain case (no per-item weights), list_size <= 256; lanes per list / items per lane by list size
-static int sm_pack_lists_per_wave(int L) { return L <= 64 ? 4 : 2; }
+// lanes per list of the packed form: 16 (four lists per wavefront) up to 64 items, beyond that TFR_SOFTMAX_PACK_LG (32 = two
+// lists per wavefront, 8 items per lane at most; 16 = four lists, up to 16 items per lane)
+static int sm_pack_lg() {
+  static const int env_lg = [] { const char* e = getenv("TFR_SOFTMAX_PACK_LG"); return (e && *e) ? atoi(e) : 32; }();
+  return env_lg == 16 ? 16 : 32;
+}
+static int sm_pack_lists_per_wave(int L) { return (L <= 64 || sm_pack_lg() == 16) ? 4 : 2; }
 // (from 4 096 wavefronts' worth of lists on: below that the one-list-per-wavefront kernel has more wavefronts to hide latency
 // behind -- B = 4 096, L = 100: 12.4 us per step against 13.3 packed; B = 65 536: 24.9 -> 22 us per launch, profiles/r05_softmax_ab.txt)
 static bool sm_packs(int B, int L, bool has_mask, bool has_weights, int lambda_kind, bool want_grad) {
@@ -851,6 +859,7 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
 #define SPK2(G_, I_, N_) do { if (item_weights) SPK3(G_, I_, N_, true); else SPK3(G_, I_, N_, false); } while (0)
 #define SPK(G_, I_) do { if (nt) SPK2(G_, I_, true); else SPK2(G_, I_, false); } while (0)
       if (L <= 16) SPK(16, 1); else if (L <= 32) SPK(16, 2); else if (L <= 64) SPK(16, 4);
+      else if (sm_pack_lg() == 16) { if (L <= 112) SPK(16, 7); else if (L <= 128) SPK(16, 8); else if (L <= 208) SPK(16, 13); else SPK(16, 16); }
       else if (L <= 128) SPK(32, 4); else SPK(32, 8);
 #undef SPK
 #undef SPK2

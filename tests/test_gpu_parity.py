@@ -2094,7 +2094,9 @@ def _softmax_form(B, L, per_item):
     kernels), otherwise a persistent form (packed: 4 x ceil(groups / 4) up to 8192; streaming: 8192)"""
     from ranking_amd import _lib
     n = _lib.load().tfr_softmax_sum_contributors(B, L, 0, 2 if per_item else 0, 0, 1)
-    packed_groups = (B + (4 if L <= 64 else 2) - 1) // (4 if L <= 64 else 2)
+    import os
+    per = 4 if (L <= 64 or os.environ.get('TFR_SOFTMAX_PACK_LG') == '16') else 2
+    packed_groups = (B + per - 1) // per
     if n == B:
         return 'per-list'
     return 'packed' if (not per_item and L <= 256 and packed_groups >= 4096) else 'streaming'

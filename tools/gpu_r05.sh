@@ -35,15 +35,12 @@ for what in "$@"; do
         ab "fused=$v" pairwise_lambda 200 TFR_LOSS_SUM_FUSED=$v
       done ;;
     softmax_ab)
-      for v in 0 1; do
-        ab "pack=$v" softmax_hbm 50 TFR_SOFTMAX_PACK=$v
-        ab "pack=$v" softmax 200 TFR_SOFTMAX_PACK=$v
-      done
-      ab "pack=1 depth=2" softmax_hbm 50 TFR_SOFTMAX_PACK_DEPTH=2
-      ab "pack=1 depth=2 groups=1024" softmax_hbm 50 TFR_SOFTMAX_PACK_DEPTH=2 TFR_SOFTMAX_STREAM_GROUPS=1024
-      ab "pack=1 groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024
-      ab "pack=1 groups=512" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=512
-      rocprofv3 -L 2>/dev/null | grep -o "TCP_[A-Z_0-9]*\|TA_[A-Z_0-9]*\|TCC_[A-Z_0-9]*\|SQ_[A-Z_0-9]*" | sort -u > $OUT/counters.txt; wc -l $OUT/counters.txt ;;
+      ab "pack=0" softmax_hbm 50 TFR_SOFTMAX_PACK=0
+      ab "pack lg=32" softmax_hbm 50 TFR_SOFTMAX_PACK_LG=32
+      ab "pack lg=16" softmax_hbm 50 TFR_SOFTMAX_PACK_LG=16
+      ab "pack lg=16 groups=1024" softmax_hbm 50 TFR_SOFTMAX_PACK_LG=16 TFR_SOFTMAX_STREAM_GROUPS=1024
+      ab "pack lg=16 groups=4096" softmax_hbm 50 TFR_SOFTMAX_PACK_LG=16 TFR_SOFTMAX_STREAM_GROUPS=4096
+      TFR_SOFTMAX_PACK_LG=16 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax or reduced_scalar" > $OUT/t_softmax16.log 2>&1; echo "softmax tests (lg=16) rc=$?"; tail -n 2 $OUT/t_softmax16.log | cut -c1-200 ;;
     ndcg_ab)
       for v in 0 1; do
         ab "lean=$v" ndcg_metric_hbm 20 TFR_NDCG_LEAN=$v
