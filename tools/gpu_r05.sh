@@ -68,7 +68,15 @@ for what in "$@"; do
       done
       timeout 60 python tools/gemm_pp_check.py $OUT compare > $OUT/gemm_pp_compare.txt 2>&1; echo "compare rc=$?"; cat $OUT/gemm_pp_compare.txt | cut -c1-160 ;;
     lrank_ab)
-      for v in ${LRANK_VARIANTS:-"TFR_LAMBDARANK_LO16=0" "TFR_LAMBDARANK_LO16=1"}; do ab "$v" pairwise_lambda 200 $v; done ;;
+      ab "default" pairwise_lambda 200 TFR_DUMMY=0
+      ab "G=4" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=4
+      ab "G=4 helpers=4" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=4 TFR_LAMBDARANK_HELPERS=4
+      ab "G=4 helpers=0" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=4 TFR_LAMBDARANK_HELPERS=0
+      ab "G=4 R=16 helpers=2" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=4 TFR_LAMBDARANK_REP=16 TFR_LAMBDARANK_HELPERS=2
+      ab "G=6 helpers=3" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=6 TFR_LAMBDARANK_HELPERS=3
+      ab "G=8 helpers=2" pairwise_lambda 200 TFR_LAMBDARANK_HELPERS=2
+      ab "G=8 helpers=6" pairwise_lambda 200 TFR_LAMBDARANK_HELPERS=6
+      ab "G=8 R=16" pairwise_lambda 200 TFR_LAMBDARANK_REP=16 ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
