@@ -314,6 +314,60 @@ def list_order(labels, mask=None):
     return order
 
 
+# The launch order is a function of the LABELS (and the mask) alone and only steers load balance -- the loss kernels write
+# every list to its own rows, so their results do not depend on it.  It is therefore cached per label tensor (round 5,
+# VERDICT r4 next #7): keyed on the tensor object, its storage address and its version counter (bumped by every in-place
+# write), so a batch whose labels are passed again unchanged -- every epoch over a device-resident dataset, every
+# evaluation pass, every replay of a training step on the same batch -- pays the two ordering launches (11 us + gaps of a
+# 136 us ApproxNDCG step at B = 16384) once.  A stale entry could only ever cost balance, never correctness.  Entries read
+# while a stream capture is recording are pinned for the life of the process (the graph holds the order's address);
+# TFR_ORDER_CACHE=0 (or order_cache(False)) recomputes the order in every call like rounds 1-4.
+_ORDER_CACHE_ON = os.environ.get('TFR_ORDER_CACHE', '1') != '0'
+_order_lru: 'OrderedDict[Tuple, Tuple]' = OrderedDict()
+_order_pinned: Dict[Tuple, Tuple] = {}
+_ORDER_CACHE_CAPACITY = 64
+
+
+class order_cache(object):
+    """Context manager / switch: ``with order_cache(False): ...`` computes the launch order in every call."""
+
+    def __init__(self, enabled: bool):
+        self._enabled = bool(enabled)
+
+    def __enter__(self):
+        global _ORDER_CACHE_ON
+        self._saved, _ORDER_CACHE_ON = _ORDER_CACHE_ON, self._enabled
+        return self
+
+    def __exit__(self, *exc):
+        global _ORDER_CACHE_ON
+        _ORDER_CACHE_ON = self._saved
+
+
+def _cached_order(labels, mask):
+    import weakref
+    if not _ORDER_CACHE_ON:
+        return list_order(labels, mask)
+    key = (labels.data_ptr(), tuple(labels.shape), str(labels.device), None if mask is None else mask.data_ptr())
+    stamp = (labels._version, None if mask is None else mask._version)
+    capturing = torch.cuda.is_current_stream_capturing()
+    ent = _order_pinned.get(key) or _order_lru.get(key)
+    if ent is not None and ent[0] == stamp and ent[1]() is labels:       # (the mask is a fresh uint8 view per call: address + version)
+        if capturing and key in _order_lru:
+            _order_pinned[key] = _order_lru.pop(key)
+        elif key in _order_lru:
+            _order_lru.move_to_end(key)
+        return ent[3]
+    order = list_order(labels, mask)
+    if capturing:                       # its storage belongs to the graph's pool: not cached
+        return order
+    _order_pinned.pop(key, None)
+    _order_lru[key] = (stamp, weakref.ref(labels), None, order)
+    while len(_order_lru) > _ORDER_CACHE_CAPACITY:
+        _order_lru.popitem(last=False)
+    return order
+
+
 def _auto_order(labels, mask, balance, min_list_size):
     """balance: None = automatic, False = index order, True = compute the order, or a ready int32 [B] order.
     Automatic: the two ordering launches cost ~20 us; they pay for themselves when the tail they remove
@@ -325,7 +379,7 @@ def _auto_order(labels, mask, balance, min_list_size):
     B, L = labels.shape
     if balance is None:
         balance = B >= _BALANCE_MIN_LISTS and L >= min_list_size
-    return list_order(labels, mask) if balance else None
+    return _cached_order(labels, mask) if balance else None
 
 
 def approx_ndcg(logits, labels, mask=None, list_scale=None, temperature=0.1, lanes_per_row=0,
@@ -636,4 +690,4 @@ def _guard_module(namespace, module_name, skip=()):
             namespace[name] = device_guarded(obj)
 
 
-_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded'))
+_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded', 'order_cache'))
