@@ -630,11 +630,12 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
     gg = gg < G ? gg : (wave_id < G ? wave_id : 0);        // a group past the end re-reads the wavefront's first one
     int bl = gg * S + seg;
     bl = bl < B ? bl : B - 1;                              // an absent list of the last group re-reads the last list
-    wl_n[d] = LW ? a.item_weights[bl] : 1.0f;
+    wl_n[d] = LW ? a.item_weights[(uint32_t)bl] : 1.0f;
+    const uint32_t row = (uint32_t)bl * (uint32_t)L;       // (B L < 2^30, checked by the launcher: uniform base + 32-bit offset)
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
-      const float* pl = a.labels + (size_t)bl * L + off[r];
-      const float* px = a.logits + (size_t)bl * L + off[r];
+      const float* pl = a.labels + (row + (uint32_t)off[r]);
+      const float* px = a.logits + (row + (uint32_t)off[r]);
       lab_n[d][r] = NT ? __builtin_nontemporal_load(pl) : *pl;
       x_n[d][r] = NT ? __builtin_nontemporal_load(px) : *px;
     }
@@ -644,25 +645,21 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
 #pragma unroll
   for (int d = 0; d < D; ++d) fetch(d, g + d * W);
   auto one_group = [&](const int d, const int g, const bool reload) {
-    float lab[IPL], x[IPL];
-    const float wl = wl_n[d];
-#pragma unroll
-    for (int r = 0; r < IPL; ++r) { lab[r] = lab_n[d][r]; x[r] = x_n[d][r]; }
-    if (reload) fetch(d, g + D * W);                      // the slot is free: the group D W further on
     const int b = g * S + seg;
     const bool have = b < B;
     float z[IPL], y[IPL], e[IPL];
     bool mv[IPL];
     float lsum = 0.f, zmax = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < IPL; ++r) {
-      mv[r] = in[r] && lab[r] >= 0.0f;
-      z[r] = mv[r] ? x[r] * inv_t : (in[r] ? kLogEps10 : -INFINITY);
-      y[r] = mv[r] ? lab[r] : 0.0f;
-      if (LW) y[r] *= wl;
+    for (int r = 0; r < IPL; ++r) {                       // the slot's values are consumed HERE (no copy of them is kept) ...
+      mv[r] = in[r] && lab_n[d][r] >= 0.0f;
+      z[r] = mv[r] ? x_n[d][r] * inv_t : (in[r] ? kLogEps10 : -INFINITY);
+      y[r] = mv[r] ? lab_n[d][r] : 0.0f;
+      if (LW) y[r] *= wl_n[d];
       lsum += y[r];
       zmax = fmaxf(zmax, z[r]);
     }
+    if (reload) fetch(d, g + D * W);                      // ... so the slot is free: the group D W further on
     const auto sg = [&](float v) { if constexpr (LG == 32) return SegOps<32>::sum(v, seg != 0); else return SegOps<16>::sum(v, seg); };
     const auto mg = [&](float v) { if constexpr (LG == 32) return SegOps<32>::max(v, seg != 0); else return SegOps<16>::max(v, seg); };
     lsum = sg(lsum);
@@ -708,7 +705,7 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
       if (a.poly_eps != 0.0f) dd -= a.poly_eps * sm * (y[r] - pt);
       const float gv = mv[r] ? (lsum * inv_t) * dd : 0.0f;
       if (have && in[r]) {
-        float* pd = a.dlogits + (size_t)b * L + off[r];
+        float* pd = a.dlogits + ((uint32_t)b * (uint32_t)L + (uint32_t)off[r]);
         if (NT) __builtin_nontemporal_store(gv, pd); else *pd = gv;
       }
     }
@@ -804,7 +801,7 @@ static bool sm_packs(int B, int L, bool has_mask, bool has_weights, int lambda_k
   static const int env_pack = [] { const char* e = getenv("TFR_SOFTMAX_PACK"); return (e && *e) ? atoi(e) : 1; }();
   static const int env_min = [] { const char* e = getenv("TFR_SOFTMAX_PACK_MIN_WAVES"); return (e && *e) ? atoi(e) : 4096; }();
   return env_wave && env_pack && lambda_kind == TFR_LAMBDA_NONE && L <= 256 && !has_mask && !has_weights && want_grad &&
-         (B + sm_pack_lists_per_wave(L) - 1) / sm_pack_lists_per_wave(L) >= env_min;
+         (long)B * L < (1L << 30) && (B + sm_pack_lists_per_wave(L) - 1) / sm_pack_lists_per_wave(L) >= env_min;
 }
 static int sm_pack_grid(int B, int L) {
   const int S = sm_pack_lists_per_wave(L);

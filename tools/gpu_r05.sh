@@ -26,6 +26,11 @@ for what in "$@"; do
       timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
       tail -n 30 $OUT/pytest_gpu.log | cut -c1-200
       timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log ;;
+    softmax_quick)
+      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "softmax or reduced_scalar" > $OUT/t_softmax.log 2>&1; echo "softmax tests rc=$?"; tail -n 2 $OUT/t_softmax.log | cut -c1-200
+      ab "pack" softmax_hbm 50 TFR_DUMMY=0
+      ab "pack groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024
+      ab "pack groups=1536" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1536 ;;
     tests_changed)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "reduced_scalar or ndcg or softmax or pairwise or lambda or list_mle or unique or pointwise or keras or metric or sigmoid" > $OUT/t_changed.log 2>&1; echo "changed-area tests rc=$?"; tail -n 12 $OUT/t_changed.log | cut -c1-200 ;;
     sums_ab)
