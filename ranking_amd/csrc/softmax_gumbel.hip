@@ -807,7 +807,10 @@ static int sm_pack_grid(int B, int L) {
   const int S = sm_pack_lists_per_wave(L);
   const int groups = (B + S - 1) / S;
   const int wg = (groups + 3) / 4;
-  return wg < sm_stream_groups() ? wg : sm_stream_groups();
+  // (six workgroups per CU: 65 536 x 100 from HBM 20.7 us with 2 048 workgroups, 20.0 with 1 024 or 1 536 -- profiles/r05_softmax_ab.txt)
+  static const int env_pg = [] { const char* e = getenv("TFR_SOFTMAX_PACK_GROUPS"); return (e && *e) ? atoi(e) : 1536; }();
+  const int cap = env_pg >= 1 ? env_pg : 1536;
+  return wg < cap ? wg : cap;
 }
 
 // has_weights: 0 none, 1 per list, 2 per item

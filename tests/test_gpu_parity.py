@@ -2147,7 +2147,7 @@ def test_lambdarank_fast_path_randomised_against_the_general_kernel(seed):
 
 def _softmax_form(B, L, per_item):
     """which kernel form a plain softmax batch takes, told by its number of sum contributors: B = one per list (per-list
-    kernels), otherwise a persistent form (packed: 4 x ceil(groups / 4) up to 8192; streaming: 8192)"""
+    kernels), otherwise a persistent form (packed: 4 x ceil(groups / 4) up to 4 x 1536; streaming: 8192)"""
     from ranking_amd import _lib
     n = _lib.load().tfr_softmax_sum_contributors(B, L, 0, 2 if per_item else 0, 0, 1)
     import os
