@@ -408,6 +408,17 @@ def measured_traffic(workload, B, L):
     return None if t is None else t['traffic_bytes']
 
 
+def measured_valu_busy(workload, B, L):
+    """Fraction of the SIMD cycles the VALU pipe was busy during the dominant kernel, from the committed SQ counter pass
+    (SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / kernel cycles), with the instruction counts per list."""
+    t, _ = _traffic_entry(workload, B, L)
+    if t is None or 'valu_busy_frac' not in t:
+        return None
+    return {'frac': t['valu_busy_frac'], 'valu_insts_per_list': t.get('valu_insts_per_list'),
+            'salu_insts_per_list': t.get('salu_insts_per_list'),
+            'source': 'committed rocprofv3 --pmc SQ_* pass (profiles/r05_pmc.txt); NOT measured in this run'}
+
+
 def traffic_source(workload, B, L):
     t, rel = _traffic_entry(workload, B, L)
     if t is None:
@@ -795,6 +806,9 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
             'traffic_source': traffic_source(name, B // cycle, L), 'kernel': info['kernel_name'], 'kernel_ms': kernel_ms,
             'algorithmic_bytes_per_launch': algo_bytes,
         }
+        vb = measured_valu_busy(name, B // cycle, L)
+        if vb is not None:
+            roof['valu_busy'] = vb
         valid = (labels >= 0)
         if name.startswith('approx_ndcg') or name == 'gumbel_approx_ndcg':
             mult = 8.0 if name == 'gumbel_approx_ndcg' else 1.0

@@ -69,6 +69,14 @@ def main(tag):
         if f is not None and wr is not None:
             traffic[w] = dict(B=B, L=L, kernel=sub, algorithmic_bytes=alg, fetch_kib=f, write_kib=wr,
                               traffic_bytes=int(round((f * 2 + wr) * 1024)))
+            # VALU pipe utilisation from the SQ pass: a wave64 VALU instruction occupies its SIMD for 4 cycles
+            # (SQ_ACTIVE_INST_VALU counts those quads), SQ_BUSY_CYCLES is summed over the 32 shader engines
+            sq = os.path.join(R, 'pmc_sq_%s.txt' % w)
+            act, busy = pmc_mean(sq, sub, 'SQ_ACTIVE_INST_VALU'), pmc_mean(sq, sub, 'SQ_BUSY_CYCLES')
+            nv, ns = pmc_mean(sq, sub, 'SQ_INSTS_VALU'), pmc_mean(sq, sub, 'SQ_INSTS_SALU')
+            if act and busy:
+                traffic[w].update(valu_busy_frac=act * 4.0 / 1024.0 / (busy / 32.0), valu_insts_per_list=nv / B,
+                                  salu_insts_per_list=(ns or 0.0) / B)
     for w, B, L in (('e2e_approx_ndcg_l1000', 512, 1000), ('e2e_groupwise_gumbel', 512, 50), ('e2e_softmax', 4096, 100)):
         pf, pw = os.path.join(R, 'pmc_fetch_%s.txt' % w), os.path.join(R, 'pmc_write_%s.txt' % w)
         unit = B * L * 512 * 2                                   # one [M, 512] bf16 matrix

@@ -120,7 +120,7 @@ for what in "$@"; do
           python tools/rocpd_summary.py pmc $OUT/pmc_${p}_$w/r_results.db > $OUT/pmc_${p}_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_${p}_$w.txt | head -n 4 | cut -c1-160
         done
       done
-      for w in softmax_hbm ndcg_metric_hbm pairwise_lambda; do
+      for w in approx_ndcg softmax_hbm ndcg_metric_hbm pairwise_lambda; do
         eager=""; st=20; case $w in *_hbm) eager="--no-graph --kernel-timing none"; st=2;; esac
         timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY -d $OUT/pmc_sq_$w -o r -- python bench.py --workload $w --steps $st --warmup 2 $eager $ONE > $OUT/pmc_sq_$w.log 2>&1
         python tools/rocpd_summary.py pmc $OUT/pmc_sq_$w/r_results.db > $OUT/pmc_sq_$w.txt 2>&1; grep -v "at::\|rocclr" $OUT/pmc_sq_$w.txt | head -n 10 | cut -c1-160
