@@ -62,7 +62,7 @@ def main(tag):
     traffic = {}
     for w, sub, B, L, alg in (('approx_ndcg', 'approx_ndcg_wave_kernel', 16384, 200, (12 * 200 + 12) * 16384),
                               ('pairwise_lambda', 'lambdarank_group_kernel', 4096, 200, (12 * 200 + 12) * 4096),
-                              ('softmax_hbm', 'softmax_stream_kernel', 65536, 100, (12 * 100 + 12) * 65536),
+                              ('softmax_hbm', 'softmax_pack_kernel', 65536, 100, (12 * 100 + 12) * 65536),
                               ('ndcg_metric_hbm', 'ndcg_lean_kernel', 16384, 200, (8 * 200 + 24) * 16384)):
         f = pmc_mean(os.path.join(R, 'pmc_fetch_%s.txt' % w), sub, 'FETCH_SIZE')
         wr = pmc_mean(os.path.join(R, 'pmc_write_%s.txt' % w), sub, 'WRITE_SIZE')
@@ -81,7 +81,7 @@ def main(tag):
         pf, pw = os.path.join(R, 'pmc_fetch_%s.txt' % w), os.path.join(R, 'pmc_write_%s.txt' % w)
         unit = B * L * 512 * 2                                   # one [M, 512] bf16 matrix
         f = wr = k0 = None
-        for k0 in ('tower_gemm256p_kernel<2, 1, 2, true>', 'tower_gemm256p_kernel<2, 1, 2, false>', 'tower_gemm256p_kernel<2, 1, 2>'):
+        for k0 in ('tower_gemm256p_kernel<2, 1, 2, 0>', 'tower_gemm256p_kernel<2, 1, 2, 1>', 'tower_gemm256p_kernel<2, 1, 2, 2>', 'tower_gemm256p_kernel<2, 1, 2>'):
             f, wr = pmc_mean(pf, k0, 'FETCH_SIZE'), pmc_mean(pw, k0, 'WRITE_SIZE')
             if f is not None:
                 break
