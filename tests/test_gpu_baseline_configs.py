@@ -87,6 +87,22 @@ def test_headline_full_batch_1e5():
     assert bool((d[lb < 0] == 0).all())
 
 
+def test_config2_full_batch_1e5():
+    """Config 2 (loss part): SoftmaxLoss, 4096 x 100 and the 65 536 x 100 batch of bench.py's `softmax_hbm` line (the packed
+    kernel): per-list loss, list weight and the gradient of weight * loss against the fp64 plain-C arbiter."""
+    c = _c()
+    from ranking_amd import _ops
+    for B, L, tag in ((4096, 100, 'config 2 softmax 4096x100'), (65536, 100, 'softmax_hbm batch 65536x100 (packed kernel)')):
+        labels, logits = make_batch(B, L, seed=4)
+        lb, lg = labels.to(DEV), logits.to(DEV)
+        loss, weight, d = _ops.softmax_loss(lg, lb, None, None, temperature=1.0, want_grad=True)
+        w_loss, w_weight, w_grad = c.softmax(logits.numpy(), labels.numpy(), temperature=1.0)
+        want_grad = torch.from_numpy(w_grad).double() * torch.from_numpy(w_weight).double().unsqueeze(1)   # kernel: d(weight * loss)
+        e_k, _, g_k, _ = _check(tag, loss, d, w_loss, want_grad, None, None)
+        assert e_k <= 1e-5 and g_k <= 1e-5, (tag, e_k, g_k)
+        assert (weight.cpu().double() - torch.from_numpy(w_weight).double()).abs().max().item() <= 1e-6 * max(1.0, float(w_weight.max()))
+
+
 def test_config3_full_batch_1e5():
     """Config 3: PairwiseLogisticLoss + NDCGLambdaWeight, 4096 x 200: per-list sums of w_ij * loss_ij and gradient."""
     c = _c()
