@@ -380,11 +380,16 @@ __device__ unsigned long long* g_prof_buf = nullptr;
 #define TFR_STAMP(i) do { } while (0)
 #endif
 
-template <int IPL>
+// CT: the lanes per row as a compile-time constant (2, the default geometry; 0 = the run-time value).  Round 5: with a
+// run-time C the column index `c + it * C` of every LDS read of the sweeps was re-formed with VALU adds -- one v_add_u32 per
+// trip of the forward sweep and FOUR per trip of the backward sweep (two reads, two address forms), 5 of the 24 vector
+// instructions of a trip pair, in a kernel whose VALU pipe is busy 102 % of the time (profiles/r05_pmc.txt); with a constant
+// stride the unrolled reads take immediate offsets from one base.
+template <int IPL, int CT>
 __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int L, int Lp,
-    float temperature, int C, float* __restrict__ loss_out, float* __restrict__ weight_out,
+    float temperature, int Crt, float* __restrict__ loss_out, float* __restrict__ weight_out,
     float* __restrict__ dlogits_out, int max_runs, int metric, const int* __restrict__ order, int pair_rcp,
     float* __restrict__ loss_sum, unsigned int* __restrict__ ticket, int B, int fast_labels) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   float* G = A + Lp;                               // [Lp] compact gain
   int* CI = reinterpret_cast<int*>(G + Lp);        // [Lp] compact -> original index
   const int lane = threadIdx.x;
+  const int C = CT ? CT : Crt;
   const int b = order ? order[blockIdx.x] : blockIdx.x;      // longest-first launch order (tfr_list_order_i32)
   const size_t base = (size_t)b * L;
   constexpr float kLn2 = 0.69314718055994530942f;
@@ -703,9 +709,14 @@ int launch_wave(const float* logits, const float* labels, const uint8_t* mask, c
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
   static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 1);   // 0: one reciprocal per pair everywhere (round 3)
   static const int int_labels = env_int("TFR_APPROX_INT_LABELS", 1);   // 0: label statistics / ideal DCG by the general reductions
-  hipLaunchKernelGGL(approx_ndcg_wave_kernel<IPL>, dim3(B), dim3(64), lds, stream, logits, labels, mask,
-                     inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order,
-                     pair_rcp, loss_sum, ticket, B, int_labels);
+  if (C == 2)
+    hipLaunchKernelGGL((approx_ndcg_wave_kernel<IPL, 2>), dim3(B), dim3(64), lds, stream, logits, labels, mask,
+                       inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order,
+                       pair_rcp, loss_sum, ticket, B, int_labels);
+  else
+    hipLaunchKernelGGL((approx_ndcg_wave_kernel<IPL, 0>), dim3(B), dim3(64), lds, stream, logits, labels, mask,
+                       inv_log1p, list_scale, L, Lp, temperature, C, loss_out, weight_out, dlogits_out, max_runs, metric, order,
+                       pair_rcp, loss_sum, ticket, B, int_labels);
   return (int)hipGetLastError();
 }
 
