@@ -181,15 +181,17 @@ class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
 
 
 # ------------------------------------------------------------------- helpers
-# The reduced scalar of loss_and_grad (TFR_LOSS_SUM_FUSED): 0 = a tfr_list_dot_f32 launch behind every loss launch (rounds
-# 1-3); 1 (default) = ApproxNDCG / GumbelApproxNDCG take it from the loss launch (its ticket chain hides behind the backward
-# sweeps: -4 us of a 136 us step), Softmax leaves per-wavefront partials and adds 8 192 of them instead of 2 x 65 536 values
-# (-8 us of a 36 us launch), the other losses keep the reduction launch; 2 = every loss takes it from its own launch
-# (tfr_*_sum_f32) -- measured SLOWER behind short kernels (round 5, profiles/r05_sum_ab.txt: the last wavefront's store ->
-# ticket -> group sum -> ticket -> final sum is five dependent device-memory round trips, +16 us behind a 5-25 us softmax
-# launch, +2.6 us behind the 48 us LambdaRank kernel, against 3.5-11.6 us for the reduction launch it replaces).
+# The reduced scalar of loss_and_grad (TFR_LOSS_SUM_FUSED): 0 = a tfr_list_dot_f32 launch over the per-list vectors behind
+# every loss launch (rounds 1-3); 1 (default) = the same, except that Softmax leaves per-wavefront partials and adds 8 192 of
+# them instead of 2 x 65 536 values (-8 us of a 36 us launch); 2 = every loss takes the scalar from its own launch
+# (tfr_*_sum_f32, ApproxNDCG included).  The in-launch form was round 4's default for ApproxNDCG (-4 us then) and measured
+# SLOWER everywhere in round 5 (profiles/r05_sum_ab.txt): the last wavefront's store -> ticket -> group sum -> ticket ->
+# final sum is five dependent device-memory round trips -- +16 us behind a 5-25 us softmax launch, +2.6 us behind the 44 us
+# LambdaRank kernel, and +10.8 us behind the ApproxNDCG kernel once that got faster and the step stopped relaunching the
+# ordering kernels (0.1188 vs 0.1080 ms per step, twice each on one box) -- against ~3 us for the reduction launch.
 _LOSS_SUM_MODE = int(os.environ.get('TFR_LOSS_SUM_FUSED', '1'))
-_LOSS_SUM_FUSED = _LOSS_SUM_MODE >= 1                  # ApproxNDCG family
+_LOSS_SUM_FUSED = _LOSS_SUM_MODE >= 2                  # ApproxNDCG family: in-launch sum
+_LOSS_SUM_PARTIALS = _LOSS_SUM_MODE >= 1               # Softmax: per-wavefront partials + a short dot
 _LOSS_SUM_ALL = _LOSS_SUM_MODE >= 2                    # every loss
 _CONST_CACHE = _ops.DeviceConstCache(64)        # graph-safe: entries a hipGraph capture has read are never evicted
 
@@ -445,7 +447,7 @@ class SoftmaxLoss(_ListwiseLoss):
         scale = self._scale(b)
         w = _const_vector(b, scale, y_pred.device) if sample_weight is None else sample_weight * scale
         lam = self._loss._lambda_args(y_true, y_pred, mask)      # only a DCGLambdaWeight is active, like __call__
-        if not _LOSS_SUM_FUSED:
+        if not _LOSS_SUM_PARTIALS:
             loss, weight, dlogits = _ops.softmax_loss(y_pred.detach(), y_true, mask, w,
                                                       temperature=self._temperature, want_grad=True,
                                                       poly_epsilon=self._loss._poly_epsilon, **lam)
@@ -526,9 +528,9 @@ class ApproxNDCGLoss(_ListwiseLoss):
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         # weight = [sum of labels > 0]; the kernel's loss of such a list is exactly 0 (all gains are 0): no `* weight`.
-        # The reduced scalar sum_b loss_b * list_scale_b comes out of the same launch (a fixed-order sum by the last
-        # workgroup to finish its forward pass): no reduction launch.
-        if not _LOSS_SUM_FUSED:                                # (developer A/B: the reduction as its own launch, rounds 1-3)
+        # The reduced scalar sum_b loss_b * list_scale_b: one short reduction launch (default; TFR_LOSS_SUM_FUSED=2: out of
+        # the loss launch itself, a fixed-order sum by the last workgroup to finish its forward pass -- see _LOSS_SUM_MODE).
+        if not _LOSS_SUM_FUSED:
             loss, _, dlogits = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale, self._temperature, 0, True)
             return _ops.list_dot(loss, list_scale), dlogits
         _, _, dlogits, total = _ops.approx_ndcg(y_pred.detach(), y_true, mask, list_scale,

@@ -32,10 +32,11 @@ for what in "$@"; do
       ab "pack groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024
       ab "pack groups=1536" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1536 ;;
     approx_sum_ab)
-      ab "fused=1" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1
-      ab "fused=0" approx_ndcg 200 TFR_LOSS_SUM_FUSED=0
-      ab "fused=1 again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1
-      ab "fused=0 again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=0 ;;
+      # (visit r05k ran this with the round-4 meaning of the switch: 1 = in-launch sum, 0 = reduction launch; now 2 / 1)
+      ab "in-launch sum" approx_ndcg 200 TFR_LOSS_SUM_FUSED=2
+      ab "reduction launch" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1
+      ab "in-launch sum again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=2
+      ab "reduction launch again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1 ;;
     approx_quick)
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel or keras_loss or launch_order" > $OUT/t_approx.log 2>&1; echo "approx tests rc=$?"; tail -n 3 $OUT/t_approx.log | cut -c1-200
       ab "C templated" approx_ndcg 200 TFR_DUMMY=0
