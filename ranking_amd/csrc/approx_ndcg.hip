@@ -542,6 +542,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
   const float m = 0.5f * (xmax + xmin);               // groups hold F = +inf (sigma = 0) and A = 0
   const bool fast = (xmax - xmin) <= kFastRange;
   const bool pair2 = pair_rcp && (xmax - xmin) <= kPairRange;      // two sigmoids per reciprocal in the forward sweep
+  const bool pair2b = pair2 && pair_rcp >= 2;                       // ... and in the backward sweep (round 5)
   // padding columns: F = +inf (sigma = 0); on the pair path F = 0 (a = 1, sigma = 1 EXACTLY when both columns of a
   // pair are padding, within an ulp next to a real column) and the padding count is taken off the rank afterwards
   const float f_pad = pair2 ? 0.0f : INFINITY;
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
         acc01 = __builtin_elementwise_fma(d23, r, acc01);
         acc23 = __builtin_elementwise_fma(d01, r, acc23);
       }
-      a0 = acc01.x * kPairScale; a1 = acc01.y * kPairScale; a2 = acc23.x * kPairScale; a3 = acc23.y * kPairScale;
+      a0 = ((acc01.x + acc01.y) + (acc23.x + acc23.y)) * kPairScale;    // (one scaling per row; a1 .. a3 stay 0)
     } else if (fast) {
       // packed fp32 (v_pk_fma_f32 / v_pk_add_f32): 2 + 2 full-rate instructions and 4 v_rcp_f32 per 4 pairs
       const float Ei = active ? E[row] : 0.f;
@@ -653,7 +654,30 @@ __global__ __launch_bounds__(64) void approx_ndcg_wave_kernel(
     const bool active = row < n;
     const float ak = active ? A[row] : 0.f;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (fast) {
+    if (pair2b) {
+      // two sigmoids per reciprocal here too (round 5; the forward sweep's trick, same scaling and range condition):
+      // t = d_partner' * rcp(d0' d2') = sigma / c, sigma = c t, sigma' = sigma - sigma^2 -- per four pairs 13 packed
+      // instructions + 2 v_rcp_f32 instead of 8 + 4 (a reciprocal costs 3.5 plain instructions).  Padding columns hold
+      // F = 0 on this path: sigma = 1 exactly, sigma' = 0; a product d0' d2' beyond FLT_MAX has both sigmas below 2^-80.
+      const float Ek = (active ? E[row] : 0.f) * kPairScale;
+      const f32x2 Ek2 = {Ek, Ek}, one2 = {kPairScale, kPairScale}, ak2 = {ak, ak};
+      f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
+      for (int it = 0; it < iters; ++it) {
+        const float4 f = F4[c + it * C];
+        const float4 aj = A4[c + it * C];
+        const f32x2 d01 = __builtin_elementwise_fma(Ek2, f32x2{f.x, f.y}, one2);
+        const f32x2 d23 = __builtin_elementwise_fma(Ek2, f32x2{f.z, f.w}, one2);
+        const f32x2 pq = d01 * d23;
+        const f32x2 r = {fast_rcp(pq.x), fast_rcp(pq.y)};
+        const f32x2 s01 = (d23 * r) * one2;
+        const f32x2 s23 = (d01 * r) * one2;
+        const f32x2 w01 = __builtin_elementwise_fma(-s01, s01, s01);          // sigma' = s - s^2
+        const f32x2 w23 = __builtin_elementwise_fma(-s23, s23, s23);
+        acc01 = __builtin_elementwise_fma(f32x2{aj.x, aj.y} - ak2, w01, acc01);
+        acc23 = __builtin_elementwise_fma(f32x2{aj.z, aj.w} - ak2, w23, acc23);
+      }
+      a0 = acc01.x; a1 = acc01.y; a2 = acc23.x; a3 = acc23.y;
+    } else if (fast) {
       const float Ek = active ? E[row] : 0.f;
       const f32x2 Ek2 = {Ek, Ek}, one2 = {1.0f, 1.0f}, ak2 = {ak, ak};
       f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
@@ -707,7 +731,7 @@ int launch_wave(const float* logits, const float* labels, const uint8_t* mask, c
   const int Lp = ((L + 3) / 4 + C) * 4;           // room for the padding column groups of the uniform sweeps
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
-  static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 1);   // 0: one reciprocal per pair everywhere (round 3)
+  static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 2);   // 0: one reciprocal per pair everywhere (round 3); 1: two sigmoids per reciprocal in the forward sweep (round 4); 2: in both sweeps
   static const int int_labels = env_int("TFR_APPROX_INT_LABELS", 1);   // 0: label statistics / ideal DCG by the general reductions
   if (C == 2)
     hipLaunchKernelGGL((approx_ndcg_wave_kernel<IPL, 2>), dim3(B), dim3(64), lds, stream, logits, labels, mask,

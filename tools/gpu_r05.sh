@@ -39,8 +39,11 @@ for what in "$@"; do
       ab "reduction launch again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1 ;;
     approx_quick)
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "approx or order or headline or smoke or gumbel or keras_loss or launch_order" > $OUT/t_approx.log 2>&1; echo "approx tests rc=$?"; tail -n 3 $OUT/t_approx.log | cut -c1-200
-      ab "C templated" approx_ndcg 200 TFR_DUMMY=0
-      ab "C run-time (lanes=2 via the generic form: TFR_APPROX_LANES=4 then 2 lanes is the default -- A/B is lanes 4)" approx_ndcg 200 TFR_APPROX_LANES=4
+      grep "headline ApproxNDCG\|config 4 ApproxNDCG\|config 5 Gumbel" $OUT/t_approx.log | cut -c1-160
+      ab "pair rcp fwd+bwd" approx_ndcg 200 TFR_APPROX_PAIR_RCP=2
+      ab "pair rcp fwd only" approx_ndcg 200 TFR_APPROX_PAIR_RCP=1
+      ab "pair rcp fwd+bwd again" approx_ndcg 200 TFR_APPROX_PAIR_RCP=2
+      ab "pair rcp fwd only again" approx_ndcg 200 TFR_APPROX_PAIR_RCP=1
       ab "gumbel" gumbel_approx_ndcg 200 TFR_DUMMY=0 ;;
     tests_changed)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "reduced_scalar or ndcg or softmax or pairwise or lambda or list_mle or unique or pointwise or keras or metric or sigmoid" > $OUT/t_changed.log 2>&1; echo "changed-area tests rc=$?"; tail -n 12 $OUT/t_changed.log | cut -c1-200 ;;
