@@ -731,7 +731,10 @@ int launch_wave(const float* logits, const float* labels, const uint8_t* mask, c
   const int Lp = ((L + 3) / 4 + C) * 4;           // room for the padding column groups of the uniform sweeps
   const size_t lds = (size_t)Lp * 4 * 6;
   static const int max_runs = env_int("TFR_APPROX_MAX_RUNS", 8);   // 0 forces the sort (A/B measurements)
-  static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 2);   // 0: one reciprocal per pair everywhere (round 3); 1: two sigmoids per reciprocal in the forward sweep (round 4); 2: in both sweeps
+  // 0: one reciprocal per pair everywhere (round 3); 1 (default): two sigmoids per reciprocal in the forward sweep (round 4);
+  // 2: in the backward sweep too -- built and measured in round 5: SLOWER (kernel 0.1057 -> 0.1103 ms, twice each on one box:
+  // the 5 extra packed multiplies of a trip cost more than the 2 reciprocals they replace), kept behind the switch
+  static const int pair_rcp = env_int("TFR_APPROX_PAIR_RCP", 1);
   static const int int_labels = env_int("TFR_APPROX_INT_LABELS", 1);   // 0: label statistics / ideal DCG by the general reductions
   if (C == 2)
     hipLaunchKernelGGL((approx_ndcg_wave_kernel<IPL, 2>), dim3(B), dim3(64), lds, stream, logits, labels, mask,

@@ -185,7 +185,7 @@ class ListMLELambdaWeight(losses_impl.ListMLELambdaWeight):
 # every loss launch (rounds 1-3); 1 (default) = the same, except that Softmax leaves per-wavefront partials and adds 8 192 of
 # them instead of 2 x 65 536 values (-8 us of a 36 us launch); 2 = every loss takes the scalar from its own launch
 # (tfr_*_sum_f32, ApproxNDCG included).  The in-launch form was round 4's default for ApproxNDCG (-4 us then) and measured
-# SLOWER everywhere in round 5 (profiles/r05_sum_ab.txt): the last wavefront's store -> ticket -> group sum -> ticket ->
+# SLOWER everywhere in round 5 (profiles/r05_headline_and_sum_ab.txt): the last wavefront's store -> ticket -> group sum -> ticket ->
 # final sum is five dependent device-memory round trips -- +16 us behind a 5-25 us softmax launch, +2.6 us behind the 44 us
 # LambdaRank kernel, and +10.8 us behind the ApproxNDCG kernel once that got faster and the step stopped relaunching the
 # ordering kernels (0.1188 vs 0.1080 ms per step, twice each on one box) -- against ~3 us for the reduction launch.
