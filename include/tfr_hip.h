@@ -373,8 +373,9 @@ int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const u
 /* Dropout after a hidden activation (keras/layers.py:72-73).  HOST struct, nullable everywhere
  * (NULL or threshold16 == 0: no dropout).  Element (row m, column k) of the layer is kept iff its
  * field of hash(seed', m, k / columns-per-word) >= the rate in field units (the narrowest field --
- * 1, 2, 4 or 8 bits -- that holds threshold16 = rate * 65536 exactly; other rates are rounded to a
- * multiple of 1 / 256), and then scaled by `scale` = 1 / (1 - rate); forward prologues and backward
+ * 1, 2, 4, 8 or 16 bits -- that holds threshold16 = rate * 65536 exactly; with 16-bit fields the
+ * scale is 65536 / (65536 - threshold16) whatever `scale` says), and then scaled by `scale` =
+ * 1 / (1 - rate); forward prologues and backward
  * kernels evaluate the same hash.  seed' = seed + *step * 0x9E3779B9 when `step` (DEVICE pointer to
  * one uint32, nullable) is given: the training-step counter lives in device memory so that a
  * replayed hipGraph of the step draws a fresh mask (a by-value seed is baked into the capture). */

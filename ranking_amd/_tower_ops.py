@@ -47,14 +47,14 @@ def _dp(d):
 def dropout_field(d: 'Dropout'):
     """(lge, threshold in field units, scale) the kernels derive from the struct (csrc/tower.hip to_drop): a hash word
     serves 2^lge columns with 32 >> lge bits each -- the narrowest field (1, 2, 4 or 8 bits) that represents the rate
-    exactly; a rate that is not a multiple of 1 / 256 is rounded to one and the scale follows the rounded rate."""
+    exactly; a rate that is not a multiple of 1 / 256 takes 16-bit fields (the rate to 1 / 65 536, the scale following
+    the threshold)."""
     t16 = min(int(d.threshold16), 65535)
     for lge in (5, 4, 3, 2):
         fb = 32 >> lge
         if t16 & ((1 << (16 - fb)) - 1) == 0:
             return lge, t16 >> (16 - fb), float(d.scale)
-    t8 = max(1, min(255, (t16 + 128) >> 8))
-    return 2, t8, 256.0 / (256.0 - t8)
+    return 1, t16, 65536.0 / (65536.0 - t16)
 
 
 def dropout_mask(d: 'Dropout', M: int, K: int, device) -> torch.Tensor:

@@ -68,13 +68,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // forward prologues and in the backward kernels, so nothing is stored.  A 32-bit hash word serves 2^lge
 // consecutive columns with a field of 32 >> lge bits each: an element is kept iff its field >= thr (the rate in
 // field units) and is then scaled by 1 / (1 - rate).  Round 3: the field is as narrow as the rate allows EXACTLY,
-// at most 8 bits (rate 0.5 -- the reference default -- needs ONE bit: a word serves 32 columns; 0.25 two bits; a
-// rate that is not a multiple of 1 / 256 is rounded to one, the scale following the rounded rate so that the mask
-// stays unbiased).  Round 2 hashed once per column PAIR (16-bit fields): the two 32-bit multiplies of the hash are
+// (rate 0.5 -- the reference default -- needs ONE bit: a word serves 32 columns; 0.25 two bits; multiples of 1 / 256
+// eight).  Round 5: any other rate (0.1, 0.3 ...) takes 16-bit fields, i.e. the rate to 1 / 65 536 with the scale following
+// the threshold, instead of being rounded to a multiple of 1 / 256 (0.1 was 0.1016): twice the hashes of the 8-bit form.  Round 2 hashed once per column PAIR (16-bit fields): the two 32-bit multiplies of the hash are
 // quarter-rate instructions and sat in every GEMM prologue -- the hidden-layer forward GEMM of BASELINE config 5
 // took 41.8 us with Dropout against 27.7 us without.  The callers walk aligned runs of 4 / 8 columns: one hash per
 // run (two for an 8-run at 8-bit fields).
-struct Drop { uint32_t seed; uint32_t thr; float scale; uint32_t lge; const uint32_t* sp; };     // lge = 2 .. 5
+struct Drop { uint32_t seed; uint32_t thr; float scale; uint32_t lge; const uint32_t* sp; };     // lge = 1 .. 5
 // The seed a kernel hashes with: the host's layer seed + (device step counter) * golden ratio.  The counter lives in
 // device memory (tfr_tower_dropout.step, nullable) so that a hipGraph replay of a training step draws a NEW mask: a
 // seed passed by value is baked into the captured launch and every replay would reuse the first step's mask.
@@ -90,8 +90,19 @@ __device__ __forceinline__ uint32_t drop_hash(uint32_t seed, uint32_t m, uint32_
   return h;
 }
 // keep factors of the N (4 or 8) consecutive columns c .. c + N - 1 of row m, c a multiple of N
-template <int N>
+// W16: the caller also serves 16-bit fields (compiled out of the persistent GEMM forms the fixed-rate towers run: the extra
+// path cost them 60-90 bytes of scratch per lane)
+template <int N, bool W16 = true>
 __device__ __forceinline__ void drop_run(const Drop d, uint32_t m, uint32_t c, float (&f)[N]) {
+  if (W16 && d.lge == 1u) {                                  // 16-bit fields: a word serves two columns (wave-uniform branch)
+#pragma unroll
+    for (int w = 0; w < N / 2; ++w) {
+      const uint32_t h = drop_hash(d.seed, m, (c >> 1) + (uint32_t)w);
+      f[2 * w] = ((h & 0xffffu) >= d.thr) ? d.scale : 0.0f;
+      f[2 * w + 1] = ((h >> 16) >= d.thr) ? d.scale : 0.0f;
+    }
+    return;
+  }
   const uint32_t fb = 32u >> d.lge;                          // (wave-uniform: scalar registers)
   const uint32_t off = (c & ((1u << d.lge) - 1u)) << (5u - d.lge);
   uint32_t x0 = drop_hash(d.seed, m, c >> d.lge) >> off;
@@ -850,7 +861,7 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 // DROP == 2: the keep bits of the fragment's 8 columns come from the stage's bit table in LDS (`bits8`: bit j = column j
 // kept) and the factor 1 / (1 - rate) = 2 is already folded into sc / sh -- see the table's comment in
 // tower_gemm256p_kernel; DROP == 1: one hash per fragment (drop_run).
-template <int PRO, int DROP>       // DROP: 0 none, 1 one hash per fragment (drop_run), 2 the stage's keep-bit table
+template <int PRO, int DROP>       // DROP: 0 none, 1 one hash per fragment (drop_run), 2 the stage's keep-bit table, 3 = 1 + 16-bit fields
 __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, const f32x4 sc1, const f32x4 sh0, const f32x4 sh1,
                                                  const Drop d, uint32_t m, uint32_t k, int act, uint32_t bits8 = 0u) {
   constexpr bool bt = DROP == 2;
@@ -861,14 +872,14 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
   const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
   uint32_t o[4];
   float kf[8];
-  if (DROP == 1) drop_run<8>(d, m, k, kf);           // one hash for the fragment's 8 columns when the rate allows
+  if (DROP == 1 || DROP == 3) drop_run<8, DROP == 3>(d, m, k, kf);     // one hash for the fragment's 8 columns when the rate allows
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
     const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
     x = x * s + h;
     if (PRO == PRO_AFFINE_ACT) { x[0] = act_fwd(act, x[0]); x[1] = act_fwd(act, x[1]); }
-    if (DROP == 1) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
+    if (DROP == 1 || DROP == 3) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
     uint32_t pk = pack_bf16(x[0], x[1]);
     if (PRO == PRO_AFFINE_RELU)
       pk = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(i16x2, pk), i16x2{0, 0}));
@@ -900,7 +911,7 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
 //  * every LOAD phase drains its LDS reads / writes (lgkmcnt(0)) before its closing barrier: no buffer is re-staged under a read;
 //  * the keep-bit table of step s + 1 is written in L(s,0) by both groups, i.e. before barrier 4 s + 2, and read after 4 s + 4;
 //  * at the end of a tile both groups pass barrier 4 n together and run their (barrier-free) epilogues side by side.
-template <int PRO, int EPI, int DROP, int PP = 0>      // PP: 0 single-phase loop, 1 ping-pong with the LDS-DMA pieces in the LOAD phases, 2 with the pieces among the MFMAs of MMA(kt, 0); DROP: 0 none, 1 hashed per fragment / epilogue run, 2 = 1 + the prologue's keep-bit table
+template <int PRO, int EPI, int DROP, int PP = 0>      // PP: 0 single-phase loop, 1 ping-pong with the LDS-DMA pieces in the LOAD phases, 2 with the pieces among the MFMAs of MMA(kt, 0); DROP: 0 none, 1 hashed per fragment / epilogue run (fields <= 8 bits), 2 = 1 + the prologue's keep-bit table, 3 = 1 + 16-bit fields (rates that are not a multiple of 1 / 256)
 __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Drop pdrop = drop_resolve(g.pro_drop), edrop = drop_resolve(g.epi_drop);
@@ -1272,7 +1283,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
             const f32x4 y = z * pb[fn] + pe[fn];
             if (DROP) {
               float kf[4];
-              drop_run<4>(edrop, (uint32_t)(g.row0 + mb + fm * 16 + fr), (uint32_t)(n0 + nl + fn * 16 + fq * 4), kf);
+              drop_run<4, DROP == 3>(edrop, (uint32_t)(g.row0 + mb + fm * 16 + fr), (uint32_t)(n0 + nl + fn * 16 + fq * 4), kf);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] *= kf[r];
             }
@@ -2124,11 +2135,9 @@ Drop to_drop(const tfr_tower_dropout* d) {
     const uint32_t fb = 32u >> lge;
     if ((t16 & ((1u << (16u - fb)) - 1u)) == 0u) return Drop{d->seed, t16 >> (16u - fb), d->scale, lge, d->step};
   }
-  // otherwise the rate is rounded to a multiple of 1 / 256 and the scale follows the rounded rate (unbiased mask)
-  uint32_t t8 = (t16 + 128u) >> 8;
-  if (t8 < 1u) t8 = 1u;
-  if (t8 > 255u) t8 = 255u;
-  return Drop{d->seed, t8, 256.0f / (256.0f - (float)t8), 2u, d->step};
+  // otherwise 16-bit fields (two columns per hash word): the rate to 1 / 65 536, the scale following the threshold so that
+  // the mask is unbiased whatever the caller passed
+  return Drop{d->seed, t16, 65536.0f / (65536.0f - (float)t16), 1u, d->step};
 }
 
 int grid_for(long work_items, int block) {
@@ -2185,12 +2194,16 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   auto fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0>
                   : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, ((PRO == PRO_AFFINE || PRO == PRO_AFFINE_RELU) && EPI <= EPI_STATS) ? 2 : 1>
                                                                             : tower_gemm256p_kernel<PRO, EPI, 1>);
+  // 16-bit keep fields (a rate that is not a multiple of 1 / 256) in either mask: the form that carries that path
+  const bool drop16 = (PRO != PRO_NONE && g.pro_drop.thr && g.pro_drop.lge == 1u) ||
+                      ((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.epi_drop.thr && g.epi_drop.lge == 1u);
+  if (drop && drop16) fn = tower_gemm256p_kernel<PRO, EPI, 3>;
   // the two-group ping-pong k loop (round 5; TFR_GEMM_PP=1 / 2; default 0 = the single-phase loop of rounds 2-4: measured
   // equal within 2 % -- profiles/r05_gemm_pp.txt), compiled for the forms a
   // BatchNorm + ReLU tower runs: hidden-layer forward (2, 1), its dgrad (0, 2), layer 1 / plain products (0, 1), (0, 0)
   static const int env_pp = [] { const char* e = getenv("TFR_GEMM_PP"); return (e && *e) ? atoi(e) : 0; }();
   constexpr bool pp_form = (PRO == PRO_AFFINE_RELU && EPI == EPI_STATS) || (PRO == PRO_NONE && EPI <= EPI_RELU_BWD);
-  if constexpr (pp_form) {
+  if constexpr (pp_form) if (!drop16) {
     if (env_pp == 1)
       fn = !drop ? tower_gemm256p_kernel<PRO, EPI, 0, 1>
                  : ((table && EPI <= EPI_STATS) ? tower_gemm256p_kernel<PRO, EPI, (PRO == PRO_AFFINE_RELU && EPI <= EPI_STATS) ? 2 : 1, 1>

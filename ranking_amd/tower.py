@@ -314,9 +314,9 @@ class FusedTower(nn.Module):
     """create_tower(...) as one fused module; call with the flattened ``[M, F]`` features.
 
     ``dropout``: the keep mask is a counter-based hash evaluated inside the kernels (nothing is stored); a rate that is
-    a multiple of 1/2, 1/4, 1/16 or 1/256 is applied exactly, any other rate is ROUNDED to the nearest multiple of
-    1/256 (0.1 -> 26/256 = 0.1016) with the scale 1 / (1 - rate) following the rounded rate, so the mask stays unbiased
-    (``_tower_ops.dropout_field`` returns what the kernels use).  The training-step counter of the masks lives in
+    a multiple of 1/2, 1/4, 1/16 or 1/256 is applied exactly through 1- to 8-bit fields of the hash, any other rate
+    through 16-bit fields, i.e. to 1 / 65 536 (0.1 -> 6554 / 65536) with the scale 1 / (1 - rate) following the threshold,
+    so the mask stays unbiased (``_tower_ops.dropout_field`` returns what the kernels use).  The training-step counter of the masks lives in
     device memory: a hipGraph replay of a step draws a new mask."""
 
     def __init__(self, input_dim: int, hidden_layer_dims: List[int], output_units: int = 1, activation=None,

@@ -178,7 +178,7 @@ def test_out_layer_bwd_and_bn_apply():
 
 
 @pytest.mark.parametrize('N', [256, 512, 768, 1024, 1280])      # 1 .. 5 n-tiles share the stores of the operand
-@pytest.mark.parametrize('pro,rate', [(2, 0.5), (2, 0.0), (1, 0.25)])
+@pytest.mark.parametrize('pro,rate', [(2, 0.5), (2, 0.0), (1, 0.25), (2, 0.1)])
 def test_gemm_writes_its_transformed_operand(pro, rate, N):
     """tfr_tower_gemm_bf16_aout: the persistent forward GEMM also writes pro(A) = act(A * scale + shift) * keep mask, the
     operand it forms in registers, for the layer's weight gradient; C and the statistics are what they are without it."""
@@ -360,7 +360,7 @@ def test_dropout_mask_statistics_and_determinism():
         d = t.Dropout.make(rate, 12345)
         m = t.dropout_mask(d, 4096, 512, DEV)
         kept = (m > 0).float().mean().item()
-        assert abs(kept - (1 - rate)) < 5e-3, (rate, kept)
+        assert abs(kept - (1 - rate)) < 1.5e-3, (rate, kept)              # 0.1 is 0.1 (16-bit fields), not 26 / 256
         assert abs(m.mean().item() - 1.0) < 2e-2                      # E[mask] = 1 (inverted dropout)
         # no row / column structure
         assert (m > 0).float().mean(0).std().item() < 2e-2 and (m > 0).float().mean(1).std().item() < 3e-2
@@ -477,6 +477,7 @@ def ref_tower_dropout(x, tower, masks):
     (1500, 136, [512, 256], 1, 'relu', True, 0.5),
     (700, 24, [64, 64, 32], 2, None, False, 0.25),
     (900, 40, [128], 1, 'relu', False, 0.1),
+    (1500, 136, [512, 256], 1, 'relu', True, 0.3),      # 16-bit keep fields through every consumer of the mask
 ])
 def test_fused_tower_dropout_forward_backward(M, F, hidden, O, act, bn, rate):
     from ranking_amd.tower import FusedTower
