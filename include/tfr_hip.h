@@ -32,15 +32,26 @@ extern "C" {
 
 #define TFR_MAX_TOPN 8
 
-/* List-size limits (TFR_ETOOLARGE beyond).  These macros are what the kernels' launchers test; every "list_size <= N"
- * statement in this header is checked against them by tests/test_host_logic.py. */
-#define TFR_MAX_LIST_SIZE 8192              /* ApproxNDCG / ApproxMRR, pairwise losses, softmax, Gumbel sampler, sort / ranks,
-                                               NDCG / MRR metrics, list order, group indices: workgroup kernels beyond the
-                                               wave-per-list range */
-#define TFR_MAX_LIST_SIZE_METRIC 4096       /* the other rank metrics and the diversity metrics: 28-32 B of LDS per item */
-#define TFR_MAX_LIST_SIZE_LISTWISE 4096     /* ListMLE, UniqueSoftmax, Circle: LDS block sort + scans, 24-36 B per item */
-#define TFR_MAX_LIST_SIZE_NEURAL_SORT 2048  /* NeuralSort losses: one wavefront per list, 40 / 60 B of LDS per item */
-#define TFR_MAX_LIST_SIZE_FLATTEN 4096      /* tfr_flatten_row_index: 16 B of LDS per item, four list-waves per workgroup */
+/* List-size limit (TFR_ETOOLARGE beyond) of every entry point that takes a list_size.  These macros are what the
+ * kernels' launchers test; every "list_size <= N" statement in this header is checked against them by
+ * tests/test_host_logic.py. */
+#define TFR_MAX_LIST_SIZE 8192
+/* Up to these list sizes the workgroup kernels keep a list's working arrays in LDS (160 KB per workgroup); beyond, up to
+ * TFR_MAX_LIST_SIZE, the arrays live in a WORKSPACE the caller passes (`workspace`, `workspace_bytes`: device memory,
+ * contents irrelevant before and after the call, one per stream in flight).  tfr_list_workspace_bytes(op, L) is what ONE
+ * list in flight needs (0: none at this list size); a launch runs min(B, workspace_bytes / that, 1024) lists
+ * concurrently.  Without a workspace of at least one slot such a list size is TFR_ETOOLARGE. */
+#define TFR_LDS_LIST_SIZE_METRIC 4096       /* rank metrics other than NDCG / MRR, diversity metrics: 28-32 B of LDS per item */
+#define TFR_LDS_LIST_SIZE_LISTWISE 4096     /* ListMLE, UniqueSoftmax, Circle: LDS block sort + scans, 24-36 B per item */
+#define TFR_LDS_LIST_SIZE_NEURAL_SORT 2048  /* NeuralSort losses: one wavefront per list, 40 / 60 B of LDS per item */
+#define TFR_WS_LIST_MLE 0
+#define TFR_WS_UNIQUE_SOFTMAX 1
+#define TFR_WS_CIRCLE 2
+#define TFR_WS_RANK_METRIC 3
+#define TFR_WS_DIV_METRIC 4
+#define TFR_WS_NEURAL_SORT_NDCG 5
+#define TFR_WS_NEURAL_SORT_CE 6
+long tfr_list_workspace_bytes(int op, int L);
 
 /* gain_kind */
 #define TFR_GAIN_IDENTITY 0   /* keras/utils.py:51  identity                  */
@@ -102,8 +113,8 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
  *   TFR_METRIC_HITS (:462-506)       TFR_METRIC_RECALL (:154-177, 539-561)   TFR_METRIC_PRECISION (:180-207, 564-586)
  *   TFR_METRIC_MAP (:589-628)        TFR_METRIC_ARP (:509-536; stats_out[:, 2] = its per-list weight)
  * stats_out [B, 3] = (sum w, sum rel, sum w*rel) with rel = gain (DCG), label (ARP) or 1{label >= 1}.
- * NDCG / MRR as above; the other kinds: list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC): one wavefront per list up to 512
- * items, one workgroup (32 B of LDS per item) beyond. */
+ * NDCG / MRR as above (no workspace at any size); the other kinds: one wavefront per list up to 512 items, one workgroup
+ * (32 B of LDS per item) beyond; workspace (TFR_WS_RANK_METRIC) above TFR_LDS_LIST_SIZE_METRIC. */
 #define TFR_METRIC_NDCG 0
 #define TFR_METRIC_MRR 1
 #define TFR_METRIC_DCG 2
@@ -119,20 +130,20 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
 int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                         int weights_per_list, const uint8_t* mask, const float* gains,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
-                        float* metric_out, float* stats_out, void* stream);
+                        float* metric_out, float* stats_out, void* workspace, long workspace_bytes, void* stream);
 
 /* Diversity metrics on subtopic labels [B, L, S] (metrics_impl.py:313-426, :746-822).
  *   TFR_DIV_ALPHA_DCG    AlphaDCGMetric: metric_out[q*B+b] = sum_{p<k} w gain discount, gain = sum_s y_ps (1-alpha)^{cum_s};
  *                        discount[p] = rank_discount_fn(p + 1); the caller divides by the per-list weight
  *   TFR_DIV_PRECISION_IA PrecisionIAMetric: the metric itself
  * mask [B, L] or NULL (then an item is valid when any of its subtopic labels is >= 0); stats_out as above
- * with relevance = any_s [y >= 1].  list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC). */
+ * with relevance = any_s [y >= 1].  Workspace (TFR_WS_DIV_METRIC) above TFR_LDS_LIST_SIZE_METRIC. */
 #define TFR_DIV_ALPHA_DCG 0
 #define TFR_DIV_PRECISION_IA 1
 int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                        int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
                        const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
-                       float* stats_out, void* stream);
+                       float* stats_out, void* workspace, long workspace_bytes, void* stream);
 
 /* Per-list metric weights [B] from the stats_out [B, 3] of the metric entry points above
  * (metrics_impl.py:63-119 _per_example_weights_to_per_list_weights): sum(w rel)/sum(rel); lists without
@@ -207,11 +218,11 @@ int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* l
 int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                          const float* pos_weight, const float* list_scale, int B, int L,
                          float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
-                         uint32_t* ticket, void* stream);
+                         uint32_t* ticket, void* workspace, long workspace_bytes, void* stream);
 int tfr_unique_softmax_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                const float* list_scale, int B, int L, float temperature,
                                float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
-                               void* stream);
+                               void* workspace, long workspace_bytes, void* stream);
 int tfr_pointwise_loss_sum_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
                                const float* item_weights, const float* list_weights, int B, int L,
                                float temperature, float* list_loss_out, float* list_weight_out,
@@ -238,38 +249,43 @@ int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* 
  *   pos_weight   nullable [L]: rank_discount_fn(p + 1) of a ListMLELambdaWeight (host table)
  *   loss_out     [B] negative log likelihood per list (the list weight is 1)
  *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
- * list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE: one wavefront per list up to 1024, one workgroup beyond); ties between
- * equal labels keep index order. */
+ * One wavefront per list up to 1024 items, one workgroup beyond; workspace (TFR_WS_LIST_MLE) above
+ * TFR_LDS_LIST_SIZE_LISTWISE.  Ties between equal labels keep index order. */
 int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                      const float* pos_weight, const float* list_scale, int B, int L,
-                     float temperature, float* loss_out, float* dlogits_out, void* stream);
+                     float temperature, float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes,
+                     void* stream);
 
 /* losses_impl.UniqueSoftmaxLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:1250-1281): loss_b = sum_i (2^l_i - 1) (log(e^s_i + sum_{j: l_j < l_i} e^s_j) - s_i).
- * Same conventions as tfr_list_mle_f32 (list weight 1, list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE)). */
+ * Same conventions as tfr_list_mle_f32 (list weight 1; workspace TFR_WS_UNIQUE_SOFTMAX). */
 int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
                            const float* list_scale, int B, int L, float temperature,
-                           float* loss_out, float* dlogits_out, void* stream);
+                           float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes, void* stream);
 
 /* NeuralSort losses (losses_impl.py:1635-1673 NeuralSortCrossEntropyLoss, :1676-1713 NeuralSortNDCGLoss,
  * :1716-1801 neural_sort): per-list loss [B] and d loss / d logits [B, L] (x list_scale[b] when given),
- * one wavefront per list, no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG
- * kind only).  list_size <= 2048 (TFR_MAX_LIST_SIZE_NEURAL_SORT: 40 / 60 B of LDS per item).  The Gumbel variants are this kernel on the sampler's
+ * no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG kind only).  One wavefront per list
+ * (40 / 60 B of LDS per item) up to TFR_LDS_LIST_SIZE_NEURAL_SORT items; beyond, one workgroup per list with the row
+ * statistics in the workspace (TFR_WS_NEURAL_SORT_NDCG / _CE).  The Gumbel variants are this kernel on the sampler's
  * expanded batch. */
 #define TFR_NEURAL_SORT_NDCG 0
 #define TFR_NEURAL_SORT_CE 1
 int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,
                              const float* inv_log1p, const float* list_scale, int B, int L,
-                             float temperature, float* loss_out, float* dlogits_out, void* stream);
+                             float temperature, float* loss_out, float* dlogits_out, void* workspace,
+                             long workspace_bytes, void* stream);
 
 /* CircleLoss (losses_impl.py:1036-1116): loss[b] = log1p(sum_{y_i > y_j} exp(gamma (a_i + b_j))) on scores
  * clipped to [0, 1]; weight[b] = 1, or NaN for a list without any preference pair (the reference's 0 / 0);
  * dlogits = d loss / d logits (x list_scale[b]).  clip != 0 applies get_logits' clip_by_value(0, 1) in
  * the kernel (compute()); compute_per_list / compute_unreduced_loss hand the scores over as they are.
- * list_size <= 4096 (TFR_MAX_LIST_SIZE_LISTWISE: one wavefront per list up to 1024, one workgroup beyond). */
+ * One wavefront per list up to 1024 items, one workgroup beyond; workspace (TFR_WS_CIRCLE) above
+ * TFR_LDS_LIST_SIZE_LISTWISE. */
 int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                         const float* list_scale, int B, int L, float gamma, float margin, int clip,
-                        float* loss_out, float* weight_out, float* dlogits_out, void* stream);
+                        float* loss_out, float* weight_out, float* dlogits_out, void* workspace, long workspace_bytes,
+                        void* stream);
 
 /* Pointwise losses (losses_impl.py:1284-1321 _PointwiseLoss, :1425-1446 SigmoidCrossEntropyLoss, :1449-1469
  * MeanSquaredLoss), forward + backward in one pass: per list sum(w l), sum(w), #(w != 0) and
@@ -396,7 +412,7 @@ int tfr_tower_multi_add(float* const* dst, const float* const* src, const int* n
 
 /* FlattenList's gather index (keras/layers.py:122-183; utils.py:203-230, :308-356 with shuffle=False) in one
  * launch: rows[b * L + p] = b * L + v_b[p mod max(n_b, 1)], v_b = valid positions of list b in index order
- * (0 when the list has none).  mask uint8 [B, L]; rows int32 [B * L]; list_size <= 4096 (TFR_MAX_LIST_SIZE_FLATTEN). */
+ * (0 when the list has none).  mask uint8 [B, L]; rows int32 [B * L]; list_size <= 8192 (TFR_MAX_LIST_SIZE). */
 int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream);
 
 /* The same with a row gather: out[m] = cast(x[row_index[m]]) (row_index NULL = identity).  Fuses FlattenList's

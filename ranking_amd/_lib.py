@@ -26,6 +26,7 @@ _lock = threading.Lock()
 _lib = None
 
 c_f32p = ctypes.c_void_p
+_WS = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]        # ... void* workspace, long workspace_bytes, void* stream
 _SIGNATURES = {
     # name: (restype, argtypes)
     'tfr_hip_abi_version': (ctypes.c_int, []),
@@ -33,7 +34,7 @@ _SIGNATURES = {
     'tfr_ndcg_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
                             + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_rank_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
-                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + _WS),
     'tfr_mrr_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p]
                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
@@ -44,20 +45,21 @@ _SIGNATURES = {
                                 + [ctypes.c_int] + [ctypes.c_void_p] * 7),
     'tfr_approx_mrr_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
                            + [ctypes.c_void_p] * 5),
+    'tfr_list_workspace_bytes': (ctypes.c_long, [ctypes.c_int] * 2),
     'tfr_list_mle_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                         + [ctypes.c_void_p] * 3),
+                         + [ctypes.c_void_p] * 2 + _WS),
     'tfr_unique_softmax_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                               + [ctypes.c_void_p] * 3),
+                               + [ctypes.c_void_p] * 2 + _WS),
     'tfr_metric_list_weights_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_div_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int]
                            + [ctypes.c_void_p] * 2 + [ctypes.c_float] + [ctypes.c_void_p] + [ctypes.c_int] * 4
-                           + [ctypes.c_void_p] * 3),
+                           + [ctypes.c_void_p] * 2 + _WS),
     'tfr_pointwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                                + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_circle_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float] * 2
-                            + [ctypes.c_int] + [ctypes.c_void_p] * 4),
+                            + [ctypes.c_int] + [ctypes.c_void_p] * 3 + _WS),
     'tfr_neural_sort_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
-                                 + [ctypes.c_float] + [ctypes.c_void_p] * 3),
+                                 + [ctypes.c_float] + [ctypes.c_void_p] * 2 + _WS),
     'tfr_pairwise_logistic_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                   + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),
@@ -133,9 +135,9 @@ _SIGNATURES = {
                                   + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 9),
     'tfr_list_mle_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                             + [ctypes.c_void_p] * 5),
+                             + [ctypes.c_void_p] * 4 + _WS),
     'tfr_unique_softmax_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                                   + [ctypes.c_void_p] * 5),
+                                   + [ctypes.c_void_p] * 4 + _WS),
     'tfr_pointwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                                    + [ctypes.c_float] + [ctypes.c_void_p] * 7),
     # groupwise scoring (groupwise.hip)

@@ -195,6 +195,21 @@ METRIC_NDCG, METRIC_MRR, METRIC_DCG, METRIC_HITS, METRIC_RECALL, METRIC_PRECISIO
 METRIC_BPREF, METRIC_BPREF_NONTREC, METRIC_PWA, METRIC_OPA = 8, 9, 10, 11
 
 
+WS_LIST_MLE, WS_UNIQUE_SOFTMAX, WS_CIRCLE, WS_RANK_METRIC, WS_DIV_METRIC, WS_NEURAL_SORT_NDCG, WS_NEURAL_SORT_CE = range(7)
+_WS_LISTS = 256                          # lists in flight of a launch that runs from the workspace
+
+
+def _workspace(op, B, L, device):
+    """(tensor or None, bytes): the workspace an entry point needs once a list's working arrays outgrow LDS
+    (include/tfr_hip.h tfr_list_workspace_bytes): min(B, 256) slots.  The tensor must outlive the launch -- it does, as
+    a local of the calling op (the caching allocator hands the block out again in stream order)."""
+    slot = int(_lib.load().tfr_list_workspace_bytes(int(op), int(L)))
+    if slot <= 0 or B <= 0:
+        return None, 0
+    n = slot * min(int(B), _WS_LISTS)
+    return torch.empty((n,), dtype=torch.uint8, device=device), n
+
+
 def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, discount=None):
     """tfr_rank_metric_f32: ([K, B] metric, [B, 3] stats) for any sort-based metric kind."""
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
@@ -205,9 +220,10 @@ def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, dis
     K = len(topns)
     out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
     stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    ws, ws_bytes = (None, 0) if kind in (METRIC_NDCG, METRIC_MRR) else _workspace(WS_RANK_METRIC, B, L, labels.device)
     rc = _lib.load().tfr_rank_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
                                          _ptr(gains), _ptr(discount), _topn_array(topns), K, B, L,
-                                         _ptr(out), _ptr(stats), _stream())
+                                         _ptr(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_rank_metric_f32')
     return out, stats
 
@@ -238,9 +254,10 @@ def div_metric(kind, labels, predictions, weights, mask, topns, discount=None, a
     K = len(topns)
     out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
     stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
+    ws, ws_bytes = _workspace(WS_DIV_METRIC, B, L, labels.device)
     rc = _lib.load().tfr_div_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
                                         _ptr(discount), float(alpha), _topn_array(topns), K, B, L, S,
-                                        _ptr(out), _ptr(stats), _stream())
+                                        _ptr(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_div_metric_f32')
     return out, stats
 
@@ -436,15 +453,16 @@ def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temper
     B, L = logits.shape
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws, ws_bytes = _workspace(WS_LIST_MLE, B, L, logits.device)
     if want_sum:
         total, ticket = _sum_outputs(logits.device)
         rc = _lib.load().tfr_list_mle_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
                                               B, L, float(temperature), _ptr(loss), _ptr(dlogits), _ptr(total),
-                                              _ptr(ticket), _stream())
+                                              _ptr(ticket), _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, 'tfr_list_mle_sum_f32')
         return loss, dlogits, total
     rc = _lib.load().tfr_list_mle_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
-                                      B, L, float(temperature), _ptr(loss), _ptr(dlogits), _stream())
+                                      B, L, float(temperature), _ptr(loss), _ptr(dlogits), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_list_mle_f32')
     return loss, dlogits
 
@@ -456,15 +474,16 @@ def unique_softmax(logits, labels, mask=None, list_scale=None, temperature=1.0, 
     B, L = logits.shape
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws, ws_bytes = _workspace(WS_UNIQUE_SOFTMAX, B, L, logits.device)
     if want_sum:
         total, ticket = _sum_outputs(logits.device)
         rc = _lib.load().tfr_unique_softmax_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
                                                     float(temperature), _ptr(loss), _ptr(dlogits), _ptr(total),
-                                                    _ptr(ticket), _stream())
+                                                    _ptr(ticket), _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, 'tfr_unique_softmax_sum_f32')
         return loss, dlogits, total
     rc = _lib.load().tfr_unique_softmax_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
-                                            float(temperature), _ptr(loss), _ptr(dlogits), _stream())
+                                            float(temperature), _ptr(loss), _ptr(dlogits), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_unique_softmax_f32')
     return loss, dlogits
 
@@ -508,10 +527,10 @@ def circle_loss(logits, labels, mask=None, list_scale=None, gamma=64.0, margin=0
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     weight = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws, ws_bytes = _workspace(WS_CIRCLE, B, L, logits.device)
     rc = _lib.load().tfr_circle_loss_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(list_scale), B, L,
                                          float(gamma), float(margin), int(bool(clip)), _ptr(loss), _ptr(weight),
-                                         _ptr(dlogits),
-                                         _stream())
+                                         _ptr(dlogits), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_circle_loss_f32')
     return loss, weight, dlogits
 
@@ -528,9 +547,10 @@ def neural_sort_loss(kind, logits, labels, mask=None, list_scale=None, temperatu
     tab = rank_table(_inv_log1p, L, logits.device) if kind == NEURAL_SORT_NDCG else None
     loss = torch.empty((B,), dtype=torch.float32, device=logits.device)
     dlogits = torch.empty((B, L), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws, ws_bytes = _workspace(WS_NEURAL_SORT_NDCG if kind == NEURAL_SORT_NDCG else WS_NEURAL_SORT_CE, B, L, logits.device)
     rc = _lib.load().tfr_neural_sort_loss_f32(int(kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(tab),
                                               _ptr(list_scale), B, L, float(temperature), _ptr(loss),
-                                              _ptr(dlogits), _stream())
+                                              _ptr(dlogits), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_neural_sort_loss_f32')
     return loss, dlogits
 

@@ -24,6 +24,15 @@ __host__ __device__ inline int pow2_ceil(int n) {
   return p;
 }
 
+// Launches of the workgroup kernels whose per-position arrays live in the caller's workspace (list sizes beyond the LDS
+// range): one workgroup per workspace slot, the lists walked with a grid stride.
+inline int big_slots(int B, size_t workspace_bytes, size_t slot_bytes) {
+  size_t n = workspace_bytes / slot_bytes;
+  if (n > (size_t)B) n = (size_t)B;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+
 // Monotone map float -> uint32 (a < b  <=>  ord(a) < ord(b)); -0 is folded
 // onto +0 so that tied zeros compare equal like tf.math.top_k treats them.
 __device__ __forceinline__ uint32_t float_to_ordered(float f) {

@@ -421,9 +421,13 @@ __global__ __launch_bounds__(64) void circle_wave_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Workgroup forms for 1024 < list_size <= 4096 (the register sort of the wave kernels does not fit beyond 16 keys per
+// Workgroup forms for 1024 < list_size <= 8192 (the register sort of the wave kernels does not fit beyond 16 keys per
 // lane): keys and per-position values in LDS, block_bitonic_sort_desc, Hillis-Steele scans.  Same arithmetic as the
 // wave kernels; the scans associate differently, so results agree to rounding, not bit for bit.
+// BIG (round 5, list_size > 4096): the per-position arrays (24 / 36 B per item) outgrow the 160 KB of LDS next to the 8 B
+// sort keys; they move to a slot of the caller's workspace (global memory, L2-resident: <= 288 KB per slot) -- the sort keys
+// and the reduction scratch stay in LDS, the code is the same (__syncthreads orders a workgroup's global accesses as it
+// orders its LDS accesses).  A BIG launch has one workgroup per workspace slot and walks the lists with a grid stride.
 template <typename T, typename Op>
 __device__ __forceinline__ void block_scan_inclusive(T* a, T* scratch, int P, Op op) {    // result ends in `a`
   T* src = a;
@@ -443,18 +447,21 @@ struct ScanAdd { __device__ float operator()(float a, float b) const { return a 
 struct ScanMaxI { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
 struct ScanMinI { __device__ int operator()(int a, int b) const { return a < b ? a : b; } };
 
+template <bool BIG>
 __global__ __launch_bounds__(1024) void list_mle_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
-    const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int L, int P, float temperature,
-    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum) {
+    const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int B, int L, int P, float temperature,
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
-  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] logits by original index, then scan scratch
+  float* XS = BIG ? ws + (size_t)blockIdx.x * 4 * P : reinterpret_cast<float*>(keys + P);   // [P] logits by original index, then scan scratch
   float* XP = XS + P;                                             // [P] logit - max by sorted position
   float* SA = XP + P;                                             // [P] reversed e -> suffix sums
   float* CA = SA + P;                                             // [P] w / S -> prefix sums
-  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const int T = blockDim.x, tid = threadIdx.x;
+ for (int b = blockIdx.x; b < B; b += gridDim.x) {                // (one list per workgroup unless BIG)
+  if (BIG) __syncthreads();
   const size_t base = (size_t)b * L;
   for (int i = tid; i < P; i += T) {
     uint64_t k = 0;
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(1024) void list_mle_block_kernel(
   const float loss = block_sum(term, red);
   if (tid == 0) loss_out[b] = loss;
   if (sum.out && tid < 64) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, tid);
-  if (!dlogits_out) return;
+  if (!dlogits_out) continue;
   __syncthreads();
   block_scan_inclusive(CA, XS, P, ScanAdd());                     // C_p = sum_{q <= p} w_q / S_q
   const float gscale = (list_scale ? list_scale[b] : 1.0f) / temperature;
@@ -500,23 +507,27 @@ __global__ __launch_bounds__(1024) void list_mle_block_kernel(
     const float w = pos_weight ? pos_weight[p] : 1.0f;
     dlogits_out[base + sort_key_index(k)] = (k >> 63) ? (expf(XP[p]) * CA[p] - w) * gscale : 0.0f;
   }
+ }
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
-    const float* __restrict__ list_scale, int L, int P, float temperature, float* __restrict__ loss_out,
-    float* __restrict__ dlogits_out, const GridSum sum) {
+    const float* __restrict__ list_scale, int B, int L, int P, float temperature, float* __restrict__ loss_out,
+    float* __restrict__ dlogits_out, const GridSum sum, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
-  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] logits by original index -> suffix sums (SA)
+  float* XS = BIG ? ws + (size_t)blockIdx.x * 7 * P : reinterpret_cast<float*>(keys + P);   // [P] logits by original index -> suffix sums (SA)
   float* LB = XS + P;                                             // [P] labels by original index -> scan scratch (SB)
   float* XP = LB + P;                                             // [P] logit - max by sorted position
   float* LP = XP + P;                                             // [P] label by sorted position
   int* GS = reinterpret_cast<int*>(LP + P);                       // [P] first position of the label group
   int* GE = GS + P;                                               // [P] one past its last position (reversed index)
   float* CA = reinterpret_cast<float*>(GE + P);                   // [P] g / D -> prefix sums
-  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const int T = blockDim.x, tid = threadIdx.x;
+ for (int b = blockIdx.x; b < B; b += gridDim.x) {                // (one list per workgroup unless BIG)
+  if (BIG) __syncthreads();
   const size_t base = (size_t)b * L;
   int nvl = 0;
   for (int i = tid; i < P; i += T) {
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
   const float loss = block_sum(term, red);
   if (tid == 0) loss_out[b] = loss;
   if (sum.out && tid < 64) grid_weighted_sum_last(loss_out, b, loss, list_scale, sum.n, sum.out, sum.st, tid);
-  if (!dlogits_out) return;
+  if (!dlogits_out) continue;
   __syncthreads();
   block_scan_inclusive(CA, SB, P, ScanAdd());                     // inclusive prefix of g / D
   const float gscale = (list_scale ? list_scale[b] : 1.0f) / temperature;
@@ -582,23 +593,27 @@ __global__ __launch_bounds__(1024) void unique_softmax_block_kernel(
     const float higher = gs > 0 ? CA[gs - 1] : 0.0f;              // sum over strictly higher labels
     dlogits_out[base + sort_key_index(keys[p])] = (-g + e * (g / D + higher)) * gscale;
   }
+ }
 }
 
+template <bool BIG>
 __global__ __launch_bounds__(1024) void circle_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
-    const float* __restrict__ list_scale, int L, int P, float gamma, float margin, int clip,
-    float* __restrict__ loss_out, float* __restrict__ weight_out, float* __restrict__ dlogits_out) {
+    const float* __restrict__ list_scale, int B, int L, int P, float gamma, float margin, int clip,
+    float* __restrict__ loss_out, float* __restrict__ weight_out, float* __restrict__ dlogits_out, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
-  float* XS = reinterpret_cast<float*>(keys + P);                 // [P] raw logits by original index -> suffix sums of F
+  float* XS = BIG ? ws + (size_t)blockIdx.x * 7 * P : reinterpret_cast<float*>(keys + P);   // [P] raw logits by original index -> suffix sums of F
   float* LB = XS + P;                                             // [P] labels by original index -> scan scratch
   float* SP = LB + P;                                             // [P] raw score by sorted position
   float* LP = SP + P;                                             // [P] label by sorted position
   int* GS = reinterpret_cast<int*>(LP + P);                       // [P] first position of the label group
   int* GE = GS + P;                                               // [P] one past its last position (reversed index)
   float* EA = reinterpret_cast<float*>(GE + P);                   // [P] E -> inclusive prefix sums
-  const int b = blockIdx.x, T = blockDim.x, tid = threadIdx.x;
+  const int T = blockDim.x, tid = threadIdx.x;
+ for (int b = blockIdx.x; b < B; b += gridDim.x) {                // (one list per workgroup unless BIG)
+  if (BIG) __syncthreads();
   const size_t base = (size_t)b * L;
   int nvl = 0;
   for (int i = tid; i < P; i += T) {
@@ -666,7 +681,7 @@ __global__ __launch_bounds__(1024) void circle_block_kernel(
     loss_out[b] = loss;
     if (weight_out) weight_out[b] = any_pair ? 1.0f : NAN;
   }
-  if (!dlogits_out) return;
+  if (!dlogits_out) continue;
   const float sig = any_pair ? 1.0f / (1.0f + expf(-lw)) : 0.0f;                          // W / (1 + W)
   const float gscale = (list_scale ? list_scale[b] : 1.0f) * gamma * sig;
   for (int p = tid; p < nv; p += T) {
@@ -684,26 +699,46 @@ __global__ __launch_bounds__(1024) void circle_block_kernel(
     }
     dlogits_out[base + sort_key_index(keys[p])] = gscale * gpart;
   }
+ }
 }
 
 }  // namespace
 
+// Bytes of workspace ONE list in flight needs (include/tfr_hip.h): the per-position arrays of the workgroup kernels once
+// they outgrow LDS next to the sort keys.  0: the op runs from LDS at this list size.
+extern "C" long tfr_list_workspace_bytes(int op, int L) {
+  if (L <= 0 || L > TFR_MAX_LIST) return 0;
+  const long P = pow2_ceil(L);
+  switch (op) {
+    case TFR_WS_LIST_MLE: return L > TFR_LDS_LIST_SIZE_LISTWISE ? 16 * P : 0;
+    case TFR_WS_UNIQUE_SOFTMAX: case TFR_WS_CIRCLE: return L > TFR_LDS_LIST_SIZE_LISTWISE ? 28 * P : 0;
+    case TFR_WS_RANK_METRIC: return L > TFR_LDS_LIST_SIZE_METRIC ? 24 * P : 0;
+    case TFR_WS_DIV_METRIC: return L > TFR_LDS_LIST_SIZE_METRIC ? 20 * P : 0;
+    case TFR_WS_NEURAL_SORT_NDCG: return L > TFR_LDS_LIST_SIZE_NEURAL_SORT ? 32 * P : 0;
+    case TFR_WS_NEURAL_SORT_CE: return L > TFR_LDS_LIST_SIZE_NEURAL_SORT ? 52 * P : 0;
+    default: return 0;
+  }
+}
+
 static int list_mle_dispatch(const float* logits, const float* labels, const uint8_t* mask,
                              const float* pos_weight, const float* list_scale, int B, int L,
                              float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
-                             void* stream) {
+                             void* workspace, long workspace_bytes, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 24 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_LIST_MLE, L);      // > 0: the per-position arrays outgrow LDS
+  if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return loss_sum_out ? (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream) : TFR_OK;
   const GridSum sum = {loss_sum_out, loss_out, ticket, B};
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
     const int P = pow2_ceil(L);
-    const size_t lds = 128 + (size_t)P * 24;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_mle_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = 128 + (size_t)P * (slot ? 8 : 24);
+    auto fn = slot ? list_mle_block_kernel<true> : list_mle_block_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(list_mle_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, pos_weight, list_scale, L, P,
-                       temperature, loss_out, dlogits_out, sum);
+    hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(1024), lds, st, logits, labels, mask,
+                       pos_weight, list_scale, B, L, P, temperature, loss_out, dlogits_out, sum, (float*)workspace);
     return (int)hipGetLastError();
   }
 #define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out, sum)
@@ -714,35 +749,40 @@ static int list_mle_dispatch(const float* logits, const float* labels, const uin
 
 extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                                 const float* pos_weight, const float* list_scale, int B, int L,
-                                float temperature, float* loss_out, float* dlogits_out, void* stream) {
+                                float temperature, float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes,
+                                void* stream) {
   return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out, nullptr,
-                           nullptr, stream);
+                           nullptr, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                     const float* pos_weight, const float* list_scale, int B, int L,
                                     float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
-                                    uint32_t* ticket, void* stream) {
+                                    uint32_t* ticket, void* workspace, long workspace_bytes, void* stream) {
   if (!loss_sum_out || !ticket) return TFR_EINVAL;
   return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out,
-                           loss_sum_out, ticket, stream);
+                           loss_sum_out, ticket, workspace, workspace_bytes, stream);
 }
 
 static int unique_softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,
                                    const float* list_scale, int B, int L, float temperature,
-                                   float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket, void* stream) {
+                                   float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
+                                   void* workspace, long workspace_bytes, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 36 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_UNIQUE_SOFTMAX, L);
+  if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return loss_sum_out ? (int)hipMemsetAsync(loss_sum_out, 0, sizeof(float), (hipStream_t)stream) : TFR_OK;
   const GridSum sum = {loss_sum_out, loss_out, ticket, B};
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
     const int P = pow2_ceil(L);
-    const size_t lds = 128 + (size_t)P * 36;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unique_softmax_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = 128 + (size_t)P * (slot ? 8 : 36);
+    auto fn = slot ? unique_softmax_block_kernel<true> : unique_softmax_block_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(unique_softmax_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, list_scale, L, P,
-                       temperature, loss_out, dlogits_out, sum);
+    hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(1024), lds, st, logits, labels, mask,
+                       list_scale, B, L, P, temperature, loss_out, dlogits_out, sum, (float*)workspace);
     return (int)hipGetLastError();
   }
 #define US(I) hipLaunchKernelGGL(unique_softmax_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, temperature, loss_out, dlogits_out, sum)
@@ -753,34 +793,39 @@ static int unique_softmax_dispatch(const float* logits, const float* labels, con
 
 extern "C" int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8_t* mask,
                                       const float* list_scale, int B, int L, float temperature,
-                                      float* loss_out, float* dlogits_out, void* stream) {
+                                      float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes,
+                                      void* stream) {
   return unique_softmax_dispatch(logits, labels, mask, list_scale, B, L, temperature, loss_out, dlogits_out, nullptr, nullptr,
-                                 stream);
+                                 workspace, workspace_bytes, stream);
 }
 
 extern "C" int tfr_unique_softmax_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                           const float* list_scale, int B, int L, float temperature,
                                           float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
-                                          void* stream) {
+                                          void* workspace, long workspace_bytes, void* stream) {
   if (!loss_sum_out || !ticket) return TFR_EINVAL;
   return unique_softmax_dispatch(logits, labels, mask, list_scale, B, L, temperature, loss_out, dlogits_out, loss_sum_out,
-                                 ticket, stream);
+                                 ticket, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tfr_circle_loss_f32(const float* logits, const float* labels, const uint8_t* mask,
                                    const float* list_scale, int B, int L, float gamma, float margin, int clip,
-                                   float* loss_out, float* weight_out, float* dlogits_out, void* stream) {
+                                   float* loss_out, float* weight_out, float* dlogits_out, void* workspace,
+                                   long workspace_bytes, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_LISTWISE) return TFR_ETOOLARGE;   // 36 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_CIRCLE, L);
+  if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   hipStream_t st = (hipStream_t)stream;
   if (L > 1024) {
     const int P = pow2_ceil(L);
-    const size_t lds = 128 + (size_t)P * 36;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&circle_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = 128 + (size_t)P * (slot ? 8 : 36);
+    auto fn = slot ? circle_block_kernel<true> : circle_block_kernel<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(circle_block_kernel, dim3(B), dim3(1024), lds, st, logits, labels, mask, list_scale, L, P, gamma, margin,
-                       clip, loss_out, weight_out, dlogits_out);
+    hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(1024), lds, st, logits, labels, mask,
+                       list_scale, B, L, P, gamma, margin, clip, loss_out, weight_out, dlogits_out, (float*)workspace);
     return (int)hipGetLastError();
   }
 #define CL(I) hipLaunchKernelGGL(circle_wave_kernel<I>, dim3(B), dim3(64), (size_t)(4 * 64 * I + 2) * sizeof(float), st, logits, labels, mask, list_scale, L, gamma, margin, clip, loss_out, weight_out, dlogits_out)

@@ -1032,21 +1032,26 @@ __device__ __forceinline__ void block_inclusive_scan(float* a, float* scratch, i
   }
 }
 
+// BIG (round 5, list_size > 4096): the six per-position arrays live in a slot of the caller's workspace (global memory)
+// instead of LDS -- see csrc/listwise.hip; one workgroup per slot walks the lists with a grid stride.
+template <bool BIG>
 __global__ void rank_metric2_block_kernel(
     int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
     const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
     const float* __restrict__ gains, const float* __restrict__ discount, TopN topn, int B, int L, int P,
-    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+    float* __restrict__ metric_out, float* __restrict__ stats_out, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
-  float* W = reinterpret_cast<float*>(keys + P);                  // [P] weight by original index
+  float* W = BIG ? ws + (size_t)blockIdx.x * 6 * P : reinterpret_cast<float*>(keys + P);   // [P] weight by original index
   float* G = W + P;                                               // [P] relevance / gain by original index
   float* REL = G + P;                                             // [P] relevance in sorted order
   float* WR = REL + P;                                            // [P] w * rel in sorted order
   float* CUM = WR + P;                                            // [P] prefix counts
   float* term = CUM + P;                                          // [P] tree-sum scratch
-  const int b = blockIdx.x, T = blockDim.x;
+  const int T = blockDim.x;
+ for (int b = blockIdx.x; b < B; b += gridDim.x) {                // (one list per workgroup unless BIG)
+  if (BIG) __syncthreads();
   const size_t base = (size_t)b * L;
   const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
 
@@ -1115,7 +1120,7 @@ __global__ void rank_metric2_block_kernel(
       stats_out[(size_t)b * 3 + 2] = tw;
       metric_out[b] = (tw != 0.0f) ? tc / tw : 0.0f;
     }
-    return;
+    continue;
   }
 
   block_bitonic_sort_desc(keys, P);                              // (Hits too: the first relevant sorted position)
@@ -1135,7 +1140,7 @@ __global__ void rank_metric2_block_kernel(
         metric_out[(size_t)q * B + b] = (pmin < (float)k) ? 1.0f : 0.0f;
       }
     }
-    return;
+    continue;
   }
   const bool bpref = (kind == TFR_METRIC_BPREF || kind == TFR_METRIC_BPREF_NONTREC);
   if (kind == TFR_METRIC_MAP || bpref) {
@@ -1185,22 +1190,26 @@ __global__ void rank_metric2_block_kernel(
     else if (kind == TFR_METRIC_ARP) out = (arp_den != 0.0f) ? total / arp_den : 0.0f;
     if (threadIdx.x == 0) metric_out[(size_t)q * B + b] = out;
   }
+ }
 }
 
+template <bool BIG>
 __global__ void div_metric_block_kernel(
     int kind, const float* __restrict__ labels, const float* __restrict__ predictions,
     const float* __restrict__ weights, int weights_per_list, const uint8_t* __restrict__ mask,
     const float* __restrict__ discount, float alpha, TopN topn, int B, int L, int S, int P,
-    float* __restrict__ metric_out, float* __restrict__ stats_out) {
+    float* __restrict__ metric_out, float* __restrict__ stats_out, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
-  float* W = reinterpret_cast<float*>(keys + P);                  // [P] weight by original index, then in sorted order
+  float* W = BIG ? ws + (size_t)blockIdx.x * 5 * P : reinterpret_cast<float*>(keys + P);   // [P] weight by original index, then in sorted order
   float* G = W + P;                                               // [P] rel by original index
   float* VAL = G + P;                                             // [P] per-position value, sorted order
   float* Y = VAL + P;                                             // [P] one subtopic's labels / their prefix
   float* term = Y + P;                                            // [P]
-  const int b = blockIdx.x, T = blockDim.x;
+  const int T = blockDim.x;
+ for (int b = blockIdx.x; b < B; b += gridDim.x) {                // (one list per workgroup unless BIG)
+  if (BIG) __syncthreads();
   const size_t base = (size_t)b * L;
   const float wl = (weights && weights_per_list) ? weights[b] : 1.0f;
   float nm = 0.f;
@@ -1283,6 +1292,7 @@ __global__ void div_metric_block_kernel(
     }
     if (threadIdx.x == 0) metric_out[(size_t)q * B + b] = out;
   }
+ }
 }
 
 // Per-list metric weights from the per-list statistics (metrics_impl.py:63-119
@@ -1598,7 +1608,8 @@ extern "C" int tfr_mrr_metric_f32(const float* labels, const float* predictions,
 extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                                    int weights_per_list, const uint8_t* mask, const float* gains,
                                    const float* discount, const int32_t* topn_host, int K, int B, int L,
-                                   float* metric_out, float* stats_out, void* stream) {
+                                   float* metric_out, float* stats_out, void* workspace, long workspace_bytes,
+                                   void* stream) {
   if (kind == TFR_METRIC_NDCG || kind == TFR_METRIC_MRR)
     return launch_metric(kind, labels, predictions, weights, weights_per_list, mask, gains, discount, topn_host, K,
                          B, L, metric_out, stats_out, stream);
@@ -1607,21 +1618,24 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == TFR_METRIC_DCG && !discount) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_METRIC) return TFR_ETOOLARGE;     // 32 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_RANK_METRIC, L);   // > 0: 32 B per item outgrow LDS
+  if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;
-  if (L > 512) {                                  // long lists: one workgroup per list, everything in LDS
-    const size_t lds = 128 + (size_t)P * 32;
+  if (L > 512) {                                  // long lists: one workgroup per list, everything in LDS (or the workspace)
+    const size_t lds = 128 + (size_t)P * (slot ? 8 : 32);
+    auto fn = slot ? rank_metric2_block_kernel<true> : rank_metric2_block_kernel<false>;
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_metric2_block_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(rank_metric2_block_kernel, dim3(B), dim3(block_threads_for(P)), lds, st, kind, labels, predictions,
-                       weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out);
+    hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(block_threads_for(P)), lds, st, kind,
+                       labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out,
+                       (float*)workspace);
     return (int)hipGetLastError();
   }
 #define M2(I) hipLaunchKernelGGL(rank_metric2_wave_kernel<I>, dim3(B), dim3(64), (size_t)2 * 64 * I * sizeof(float), st, kind, labels, predictions, weights, weights_per_list, mask, gains, discount, tn, B, L, P, metric_out, stats_out)
@@ -1633,26 +1647,29 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
 extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                                   int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
                                   const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
-                                  float* stats_out, void* stream) {
+                                  float* stats_out, void* workspace, long workspace_bytes, void* stream) {
   if (kind != TFR_DIV_ALPHA_DCG && kind != TFR_DIV_PRECISION_IA) return TFR_EINVAL;
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0 || S <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == TFR_DIV_ALPHA_DCG && !discount) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_METRIC) return TFR_ETOOLARGE;     // 28 B of LDS per item in the workgroup kernel
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_DIV_METRIC, L);    // > 0: 28 B per item outgrow LDS
+  if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
   TopN tn; tn.n = K;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;
   if (L > 512) {                                  // long lists: one workgroup per list
-    const size_t lds = 128 + (size_t)P * 28;
+    const size_t lds = 128 + (size_t)P * (slot ? 8 : 28);
+    auto fn = slot ? div_metric_block_kernel<true> : div_metric_block_kernel<false>;
     if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&div_metric_block_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(div_metric_block_kernel, dim3(B), dim3(block_threads_for(P)), lds, st, kind, labels, predictions,
-                       weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out);
+    hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(block_threads_for(P)), lds, st, kind,
+                       labels, predictions, weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out,
+                       (float*)workspace);
     return (int)hipGetLastError();
   }
 #define DM(I) hipLaunchKernelGGL(div_metric_wave_kernel<I>, dim3(B), dim3(64), 0, st, kind, labels, predictions, weights, weights_per_list, mask, discount, alpha, tn, B, L, S, P, metric_out, stats_out)

@@ -2306,10 +2306,15 @@ extern "C" int tfr_tower_multi_add(float* const* dst, const float* const* src, c
 // rows[b * L + p] for tfr_tower_cast_gather_f32_bf16 (keras/layers.py:122-183 FlattenList, utils.py:308-356).
 extern "C" int tfr_flatten_row_index(const unsigned char* mask, int B, int L, int* rows, void* stream) {
   if (!mask || !rows || B < 0 || L <= 0 || (long)B * L > 0x7fffffffL) return TFR_EINVAL;
-  if (L > TFR_MAX_LIST_SIZE_FLATTEN) return TFR_ETOOLARGE;   // 16 B of LDS per item x 4 list-waves <= 64 KiB
+  if (L > TFR_MAX_LIST_SIZE) return TFR_ETOOLARGE;           // 4 B of LDS per item and list-wave, 4 list-waves: <= 128 KiB
   if (B == 0) return TFR_OK;
-  hipLaunchKernelGGL(flatten_row_index_kernel, dim3((B + 3) / 4), dim3(256), (size_t)L * 16, (hipStream_t)stream,
-                     mask, B, L, rows);
+  const size_t lds = (size_t)L * 16;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&flatten_row_index_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(flatten_row_index_kernel, dim3((B + 3) / 4), dim3(256), lds, (hipStream_t)stream, mask, B, L, rows);
   return (int)hipGetLastError();
 }
 

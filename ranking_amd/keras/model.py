@@ -60,7 +60,7 @@ class DNNScorer(UnivariateScorer):
             if torch.is_tensor(x) and x.dim() == 3 and x.dtype in _feed:
                 mask = torch.as_tensor(mask, device=x.device).to(torch.bool)
                 b, l = mask.shape
-                if l <= 4096 and b * l < 2 ** 31:
+                if l <= 8192 and b * l < 2 ** 31:
                     rows = _tower_ops.flatten_row_index(mask)        # one launch (utils.py:308-356)
                 else:
                     idx, _ = _tfr_utils.padded_nd_indices(is_valid=mask)

@@ -1088,7 +1088,8 @@ def test_more_metrics_reference_literals(case):
         assert_loss_close(w, torch.tensor(exp_w), 1e-6, cls + ' weights')
 
 
-@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (5, 513), (3, 700), (2, 2500), (1, 4096)])   # > 512: workgroup kernel
+@pytest.mark.parametrize('B,L', SHAPES + [(1100, 300), (5, 513), (3, 700), (2, 2500), (1, 4096),   # > 512: workgroup kernel
+                                          (2, 5000), (1, 8192)])                                 # > 4096: its arrays in the workspace
 @pytest.mark.parametrize('weighted', [False, True])
 def test_more_metrics_bit_exact(B, L, weighted):
     labels, preds = make_batch(B, L, seed=1000 + L)
@@ -1157,7 +1158,8 @@ def test_more_metrics_keras_and_factory_keys():
 
 
 # ------------------------------------------------------------------ ListMLE
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096)])       # > 1024: the workgroup kernel
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096),        # > 1024: the workgroup kernel
+                                          (2, 5000), (3, 8192)])                     # > 4096: its arrays in the workspace
 @pytest.mark.parametrize('with_lambda', [False, True])
 def test_list_mle_parity(B, L, with_lambda):
     labels, logits = make_batch(B, L, seed=1100 + L)
@@ -1230,7 +1232,8 @@ def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_
 
 
 # ------------------------------------------------------------------ UniqueSoftmax
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096)])       # > 1024: the workgroup kernel
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 300), (3, 1500), (2, 4096),        # > 1024: the workgroup kernel
+                                          (2, 5000), (2, 8192)])                     # > 4096: its arrays in the workspace
 def test_unique_softmax_parity(B, L):
     labels, logits = make_batch(B, L, seed=1300 + L)        # graded labels: plenty of tie groups
     if B >= 3:
@@ -1361,6 +1364,58 @@ def test_neural_sort_loss_parity(B, L, kind, temperature):
     assert torch.isfinite(d).all()
 
 
+@pytest.mark.parametrize('B,L,temperature', [(3, 2100, 1.0), (2, 2500, 0.1), (1, 8192, 1.0)])
+@pytest.mark.parametrize('kind', ['ndcg', 'ce'])
+def test_neural_sort_workgroup_form_parity(B, L, kind, temperature):
+    """list_size > 2048 (TFR_LDS_LIST_SIZE_NEURAL_SORT): one workgroup per list, the row statistics in the caller's
+    workspace (round 5; the wave kernel stops at 32 items per lane).  Same oracle comparison as the wave kernel."""
+    labels, logits = make_batch(B, L, seed=1600 + L)
+    if B >= 3:
+        labels[1] = -1.0                                                                  # fully padded
+    octor = R.NeuralSortNDCGLoss if kind == 'ndcg' else R.NeuralSortCrossEntropyLoss
+    oracle = octor(temperature=temperature)
+    o32, g32 = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels, lg / temperature)[0], logits)
+    truth, gt = _oracle_grad(lambda lg: oracle._compute_unreduced_loss_impl(labels.double(), lg / temperature)[0],
+                             logits.double())
+    from ranking_amd import _ops
+    k = _ops.NEURAL_SORT_NDCG if kind == 'ndcg' else _ops.NEURAL_SORT_CE
+    loss, d = _ops.neural_sort_loss(k, logits.to(DEV), labels.to(DEV), None, None, temperature)
+    _fp64_arbitrated(loss, o32, truth, 1e-5, 'neural sort %s loss (workgroup form)' % kind)
+    _fp64_arbitrated(d, g32, gt, 2e-5, 'neural sort %s grad (workgroup form)' % kind)
+    assert torch.isfinite(d).all()
+    loss_only, none = _ops.neural_sort_loss(k, logits.to(DEV), labels.to(DEV), None, None, temperature, want_grad=False)
+    assert none is None and torch.equal(loss_only, loss)
+
+
+def test_workspace_launches_walk_the_lists_with_a_grid_stride(monkeypatch):
+    """Beyond the LDS range a launch has one workgroup per workspace SLOT (at most 256 from `_ops`) and the workgroups
+    walk the lists with a grid stride: 5 lists through 2 slots give the bits of 5 lists through 5 slots."""
+    from ranking_amd import _ops
+    mi = ra().metrics_impl
+    B, L = 5, 4500
+    labels, logits = make_batch(B, L, seed=77)
+    labels[3] = -1.0
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    sub = (torch.rand((B, L, 2), generator=torch.Generator().manual_seed(5)) < 0.3).float().to(DEV)
+
+    def run():
+        out = list(_ops.list_mle(lg, lb)) + list(_ops.unique_softmax(lg, lb)) + list(_ops.circle_loss(torch.sigmoid(lg), lb))
+        out += list(_ops.neural_sort_loss(_ops.NEURAL_SORT_CE, lg[:, :2100].contiguous(), lb[:, :2100].contiguous()))
+        out += list(_ops.neural_sort_loss(_ops.NEURAL_SORT_NDCG, lg[:, :2100].contiguous(), lb[:, :2100].contiguous()))
+        out += list(mi.MeanAveragePrecisionMetric(None, None).compute_multi(lb, lg, None, None, [5, None]))
+        out += list(mi.OPAMetric(None).compute(lb, lg, None))
+        out += list(_ops.div_metric(_ops.DIV_ALPHA_DCG, sub, lg, None, None, [10, None],
+                                    discount=_ops.rank_table(lambda r: 1. / torch.log1p(r), L, torch.device(DEV))))
+        torch.cuda.synchronize()
+        return out
+    full = run()
+    monkeypatch.setattr(_ops, '_WS_LISTS', 2)
+    two = run()
+    assert len(full) == len(two)
+    for a, b in zip(full, two):
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
 def test_neural_sort_reference_goldens():
     L = ra().losses_impl
     t = lambda x: torch.tensor(x, device=DEV)
@@ -1400,7 +1455,8 @@ def test_neural_sort_reference_goldens():
 
 
 # ------------------------------------------------------------------ Circle loss
-@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40), (3, 1500), (2, 4096)])        # > 1024: the workgroup kernel
+@pytest.mark.parametrize('B,L', SHAPES + [(1030, 40), (3, 1500), (2, 4096),         # > 1024: the workgroup kernel
+                                          (2, 5000), (1, 8192)])                     # > 4096: its arrays in the workspace
 @pytest.mark.parametrize('gamma,margin,lo,hi', [(64., 0.25, 0.2, 0.6), (4., 0.1, -0.3, 1.3), (16., 0.25, 0.0, 1.0)])
 def test_circle_loss_parity(B, L, gamma, margin, lo, hi):
     labels, logits = make_batch(B, L, seed=1700 + L)
@@ -1446,7 +1502,8 @@ def test_circle_loss_reference_goldens():
 
 # ------------------------------------------------------------------ diversity metrics
 @pytest.mark.parametrize('B,L,S', [(1, 1, 1), (3, 2, 2), (5, 50, 3), (6, 65, 5), (4, 200, 4), (2, 1000, 2), (1030, 30, 3),
-                                   (3, 600, 3), (1, 3000, 2)])                  # > 512: workgroup kernel
+                                   (3, 600, 3), (1, 3000, 2),                   # > 512: workgroup kernel
+                                   (2, 5000, 2), (1, 8192, 3)])                 # > 4096: its arrays in the workspace
 @pytest.mark.parametrize('weighted', [False, True])
 def test_diversity_metrics_parity(B, L, S, weighted):
     g = torch.Generator().manual_seed(1900 + L)

@@ -609,7 +609,7 @@ def test_gemm_relu_bwd_epilogue(M, N, K):
     assert (s[1] - (want * zhat).sum(dim=0)).abs().max().item() <= lim * max(1.0, zhat.abs().max().item())
 
 
-@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (37, 64), (130, 65), (64, 200), (9, 1000), (3, 4096)])
+@pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (37, 64), (130, 65), (64, 200), (9, 1000), (3, 4096), (5, 5000), (6, 8192)])
 def test_flatten_row_index_is_bit_exact_against_padded_nd_indices(B, L):
     """tfr_flatten_row_index == utils.padded_nd_indices(shuffle=False) (utils.py:308-356) + the batch offset:
     scattered masks, all-valid, single-valid and EMPTY lists (which read position 0)."""

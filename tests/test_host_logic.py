@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     src = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
-    return sorted(set(re.findall(r'^int\s+(tfr_\w+)\s*\(', src, flags=re.M)))
+    return sorted(set(re.findall(r'^(?:int|long)\s+(tfr_\w+)\s*\(', src, flags=re.M)))
 
 
 def test_header_and_library_agree():
@@ -52,8 +52,23 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.tfr_pairwise_logistic_f32(one, one, None, None, None, 7, 0, 0.0, 0, 0, None, one, 1, 8, 1.0,
                                          None, None, None, None, None) == -1       # lambda kind
     assert lib.tfr_list_order_i32(None, None, 4, 8, one, one, None) == -1
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, None) == -2
-    assert lib.tfr_rank_metric_f32(12, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, None) == -1
+    # beyond the LDS range a list needs a workspace slot (tfr_list_workspace_bytes): absent / short -> TFR_ETOOLARGE
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, None, 0, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, one, 16 * 8192 - 1, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 9000, 1.0, one, None, one, 1 << 30, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 0, 5000, 1.0, one, None, one, 16 * 8192, None) == 0    # B == 0
+    assert lib.tfr_circle_loss_f32(one, one, None, None, 1, 5000, 64.0, 0.25, 1, one, None, None, None, 0, None) == -2
+    assert lib.tfr_unique_softmax_f32(one, one, None, None, 1, 5000, 1.0, one, None, None, 0, None) == -2
+    assert lib.tfr_neural_sort_loss_f32(0, one, one, None, one, None, 1, 2049, 1.0, one, None, None, 0, None) == -2
+    assert lib.tfr_neural_sort_loss_f32(1, one, one, None, None, None, 0, 2049, 1.0, one, None, one, 52 * 4096, None) == 0
+    one_topn = (ctypes.c_int32 * 1)(1)
+    assert lib.tfr_rank_metric_f32(3, one, one, None, 0, None, None, one, one_topn, 1, 1, 5000, one, one, None, 0, None) == -2
+    assert lib.tfr_div_metric_f32(1, one, one, None, 0, None, None, 0.5, one_topn, 1, 1, 5000, 2, one, one, None, 0, None) == -2
+    ws = lib.tfr_list_workspace_bytes
+    assert [ws(op, 4096) for op in range(5)] == [0] * 5 and ws(5, 2048) == 0 and ws(6, 2048) == 0
+    assert [ws(op, 4097) for op in range(7)] == [16 * 8192, 28 * 8192, 28 * 8192, 24 * 8192, 20 * 8192, 32 * 8192, 52 * 8192]
+    assert ws(5, 2049) == 32 * 4096 and ws(6, 3000) == 52 * 4096 and ws(0, 8193) == 0 and ws(7, 5000) == 0
+    assert lib.tfr_rank_metric_f32(12, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, None, 0, None) == -1
     topn = (ctypes.c_int32 * 1)(10)
     assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
     assert lib.tfr_gumbel_sample_f32(one, one, None, None, 0, 0, 1, 0, 8, 1.0, one, None) == -1
@@ -63,7 +78,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert ob(None, None, None) == -1 and ob(one, None, None) == -1
     assert ob(None, one, one) == -1 and ob(one, one, one) == -1
     assert lib.tfr_flatten_row_index(None, 1, 8, one, None) == -1
-    assert lib.tfr_flatten_row_index(one, 1, 5000, one, None) == -2         # L > 4096: LDS compaction buffer
+    assert lib.tfr_flatten_row_index(one, 1, 9000, one, None) == -2         # L > 8192
     assert lib.tfr_flatten_row_index(one, 0, 8, one, None) == 0
     assert lib.tfr_tower_multi_add(None, None, None, 0, None) == 0
     assert lib.tfr_tower_multi_add(None, None, None, 2, None) == -1
@@ -75,8 +90,8 @@ def test_invalid_arguments_are_rejected_before_any_launch():
                                         None, None, one, one, None) == -1
     assert lib.tfr_pairwise_loss_sum_f32(0, one, one, None, None, None, 0, 0, 0.0, 0, 0, None, None, 1, 8, 1.0,
                                          None, None, None, None, None, None, one, one, None) == -1     # no list_loss_out
-    assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, None) == -1
-    assert lib.tfr_unique_softmax_sum_f32(one, one, None, None, 1, 8, 1.0, one, None, None, one, None) == -1
+    assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, None, 0, None) == -1
+    assert lib.tfr_unique_softmax_sum_f32(one, one, None, None, 1, 8, 1.0, one, None, None, one, None, 0, None) == -1
     assert lib.tfr_pointwise_loss_sum_f32(0, one, one, None, None, None, 1, 8, 1.0, one, None, None, None, None, one,
                                           None) == -1
     with pytest.raises(ValueError):
@@ -273,7 +288,7 @@ def integration_stub_namespace():
 
 def header_arity(name):
     src = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
-    m = re.search(r'^int\s+%s\s*\((.*?)\)\s*;' % re.escape(name), src, flags=re.M | re.S)
+    m = re.search(r'^(?:int|long)\s+%s\s*\((.*?)\)\s*;' % re.escape(name), src, flags=re.M | re.S)
     assert m, name
     return len([a for a in m.group(1).split(',') if a.strip() and a.strip() != 'void'])
 
@@ -330,18 +345,20 @@ def test_isa_floor_json_describes_the_current_kernels():
 
 
 def test_list_size_limits_in_the_header_are_the_ones_the_launchers_test():
-    """the public header said "L <= 1024" where the code took 4096.  The limits are macros of
-    include/tfr_hip.h now; every "list_size <= N" statement of the header must name a macro with that value, the
+    """the public header said "L <= 1024" where the code took 4096.  The limit is a macro of
+    include/tfr_hip.h (one for every entry point since round 5; the LDS ranges beyond which a workspace is needed are
+    TFR_LDS_LIST_SIZE_*); every "list_size <= N" statement of the header must name a macro with that value, the
     launchers must compare against the macros (no literal next to TFR_ETOOLARGE), and common.h's TFR_MAX_LIST must
     equal TFR_MAX_LIST_SIZE."""
     import re
     hdr = open(os.path.join(ROOT, 'include', 'tfr_hip.h')).read()
     macros = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define (TFR_MAX_LIST_SIZE\w*) (\d+)', hdr)}
-    assert set(macros) == {'TFR_MAX_LIST_SIZE', 'TFR_MAX_LIST_SIZE_METRIC', 'TFR_MAX_LIST_SIZE_LISTWISE',
-                           'TFR_MAX_LIST_SIZE_NEURAL_SORT', 'TFR_MAX_LIST_SIZE_FLATTEN'}, macros
-    # statements: "list_size <= 4096 (TFR_MAX_LIST_SIZE_METRIC" -- the number and the macro must agree
+    assert macros == {'TFR_MAX_LIST_SIZE': 8192}, macros
+    lds = {m.group(1): int(m.group(2)) for m in re.finditer(r'#define (TFR_LDS_LIST_SIZE\w*) (\d+)', hdr)}
+    assert lds == {'TFR_LDS_LIST_SIZE_METRIC': 4096, 'TFR_LDS_LIST_SIZE_LISTWISE': 4096, 'TFR_LDS_LIST_SIZE_NEURAL_SORT': 2048}
+    # statements: "list_size <= 8192 (TFR_MAX_LIST_SIZE" -- the number and the macro must agree
     stated = re.findall(r'list_size <= (\d+) \((TFR_MAX_LIST_SIZE\w*)', hdr)
-    assert len(stated) >= 6, stated
+    assert len(stated) >= 3, stated
     for n, name in stated:
         assert macros[name] == int(n), (n, name, macros[name])
     # no other "L <= <number >= 1000>" / "list_size <= <number>" claims without a macro (256 = the fast-path range, not a limit)

@@ -2,7 +2,7 @@
 # Round-5 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r05.sh <tag> <what...>
 #   what: tests (full -m gpu suite + smoke) | sums_ab (TFR_LOSS_SUM_FUSED 0 / 1 on the softmax and LambdaRank steps) |
 #         ndcg_ab (TFR_NDCG_LEAN 0 / 1 and the persistent-grid size) | gemm_ab (tower GEMM variants: tools/tower_bench.py +
-#         the e2e steps) | lrank_ab (LambdaRank switches) | one:<workload> | prof:<workload> | pmc:<workload> |
+#         the e2e steps) | lrank_ab (LambdaRank switches) | late (tests of the late round-5 changes) | one:<workload> | prof:<workload> | pmc:<workload> |
 #         profiles (everything profiles/r05_* is made from: bench lines, rocprofv3 kernel-trace stats, FETCH / WRITE / SQ
 #         passes of every dominant kernel, on the tree as it is) | final (the driver's command) | multi (N = 2 if two
 #         devices are visible: bench.py --gpus 2 and the RCCL test)
@@ -45,6 +45,9 @@ for what in "$@"; do
       ab "pair rcp fwd+bwd again" approx_ndcg 200 TFR_APPROX_PAIR_RCP=2
       ab "pair rcp fwd only again" approx_ndcg 200 TFR_APPROX_PAIR_RCP=1
       ab "gumbel" gumbel_approx_ndcg 200 TFR_DUMMY=0 ;;
+    late)
+      # the late round-5 changes: 16-bit Dropout fields, list sizes beyond the LDS range (workspace forms), flatten at 8192
+      timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_tower.py -x -q -m gpu -k "5000 or 8192 or workgroup_form or grid_stride or 2500 or flatten or dropout or writes_its_transformed" > $OUT/t_late.log 2>&1; echo "late tests rc=$?"; tail -n 12 $OUT/t_late.log | cut -c1-220 ;;
     tests_changed)
       timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "reduced_scalar or ndcg or softmax or pairwise or lambda or list_mle or unique or pointwise or keras or metric or sigmoid" > $OUT/t_changed.log 2>&1; echo "changed-area tests rc=$?"; tail -n 12 $OUT/t_changed.log | cut -c1-200 ;;
     sums_ab)
