@@ -256,17 +256,24 @@ def _ste(x):
     return x + (x.to(torch.bfloat16).float() - x).detach()
 
 
-def ref_tower(x, tower, training=True):
+def _pin(x, value):
+    """x with its VALUE replaced by `value` (straight-through: the derivative stays x's)."""
+    return x + (value.to(torch.float32) - x).detach()
+
+
+def ref_tower(x, tower, training=True, pin=None):
     """fp32 torch restatement of create_tower with the kernel's bf16 rounding points
-    (straight-through), differentiable by autograd."""
+    (straight-through), differentiable by autograd.  `pin` = (x0, zs) of a kernel forward (the autograd node's bf16 layer
+    input and pre-activations): the replica's forward VALUES at the rounding points become the kernel's, so that both sides
+    differentiate at the same point (same ReLU gates) and what is left between the two gradients is backward arithmetic."""
     if getattr(tower, 'input_batch_norm', False):        # keras/layers.py:57-60: BatchNormalization on the raw features
         mean = x.mean(0); var = x.var(0, unbiased=False)
         x = (x - mean) * torch.rsqrt(var + 1e-3) * tower.gamma_in + tower.beta_in
-    a = _ste(x)
+    a = _ste(x) if pin is None else _pin(x, pin[0][:, :x.shape[1]])
     n_h = len(tower.hidden_layer_dims)
     for l in range(n_h):
         z32 = a @ _ste(tower.weights[l]).t() + tower.biases[l]
-        z = _ste(z32)
+        z = _ste(z32) if pin is None else _pin(z32, pin[1][l])
         if tower.use_batch_norm:
             mean = z32.mean(0); var = z32.var(0, unbiased=False)
             y = (z - mean) * torch.rsqrt(var + 1e-3) * tower.gammas[l] + tower.betas[l]
@@ -396,8 +403,22 @@ def test_fused_tower_input_gradient(M, F, hidden, O, act, bn, in_bn, gather):
     tower.train()
     xa = x.clone().requires_grad_(True)
     got = tower(xa, row_index=rows)
+    pin = (got.grad_fn.x0, list(got.grad_fn.zs))            # the kernel forward's bf16 layer input and pre-activations
     got.backward(up)
     g_params = [p.grad.clone() for p in tower.parameters()]
+    tower.zero_grad()
+    # (1) the replica differentiated at the KERNEL's forward point: what is left is backward arithmetic (bf16 dz / dx with
+    # stochastic rounding, MFMA summation order).  VERDICT r4 next #8: the bar is 3 x the spread of two such backward
+    # passes with independent rounding seeds (0.6-1.1 % of max|dx| on these cases), not the 10 % of the free-running
+    # comparison below, whose single-entry errors are ReLU gates that fall differently after one-ulp differences of a
+    # recomputed forward (two bf16 forwards with independent rounding differ by 10-26 % in this norm).
+    xp = x.clone().requires_grad_(True)
+    ref_tower(xp if rows is None else xp.index_select(0, rows.long()), tower, pin=pin).backward(up)
+    rel_p = (xa.grad - xp.grad).norm().item() / xp.grad.norm().item()
+    err_p = (xa.grad - xp.grad).abs().max().item() / xp.grad.abs().max().item()
+    record_margin('fused tower d loss / d features, forward pinned: ||dx - dx_ref|| / ||dx_ref||', rel_p, 1e-2)
+    record_margin('fused tower d loss / d features, forward pinned: max-norm / max|dx_ref|', err_p, 2e-2)
+    assert rel_p <= 1e-2 and err_p <= 2e-2, (rel_p, err_p)   # measured 4.8e-3 / 5.4e-3 (free-running below: 1.3e-2 / 8.3e-2)
     tower.zero_grad()
     xb = x.clone().requires_grad_(True)
     want = ref_tower(xb if rows is None else xb.index_select(0, rows.long()), tower)
