@@ -218,7 +218,7 @@ int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* l
 int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                          const float* pos_weight, const float* list_scale, int B, int L,
                          float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
-                         uint32_t* ticket, void* workspace, long workspace_bytes, void* stream);
+                         uint32_t* ticket, uint32_t tie_seed, void* workspace, long workspace_bytes, void* stream);
 int tfr_unique_softmax_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                const float* list_scale, int B, int L, float temperature,
                                float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
@@ -250,11 +250,13 @@ int tfr_approx_mrr_f32(const float* logits, const float* labels, const uint8_t* 
  *   loss_out     [B] negative log likelihood per list (the list weight is 1)
  *   dlogits_out  nullable [B, L] = list_scale_b * d loss_b / d logits[b, :]
  * One wavefront per list up to 1024 items, one workgroup beyond; workspace (TFR_WS_LIST_MLE) above
- * TFR_LDS_LIST_SIZE_LISTWISE.  Ties between equal labels keep index order. */
+ * TFR_LDS_LIST_SIZE_LISTWISE.  tie_seed: the reference sorts with shuffle_ties=True (:1558-1561, utils.py:84-112) -- equal
+ * labels in a random order, new in every step; tie_seed != 0 orders them by a counter-based 15-bit hash of (tie_seed,
+ * list, item) (then by index), tie_seed == 0 keeps index order. */
 int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                      const float* pos_weight, const float* list_scale, int B, int L,
-                     float temperature, float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes,
-                     void* stream);
+                     float temperature, float* loss_out, float* dlogits_out, uint32_t tie_seed, void* workspace,
+                     long workspace_bytes, void* stream);
 
 /* losses_impl.UniqueSoftmaxLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:1250-1281): loss_b = sum_i (2^l_i - 1) (log(e^s_i + sum_{j: l_j < l_i} e^s_j) - s_i).

@@ -47,7 +47,7 @@ _SIGNATURES = {
                            + [ctypes.c_void_p] * 5),
     'tfr_list_workspace_bytes': (ctypes.c_long, [ctypes.c_int] * 2),
     'tfr_list_mle_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                         + [ctypes.c_void_p] * 2 + _WS),
+                         + [ctypes.c_void_p] * 2 + [ctypes.c_uint32] + _WS),
     'tfr_unique_softmax_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                + [ctypes.c_void_p] * 2 + _WS),
     'tfr_metric_list_weights_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
@@ -135,7 +135,7 @@ _SIGNATURES = {
                                   + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 9),
     'tfr_list_mle_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
-                             + [ctypes.c_void_p] * 4 + _WS),
+                             + [ctypes.c_void_p] * 4 + [ctypes.c_uint32] + _WS),
     'tfr_unique_softmax_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                    + [ctypes.c_void_p] * 4 + _WS),
     'tfr_pointwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2

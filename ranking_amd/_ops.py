@@ -443,10 +443,26 @@ def approx_mrr(logits, labels, mask=None, list_scale=None, temperature=0.1, want
     return loss, weight, dlogits
 
 
+def tie_keys(tie_seed: int, B: int, L: int, device=None) -> torch.Tensor:
+    """The [B, L] 15-bit tie keys the kernels derive from a tie seed (csrc/common.h tie_key15; smaller sorts first
+    among equal scores, then the index): torch restatement for tests / debugging."""
+    if not tie_seed:
+        return torch.zeros((B, L), dtype=torch.int64, device=device)
+    m32 = 0xffffffff
+    b = torch.arange(B, dtype=torch.int64, device=device).unsqueeze(1)
+    i = torch.arange(L, dtype=torch.int64, device=device).unsqueeze(0)
+    h = (b * 0x9E3779B1 + i * 0x85EBCA77 + (int(tie_seed) & m32)) & m32
+    h = h ^ (h >> 16); h = (h * 0x7feb352d) & m32
+    h = h ^ (h >> 15); h = (h * 0x846ca68b) & m32
+    h = h ^ (h >> 16)
+    return h >> 17
+
+
 def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temperature=1.0, want_grad=True,
-             want_sum=False):
+             want_sum=False, tie_seed=0):
     """want_sum=True (here and in the other losses below): one more result, the 0-d reduced scalar of the launch
-    (sum_b loss_b * list_scale_b) from the `*_sum_f32` entry point -- no reduction launch."""
+    (sum_b loss_b * list_scale_b) from the `*_sum_f32` entry point -- no reduction launch.  tie_seed != 0: equal labels
+    in the hashed order of `tie_keys` (the reference's shuffle_ties), 0: index order."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); list_scale = _f32(list_scale, 'list_scale'); pos_weight = _f32(pos_weight, 'pos_weight')
@@ -458,11 +474,12 @@ def list_mle(logits, labels, mask=None, pos_weight=None, list_scale=None, temper
         total, ticket = _sum_outputs(logits.device)
         rc = _lib.load().tfr_list_mle_sum_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
                                               B, L, float(temperature), _ptr(loss), _ptr(dlogits), _ptr(total),
-                                              _ptr(ticket), _ptr(ws), ws_bytes, _stream())
+                                              _ptr(ticket), int(tie_seed) & 0xffffffff, _ptr(ws), ws_bytes, _stream())
         _lib.check(rc, 'tfr_list_mle_sum_f32')
         return loss, dlogits, total
     rc = _lib.load().tfr_list_mle_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(pos_weight), _ptr(list_scale),
-                                      B, L, float(temperature), _ptr(loss), _ptr(dlogits), _ptr(ws), ws_bytes, _stream())
+                                      B, L, float(temperature), _ptr(loss), _ptr(dlogits), int(tie_seed) & 0xffffffff,
+                                      _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_list_mle_f32')
     return loss, dlogits
 
@@ -710,4 +727,4 @@ def _guard_module(namespace, module_name, skip=()):
             namespace[name] = device_guarded(obj)
 
 
-_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded', 'order_cache'))
+_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded', 'order_cache', 'tie_keys'))

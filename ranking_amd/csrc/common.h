@@ -134,6 +134,17 @@ __device__ __forceinline__ uint64_t make_sort_key(bool valid, float score, int t
 }
 __device__ __forceinline__ int sort_key_index(uint64_t key) { return 0xffff - (int)(key & 0xffffull); }
 
+// Random tie order (utils.py:84-112 _get_shuffle_indices: the reference permutes a list at random before its stable sort,
+// so equal keys come out in a uniformly random order): a 15-bit counter-based hash of (seed, list, item) for the
+// `tiebreak` field of make_sort_key -- the smaller value sorts first among equal scores, the index decides the (2^-15)
+// collisions.  seed 0 = no shuffle (index order).  Restated in ranking_amd/_ops.py tie_keys for the tests.
+__device__ __forceinline__ int tie_key15(uint32_t seed, uint32_t b, uint32_t i) {
+  if (seed == 0u) return 0;
+  uint32_t h = b * 0x9E3779B1u + i * 0x85EBCA77u + seed;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return (int)(h >> 17);
+}
+
 // 2^l - 1 (keras/utils.py:79-92): exact for integer grades (the hardware exp2 is
 // only 1-ulp accurate, which would break bit-exact NDCG on integer labels).
 __device__ __forceinline__ float gain_pow2m1(float l) {

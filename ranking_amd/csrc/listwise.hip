@@ -2,8 +2,9 @@
 //
 // Reference behaviour restated (losses_impl.py:1541-1576 ListMLELoss, :457-480
 // ListMLELambdaWeight): masked labels := 0, masked logits := log(1e-10); items sorted by label
-// (descending; the reference shuffles ties with a fixed op seed -- here ties keep index order,
-// "parity unpinned" like every tie rule); with s the sorted logits,
+// (descending; the reference shuffles ties at random, op seed 37 under the graph seed -- `tie_seed` != 0 orders equal
+// labels by a counter-based hash of (tie_seed, list, item), 0 keeps index order; the TF random stream itself is not
+// reproducible: "parity unpinned" like every tie rule); with s the sorted logits,
 //     loss = sum_p w_p * ( log sum_{q >= p} exp(s_q) - s_p ),   w_p = rank_discount(p + 1) or 1.
 // Backward (autodiff in the reference):  d loss / d s_p = exp(s_p) * sum_{q <= p} w_q / S_q - w_p.
 //
@@ -22,7 +23,7 @@ template <int IPL>
 __global__ __launch_bounds__(64) void list_mle_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int L, float temperature,
-    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum) {
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum, const uint32_t tie_seed) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* XS = reinterpret_cast<float*>(smem_raw);          // [64 * IPL] logits by original index
   const int lane = threadIdx.x, b = blockIdx.x;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(64) void list_mle_wave_kernel(
       const bool v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
       valid[r] = v;
       XS[i] = v ? logits[base + i] / temperature : kLogEps;
-      key[r] = make_sort_key(v, v ? lab : 0.0f, 0, i);          // valid first, label desc, then index
+      key[r] = make_sort_key(v, v ? lab : 0.0f, tie_key15(tie_seed, (uint32_t)b, (uint32_t)i), i);   // valid first, label desc, then the tie key, then index
     }
   }
   __syncthreads();
@@ -451,7 +452,8 @@ template <bool BIG>
 __global__ __launch_bounds__(1024) void list_mle_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ pos_weight, const float* __restrict__ list_scale, int B, int L, int P, float temperature,
-    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum, float* __restrict__ ws) {
+    float* __restrict__ loss_out, float* __restrict__ dlogits_out, const GridSum sum, float* __restrict__ ws,
+    const uint32_t tie_seed) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);               // [32]
   uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);  // [P]
@@ -470,7 +472,7 @@ __global__ __launch_bounds__(1024) void list_mle_block_kernel(
       const float lab = labels[base + i];
       const bool v = mask ? (mask[base + i] != 0) : (lab >= 0.0f);
       x = v ? logits[base + i] / temperature : kLogEps;
-      k = make_sort_key(v, v ? lab : 0.0f, 0, i);                 // valid first, label desc, then index
+      k = make_sort_key(v, v ? lab : 0.0f, tie_key15(tie_seed, (uint32_t)b, (uint32_t)i), i);   // valid first, label desc, tie key, index
     }
     keys[i] = k; XS[i] = x;
   }
@@ -723,7 +725,7 @@ extern "C" long tfr_list_workspace_bytes(int op, int L) {
 static int list_mle_dispatch(const float* logits, const float* labels, const uint8_t* mask,
                              const float* pos_weight, const float* list_scale, int B, int L,
                              float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out, uint32_t* ticket,
-                             void* workspace, long workspace_bytes, void* stream) {
+                             uint32_t tie_seed, void* workspace, long workspace_bytes, void* stream) {
   if (!logits || !labels || !loss_out || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
   const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_LIST_MLE, L);      // > 0: the per-position arrays outgrow LDS
@@ -738,10 +740,10 @@ static int list_mle_dispatch(const float* logits, const float* labels, const uin
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(slot ? big_slots(B, (size_t)workspace_bytes, slot) : B), dim3(1024), lds, st, logits, labels, mask,
-                       pos_weight, list_scale, B, L, P, temperature, loss_out, dlogits_out, sum, (float*)workspace);
+                       pos_weight, list_scale, B, L, P, temperature, loss_out, dlogits_out, sum, (float*)workspace, tie_seed);
     return (int)hipGetLastError();
   }
-#define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out, sum)
+#define LM(I) hipLaunchKernelGGL(list_mle_wave_kernel<I>, dim3(B), dim3(64), (size_t)64 * I * sizeof(float), st, logits, labels, mask, pos_weight, list_scale, L, temperature, loss_out, dlogits_out, sum, tie_seed)
   if (L <= 64) LM(1); else if (L <= 128) LM(2); else if (L <= 256) LM(4); else if (L <= 512) LM(8); else LM(16);
 #undef LM
   return (int)hipGetLastError();
@@ -749,19 +751,19 @@ static int list_mle_dispatch(const float* logits, const float* labels, const uin
 
 extern "C" int tfr_list_mle_f32(const float* logits, const float* labels, const uint8_t* mask,
                                 const float* pos_weight, const float* list_scale, int B, int L,
-                                float temperature, float* loss_out, float* dlogits_out, void* workspace, long workspace_bytes,
-                                void* stream) {
+                                float temperature, float* loss_out, float* dlogits_out, uint32_t tie_seed, void* workspace,
+                                long workspace_bytes, void* stream) {
   return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out, nullptr,
-                           nullptr, workspace, workspace_bytes, stream);
+                           nullptr, tie_seed, workspace, workspace_bytes, stream);
 }
 
 extern "C" int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                                     const float* pos_weight, const float* list_scale, int B, int L,
                                     float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
-                                    uint32_t* ticket, void* workspace, long workspace_bytes, void* stream) {
+                                    uint32_t* ticket, uint32_t tie_seed, void* workspace, long workspace_bytes, void* stream) {
   if (!loss_sum_out || !ticket) return TFR_EINVAL;
   return list_mle_dispatch(logits, labels, mask, pos_weight, list_scale, B, L, temperature, loss_out, dlogits_out,
-                           loss_sum_out, ticket, workspace, workspace_bytes, stream);
+                           loss_sum_out, ticket, tie_seed, workspace, workspace_bytes, stream);
 }
 
 static int unique_softmax_dispatch(const float* logits, const float* labels, const uint8_t* mask,

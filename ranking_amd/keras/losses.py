@@ -569,12 +569,20 @@ class UniqueSoftmaxLoss(ApproxNDCGLoss):
 
 @utils.register_keras_serializable()
 class ListMLELoss(ApproxNDCGLoss):
-    """keras/losses.py:1013-1091."""
+    """keras/losses.py:1013-1091.  ``shuffle_ties`` / ``seed`` (not in the reference signature): see
+    ``losses_impl.ListMLELoss`` -- equal labels in a new random order per call by default, as the reference sorts them."""
 
-    def __init__(self, reduction=Reduction.AUTO, name=None, lambda_weight=None, temperature=1.0, ragged=False):
+    def __init__(self, reduction=Reduction.AUTO, name=None, lambda_weight=None, temperature=1.0, ragged=False,
+                 shuffle_ties=True, seed=None):
         _ListwiseLoss.__init__(self, reduction, name, lambda_weight, temperature, ragged)
         self._loss = losses_impl.ListMLELoss(name='{}_impl'.format(name) if name else None,
                                              lambda_weight=lambda_weight, temperature=temperature, ragged=ragged)
+        self._loss.shuffle_ties, self._loss.seed = bool(shuffle_ties), seed
+
+    def get_config(self):
+        config = super().get_config()
+        config.update({'shuffle_ties': self._loss.shuffle_ties, 'seed': self._loss.seed})
+        return config
 
     def loss_and_grad(self, y_true, y_pred, sample_weight=None):
         if self.reduction == Reduction.NONE:
@@ -588,11 +596,13 @@ class ListMLELoss(ApproxNDCGLoss):
         else:
             list_scale = _const_vector(b, scale * float(sw), y_pred.device)
         pw = self._loss._pos_weight(y_pred.shape[1], y_pred.device)
+        tie_seed = self._loss._tie_seed()
         if not _LOSS_SUM_ALL:
-            loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True)
+            loss, dlogits = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True,
+                                          tie_seed=tie_seed)
             return _ops.list_dot(loss, list_scale), dlogits
         _, dlogits, total = _ops.list_mle(y_pred.detach(), y_true, mask, pw, list_scale, self._temperature, True,
-                                          want_sum=True)
+                                          want_sum=True, tie_seed=tie_seed)
         return total, dlogits
 
 

@@ -593,9 +593,33 @@ class ListMLELambdaWeight(_LambdaWeight):
         return torch.ones_like(labels) * self._rank_discount_fn(ranks.to(torch.float32))
 
 
+_tie_rng = [None, None]                    # (generator, the torch.initial_seed() it was derived from)
+
+
+def _fresh_tie_seed() -> int:
+    """A new non-zero 31-bit tie seed per call, from a host generator derived from torch.initial_seed(): the sequence
+    is reproducible after torch.manual_seed, the role TF's graph-level seed plays for the op seed 37 of
+    losses_impl.py:1558-1561.  (A host draw: under hipGraph capture the seed of the captured step is replayed.)"""
+    base = torch.initial_seed()
+    if _tie_rng[0] is None or _tie_rng[1] != base:
+        _tie_rng[0] = torch.Generator().manual_seed((base ^ 37) & 0x7fffffffffffffff)
+        _tie_rng[1] = base
+    return int(torch.randint(1, 2 ** 31 - 1, (1,), generator=_tie_rng[0]).item())
+
+
 class ListMLELoss(_ListwiseLoss):
-    """losses_impl.py:1541-1576; fused kernel tfr_list_mle_f32 (ties between equal labels keep index
-    order; the reference shuffles them with a fixed op seed)."""
+    """losses_impl.py:1541-1576; fused kernel tfr_list_mle_f32.  Equal labels: the reference sorts with
+    shuffle_ties=True (:1558-1561) -- a new random order of the tied items in every step; here ``shuffle_ties`` (default
+    True) orders them by a counter-based hash of a tie seed, list and item (``seed``: None = a new seed per call, an int =
+    the same order in every call); ``shuffle_ties=False`` keeps index order.  The TF random stream is not reproducible."""
+
+    shuffle_ties = True
+    seed = None
+
+    def _tie_seed(self):
+        if not self.shuffle_ties:
+            return 0
+        return _fresh_tie_seed() if self.seed is None else (int(self.seed) & 0x7fffffff) or 1
 
     def _pos_weight(self, list_size, device):
         if isinstance(self._lambda_weight, ListMLELambdaWeight):
@@ -604,9 +628,10 @@ class ListMLELoss(_ListwiseLoss):
 
     def _unreduced(self, labels, logits, mask, temperature):
         pw = self._pos_weight(logits.shape[1], logits.device)
+        tie_seed = self._tie_seed()
 
         def runner(lg, want_grad):
-            loss, d = _ops.list_mle(lg, labels, mask, pw, None, temperature, want_grad)
+            loss, d = _ops.list_mle(lg, labels, mask, pw, None, temperature, want_grad, tie_seed=tie_seed)
             return loss, d, ()
         (loss,) = _PerListLossFn.apply(logits, runner)
         return loss.unsqueeze(1), torch.ones_like(loss).unsqueeze(1)

@@ -1196,11 +1196,56 @@ def test_list_mle_reference_goldens_and_keras():
     assert abs(got.item() + (ln(3. / 4) + ln(1. / 1))) < 1e-5                                    # :1318-1328
     k = K.get('list_mle_loss')
     assert abs(k(t([[1., 0.]]), t([[0.6, 0.8]])).item() - 0.7981389) < 1e-6                      # keras/losses.py:1032-1036
+    assert k.get_config()['shuffle_ties'] is True and k.get_config()['seed'] is None
+    k = K.get('list_mle_loss', seed=11)                   # graded labels tie: one fixed tie order for the two calls below
     lb, lg = make_batch(6, 30, seed=4)
     v, d = k.loss_and_grad(lb.to(DEV), lg.to(DEV))
     lgd = lg.to(DEV).requires_grad_(True)
     out = k(lb.to(DEV), lgd); out.backward()
     assert abs(v.item() - out.item()) < 1e-5 and torch.allclose(d, lgd.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,L', [(5, 7), (40, 130), (3, 1500), (2, 5000)])      # wave kernel, workgroup kernel, workspace form
+def test_list_mle_shuffles_tied_labels_like_the_reference(B, L):
+    """losses_impl.py:1558-1561 sorts with shuffle_ties=True: equal labels in a random order, new in every step.  The
+    kernel orders them by the 15-bit hash of (tie seed, list, item) that `_ops.tie_keys` restates: the oracle, fed labels
+    made distinct in exactly that order, must give the kernel's loss and gradient; seed 0 is index order; the loss
+    classes draw a new seed per call (reproducible after torch.manual_seed) unless a seed is fixed."""
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=2100 + L)       # graded labels 0..4: long tie groups
+    if B >= 3:
+        labels[1] = -1.0
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    oracle = R.ListMLELoss()
+    outs = {}
+    for seed in (0, 12345, 99):
+        keys = _ops.tie_keys(seed, B, L)
+        # the kernel's order: label descending, then the tie key ascending, then the index -> distinct pseudo-labels
+        idx = torch.arange(L).unsqueeze(0).expand(B, L)
+        comp = labels.double() * 2.0 ** 32 - keys.double() * 2.0 ** 16 - idx.double()
+        order = torch.argsort(torch.where(labels >= 0, comp, torch.full_like(comp, -1e30)), dim=1, descending=True)
+        pseudo = torch.empty_like(labels)
+        pseudo.scatter_(1, order, torch.arange(L, 0, -1, dtype=labels.dtype).unsqueeze(0).expand(B, L).contiguous())
+        pseudo = torch.where(labels >= 0, pseudo, labels)
+        want, want_g = _oracle_grad(lambda x: oracle._compute_unreduced_loss_impl(pseudo, x)[0], logits)
+        loss, d = _ops.list_mle(lg, lb, tie_seed=seed)
+        scale = max(1.0, want.abs().max().item())
+        assert_loss_close(loss / scale, want.reshape(-1) / scale, what='list_mle loss, tie seed %d' % seed)
+        assert_grad_close(d, want_g, what='list_mle grad, tie seed %d' % seed)
+        outs[seed] = loss
+    if L >= 100:
+        assert not torch.equal(outs[0], outs[12345]) and not torch.equal(outs[12345], outs[99])
+    Limpl = ra().losses_impl
+    red = Limpl.Reduction.SUM
+    fixed = Limpl.ListMLELoss(None); fixed.seed = 7
+    assert fixed.compute(lb, lg, None, red).item() == fixed.compute(lb, lg, None, red).item()
+    plain = Limpl.ListMLELoss(None); plain.shuffle_ties = False
+    assert abs(plain.compute(lb, lg, None, red).item() - outs[0].sum().item()) <= 1e-5 * abs(outs[0].sum().item())
+    fresh = Limpl.ListMLELoss(None)
+    if L >= 100:
+        torch.manual_seed(1); a1, a2 = fresh.compute(lb, lg, None, red).item(), fresh.compute(lb, lg, None, red).item()
+        torch.manual_seed(1); b1 = fresh.compute(lb, lg, None, red).item()
+        assert a1 != a2 and a1 == b1
 
 
 # ------------------------------------------------------------------ longest-first launch order

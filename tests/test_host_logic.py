@@ -53,10 +53,10 @@ def test_invalid_arguments_are_rejected_before_any_launch():
                                          None, None, None, None, None) == -1       # lambda kind
     assert lib.tfr_list_order_i32(None, None, 4, 8, one, one, None) == -1
     # beyond the LDS range a list needs a workspace slot (tfr_list_workspace_bytes): absent / short -> TFR_ETOOLARGE
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, None, 0, None) == -2
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, one, 16 * 8192 - 1, None) == -2
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 9000, 1.0, one, None, one, 1 << 30, None) == -2
-    assert lib.tfr_list_mle_f32(one, one, None, None, None, 0, 5000, 1.0, one, None, one, 16 * 8192, None) == 0    # B == 0
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, 0, None, 0, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 5000, 1.0, one, None, 7, one, 16 * 8192 - 1, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 1, 9000, 1.0, one, None, 0, one, 1 << 30, None) == -2
+    assert lib.tfr_list_mle_f32(one, one, None, None, None, 0, 5000, 1.0, one, None, 0, one, 16 * 8192, None) == 0    # B == 0
     assert lib.tfr_circle_loss_f32(one, one, None, None, 1, 5000, 64.0, 0.25, 1, one, None, None, None, 0, None) == -2
     assert lib.tfr_unique_softmax_f32(one, one, None, None, 1, 5000, 1.0, one, None, None, 0, None) == -2
     assert lib.tfr_neural_sort_loss_f32(0, one, one, None, one, None, 1, 2049, 1.0, one, None, None, 0, None) == -2
@@ -90,7 +90,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
                                         None, None, one, one, None) == -1
     assert lib.tfr_pairwise_loss_sum_f32(0, one, one, None, None, None, 0, 0, 0.0, 0, 0, None, None, 1, 8, 1.0,
                                          None, None, None, None, None, None, one, one, None) == -1     # no list_loss_out
-    assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, None, 0, None) == -1
+    assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, 0, None, 0, None) == -1
     assert lib.tfr_unique_softmax_sum_f32(one, one, None, None, 1, 8, 1.0, one, None, None, one, None, 0, None) == -1
     assert lib.tfr_pointwise_loss_sum_f32(0, one, one, None, None, None, 1, 8, 1.0, one, None, None, None, None, one,
                                           None) == -1
