@@ -593,18 +593,11 @@ class ListMLELambdaWeight(_LambdaWeight):
         return torch.ones_like(labels) * self._rank_discount_fn(ranks.to(torch.float32))
 
 
-_tie_rng = [None, None]                    # (generator, the torch.initial_seed() it was derived from)
-
-
 def _fresh_tie_seed() -> int:
-    """A new non-zero 31-bit tie seed per call, from a host generator derived from torch.initial_seed(): the sequence
-    is reproducible after torch.manual_seed, the role TF's graph-level seed plays for the op seed 37 of
-    losses_impl.py:1558-1561.  (A host draw: under hipGraph capture the seed of the captured step is replayed.)"""
-    base = torch.initial_seed()
-    if _tie_rng[0] is None or _tie_rng[1] != base:
-        _tie_rng[0] = torch.Generator().manual_seed((base ^ 37) & 0x7fffffffffffffff)
-        _tie_rng[1] = base
-    return int(torch.randint(1, 2 ** 31 - 1, (1,), generator=_tie_rng[0]).item())
+    """A new non-zero 31-bit tie seed per call from torch's default host generator: the sequence restarts with
+    torch.manual_seed, the role TF's graph-level seed plays for the op seed 37 of losses_impl.py:1558-1561.  (A host
+    draw: under hipGraph capture the seed of the captured step is replayed.)"""
+    return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
 
 
 class ListMLELoss(_ListwiseLoss):
