@@ -631,11 +631,15 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
     int bl = gg * S + seg;
     bl = bl < B ? bl : B - 1;                              // an absent list of the last group re-reads the last list
     wl_n[d] = LW ? a.item_weights[(uint32_t)bl] : 1.0f;
-    const uint32_t row = (uint32_t)bl * (uint32_t)L;       // (B L < 2^30, checked by the launcher: uniform base + 32-bit offset)
+    // (B L < 2^30, checked by the launcher: the BYTE offset of an item fits 32 bits, so an access is the uniform base
+    // pointer + a 32-bit lane offset -- `global_load_dword v, v_off, s[base:base+1]` -- instead of a 64-bit address per
+    // lane and item: 16 v_lshl_add_u64 + their moves per group of lists were address arithmetic)
+    const uint32_t row = (uint32_t)bl * (uint32_t)L;
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
-      const float* pl = a.labels + (row + (uint32_t)off[r]);
-      const float* px = a.logits + (row + (uint32_t)off[r]);
+      const uint32_t boff = (row + (uint32_t)off[r]) * 4u;
+      const float* pl = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.labels) + boff);
+      const float* px = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.logits) + boff);
       lab_n[d][r] = NT ? __builtin_nontemporal_load(pl) : *pl;
       x_n[d][r] = NT ? __builtin_nontemporal_load(px) : *px;
     }
@@ -675,25 +679,30 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
       e[r] = in[r] ? __builtin_amdgcn_exp2f((z[r] - zmax) * 1.44269504088896340736f) : 0.0f;
       esum += e[r];
     }
-    psum = sg(psum);
+    // (every list of the wavefront has a positive label sum -- the common case: the normalised labels ARE the labels, their
+    // sum is lsum, bit for bit: one segmented reduction less)
+    psum = __ballot(!nonzero) ? sg(psum) : lsum;
     esum = sg(esum);
     // single-instruction log / reciprocals (1 ulp each: the loss and the gradient stay within a few 1e-7 of the fp64
     // arbiter; the libm logf and two IEEE divisions were ~35 of the ~300 vector instructions of a group)
     const float lse = __builtin_amdgcn_logf(esum) * 0.69314718055994530942f;
     const float inv_p = (psum != 0.0f) ? __builtin_amdgcn_rcpf(psum) : 0.0f;      // divide_no_nan
     const float inv_e = __builtin_amdgcn_rcpf(esum);
-    float loss = 0.f, ptot = 0.f, pt = 0.f;
+    float loss = 0.f, pt = 0.f;
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
       const float p = y[r] * inv_p;
       loss += in[r] ? p * (lse - (z[r] - zmax)) : 0.0f;
-      ptot += p;
-      pt += p * (e[r] * inv_e);
       y[r] = p;
     }
     loss = sg(loss);
-    ptot = sg(ptot);
-    if (a.poly_eps != 0.0f) {
+    // sum_i p_i: 1 for a list with a valid item (its labels were normalised by their sum, or replaced by a uniform
+    // 1e-10), 0 for a list without one -- in exact arithmetic; the per-list kernels add the p_i up (1 +- 1e-7).  The packed
+    // form takes the exact value: one accumulation per item and one segmented reduction less.
+    const float ptot = (psum != 0.0f) ? 1.0f : 0.0f;
+    if (a.poly_eps != 0.0f) {                                // (uniform; PolyOneSoftmax only)
+#pragma unroll
+      for (int r = 0; r < IPL; ++r) pt += y[r] * (e[r] * inv_e);
       pt = sg(pt);
       loss += a.poly_eps * (1.0f - pt);
     }
@@ -705,7 +714,7 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
       if (a.poly_eps != 0.0f) dd -= a.poly_eps * sm * (y[r] - pt);
       const float gv = mv[r] ? (lsum * inv_t) * dd : 0.0f;
       if (have && in[r]) {
-        float* pd = a.dlogits + ((uint32_t)b * (uint32_t)L + (uint32_t)off[r]);
+        float* pd = reinterpret_cast<float*>(reinterpret_cast<char*>(a.dlogits) + ((uint32_t)b * (uint32_t)L + (uint32_t)off[r]) * 4u);
         if (NT) __builtin_nontemporal_store(gv, pd); else *pd = gv;
       }
     }
