@@ -100,12 +100,16 @@ int tfr_sort_ranks_f32(const float* scores, const float* labels, const uint8_t* 
  *   stats_out    [B, 3] = (sum w, sum gain, sum w*gain) in tree_sum order; the
  *                cross-list part of _per_example_weights_to_per_list_weights
  *                (metrics_impl.py:63-119) is done by the caller on [B] vectors.
+ *   tie_seed     (every metric entry point) the reference sorts the predictions with shuffle_ties=True
+ *                (utils.py:84-164): equal predictions in a random order.  tie_seed != 0 orders them by a counter-based
+ *                15-bit hash of (tie_seed, list, item), then by index (NDCG then runs on its sort kernel instead of the
+ *                counting / bucket forms); tie_seed == 0 keeps index order.
  * NDCG and MRR (below): list_size <= 8192 (TFR_MAX_LIST_SIZE) -- one wavefront per list up to 512 / 256 items, one
  * workgroup with 16 B of LDS per item beyond. */
 int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const float* weights,
                         int weights_per_list, const uint8_t* mask, const float* gains,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
-                        float* ndcg_out, float* stats_out, void* stream);
+                        float* ndcg_out, float* stats_out, uint32_t tie_seed, void* stream);
 
 /* The sort-based metrics of metrics_impl.py behind one entry point; `kind`:
  *   TFR_METRIC_NDCG / TFR_METRIC_MRR  = the two entry points above;
@@ -130,7 +134,8 @@ int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const flo
 int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                         int weights_per_list, const uint8_t* mask, const float* gains,
                         const float* discount, const int32_t* topn_host, int K, int B, int L,
-                        float* metric_out, float* stats_out, void* workspace, long workspace_bytes, void* stream);
+                        float* metric_out, float* stats_out, uint32_t tie_seed, void* workspace, long workspace_bytes,
+                        void* stream);
 
 /* Diversity metrics on subtopic labels [B, L, S] (metrics_impl.py:313-426, :746-822).
  *   TFR_DIV_ALPHA_DCG    AlphaDCGMetric: metric_out[q*B+b] = sum_{p<k} w gain discount, gain = sum_s y_ps (1-alpha)^{cum_s};
@@ -143,7 +148,7 @@ int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions,
 int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                        int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
                        const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
-                       float* stats_out, void* workspace, long workspace_bytes, void* stream);
+                       float* stats_out, uint32_t tie_seed, void* workspace, long workspace_bytes, void* stream);
 
 /* Per-list metric weights [B] from the stats_out [B, 3] of the metric entry points above
  * (metrics_impl.py:63-119 _per_example_weights_to_per_list_weights): sum(w rel)/sum(rel); lists without
@@ -154,7 +159,7 @@ int tfr_metric_list_weights_f32(const float* stats, int B, float* weights_out, v
  *   mrr_out [K, B]; stats_out [B, 3] = (sum w, sum rel, sum w*rel), rel = 1{l>=1}. */
 int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,
                        int weights_per_list, const uint8_t* mask, const int32_t* topn_host,
-                       int K, int B, int L, float* mrr_out, float* stats_out, void* stream);
+                       int K, int B, int L, float* mrr_out, float* stats_out, uint32_t tie_seed, void* stream);
 
 /* losses_impl.ApproxNDCGLoss._compute_unreduced_loss_impl fused with its
  * backward (losses_impl.py:77-167, 1579-1603).

@@ -32,11 +32,14 @@ _SIGNATURES = {
     'tfr_hip_abi_version': (ctypes.c_int, []),
     'tfr_sort_ranks_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
     'tfr_ndcg_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
-                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+                            + [ctypes.c_uint32, ctypes.c_void_p]),
     'tfr_rank_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p] * 3
-                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2 + _WS),
+                            + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+                            + [ctypes.c_uint32] + _WS),
     'tfr_mrr_metric_f32': (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int] + [ctypes.c_void_p]
-                           + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3),
+                           + [ctypes.POINTER(ctypes.c_int32)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
+                           + [ctypes.c_uint32, ctypes.c_void_p]),
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                             + [ctypes.c_int] + [ctypes.c_void_p] * 5),
     'tfr_list_order_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
@@ -53,7 +56,7 @@ _SIGNATURES = {
     'tfr_metric_list_weights_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_div_metric_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int]
                            + [ctypes.c_void_p] * 2 + [ctypes.c_float] + [ctypes.c_void_p] + [ctypes.c_int] * 4
-                           + [ctypes.c_void_p] * 2 + _WS),
+                           + [ctypes.c_void_p] * 2 + [ctypes.c_uint32] + _WS),
     'tfr_pointwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                                + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_circle_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float] * 2

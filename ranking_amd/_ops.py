@@ -175,7 +175,9 @@ def _weights_arg(weights, labels):
                      % (tuple(weights.shape), (B, L)))
 
 
-def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns):
+def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns, tie_seed=0):
+    """tie_seed (here and in the other metric ops): 0 = equal predictions in index order; != 0 = in the hashed order of
+    `tie_keys` (the reference's shuffle_ties; NDCG then runs on its sort kernel)."""
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
     w, per_list = _weights_arg(weights, labels)
@@ -186,7 +188,7 @@ def ndcg_metric(labels, predictions, weights, mask, gains, discount, topns):
     stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
     rc = _lib.load().tfr_ndcg_metric_f32(_ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
                                          _ptr(gains), _ptr(discount), _topn_array(topns), K, B, L,
-                                         _ptr(out), _ptr(stats), _stream())
+                                         _ptr(out), _ptr(stats), int(tie_seed) & 0xffffffff, _stream())
     _lib.check(rc, 'tfr_ndcg_metric_f32')
     return out, stats
 
@@ -210,7 +212,7 @@ def _workspace(op, B, L, device):
     return torch.empty((n,), dtype=torch.uint8, device=device), n
 
 
-def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, discount=None):
+def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, discount=None, tie_seed=0):
     """tfr_rank_metric_f32: ([K, B] metric, [B, 3] stats) for any sort-based metric kind."""
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
@@ -223,7 +225,7 @@ def rank_metric(kind, labels, predictions, weights, mask, topns, gains=None, dis
     ws, ws_bytes = (None, 0) if kind in (METRIC_NDCG, METRIC_MRR) else _workspace(WS_RANK_METRIC, B, L, labels.device)
     rc = _lib.load().tfr_rank_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
                                          _ptr(gains), _ptr(discount), _topn_array(topns), K, B, L,
-                                         _ptr(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
+                                         _ptr(out), _ptr(stats), int(tie_seed) & 0xffffffff, _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_rank_metric_f32')
     return out, stats
 
@@ -241,7 +243,7 @@ def metric_list_weights(stats):
 DIV_ALPHA_DCG, DIV_PRECISION_IA = 0, 1
 
 
-def div_metric(kind, labels, predictions, weights, mask, topns, discount=None, alpha=0.5):
+def div_metric(kind, labels, predictions, weights, mask, topns, discount=None, alpha=0.5, tie_seed=0):
     """tfr_div_metric_f32: ([K, B] metric, [B, 3] stats) on subtopic labels [B, L, S]."""
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions')
@@ -257,12 +259,12 @@ def div_metric(kind, labels, predictions, weights, mask, topns, discount=None, a
     ws, ws_bytes = _workspace(WS_DIV_METRIC, B, L, labels.device)
     rc = _lib.load().tfr_div_metric_f32(int(kind), _ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
                                         _ptr(discount), float(alpha), _topn_array(topns), K, B, L, S,
-                                        _ptr(out), _ptr(stats), _ptr(ws), ws_bytes, _stream())
+                                        _ptr(out), _ptr(stats), int(tie_seed) & 0xffffffff, _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, 'tfr_div_metric_f32')
     return out, stats
 
 
-def mrr_metric(labels, predictions, weights, mask, topns):
+def mrr_metric(labels, predictions, weights, mask, topns, tie_seed=0):
     labels = _f32(labels, 'labels'); predictions = _f32(predictions, 'predictions')
     _check2d(predictions, 'predictions'); _same_shape(labels, predictions, 'labels', 'predictions')
     w, per_list = _weights_arg(weights, labels)
@@ -272,7 +274,8 @@ def mrr_metric(labels, predictions, weights, mask, topns):
     out = torch.empty((K, B), dtype=torch.float32, device=labels.device)
     stats = torch.empty((B, 3), dtype=torch.float32, device=labels.device)
     rc = _lib.load().tfr_mrr_metric_f32(_ptr(labels), _ptr(predictions), _ptr(w), per_list, _ptr(mask),
-                                        _topn_array(topns), K, B, L, _ptr(out), _ptr(stats), _stream())
+                                        _topn_array(topns), K, B, L, _ptr(out), _ptr(stats), int(tie_seed) & 0xffffffff,
+                                        _stream())
     _lib.check(rc, 'tfr_mrr_metric_f32')
     return out, stats
 

@@ -14,7 +14,7 @@ using namespace tfr;
 
 namespace {
 
-struct TopN { int k[TFR_MAX_TOPN]; int n; };
+struct TopN { int k[TFR_MAX_TOPN]; int n; uint32_t tie_seed; };      // tie_seed: 0 = equal predictions in index order, else hashed (common.h tie_key15)
 
 __device__ __forceinline__ bool item_valid(const float* labels, const uint8_t* mask, size_t off) {
   if (mask) return mask[off] != 0;
@@ -97,7 +97,7 @@ __global__ void rank_metric_kernel(const float* __restrict__ labels, const float
   // ---- sort by prediction (masked entries last): utils.py:115-164.
   for (int i = threadIdx.x; i < P; i += blockDim.x) {
     float w, g; bool m; item(i, w, g, m);
-    keys[i] = (i < L) ? make_sort_key(m, predictions[base + i], 0, i) : 0ull;
+    keys[i] = (i < L) ? make_sort_key(m, predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i) : 0ull;
     if (KIND == 1) WG[i] = g;                                  // MRR asks for the relevance of the sorted items
   }
   block_bitonic_sort_desc(keys, P);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64) void rank_metric_wave_kernel(
       const float labc = m[r] ? lab : 0.0f;
       if (KIND == 0) g[r] = gains ? gains[base + i] : gain_pow2m1(labc);
       else g[r] = (labc >= 1.0f) ? 1.0f : 0.0f;
-      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+      key[r] = make_sort_key(m[r], predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i);
     }
     wg[r] = w[r] * g[r];
     WG[i] = (KIND == 0) ? wg[r] : g[r];
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(64) void rank_metric2_wave_kernel(
       if (kind == TFR_METRIC_DCG) g[r] = gains ? gains[base + i] : gain_pow2m1(labc);
       else if (kind == TFR_METRIC_ARP || kind == TFR_METRIC_PWA) g[r] = labc;
       else g[r] = (labc >= 1.0f) ? 1.0f : 0.0f;
-      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+      key[r] = make_sort_key(m[r], predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i);
     }
     wg[r] = w[r] * g[r];
     WG[i] = wg[r];
@@ -923,7 +923,7 @@ __global__ __launch_bounds__(64) void div_metric_wave_kernel(
       for (int t = 0; t < S; ++t) { const float y = lab[t]; any_valid |= (y >= 0.0f); any_rel |= (y >= 1.0f); }
       m[r] = mask ? (mask[base + i] != 0) : any_valid;        // :354-358 (a rank-3 mask is reduced by the caller)
       g[r] = (m[r] && any_rel) ? 1.0f : 0.0f;
-      key[r] = make_sort_key(m[r], predictions[base + i], 0, i);
+      key[r] = make_sort_key(m[r], predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i);
     }
     nmask += __popcll(__ballot(m[r]));
   }
@@ -1069,7 +1069,7 @@ __global__ void rank_metric2_block_kernel(
       if (kind == TFR_METRIC_DCG) g = gains ? gains[base + i] : gain_pow2m1(labc);
       else if (kind == TFR_METRIC_ARP || kind == TFR_METRIC_PWA) g = labc;
       else g = (labc >= 1.0f) ? 1.0f : 0.0f;
-      key = make_sort_key(m, predictions[base + i], 0, i);
+      key = make_sort_key(m, predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i);
     }
     W[i] = w; G[i] = g; keys[i] = key;
     nm += m ? 1.0f : 0.0f;
@@ -1223,7 +1223,7 @@ __global__ void div_metric_block_kernel(
       for (int t = 0; t < S; ++t) { const float y = lab[t]; any_valid |= (y >= 0.0f); any_rel |= (y >= 1.0f); }
       const bool m = mask ? (mask[base + i] != 0) : any_valid;
       g = (m && any_rel) ? 1.0f : 0.0f;
-      key = make_sort_key(m, predictions[base + i], 0, i);
+      key = make_sort_key(m, predictions[base + i], tie_key15(topn.tie_seed, (uint32_t)b, (uint32_t)i), i);
       nm += m ? 1.0f : 0.0f;
     }
     W[i] = w; G[i] = g; keys[i] = key;
@@ -1343,7 +1343,8 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
                         int L, int P, float* metric_out, float* stats_out, hipStream_t st) {
   static const int env_count = [] { const char* e = getenv("TFR_NDCG_COUNT"); return (e && *e) ? atoi(e) : 1; }();
   static const int env_lean = [] { const char* e = getenv("TFR_NDCG_LEAN"); return (e && *e) ? atoi(e) : 1; }();
-  if (KIND == 0 && IPL <= 4 && env_lean && env_count && !gains && !mask && (!weights || weights_per_list)) {
+  // (a tie seed -- equal predictions in a hashed order -- goes through the sort kernel below: its key has the tie field)
+  if (KIND == 0 && IPL <= 4 && env_lean && env_count && !gains && !mask && (!weights || weights_per_list) && !tn.tie_seed) {
     // the lean form (round 5): cut-offs <= 16 packed four to a launch pass, the rest through full tree sums
     NdcgCut cut;
     cut.small_k = 0u; cut.small_q = 0u; cut.n_large = 0;
@@ -1367,7 +1368,7 @@ void launch_metric_wave(const float* labels, const float* predictions, const flo
                        discount, cut, B, L, P, metric_out, stats_out);
     return;
   }
-  if (KIND == 0 && env_count && !gains) {          // NDCG with the built-in gain: ranks by counting, no register sort
+  if (KIND == 0 && env_count && !gains && !tn.tie_seed) {          // NDCG with the built-in gain: ranks by counting, no register sort
     constexpr size_t lds = (size_t)64 * IPL * 6 * sizeof(float) + 8 * sizeof(float);
     static const int env_bucket = [] { const char* e = getenv("TFR_NDCG_BUCKET"); return (e && *e) ? atoi(e) : 1; }();
     if (env_bucket) {
@@ -1554,13 +1555,13 @@ extern "C" int tfr_sort_ranks_f32(const float* scores, const float* labels, cons
 static int launch_metric(int kind, const float* labels, const float* predictions, const float* weights,
                          int weights_per_list, const uint8_t* mask, const float* gains,
                          const float* discount, const int32_t* topn_host, int K, int B, int L,
-                         float* metric_out, float* stats_out, void* stream) {
+                         float* metric_out, float* stats_out, uint32_t tie_seed, void* stream) {
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
   if (kind == 0 && !discount) return TFR_EINVAL;
   if (L > TFR_MAX_LIST_SIZE) return TFR_ETOOLARGE;            // NDCG / MRR: 16 B of LDS per item in the workgroup kernel
   if (B == 0) return TFR_OK;
-  TopN tn; tn.n = K;
+  TopN tn; tn.n = K; tn.tie_seed = tie_seed;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   static const int env_wave = [] { const char* e = getenv("TFR_SORT_WAVE"); return (e && *e) ? atoi(e) : 1; }();
@@ -1593,26 +1594,26 @@ static int launch_metric(int kind, const float* labels, const float* predictions
 extern "C" int tfr_ndcg_metric_f32(const float* labels, const float* predictions, const float* weights,
                                    int weights_per_list, const uint8_t* mask, const float* gains,
                                    const float* discount, const int32_t* topn_host, int K, int B,
-                                   int L, float* ndcg_out, float* stats_out, void* stream) {
+                                   int L, float* ndcg_out, float* stats_out, uint32_t tie_seed, void* stream) {
   return launch_metric(0, labels, predictions, weights, weights_per_list, mask, gains, discount,
-                       topn_host, K, B, L, ndcg_out, stats_out, stream);
+                       topn_host, K, B, L, ndcg_out, stats_out, tie_seed, stream);
 }
 
 extern "C" int tfr_mrr_metric_f32(const float* labels, const float* predictions, const float* weights,
                                   int weights_per_list, const uint8_t* mask, const int32_t* topn_host,
-                                  int K, int B, int L, float* mrr_out, float* stats_out, void* stream) {
+                                  int K, int B, int L, float* mrr_out, float* stats_out, uint32_t tie_seed, void* stream) {
   return launch_metric(1, labels, predictions, weights, weights_per_list, mask, nullptr, nullptr,
-                       topn_host, K, B, L, mrr_out, stats_out, stream);
+                       topn_host, K, B, L, mrr_out, stats_out, tie_seed, stream);
 }
 
 extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                                    int weights_per_list, const uint8_t* mask, const float* gains,
                                    const float* discount, const int32_t* topn_host, int K, int B, int L,
-                                   float* metric_out, float* stats_out, void* workspace, long workspace_bytes,
-                                   void* stream) {
+                                   float* metric_out, float* stats_out, uint32_t tie_seed, void* workspace,
+                                   long workspace_bytes, void* stream) {
   if (kind == TFR_METRIC_NDCG || kind == TFR_METRIC_MRR)
     return launch_metric(kind, labels, predictions, weights, weights_per_list, mask, gains, discount, topn_host, K,
-                         B, L, metric_out, stats_out, stream);
+                         B, L, metric_out, stats_out, tie_seed, stream);
   if (kind < TFR_METRIC_DCG || kind > TFR_METRIC_OPA) return TFR_EINVAL;
   if (kind == TFR_METRIC_OPA && K != 1) return TFR_EINVAL;
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0) return TFR_EINVAL;
@@ -1622,7 +1623,7 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
   const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_RANK_METRIC, L);   // > 0: 32 B per item outgrow LDS
   if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
-  TopN tn; tn.n = K;
+  TopN tn; tn.n = K; tn.tie_seed = tie_seed;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;
@@ -1647,7 +1648,7 @@ extern "C" int tfr_rank_metric_f32(int kind, const float* labels, const float* p
 extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* predictions, const float* weights,
                                   int weights_per_list, const uint8_t* mask, const float* discount, float alpha,
                                   const int32_t* topn_host, int K, int B, int L, int S, float* metric_out,
-                                  float* stats_out, void* workspace, long workspace_bytes, void* stream) {
+                                  float* stats_out, uint32_t tie_seed, void* workspace, long workspace_bytes, void* stream) {
   if (kind != TFR_DIV_ALPHA_DCG && kind != TFR_DIV_PRECISION_IA) return TFR_EINVAL;
   if (!labels || !predictions || !metric_out || !stats_out || B < 0 || L <= 0 || S <= 0) return TFR_EINVAL;
   if (K < 1 || K > TFR_MAX_TOPN || !topn_host) return TFR_EINVAL;
@@ -1656,7 +1657,7 @@ extern "C" int tfr_div_metric_f32(int kind, const float* labels, const float* pr
   const size_t slot = (size_t)tfr_list_workspace_bytes(TFR_WS_DIV_METRIC, L);    // > 0: 28 B per item outgrow LDS
   if (slot && (!workspace || workspace_bytes < (long)slot)) return TFR_ETOOLARGE;
   if (B == 0) return TFR_OK;
-  TopN tn; tn.n = K;
+  TopN tn; tn.n = K; tn.tie_seed = tie_seed;
   for (int q = 0; q < TFR_MAX_TOPN; ++q) tn.k[q] = (q < K) ? topn_host[q] : 0;
   const int P = pow2_ceil(L < 2 ? 2 : L);
   hipStream_t st = (hipStream_t)stream;

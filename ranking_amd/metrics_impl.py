@@ -53,10 +53,24 @@ def per_list_weights_from_stats(stats):
 
 
 class _RankingMetric(object, metaclass=abc.ABCMeta):
-    """metrics_impl.py:210-310."""
+    """metrics_impl.py:210-310.  Equal predictions: the reference sorts with ``shuffle_ties=True`` (utils.py:115-164, a
+    random order of the tied items in every call); here ties keep index order unless ``shuffle_ties`` is set on the
+    metric object -- then they are ordered by a counter-based hash of a tie seed, list and item (``seed``: None = a new
+    seed per call from torch's host generator, an int = the same order in every call).  NDCG with ``shuffle_ties`` runs
+    on the sort kernel instead of the counting forms."""
+
+    shuffle_ties = False
+    seed = None
 
     def __init__(self, ragged=False):
         self._ragged = ragged
+
+    def _tie_seed(self):
+        if not self.shuffle_ties:
+            return 0
+        if self.seed is None:
+            return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+        return (int(self.seed) & 0x7fffffff) or 1
 
     @property
     @abc.abstractmethod
@@ -120,7 +134,7 @@ class MRRMetric(_RankingMetric):
         return self._name
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
-        out, stats = _ops.mrr_metric(labels, predictions, weights, mask, topns)
+        out, stats = _ops.mrr_metric(labels, predictions, weights, mask, topns, tie_seed=self._tie_seed())
         return out, per_list_weights_from_stats(stats)
 
 
@@ -149,7 +163,8 @@ class NDCGMetric(_RankingMetric):
                     weights if weights.dim() == 2 else weights.reshape(-1, 1), labels.shape) > 0)
             gains = self._gain_fn(torch.where(m, labels, torch.zeros_like(labels))).to(torch.float32)
         discount = _ops.rank_table(self._rank_discount_fn, labels.shape[1], labels.device)
-        out, stats = _ops.ndcg_metric(labels, predictions, weights, mask, gains, discount, topns)
+        out, stats = _ops.ndcg_metric(labels, predictions, weights, mask, gains, discount, topns,
+                                      tie_seed=self._tie_seed())
         return out, per_list_weights_from_stats(stats)
 
 
@@ -167,7 +182,7 @@ class _KindMetric(_RankingMetric):
         return self._name
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
-        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns)
+        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns, tie_seed=self._tie_seed())
         return out, per_list_weights_from_stats(stats)
 
 
@@ -199,7 +214,7 @@ class ARPMetric(_KindMetric):
         super().__init__(name, None, ragged=ragged)
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
-        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, [None])
+        out, stats = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, [None], tie_seed=self._tie_seed())
         return out, stats[:, 2:3]
 
 
@@ -239,7 +254,7 @@ class PWAMetric(_KindMetric):
         return super().compute(labels, predictions, weights, mask)
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
-        out, _ = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns)
+        out, _ = _ops.rank_metric(self._KIND, labels, predictions, weights, mask, topns, tie_seed=self._tie_seed())
         b = labels.shape[0]
         if weights is None:
             w = torch.ones((b, 1), dtype=torch.float32, device=labels.device)
@@ -293,23 +308,26 @@ class PrecisionIAMetric(_DivRankingMetric):
     """metrics_impl.py:746-782."""
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
-        out, stats = _ops.div_metric(_ops.DIV_PRECISION_IA, labels, predictions, weights, mask, topns)
+        out, stats = _ops.div_metric(_ops.DIV_PRECISION_IA, labels, predictions, weights, mask, topns,
+                                     tie_seed=self._tie_seed())
         return out, per_list_weights_from_stats(stats)
 
 
 class AlphaDCGMetric(_DivRankingMetric):
-    """metrics_impl.py:785-822 (``seed`` only shuffles ties in the reference; ties keep index order here)."""
+    """metrics_impl.py:785-822 (``seed``: the reference's op seed of the tie shuffle; used here when ``shuffle_ties`` is
+    set on the object, see ``_RankingMetric``)."""
 
     def __init__(self, name, topn, alpha=0.5, rank_discount_fn=_DEFAULT_RANK_DISCOUNT_FN, seed=None, ragged=False):
         super().__init__(name, topn, ragged=ragged)
         self._alpha = alpha
         self._rank_discount_fn = rank_discount_fn
         self._seed = seed
+        self.seed = seed
 
     def _compute_multi(self, labels, predictions, weights, mask, topns):
         discount = _ops.rank_table(self._rank_discount_fn, predictions.shape[1], predictions.device)
         out, stats = _ops.div_metric(_ops.DIV_ALPHA_DCG, labels, predictions, weights, mask, topns, discount,
-                                     self._alpha)
+                                     self._alpha, tie_seed=self._tie_seed())
         plw = per_list_weights_from_stats(stats)
         return _safe_div(out, plw.reshape(1, -1)), plw
 
@@ -326,6 +344,7 @@ class DCGMetric(NDCGMetric):
                     weights if weights.dim() == 2 else weights.reshape(-1, 1), labels.shape) > 0)
             gains = self._gain_fn(torch.where(m, labels, torch.zeros_like(labels))).to(torch.float32)
         discount = _ops.rank_table(self._rank_discount_fn, labels.shape[1], labels.device)
-        out, stats = _ops.rank_metric(_ops.METRIC_DCG, labels, predictions, weights, mask, topns, gains, discount)
+        out, stats = _ops.rank_metric(_ops.METRIC_DCG, labels, predictions, weights, mask, topns, gains, discount,
+                                      tie_seed=self._tie_seed())
         plw = per_list_weights_from_stats(stats)
         return _safe_div(out, plw.reshape(1, -1)), plw

@@ -1131,6 +1131,50 @@ def test_more_metrics_bit_exact(B, L, weighted):
         assert_loss_close(got, want, 1e-6, 'opa'); assert_loss_close(got_w / max(1., want_w.max().item()), want_w / max(1., want_w.max().item()), 1e-6, 'opa weights')
 
 
+@pytest.mark.parametrize('B,L', [(6, 9), (40, 130), (1100, 200), (3, 700), (2, 5000)])   # wave / lean-eligible / workgroup / workspace forms
+def test_metrics_shuffle_tied_predictions_like_the_reference(B, L):
+    """The reference metrics sort predictions with shuffle_ties=True (utils.py:115-164): tied predictions in a random order.
+    With `shuffle_ties` set on a metric object the kernels order ties by the 15-bit hash `_ops.tie_keys` restates: the
+    oracle, fed predictions made distinct in exactly that order, must give the same numbers (bit for bit where the untied
+    comparison is bit-exact); without it ties keep index order; a fixed seed reproduces, a fresh one does not."""
+    from ranking_amd import _ops
+    g = torch.Generator().manual_seed(3100 + L)
+    labels, _ = make_batch(B, L, seed=3100 + L)
+    preds = torch.randint(0, 4, (B, L), generator=g).float() * 0.5          # four distinct scores: long tie groups
+    mi = ra().metrics_impl
+    d = lambda x: x.to(DEV)
+    topns = [1, 5, None]
+    seed = 4242
+    keys = _ops.tie_keys(seed, B, L)
+    # order of the kernel: prediction descending, tie key ascending, index ascending -> distinct stand-in predictions
+    idx = torch.arange(L).unsqueeze(0).expand(B, L)
+    comp = preds.double() * 2.0 ** 40 - keys.double() * 2.0 ** 16 - idx.double()
+    order = torch.argsort(comp, dim=1, descending=True)
+    stand_in = torch.empty_like(preds)
+    stand_in.scatter_(1, order, torch.arange(L, 0, -1, dtype=preds.dtype).unsqueeze(0).expand(B, L).contiguous())
+    for name in ('NDCGMetric', 'MRRMetric', 'PrecisionMetric', 'MeanAveragePrecisionMetric', 'DCGMetric'):
+        m = getattr(mi, name)(None, None)
+        m.shuffle_ties, m.seed = True, seed
+        got, _ = m.compute_multi(d(labels), d(preds), None, None, topns)
+        plain, _ = getattr(mi, name)(None, None).compute_multi(d(labels), d(preds), None, None, topns)
+        for q, k in enumerate(topns):
+            want, _ = getattr(R, name)(topn=k).compute(labels, stand_in, None)
+            assert torch.equal(got[q].cpu(), want.reshape(-1)), '%s@%s with tie seed: max diff %g' % (
+                name, k, (got[q].cpu() - want.reshape(-1)).abs().max())
+            want0, _ = getattr(R, name)(topn=k).compute(labels, preds, None)          # the oracle's own rule: index order
+            assert torch.equal(plain[q].cpu(), want0.reshape(-1)), '%s@%s index order' % (name, k)
+        again, _ = m.compute_multi(d(labels), d(preds), None, None, topns)
+        assert torch.equal(got, again)
+        if B * L >= 5000:
+            m.seed = None
+            fresh, _ = m.compute_multi(d(labels), d(preds), None, None, topns)
+            assert not torch.equal(got, fresh)
+    m = mi.ARPMetric(None); m.shuffle_ties, m.seed = True, seed
+    got, _ = m.compute(d(labels), d(preds), None)
+    want, _ = R.ARPMetric().compute(labels, stand_in, None)
+    assert torch.equal(got.cpu(), want)
+
+
 def test_more_metrics_keras_and_factory_keys():
     km = ra().keras.metrics
     t = lambda x: torch.tensor(x, device=DEV)

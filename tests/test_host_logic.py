@@ -62,15 +62,15 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.tfr_neural_sort_loss_f32(0, one, one, None, one, None, 1, 2049, 1.0, one, None, None, 0, None) == -2
     assert lib.tfr_neural_sort_loss_f32(1, one, one, None, None, None, 0, 2049, 1.0, one, None, one, 52 * 4096, None) == 0
     one_topn = (ctypes.c_int32 * 1)(1)
-    assert lib.tfr_rank_metric_f32(3, one, one, None, 0, None, None, one, one_topn, 1, 1, 5000, one, one, None, 0, None) == -2
-    assert lib.tfr_div_metric_f32(1, one, one, None, 0, None, None, 0.5, one_topn, 1, 1, 5000, 2, one, one, None, 0, None) == -2
+    assert lib.tfr_rank_metric_f32(3, one, one, None, 0, None, None, one, one_topn, 1, 1, 5000, one, one, 0, None, 0, None) == -2
+    assert lib.tfr_div_metric_f32(1, one, one, None, 0, None, None, 0.5, one_topn, 1, 1, 5000, 2, one, one, 9, None, 0, None) == -2
     ws = lib.tfr_list_workspace_bytes
     assert [ws(op, 4096) for op in range(5)] == [0] * 5 and ws(5, 2048) == 0 and ws(6, 2048) == 0
     assert [ws(op, 4097) for op in range(7)] == [16 * 8192, 28 * 8192, 28 * 8192, 24 * 8192, 20 * 8192, 32 * 8192, 52 * 8192]
     assert ws(5, 2049) == 32 * 4096 and ws(6, 3000) == 52 * 4096 and ws(0, 8193) == 0 and ws(7, 5000) == 0
-    assert lib.tfr_rank_metric_f32(12, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, None, 0, None) == -1
+    assert lib.tfr_rank_metric_f32(12, one, one, None, 0, None, None, one, (ctypes.c_int32 * 1)(1), 1, 1, 8, one, one, 0, None, 0, None) == -1
     topn = (ctypes.c_int32 * 1)(10)
-    assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, None) == -1
+    assert lib.tfr_ndcg_metric_f32(one, one, None, 0, None, None, one, topn, 9, 1, 8, one, one, 0, None) == -1
     assert lib.tfr_gumbel_sample_f32(one, one, None, None, 0, 0, 1, 0, 8, 1.0, one, None) == -1
     # tower: the two-pass output-layer backward accepts exactly (dy, partial), (NULL, partial), (dy, NULL, pqr)
     ob = lambda dy, partial, pqr: lib.tfr_tower_out_bwd2(one, 8, 4, 8, 0, None, None, None, None, one, one, 1, dy, 8,
