@@ -1165,7 +1165,7 @@ def test_metrics_shuffle_tied_predictions_like_the_reference(B, L):
             assert torch.equal(plain[q].cpu(), want0.reshape(-1)), '%s@%s index order' % (name, k)
         again, _ = m.compute_multi(d(labels), d(preds), None, None, topns)
         assert torch.equal(got, again)
-        if B * L >= 5000:
+        if B * L >= 5000 and name == 'NDCGMetric':          # (MRR / Precision@1 of a few long lists can coincide)
             m.seed = None
             fresh, _ = m.compute_multi(d(labels), d(preds), None, None, topns)
             assert not torch.equal(got, fresh)
