@@ -219,7 +219,7 @@ int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* l
                               const float* discount, int B, int L, float temperature,
                               float* row_loss_out, float* row_weight_out, float* nnz_out,
                               float* dlogits_out, const int32_t* list_order, float* list_loss_out,
-                              float* loss_sum_out, uint32_t* ticket, void* stream);
+                              float* loss_sum_out, uint32_t* ticket, uint32_t tie_seed, void* stream);
 int tfr_list_mle_sum_f32(const float* logits, const float* labels, const uint8_t* mask,
                          const float* pos_weight, const float* list_scale, int B, int L,
                          float temperature, float* loss_out, float* dlogits_out, float* loss_sum_out,
@@ -335,14 +335,18 @@ int tfr_pairwise_logistic_f32(const float* logits, const float* labels, const ui
  * PairwiseLogisticLoss with a DCGLambdaWeight (smooth_fraction 0, no topn, identity / 2^l - 1 gain, no mask) and
  * list_size <= 256 runs the LambdaRank fast path: items re-homed by grade, only the pairs with l_i > l_j visited (from 512
  * lists: the group kernel of csrc/lambdarank_group.h -- several lists per workgroup, shared pair sweeps); any
- * list_size <= 8192 (TFR_MAX_LIST_SIZE) through the general wave / workgroup kernels. */
+ * list_size <= 8192 (TFR_MAX_LIST_SIZE) through the general wave / workgroup kernels.
+ * tie_seed: the ranks behind the lambda weights are `_compute_ranks(logits, shuffle_ties=True)` in the reference (:483-500):
+ * equal scores in a random order.  tie_seed != 0 ranks them by the 15-bit hash of (tie_seed, list, item) (then by index) --
+ * on the workgroup kernel, whatever the list size; tie_seed == 0 keeps index order and the fast paths. */
 int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
                           const float* item_weights, const float* list_weights,
                           int lambda_kind, int topn, float smooth_fraction, int normalized,
                           int gain_kind, const float* gains, const float* discount,
                           int B, int L, float temperature,
                           float* row_loss_out, float* row_weight_out, float* nnz_out,
-                          float* dlogits_out, const int32_t* list_order, float* list_loss_out, void* stream);
+                          float* dlogits_out, const int32_t* list_order, float* list_loss_out, uint32_t tie_seed,
+                          void* stream);
 
 /* losses_impl.SoftmaxLoss.precompute + _compute_unreduced_loss_impl fused with
  * the backward (losses_impl.py:1119-1197, 281-296).

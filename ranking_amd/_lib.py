@@ -68,7 +68,7 @@ _SIGNATURES = {
                                   + [ctypes.c_float] + [ctypes.c_void_p] * 5),
     'tfr_pairwise_loss_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                               + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
-                              + [ctypes.c_float] + [ctypes.c_void_p] * 7),
+                              + [ctypes.c_float] + [ctypes.c_void_p] * 6 + [ctypes.c_uint32, ctypes.c_void_p]),
     'tfr_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
                              + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 4),
     'tfr_poly1_softmax_loss_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 5 + [ctypes.c_void_p] * 2
@@ -136,7 +136,7 @@ _SIGNATURES = {
     'tfr_softmax_sum_contributors': (ctypes.c_int, [ctypes.c_int] * 6),
     'tfr_pairwise_loss_sum_f32': (ctypes.c_int, [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2
                                   + [ctypes.c_float] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2
-                                  + [ctypes.c_float] + [ctypes.c_void_p] * 9),
+                                  + [ctypes.c_float] + [ctypes.c_void_p] * 8 + [ctypes.c_uint32, ctypes.c_void_p]),
     'tfr_list_mle_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                              + [ctypes.c_void_p] * 4 + [ctypes.c_uint32] + _WS),
     'tfr_unique_softmax_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 2 + [ctypes.c_float]

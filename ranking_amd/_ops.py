@@ -579,10 +579,12 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
                       lambda_kind=LAMBDA_NONE, topn=0, smooth_fraction=0.0, normalized=False,
                       gain_kind=GAIN_IDENTITY, gains=None, discount=None, temperature=1.0,
                       want_grad=True, want_rows=True, want_aux=True, loss_kind=0, balance=None, want_list=False,
-                      want_sum=False):
+                      want_sum=False, tie_seed=0):
     """loss_kind: PAIR_LOGISTIC / PAIR_HINGE / PAIR_SOFT_ZERO_ONE.  want_aux=False skips the per-row weight sums and the non-zero pair counts (only the MEAN /
     SUM_BY_NONZERO_WEIGHTS reductions and compute_per_list need them): a leaner kernel variant.  want_list=True
-    returns the per-list loss sums [B] in place of the [B, L] row losses (5-tuple: rows, weights, nnz, dlogits, list)."""
+    returns the per-list loss sums [B] in place of the [B, L] row losses (5-tuple: rows, weights, nnz, dlogits, list).
+    tie_seed != 0: equal scores are ranked in the hashed order of `tie_keys` (the reference's _compute_ranks with
+    shuffle_ties) -- on the workgroup kernel, not the LambdaRank fast paths."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); item_weights = _f32(item_weights, 'item_weights')
@@ -602,14 +604,15 @@ def pairwise_logistic(logits, labels, mask=None, item_weights=None, list_weights
             int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
             _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
             _ptr(nnz), _ptr(dlogits), _ptr(_auto_order(labels, mask, balance, 128)), _ptr(list_loss), _ptr(total),
-            _ptr(ticket), _stream())
+            _ptr(ticket), int(tie_seed) & 0xffffffff, _stream())
         _lib.check(rc, 'tfr_pairwise_loss_sum_f32')
         return row_loss, row_weight, nnz, dlogits, list_loss, total
     rc = _lib.load().tfr_pairwise_loss_f32(
         int(loss_kind), _ptr(logits), _ptr(labels), _ptr(mask), _ptr(item_weights), _ptr(list_weights),
         int(lambda_kind), int(topn or 0), float(smooth_fraction), int(bool(normalized)), int(gain_kind),
         _ptr(gains), _ptr(discount), B, L, float(temperature), _ptr(row_loss), _ptr(row_weight),
-        _ptr(nnz), _ptr(dlogits), _ptr(_auto_order(labels, mask, balance, 128)), _ptr(list_loss), _stream())
+        _ptr(nnz), _ptr(dlogits), _ptr(_auto_order(labels, mask, balance, 128)), _ptr(list_loss),
+        int(tie_seed) & 0xffffffff, _stream())
     _lib.check(rc, 'tfr_pairwise_loss_f32')
     if want_list:
         return row_loss, row_weight, nnz, dlogits, list_loss

@@ -36,6 +36,7 @@ struct PwArgs {
   float* list_loss;                      // nullable [B]: sum of the row losses of a list
   const int* order;                      // longest-first launch order (nullable)
   GridSum sum;                           // round 5: sum_b list_loss[b] from the same launch (tfr_pairwise_loss_sum_f32); out == NULL: off
+  uint32_t tie_seed;                     // != 0: equal scores ranked in the hashed order of common.h tie_key15 (the workgroup kernel only)
 };
 
 __host__ __device__ inline size_t pw_wave_lds(int Lp) { return (size_t)Lp * (16 + 8 + 4 + 4 + 4) + 16; }
@@ -238,7 +239,7 @@ __global__ void pairwise_logistic_kernel(const PwArgs a) {
       float w = a.item_weights ? a.item_weights[base + i] : 1.0f;
       w = lv ? (w * lw) : 0.0f;                                  // :917-930
       Xr[i] = x; Gr[i] = g; Wr[i] = w; MV[i] = mv; LV[i] = lv;
-      key = make_sort_key(mv, x, 0, i);
+      key = make_sort_key(mv, x, tie_key15(a.tie_seed, (uint32_t)b, (uint32_t)i), i);
     }
     keys[i] = key;
   }
@@ -1124,7 +1125,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          const float* discount, int B, int L, float temperature,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
                                          float* dlogits_out, const int* order, float* list_loss_out, void* stream,
-                                         float* loss_sum_out = nullptr, uint32_t* ticket = nullptr) {
+                                         float* loss_sum_out = nullptr, uint32_t* ticket = nullptr, uint32_t tie_seed = 0u) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (loss_sum_out && (!list_loss_out || !ticket)) return TFR_EINVAL;       // the per-list sums are the entries that are added up
   if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_MSE) return TFR_EINVAL;
@@ -1153,8 +1154,11 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   static const int env_wave = env_int("TFR_PAIRWISE_WAVE", 1);
   const int C = env_lanes > 0 ? env_lanes : 2;
   if (C > 64 || (C & (C - 1))) return TFR_EINVAL;
-  if (env_wave && env_threads == 0 && L <= 256) {      // longer lists: workgroup-per-list kernel below
+  // (a tie seed -- _compute_ranks(shuffle_ties=True), :483-500: equal scores ranked in a random order -- goes to the
+  // workgroup kernel, whose ranks come from a key sort with a tie field; the wave kernels rank by counting, index order)
+  if (env_wave && env_threads == 0 && L <= 256 && tie_seed == 0u) {      // longer lists: workgroup-per-list kernel below
     PwArgs w;
+    w.tie_seed = 0u;
     w.logits = logits; w.labels = labels; w.mask = mask; w.item_weights = item_weights;
     w.list_weights = list_weights; w.lambda_kind = lambda_kind; w.lambda_sub = lambda_sub; w.topn = topn;
     w.smooth = smooth_fraction; w.normalized = normalized; w.gain_kind = gain_kind; w.gains = gains;
@@ -1176,6 +1180,7 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
   a.discount = discount; a.L = L; a.Lp = ((L + 3) / 4) * 4 + 4; a.P = pow2_ceil(L < 2 ? 2 : L);
   a.temperature = temperature; a.C = C; a.kind = kind; a.row_loss = row_loss_out; a.row_weight = row_weight_out;
   a.nnz = nnz_out; a.dlogits = dlogits_out; a.order = order; a.list_loss = list_loss_out; a.sum = gsum;
+  a.tie_seed = tie_seed;
   const size_t lds = pw_smem_bytes(a.Lp, a.P);
   if (lds > 160 * 1024) return TFR_ETOOLARGE;
   const bool generic = (lambda_kind == TFR_LAMBDA_DCG) &&
@@ -1218,10 +1223,11 @@ extern "C" int tfr_pairwise_loss_f32(int loss_kind, const float* logits, const f
                                      const float* discount, int B, int L, float temperature,
                                      float* row_loss_out, float* row_weight_out, float* nnz_out,
                                      float* dlogits_out, const int32_t* list_order, float* list_loss_out,
-                                     void* stream) {
+                                     uint32_t tie_seed, void* stream) {
   return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
-                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream);
+                           row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream,
+                           nullptr, nullptr, tie_seed);
 }
 
 extern "C" int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, const float* labels, const uint8_t* mask,
@@ -1231,12 +1237,12 @@ extern "C" int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, con
                                          const float* discount, int B, int L, float temperature,
                                          float* row_loss_out, float* row_weight_out, float* nnz_out,
                                          float* dlogits_out, const int32_t* list_order, float* list_loss_out,
-                                         float* loss_sum_out, uint32_t* ticket, void* stream) {
+                                         float* loss_sum_out, uint32_t* ticket, uint32_t tie_seed, void* stream) {
   if (!loss_sum_out || !ticket || !list_loss_out) return TFR_EINVAL;
   return pairwise_dispatch(loss_kind, logits, labels, mask, item_weights, list_weights, lambda_kind, topn,
                            smooth_fraction, normalized, gain_kind, gains, discount, B, L, temperature,
                            row_loss_out, row_weight_out, nnz_out, dlogits_out, list_order, list_loss_out, stream,
-                           loss_sum_out, ticket);
+                           loss_sum_out, ticket, tie_seed);
 }
 
 #ifdef TFR_PROFILE_STAMPS

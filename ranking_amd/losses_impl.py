@@ -415,9 +415,22 @@ class _RankingLoss(object, metaclass=abc.ABCMeta):
 
 # ------------------------------------------------------------------ pairwise
 class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
-    """losses_impl.py:863-930."""
+    """losses_impl.py:863-930.  Equal scores: the ranks behind a lambda weight are ``_compute_ranks(logits,
+    shuffle_ties=True)`` in the reference (:483-500, a random order of tied scores in every call); the fused kernels rank
+    ties by index unless ``shuffle_ties`` is set on the loss object -- then by a counter-based hash of a tie seed, list and
+    item (``seed``: None = a new seed per call from torch's host generator), on the general workgroup kernel instead of the
+    LambdaRank fast paths.  Only a lambda weight looks at ranks."""
 
     _fused_kind = None   # subclasses with a fused kernel set this
+    shuffle_ties = False
+    seed = None
+
+    def _tie_seed(self):
+        if not self.shuffle_ties or self._lambda_weight is None:
+            return 0
+        if self.seed is None:
+            return _fresh_tie_seed()
+        return (int(self.seed) & 0x7fffffff) or 1
 
     @abc.abstractmethod
     def _pairwise_loss(self, pairwise_logits):
@@ -452,11 +465,12 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
         elif weights is not None:
             list_w = torch.broadcast_to(weights.reshape(()), (b,)).contiguous()
         temperature = self._temperature if apply_temperature else 1.0
+        tie_seed = self._tie_seed()
 
         def runner(lg, want_grad):
             row_loss, row_weight, nnz, d = _ops.pairwise_logistic(
                 lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad,
-                want_aux=want_aux, loss_kind=self._fused_kind, **lam)
+                want_aux=want_aux, loss_kind=self._fused_kind, tie_seed=tie_seed, **lam)
             return row_loss.sum(dim=1), d, (row_loss, row_weight, nnz)
 
         return _PerListLossFn.apply(logits, runner)

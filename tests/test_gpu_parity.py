@@ -624,6 +624,54 @@ def test_pairwise_logistic_parity(B, L, lam_idx, wkind):
         assert_loss_close(got / scale, want / scale, what='pairwise compute %s' % red_mine)
 
 
+@pytest.mark.parametrize('B,L', [(5, 9), (40, 130), (520, 200), (3, 700)])       # wave / lean / LambdaRank group / workgroup ranges
+def test_pairwise_lambda_ranks_shuffle_tied_scores_like_the_reference(B, L, monkeypatch):
+    """The ranks behind a lambda weight are `_compute_ranks(logits, shuffle_ties=True)` in the reference (:483-500): equal
+    scores in a random order.  With `shuffle_ties` on the loss object the fused path ranks ties by the hash `_ops.tie_keys`
+    restates (on the workgroup kernel, whatever the list size): the oracle with exactly those ranks must give the same rows
+    and gradient; without it the result is the oracle's own (index order) and comes from the fast paths."""
+    from ranking_amd import _ops
+    labels, _ = make_batch(B, L, seed=3300 + L)
+    g = torch.Generator().manual_seed(3300 + L)
+    logits = torch.randint(-2, 3, (B, L), generator=g).float() * 0.5          # five distinct scores: long tie groups
+    K = ra().keras.losses
+    seed = 31337
+    keys = _ops.tie_keys(seed, B, L)
+    idx = torch.arange(L).unsqueeze(0).expand(B, L)
+
+    def hashed_ranks(lg, is_valid):
+        scores = torch.where(is_valid, lg.detach(), lg.detach().min(dim=1, keepdim=True).values - 1.0)
+        comp = scores.double() * 2.0 ** 40 - keys.double() * 2.0 ** 16 - idx.double()
+        comp = torch.where(is_valid, comp, comp - 2.0 ** 60)
+        order = torch.argsort(comp, dim=1, descending=True)
+        ranks = torch.empty_like(order)
+        ranks.scatter_(1, order, torch.arange(1, L + 1).unsqueeze(0).expand(B, L).contiguous())
+        return ranks.to(torch.int32)
+
+    def oracle_rows(lg):
+        oracle = R.PairwiseLogisticLoss(lambda_weight=R.NDCGLambdaWeight())
+        losses, w = oracle._compute_unreduced_loss_impl(labels, lg, labels >= 0)
+        return (losses * w).sum(dim=2)
+
+    plain_lg = logits.clone().requires_grad_(True)
+    want_plain = oracle_rows(plain_lg); want_plain.sum().backward()
+    monkeypatch.setattr(R, '_compute_ranks', hashed_ranks)
+    tied_lg = logits.clone().requires_grad_(True)
+    want_tied = oracle_rows(tied_lg); want_tied.sum().backward()
+    monkeypatch.undo()
+    for shuffle, want, want_g in ((False, want_plain, plain_lg.grad), (True, want_tied, tied_lg.grad)):
+        loss = ra().losses_impl.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
+        loss.shuffle_ties, loss.seed = shuffle, seed
+        lgd = logits.to(DEV).requires_grad_(True)
+        list_loss, row_loss, _, _ = loss._fused(labels.to(DEV), lgd, None, None)
+        scale = max(1.0, want.abs().max().item())
+        assert_loss_close(row_loss / scale, want.detach() / scale, what='pairwise rows, shuffle_ties=%s' % shuffle)
+        list_loss.sum().backward()
+        assert_grad_close(lgd.grad, want_g, what='pairwise grad, shuffle_ties=%s' % shuffle)
+    if L >= 100:
+        assert (want_tied.detach() - want_plain.detach()).abs().max().item() > 1e-4 * max(1.0, want_plain.abs().max().item())
+
+
 def test_pairwise_materialized_api_matches_fused():
     """compute_unreduced_loss ([B,L,L], torch device ops) agrees with the fused kernel."""
     labels, logits = make_batch(4, 33, seed=77)

@@ -89,7 +89,7 @@ def test_invalid_arguments_are_rejected_before_any_launch():
     assert lib.tfr_softmax_loss_sum_f32(one, one, None, None, 0, 0, 0, 0, 0, None, None, 1, 8, 1.0, 0.0, one, one,
                                         None, None, one, one, None) == -1
     assert lib.tfr_pairwise_loss_sum_f32(0, one, one, None, None, None, 0, 0, 0.0, 0, 0, None, None, 1, 8, 1.0,
-                                         None, None, None, None, None, None, one, one, None) == -1     # no list_loss_out
+                                         None, None, None, None, None, None, one, one, 0, None) == -1  # no list_loss_out
     assert lib.tfr_list_mle_sum_f32(one, one, None, None, None, 1, 8, 1.0, one, None, one, None, 0, None, 0, None) == -1
     assert lib.tfr_unique_softmax_sum_f32(one, one, None, None, 1, 8, 1.0, one, None, None, one, None, 0, None) == -1
     assert lib.tfr_pointwise_loss_sum_f32(0, one, one, None, None, None, 1, 8, 1.0, one, None, None, None, None, one,

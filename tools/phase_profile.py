@@ -142,11 +142,11 @@ def main_group():
     order = _ops.list_order(labels) if os.environ.get('ORDER', '1') != '0' else None
     f = lib.tfr_pairwise_loss_f32
     f.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_int] * 2 + \
-        [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 7
+        [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_float] + [ctypes.c_void_p] * 6 + [ctypes.c_uint32, ctypes.c_void_p]
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     call = lambda: f(0, logits.data_ptr(), labels.data_ptr(), None, None, lw.data_ptr(), 2, 0, 0.0, 1, 1, None,
                      disc.data_ptr(), B, L, 1.0, None, None, None, dl.data_ptr(),
-                     None if order is None else order.data_ptr(), lst.data_ptr(), st)
+                     None if order is None else order.data_ptr(), lst.data_ptr(), 0, st)
     for _ in range(3):
         rc = call()
     torch.cuda.synchronize()
