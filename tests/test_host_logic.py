@@ -506,3 +506,45 @@ def test_bucket_rank_algorithm_equals_the_counting_ranks():
         ranked += 1
         assert np.array_equal(got, reference(x)), (trial, n, kind)
     assert ranked > 150 and declined > 20                          # both outcomes are exercised
+
+
+def test_tie_seeds_of_losses_and_metrics_host_side():
+    """shuffle_ties / seed on the loss and metric objects (round 5): which tie seed a call hands to the kernels.  ListMLE
+    shuffles by default like the reference (losses_impl.py:1558-1561), metrics and pairwise losses on request; a fixed
+    seed repeats, a fresh one follows torch's host generator (torch.manual_seed restarts the sequence); 0 = index order."""
+    L, M, K = ra.losses_impl, ra.metrics_impl, ra.keras.losses
+    mle = L.ListMLELoss(None)
+    assert mle.shuffle_ties is True and mle.seed is None
+    torch.manual_seed(5); a, b = mle._tie_seed(), mle._tie_seed()
+    torch.manual_seed(5); c = mle._tie_seed()
+    assert a != 0 and b != 0 and a != b and a == c and 0 < a < 2 ** 31
+    mle.seed = 9
+    assert mle._tie_seed() == 9 == mle._tie_seed()
+    mle.seed = 0
+    assert mle._tie_seed() == 1                                   # a fixed seed is never the "no shuffle" value
+    mle.shuffle_ties = False
+    assert mle._tie_seed() == 0
+    k = K.get('list_mle_loss', seed=3, shuffle_ties=True)
+    cfg = k.get_config()
+    assert cfg['seed'] == 3 and cfg['shuffle_ties'] is True and k._loss._tie_seed() == 3
+    assert type(k).from_config(cfg)._loss.seed == 3
+    assert K.get('list_mle_loss', shuffle_ties=False)._loss._tie_seed() == 0
+    for m in (M.NDCGMetric(None, None), M.MRRMetric(None, None), M.PrecisionMetric(None, None), M.AlphaDCGMetric(None, None, seed=4)):
+        assert m._tie_seed() == 0                                 # default: index order (the fast NDCG kernels)
+        m.shuffle_ties = True
+        s1 = m._tie_seed()
+        assert s1 != 0 and (s1 == 4 if isinstance(m, M.AlphaDCGMetric) else True)
+        m.seed = 12
+        assert m._tie_seed() == 12
+    pw = L.PairwiseLogisticLoss(None, lambda_weight=K.NDCGLambdaWeight())
+    assert pw._tie_seed() == 0
+    pw.shuffle_ties, pw.seed = True, 21
+    assert pw._tie_seed() == 21
+    plain = L.PairwiseLogisticLoss(None)
+    plain.shuffle_ties = True
+    assert plain._tie_seed() == 0                                 # no lambda weight: no ranks, nothing to shuffle
+    from ranking_amd import _ops as ops
+    keys = ops.tie_keys(12345, 3, 50)
+    assert keys.shape == (3, 50) and int(keys.min()) >= 0 and int(keys.max()) < 2 ** 15
+    assert torch.equal(keys, ops.tie_keys(12345, 3, 50)) and not torch.equal(keys, ops.tie_keys(12346, 3, 50))
+    assert int(ops.tie_keys(0, 2, 4).abs().sum()) == 0
