@@ -273,9 +273,9 @@ int tfr_unique_softmax_f32(const float* logits, const float* labels, const uint8
 /* NeuralSort losses (losses_impl.py:1635-1673 NeuralSortCrossEntropyLoss, :1676-1713 NeuralSortNDCGLoss,
  * :1716-1801 neural_sort): per-list loss [B] and d loss / d logits [B, L] (x list_scale[b] when given),
  * no [L, L] tensor materialised.  inv_log1p[r] = 1 / log1p(r + 1), r < L (NDCG kind only).  One wavefront per list
- * (40 / 60 B of LDS per item) up to TFR_LDS_LIST_SIZE_NEURAL_SORT items; beyond, one workgroup per list with the row
- * statistics in the workspace (TFR_WS_NEURAL_SORT_NDCG / _CE).  The Gumbel variants are this kernel on the sampler's
- * expanded batch. */
+ * (40 / 60 B of LDS per item) up to 1024 items, one workgroup per list beyond: everything in LDS up to
+ * TFR_LDS_LIST_SIZE_NEURAL_SORT items, the row statistics in the workspace (TFR_WS_NEURAL_SORT_NDCG / _CE) above.  The
+ * Gumbel variants are this kernel on the sampler's expanded batch. */
 #define TFR_NEURAL_SORT_NDCG 0
 #define TFR_NEURAL_SORT_CE 1
 int tfr_neural_sort_loss_f32(int kind, const float* logits, const float* labels, const uint8_t* mask,

@@ -321,13 +321,19 @@ __global__ __launch_bounds__(64) void neural_sort_wave_kernel(
 // differently, so the two agree to rounding.  A launch has one workgroup per workspace slot.
 constexpr int NSB_T = 1024, NSB_IPL = 8, NSB_TILE = 512, HP = 4;
 
-template <int KIND>
+// LDSWS: list sizes up to 2048 (P <= 2048) keep that slot in LDS behind the tiles (32 / 52 B per item: 152 KB in all for the
+// CE kind) -- no workspace, and the form the launcher takes from 1025 items on: the one-wavefront kernel needs 40 / 60 B of LDS
+// per item, i.e. ONE wavefront per CU beyond 1024 items, where this form runs sixteen on the same list (measured at 16 lists:
+// 1.99 ms here at 2049 items against 3.82 ms there at 2048, profiles/r05_long_lists.txt).
+template <int KIND, bool LDSWS>
 __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int B, int L, int P, float temperature,
     float* __restrict__ loss_out, float* __restrict__ dlogits_out, unsigned char* __restrict__ ws, long slot_bytes) {
   constexpr bool CE = (KIND == TFR_NEURAL_SORT_CE);
   constexpr int IPL = NSB_IPL;
+  constexpr int RM = LDSWS ? 2 : NSB_IPL;               // items a thread can own (P / NSB_T)
+  constexpr int HPc = LDSWS ? 2 : HP;                   // items of a thread per pass of phases A - C (P <= 2048: two per thread)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);                       // [32]
   float4* COL = reinterpret_cast<float4*>(smem_raw + 128);                // [P] (s, A, g | y, A^y), compact order
@@ -335,7 +341,8 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
   uint32_t* G32 = reinterpret_cast<uint32_t*>(COL);                       // [P] before that: the gains' bits (ideal DCG)
   float4* TILE = COL + P;                                                 // [NSB_TILE] rows of ROW / (s, Q) pairs
   float4* TILE2 = TILE + NSB_TILE;                                        // [NSB_TILE] rows of ROW2 (CE)
-  unsigned char* slot = ws + (size_t)blockIdx.x * (size_t)slot_bytes;
+  unsigned char* slot = LDSWS ? reinterpret_cast<unsigned char*>(TILE2 + NSB_TILE)
+                              : ws + (size_t)blockIdx.x * (size_t)slot_bytes;
   float* XS = reinterpret_cast<float*>(slot);                             // [P] score by original index
   float* YS = XS + P;                                                     // [P] label / gain by original index
   float* MS = YS + P;                                                     // [P] row maximum (scores)
@@ -420,15 +427,15 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
     __syncthreads();
 
     // ---- A. per item: A_k = sum_j |s_k - s_j| (and A^y_k), descending rank, closed-form row maxima.  (Phases A - C
-    // take a thread's 8 items in two halves of HP = 4: at 128 registers per thread the full set spilled 100-150 words.)
-    for (int h = 0; h < IPL / HP; ++h) {
-      if (NSB_T * HP * h >= n) break;                                    // (uniform)
-      float sk_[HP], gk[HP];
-      double accA[HP], accY[HP];
-      int cnt[HP], cnty[HP];
+    // take a thread's 8 items in two halves of HPc = 4: at 128 registers per thread the full set spilled 100-150 words.)
+    for (int h = 0; h < IPL / HPc; ++h) {
+      if (NSB_T * HPc * h >= n) break;                                    // (uniform)
+      float sk_[HPc], gk[HPc];
+      double accA[HPc], accY[HPc];
+      int cnt[HPc], cnty[HPc];
 #pragma unroll
-      for (int r = 0; r < HP; ++r) {
-        const int k = tid + NSB_T * (HP * h + r);
+      for (int r = 0; r < HPc; ++r) {
+        const int k = tid + NSB_T * (HPc * h + r);
         const float4 c = COL[k < n ? k : 0];
         sk_[r] = c.x; gk[r] = c.z;
         accA[r] = 0.0; accY[r] = 0.0; cnt[r] = 0; cnty[r] = 0;
@@ -436,8 +443,8 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
       for (int j = 0; j < n; ++j) {
         const float4 cj = COL[j];
 #pragma unroll
-        for (int r = 0; r < HP; ++r) {
-          const int k = tid + NSB_T * (HP * h + r);
+        for (int r = 0; r < HPc; ++r) {
+          const int k = tid + NSB_T * (HPc * h + r);
           accA[r] += (double)fabsf(sk_[r] - cj.x);
           cnt[r] += (cj.x > sk_[r] || (cj.x == sk_[r] && j < k)) ? 1 : 0;
           if (CE) {
@@ -448,8 +455,8 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
       }
       __syncthreads();                                                   // (the sweeps read .x / .z only; .y / .w change below)
 #pragma unroll
-      for (int r = 0; r < HP; ++r) {
-        const int k = tid + NSB_T * (HP * h + r);
+      for (int r = 0; r < HPc; ++r) {
+        const int k = tid + NSB_T * (HPc * h + r);
         if (k < n) {
           const float ak = (float)accA[r], ayk = CE ? (float)accY[r] : 0.f;
           COL[k] = make_float4(sk_[r], ak, gk[r], ayk);
@@ -462,32 +469,32 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
 
     // ---- B. per row t (threads = rows): Z_t and the row statistics.
     float part = 0.f;
-    for (int h = 0; h < IPL / HP; ++h) {
-      if (NSB_T * HP * h >= n) break;
-      float ct[HP], ms[HP], my[HP];
+    for (int h = 0; h < IPL / HPc; ++h) {
+      if (NSB_T * HPc * h >= n) break;
+      float ct[HPc], ms[HPc], my[HPc];
 #pragma unroll
-      for (int r = 0; r < HP; ++r) {
-        const int t = tid + NSB_T * (HP * h + r);
+      for (int r = 0; r < HPc; ++r) {
+        const int t = tid + NSB_T * (HPc * h + r);
         ct[r] = (t < n) ? (float)(n - 1 - 2 * t) : 0.f;
         ms[r] = (t < n) ? MS[t] : 0.f;
         my[r] = (CE && t < n) ? MY[t] : 0.f;
       }
       if (!CE) {
-        float Z[HP], N[HP];
+        float Z[HPc], N[HPc];
 #pragma unroll
-        for (int r = 0; r < HP; ++r) { Z[r] = 0.f; N[r] = 0.f; }
+        for (int r = 0; r < HPc; ++r) { Z[r] = 0.f; N[r] = 0.f; }
         for (int k = 0; k < n; ++k) {
           const float4 c = COL[k];
 #pragma unroll
-          for (int r = 0; r < HP; ++r) {
+          for (int r = 0; r < HPc; ++r) {
             const float e = ns_exp(__builtin_fmaf(ct[r], c.x, -c.y) - ms[r]);
             Z[r] += e;
             N[r] = __builtin_fmaf(e, c.z, N[r]);
           }
         }
 #pragma unroll
-        for (int r = 0; r < HP; ++r) {
-          const int t = tid + NSB_T * (HP * h + r);
+        for (int r = 0; r < HPc; ++r) {
+          const int t = tid + NSB_T * (HPc * h + r);
           if (t < n) {
             const float G = N[r] / Z[r];
             const float D = inv_log1p[t];
@@ -496,24 +503,24 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
           }
         }
       } else {
-        float Z[HP], ZY[HP];
+        float Z[HPc], ZY[HPc];
 #pragma unroll
-        for (int r = 0; r < HP; ++r) { Z[r] = 0.f; ZY[r] = 0.f; }
+        for (int r = 0; r < HPc; ++r) { Z[r] = 0.f; ZY[r] = 0.f; }
         for (int k = 0; k < n; ++k) {
           const float4 c = COL[k];
 #pragma unroll
-          for (int r = 0; r < HP; ++r) {
+          for (int r = 0; r < HPc; ++r) {
             Z[r] += ns_exp(__builtin_fmaf(ct[r], c.x, -c.y) - ms[r]);
             ZY[r] += ns_exp(__builtin_fmaf(ct[r], c.z, -c.w) - my[r]);
           }
         }
-        float rz[HP], rzy[HP], H[HP], ll[HP];
+        float rz[HPc], rzy[HPc], H[HPc], ll[HPc];
 #pragma unroll
-        for (int r = 0; r < HP; ++r) { rz[r] = 1.0f / Z[r]; rzy[r] = 1.0f / ZY[r]; H[r] = 0.f; ll[r] = 0.f; }
+        for (int r = 0; r < HPc; ++r) { rz[r] = 1.0f / Z[r]; rzy[r] = 1.0f / ZY[r]; H[r] = 0.f; ll[r] = 0.f; }
         for (int k = 0; k < n; ++k) {
           const float4 c = COL[k];
 #pragma unroll
-          for (int r = 0; r < HP; ++r) {
+          for (int r = 0; r < HPc; ++r) {
             const float p = ns_exp(__builtin_fmaf(ct[r], c.x, -c.y) - ms[r]) * rz[r];
             const float tt = ns_exp(__builtin_fmaf(ct[r], c.z, -c.w) - my[r]) * rzy[r];
             const float den = kTiny + p;
@@ -522,8 +529,8 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
           }
         }
 #pragma unroll
-        for (int r = 0; r < HP; ++r) {
-          const int t = tid + NSB_T * (HP * h + r);
+        for (int r = 0; r < HPc; ++r) {
+          const int t = tid + NSB_T * (HPc * h + r);
           if (t < n) {
             part += ll[r];
             ROW[t] = make_float4(ms[r], rz[r], H[r], 0.f);
@@ -556,12 +563,12 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
         __syncthreads();
         const int tn = (n - t0 < NSB_TILE) ? n - t0 : NSB_TILE;
 #pragma unroll
-        for (int h = 0; h < IPL / HP; ++h) {
-          if (NSB_T * HP * h < n) {
-            float ak[HP], gk[HP], ayk[HP];
+        for (int h = 0; h < IPL / HPc; ++h) {
+          if (NSB_T * HPc * h < n) {
+            float ak[HPc], gk[HPc], ayk[HPc];
 #pragma unroll
-            for (int r = 0; r < HP; ++r) {
-              const int k = tid + NSB_T * (HP * h + r);
+            for (int r = 0; r < HPc; ++r) {
+              const int k = tid + NSB_T * (HPc * h + r);
               const float4 c = COL[k < n ? k : 0];
               ak[r] = c.y; gk[r] = c.z; ayk[r] = c.w;
             }
@@ -570,22 +577,22 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
               const float4 row = TILE[tt0];
               if (!CE) {
 #pragma unroll
-                for (int r = 0; r < HP; ++r) {
-                  const float e = ns_exp(__builtin_fmaf(c, sk_[HP * h + r], -ak[r]) - row.x);
+                for (int r = 0; r < HPc; ++r) {
+                  const float e = ns_exp(__builtin_fmaf(c, sk_[HPc * h + r], -ak[r]) - row.x);
                   const float u = (row.y * e) * (gk[r] - row.z);        // -inv D_t P[t,k] (g_k - G_t)
-                  Q[HP * h + r] += u;
-                  R[HP * h + r] = __builtin_fmaf(c, u, R[HP * h + r]);
+                  Q[HPc * h + r] += u;
+                  R[HPc * h + r] = __builtin_fmaf(c, u, R[HPc * h + r]);
                 }
               } else {
                 const float4 row2 = TILE2[tt0];
 #pragma unroll
-                for (int r = 0; r < HP; ++r) {
-                  const float p = ns_exp(__builtin_fmaf(c, sk_[HP * h + r], -ak[r]) - row.x) * row.y;
+                for (int r = 0; r < HPc; ++r) {
+                  const float p = ns_exp(__builtin_fmaf(c, sk_[HPc * h + r], -ak[r]) - row.x) * row.y;
                   const float tt = ns_exp(__builtin_fmaf(c, gk[r], -ayk[r]) - row2.x) * row2.y;
                   const float rho = p * __builtin_amdgcn_rcpf(kTiny + p);
                   const float u = inv_n * __builtin_fmaf(p, row.z, -tt * rho);   // (P H_t - T rho) / n
-                  Q[HP * h + r] += u;
-                  R[HP * h + r] = __builtin_fmaf(c, u, R[HP * h + r]);
+                  Q[HPc * h + r] += u;
+                  R[HPc * h + r] = __builtin_fmaf(c, u, R[HPc * h + r]);
                 }
               }
             }
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
     // ---- D. dL/ds_k = R_k - sum_j sign(s_k - s_j) (Q_k + Q_j).
     float acc[IPL];
 #pragma unroll
-    for (int r = 0; r < IPL; ++r) acc[r] = 0.f;
+    for (int r = 0; r < RM; ++r) acc[r] = 0.f;
     float2* T2 = reinterpret_cast<float2*>(TILE);                       // [2 * NSB_TILE] pairs
     for (int j0 = 0; j0 < n; j0 += 2 * NSB_TILE) {
       __syncthreads();                                                 // SQ is written / the previous tile is consumed
@@ -614,14 +621,14 @@ __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
       for (int jj = 0; jj < jn; ++jj) {
         const float2 sq = T2[jj];
 #pragma unroll
-        for (int r = 0; r < IPL; ++r) {
+        for (int r = 0; r < RM; ++r) {
           const float sg = (sk_[r] > sq.x) ? 1.0f : ((sk_[r] < sq.x) ? -1.0f : 0.0f);
           acc[r] = __builtin_fmaf(sg, Q[r] + sq.y, acc[r]);
         }
       }
     }
 #pragma unroll
-    for (int r = 0; r < IPL; ++r) {
+    for (int r = 0; r < RM; ++r) {
       const int k = tid + NSB_T * r;
       if (k < n) dlogits_out[base + CI[k]] = scale * ((R[r] - acc[r]) / temperature);
     }
@@ -651,11 +658,25 @@ extern "C" int tfr_neural_sort_loss_f32(int kind, const float* logits, const flo
   if (slot) {                                       // one workgroup per list, row statistics in the workspace
     const int P = pow2_ceil(L);
     const size_t lds = 128 + (size_t)P * 16 + 2 * (size_t)NSB_TILE * 16;
-    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG> : neural_sort_block_kernel<TFR_NEURAL_SORT_CE>;
+    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, false>
+                                           : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, false>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(big_slots(B, (size_t)workspace_bytes, (size_t)slot)), dim3(NSB_T), lds, st, logits, labels, mask,
                        inv_log1p, list_scale, B, L, P, temperature, loss_out, dlogits_out, (unsigned char*)workspace, slot);
+    return (int)hipGetLastError();
+  }
+  static const int env_block = env_int_ns("TFR_NEURAL_SORT_BLOCK", 1);
+  if (env_block && L > 1024) {                      // 1024 < L <= 2048: the workgroup form with everything in LDS
+    const int P = 2048;
+    const size_t per_item = (kind == TFR_NEURAL_SORT_NDCG) ? 32 : 52;
+    const size_t lds = 128 + (size_t)P * 16 + 2 * (size_t)NSB_TILE * 16 + (size_t)P * per_item;
+    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, true>
+                                           : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, true>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fn, dim3(B < 65535 * 16 ? B : 65535 * 16), dim3(NSB_T), lds, st, logits, labels, mask, inv_log1p, list_scale, B,
+                       L, P, temperature, loss_out, dlogits_out, (unsigned char*)nullptr, 0L);
     return (int)hipGetLastError();
   }
   const int Lp = ((L + 3) / 4) * 4 + 4;
