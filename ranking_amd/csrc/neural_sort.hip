@@ -325,15 +325,16 @@ constexpr int NSB_T = 1024, NSB_IPL = 8, NSB_TILE = 512, HP = 4;
 // CE kind) -- no workspace, and the form the launcher takes from 1025 items on: the one-wavefront kernel needs 40 / 60 B of LDS
 // per item, i.e. ONE wavefront per CU beyond 1024 items, where this form runs sixteen on the same list (measured at 16 lists:
 // 1.99 ms here at 2049 items against 3.82 ms there at 2048, profiles/r05_long_lists.txt).
-template <int KIND, bool LDSWS>
+template <int KIND, int ITEMS>      // ITEMS: 0 = up to 8 items per thread, their side arrays in the workspace; 1 / 2 = P = 1024 / 2048, all in LDS
 __global__ __launch_bounds__(NSB_T) void neural_sort_block_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ inv_log1p, const float* __restrict__ list_scale, int B, int L, int P, float temperature,
     float* __restrict__ loss_out, float* __restrict__ dlogits_out, unsigned char* __restrict__ ws, long slot_bytes) {
   constexpr bool CE = (KIND == TFR_NEURAL_SORT_CE);
   constexpr int IPL = NSB_IPL;
-  constexpr int RM = LDSWS ? 2 : NSB_IPL;               // items a thread can own (P / NSB_T)
-  constexpr int HPc = LDSWS ? 2 : HP;                   // items of a thread per pass of phases A - C (P <= 2048: two per thread)
+  constexpr bool LDSWS = ITEMS != 0;
+  constexpr int RM = LDSWS ? ITEMS : NSB_IPL;           // items a thread can own (P / NSB_T)
+  constexpr int HPc = LDSWS ? ITEMS : HP;                   // items of a thread per pass of phases A - C (P <= 2048: two per thread)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);                       // [32]
   float4* COL = reinterpret_cast<float4*>(smem_raw + 128);                // [P] (s, A, g | y, A^y), compact order
@@ -658,8 +659,8 @@ extern "C" int tfr_neural_sort_loss_f32(int kind, const float* logits, const flo
   if (slot) {                                       // one workgroup per list, row statistics in the workspace
     const int P = pow2_ceil(L);
     const size_t lds = 128 + (size_t)P * 16 + 2 * (size_t)NSB_TILE * 16;
-    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, false>
-                                           : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, false>;
+    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, 0>
+                                           : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, 0>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(big_slots(B, (size_t)workspace_bytes, (size_t)slot)), dim3(NSB_T), lds, st, logits, labels, mask,
@@ -667,12 +668,20 @@ extern "C" int tfr_neural_sort_loss_f32(int kind, const float* logits, const flo
     return (int)hipGetLastError();
   }
   static const int env_block = env_int_ns("TFR_NEURAL_SORT_BLOCK", 1);
-  if (env_block && L > 1024) {                      // 1024 < L <= 2048: the workgroup form with everything in LDS
-    const int P = 2048;
+  // 512 < L <= 2048: the workgroup form with everything in LDS -- sixteen wavefronts on a list instead of one.  Always from 1025
+  // items on (the wave kernel's 40 / 60 B of LDS per item leave ONE wavefront per CU there: 3.8-4.4x measured); between 513
+  // and 1024 items a list runs 2.8-3.1x faster on the workgroup form, but only 256 lists are resident against two to six
+  // wavefronts per CU of the wave kernel: the workgroup form is taken when the batch fits two rounds of it or the wave
+  // kernel would not get three wavefronts per CU (measured at 600 / 1024 items, 16 - 1024 lists: profiles/r05_long_lists.txt)
+  static const int env_block_min = env_int_ns("TFR_NEURAL_SORT_BLOCK_MIN", 513);
+  const bool few_waves = 3 * ns_lds_bytes(((L + 3) / 4) * 4 + 4, kind) > (size_t)160 * 1024;
+  if (env_block && L >= env_block_min && L > 512 && (L > 1024 || B <= 512 || few_waves)) {
+    const int P = L > 1024 ? 2048 : 1024;
     const size_t per_item = (kind == TFR_NEURAL_SORT_NDCG) ? 32 : 52;
     const size_t lds = 128 + (size_t)P * 16 + 2 * (size_t)NSB_TILE * 16 + (size_t)P * per_item;
-    auto fn = kind == TFR_NEURAL_SORT_NDCG ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, true>
-                                           : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, true>;
+    auto fn = kind == TFR_NEURAL_SORT_NDCG
+                  ? (P == 2048 ? neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, 2> : neural_sort_block_kernel<TFR_NEURAL_SORT_NDCG, 1>)
+                  : (P == 2048 ? neural_sort_block_kernel<TFR_NEURAL_SORT_CE, 2> : neural_sort_block_kernel<TFR_NEURAL_SORT_CE, 1>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(fn, dim3(B < 65535 * 16 ? B : 65535 * 16), dim3(NSB_T), lds, st, logits, labels, mask, inv_log1p, list_scale, B,
