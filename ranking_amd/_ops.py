@@ -335,16 +335,18 @@ def list_order(labels, mask=None):
 
 
 # The launch order is a function of the LABELS (and the mask) alone and only steers load balance -- the loss kernels write
-# every list to its own rows, so their results do not depend on it.  It is therefore cached per label tensor (round 5,
-# VERDICT r4 next #7): keyed on the tensor object, its storage address and its version counter (bumped by every in-place
-# write), so a batch whose labels are passed again unchanged -- every epoch over a device-resident dataset, every
-# evaluation pass, every replay of a training step on the same batch -- pays the two ordering launches (11 us + gaps of a
-# 136 us ApproxNDCG step at B = 16384) once.  A stale entry could only ever cost balance, never correctness.  Entries read
-# while a stream capture is recording are pinned for the life of the process (the graph holds the order's address);
-# TFR_ORDER_CACHE=0 (or order_cache(False)) recomputes the order in every call like rounds 1-4.
+# every list to its own rows, so their results do not depend on it.  EAGER calls cache it per label tensor (round 5): keyed
+# on the tensor object, its storage address and its version counter (bumped by every in-place write), so a batch whose
+# labels are passed again unchanged -- an evaluation pass, an epoch over a device-resident dataset -- pays the two ordering
+# launches once.  A stale entry could only ever cost balance, never correctness.
+# Round 6 (ADVICE r5 high + medium): a stream capture NEVER reads or writes the cache.  The two ordering launches are
+# recorded into the graph like rounds 1-4 did, so (a) a replay after `labels.copy_(next batch)` orders the NEW batch (a
+# cached order baked into the graph was the warm-up batch's: a silently random order for every later batch), and (b) no
+# graph ever holds the address of a cache entry -- round 5 "pinned" such entries and a later eager miss on the same key
+# dropped the only reference (use-after-free under replay).  A caller who knows the labels of a captured step never
+# change passes a ready order: `balance=order`.  TFR_ORDER_CACHE=0 (or order_cache(False)) turns the eager cache off too.
 _ORDER_CACHE_ON = os.environ.get('TFR_ORDER_CACHE', '1') != '0'
 _order_lru: 'OrderedDict[Tuple, Tuple]' = OrderedDict()
-_order_pinned: Dict[Tuple, Tuple] = {}
 _ORDER_CACHE_CAPACITY = 64
 
 
@@ -364,25 +366,42 @@ class order_cache(object):
         _ORDER_CACHE_ON = self._saved
 
 
+_FIXED_ORDER = None
+
+
+class launch_order(object):
+    """``with launch_order(order): step()``: every automatic ordering decision inside takes this ready int32 [B] order
+    (``tfr_list_order_i32``'s output for the labels in use) -- for a caller who captures a step whose labels never change
+    (an evaluation set resident on the device) and does not want the two ordering launches inside every replay.  The
+    caller keeps `order` alive as long as the graph."""
+
+    def __init__(self, order):
+        self._order = order
+
+    def __enter__(self):
+        global _FIXED_ORDER
+        self._saved, _FIXED_ORDER = _FIXED_ORDER, self._order
+        return self
+
+    def __exit__(self, *exc):
+        global _FIXED_ORDER
+        _FIXED_ORDER = self._saved
+
+
 def _cached_order(labels, mask):
     import weakref
-    if not _ORDER_CACHE_ON:
-        return list_order(labels, mask)
+    if _FIXED_ORDER is not None and _FIXED_ORDER.shape[0] == labels.shape[0]:
+        return _FIXED_ORDER
+    if not _ORDER_CACHE_ON or torch.cuda.is_current_stream_capturing():
+        return list_order(labels, mask)         # inside a capture: two nodes of the graph, memory of the graph's pool
     key = (labels.data_ptr(), tuple(labels.shape), str(labels.device), None if mask is None else mask.data_ptr())
     stamp = (labels._version, None if mask is None else mask._version)
-    capturing = torch.cuda.is_current_stream_capturing()
-    ent = _order_pinned.get(key) or _order_lru.get(key)
+    ent = _order_lru.get(key)
     if ent is not None and ent[0] == stamp and ent[1]() is labels:       # (the mask is a fresh uint8 view per call: address + version)
-        if capturing and key in _order_lru:
-            _order_pinned[key] = _order_lru.pop(key)
-        elif key in _order_lru:
-            _order_lru.move_to_end(key)
-        return ent[3]
+        _order_lru.move_to_end(key)
+        return ent[2]
     order = list_order(labels, mask)
-    if capturing:                       # its storage belongs to the graph's pool: not cached
-        return order
-    _order_pinned.pop(key, None)
-    _order_lru[key] = (stamp, weakref.ref(labels), None, order)
+    _order_lru[key] = (stamp, weakref.ref(labels), order)
     while len(_order_lru) > _ORDER_CACHE_CAPACITY:
         _order_lru.popitem(last=False)
     return order
@@ -733,4 +752,4 @@ def _guard_module(namespace, module_name, skip=()):
             namespace[name] = device_guarded(obj)
 
 
-_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded', 'order_cache', 'tie_keys'))
+_guard_module(globals(), __name__, skip=('require_device', 'rank_table', 'device_guarded', 'order_cache', 'launch_order', 'tie_keys'))

@@ -142,3 +142,48 @@ def test_a_dead_or_silent_child_costs_one_entry(monkeypatch, tmp_path):
 def test_last_json_line_takes_the_last_parseable_one():
     assert bench.last_json_line('{"a": 1}\n{"a": 2}\nnot json\n{broken') == {'a': 2}
     assert bench.last_json_line('nothing') is None
+
+
+def test_traffic_entries_are_keyed_by_kernel_symbol():
+    """Round 6: counters are attached only to the kernel symbol they were measured on -- no fallback to
+    older rounds' files, no counters of a replaced kernel under a new kernel's time."""
+    assert all(f.startswith('profiles/r06') or f.startswith('profiles/r05') for f in bench.TRAFFIC_FILES)
+    assert bench._symbol('tower_gemm256p_kernel<2, 1, 2, 0> (forward hidden layer)') == 'tower_gemm256p_kernel'
+    assert bench._symbol('ndcg_lean_kernel (ranks from ...)') == 'ndcg_lean_kernel'
+    assert bench.measured_traffic('approx_ndcg', 16384, 200, 'approx_ndcg_wave_kernel') is not None
+    assert bench.measured_traffic('approx_ndcg', 16384, 200, 'some_new_kernel') is None
+    assert bench.measured_traffic('ndcg_metric_hbm', 16384, 200, 'ndcg_count_wave_kernel') is None
+    assert 'kernel' in bench.traffic_source('approx_ndcg', 16384, 200, 'some_new_kernel')
+
+
+def test_digest_line_carries_the_contract_and_fits_a_short_tail():
+    """Round 6 (VERDICT r5 next #5b): the LAST line bench.py prints is the contract line in compact form -- every contract key
+    of the main workload + one short record per extra -- below 4 KB for eight workloads, so it survives an 8 KB tail."""
+    roof = {'bound': 'hbm', 'achieved': 376.9, 'peak': 8000.0, 'unit': 'GB/s', 'frac': 0.047, 'traffic': 45140992,
+            'traffic_source': 'x' * 300, 'kernel': 'approx_ndcg_wave_kernel', 'kernel_ms': 0.1048, 'note': 'y' * 500,
+            'valu_frac': 0.65, 'trans_frac': 0.3, 'algorithmic_bytes_per_launch': 39518208}
+    cb = {'value': 5429.4, 'unit': 'lists/s', 'cores': 16, 'kind': 'port', 'sample': 's' * 300, 'fused_c': {'value': 1.4e6, 'note': 'n' * 300}}
+    main = {'metric': 'ranked lists/sec (fwd+bwd), ApproxNDCG list_size=200', 'value': 1.36e8, 'unit': 'lists/s', 'n_gpus': 1,
+            'steps': 20, 'warmup': 5, 'ms_per_step': 0.12, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic', 'config': {'workload': 'w' * 200, 'lists_per_gpu_per_step': 16384, 'list_size': 200,
+                                                            'parallelism': 'dp1', 'launch_order': 'o' * 300},
+            'roofline': roof, 'cpu_baseline': cb, 'steady_state': {'ms_per_step': 0.12, 'value': 1.37e8, 'note': 'z' * 400},
+            'order_cached': {'ms_per_step': 0.11, 'value': 1.5e8, 'note': 'z' * 400}}
+    child = dict(main, roofline=dict(roof, step={'frac': 0.15}, kernel='tower_gemm256p_kernel<BN+ReLU prologue> (long text ' + 'k' * 300),
+                 dropout_0={'ms_per_step': 3.3, 'value': 1.0}, all_reduce={'ms': 0.08, 'exposed_ms': 0.01})
+    main['also'] = {w: child for w in bench.DEFAULT_ALSO}
+    main['also']['broken'] = {'error': 'child exited with rc -6 ' + 'e' * 500}
+    d = bench.digest_line(main)
+    line = json.dumps(d)
+    assert len(line) < 4096, len(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+              'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in d['roofline'], k
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in d['cpu_baseline'], k
+    assert set(d['also']) == set(bench.DEFAULT_ALSO) | {'broken'}
+    e = d['also']['e2e_softmax']
+    assert e['kernel'] == 'tower_gemm256p_kernel<BN+ReLU' or e['kernel'].startswith('tower_gemm256p_kernel')
+    assert e['step_frac'] == 0.15 and e['all_reduce_exposed_ms'] == 0.01 and 'error' in d['also']['broken']

@@ -128,9 +128,9 @@ def test_approx_ndcg_reduced_scalar_from_the_same_launch(B, L):
 def test_launch_order_is_cached_per_label_tensor(monkeypatch):
     """Round 5: the longest-first launch order of the O(n^2) losses is a function of the labels alone and is cached per
     label tensor (address + version + object identity): the second call on an unchanged batch launches no ordering
-    kernels, an in-place write to the labels invalidates the entry, the switch recomputes every time, a hipGraph captured
-    after a first eager call replays without the ordering launches -- and the outputs are the same bits in every case
-    (the order only steers load balance)."""
+    kernels, an in-place write to the labels invalidates the entry, the switch recomputes every time, a hipGraph capture
+    never touches the cache (round 6: the ordering launches are recorded, the graph survives new batches copied into its
+    inputs) -- and the outputs are the same bits in every case (the order only steers load balance)."""
     from ranking_amd import _ops
     B, L = 2048, 200
     labels, logits = make_batch(B, L, seed=4242)
@@ -154,7 +154,8 @@ def test_launch_order_is_cached_per_label_tensor(monkeypatch):
         lb.mul_(1.0)                                          # an in-place write bumps the version: recomputed
         _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
         assert len(calls) == 4
-        # a graph captured after the eager call: no ordering launch inside, the same results on replay
+        # Round 6: a capture never reads the cache -- the ordering launches are nodes of the graph, so a replay
+        # after `labels.copy_(next batch)` orders the NEW batch, and the graph holds no address of a cache entry.
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -165,11 +166,26 @@ def test_launch_order_is_cached_per_label_tensor(monkeypatch):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
-        assert len(calls) == n_before                         # the cached (now pinned) order was used
+        assert len(calls) == n_before + 1                     # recorded into the graph, not taken from the cache
         g.replay()
         torch.cuda.synchronize()
         for x, y in zip(ref, out):
             assert torch.equal(x, y)
+        # the static-input pattern: new batch copied into the captured tensors, an eager call on them (a cache miss that
+        # round 5 answered by dropping the entry the graph pointed at), allocator churn, then the replay
+        labels2, logits2 = make_batch(B, L, seed=777)
+        lb.copy_(labels2.to(DEV)); lg.copy_(logits2.to(DEV))
+        eager2 = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
+        _ops._order_lru.clear()
+        junk = [torch.full((B,), 2 ** 30, dtype=torch.int32, device=DEV) for _ in range(64)]
+        g.replay()
+        torch.cuda.synchronize()
+        del junk
+        for x, y in zip(eager2, out):
+            assert torch.equal(x, y)
+        with _ops.order_cache(False):
+            ref = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
+            ref2 = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
         # the pairwise loss shares the mechanism (its own threshold: list_size >= 128)
         from ranking_amd.keras import losses as K
         loss = K.PairwiseLogisticLoss(lambda_weight=K.NDCGLambdaWeight())
