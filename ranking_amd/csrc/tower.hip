@@ -877,7 +877,7 @@ __device__ __forceinline__ bf16x8 transform_frag(bf16x8 raw, const f32x4 sc0, co
   for (int i = 0; i < 4; ++i) {
     f32x2 x = {bf16_lo(w[i]), bf16_hi(w[i])};
     const f32x2 s = {sc[2 * i], sc[2 * i + 1]}, h = {sh[2 * i], sh[2 * i + 1]};
-    x = x * s + h;
+    x = __builtin_elementwise_fma(x, s, h);           // one v_pk_fma_f32 (-ffp-contract=off splits x * s + h into v_pk_mul + v_pk_add)
     if (PRO == PRO_AFFINE_ACT) { x[0] = act_fwd(act, x[0]); x[1] = act_fwd(act, x[1]); }
     if (DROP == 1 || DROP == 3) x = x * f32x2{kf[2 * i], kf[2 * i + 1]};    // relu(y) * f == relu(y * f) for f >= 0
     uint32_t pk = pack_bf16(x[0], x[1]);
@@ -1340,6 +1340,24 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
     q = qn; tm = tmn; tn = tnn; p = pn;
   }
 }
+
+#include "tower_gemm_rp.h"
+
+#if (TFR_RP_ABLATE & 16)
+}  // namespace
+extern "C" int tfr_prof_set_buffer_rp(void* device_u64_buffer) {
+  unsigned long long* p = (unsigned long long*)device_u64_buffer;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_rp), &p, sizeof(p));
+}
+namespace {
+#endif
+
+#ifdef TFR_RP_DEV
+// developer aid: `hipcc -DTFR_RP_DEV=P,E,D,NK -S tower.hip` compiles ONE instantiation of the resident-panel kernel (20 s instead
+// of the 2.5 min of the whole translation unit) for reading its ISA / register use
+template __global__ void tower_gemm_rp_kernel<TFR_RP_DEV>(const GemmArgs);
+}  // namespace
+#else
 
 // ------------------------------------------------------------------------------------
 // fp32 [M, F] -> bf16 [M, Kp] (zero padded columns), optional per-column affine (input BN).  TIn = uint16_t: the
@@ -2227,6 +2245,57 @@ int launch_gemm256p(const GemmArgs& g0, hipStream_t st) {
   return launch_gemm_v<PRO, EPI, true>(t, st);
 }
 
+// Round 6: the resident-panel kernel (tower_gemm_rp.h) over the full 512-row tiles of the shapes it serves; the last
+// M % 512 rows and every other shape stay with the kernels above.  TFR_GEMM_RP=0 restores round 5's dispatch.
+static bool gemm_rp_shape_ok(int M, int N, int K, long lda, long ldb, long ldc, long ldz) {
+  // (read on every call, not cached: tests and A/B runs flip them inside one process; two getenv calls per GEMM launch)
+  const char* e_rp = getenv("TFR_GEMM_RP");
+  const char* e_mt = getenv("TFR_GEMM_RP_MIN_TILES");
+  const int env_rp = (e_rp && *e_rp) ? atoi(e_rp) : 0;      // (off by default until it beats the round-5 kernels on every form)
+  const int min_tiles = (e_mt && *e_mt) ? atoi(e_mt) : 512;
+  if (!env_rp || (N % RP_BN) != 0 || K != 512) return false;
+  const int tiles_n = N / RP_BN;
+  if (tiles_n > 32 || (32 % tiles_n) != 0) return false;
+  if ((long)(M / RP_BM) * tiles_n < min_tiles) return false;          // fewer than ~two tiles per CU: the 256 x 256 kernel spreads better
+  return lda < (1L << 21) && ldb < (1L << 21) && ldc < (1L << 21) && ldz < (1L << 21);
+}
+
+template <int PRO, int EPI> int launch_gemm_rest(const GemmArgs& g, hipStream_t st);
+
+template <int PRO, int EPI>
+int launch_gemm_rp(const GemmArgs& g0, hipStream_t st) {
+  constexpr bool BWD = EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD;
+  GemmArgs g = g0;
+  const int m_full = (g0.M / RP_BM) * RP_BM;
+  g.M = m_full; g.tiles_m = m_full / RP_BM; g.tiles_n = g.N / RP_BN; g.flags = 0;
+  // Dropout: the prologue form is the keep-bit-table one (rate 1/2, the reference default; DROP = 2) -- the per-fragment hash
+  // forms of other rates need more registers than this kernel has left (19-90 spilled) and stay with the round-5 kernels;
+  // the epilogue mask of the dgrad forms (DROP = 1: 8-bit fields, 3: 16-bit fields) fits.
+  void (*fn)(const GemmArgs) = nullptr;
+  if constexpr (PRO != PRO_NONE) {
+    const bool table = PRO != PRO_AFFINE_ACT && g.pro_drop.lge == 5u && EPI <= EPI_STATS;
+    if (g.pro_drop.thr != 0u && !table) return launch_gemm_rest<PRO, EPI>(g0, st);
+    if (g.Aout != nullptr) fn = g.pro_drop.thr ? tower_gemm_rp_kernel<PRO, EPI, 2, 8, true> : tower_gemm_rp_kernel<PRO, EPI, 0, 8, true>;
+    else fn = g.pro_drop.thr ? tower_gemm_rp_kernel<PRO, EPI, 2, 8> : tower_gemm_rp_kernel<PRO, EPI, 0, 8>;
+  } else {
+    const bool drop = BWD && g.epi_drop.thr;
+    const bool drop16 = drop && g.epi_drop.lge == 1u;
+    fn = !drop ? tower_gemm_rp_kernel<PRO, EPI, 0, 8> : (drop16 ? tower_gemm_rp_kernel<PRO, EPI, 3, 8> : tower_gemm_rp_kernel<PRO, EPI, 1, 8>);
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, RP_LDS);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(fn, dim3(256), dim3(512), RP_LDS, st, g);
+  int rc = (int)hipGetLastError();
+  if (rc != 0 || m_full == g0.M) return rc;
+  GemmArgs t = g0;                                  // the last M - m_full (< 512) rows
+  t.A = g0.A + (long)m_full * g0.lda; t.C = g0.C + (long)m_full * g0.ldc;
+  if (g0.Zp) t.Zp = g0.Zp + (long)m_full * g0.ldz;
+  if (g0.stats) t.stats = g0.stats + (long)(m_full / 64) * 2 * g0.N;
+  t.M = g0.M - m_full; t.row0 = g0.row0 + m_full;
+  t.tiles_m = (t.M + BM - 1) / BM; t.tiles_n = (t.N + BN - 1) / BN;
+  return launch_gemm_rest<PRO, EPI>(t, st);
+}
+
 // The shapes the persistent kernel serves (tfr_tower_gemm_persistent: the host asks before it passes `a_out`).
 static bool gemm_persistent_ok(int M, int N, int K, long lda, long ldb, long ldc, long ldz) {
   static const bool persist = [] { const char* e = getenv("TFR_TOWER_PERSIST"); return !(e && *e) || atoi(e) != 0; }();
@@ -2236,6 +2305,18 @@ static bool gemm_persistent_ok(int M, int N, int K, long lda, long ldb, long ldc
 
 template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
+  // the forms a BatchNorm + ReLU tower runs: hidden-layer forward (2, 1), its dgrad (0, 2), plain products (0, 0), (0, 1)
+  constexpr bool rp_form = (PRO == PRO_AFFINE_RELU && EPI == EPI_STATS) || (PRO == PRO_NONE && EPI <= EPI_RELU_BWD);
+  if constexpr (rp_form) {
+    if (gemm_rp_shape_ok(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldz) && !(EPI == EPI_RELU_BWD && g.bias) &&
+        (g.Aout == nullptr || ((g.M % RP_BM) == 0 && PRO != PRO_NONE)))
+      return launch_gemm_rp<PRO, EPI>(g, st);
+  }
+  return launch_gemm_rest<PRO, EPI>(g, st);
+}
+
+template <int PRO, int EPI>
+int launch_gemm_rest(const GemmArgs& g, hipStream_t st) {
   const bool pers = gemm_persistent_ok(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldz) &&
                     !((EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD) && g.bias);
   if (g.Aout && !(pers && (g.M % BM2) == 0 && PRO != PRO_NONE && EPI <= EPI_STATS)) return TFR_EINVAL;
@@ -2670,3 +2751,4 @@ extern "C" int tfr_tower_bn_bwd_coeffs(const float* gamma, const float* rstd, co
                      rstd, mean, c, N, 1.0f / (float)M, pqr);
   return (int)hipGetLastError();
 }
+#endif  // TFR_RP_DEV

@@ -6,6 +6,12 @@
 //   PATH 3  half the bytes by PATH 1 from the streamed source, half by PATH 0 from a 512 KB panel (L2 resident)
 //           -- the proposed split: activations direct to registers, the weight panel by LDS-DMA
 //   PATH 4  PATH 3 + every wave ds_read_b128's the whole 32 KB panel stage (256 KB of LDS reads per step and CU)
+//   PATH 5  global_load_dwordx4 -> VGPR in MFMA OPERAND LAYOUT: lane l takes 16 B of row (l & 15) at chunk (l >> 4) of a
+//           [256 rows][1024 B] tile -- adjacent lanes are 1 KB apart, four NON-adjacent lanes cover a 64-byte segment
+//           (what tower_gemm_rp.h's first version did for its activation operand); 32 KB per step and workgroup
+//   PATH 6  the same bytes with lane l taking row (l >> 3), 16-byte piece (l & 7): eight adjacent lanes = one 128-byte line
+//   PATH 7  lane l takes row (l >> 2), piece (l & 3): four adjacent lanes = one 64-byte segment (16 rows per instruction)
+//   PATH 8  lane l takes row (l >> 1), piece (l & 1): two adjacent lanes = 32 bytes (32 rows per instruction)
 // SRC 0: every workgroup streams its own slice of a 2 GiB buffer (HBM); SRC 1: every workgroup re-reads one 512 KB panel
 // (L2 resident after the first pass).  DEPTH = steps in flight (vmcnt-counted, 1..3).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/fill_bench tools/fill_bench.hip && tools/fill_bench
@@ -82,6 +88,33 @@ __global__ __launch_bounds__(512, 1) void fill_kernel(const unsigned char* __res
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) use(d, r[d]);
+  } else if (PATH >= 5 && PATH <= 8) {
+    uint4 r[3][4];
+    auto load = [&](int s, uint4 (&d)[4]) __attribute__((always_inline)) {
+      // tile: [256 rows][1024 B] (L2 resident: src = panel-sized region); wave w owns rows 32 w .., step s the 128-byte column block s % 8
+      const unsigned char* sb = base + (long)(wave * 32) * 1024 + (s % 8) * 128;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int off = PATH == 5 ? (((i >> 1) * 16 + (lane & 15)) * 1024 + (i & 1) * 64 + (lane >> 4) * 16)
+                      : PATH == 6 ? ((i * 8 + (lane >> 3)) * 1024 + (lane & 7) * 16)
+                      : PATH == 7 ? (((i >> 1) * 16 + (lane >> 2)) * 1024 + (i & 1) * 64 + (lane & 3) * 16)
+                                  : ((lane >> 1) * 1024 + i * 32 + (lane & 1) * 16);
+        d[i] = *reinterpret_cast<const uint4*>(sb + off);
+      }
+    };
+    auto use = [&](uint4 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc.x ^= d[i].x; acc.y ^= d[i].y; acc.z ^= d[i].z; acc.w ^= d[i].w; }
+    };
+    load(0, r[0]);
+    if (DEPTH >= 2) load(1, r[1]);
+    if (DEPTH >= 3) load(2, r[2]);
+    for (int s = 0; s < n_steps; s += DEPTH) {
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) { use(r[d]); load(s + d + DEPTH, r[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) use(r[d]);
   } else {                                    // PATH 3 / 4: 32 KB direct (4 loads per lane) + 32 KB panel by LDS-DMA (4 pieces per wave)
     uint4 r[3][4];
     auto load = [&](int s, uint4 (&d)[4]) __attribute__((always_inline)) {
@@ -147,7 +180,9 @@ int main() {
   CHECK(hipMalloc(&src, total)); CHECK(hipMalloc(&panel, 512 * 1024)); CHECK(hipMalloc(&out, WGS * 512 * 4));
   CHECK(hipMemset(src, 1, total)); CHECK(hipMemset(panel, 2, 512 * 1024));
   const char* pn[] = {"LDS-DMA (global_load_lds_dwordx4)", "global_load_dwordx4 -> VGPR", "global_load_dwordx4 -> VGPR -> ds_write_b128",
-                      "half direct (stream) + half LDS-DMA (L2 panel)", "  + every wave reads the 32 KB panel stage"};
+                      "half direct (stream) + half LDS-DMA (L2 panel)", "  + every wave reads the 32 KB panel stage",
+                      "dwordx4 -> VGPR, MFMA operand layout (32 KB / step)", "dwordx4 -> VGPR, 8 lanes per 128-B line (32 KB / step)",
+                      "dwordx4 -> VGPR, 4 lanes per 64-B segment (32 KB / step)", "dwordx4 -> VGPR, 2 lanes per 32 B (32 KB / step)"};
   printf("%-52s %-4s %5s %9s %10s %12s %10s\n", "path", "src", "depth", "ms", "TB/s chip", "GB/s per CU", "B/clk/CU@2.4");
 #define RUN(P, D, SRCK) { \
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_kernel<P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STEP)); \
@@ -157,12 +192,14 @@ int main() {
     const int wrap = hbm ? (int)(stride / per_step) : (512 * 1024) / per_step; \
     const int n_steps = hbm ? ((P >= 3) ? wrap / 2 : wrap) / 6 * 6 : 6000; \
     double ms = time_ms([&] { hipLaunchKernelGGL((fill_kernel<P, D>), dim3(WGS), dim3(512), 2 * STEP, 0, hbm ? src : panel, stride, wrap, n_steps, panel, out); }); \
-    const double bytes = (double)WGS * n_steps * STEP; \
+    const double bytes = (double)WGS * n_steps * ((P >= 5) ? STEP / 2 : STEP); \
     printf("%-52s %-4s %5d %9.4f %10.3f %12.1f %10.1f\n", pn[P], hbm ? "HBM" : "L2", D, ms, bytes / ms / 1e9, bytes / ms / 1e6 / WGS, bytes / (ms * 1e-3) / WGS / 2.4e9); }
   RUN(0, 1, 0) RUN(0, 2, 0) RUN(0, 1, 1) RUN(0, 2, 1)
   RUN(1, 1, 0) RUN(1, 2, 0) RUN(1, 3, 0) RUN(1, 1, 1) RUN(1, 2, 1) RUN(1, 3, 1)
   RUN(2, 1, 0) RUN(2, 2, 0) RUN(2, 1, 1) RUN(2, 2, 1)
   RUN(3, 1, 0) RUN(3, 2, 0) RUN(3, 3, 0) RUN(3, 2, 1) RUN(3, 3, 1)
   RUN(4, 2, 0) RUN(4, 3, 0) RUN(4, 3, 1)
+  RUN(5, 1, 1) RUN(5, 2, 1) RUN(5, 3, 1) RUN(6, 1, 1) RUN(6, 2, 1) RUN(6, 3, 1)
+  RUN(7, 1, 1) RUN(7, 2, 1) RUN(8, 1, 1) RUN(8, 2, 1)
   return 0;
 }
