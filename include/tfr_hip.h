@@ -63,6 +63,12 @@ long tfr_list_workspace_bytes(int op, int L);
 #define TFR_PAIR_HINGE 1
 #define TFR_PAIR_SOFT_ZERO_ONE 2
 #define TFR_PAIR_MSE 3           /* losses_impl.py:961-998: ((s_i - s_j) - (y_i - y_j))^2 over all i != j */
+/* OR-ed into loss_kind TFR_PAIR_LOGISTIC: the reference's gradient at EXACTLY tied scores.  losses_impl.py:936-940 writes the
+ * pair loss as relu(-t) + log1p(exp(-|t|)); under TF autodiff that differentiates to 0 at t = 0 (relu'(0) = 0, sign(0) = 0),
+ * not to the analytic -sigma(0) = -1/2 the kernels return by default.  With the flag a pair with s_i == s_j contributes its
+ * loss (log 2) and no gradient -- what a reference run does on an all-equal initial logit vector.  The flag declines the
+ * LambdaRank fast paths (their factorised exponentials cannot see an exact tie): general wave / workgroup kernels. */
+#define TFR_PAIR_TIED_ZERO 0x100
 
 /* lambda_kind */
 #define TFR_LAMBDA_NONE 0

@@ -20,6 +20,7 @@ GAIN_IDENTITY, GAIN_POW2M1, GAIN_CUSTOM = 0, 1, 2
 LAMBDA_NONE, LAMBDA_LABELDIFF, LAMBDA_DCG = 0, 1, 2
 LAMBDA_DCG_V2, LAMBDA_YETI_DCG, LAMBDA_PRECISION = 3, 4, 5
 PAIR_LOGISTIC, PAIR_HINGE, PAIR_SOFT_ZERO_ONE, PAIR_MSE = 0, 1, 2, 3
+PAIR_TIED_ZERO = 0x100          # | PAIR_LOGISTIC: the reference's (TF autodiff) zero gradient at exactly tied scores (tfr_hip.h)
 MAX_TOPN = 8
 
 

@@ -53,18 +53,22 @@ __host__ __device__ inline size_t pw_smem_bytes(int Lp, int P) {
 //   hinge         : loss = relu(1 - t),                  -loss' = 1[t < 1]        (relu'(0) = 0)
 //   soft zero-one : loss = sigma(-t),                    -loss' = sigma(t) sigma(-t)
 __device__ __forceinline__ void pair_loss(const int kind, const float d0, const bool hi, float& loss, float& sel) {
-  if (kind == TFR_PAIR_HINGE) {
+  if ((kind & 0xff) == TFR_PAIR_HINGE) {
     loss = fmaxf(1.0f - d0, 0.0f);
     const float t = hi ? d0 : -d0;
     sel = (t < 1.0f) ? 1.0f : 0.0f;
     return;
   }
+  // TFR_PAIR_TIED_ZERO (with TFR_PAIR_LOGISTIC only): the reference's gradient at EXACTLY tied scores.  Its formula
+  // relu(-t) + log1p(exp(-|t|)) differentiates to 0 at t = 0 under TF autodiff (relu'(0) = 0, d|t|/dt = sign(0) = 0), not to
+  // the analytic -sigma(0) = -1/2: a tied pair contributes its loss log 2 and NO gradient.
+  const bool tied_zero = (kind & TFR_PAIR_TIED_ZERO) != 0 && d0 == 0.0f;
   const float e = __builtin_amdgcn_exp2f(-fabsf(d0) * kLog2e);     // exp(-|d|)
   const float w1 = 1.0f + e;
   const float q = __builtin_amdgcn_rcpf(w1);
   const float eq = e * q;
   const bool pos = d0 >= 0.0f;
-  if (kind == TFR_PAIR_SOFT_ZERO_ONE) {
+  if ((kind & 0xff) == TFR_PAIR_SOFT_ZERO_ONE) {
     loss = pos ? eq : q;                                           // sigma(-d0)
     sel = q * eq;
     return;
@@ -72,6 +76,7 @@ __device__ __forceinline__ void pair_loss(const int kind, const float d0, const 
   // relu(-d) + log1p(exp(-|d|)); fl(1 + e) costs <= 6e-8 absolute per pair, far inside 1e-5
   loss = __builtin_fmaf(__builtin_amdgcn_logf(w1), kLn2, fmaxf(-d0, 0.0f));
   sel = (pos == hi) ? eq : q;                                      // hi: sigma(-d0), lo: sigma(+d0)
+  if (tied_zero) sel = 0.0f;
 }
 
 // Pair weight of the GENERIC lambda path.  sub 0: DCGLambdaWeight (losses_impl.py:299-369),
@@ -1128,7 +1133,8 @@ static int pairwise_dispatch(int kind, const float* logits, const float* labels,
                                          float* loss_sum_out = nullptr, uint32_t* ticket = nullptr, uint32_t tie_seed = 0u) {
   if (!logits || !labels || B < 0 || L <= 0 || !(temperature > 0.0f)) return TFR_EINVAL;
   if (loss_sum_out && (!list_loss_out || !ticket)) return TFR_EINVAL;       // the per-list sums are the entries that are added up
-  if (kind < TFR_PAIR_LOGISTIC || kind > TFR_PAIR_MSE) return TFR_EINVAL;
+  if ((kind & ~TFR_PAIR_TIED_ZERO) < TFR_PAIR_LOGISTIC || (kind & ~TFR_PAIR_TIED_ZERO) > TFR_PAIR_MSE) return TFR_EINVAL;
+  if ((kind & TFR_PAIR_TIED_ZERO) && (kind & 0xff) != TFR_PAIR_LOGISTIC) return TFR_EINVAL;     // the flag is the logistic loss's
   if (lambda_kind < TFR_LAMBDA_NONE || lambda_kind > TFR_LAMBDA_PRECISION) return TFR_EINVAL;
   // DCGLambdaWeightV2 / YetiDCGLambdaWeight / PrecisionLambdaWeight run as sub-kinds of the generic DCG path
   int lambda_sub = TFR_SUB_DCG;

@@ -1306,6 +1306,21 @@ __global__ __launch_bounds__(1024) void metric_list_weights_kernel(const float* 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   float cnt = 0.f, sum = 0.f;
   int b = tid;
+  // Round 6: SIXTEEN lists in flight per thread (B = 16 384: the whole of pass 1 behind ONE memory round trip instead of
+  // four dependent ones -- the kernel is 6.6 us of latency, 20 % of the NDCG metric step), still added in index order
+  for (; b + 15 * 1024 < B; b += 16 * 1024) {
+    float sw[16], sr[16], swr[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const size_t o = (size_t)(b + u * 1024) * 3;
+      sw[u] = stats[o]; sr[u] = stats[o + 1]; swr[u] = stats[o + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      cnt += (sw[u] > 0.0f && sr[u] > 0.0f) ? 1.0f : 0.0f;
+      sum += (sr[u] != 0.0f) ? swr[u] / sr[u] : 0.0f;
+    }
+  }
   for (; b + 3 * 1024 < B; b += 4 * 1024) {                 // four lists in flight per thread, added in index order
     float sw[4], sr[4], swr[4];
 #pragma unroll
@@ -1331,7 +1346,7 @@ __global__ __launch_bounds__(1024) void metric_list_weights_kernel(const float* 
   float tc = 0.f, ts = 0.f;
   for (int w = 0; w < 16; ++w) { tc += red[0][w]; ts += red[1][w]; }
   const float avg = (tc > 0.0f) ? ts / tc : 1.0f;
-  for (int b2 = blockIdx.x * 1024 + tid; b2 < B; b2 += gridDim.x * 1024) {
+  for (int b2 = blockIdx.x * 1024 + tid; b2 < B; b2 += gridDim.x * 1024) {      // (L1 / L2 hits: pass 1 read every line)
     const float sw = stats[(size_t)b2 * 3], sr = stats[(size_t)b2 * 3 + 1], swr = stats[(size_t)b2 * 3 + 2];
     out[b2] = (sw > 0.0f) ? ((sr > 0.0f) ? swr / sr : avg) : 0.0f;
   }

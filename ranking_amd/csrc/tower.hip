@@ -2267,7 +2267,9 @@ int launch_gemm_rp(const GemmArgs& g0, hipStream_t st) {
   constexpr bool BWD = EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD;
   GemmArgs g = g0;
   const int m_full = (g0.M / RP_BM) * RP_BM;
-  g.M = m_full; g.tiles_m = m_full / RP_BM; g.tiles_n = g.N / RP_BN; g.flags = 0;
+  g.M = m_full; g.tiles_m = m_full / RP_BM; g.tiles_n = g.N / RP_BN;
+  { const char* e_rot = getenv("TFR_GEMM_RP_ROT"); g.flags = (e_rot && *e_rot && atoi(e_rot) == 0) ? 1 : 0;
+    const char* e_st = getenv("TFR_GEMM_RP_STAGGER"); g.flags |= (((e_st && *e_st) ? atoi(e_st) : 4) & 0xff) << 8; }   // bit 0: every n-tile in the same k order (bit-identical to the round-5 kernels)
   // Dropout: the prologue form is the keep-bit-table one (rate 1/2, the reference default; DROP = 2) -- the per-fragment hash
   // forms of other rates need more registers than this kernel has left (19-90 spilled) and stay with the round-5 kernels;
   // the epilogue mask of the dgrad forms (DROP = 1: 8-bit fields, 3: 16-bit fields) fits.

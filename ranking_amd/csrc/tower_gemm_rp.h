@@ -27,6 +27,10 @@
 // Shapes: N % 128 == 0 with N / 128 dividing 32, K in {256, 512} (NK = K / 64 a multiple of the ring depth), full 512-row
 // tiles; the launcher sends the last M % 512 rows through the older kernels.
 constexpr int RP_BM = 512, RP_BN = 128, RP_RING = 4;
+#ifndef TFR_RP_QA
+#define TFR_RP_QA 2
+#endif
+constexpr int RP_QA = TFR_RP_QA;
 // developer aid (tools/gemm_rp_ablate.py; results are garbage, timing only): 1 no activation loads inside the k loop,
 // 2 no epilogue (nothing written), 4 no MFMAs, 8 no panel fragment reads
 #ifndef TFR_RP_ABLATE
@@ -103,13 +107,26 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
   auto a_rows = [&](int tm_, int pass_) __attribute__((always_inline)) {
     return reinterpret_cast<const char*>(g.A) + ((long)(tm_ * RP_BM + wave * 64 + pass_ * 32) * g.lda) * 2;
   };
+  // The k ORDER is rotated per n-tile: position kt of the loop works on k block ka[kt] = (kt + tn * NK / tiles_n) mod NK.
+  // The tiles_n workgroups of a group read the same activation rows at the same time; in the same k order all of them ask for
+  // the same lines at once, every request waits a full HBM round trip and the bytes in flight that are UNIQUE are a quarter
+  // of the registers spent on them (measured: tools/fill_bench.hip PATH 9 -- 3.7 TB/s instead of 5.9).  Rotated, each
+  // workgroup misses on NK / tiles_n blocks of a pass and finds the others in L2, fetched by its neighbours two steps
+  // earlier; the four requests for one 1 KB row are in flight together (one DRAM page).  fp32 accumulation order differs
+  // from the round-5 kernels for tn > 0: results agree to fp32 rounding, not bit for bit.
+  int ka[NK];
+  {
+    const int rot = (g.flags & 1) ? 0 : (g.tiles_n <= NK ? tn * (NK / g.tiles_n) : tn % NK);
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) ka[kt] = (kt + rot) & (NK - 1);
+  }
   uint4 ar[RP_RING][4];                              // [ring slot][fm * 2 + kk]
 #define RP_LOAD(SLOT, BASE, KT)                                                                  \
   do {                                                                                           \
-    ar[SLOT][0] = *reinterpret_cast<const uint4*>((BASE) + a_off0 + (KT) * 128);                  \
-    ar[SLOT][1] = *reinterpret_cast<const uint4*>((BASE) + a_off0 + (KT) * 128 + 64);             \
-    ar[SLOT][2] = *reinterpret_cast<const uint4*>((BASE) + a_off1 + (KT) * 128);                  \
-    ar[SLOT][3] = *reinterpret_cast<const uint4*>((BASE) + a_off1 + (KT) * 128 + 64);             \
+    ar[SLOT][0] = *reinterpret_cast<const uint4*>((BASE) + a_off0 + ka[KT] * 128);                  \
+    ar[SLOT][1] = *reinterpret_cast<const uint4*>((BASE) + a_off0 + ka[KT] * 128 + 64);             \
+    ar[SLOT][2] = *reinterpret_cast<const uint4*>((BASE) + a_off1 + ka[KT] * 128);                  \
+    ar[SLOT][3] = *reinterpret_cast<const uint4*>((BASE) + a_off1 + ka[KT] * 128 + 64);             \
   } while (0)
 
   // ---- the first three k steps of the first pass go out before anything else
@@ -143,6 +160,15 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
     }
   }
   __syncthreads();
+  // De-phase the two wavefronts of every SIMD (waves w and w + 4).  All eight waves run the same instruction stream on equal
+  // work: started together they STAY together -- all in the k loop, then all in the epilogue -- and the phases of the launch
+  // add up instead of overlapping (ablations, tools/gemm_rp_ablate.py: MFMA 108 + panel reads 82 + activation loads 67 +
+  // epilogue 114 = the 371 us of the full kernel).  Half a pass of delay for waves 4-7, once, puts one wave of a SIMD in its
+  // epilogue / memory waits while the other feeds the matrix pipe.  flags bits 8-15: the delay in units of 2 048 cycles.
+  if (wave >= 4) {
+    const int units = (g.flags >> 8) & 0xff;
+    for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(32);
+  }
 
   const unsigned char* pb_lane = smem + RP_PANEL + fq * 2048 + fr * 16;
   // the operand a wave forms in its prologue is written out for the weight gradient by ONE of the tiles_n workgroups that
@@ -151,7 +177,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
   if (AOUT) {
     const int tdiv = g.tiles_n < NK ? g.tiles_n : NK;
 #pragma unroll
-    for (int kt = 0; kt < NK; ++kt) store_mask |= ((kt % tdiv) == tn) ? (1 << kt) : 0;
+    for (int kt = 0; kt < NK; ++kt) store_mask |= ((kt % tdiv) == tn) ? (1 << kt) : 0;      // (kt = loop position: any partition of the k blocks does)
   }
 
   // epilogue addressing (tile independent): the lane's 8-byte slot of fragment column f2 (0 / 1) in a [16][32] sub-chunk,
@@ -202,12 +228,12 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
         if (bt) {      // the k step's keep words (rate 1/2: a hash word serves 32 columns of a row): ONE hash per lane -- lane row fq takes
                        // (fm, kk) = (fq >> 1, fq & 1) -- exchanged across the four 16-lane rows; same words and bits as drop_run
           if (kk == 0) {
-            const uint32_t own = drop_hash(pdrop.seed, (uint32_t)(g.row0 + m0 + (fq >> 1) * 16 + fr), (uint32_t)(2 * kt + (fq & 1)));
+            const uint32_t own = drop_hash(pdrop.seed, (uint32_t)(g.row0 + m0 + (fq >> 1) * 16 + fr), (uint32_t)(2 * ka[kt] + (fq & 1)));
             rows_allgather4(own, wk);
           }
           bits[0] = wk[kk] >> (fq * 8); bits[1] = wk[2 + kk] >> (fq * 8);
         }
-        const int k = kt * BK + kk * 32 + fq * 8;
+        const int k = ka[kt] * BK + kk * 32 + fq * 8;
         const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s_scale + k), sc1 = *reinterpret_cast<const f32x4*>(s_scale + k + 4);
         const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s_shift + k), sh1 = *reinterpret_cast<const f32x4*>(s_shift + k + 4);
 #pragma unroll
@@ -223,19 +249,21 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
           const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(g.Aout + (long)m0 * g.ldao, 0, (int)span, 0x00020000);
 #pragma unroll
           for (int fm = 0; fm < 2; ++fm)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rp_i32x4, fa[fm]), rs, ao_off[fm] + (kt * 128 + kk * 64), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rp_i32x4, fa[fm]), rs, ao_off[fm], ka[kt] * 128 + kk * 64, 0);
         }
       }
     };
     auto read_quad = [&](int qi, bf16x8 (&fb)[4]) __attribute__((always_inline)) {       // qi = (kt * 2 + kk) * 2 + half
-      const unsigned char* pk = pb_lane + (qi >> 1) * 4 * 2048 + (qi & 1) * 4 * 256;
+      const unsigned char* pk = pb_lane + (ka[qi >> 2] * 8 + ((qi >> 1) & 1) * 4) * 2048 + (qi & 1) * 4 * 256;
 #pragma unroll
       for (int f = 0; f < 4; ++f) fb[f] = *reinterpret_cast<const bf16x8*>(pk + f * 256);
     };
     RP_STAMP(0);
-    bf16x8 fa_cur[2], fa_nxt[2], fbq[2][4];
+    // panel fragments: RP_QA quads (of four fragments = eight MFMAs) requested ahead of the one being multiplied
+    bf16x8 fa_cur[2], fa_nxt[2], fbq[RP_QA + 1][4];
     prep(0, 0, fa_cur);
-    read_quad(0, fbq[0]);
+#pragma unroll
+    for (int q0 = 0; q0 < RP_QA; ++q0) read_quad(q0, fbq[q0]);
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
       __builtin_amdgcn_sched_barrier(0);
@@ -260,8 +288,8 @@ __global__ __launch_bounds__(512, 1) void tower_gemm_rp_kernel(const GemmArgs g)
         if (kn < NK * 2) prep(kn >> 1, kn & 1, fa_nxt);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-          const int qi = (kt * 2 + kk) * 2 + half, cur = qi & 1;
-          if (qi + 1 < NK * 4 && !(kRpAb & 8)) read_quad(qi + 1, fbq[cur ^ 1]);
+          const int qi = (kt * 2 + kk) * 2 + half, cur = qi % (RP_QA + 1);
+          if (qi + RP_QA < NK * 4 && !(kRpAb & 8)) read_quad(qi + RP_QA, fbq[(qi + RP_QA) % (RP_QA + 1)]);
 #pragma unroll
           for (int f = 0; f < 4; ++f) {
             if (kRpAb & 4) {                           // (keeps the operands live without the matrix pipe)

@@ -348,13 +348,13 @@ class _PairwiseLoss(_LambdaConfigMixin, _RankingLoss):
         if not _LOSS_SUM_ALL:
             _, _, _, dlogits, list_loss = _ops.pairwise_logistic(
                 y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-                want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind,
+                want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._kind(),
                 tie_seed=tie_seed, **lam)
             return _ops.list_dot(list_loss), dlogits       # [B] per-list sums: nothing [B, L]-sized for the loss
         # the reduced scalar out of the same launch (round 5: every loss, not only ApproxNDCG)
         _, _, _, dlogits, _, total = _ops.pairwise_logistic(
             y_pred.detach(), y_true, mask, item_w, list_w, temperature=self._temperature,
-            want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._fused_kind,
+            want_grad=True, want_rows=False, want_aux=False, want_list=True, loss_kind=self._loss._kind(),
             want_sum=True, tie_seed=tie_seed, **lam)
         return total, dlogits
 

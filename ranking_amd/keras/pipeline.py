@@ -299,8 +299,8 @@ class ModelFitPipeline(AbstractPipeline):
                     logits = model(features)
                     vloss += loss(labels, logits, weights)
                     vcount += 1
-                    for m in metrics:
-                        m.update_state(labels, logits, weights if h.use_weighted_metrics else None)
+                    # (objects that differ only in their cut-off share one launch: keras/metrics.py update_metrics)
+                    metrics_lib.update_metrics(metrics, labels, logits, weights if h.use_weighted_metrics else None)
             # Every rank must see the same numbers: the early-stopping / ReduceLROnPlateau / best-checkpoint decisions
             # below decide whether this rank enters the next all-reduce.  ONE collective carries the validation loss
             # and every metric's Mean sums (a metric without a batch on this rank contributes zeros); BatchNorm moving

@@ -14,6 +14,7 @@ no reduced path uses them.
 from __future__ import annotations
 
 import abc
+import os
 import math
 from typing import Callable, Optional
 
@@ -424,6 +425,19 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
     _fused_kind = None   # subclasses with a fused kernel set this
     shuffle_ties = False
     seed = None
+    # 'analytic' (default): d loss / d t of a pair at t = s_i - s_j = 0 is the function's derivative, -sigma(0) = -1/2.
+    # 'reference': what TF autodiff returns for the reference's own formula relu(-t) + log1p(exp(-|t|)) (:936-940) at
+    # exactly t = 0 -- zero (relu'(0) = 0, sign(0) = 0): an all-equal logit vector (a zero-initialised output layer) then
+    # gets no pairwise-logistic gradient, as in a reference run.  Only PairwiseLogisticLoss differs; the mode runs the general
+    # kernels (TFR_PAIR_TIED_ZERO declines the LambdaRank fast paths).  TFR_TIED_GRADIENT=reference sets the default.
+    tied_gradient = os.environ.get('TFR_TIED_GRADIENT', 'analytic')
+
+    def _kind(self):
+        if self.tied_gradient not in ('analytic', 'reference'):
+            raise ValueError("tied_gradient must be 'analytic' or 'reference', got %r" % (self.tied_gradient,))
+        if self._fused_kind == _ops.PAIR_LOGISTIC and self.tied_gradient == 'reference':
+            return _ops.PAIR_LOGISTIC | _ops.PAIR_TIED_ZERO
+        return self._fused_kind
 
     def _tie_seed(self):
         if not self.shuffle_ties or self._lambda_weight is None:
@@ -470,7 +484,7 @@ class _PairwiseLoss(_RankingLoss, metaclass=abc.ABCMeta):
         def runner(lg, want_grad):
             row_loss, row_weight, nnz, d = _ops.pairwise_logistic(
                 lg, labels, mask, item_w, list_w, temperature=temperature, want_grad=want_grad,
-                want_aux=want_aux, loss_kind=self._fused_kind, tie_seed=tie_seed, **lam)
+                want_aux=want_aux, loss_kind=self._kind(), tie_seed=tie_seed, **lam)
             return row_loss.sum(dim=1), d, (row_loss, row_weight, nnz)
 
         return _PerListLossFn.apply(logits, runner)

@@ -137,9 +137,8 @@ def test_config4_full_batch():
     o = R.ApproxNDCGLoss(temperature=0.1)
     o_loss, o_grad = _oracle32_chunks(lambda l, x: o._compute_unreduced_loss_impl(l, x / 0.1)[0], labels, logits, 16, stride=4)
     e_k, e_o, g_k, g_o = _check('config 4 ApproxNDCG 512x1000', loss, d, w_loss, w_grad, o_loss, o_grad, stride=4)
-    # approx ranks are sums of up to 1000 sigmoids (~500): one fp32 ulp of a rank is 3e-5, so fp32 -- the reference's own
-    # arithmetic -- cannot hold 1e-5 on every gradient entry here; the kernel must not be worse than the fp32 op graph
-    assert e_k <= max(1e-5, 2 * e_o) and g_k <= max(1e-5, 2 * g_o), (e_k, e_o, g_k, g_o)
+    # north_star's bar, flat (round 6: measured 1.8e-7 / 6.1e-7; the `max(1e-5, 2 x oracle error)` relaxation was never needed)
+    assert e_k <= 1e-5 and g_k <= 1e-5, (e_k, e_o, g_k, g_o)
 
 
 def test_config5_full_batch_gumbel_injected_uniform():

@@ -16,7 +16,7 @@ from tests.common import make_batch
 
 pytestmark = pytest.mark.gpu
 PINNED_BAR = 5e-2     # forward pinned to the kernel's: backward arithmetic only (bf16 dz with stochastic rounding, 3200 randomly signed rows per entry): measured 2.9e-2 of max|dW| element-wise, 5.6e-3 in norm (bar 1.5e-2)
-ELEM_BAR = 2e-1       # measured 8.9e-2 (layer 0) / 1.33e-1 (layer 1) without BatchNorm: a randomly signed upstream makes dW a sum of 3200 cancelling terms; the trajectory test (test_gpu_e2e_parity.py) is the meaningful end-to-end bound
+ELEM_BAR = 2e-1       # (round 6: no longer asserted) measured 8.9e-2 (layer 0) / 1.33e-1 (layer 1) without BatchNorm: a randomly signed upstream makes dW a sum of 3200 cancelling terms; the trajectory test (test_gpu_e2e_parity.py) is the meaningful end-to-end bound
 DEV = 'cuda'
 
 
@@ -270,9 +270,10 @@ def test_groupwise_scorer_fused_tower_against_the_oracle(shuffle, use_bn):
         # the weight-gradient GEMM (dz and the activations) are bf16 (2^-9 relative rounding each) and 3200 rows are
         # summed with a randomly signed upstream, so the error of an entry is ~ sqrt(rows) * 2^-9 * |dz| |a| -- a few
         # per cent of the LARGEST entries, not of each entry.
+        # Round 6: recorded, no longer a gate -- it needed a 20 % bar (13 % used), wide enough to hide a
+        # regression; direction and norm against the oracle are asserted above, the element-wise bar is (c)'s (5 %).
         err = (a_ - b_).abs().max().item() / (b_.abs().max().item() + 1e-30)
-        record_margin('groupwise scorer dW element-wise / max|dW| vs fp32 oracle (bf16 operands)', err, ELEM_BAR)
-        assert err <= ELEM_BAR, ('vs oracle, element-wise', i, err)
+        record_margin('groupwise scorer dW element-wise / max|dW| vs fp32 oracle (bf16 operands; recorded, not a gate)', err, float('inf'))
     # (c) the tower backward alone, at the kernel's own forward point: the bf16-aware replica of
     #     tests/test_gpu_tower.py with its forward values pinned to the kernel's bf16 input and pre-activations (same ReLU
     #     gates) and the upstream gradient the kernel backward received.  What is left is backward arithmetic -- bf16 dz with

@@ -429,11 +429,12 @@ def test_fused_tower_input_gradient(M, F, hidden, O, act, bn, in_bn, gather):
     rel = (xa.grad - xb.grad).norm().item() / xb.grad.norm().item()
     err = (xa.grad - xb.grad).abs().max().item() / scale
     record_margin('fused tower d loss / d features: ||dx - dx_ref|| / ||dx_ref||', rel, 3e-2)
-    record_margin('fused tower d loss / d features: max-norm / max|dx_ref|', err, 1e-1)
-    # dx comes out of the MFMA kernel as bf16 (2^-9 per entry); behind an input BatchNormalization its mean and
-    # xhat-correlated parts are subtracted again, so single entries carry more of that rounding (8.3e-2 of max|dx| measured
-    # with the gather's doubled rows) while the tensor as a whole stays within 1.3 %
-    assert rel <= 3e-2 and err <= 1e-1, (rel, err)
+    # Round 6: the free-running comparison asserts the TENSOR norm only.  Its single-entry max norm
+    # (8.3e-2 of max|dx| with the gather's doubled rows) is ReLU gates falling differently in a forward without bf16
+    # rounding, needed a 10 % bar and could hide a regression of the backward arithmetic; the forward-pinned comparison
+    # above holds exactly that arithmetic to 2 % per entry.  The figure is still recorded with the session's margins.
+    record_margin('fused tower d loss / d features: max-norm / max|dx_ref| (recorded, not a gate)', err, float('inf'))
+    assert rel <= 3e-2, (rel, err)
     # the parameter gradients are what they were without the input gradient
     for n, a, b in zip([n for n, _ in tower.named_parameters()], g_params, [p.grad for p in tower.parameters()]):
         denom = b.norm().item() + 1e-6 * b.numel() ** 0.5

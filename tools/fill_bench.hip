@@ -12,6 +12,11 @@
 //   PATH 6  the same bytes with lane l taking row (l >> 3), 16-byte piece (l & 7): eight adjacent lanes = one 128-byte line
 //   PATH 7  lane l takes row (l >> 2), piece (l & 3): four adjacent lanes = one 64-byte segment (16 rows per instruction)
 //   PATH 8  lane l takes row (l >> 1), piece (l & 1): two adjacent lanes = 32 bytes (32 rows per instruction)
+//   PATH 9  HBM stream, 32 KB per step and workgroup with three steps in flight (the register ring of tower_gemm_rp.h), but the
+//           FOUR workgroups of a group (same XCD: slots 4 g .. 4 g + 3) read the SAME slice -- the four n-tile CUs of an M-tile:
+//           the unique bytes in flight are a quarter of the requested ones.  DEPTH here = the variant: 1 = as described,
+//           2 = every workgroup also touches (one dword per 128-byte line) its quarter of the lines 8 steps ahead,
+//           3 = no sharing (every workgroup its own slice): the reference
 // SRC 0: every workgroup streams its own slice of a 2 GiB buffer (HBM); SRC 1: every workgroup re-reads one 512 KB panel
 // (L2 resident after the first pass).  DEPTH = steps in flight (vmcnt-counted, 1..3).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/fill_bench tools/fill_bench.hip && tools/fill_bench
@@ -115,6 +120,34 @@ __global__ __launch_bounds__(512, 1) void fill_kernel(const unsigned char* __res
     }
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) use(r[d]);
+  } else if (PATH == 9) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, grp = slot >> 2, tn = slot & 3;
+    const unsigned char* gb = src + (long)((DEPTH == 3 ? (int)blockIdx.x : (xcd * 8 + grp) * 4)) * wg_stride;   // the slice (shared by the group unless DEPTH == 3)
+    uint4 r[3][4];
+    uint32_t tacc = 0;
+    auto load = [&](int s, uint4 (&d)[4]) __attribute__((always_inline)) {
+      const unsigned char* sb = gb + (long)(s % wrap) * (STEP / 2) + wave * 4 * PIECE + lane * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[i] = *reinterpret_cast<const uint4*>(sb + i * PIECE);
+    };
+    auto use = [&](uint4 (&d)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc.x ^= d[i].x; acc.y ^= d[i].y; acc.z ^= d[i].z; acc.w ^= d[i].w; }
+    };
+    load(0, r[0]); load(1, r[1]); load(2, r[2]);
+    for (int s = 0; s < n_steps; s += 3) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (DEPTH == 2 && ((s + d) & 7) == 0) {
+          // 8 steps = 256 KB of the slice = 2048 lines; this workgroup's quarter = 512 lines = 8 waves x 64 lanes: one dword each
+          const int line = (wave * 64 + lane) * 4 + tn;
+          tacc ^= *reinterpret_cast<const uint32_t*>(gb + (long)(((s + d) / 8 + 1) * 8 % wrap) * (STEP / 2) + (long)line * 128);
+        }
+        use(r[d]); load(s + d + 3, r[d]);
+      }
+    }
+    use(r[0]); use(r[1]); use(r[2]);
+    acc.x ^= tacc;
   } else {                                    // PATH 3 / 4: 32 KB direct (4 loads per lane) + 32 KB panel by LDS-DMA (4 pieces per wave)
     uint4 r[3][4];
     auto load = [&](int s, uint4 (&d)[4]) __attribute__((always_inline)) {
@@ -182,17 +215,19 @@ int main() {
   const char* pn[] = {"LDS-DMA (global_load_lds_dwordx4)", "global_load_dwordx4 -> VGPR", "global_load_dwordx4 -> VGPR -> ds_write_b128",
                       "half direct (stream) + half LDS-DMA (L2 panel)", "  + every wave reads the 32 KB panel stage",
                       "dwordx4 -> VGPR, MFMA operand layout (32 KB / step)", "dwordx4 -> VGPR, 8 lanes per 128-B line (32 KB / step)",
-                      "dwordx4 -> VGPR, 4 lanes per 64-B segment (32 KB / step)", "dwordx4 -> VGPR, 2 lanes per 32 B (32 KB / step)"};
+                      "dwordx4 -> VGPR, 4 lanes per 64-B segment (32 KB / step)", "dwordx4 -> VGPR, 2 lanes per 32 B (32 KB / step)",
+                      "ring of 3 x 32 KB, 4 CUs share a slice (1) + touch ahead (2) / own slice (3)"};
   printf("%-52s %-4s %5s %9s %10s %12s %10s\n", "path", "src", "depth", "ms", "TB/s chip", "GB/s per CU", "B/clk/CU@2.4");
 #define RUN(P, D, SRCK) { \
     CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&fill_kernel<P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STEP)); \
     const bool hbm = (SRCK) == 0; \
     const long stride = hbm ? total / WGS : 0;                  /* L2: every workgroup re-reads the same 512 KB */ \
     const int per_step = (P >= 3) ? STEP / 2 : STEP;            /* streamed bytes per step */ \
+    const int p9 = (P == 9); \
     const int wrap = hbm ? (int)(stride / per_step) : (512 * 1024) / per_step; \
-    const int n_steps = hbm ? ((P >= 3) ? wrap / 2 : wrap) / 6 * 6 : 6000; \
+    const int n_steps = hbm ? (p9 ? wrap - 24 : ((P >= 3) ? wrap / 2 : wrap)) / 6 * 6 : 6000; \
     double ms = time_ms([&] { hipLaunchKernelGGL((fill_kernel<P, D>), dim3(WGS), dim3(512), 2 * STEP, 0, hbm ? src : panel, stride, wrap, n_steps, panel, out); }); \
-    const double bytes = (double)WGS * n_steps * ((P >= 5) ? STEP / 2 : STEP); \
+    const double bytes = (double)WGS * n_steps * ((P >= 5) ? STEP / 2 : STEP) / ((P == 9 && D != 3) ? 4 : 1);   /* PATH 9: UNIQUE bytes */ \
     printf("%-52s %-4s %5d %9.4f %10.3f %12.1f %10.1f\n", pn[P], hbm ? "HBM" : "L2", D, ms, bytes / ms / 1e9, bytes / ms / 1e6 / WGS, bytes / (ms * 1e-3) / WGS / 2.4e9); }
   RUN(0, 1, 0) RUN(0, 2, 0) RUN(0, 1, 1) RUN(0, 2, 1)
   RUN(1, 1, 0) RUN(1, 2, 0) RUN(1, 3, 0) RUN(1, 1, 1) RUN(1, 2, 1) RUN(1, 3, 1)
@@ -201,5 +236,6 @@ int main() {
   RUN(4, 2, 0) RUN(4, 3, 0) RUN(4, 3, 1)
   RUN(5, 1, 1) RUN(5, 2, 1) RUN(5, 3, 1) RUN(6, 1, 1) RUN(6, 2, 1) RUN(6, 3, 1)
   RUN(7, 1, 1) RUN(7, 2, 1) RUN(8, 1, 1) RUN(8, 2, 1)
+  RUN(9, 3, 0) RUN(9, 1, 0) RUN(9, 2, 0) RUN(9, 3, 0) RUN(9, 1, 0) RUN(9, 2, 0)
   return 0;
 }

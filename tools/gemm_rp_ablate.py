@@ -17,8 +17,12 @@ NAMES = {16: 'full + stamps', 0: 'full', 1: 'no A loads', 2: 'no epilogue', 3: '
          4: 'no MFMA', 6: 'loads + panel reads only', 9: 'MFMA + epilogue', 10: 'loads + MFMA'}
 
 
+TAG = os.environ.get('TAG', '')
+EXTRA = os.environ.get('EXTRA', '').split()
+
+
 def lib_path(mask):
-    return os.path.join(OUT, 'libtower_rp%d.so' % mask)
+    return os.path.join(OUT, 'libtower_rp%d%s.so' % (mask, TAG))
 
 
 def build():
@@ -26,7 +30,7 @@ def build():
 
     def one(mask):
         cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-shared', '-fPIC', '-I', os.path.join(ROOT, 'include'),
-               '-DTFR_RP_ABLATE=%d' % mask, SRC, '-o', lib_path(mask)]
+               '-DTFR_RP_ABLATE=%d' % mask, *EXTRA, SRC, '-o', lib_path(mask)]
         subprocess.run(cmd, check=True)
         return mask
     with ThreadPoolExecutor(int(os.environ.get('JOBS', '4'))) as ex:

@@ -52,8 +52,17 @@ def main():
             for rp in ('0', '1', '0', '1'):
                 os.environ['TFR_GEMM_RP'] = rp
                 row.append(timeit(fn))
-            print('M=%d %-32s RP=0 %.4f / %.4f ms   RP=1 %.4f / %.4f ms   (%.0f -> %.0f TFLOP/s, x%.2f)' % (
-                M, name, row[0], row[2], row[1], row[3], flops / min(row[0], row[2]) / 1e9, flops / min(row[1], row[3]) / 1e9,
+            os.environ['TFR_GEMM_RP_ROT'] = '0'
+            norot = timeit(fn)
+            os.environ.pop('TFR_GEMM_RP_ROT')
+            stag = []
+            for u in os.environ.get('STAGGERS', '0,2,4,6,8,12').split(','):
+                os.environ['TFR_GEMM_RP_STAGGER'] = u
+                stag.append('%s: %.4f' % (u, timeit(fn)))
+            os.environ.pop('TFR_GEMM_RP_STAGGER')
+            print('      stagger units -> ms   ' + '   '.join(stag))
+            print('M=%d %-32s RP=0 %.4f / %.4f ms   RP=1 %.4f / %.4f ms [same k order: %.4f]  (%.0f -> %.0f TFLOP/s, x%.2f)' % (
+                M, name, row[0], row[2], row[1], row[3], norot, flops / min(row[0], row[2]) / 1e9, flops / min(row[1], row[3]) / 1e9,
                 min(row[0], row[2]) / min(row[1], row[3])), flush=True)
 
 
