@@ -34,6 +34,7 @@
 #include "../../include/tfr_hip.h"
 
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 using namespace tfr;
@@ -1342,6 +1343,7 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 }
 
 #include "tower_gemm_rp.h"
+#include "tower_gemm_bs.h"
 
 #if (TFR_RP_ABLATE & 16)
 }  // namespace
@@ -1355,7 +1357,11 @@ namespace {
 #ifdef TFR_RP_DEV
 // developer aid: `hipcc -DTFR_RP_DEV=P,E,D,NK -S tower.hip` compiles ONE instantiation of the resident-panel kernel (20 s instead
 // of the 2.5 min of the whole translation unit) for reading its ISA / register use
+#ifdef TFR_BS_DEV
+template __global__ void tower_gemm_bs_kernel<TFR_BS_DEV>(const GemmArgs);
+#else
 template __global__ void tower_gemm_rp_kernel<TFR_RP_DEV>(const GemmArgs);
+#endif
 }  // namespace
 #else
 
@@ -2262,6 +2268,43 @@ static bool gemm_rp_shape_ok(int M, int N, int K, long lda, long ldb, long ldc, 
 
 template <int PRO, int EPI> int launch_gemm_rest(const GemmArgs& g, hipStream_t st);
 
+// Round 6: the weight-stationary kernel (tower_gemm_bs.h) for the forms without a prologue.  TFR_GEMM_BS=0 / 1.
+static bool gemm_bs_shape_ok(int M, int N, int K, long lda, long ldb, long ldc, long ldz) {
+  const char* e_bs = getenv("TFR_GEMM_BS");
+  const char* e_mt = getenv("TFR_GEMM_BS_MIN_TILES");
+  const int env_bs = (e_bs && *e_bs) ? atoi(e_bs) : 0;
+  const int min_tiles = (e_mt && *e_mt) ? atoi(e_mt) : 2048;         // (64 x 256 tiles: eight per CU)
+  if (!env_bs || (N % BS_BN) != 0 || K != 512) return false;
+  const int tiles_n = N / BS_BN;
+  if (tiles_n > 32 || (32 % tiles_n) != 0) return false;
+  if ((long)(M / BS_BM) * tiles_n < min_tiles) return false;
+  return lda < (1L << 21) && ldb < (1L << 21) && ldc < (1L << 21) && ldz < (1L << 21);
+}
+
+template <int EPI>
+int launch_gemm_bs(const GemmArgs& g0, hipStream_t st) {
+  constexpr bool BWD = EPI == EPI_RELU_BWD;
+  GemmArgs g = g0;
+  const int m_full = (g0.M / BS_BM) * BS_BM;
+  g.M = m_full; g.tiles_m = m_full / BS_BM; g.tiles_n = g.N / BS_BN; g.flags = 0;
+  const bool drop = BWD && g.epi_drop.thr;
+  const bool drop16 = drop && g.epi_drop.lge == 1u;
+  constexpr int D = BWD ? 5 : 7;                    // stages in flight (16 KB each); the dgrad's epilogue operations limit the counted waits to 5
+  auto fn = !drop ? tower_gemm_bs_kernel<EPI, 0, D> : (drop16 ? tower_gemm_bs_kernel<EPI, 3, D> : tower_gemm_bs_kernel<EPI, 1, D>);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, BS_LDS);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(fn, dim3(256), dim3(256), BS_LDS, st, g);
+  int rc = (int)hipGetLastError();
+  if (rc != 0 || m_full == g0.M) return rc;
+  GemmArgs t = g0;                                  // the last M - m_full (< 64) rows
+  t.A = g0.A + (long)m_full * g0.lda; t.C = g0.C + (long)m_full * g0.ldc;
+  if (g0.Zp) t.Zp = g0.Zp + (long)m_full * g0.ldz;
+  if (g0.stats) t.stats = g0.stats + (long)(m_full / 64) * 2 * g0.N;
+  t.M = g0.M - m_full; t.row0 = g0.row0 + m_full;
+  t.tiles_m = (t.M + BM - 1) / BM; t.tiles_n = (t.N + BN - 1) / BN;
+  return launch_gemm_rest<PRO_NONE, EPI>(t, st);
+}
+
 template <int PRO, int EPI>
 int launch_gemm_rp(const GemmArgs& g0, hipStream_t st) {
   constexpr bool BWD = EPI == EPI_RELU_BWD || EPI == EPI_ACT_BWD;
@@ -2309,6 +2352,10 @@ template <int PRO, int EPI>
 int launch_gemm(const GemmArgs& g, hipStream_t st) {
   // the forms a BatchNorm + ReLU tower runs: hidden-layer forward (2, 1), its dgrad (0, 2), plain products (0, 0), (0, 1)
   constexpr bool rp_form = (PRO == PRO_AFFINE_RELU && EPI == EPI_STATS) || (PRO == PRO_NONE && EPI <= EPI_RELU_BWD);
+  if constexpr (PRO == PRO_NONE && (EPI == EPI_PLAIN || EPI == EPI_RELU_BWD)) {
+    if (g.Aout == nullptr && gemm_bs_shape_ok(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldz) && !(EPI == EPI_RELU_BWD && g.bias))
+      return launch_gemm_bs<EPI>(g, st);
+  }
   if constexpr (rp_form) {
     if (gemm_rp_shape_ok(g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldz) && !(EPI == EPI_RELU_BWD && g.bias) &&
         (g.Aout == nullptr || ((g.M % RP_BM) == 0 && PRO != PRO_NONE)))

@@ -28,7 +28,7 @@
 // tiles; the launcher sends the last M % 512 rows through the older kernels.
 constexpr int RP_BM = 512, RP_BN = 128, RP_RING = 4;
 #ifndef TFR_RP_QA
-#define TFR_RP_QA 2
+#define TFR_RP_QA 1
 #endif
 constexpr int RP_QA = TFR_RP_QA;
 // developer aid (tools/gemm_rp_ablate.py; results are garbage, timing only): 1 no activation loads inside the k loop,

@@ -18,6 +18,7 @@ def rp_everywhere(monkeypatch):
     """the launcher only picks the resident-panel kernel from ~two tiles per CU; the tests run it from one tile"""
     monkeypatch.setenv('TFR_GEMM_RP_MIN_TILES', '1')
     monkeypatch.setenv('TFR_GEMM_RP', '1')
+    monkeypatch.setenv('TFR_GEMM_RP_ROT', '0')      # every n-tile in the round-5 k order: the bit-identity below (the rotated order: test_rotated_k_order)
     yield monkeypatch
 
 
@@ -117,6 +118,22 @@ def test_dgrad_relu_backward_epilogue(M, N, rate, rp_everywhere):
     assert (s[1] - (want * zhat).sum(dim=0)).abs().max().item() <= lim * max(1.0, zhat.abs().max().item())
 
 
+def test_rotated_k_order(rp_everywhere):
+    """the default: n-tile tn works through the k blocks rotated by tn * NK / tiles_n (its neighbours' L2 traffic instead of
+    four simultaneous HBM misses per line) -- another fp32 summation order: C within a bf16 ulp of the unrotated kernel,
+    identical for n-tile 0"""
+    t = T()
+    M, N, K = 4096, 512, 512
+    A, W = _operands(M, N, K, 700)
+    C0, _ = t.gemm(A, W, N, K)
+    rp_everywhere.delenv('TFR_GEMM_RP_ROT')
+    C1, _ = t.gemm(A, W, N, K)
+    assert torch.equal(C0[:, :128].view(torch.int16), C1[:, :128].view(torch.int16))
+    assert not torch.equal(C0.view(torch.int16), C1.view(torch.int16))
+    bf16_close(C1, A.float() @ W.float().t(), 'C (rotated k order)')
+    assert (C1.float() - C0.float()).abs().max().item() <= 2.0 ** -7 * C0.float().abs().max().item()
+
+
 def test_strided_operands_and_row_offsets(rp_everywhere):
     """pitches larger than the logical widths (views of wider buffers), as the tower passes them"""
     t = T()
@@ -129,3 +146,61 @@ def test_strided_operands_and_row_offsets(rp_everywhere):
     C, _ = t.gemm(Abuf[:, :K], Wbuf[:, :K], N, K, out=out[:, :N])
     bf16_close(C, A0.float() @ W0.float().t(), 'C (strided)')
     assert bool((out[:, N:] == 0).all())
+
+
+# ------------------------------------------------------------------ the weight-stationary kernel (csrc/tower_gemm_bs.h)
+@pytest.fixture
+def bs_everywhere(monkeypatch):
+    monkeypatch.setenv('TFR_GEMM_BS_MIN_TILES', '1')
+    monkeypatch.setenv('TFR_GEMM_BS', '1')
+    monkeypatch.setenv('TFR_GEMM_RP', '0')
+    yield monkeypatch
+
+
+@pytest.mark.parametrize('M,N', [(64, 256), (64 * 9, 512), (51200 + 30, 512), (4096 + 63, 1024), (64 * 257, 256)])
+def test_bs_plain_against_fp32_and_the_round5_kernels(M, N, bs_everywhere):
+    """plain products (with and without a bias): same k order per accumulator as the round-5 kernels -> the same bits"""
+    t = T()
+    K = 512
+    A, W = _operands(M, N, K, 500 + N)
+    bias = rnd((N,), 3, 0.2).to(DEV)
+    for b in (None, bias):
+        C, none = t.gemm(A, W, N, K, bias=b)
+        assert none is None
+        bs_everywhere.setenv('TFR_GEMM_BS', '0')
+        C0, _ = t.gemm(A, W, N, K, bias=b)
+        bs_everywhere.setenv('TFR_GEMM_BS', '1')
+        assert torch.equal(C.view(torch.int16), C0.view(torch.int16)), 'C differs from the round-5 kernels'
+        bf16_close(C, A.float() @ W.float().t() + (0 if b is None else b), 'C')
+
+
+@pytest.mark.parametrize('rate', [0.0, 0.5, 0.1])
+@pytest.mark.parametrize('M,N', [(64, 256), (51200 + 300, 512), (64 * 40, 1024)])
+def test_bs_dgrad_relu_backward_epilogue(M, N, rate, bs_everywhere):
+    t = T()
+    K = 512
+    A, W = _operands(M, N, K, 600 + N)
+    Zp = rnd((M, N), 42).to(DEV).to(torch.bfloat16)
+    es = (rnd((N,), 43) * 0.5 + 1.0).to(DEV); eh = rnd((N,), 44, 0.3).to(DEV)
+    em = rnd((N,), 45, 0.2).to(DEV); er = (rnd((N,), 46).abs() + 0.5).to(DEV)
+    d = t.Dropout.make(rate, 99) if rate > 0 else None
+    kw = dict(prologue=t.PRO_NONE, epilogue=t.EPI_RELU_BWD, Zp=Zp, e_scale=es, e_shift=eh, e_mean=em, e_rstd=er, epi_dropout=d)
+    C, stats = t.gemm(A, W, N, K, **kw)
+    bs_everywhere.setenv('TFR_GEMM_BS', '0')
+    C0, stats0 = t.gemm(A, W, N, K, **kw)
+    bs_everywhere.setenv('TFR_GEMM_BS', '1')
+    assert torch.equal(C.view(torch.int16), C0.view(torch.int16)), 'dy differs from the round-5 kernels'
+    assert stats.shape == stats0.shape == (t.stats_rows(M), 2, N)
+    scale = stats0.abs().amax(dim=0, keepdim=True).clamp_min(1.0)
+    assert ((stats - stats0).abs() / scale).max().item() <= 4e-6
+    z = Zp.float()
+    want = A.float() @ W.float().t()
+    if d is not None:
+        want = want * t.dropout_mask(d, M, N, DEV)
+    want = want * ((z * es + eh) > 0).float()
+    bf16_close(C, want, 'dy')
+    s = stats.sum(dim=0)
+    zhat = (z - em) * er
+    lim = 4e-3 * max(1.0, want.abs().max().item()) * M ** 0.5 + 1e-2
+    assert (s[0] - want.sum(dim=0)).abs().max().item() <= lim
+    assert (s[1] - (want * zhat).sum(dim=0)).abs().max().item() <= lim * max(1.0, zhat.abs().max().item())

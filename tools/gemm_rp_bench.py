@@ -52,11 +52,17 @@ def main():
             for rp in ('0', '1', '0', '1'):
                 os.environ['TFR_GEMM_RP'] = rp
                 row.append(timeit(fn))
+            os.environ['TFR_GEMM_RP'] = '0'
+            os.environ['TFR_GEMM_BS'] = '1'
+            bs = [timeit(fn), timeit(fn)]
+            os.environ['TFR_GEMM_BS'] = '0'
+            print('      weight-stationary (TFR_GEMM_BS=1; only the forms without a prologue take it): %.4f / %.4f ms  (%.0f TFLOP/s)' % (
+                bs[0], bs[1], flops / min(bs) / 1e9))
             os.environ['TFR_GEMM_RP_ROT'] = '0'
             norot = timeit(fn)
             os.environ.pop('TFR_GEMM_RP_ROT')
             stag = []
-            for u in os.environ.get('STAGGERS', '0,2,4,6,8,12').split(','):
+            for u in os.environ.get('STAGGERS', '0,4').split(','):
                 os.environ['TFR_GEMM_RP_STAGGER'] = u
                 stag.append('%s: %.4f' % (u, timeit(fn)))
             os.environ.pop('TFR_GEMM_RP_STAGGER')
