@@ -294,14 +294,24 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
             loss = ra.keras.losses.ApproxNDCGLoss()
     scorer.train()
     D.broadcast_module(scorer)                             # ... and made so explicitly, like the pipeline does
-    bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2, flatten_params=True)
+    _, world = D.world()
+    # N > 1 (or TFR_BENCH_SPLIT=1 at N = 1: the same control flow without the collectives): the gradient exchange overlaps the
+    # backward -- distributed.SplitStep: the bucket holds the gradients in completion order, the output layer's and the upper
+    # hidden layers' all-reduce runs on a side stream under the backward of the layers below (round 6)
+    split = int(os.environ.get('TFR_BENCH_SPLIT', '1' if world > 1 else '0'))
+    if split and use_graph and not os.environ.get('TFR_NO_INPLACE_GRADS'):
+        order, early_numel = D.completion_order(scorer, split)
+        bucket = D.FlatGradBucket(order, n_scalars=2, flatten_params=True)
+    else:
+        split, early_numel = 0, 0
+        bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2, flatten_params=True)
     if not os.environ.get('TFR_NO_INPLACE_GRADS'):
         bucket.attach(scorer)
     lr = 0.01
-    _, world = D.world()
 
-    def fwd_bwd():
-        bucket.zero()
+    def fwd_bwd(zero=True):
+        if zero:
+            bucket.zero()
         logits = run_scorer()
         value, dlogits = loss.loss_and_grad(labels, logits.detach())
         logits.backward(dlogits)                           # scorer backward, grads land in the flat bucket
@@ -344,6 +354,19 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         info.update(step=eager_step, all_reduce=lambda: bucket.all_reduce(scal, average=True))
         return info
 
+    if split:
+        ss = D.SplitStep(scorer, bucket, early_numel, split, lambda: fwd_bwd(zero=False), sgd, average=True,
+                         graph_generators=graph_generators)
+
+        def split_step():
+            return ss()[0] / max(world, 1)
+
+        def both_collectives():
+            bucket.all_reduce_range(0, early_numel, True)
+            bucket.all_reduce_range(early_numel, bucket.flat.numel(), False)
+        info.update(step=split_step, all_reduce=both_collectives, compute_only=ss.compute_only, overlap_split=split,
+                    all_reduce_early_bytes=int(early_numel * 4), keep_alive=(ss, fwd_bwd, sgd))
+        return info
     # hipGraph capture of the launch-bound parts: [zero, scorer fwd, loss, scorer bwd] and [SGD];
     # the ONE all-reduce of the flat bucket stays between the two replays (RCCL, eager).
     side = torch.cuda.Stream()
@@ -762,8 +785,13 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
                                 'not change between steps -- evaluation, device-resident epochs); round 5 reported this as `value`'}
         info['keep_alive_c'] = (step_c, ready)
     all_reduce_ms = None
+    exposed_ms = None
     if is_e2e:
         all_reduce_ms = 1e3 * _timed_loop(info['all_reduce'], steps, dist) / steps if world > 1 else 0.0
+        if info.get('compute_only') is not None:           # the same graphs without the collectives: what the exchange adds
+            for _ in range(warmup):
+                info['compute_only']()
+            exposed_ms = max(0.0, 1e3 * (elapsed - _timed_loop(info['compute_only'], steps, dist)) / steps)
     e_drop0 = None
     if is_e2e and dropout > 0.0 and args.dropout is None:
         # the same step without Dropout (what rounds 1-2 timed), beside the reference-default number: every rank
@@ -888,8 +916,11 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         result['all_reduce'] = {'ms': all_reduce_ms, 'bytes': info['all_reduce_bytes'], 'params': info['params'],
                                 'frac_of_step': (all_reduce_ms / ms_per_step) if ms_per_step else None,
                                 'compute_ms': ms_per_step - all_reduce_ms,
-                                'note': 'the step\'s ONE collective (flat fp32 gradient bucket + 2 scalars) timed '
-                                        'alone over the same number of iterations; 0 at N = 1 (no collective issued)'}
+                                'exposed_ms': exposed_ms, 'overlap_split': info.get('overlap_split'),
+                                'early_bytes': info.get('all_reduce_early_bytes'),
+                                'note': 'the step\'s collective(s) timed alone over the same number of iterations (0 at N = 1: none issued).  With overlap_split = k '
+                                        'the bucket is exchanged in two parts: the output layer + hidden layers >= k on a side stream under the backward '
+                                        'of the layers below, the rest (+ 2 scalars) after it; exposed_ms = step - the same graphs without collectives'}
     if not args.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only (bounded sample)
         base_name = HBM_VARIANTS[name][0] if name in HBM_VARIANTS else name
         try:

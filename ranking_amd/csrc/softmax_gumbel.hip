@@ -610,8 +610,16 @@ template <> struct SegOps<16> {      // totals of the four 16-lane rows
   }
 };
 
-template <int LG, int IPL, bool NT, bool LW, int D>      // D groups of lists in flight per wavefront (TFR_SOFTMAX_PACK_DEPTH)
+// V4 (round 6; list_size % 4 == 0, 16-byte aligned rows, IPL == 4): lane sl owns the four ADJACENT items
+// 4 sl .. 4 sl + 3 and moves them as ONE 16-byte access per array -- 25 lanes x 16 B for list_size 100 -- instead of four
+// dword accesses (items sl, sl + LG, ...).  The texture addresser takes a wave's dword access in the same 16 cycles as a
+// dwordx4 one (four lanes per cycle, tools/fill_bench.hip): per list 12 wave-instructions of address processing become 3.
+// The sums of a list run over another item order than without V4 (same few-ulp distance to the fp64 arbiter).
+typedef float sm_f4 __attribute__((ext_vector_type(4)));
+
+template <int LG, int IPL, bool NT, bool LW, int D, bool V4 = false>      // D groups of lists in flight per wavefront (TFR_SOFTMAX_PACK_DEPTH)
 __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B) {
+  static_assert(!V4 || IPL == 4, "V4: four adjacent items per lane");
   constexpr int S = 64 / LG;                              // lists per wavefront
   const int lane = threadIdx.x & 63;
   const int seg = lane / LG, sl = lane % LG;
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
   int off[IPL];
   bool in[IPL];
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) { const int i = sl + LG * r; in[r] = i < L; off[r] = in[r] ? i : 0; }
+  for (int r = 0; r < IPL; ++r) { const int i = V4 ? 4 * sl + r : sl + LG * r; in[r] = i < L; off[r] = in[r] ? i : 0; }
   float lab_n[D][IPL], x_n[D][IPL], wl_n[D];              // (LW: one weight per list, item_weights[b])
   auto fetch = [&](const int d, int gg) {
     gg = gg < G ? gg : (wave_id < G ? wave_id : 0);        // a group past the end re-reads the wavefront's first one
@@ -635,6 +643,16 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
     // pointer + a 32-bit lane offset -- `global_load_dword v, v_off, s[base:base+1]` -- instead of a 64-bit address per
     // lane and item: 16 v_lshl_add_u64 + their moves per group of lists were address arithmetic)
     const uint32_t row = (uint32_t)bl * (uint32_t)L;
+    if constexpr (V4) {                                    // (list_size % 4 == 0: a lane's four items are all inside or all outside)
+      const uint32_t boff = (row + (uint32_t)off[0]) * 4u;
+      const sm_f4* pl = reinterpret_cast<const sm_f4*>(reinterpret_cast<const char*>(a.labels) + boff);
+      const sm_f4* px = reinterpret_cast<const sm_f4*>(reinterpret_cast<const char*>(a.logits) + boff);
+      const sm_f4 l4 = NT ? __builtin_nontemporal_load(pl) : *pl;
+      const sm_f4 x4 = NT ? __builtin_nontemporal_load(px) : *px;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { lab_n[d][r] = l4[r]; x_n[d][r] = x4[r]; }
+      return;
+    }
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
       const uint32_t boff = (row + (uint32_t)off[r]) * 4u;
@@ -707,15 +725,23 @@ __global__ __launch_bounds__(256) void softmax_pack_kernel(const SmArgs a, int B
       loss += a.poly_eps * (1.0f - pt);
     }
     if (have && sl == 0) { a.loss[b] = loss; a.weight[b] = lsum; wacc = __builtin_fmaf(loss, lsum, wacc); }
+    sm_f4 g4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < IPL; ++r) {
       const float sm = e[r] * inv_e;
       float dd = ptot * sm - y[r];
       if (a.poly_eps != 0.0f) dd -= a.poly_eps * sm * (y[r] - pt);
       const float gv = mv[r] ? (lsum * inv_t) * dd : 0.0f;
+      if constexpr (V4) { g4[r & 3] = gv; continue; }
       if (have && in[r]) {
         float* pd = reinterpret_cast<float*>(reinterpret_cast<char*>(a.dlogits) + ((uint32_t)b * (uint32_t)L + (uint32_t)off[r]) * 4u);
         if (NT) __builtin_nontemporal_store(gv, pd); else *pd = gv;
+      }
+    }
+    if constexpr (V4) {
+      if (have && in[0]) {
+        sm_f4* pd = reinterpret_cast<sm_f4*>(reinterpret_cast<char*>(a.dlogits) + ((uint32_t)b * (uint32_t)L + (uint32_t)off[0]) * 4u);
+        if (NT) __builtin_nontemporal_store(g4, pd); else *pd = g4;
       }
     }
   };
@@ -867,6 +893,16 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
                                  else hipLaunchKernelGGL((softmax_pack_kernel<G_, I_, N_, W_, 1>), dim3(grid), dim3(256), 0, st, a, B); } while (0)
 #define SPK2(G_, I_, N_) do { if (item_weights) SPK3(G_, I_, N_, true); else SPK3(G_, I_, N_, false); } while (0)
 #define SPK(G_, I_) do { if (nt) SPK2(G_, I_, true); else SPK2(G_, I_, false); } while (0)
+      static const int env_v4 = [] { const char* e = getenv("TFR_SOFTMAX_V4"); return (e && *e) ? atoi(e) : 1; }();
+      const bool v4 = env_v4 && (L % 4) == 0 && ((((uintptr_t)logits | (uintptr_t)labels | (uintptr_t)dlogits_out) & 15u) == 0);
+#define SPV3(G_, N_, W_) do { if (env_pdepth >= 2) hipLaunchKernelGGL((softmax_pack_kernel<G_, 4, N_, W_, 2, true>), dim3(grid), dim3(256), 0, st, a, B); \
+                              else hipLaunchKernelGGL((softmax_pack_kernel<G_, 4, N_, W_, 1, true>), dim3(grid), dim3(256), 0, st, a, B); } while (0)
+#define SPV(G_) do { if (nt) { if (item_weights) SPV3(G_, true, true); else SPV3(G_, true, false); } \
+                     else { if (item_weights) SPV3(G_, false, true); else SPV3(G_, false, false); } } while (0)
+      if (v4 && L <= 64) { SPV(16); return (int)hipGetLastError(); }                       // 16 lanes x 4 adjacent items
+      if (v4 && L <= 128 && sm_pack_lg() != 16) { SPV(32); return (int)hipGetLastError(); } // 32 lanes x 4 adjacent items
+#undef SPV
+#undef SPV3
       if (L <= 16) SPK(16, 1); else if (L <= 32) SPK(16, 2); else if (L <= 64) SPK(16, 4);
       else if (sm_pack_lg() == 16) { if (L <= 112) SPK(16, 7); else if (L <= 128) SPK(16, 8); else if (L <= 208) SPK(16, 13); else SPK(16, 16); }
       else if (L <= 128) SPK(32, 4); else SPK(32, 8);

@@ -72,6 +72,34 @@ def all_reduce_scalars(values: Sequence, device, average: bool = False, group=No
     return [float(x) for x in buf.tolist()]
 
 
+def completion_order(module: torch.nn.Module, split: int):
+    """(params in the order their gradients become final in a backward, number of elements of the EARLY part).
+    Early = the output layer and the hidden layers >= `split` of every FusedTower in `module` (what
+    FusedTower.grad_split_hook announces); late = everything else (hidden layers < split, parameters outside a fused
+    tower).  A FlatGradBucket built on this order holds the early gradients as one contiguous prefix: their all-reduce can
+    run while the rest of the backward computes."""
+    from .tower import FusedTower
+    early, late, seen = [], [], set()
+    for m in module.modules():
+        if not isinstance(m, FusedTower):
+            continue
+        n_h = len(m.hidden_layer_dims)
+        if not 1 <= split < n_h:
+            raise ValueError('split must be in [1, %d), got %d' % (n_h, split))
+        for l in range(n_h - 1, -1, -1):
+            group = [m.weights[l], m.biases[l]] + ([m.gammas[l], m.betas[l]] if m.use_batch_norm else [])
+            (early if l >= split else late).extend(group)
+        early[0:0] = [m.out_weight, m.out_bias]
+        if m.input_batch_norm:
+            late.extend([m.gamma_in, m.beta_in])
+    for p in early + late:
+        seen.add(id(p))
+    late.extend(p for p in module.parameters() if id(p) not in seen)
+    early = [p for p in early if p.requires_grad]
+    late = [p for p in late if p.requires_grad]
+    return early + late, sum(p.numel() for p in early)
+
+
 class FlatGradBucket:
     """Re-homes every parameter's ``.grad`` into one contiguous fp32 buffer with
     ``n_scalars`` extra slots at its end, so a step needs exactly one all-reduce."""
@@ -144,6 +172,155 @@ class FlatGradBucket:
 
     def scale_grads(self, factor):
         self.flat[:self.numel].mul_(factor)
+
+    def all_reduce_range(self, lo: int, hi: int, average: bool = False) -> None:
+        """The collective of one contiguous part of the bucket, on the CURRENT stream (a view of the flat buffer: no copy)."""
+        _, w = world()
+        if w <= 1 or hi <= lo:
+            return
+        part = self.flat[lo:hi]
+        dist.all_reduce(part, group=self.group)
+        if average:
+            part.div_(w)
+
+
+class SplitStep:
+    """A data-parallel training step whose gradient exchange overlaps the backward (round 6).
+
+        zero | forward | loss | backward of the output layer and the hidden layers >= split        <- part A (one hipGraph)
+        all-reduce of the early gradients on a SIDE stream  ||  backward of the layers < split     <- part B (one hipGraph)
+        all-reduce of the late gradients + the step's scalars | wait for the side stream | optimizer  (one hipGraph)
+
+    The cut inside the backward is FusedTower.grad_split_hook: during capture the hook ends graph A and begins graph B (same
+    memory pool: B consumes what A produced).  At world size 1 no collective is issued and the three graphs replay back to
+    back -- the same launches in the same order as the single-graph step: bit-identical parameters.  The reference's
+    MirroredStrategy overlaps per-variable all-reduces with the backward (keras/strategy_utils.py:87-116); here there are
+    exactly two collectives per step and the second one is 0.3 MB.
+
+    `fwd_bwd()` -> 0-d loss value: zeroes nothing itself (the bucket is zeroed here), runs forward, loss and
+    `logits.backward(...)`; `optimizer()` applies the update.  `scalars(value)` -> 1-D tensor of per-rank scalars summed
+    with the late part (default: [value, 1]).  `capture` = the context manager to capture with (bench.capture)."""
+
+    def __init__(self, module, bucket: 'FlatGradBucket', early_numel: int, split: int, fwd_bwd, optimizer, average=True,
+                 scalars=None, use_graph=True, capture=None, graph_generators=()):
+        from .tower import FusedTower
+        self.bucket, self.early, self.average = bucket, int(early_numel), average
+        self.towers = [m for m in module.modules() if isinstance(m, FusedTower)]
+        if len(self.towers) != 1:
+            raise ValueError('SplitStep needs exactly one FusedTower in the module, found %d' % len(self.towers))
+        self.tower = self.towers[0]
+        if not self.tower.accumulate_grads_in_place:
+            raise ValueError('SplitStep needs FlatGradBucket.attach(module) (gradients accumulated in place)')
+        self.tower.grad_split = int(split)
+        self.fwd_bwd, self.optimizer = fwd_bwd, optimizer
+        self.make_scalars = scalars or (lambda v: torch.stack([v, torch.ones_like(v)]))
+        self.side = torch.cuda.Stream()
+        self.use_graph = use_graph
+        self.value = None
+        self.static_scalars = None
+        self._hook_calls = 0
+        if use_graph:
+            self._capture(capture, graph_generators)
+
+    # -- eager form (also the warm-up of the capture)
+    def _eager(self):
+        _, w = world()
+        main = torch.cuda.current_stream()
+        ev = {}
+
+        def hook(_tower):
+            self._hook_calls += 1
+            if w > 1:
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self.bucket.all_reduce_range(0, self.early, self.average)
+        self.tower.grad_split_hook = hook
+        try:
+            self.bucket.zero()
+            value = self.fwd_bwd()
+        finally:
+            self.tower.grad_split_hook = None
+        s = self._late(self.make_scalars(value))
+        main.wait_stream(self.side)
+        self.optimizer()
+        return s
+
+    def _late(self, scalars):
+        _, w = world()
+        b = self.bucket
+        if w <= 1:
+            return scalars.reshape(-1)
+        b.scalars.copy_(scalars.reshape(-1))
+        b.all_reduce_range(self.early, b.flat.numel(), False)
+        if self.average:
+            b.flat[self.early:b.numel].div_(w)
+        return b.scalars.clone()
+
+    def _capture(self, capture, graph_generators):
+        main = torch.cuda.current_stream()
+        warm = torch.cuda.Stream()
+        warm.wait_stream(main)
+        with torch.cuda.stream(warm):
+            for _ in range(3):
+                self._eager()
+        main.wait_stream(warm)
+        torch.cuda.synchronize()
+        self.gA, self.gB, self.gO = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        for gen in graph_generators:
+            self.gA.register_generator_state(gen)
+        _, w = world()
+        # 'relaxed': graph A begins on this thread and ends on the autograd engine's device thread (where the backward -- and
+        # the split hook -- runs), graph B the other way round; the stricter modes tie a capture to the thread that began it
+        mode = 'relaxed'
+        cap_stream = torch.cuda.Stream()
+        cap_stream.wait_stream(main)
+        state = {'in_b': False}
+
+        def hook(_tower):                                   # ends graph A, begins graph B: in the middle of the backward
+            self._hook_calls += 1
+            self.gA.capture_end()
+            self.gB.capture_begin(pool=self.gA.pool(), capture_error_mode=mode)
+            state['in_b'] = True
+        self.tower.grad_split_hook = hook
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cap_stream):
+            self.gA.capture_begin(capture_error_mode=mode)
+            try:
+                self.bucket.zero()
+                self.value = self.fwd_bwd()
+                self.static_scalars = self.make_scalars(self.value)
+            finally:
+                self.tower.grad_split_hook = None
+                (self.gB if state['in_b'] else self.gA).capture_end()
+            if not state['in_b']:
+                raise RuntimeError('SplitStep: the backward never reached the split (is grad_split inside the tower?)')
+            self.gO.capture_begin(pool=self.gA.pool(), capture_error_mode=mode)
+            self.optimizer()
+            self.gO.capture_end()
+        main.wait_stream(cap_stream)
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        """one step; returns the (globally summed) scalars"""
+        if not self.use_graph:
+            return self._eager()
+        _, w = world()
+        main = torch.cuda.current_stream()
+        self.gA.replay()
+        if w > 1:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                self.bucket.all_reduce_range(0, self.early, self.average)
+        self.gB.replay()
+        s = self._late(self.static_scalars)
+        if w > 1:
+            main.wait_stream(self.side)
+        self.gO.replay()
+        return s
+
+    def compute_only(self):
+        """the same three graphs without the collectives (what the exposed time of the exchange is measured against)"""
+        self.gA.replay(); self.gB.replay(); self.gO.replay()
 
 
 def global_normalizer_step(bucket: FlatGradBucket, local_numerator: torch.Tensor,

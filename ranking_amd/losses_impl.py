@@ -621,11 +621,19 @@ class ListMLELambdaWeight(_LambdaWeight):
         return torch.ones_like(labels) * self._rank_discount_fn(ranks.to(torch.float32))
 
 
+_TIE_GEN = {'seed': None, 'gen': None}
+
+
 def _fresh_tie_seed() -> int:
-    """A new non-zero 31-bit tie seed per call from torch's default host generator: the sequence restarts with
-    torch.manual_seed, the role TF's graph-level seed plays for the op seed 37 of losses_impl.py:1558-1561.  (A host
-    draw: under hipGraph capture the seed of the captured step is replayed.)"""
-    return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+    """A new non-zero 31-bit tie seed per call from a PRIVATE host generator seeded from torch.initial_seed() (round 6,
+    ADVICE r5: drawing from torch's global generator perturbed the caller's own random streams -- dropout, shuffling -- by
+    one draw per loss call).  The sequence restarts when torch.manual_seed changes the initial seed: the role TF's
+    graph-level seed plays for the op seed 37 of losses_impl.py:1558-1561.  (A host draw: under hipGraph capture the seed
+    of the captured step is replayed -- pass ``seed`` for a fixed order, or re-capture.)"""
+    base = torch.initial_seed()
+    if _TIE_GEN['seed'] != base:
+        _TIE_GEN['seed'], _TIE_GEN['gen'] = base, torch.Generator().manual_seed((base ^ 0x5DEECE66D) & (2 ** 63 - 1))
+    return int(torch.randint(1, 2 ** 31 - 1, (1,), generator=_TIE_GEN['gen']).item())
 
 
 class ListMLELoss(_ListwiseLoss):

@@ -69,7 +69,8 @@ class _RankingMetric(object, metaclass=abc.ABCMeta):
         if not self.shuffle_ties:
             return 0
         if self.seed is None:
-            return int(torch.randint(1, 2 ** 31 - 1, (1,)).item())
+            from .losses_impl import _fresh_tie_seed      # a private generator: the caller's global random stream is not touched
+            return _fresh_tie_seed()
         return (int(self.seed) & 0x7fffffff) or 1
 
     @property

@@ -70,6 +70,23 @@ _FUSED_LAST_MIN_ELEMS = 1 << 25
 _AOUT_MODE = int(os.environ.get('TFR_TOWER_AOUT', '1'))
 
 
+def _grad_list(dW, db, dgam, dbet, use_bn, n_h, dw_out, db_out, extra):
+    """the gradients in the order of _TowerFn's `params` (weights, biases, [gammas, betas], [input BN], out weight / bias)"""
+    g = list(dW) + list(db)
+    if use_bn:
+        g += list(dgam) + list(dbet)
+    if extra:
+        g += list(extra)
+    return g + [dw_out, db_out]
+
+
+def _layer_of(j, n_h, use_bn):
+    """hidden layer a position of `params` belongs to (the output layer counts as n_h: it is final first); valid without an
+    input BatchNormalization"""
+    per = 4 if use_bn else 2
+    return j % n_h if j < per * n_h else n_h
+
+
 class _TowerFn(torch.autograd.Function):
     """forward(x, training, tower, *params) -> logits [M, O] (fp32)."""
 
@@ -198,6 +215,10 @@ class _TowerFn(torch.autograd.Function):
             p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous() for p in params)
         dW, db = [None] * n_h, [None] * n_h
         dgam, dbet = [None] * n_h, [None] * n_h
+        split = int(getattr(tower, 'grad_split', 0) or 0) if direct else 0
+        if split and tower.input_batch_norm:
+            raise RuntimeError('FusedTower.grad_split with input_batch_norm is not supported')
+        params_all, flushed = params, set()
         # output layer
         pro, sc, sh, mean, rstd, drop = coefs[-1]
         n_last = zs[-1].shape[1]
@@ -264,6 +285,15 @@ class _TowerFn(torch.autograd.Function):
                     cc, pqr = T.reduce_partials(partial, (gammas[l - 1], rstd_p, mean_p, M))
                 else:
                     cc = T.reduce_partials(partial)
+            if direct and l == split and l > 0:
+                # everything of the layers >= l and of the output layer is computed: add the vector gradients into their
+                # buffers now (the weight gradients went there inside the split reduction) and tell the caller
+                early = [(j, g_) for j, g_ in enumerate(_grad_list(dW, db, dgam, dbet, use_bn, n_h, dw_out, db_out, None))
+                         if g_ is not None and _layer_of(j, n_h, use_bn) >= l]
+                T.multi_add_([params_all[j].grad for j, _ in early], [g_ for _, g_ in early])
+                flushed = set(j for j, _ in early)
+                if tower.grad_split_hook is not None:
+                    tower.grad_split_hook(tower)
         grads = list(dW) + list(db)
         if use_bn:
             grads += list(dgam) + list(dbet)
@@ -304,7 +334,7 @@ class _TowerFn(torch.autograd.Function):
                 dx = torch.nn.functional.pad(dx, (0, ctx.x_shape[1] - dx.shape[1]))
         grads += [dw_out, db_out]
         if direct:
-            todo = [(p.grad, g) for p, g in zip(params, grads) if g is not None]         # (zero bias grads are None here)
+            todo = [(p.grad, g) for j, (p, g) in enumerate(zip(params, grads)) if g is not None and j not in flushed]         # (zero bias grads are None here)
             T.multi_add_([a for a, _ in todo], [g for _, g in todo])
             grads = [None] * len(grads)
         return (None if dx is None else dx.to(ctx.x_dtype), None, None, None) + tuple(grads)
@@ -345,6 +375,14 @@ class FusedTower(nn.Module):
         # True: backward adds into the existing .grad buffers itself (see _TowerFn.backward); set by
         # distributed.FlatGradBucket.attach(), whose flat buffer owns every .grad for the life of the model.
         self.accumulate_grads_in_place = False
+        # Overlapped gradient exchange (round 6; distributed.SplitStep): with `grad_split = k` (1 <= k < number of hidden
+        # layers) and in-place accumulation on, backward calls `grad_split_hook(self)` at the moment the gradients of the
+        # output layer and of the hidden layers >= k are FINAL in their .grad buffers -- the layers below are still to be
+        # differentiated -- so that the caller can start their all-reduce (or end a hipGraph capture there) while the rest
+        # of the backward runs.  The reference's MirroredStrategy overlaps per-variable all-reduces with the backward the
+        # same way (keras/strategy_utils.py:87-116).
+        self.grad_split = 0
+        self.grad_split_hook = None
         self.weights = nn.ParameterList()
         self.biases = nn.ParameterList()
         self.gammas = nn.ParameterList()

@@ -279,3 +279,32 @@ def test_flat_params_sgd_equals_per_tensor_sgd():
     assert all(p.data_ptr() >= bucket.flat_params.data_ptr() for p in flat.parameters())
     with pytest.raises(ValueError):
         D.FlatGradBucket(_toy_model().parameters()).sgd_step(0.1)
+
+
+def test_completion_order_puts_the_early_gradients_in_one_prefix():
+    """Round 6: distributed.completion_order -- the bucket order behind the overlapped exchange (SplitStep): output layer and
+    hidden layers >= split first (final first in a backward), then the layers below; every parameter exactly once."""
+    import torch
+    from ranking_amd import distributed as D
+    from ranking_amd.tower import FusedTower
+    t = FusedTower(136, [64, 32, 16], output_units=1, activation=torch.relu, use_batch_norm=True)
+    for split in (1, 2):
+        order, early = D.completion_order(t, split)
+        assert len(order) == len(list(t.parameters())) and len({id(p) for p in order}) == len(order)
+        assert order[0] is t.out_weight and order[1] is t.out_bias
+        upper = [t.weights[l] for l in range(2, split - 1, -1)]
+        assert [p for p in order if any(p is w for w in t.weights)][:len(upper)] == upper or all(
+            a is b for a, b in zip([p for p in order if any(p is w for w in t.weights)][:len(upper)], upper))
+        n_early = t.out_weight.numel() + t.out_bias.numel() + sum(
+            t.weights[l].numel() + t.biases[l].numel() + t.gammas[l].numel() + t.betas[l].numel() for l in range(split, 3))
+        assert early == n_early
+        # a bucket on this order: the early gradients are the contiguous prefix [0, early)
+        b = D.FlatGradBucket(order, n_scalars=2)
+        assert t.out_weight.grad.data_ptr() == b.flat.data_ptr()
+        last_early = order[[i for i, p in enumerate(order) if sum(q.numel() for q in order[:i + 1]) == early][0]]
+        assert last_early.grad.data_ptr() + last_early.numel() * 4 == b.flat.data_ptr() + early * 4
+    import pytest
+    with pytest.raises(ValueError):
+        D.completion_order(t, 3)
+    with pytest.raises(ValueError):
+        D.completion_order(t, 0)

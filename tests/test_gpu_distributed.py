@@ -89,3 +89,136 @@ def test_two_ranks_on_rccl_match_the_two_shards_run_in_one_process():
         assert abs(v.item() - want_v.item()) <= 1e-6 * max(1.0, abs(want_v.item())), (r, v, want_v)
         assert torch.allclose(g, want_g, rtol=1e-5, atol=1e-7 * want_g.abs().max().item()), r
         assert torch.equal(m, mm), r                               # per-replica BatchNorm statistics: the shard's own
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 6: the overlapped gradient exchange (distributed.SplitStep) -- the step bench.py runs at N > 1.
+def _make_step(labels, feats, dev, mode, steps, dropout=0.0, use_graph=True):
+    """K training steps of the scaled config-2 model on one shard.  mode 'single': forward + backward + SGD as ONE graph
+    (bench.py at N = 1); 'split': distributed.SplitStep with the backward cut above layer 1.  Returns (values, flat params)."""
+    import ranking_amd as ra
+    from ranking_amd import distributed as D
+    torch.manual_seed(0)
+    scorer = ra.keras.model.DNNScorer(input_dim=feats.shape[2], hidden_layer_dims=[512, 512, 512], output_units=1,
+                                      activation=torch.relu, use_batch_norm=True, dropout=dropout,
+                                      compute_dtype=torch.bfloat16).to(dev)
+    scorer.train()
+    D.broadcast_module(scorer)
+    if mode == 'split':
+        order, early = D.completion_order(scorer, 1)
+        bucket = D.FlatGradBucket(order, n_scalars=2, flatten_params=True)
+    else:
+        bucket = D.FlatGradBucket(scorer.parameters(), n_scalars=2, flatten_params=True)
+    bucket.attach(scorer)
+    labels, feats = labels.to(dev), feats.to(dev)
+    loss = ra.keras.losses.SoftmaxLoss()
+    mask = labels >= 0
+
+    def fwd_bwd():
+        logits = scorer({}, {'x': feats}, mask)
+        value, dlogits = loss.loss_and_grad(labels, logits.detach())
+        logits.backward(dlogits)
+        return value
+
+    def sgd():
+        bucket.sgd_step(0.05)
+    _, world = D.world()
+    values = []
+    if mode == 'split':
+        ss = D.SplitStep(scorer, bucket, early, 1, fwd_bwd, sgd, average=True, use_graph=use_graph)
+        assert ss._hook_calls >= (4 if use_graph else 0)          # the hook fired in every warm-up step and in the capture
+        for _ in range(steps):
+            s = ss()
+            values.append((s[0] / max(world, 1)).item())
+    else:
+        for _ in range(steps):
+            bucket.zero()
+            v = fwd_bwd()
+            s = bucket.all_reduce(torch.stack([v, v.new_tensor(1.0)]), average=True)
+            sgd()
+            values.append((s[0] / max(world, 1)).item())
+    torch.cuda.synchronize()
+    # parameters by NAME (the two bucket orders differ)
+    named = {n: p.detach().float().cpu().clone() for n, p in scorer.named_parameters()}
+    return values, named
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_split_step_is_bit_identical_to_the_single_step_on_one_gpu(use_graph):
+    """At world size 1 SplitStep issues no collective: three graphs (backward cut inside autograd by the tower's hook)
+    replay the launches of the plain step in the same order -- the same parameters, bit for bit, after several steps."""
+    dev = torch.device('cuda', 0)
+    labels, feats = _batch(96, 100, 136)
+    v_ref, p_ref = _make_step(labels, feats, dev, 'single', 4)
+    v_new, p_new = _make_step(labels, feats, dev, 'split', 4, use_graph=use_graph)
+    # (split mode ran 3 eager warm-up steps [+ 1 captured] before its 4 steps when captured: compare like with like)
+    extra = 3 + 0 if use_graph else 0
+    if extra:
+        v_ref, p_ref = _make_step(labels, feats, dev, 'single', 4 + 3)
+        v_ref = v_ref[3:]
+    assert v_new == v_ref, (v_new, v_ref)
+    for n in p_ref:
+        assert torch.equal(p_ref[n], p_new[n]), n
+
+
+def _gloo_worker(rank, world, port, out):
+    """two processes on the ONE visible GPU, gloo on device tensors (RCCL refuses duplicate devices): bench.py's N > 1 control
+    flow -- graph A | early all-reduce on a side stream || graph B | late all-reduce | optimizer graph"""
+    import torch.distributed as dist
+    from ranking_amd import distributed as D
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    labels, feats = _batch(96, 100, 136)
+    lb, ft = D.shard_lists([labels, feats])
+    out[rank] = _make_step(lb, ft, dev, 'split', 3)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_split_step_with_two_gloo_ranks_on_one_gpu_matches_the_serial_shards():
+    import torch.multiprocessing as mp
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gloo_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    # the reference: the two shards stepped in ONE process with the gradients averaged by hand, same number of steps
+    # (3 warm-up + 3) from the same initialisation
+    import ranking_amd as ra
+    from ranking_amd import distributed as D
+    dev = torch.device('cuda', 0)
+    labels, feats = _batch(96, 100, 136)
+    torch.manual_seed(0)
+    scorers, buckets = [], []
+    for _ in range(2):
+        torch.manual_seed(0)
+        sc = ra.keras.model.DNNScorer(input_dim=136, hidden_layer_dims=[512, 512, 512], output_units=1, activation=torch.relu,
+                                      use_batch_norm=True, dropout=0.0, compute_dtype=torch.bfloat16).to(dev)
+        sc.train()
+        b = D.FlatGradBucket(sc.parameters(), n_scalars=2, flatten_params=True).attach(sc)
+        scorers.append(sc); buckets.append(b)
+    loss = ra.keras.losses.SoftmaxLoss()
+    shards = [(labels[:48].to(dev), feats[:48].to(dev)), (labels[48:].to(dev), feats[48:].to(dev))]
+    vals = []
+    for step in range(6):
+        vs = []
+        for (lb, ft), sc, b in zip(shards, scorers, buckets):
+            b.zero()
+            logits = sc({}, {'x': ft}, lb >= 0)
+            v, d = loss.loss_and_grad(lb, logits.detach())
+            logits.backward(d)
+            vs.append(v)
+        avg = (buckets[0].flat[:buckets[0].numel] + buckets[1].flat[:buckets[1].numel]) / 2
+        for b in buckets:
+            b.flat[:b.numel].copy_(avg)
+            b.sgd_step(0.05)
+        vals.append(((vs[0] + vs[1]) / 2).item())
+    want = {n: p.detach().float().cpu() for n, p in scorers[0].named_parameters()}
+    for r in range(2):
+        v, named = out[r]
+        for a, b in zip(v, vals[3:]):
+            assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (r, v, vals)
+        for n in want:
+            assert torch.allclose(named[n], want[n], rtol=2e-5, atol=2e-6 * max(1e-3, want[n].abs().max().item())), (r, n)

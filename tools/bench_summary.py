@@ -7,6 +7,10 @@ def row(name, d):
     if not isinstance(d, dict) or 'error' in d:
         print('  %-26s ERROR %s' % (name, (d or {}).get('error')))
         return
+    if 'ms' in d and 'ms_per_step' not in d:               # an entry of the compact digest line (bench.digest_entry)
+        print('  %-26s %10.4g lists/s  %8.4f ms/step  kernel_ms %s  frac %s  valu_frac %s  cpu %s  [digest]'
+              % (name, d['value'], d['ms'], d.get('kernel_ms'), d.get('frac'), d.get('valu_frac'), d.get('cpu')))
+        return
     r = d.get('roofline') or {}
     cb = d.get('cpu_baseline') or {}
     print('  %-26s %10.4g lists/s  %8.4f ms/step  kernel_ms %s  frac %s  valu_frac %s  cpu %s (%s cores)  x%s'

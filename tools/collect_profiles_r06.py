@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Assembles profiles/r05_*.{txt,json} from one consolidated GPU visit under gpurun_out/<tag>/ (bash tools/gpu_r05.sh
+"""Assembles profiles/r06_*.{txt,json} from one consolidated GPU visit under gpurun_out/<tag>/ (bash tools/gpu_r06.sh
 <tag> profiles): bench.py lines, rocprofv3 --kernel-trace --stats tables of the same commands, the separate --pmc
 passes (FETCH_SIZE / WRITE_SIZE) and the traffic figures bench.py reports as `roofline.traffic`."""
 import json
@@ -29,7 +29,7 @@ def pmc_mean(path, kernel_sub, counter):
 
 def main(tag):
     R = os.path.join(ROOT, 'gpurun_out', tag)
-    out = ['# Round 5, consolidated GPU visit %s (one MI355X, fresh box): bash tools/gpu_r05.sh %s profiles\n'
+    out = ['# Round 6, consolidated GPU visit %s (one MI355X, fresh box): bash tools/gpu_r06.sh %s profiles\n'
            '# bench.py lines (graph replay; dominant-kernel time = HIP events around graph-replayed launches of that kernel),\n'
            '# rocprofv3 --kernel-trace --stats tables of the same commands.  e2e workloads run at the reference dropout 0.5;\n'
            '# `dropout_0` in their lines is the same step without Dropout.  `*_hbm` = the same kernels on a cycled working\n'
@@ -44,9 +44,9 @@ def main(tag):
         if m:
             out.append('## rocprofv3 --kernel-trace --stats -- python bench.py --workload %s --steps 50 --warmup 5 '
                        '--no-cpu-baseline --also none\n%s\n' % (m.group(1), open(os.path.join(R, f)).read().rstrip()))
-    open(os.path.join(ROOT, 'profiles', 'r05_all_workloads.txt'), 'w').write('\n'.join(out))
+    open(os.path.join(ROOT, 'profiles', 'r06_all_workloads.txt'), 'w').write('\n'.join(out))
 
-    pm = ['# Round 5 PMC passes (visit %s): separate rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in\n'
+    pm = ['# Round 6 PMC passes (visit %s): separate rocprofv3 --pmc runs as MI355X_MICROARCH.md prescribes (FETCH_SIZE / WRITE_SIZE in\n'
           '# KiB per dispatch; FETCH_SIZE x 2 on gfx950 for wide coalesced reads).  Columns: mean counter value per dispatch, avg ns.\n' % tag]
     for f in sorted(os.listdir(R)):
         m = re.match(r'pmc_(fetch|write|sq)_(.+)\.txt', f)
@@ -57,7 +57,7 @@ def main(tag):
             how = ' --no-graph --kernel-timing none (eager launches: rocprofv3 --pmc died on the 128-launch graphs)' if m.group(2).endswith('_hbm') else ''
             pm.append('## rocprofv3 --pmc %s -- python bench.py --workload %s --no-cpu-baseline --also none%s\n%s\n'
                       % (what, m.group(2), how, '\n'.join(body)))
-    open(os.path.join(ROOT, 'profiles', 'r05_pmc.txt'), 'w').write('\n'.join(pm))
+    open(os.path.join(ROOT, 'profiles', 'r06_pmc.txt'), 'w').write('\n'.join(pm))
 
     traffic = {}
     for w, sub, B, L, alg in (('approx_ndcg', 'approx_ndcg_wave_kernel', 16384, 200, (12 * 200 + 12) * 16384),
@@ -89,14 +89,14 @@ def main(tag):
             traffic[w] = dict(B=B, L=L, kernel=k0 + ' (forward hidden layer, BN + ReLU + Dropout prologue: reads z, writes z; in the training step also the transformed operand for the weight gradient)',
                               fetch_kib=f, write_kib=wr, traffic_bytes=int(round((2 * f + wr) * 1024)), algorithmic_bytes=2 * unit)
     doc = {'_comment': ('HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB per '
-                        'dispatch, mean over dispatches; visit %s, tables in profiles/r05_pmc.txt), corrected as MI355X_MICROARCH.md '
+                        'dispatch, mean over dispatches; visit %s, tables in profiles/r06_pmc.txt), corrected as MI355X_MICROARCH.md '
                         'prescribes for gfx950 (FETCH_SIZE x 2 for wide coalesced reads).  bench.py copies the entry that matches its '
                         'workload and batch into roofline.traffic and says so in roofline.traffic_source.' % tag)}
     doc.update(traffic)
-    json.dump(doc, open(os.path.join(ROOT, 'profiles', 'r05_traffic.json'), 'w'), indent=1)
+    json.dump(doc, open(os.path.join(ROOT, 'profiles', 'r06_traffic.json'), 'w'), indent=1)
     for w, v in traffic.items():
         print(w, 'traffic / algorithmic = %.3f' % (v['traffic_bytes'] / v['algorithmic_bytes']))
 
 
 if __name__ == '__main__':
-    main(sys.argv[1] if len(sys.argv) > 1 else 'r05p')
+    main(sys.argv[1] if len(sys.argv) > 1 else 'r06p')

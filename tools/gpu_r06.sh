@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-5 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r05.sh <tag> <what...>
+# Round-6 GPU-box visits.  Usage (through gpurun, from the repo root):  bash tools/gpu_r06.sh <tag> <what...>
 #   what: tests (full -m gpu suite + smoke) | sums_ab (TFR_LOSS_SUM_FUSED 0 / 1 on the softmax and LambdaRank steps) |
 #         ndcg_ab (TFR_NDCG_LEAN 0 / 1 and the persistent-grid size) | gemm_ab (tower GEMM variants: tools/tower_bench.py +
 #         the e2e steps) | lrank_ab (LambdaRank switches) | late (tests of the late round-5 changes) | one:<workload> | prof:<workload> | pmc:<workload> |
-#         profiles (everything profiles/r05_* is made from: bench lines, rocprofv3 kernel-trace stats, FETCH / WRITE / SQ
+#         profiles (everything profiles/r06_* is made from: bench lines, rocprofv3 kernel-trace stats, FETCH / WRITE / SQ
 #         passes of every dominant kernel, on the tree as it is) | final (the driver's command) | multi (N = 2 if two
 #         devices are visible: bench.py --gpus 2 and the RCCL test)
 set -u
-TAG=${1:-r05}; shift
+TAG=${1:-r06}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -23,7 +23,7 @@ ab() {   # ab <label> <workload> <steps> <env assignments...>: one bench line un
 for what in "$@"; do
   case $what in
     tests)
-      timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+      timeout 2400 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
       tail -n 30 $OUT/pytest_gpu.log | cut -c1-200
       timeout 300 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 1 $OUT/smoke.log ;;
     softmax_quick)
@@ -32,7 +32,7 @@ for what in "$@"; do
       ab "pack groups=1024" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1024
       ab "pack groups=1536" softmax_hbm 50 TFR_SOFTMAX_STREAM_GROUPS=1536 ;;
     approx_sum_ab)
-      # (visit r05k ran this with the round-4 meaning of the switch: 1 = in-launch sum, 0 = reduction launch; now 2 / 1)
+      # (visit r06k ran this with the round-4 meaning of the switch: 1 = in-launch sum, 0 = reduction launch; now 2 / 1)
       ab "in-launch sum" approx_ndcg 200 TFR_LOSS_SUM_FUSED=2
       ab "reduction launch" approx_ndcg 200 TFR_LOSS_SUM_FUSED=1
       ab "in-launch sum again" approx_ndcg 200 TFR_LOSS_SUM_FUSED=2
@@ -121,7 +121,7 @@ for what in "$@"; do
       find $OUT -name '*.db' -size +4M -delete ;;
     profiles)
       # ONE consolidated visit on the final tree: every bench line, kernel-trace stats of every dominant kernel, FETCH / WRITE /
-      # SQ passes -- what profiles/r05_all_workloads.txt, r05_pmc.txt and r05_traffic.json are assembled from
+      # SQ passes -- what profiles/r06_all_workloads.txt, r06_pmc.txt and r06_traffic.json are assembled from
       for w in approx_ndcg pairwise_lambda softmax ndcg_metric softmax_hbm ndcg_metric_hbm gumbel_approx_ndcg approx_ndcg_l1000 e2e_softmax e2e_pairwise_lambda e2e_approx_ndcg_l1000 e2e_groupwise_gumbel; do
         timeout 300 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err; echo "$w rc=$?"; brief $OUT/one_$w.out
       done
