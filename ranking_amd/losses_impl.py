@@ -627,7 +627,8 @@ _TIE_GEN = {'seed': None, 'gen': None}
 def _fresh_tie_seed() -> int:
     """A new non-zero 31-bit tie seed per call from a PRIVATE host generator seeded from torch.initial_seed() (round 6,
     ADVICE r5: drawing from torch's global generator perturbed the caller's own random streams -- dropout, shuffling -- by
-    one draw per loss call).  The sequence restarts when torch.manual_seed changes the initial seed: the role TF's
+    one draw per loss call).  The sequence restarts when torch.manual_seed CHANGES the initial seed (re-seeding with the
+    same value continues it -- nothing observable distinguishes the two states without consuming the global stream): the role TF's
     graph-level seed plays for the op seed 37 of losses_impl.py:1558-1561.  (A host draw: under hipGraph capture the seed
     of the captured step is replayed -- pass ``seed`` for a fixed order, or re-capture.)"""
     base = torch.initial_seed()

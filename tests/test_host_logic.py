@@ -515,9 +515,14 @@ def test_tie_seeds_of_losses_and_metrics_host_side():
     L, M, K = ra.losses_impl, ra.metrics_impl, ra.keras.losses
     mle = L.ListMLELoss(None)
     assert mle.shuffle_ties is True and mle.seed is None
+    # (round 6, ADVICE r5: a PRIVATE generator keyed on torch.initial_seed() -- the caller's global stream is not consumed,
+    # and the sequence restarts when the initial seed changes)
+    torch.manual_seed(5); before = torch.rand(1)
     torch.manual_seed(5); a, b = mle._tie_seed(), mle._tie_seed()
+    assert torch.equal(torch.rand(1), before)                     # the two tie seeds did not advance the global generator
+    torch.manual_seed(6); other = mle._tie_seed()
     torch.manual_seed(5); c = mle._tie_seed()
-    assert a != 0 and b != 0 and a != b and a == c and 0 < a < 2 ** 31
+    assert a != 0 and b != 0 and a != b and a == c and other != a and 0 < a < 2 ** 31
     mle.seed = 9
     assert mle._tie_seed() == 9 == mle._tie_seed()
     mle.seed = 0
