@@ -1345,6 +1345,15 @@ __global__ __launch_bounds__(512, 1) void tower_gemm256p_kernel(const GemmArgs g
 #include "tower_gemm_rp.h"
 #include "tower_gemm_bs.h"
 
+#ifdef TFR_BS_STAMPS
+}  // namespace
+extern "C" int tfr_prof_set_buffer_bs(void* device_u64_buffer) {
+  unsigned long long* p = (unsigned long long*)device_u64_buffer;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_bs), &p, sizeof(p));
+}
+namespace {
+#endif
+
 #if (TFR_RP_ABLATE & 16)
 }  // namespace
 extern "C" int tfr_prof_set_buffer_rp(void* device_u64_buffer) {

@@ -40,6 +40,15 @@ constexpr int bs_count(int ks, int lo_back, int hi_back, int residue, int tiles_
   return n < tiles_so_far_max ? n : tiles_so_far_max;
 }
 
+// developer aid (tools/gemm_bs_timeline.py): -DTFR_BS_STAMPS -- lane 0 of wave 0 records s_memtime per tile (the first 48 tiles
+// of a workgroup): [2 ks] before the stage wait, [2 ks + 1] after its barrier, [8] start of the epilogue, [9] its end
+#ifdef TFR_BS_STAMPS
+__device__ unsigned long long* g_prof_bs = nullptr;
+#define BS_STAMP(i) do { if (tid == 0 && ti < 48) g_prof_bs[((size_t)blockIdx.x * 48 + ti) * 10 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BS_STAMP(i) do { } while (0)
+#endif
+
 template <int EPI, int DROP, int D>
 __global__ __launch_bounds__(256, 1) void tower_gemm_bs_kernel(const GemmArgs g) {
   static_assert(D >= 2 && D <= 7, "8 ring slots: the slot of stage s - 1 is free once every wave has passed the barrier of stage s");
@@ -172,7 +181,9 @@ __global__ __launch_bounds__(256, 1) void tower_gemm_bs_kernel(const GemmArgs g)
           constexpr int n1 = base + E * bs_count(ks, D - 1, 1, 3, 1) + ZP * bs_count(ks, D - 2, 0, 0, 2);
           constexpr int n0 = base + ZP * bs_count(ks, D - 2, 0, 0, 1);
           static_assert(n2 <= 63, "vmcnt is a 6-bit field");
+          BS_STAMP(2 * ks);
           if (ti >= 2) bs_wait_barrier<n2>(); else if (ti == 1) bs_wait_barrier<n1>(); else bs_wait_barrier<n0>();
+          BS_STAMP(2 * ks + 1);
           if (ks < 3) read_frags(ti, ks + 1, 0, fa[cur ^ 1]); else read_frags(ti + 1, 0, 0, fa[cur ^ 1]);
         }
 #pragma unroll
@@ -186,6 +197,7 @@ __global__ __launch_bounds__(256, 1) void tower_gemm_bs_kernel(const GemmArgs g)
     stage(std::integral_constant<int, 2>{}); stage(std::integral_constant<int, 3>{});
     // (fa[0] now holds the next tile's first fragments: 4 kk per stage, an even number of swaps)
 
+    BS_STAMP(8);
     // ---- epilogue: 4 chunks of [16 rows][64 columns] through the wave's 2 KB slot
     if (BWD) asm volatile("s_waitcnt vmcnt(16)" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]), "+v"(zq[4]), "+v"(zq[5]), "+v"(zq[6]), "+v"(zq[7]) :: "memory");   // behind the Zp loads: the 16 pieces of stages (ti + 1, 0 .. 3)
     f32x4 pb[4], pe[4], s1[4], s2[4];
@@ -246,6 +258,7 @@ __global__ __launch_bounds__(256, 1) void tower_gemm_bs_kernel(const GemmArgs g)
         }
       }
     }
+    BS_STAMP(9);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the dummy stages past the last tile land before the workgroup leaves
 }
