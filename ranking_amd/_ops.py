@@ -285,30 +285,50 @@ def mrr_metric(labels, predictions, weights, mask, topns, tie_seed=0):
 _BALANCE_MIN_LISTS = 1024      # below this the ordering launch costs more than the tail it removes
 
 
-_device_state: Dict[Tuple, torch.Tensor] = {}
+# Persistent zero-initialised int32 scratch of the kernels that synchronise their workgroups through device memory
+# (last-workgroup tickets, class counters) and leave it zero.  One POOL per device (never freed: captured hipGraphs hold
+# addresses inside it), cut into slots; a launch gets a slot no launch that may overlap it shares:
+#   * eager launches: one slot per (kind, current stream) -- launches on one stream run in order;
+#   * launches recorded by a stream capture run wherever and whenever the graph is replayed, so EVERY recorded launch takes a
+#     fresh slot of its own (one state per kind shared by all graphs let two graphs replayed on different streams
+#     corrupt each other's tickets).  The pool is created by the first eager call on the device (every capture is preceded
+#     by an eager run of the step); a capture that finds no pool, or an exhausted one, gets None and the caller falls back
+#     (a private zero-filled tensor from the graph's own pool -- the fill becomes a node of the graph -- or a path that
+#     needs no state).
+_STATE_SLOT_INTS = 256
+_STATE_SLOTS = 2048
+_state_pools: Dict[str, dict] = {}
+
+
+def _state_slot(kind: str, n_ints: int, device) -> Optional[torch.Tensor]:
+    if n_ints > _STATE_SLOT_INTS:
+        raise ValueError('state of %d ints does not fit a slot' % n_ints)
+    capturing = torch.cuda.is_current_stream_capturing()
+    pool = _state_pools.get(str(device))
+    if pool is None:
+        if capturing:
+            return None
+        pool = {'buf': torch.zeros((_STATE_SLOTS, _STATE_SLOT_INTS), dtype=torch.int32, device=device), 'next': 0, 'eager': {}}
+        _state_pools[str(device)] = pool
+    if capturing:
+        key = None
+    else:
+        key = (kind, int(torch.cuda.current_stream(device).cuda_stream))
+        if key in pool['eager']:
+            return pool['buf'][pool['eager'][key], :n_ints]
+    if pool['next'] >= _STATE_SLOTS:
+        return None
+    i = pool['next']
+    pool['next'] = i + 1
+    if key is not None:
+        pool['eager'][key] = i
+    return pool['buf'][i, :n_ints]
 
 
 def _zero_state(kind: str, n_ints: int, device) -> torch.Tensor:
-    """A persistent zero-initialised int32 scratch of a kernel that synchronises its workgroups through device memory
-    (last-workgroup tickets) and leaves it zero; never freed -- a captured hipGraph holds its address.  tfr_hip.h asks for
-    one per stream in flight: eager launches get one per (kind, device, current stream), so two streams never
-    share tickets.  Launches recorded by a stream capture run wherever the graph is replayed; they share one state per
-    (kind, device), created at the first eager call (every capture is preceded by an eager run of the step): graphs that
-    contain the same loss kind must be replayed in stream order on a device, as training steps are.  A capture with no
-    eager run before it gets a private state from the graph's own pool (the zero fill becomes a node of the graph)."""
-    capturing = torch.cuda.is_current_stream_capturing()
-    graph_key = (kind, str(device))
-    if capturing:
-        t = _device_state.get(graph_key)
-        return t if t is not None else torch.zeros(n_ints, dtype=torch.int32, device=device)
-    if graph_key not in _device_state:
-        _device_state[graph_key] = torch.zeros(n_ints, dtype=torch.int32, device=device)
-    key = (kind, str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    t = _device_state.get(key)
-    if t is None:
-        t = torch.zeros(n_ints, dtype=torch.int32, device=device)
-        _device_state[key] = t
-    return t
+    """The state of one launch (see above); when the pool cannot serve it, a zero-filled tensor of its own."""
+    t = _state_slot(kind, n_ints, device)
+    return t if t is not None else torch.zeros(n_ints, dtype=torch.int32, device=device)
 
 
 def _sum_outputs(device):

@@ -425,7 +425,9 @@ __device__ __forceinline__ int wave_scan_incl_i(int x) {
 constexpr int kRankBucketMax = 32;
 template <int NC>
 __device__ __forceinline__ bool wave_rank_by_bucket(const float* XS, int n, int lane, int* RKS, int* OCC, float* BX,
-                                                    int* HB) {
+                                                    int* HB, bool have_range = false, float mn_in = 0.0f,
+                                                    float mx_in = 0.0f) {
+  // have_range: the caller already holds the (wave-uniform) minimum and maximum of XS[0 .. n) -- two wave reductions less
   float x[NC];
   bool in[NC];
   float mn = INFINITY, mx = -INFINITY;
@@ -434,9 +436,10 @@ __device__ __forceinline__ bool wave_rank_by_bucket(const float* XS, int n, int 
     const int p = lane + 64 * k;
     in[k] = p < n;
     x[k] = in[k] ? XS[p] : 0.0f;
-    if (in[k]) { mn = fminf(mn, x[k]); mx = fmaxf(mx, x[k]); }
+    if (!have_range && in[k]) { mn = fminf(mn, x[k]); mx = fmaxf(mx, x[k]); }
   }
-  mn = wave_min_u(mn); mx = wave_max_u(mx);
+  if (have_range) { mn = mn_in; mx = mx_in; }
+  else { mn = wave_min_u(mn); mx = wave_max_u(mx); }
   const float range = mx - mn;
   const float scale = 64.0f / range;
   if (!(range > 0.0f) || !(range < INFINITY) || !(scale < INFINITY)) return false;

@@ -302,9 +302,14 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
 #ifdef TFR_PROFILE_STAMPS
   unsigned long long grp_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int grp_passes = 0, grp_polls = 0;
-#define GRP_STAMP(i) do { grp_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  const int grp_stop = g_prof_stop_pw;
+#define GRP_STAMP(i) do { grp_t[i] = __builtin_amdgcn_s_memtime(); if ((i) >= 1 && (i) <= 5 && grp_stop == (i)) return; } while (0)
+#define GRP_SKIP_HI (grp_stop == 7)
+#define GRP_SKIP_LO (grp_stop == 6)
 #else
 #define GRP_STAMP(i) do { } while (0)
+#define GRP_SKIP_HI false
+#define GRP_SKIP_LO false
 #endif
   GRP_STAMP(0);
 #define GRP_HDR(l) reinterpret_cast<GrpHdr*>(grp_smem + tab_bytes + (size_t)(l) * per_list)
@@ -354,6 +359,9 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
     }
   }
   __syncthreads();                                            // the table and the tickets are in place
+#ifdef TFR_PROFILE_STAMPS
+  if (grp_stop >= 1 && grp_stop <= 5 && !builder) return;
+#endif
   GRP_STAMP(1);
 
   // ---- 1. wave w < G builds the LDS image of its list.
@@ -415,7 +423,7 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
       //  Lp + 24 -- and the 192 counters in GS, which the records phase writes later; lists with LpS < 192 are short
       //  enough for the sweep)
       if (!BKT || LpS < 192 ||
-          !wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, XS + Lp + 8, reinterpret_cast<int*>(GS)))
+          !wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, XS + Lp + 8, reinterpret_cast<int*>(GS), true, xmin, xmax))
         wave_rank_by_count(XS, n, lane, RKS, OCC);       // (common.h: all row chunks against each float4 of columns at once)
 #pragma unroll
       for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
@@ -640,8 +648,10 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
         const int npure = tail ? nseg - 1 : nseg;             // pure grade segments; the unsorted tail (if any) is segment nseg - 1
         const bool in_tail = tail && s_last == nseg - 1;      // some row of this pass lies in the tail segment
         // row preferred: the lower grades behind it (pure segments s_first + 1 .. npure - 1 in ONE loop)
+        if (!GRP_SKIP_HI)
         grp_hi_sweep<AUX>(recH, s_first + 1, npure, seg_s, seg_e, seg_g, c, Ai, Gi, ri, ubase, accL, accG, accW, accNZ);
         // column preferred: the higher grades in front of it (pure segments 0 .. s_last - 1)
+        if (!GRP_SKIP_LO)
         grp_lo_sweep<ITEMW>(recL, WS, s_last < npure ? s_last : npure, seg_e, seg_g, c, Bi, Gi, ri, ubase, accG2);
         if (tail) {                                           // the tail segment: gain difference per pair
           const int s = __builtin_amdgcn_readlane(seg_s, nseg - 1), e = __builtin_amdgcn_readlane(seg_e, nseg - 1);
@@ -694,7 +704,11 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
         if (a.row_loss) a.row_loss[base + ci] = row_l;
         if (AUX && a.row_weight) a.row_weight[base + ci] = accW * wi;
         const float g2 = ITEMW ? accG2 : accG2 * llw;
-        if (a.dlogits) a.dlogits[base + ci] = (g2 - accG * wi) / a.temperature;
+        if (a.dlogits) {                                      // (x / 1 = x: the ~13-instruction division only when T != 1, a scalar branch)
+          const float dv = g2 - accG * wi;
+          if (a.temperature == 1.0f) a.dlogits[base + ci] = dv;
+          else a.dlogits[base + ci] = dv / a.temperature;
+        }
         if (AUX) row_nz = (wi != 0.0f) ? accNZ : 0.0f;
       }
       const bool want_list = a.list_loss != nullptr, want_nnz = AUX && a.nnz != nullptr;
@@ -742,7 +756,7 @@ inline bool grp_geometry(int B, int L, bool itemw, int& G, int& Wt, int& R, size
   static const int env_h = env_int("TFR_LAMBDARANK_HELPERS", -1);       // extra sweep-only waves per workgroup
   static const int env_r = env_int("TFR_LAMBDARANK_REP", 0);
   G = env_w > 0 ? env_w : (B >= 2048 ? 8 : (B >= 1024 ? 4 : (B >= 512 ? 2 : 1)));
-  if (G > 8) G = 8;
+  if (G > 16) G = 16;                                        // (one workgroup of 16 waves / 16 lists per CU: TFR_LAMBDARANK_WAVES=16)
   Wt = G + (env_h >= 0 ? env_h : G / 2);                      // (measured: 8 + 4 waves beat 8 + 0, 8 + 2 and 8 + 8 at B = 4096 and 16384)
   if (Wt > 16) Wt = 16;
   R = (env_r == 16 || env_r == 32 || env_r == 8) ? env_r : 32;

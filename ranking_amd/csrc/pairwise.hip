@@ -413,6 +413,9 @@ __device__ __forceinline__ void wave_sort_desc_u32(uint32_t (&a)[IPL], int lane)
 // Developer aid (never in the product build): see approx_ndcg.hip / tools/phase_profile.py.
 #ifdef TFR_PROFILE_STAMPS
 __device__ unsigned long long* g_prof_buf_pw = nullptr;
+// group kernel, counter runs (tools/phase_profile.py group_counts): 1 .. 5 = every builder returns after that build phase
+// (nothing is published, nobody sweeps), 6 = hi sweeps only, 7 = lo sweeps only, 0 = the whole kernel
+__device__ int g_prof_stop_pw = 0;
 #define PW_STAMP(i) do { if (lane == 0 && wave == 0) prof_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define PW_STAMP(i) do { } while (0)
@@ -1255,5 +1258,8 @@ extern "C" int tfr_pairwise_loss_sum_f32(int loss_kind, const float* logits, con
 extern "C" int tfr_prof_set_buffer_pw(void* device_u64_buffer) {
   unsigned long long* p = (unsigned long long*)device_u64_buffer;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_buf_pw), &p, sizeof(p));
+}
+extern "C" int tfr_prof_set_stop_pw(int phase) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof_stop_pw), &phase, sizeof(phase));
 }
 #endif

@@ -1471,6 +1471,7 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
 constexpr int kOrderParallelMin = 512;
 constexpr int kOrderLists = 256;    // lists per workgroup
 
+template <bool DEEP>
 __global__ __launch_bounds__(1024) void list_class_kernel(const float* __restrict__ labels,
                                                           const uint8_t* __restrict__ mask, int B, int L,
                                                           uint8_t* __restrict__ cls, int* __restrict__ partial) {
@@ -1487,10 +1488,32 @@ __global__ __launch_bounds__(1024) void list_class_kernel(const float* __restric
     const size_t base = (size_t)b * L;
     if (!mask && (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0)) {
       const float4* p = reinterpret_cast<const float4*>(labels + base);     // the quad reads 64 contiguous bytes a step
+      // round 6, DEEP (fewer than 32 workgroups, i.e. most of the chip idle and the launch latency-bound): 16 loads of a
+      // thread issued before the first add -- a list of up to 256 items = ONE memory round trip instead of four
+      // (6.7 -> 4.9 us at B = 4096).  With 64 workgroups the deep form measured SLOWER (6.3 -> 7.2 us at B = 16 384: the
+      // 64 CUs that run it are bandwidth-bound), so larger batches keep the four-deep loop.
+      const int q = L / 4;
+      int i = t;
+      if (!DEEP) {
 #pragma unroll 4
-      for (int i = t; i < L / 4; i += 4) {
-        const float4 v = p[i];
-        n += (v.x >= 0.0f) + (v.y >= 0.0f) + (v.z >= 0.0f) + (v.w >= 0.0f);
+        for (; i < q; i += 4) {
+          const float4 v = p[i];
+          n += (v.x >= 0.0f) + (v.y >= 0.0f) + (v.z >= 0.0f) + (v.w >= 0.0f);
+        }
+      }
+      for (; DEEP && i + 60 < q; i += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[i + 4 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n += (v[k].x >= 0.0f) + (v[k].y >= 0.0f) + (v[k].z >= 0.0f) + (v[k].w >= 0.0f);
+      }
+      if (DEEP) {
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (i + 4 * k < q) ? p[i + 4 * k] : make_float4(-1.f, -1.f, -1.f, -1.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n += (v[k].x >= 0.0f) + (v[k].y >= 0.0f) + (v[k].z >= 0.0f) + (v[k].w >= 0.0f);
       }
     } else {
       const int per = (L + 3) / 4, lo = t * per, hi = (lo + per < L) ? lo + per : L;
@@ -1515,10 +1538,12 @@ __global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const 
   __shared__ int s_part[4][2][kOrderClasses];               // per wave: (total, before-me) partial column sums
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tot = 0, before = 0;
-  for (int r = wave; r < nblk; r += 4) {                    // lane = class: coalesced rows of the histogram matrix
-    const int v = partial[r * kOrderClasses + lane];
-    tot += v;
-    before += (r < (int)blockIdx.x) ? v : 0;
+  for (int r0 = wave; r0 < nblk; r0 += 32) {                // lane = class: coalesced rows of the histogram matrix,
+    int v[8];                                                // eight rows of a wave in flight (round 6)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int r = r0 + 4 * k; v[k] = r < nblk ? partial[r * kOrderClasses + lane] : 0; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { tot += v[k]; before += (r0 + 4 * k < (int)blockIdx.x) ? v[k] : 0; }
   }
   s_part[wave][0][lane] = tot; s_part[wave][1][lane] = before;
   __syncthreads();
@@ -1713,7 +1738,8 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
     const int nblk = (B + kOrderLists - 1) / kOrderLists;
     uint8_t* cls = reinterpret_cast<uint8_t*>(workspace);                    // B bytes
     int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 4 + 64 <= B - B/4)
-    hipLaunchKernelGGL(list_class_kernel, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
+    if (nblk < 32) hipLaunchKernelGGL(list_class_kernel<true>, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
+    else hipLaunchKernelGGL(list_class_kernel<false>, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
     hipLaunchKernelGGL(list_place_kernel, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
                        (const int*)partial, (int*)order_out);
     return (int)hipGetLastError();

@@ -198,13 +198,14 @@ def test_launch_order_is_cached_per_label_tensor(monkeypatch):
 
 
 def _assert_tickets_zero():
-    """every ticket state of the process (one per stream that launched eagerly + the shared one of captured launches):
-    group tickets and the top ticket are back to zero after a launch"""
+    """every state slot the process handed out (one per stream that launched eagerly + one per launch recorded by a
+    capture): tickets and counters are back to zero after a launch"""
     from ranking_amd import _ops
-    states = [t for k, t in _ops._device_state.items() if k[0] == 'loss_sum']
-    assert states
-    for t in states:
-        assert int(t[:65].abs().sum().item()) == 0
+    pools = list(_ops._state_pools.values())
+    assert pools and any(p['next'] > 0 for p in pools)
+    for p in pools:
+        used = p['buf'][:p['next']]
+        assert int(used[:, :65].abs().sum().item()) == 0
 
 
 def _sum_case(name, B, L):
@@ -313,8 +314,8 @@ def test_reduced_scalar_stress_across_streams():
         with torch.cuda.stream(s2):
             r2.append(_ops.softmax_loss(lg2, lb2, None, w2, want_grad=True, want_sum=True)[3])
     torch.cuda.synchronize()
-    keys = [k for k in _ops._device_state if k[0] == 'loss_sum' and len(k) == 3]
-    assert len({k[2] for k in keys}) >= 2                     # one ticket state per launching stream
+    keys = [k for p in _ops._state_pools.values() for k in p['eager'] if k[0] == 'loss_sum']
+    assert len({k[1] for k in keys}) >= 2                     # one ticket state per launching stream
     for t in r1:
         assert torch.equal(t, first)
     for t in r2:
@@ -1406,6 +1407,68 @@ def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_
     a = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=False, **lam)
     b = _ops.pairwise_logistic(logits.to(DEV), labels.to(DEV), balance=True, **lam)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def _check_order(order, labels, L):
+    order = order.cpu().long()
+    B = labels.shape[0]
+    assert torch.equal(torch.sort(order).values, torch.arange(B))
+    n = (labels.cpu() >= 0).sum(1)
+    c = 63 - (n * 64) // (L + 1)                              # the kernels' 64 length classes, class 0 = longest
+    assert bool((c[order][:-1] <= c[order][1:]).all())
+
+
+@pytest.mark.parametrize('B,L', [(512, 200), (4096, 200), (16384, 200), (5000, 37), (700, 1000), (600, 260)])
+def test_launch_order_follows_the_64_length_classes_eagerly_and_under_replay(B, L):
+    """the kernels' own 64 classes (the test above checks 16); a captured launch orders whatever the label buffer holds
+    at replay (the order is never baked into a graph)"""
+    from ranking_amd import _ops
+    labels, _ = make_batch(B, L, seed=77 + B)
+    lb = labels.to(DEV)
+    for _ in range(3):
+        _check_order(_ops.list_order(lb), labels, L)
+    static = lb.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            out = _ops.list_order(static)
+    for seed in (1, 2, 3):
+        l2, _ = make_batch(B, L, seed=seed)
+        static.copy_(l2.to(DEV))
+        g.replay()
+        torch.cuda.synchronize()
+        _check_order(out, l2, L)
+
+
+def test_every_recorded_launch_with_a_ticket_state_owns_its_slot():
+    """launches recorded by stream captures no longer share one ticket state per loss kind -- two graphs
+    replayed on different streams at the same time would have corrupted each other's tickets"""
+    from ranking_amd import _ops
+    lb, lg = make_batch(2048, 64, seed=5)
+    lb, lg = lb.to(DEV), lg.to(DEV)
+    w = torch.full((2048,), 1.0 / 2048, device=DEV)
+    ref = _ops.softmax_loss(lg, lb, None, w, want_grad=True, want_sum=True)[3].clone()
+    pool = _ops._state_pools[str(lb.device)]
+    graphs, outs, streams = [], [], [torch.cuda.Stream(), torch.cuda.Stream()]
+    before = pool['next']
+    for s in streams:
+        s.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                outs.append(_ops.softmax_loss(lg, lb, None, w, want_grad=True, want_sum=True)[3])
+        graphs.append(g)
+    assert pool['next'] == before + 2
+    torch.cuda.synchronize()
+    for _ in range(20):                                       # the two graphs in flight together, on their own streams
+        for g, s in zip(graphs, streams):
+            with torch.cuda.stream(s):
+                g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
+    _assert_tickets_zero()
 
 
 # ------------------------------------------------------------------ UniqueSoftmax (SURVEY 8f #2)

@@ -99,6 +99,34 @@ for what in "$@"; do
       ab "G=8 helpers=2" pairwise_lambda 200 TFR_LAMBDARANK_HELPERS=2
       ab "G=8 helpers=6" pairwise_lambda 200 TFR_LAMBDARANK_HELPERS=6
       ab "G=8 R=16" pairwise_lambda 200 TFR_LAMBDARANK_REP=16 ;;
+    lrank16)
+      ab "default" pairwise_lambda 200 TFR_DUMMY=0
+      ab "G=16 helpers=0" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=16 TFR_LAMBDARANK_HELPERS=0
+      ab "G=12 helpers=4" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=12 TFR_LAMBDARANK_HELPERS=4
+      ab "G=16 helpers=0 R=16" pairwise_lambda 200 TFR_LAMBDARANK_WAVES=16 TFR_LAMBDARANK_HELPERS=0 TFR_LAMBDARANK_REP=16
+      ab "default again" pairwise_lambda 200 TFR_DUMMY=0
+      TFR_LAMBDARANK_WAVES=16 TFR_LAMBDARANK_HELPERS=0 timeout 200 python tools/phase_profile.py group > $OUT/lrank_phase_g16.txt 2>&1; head -n 12 $OUT/lrank_phase_g16.txt; tail -n 16 $OUT/lrank_phase_g16.txt | head -n 7 ;;
+    lrank_counts)
+      # per-phase instruction counts of the LambdaRank group kernel: the stamped build truncated after each build phase /
+      # with one sweep only (tools/phase_profile.py, STOP=n), SQ counters of every variant
+      for st in 1 2 3 4 5 6 7 0; do
+        STOP=$st timeout 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/cnt_$st -o r -- python tools/phase_profile.py group > $OUT/cnt_$st.log 2>&1
+        python tools/rocpd_summary.py pmc $OUT/cnt_$st/r_results.db > $OUT/cnt_$st.txt 2>&1
+        echo "STOP=$st"; grep "lambdarank_group" $OUT/cnt_$st.txt | cut -c60-130
+      done
+      find $OUT -name '*.db' -size +4M -delete ;;
+    order_quick)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "order or ticket or reduced_scalar or sum or slot" > $OUT/t_order.log 2>&1; echo "order tests rc=$?"; tail -n 4 $OUT/t_order.log | cut -c1-200
+      timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "pairwise or lambda" > $OUT/t_pw.log 2>&1; echo "pairwise tests rc=$?"; tail -n 3 $OUT/t_pw.log | cut -c1-200
+      ab "now" approx_ndcg 200 TFR_DUMMY=0
+      ab "now" pairwise_lambda 200 TFR_DUMMY=0
+      ab "now again" approx_ndcg 200 TFR_DUMMY=0
+      ab "now again" pairwise_lambda 200 TFR_DUMMY=0
+      for w in approx_ndcg pairwise_lambda; do
+        timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_$w -o r -- python bench.py --workload $w --steps 50 --warmup 5 $ONE > $OUT/prof_$w.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 6 $OUT/stats_$w.txt | cut -c1-130
+      done
+      find $OUT -name '*.db' -size +4M -delete ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err

@@ -147,6 +147,18 @@ def main_group():
     call = lambda: f(0, logits.data_ptr(), labels.data_ptr(), None, None, lw.data_ptr(), 2, 0, 0.0, 1, 1, None,
                      disc.data_ptr(), B, L, 1.0, None, None, None, dl.data_ptr(),
                      None if order is None else order.data_ptr(), lst.data_ptr(), 0, st)
+    stop = int(os.environ.get('STOP', '0'))
+    if stop:
+        # counter runs (under rocprofv3 --pmc): the kernel truncated after build phase `stop` (1 .. 5) or with one of the
+        # two sweeps only (6 = hi, 7 = lo); differences of SQ_INSTS_* between successive runs = that phase's instructions
+        lib.tfr_prof_set_stop_pw.argtypes = [ctypes.c_int]
+        assert lib.tfr_prof_set_stop_pw(stop) == 0
+        for _ in range(6):
+            rc = call()
+        torch.cuda.synchronize()
+        assert rc == 0, rc
+        print('STOP=%d: 6 launches' % stop)
+        return
     for _ in range(3):
         rc = call()
     torch.cuda.synchronize()
@@ -202,6 +214,38 @@ def main_group():
     for c in sorted(set(cnts)):
         idx = [i for v in per_cu.values() if len(v) == c for i in v]
         print('  CUs hosting %d workgroups: mean lifetime %.0f (n = %d)' % (c, life[idx].mean().item(), len(idx)))
+
+    # what the lifetime of a workgroup follows: its own work (passes swept by its waves = passes of its lists), the
+    # builds (the longest build of the workgroup), or the partner workgroup on the same CU
+    import numpy as np
+    passes_wg = d[:, 9].reshape(-1, Wt).double().sum(dim=1)
+    bt = (t[:, 5] - t[:, 0]).reshape(-1, Wt)[:, :W]
+    build_max = bt.max(dim=1).values
+    lf = life.numpy()
+    print('per workgroup: passes mean %.1f min %d max %d; corr(lifetime, passes) %.3f; corr(lifetime, longest build) %.3f' % (
+        passes_wg.mean().item(), int(passes_wg.min()), int(passes_wg.max()),
+        np.corrcoef(lf, passes_wg.numpy())[0, 1], np.corrcoef(lf, build_max.numpy())[0, 1]))
+    print('longest build of a workgroup: mean %.0f min %.0f max %.0f; first list published (min build): mean %.0f' % (
+        build_max.mean().item(), build_max.min().item(), build_max.max().item(), bt.min(dim=1).values.mean().item()))
+    sweep_span = en0 - (tw[:, :W, 5].min(dim=1).values)
+    print('first publish -> workgroup end: mean %.0f min %.0f max %.0f ticks; per pass of the workgroup: %.0f' % (
+        sweep_span.mean().item(), sweep_span.min().item(), sweep_span.max().item(), (sweep_span / passes_wg).mean().item()))
+    pairs = [v for v in per_cu.values() if len(v) == 2]
+    if pairs:
+        a = np.array([lf[v[0]] for v in pairs]); b2 = np.array([lf[v[1]] for v in pairs])
+        dst = np.array([abs(st0[v[0]].item() - st0[v[1]].item()) for v in pairs])
+        cu_end = np.array([max(en0[v[0]].item(), en0[v[1]].item()) - min(st0[v[0]].item(), st0[v[1]].item()) for v in pairs])
+        pw = np.array([passes_wg[v[0]].item() + passes_wg[v[1]].item() for v in pairs])
+        print('CU pairs: corr(lifetime A, lifetime B) %.3f; start offset between the two: mean %.0f max %.0f; CU busy span mean %.0f min %.0f max %.0f; corr(span, passes of both) %.3f'
+              % (np.corrcoef(a, b2)[0, 1], dst.mean(), dst.max(), cu_end.mean(), cu_end.min(), cu_end.max(), np.corrcoef(cu_end, pw)[0, 1]))
+        q = np.percentile(cu_end, [5, 25, 50, 75, 95])
+        print('CU busy span percentiles 5/25/50/75/95: %s' % ' '.join('%.0f' % x for x in q))
+    dec = np.percentile(lf, [5, 25, 50, 75, 95])
+    print('workgroup lifetime percentiles 5/25/50/75/95: %s' % ' '.join('%.0f' % x for x in dec))
+    for x in range(8):
+        sel = (xcc == x)
+        if sel.any():
+            print('  XCC %d: lifetime p5 %.0f p50 %.0f p95 %.0f' % ((x,) + tuple(np.percentile(lf[sel.numpy()], [5, 50, 95]))))
 
 
 if __name__ == '__main__':
