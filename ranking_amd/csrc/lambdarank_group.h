@@ -279,13 +279,198 @@ __device__ __forceinline__ void grp_lo_sweep(const float2* recL, const float* WS
   accG2 = __builtin_fmaf(dG, ag, accG2);
 }
 
+// Round 6: the builder for graded relevance (labels = small non-negative integers, at most kMaxRuns distinct values, up
+// to 255 items) -- BASELINE config 3.  profiles/r06_lambdarank_counts.txt: the general builder below spends 257 + 434
+// vector instructions per list on the compaction and the grade order (a ballot + popcount round per register and per
+// grade, every one a VALU -> SALU -> VALU round trip), 15 % of the kernel's vector-pipe time.  Here a lane owns IPL
+// CONSECUTIVE items (element order = lane-major order), every item adds a one-hot BYTE for its grade into a 64-bit word
+// and ONE inclusive scan of that word over the wavefront (two dwords x six DPP adds) gives, for every grade at once, how
+// many items of the grade precede each item: its position inside the grade segment (the byte of its own grade) and its
+// compact position among the valid items (the sum of all eight bytes, one v_sad_u8 per dword).  Segment starts come
+// from a three-step scan of the per-grade totals on lanes 0 .. 7 and reach the items through one ds_bpermute.
+// The image is the one the general builder writes (same segments, same order inside a segment, same padding), and the
+// ideal DCG is added up in the general builder's order (the terms go through LDS once), so the outputs are
+// bit-identical to it (tests/test_gpu_parity.py compares the two builders).  Returns false (wave-uniform, nothing of the
+// image written) for any other label set: the caller then runs the general builder.
+template <int IPL>
+__device__ __forceinline__ bool grp_build_graded(const PwArgs& a, const int b, const int lane, const int L, const int Lp,
+                                                 const int LpS, const int R, const float lw, const float (&lab)[IPL],
+                                                 const float (&xin)[IPL], GrpHdr* H, float2* recH, float2* recL,
+                                                 float* GS, int* CIS, const float* Dlds) {
+  const size_t base = (size_t)b * L;
+  const bool unit_t = a.temperature == 1.0f, pow2 = a.gain_kind == TFR_GAIN_POW2M1;
+  bool lv[IPL];
+  int li[IPL];
+  float x[IPL];
+  bool bad = false;
+  unsigned present = 0u;
+  float xmin = INFINITY, xmax = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const int e = IPL * lane + r;
+    lv[r] = e < L && lab[r] >= 0.0f;
+    const int q = (int)lab[r];
+    const bool ok = (float)q == lab[r] && (unsigned)q < 32u;
+    bad = bad || (lv[r] && !ok);
+    li[r] = q & 31;
+    x[r] = unit_t ? xin[r] : xin[r] / a.temperature;
+    if (lv[r]) {
+      present |= 1u << li[r];
+      xmin = fminf(xmin, x[r]); xmax = fmaxf(xmax, x[r]);
+    } else if (e < L) {
+      if (a.row_loss) a.row_loss[base + e] = 0.f;
+      if (a.dlogits) a.dlogits[base + e] = 0.f;
+    }
+  }
+  if (__ballot(bad)) return false;
+  present = grp_wave_or(present);
+  const int ng = __popc(present);
+  if (ng > kMaxRuns) return false;
+
+  // one-hot grade bytes: grade index k = how many of the present grades lie above the item's
+  const unsigned presh = present >> 1;
+  unsigned sh[IPL], pl[IPL], ph[IPL];
+  unsigned sl = 0u, su = 0u;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    sh[r] = ((unsigned)__popc(presh >> li[r]) & 7u) << 3;      // (k <= 7 for a valid item; the mask only tames invalid ones)
+    const unsigned long long o = (unsigned long long)(lv[r] ? 1u : 0u) << sh[r];
+    pl[r] = sl; ph[r] = su;
+    sl += (unsigned)o; su += (unsigned)(o >> 32);
+  }
+  const unsigned il = (unsigned)wave_scan_incl_i((int)sl), iu = (unsigned)wave_scan_incl_i((int)su);
+  const unsigned Tl = (unsigned)__builtin_amdgcn_readlane((int)il, 63), Tu = (unsigned)__builtin_amdgcn_readlane((int)iu, 63);
+  const unsigned el = il - sl, eu = iu - su;
+  const int n = (int)((Tl & 0xffu) + ((Tl >> 8) & 0xffu) + ((Tl >> 16) & 0xffu) + (Tl >> 24) +
+                      (Tu & 0xffu) + ((Tu >> 8) & 0xffu) + ((Tu >> 16) & 0xffu) + (Tu >> 24));
+
+  // lanes 0 .. 7: the grade's count, label and (sorted position | padded grade position << 16) of its first item
+  unsigned long long labs = 0ull;                             // byte g = the g-th largest label present (scalar loop)
+  {
+    unsigned pm = present;
+    for (int g = 0; g < ng; ++g) {
+      const int gb = 31 - __builtin_clz(pm);
+      pm &= ~(1u << gb);
+      labs |= (unsigned long long)gb << (8 * g);
+    }
+  }
+  const unsigned gsh = (unsigned)(lane & 7) << 3;
+  const unsigned long long T64 = ((unsigned long long)Tu << 32) | Tl;
+  const unsigned cnt_g = lane < ng ? (unsigned)(T64 >> gsh) & 0xffu : 0u;
+  const unsigned lab_g = (unsigned)(labs >> gsh) & 0xffu;
+  const unsigned pc = cnt_g | (((cnt_g + 3u) & ~3u) << 16);
+  unsigned sc = pc;
+  sc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sc, 0x111, 0xf, 0xf, true);
+  sc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sc, 0x112, 0xf, 0xf, true);
+  sc += (unsigned)__builtin_amdgcn_update_dpp(0, (int)sc, 0x114, 0xf, 0xf, true);
+  const unsigned startv = sc - pc;
+  const int np = ng > 0 ? (int)((unsigned)__builtin_amdgcn_readlane((int)sc, ng - 1) >> 16) : 0;   // padded length (multiple of 4)
+  const float gain_g = pow2 ? (__builtin_amdgcn_ldexpf(1.0f, (int)lab_g) - 1.0f) : (float)lab_g;
+
+  // per item: position inside its grade, compact position, sorted / padded grade position
+  int posr[IPL], sp[IPL], gp[IPL];
+  float g[IPL];
+  float* XS = reinterpret_cast<float*>(recH);                 // scratch: compact scores (rank count)
+  int* RKS = reinterpret_cast<int*>(recL);                    // scratch: count by compact position
+  int* OCC = RKS + Lp;                                        // scratch: how many items share a count
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    const unsigned cl = el + pl[r], cu = eu + ph[r];
+    const unsigned off = (unsigned)((((unsigned long long)cu << 32) | cl) >> sh[r]) & 0xffu;
+    posr[r] = (int)__builtin_amdgcn_sad_u8(cl, 0u, __builtin_amdgcn_sad_u8(cu, 0u, 0u));
+    const unsigned st = (unsigned)__builtin_amdgcn_ds_bpermute((int)(sh[r] >> 1), (int)startv);
+    sp[r] = (int)((st & 0xffffu) + off);
+    gp[r] = (int)((st >> 16) + off);
+    g[r] = pow2 ? (__builtin_amdgcn_ldexpf(1.0f, li[r]) - 1.0f) : (float)li[r];
+    if (lv[r]) XS[posr[r]] = x[r];
+  }
+  xmin = wave_min_u(xmin); xmax = wave_max_u(xmax);
+  const bool fast = (xmax - xmin) <= kLeanRange;              // wave-uniform
+  const float m = 0.5f * (xmax + xmin);
+  const int n4 = (n + 3) >> 2;
+  for (int p = n + lane; p < n4 * 4 + 4; p += 64) XS[p] = -INFINITY;
+  WAVE_LDS_SYNC();
+
+  // ranks by counting (score descending, ties by index) (:483-500): the bucket partition, the sweep as its fallback
+  int rk[IPL];
+  if (LpS < 192 || !wave_rank_by_bucket<IPL>(XS, n, lane, RKS, OCC, XS + Lp + 8, reinterpret_cast<int*>(GS), true, xmin, xmax))
+    wave_rank_by_count(XS, n, lane, RKS, OCC);
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) rk[r] = lv[r] ? RKS[posr[r]] : 0;
+  WAVE_LDS_SYNC();                                            // the scratch is rewritten below
+
+  // ideal DCG (:109-134): the terms g * D[sorted position] through LDS, added up in the general builder's order
+  float inv_max_dcg = 1.0f;
+  if (a.normalized) {
+    float* TS = reinterpret_cast<float*>(recL);               // 64 * IPL floats (2 LpS >= 64 * IPL + 32)
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) TS[IPL * lane + r] = lv[r] ? g[r] * Dlds[sp[r]] : 0.0f;
+    WAVE_LDS_SYNC();
+    float idcg = 0.f;
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) idcg += TS[lane + 64 * r];
+    idcg = wave_sum_u(idcg);
+    inv_max_dcg = (idcg > 0.0f) ? (1.0f / idcg) : 0.0f;
+    WAVE_LDS_SYNC();
+  }
+
+  // the image: zero records in the (at most three) padding slots behind every segment and in the 32 slots behind the
+  // last one (rows of the last pass, prefetch overrun of the column loops); CIS = -1 there
+  if (lane < ng) {
+    const int e0 = (int)(startv >> 16) + (int)cnt_g, e1 = (int)(startv >> 16) + (int)((cnt_g + 3u) & ~3u);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int p = e0 + j;
+      if (p < e1) { recH[p] = make_float2(0.f, 0.f); recL[p] = make_float2(0.f, 0.f); GS[p] = 0.f; CIS[p] = -1; }
+    }
+    H->seg_start[lane] = (int)(startv >> 16); H->seg_end[lane] = e1; H->seg_gain[lane] = gain_g * inv_max_dcg;
+  }
+  if (lane < 32) {
+    const int p = np + lane;
+    if (p < LpS) { recH[p] = make_float2(0.f, 0.f); recL[p] = make_float2(0.f, 0.f); GS[p] = 0.f; }
+    if (p < Lp) CIS[p] = -1;
+  }
+  const int rscale = 4 * R;
+#pragma unroll
+  for (int r = 0; r < IPL; ++r) {
+    if (!lv[r]) continue;
+    const float xv = x[r];
+    float Bv, Av;
+    if (fast) {
+      const float t_hi = xv - m;
+      const float bb = t_hi - xv;
+      const float t_lo = (xv - (t_hi - bb)) + (-m - bb);
+      Bv = exp_df_hw(t_hi, t_lo);                             // e^(x - m), 1 ulp
+      Av = __builtin_amdgcn_rcpf(Bv);                        // e^-(x - m)
+    } else {
+      Bv = xv; Av = 1.0f;                                     // slow path: the score itself / a validity flag
+    }
+    const float rb = __int_as_float(rk[r] * rscale);
+    recH[gp[r]] = make_float2(Bv, rb);
+    recL[gp[r]] = make_float2(Av, rb);
+    GS[gp[r]] = g[r] * inv_max_dcg;
+    CIS[gp[r]] = IPL * lane + r;
+  }
+  const int npass = (np + kGrpPassRows - 1) / kGrpPassRows;
+  if (lane == 0) {
+    H->n = n; H->np = np; H->nseg = ng; H->flags = fast ? 1 : 0;
+    H->npass = npass; H->lw = lw;
+    if (npass == 0) {                                         // no valid item: nothing to sweep, the sums are zero
+      if (a.list_loss && !a.sum.out) a.list_loss[b] = 0.f;
+    }
+  }
+  if (npass == 0 && a.sum.out) grid_sum_contribute(a.sum, b, 0.f, lane);
+  return true;
+}
+
 // BKT (round 4, TFR_LAMBDARANK_BUCKET=0 to switch off): the builder takes its ranks from wave_rank_by_bucket (the NDCG
 // metric kernel's rank step since round 4: same integers, ~1/5 of the instructions for 200 items) with the counting
 // sweep as the fallback -- outputs bit-identical to the counting builder (tools/lbucket_check.py: the config-3 batch,
 // 1024 x 256, tied scores, an outlier, short lists), kernel 47.5 -> 44.5 us at B = 4096, L = 200.
 template <int IPL, bool AUX, bool ITEMW, bool BKT = false>
-__global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp,
-                                                                const int G) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void lambdarank_group_kernel(const PwArgs a, const int B, const int R, const int Lp,
+                                                                const int G, const int kflags) {
+  // kflags bit 0: BKT builders take grp_build_graded (lane-major loads) when the labels allow it
   // G lists per workgroup, blockDim.x / 64 >= G wavefronts: waves 0 .. G-1 each BUILD one list's LDS image, then every
   // wave SWEEPS (list, 32-row pass) work items of whichever lists are ready, taken from per-list LDS tickets -- no
   // barrier between the two phases: a wave that has built its (short) list sweeps while a long list is still being
@@ -329,14 +514,37 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
       H->state = 0; H->next_pass = 0; H->done_pass = 0; H->npass = 0; H->b = b; H->n = 0;
     }
   }
+  const bool graded = BKT && (kflags & 1) && L <= 255;        // (wave-uniform) lane-major loads for grp_build_graded
 #pragma unroll
-  for (int r = 0; r < IPL; ++r) {
-    lab_raw[r] = -1.0f; x_raw[r] = 0.0f; w_raw[r] = 1.0f;
-    const int e = lane + 64 * r;
-    if (b >= 0 && e < L) {
-      lab_raw[r] = a.labels[(size_t)b * L + e];
-      x_raw[r] = a.logits[(size_t)b * L + e];
-      if (ITEMW) w_raw[r] = a.item_weights[(size_t)b * L + e];
+  for (int r = 0; r < IPL; ++r) { lab_raw[r] = -1.0f; x_raw[r] = 0.0f; w_raw[r] = 1.0f; }
+  if (BKT && graded) {
+    if (b >= 0) {
+      const float* lp = a.labels + (size_t)b * L;
+      const float* xp = a.logits + (size_t)b * L;
+      if (IPL == 4 && (L & 3) == 0 && (((uintptr_t)a.labels | (uintptr_t)a.logits) & 15) == 0) {
+        if (4 * lane < L) {                                   // one 16-byte load per array
+          const float4 lv4 = *reinterpret_cast<const float4*>(lp + 4 * lane);
+          const float4 xv4 = *reinterpret_cast<const float4*>(xp + 4 * lane);
+          lab_raw[0] = lv4.x; lab_raw[1 % IPL] = lv4.y; lab_raw[2 % IPL] = lv4.z; lab_raw[3 % IPL] = lv4.w;
+          x_raw[0] = xv4.x; x_raw[1 % IPL] = xv4.y; x_raw[2 % IPL] = xv4.z; x_raw[3 % IPL] = xv4.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) {
+          const int e = IPL * lane + r;
+          if (e < L) { lab_raw[r] = lp[e]; x_raw[r] = xp[e]; }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < IPL; ++r) {
+      const int e = lane + 64 * r;
+      if (b >= 0 && e < L) {
+        lab_raw[r] = a.labels[(size_t)b * L + e];
+        x_raw[r] = a.logits[(size_t)b * L + e];
+        if (ITEMW) w_raw[r] = a.item_weights[(size_t)b * L + e];
+      }
     }
   }
   if (b >= 0 && a.list_weights) lw = a.list_weights[b];
@@ -372,7 +580,20 @@ __global__ __launch_bounds__(1024) void lambdarank_group_kernel(const PwArgs a, 
     float* GS = reinterpret_cast<float*>(recL + LpS);
     float* WS = GS + LpS;                                                   // ITEMW only
     int* CIS = reinterpret_cast<int*>(GS + LpS + (ITEMW ? LpS : 0));
-    if (b >= 0) {
+    bool built = false;
+    if (BKT && graded && b >= 0) {
+      built = grp_build_graded<IPL>(a, b, lane, L, Lp, LpS, R, lw, lab_raw, x_raw, H, recH, recL, GS, CIS, Dlds);
+      if (!built) {                                           // any other label set: the general builder, element e = lane + 64 r
+        float* TS = reinterpret_cast<float*>(recH);           // (2 LpS floats >= 128 IPL)
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) { TS[IPL * lane + r] = lab_raw[r]; TS[64 * IPL + IPL * lane + r] = x_raw[r]; }
+        WAVE_LDS_SYNC();
+#pragma unroll
+        for (int r = 0; r < IPL; ++r) { lab_raw[r] = TS[lane + 64 * r]; x_raw[r] = TS[64 * IPL + lane + 64 * r]; }
+        WAVE_LDS_SYNC();
+      }
+    }
+    if (b >= 0 && !built) {
       const size_t base = (size_t)b * L;
       float* XS = reinterpret_cast<float*>(recH);                           // scratch: compact scores (rank count)
       int* RKS = reinterpret_cast<int*>(recL);                              // scratch: count by compact position

@@ -1039,7 +1039,7 @@ int launch_grp(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, hipStre
     if (e != hipSuccess) return (int)e;
   }
   const int N = (B + G - 1) / G;
-  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R, grp_lp(a.L), G);
+  hipLaunchKernelGGL((lambdarank_group_kernel<IPL, AUX, IW>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R, grp_lp(a.L), G, 0);
   return (int)hipGetLastError();
 }
 
@@ -1052,8 +1052,9 @@ int launch_grp_bucket(const PwArgs& a, int B, int G, int Wt, int R, size_t lds, 
     if (e != hipSuccess) return (int)e;
   }
   const int N = (B + G - 1) / G;
+  static const int env_graded = env_int("TFR_LAMBDARANK_GRADED", 1);     // 0: every list through the general builder
   hipLaunchKernelGGL((lambdarank_group_kernel<IPL, false, false, true>), dim3(N), dim3(64 * Wt), lds, stream, a, B, R,
-                     grp_lp(a.L), G);
+                     grp_lp(a.L), G, env_graded ? 1 : 0);
   return (int)hipGetLastError();
 }
 

@@ -8,6 +8,7 @@ bit-exact; fp32 losses |delta| <= 1e-5; gradients max|delta| <= 1e-5 * max|g|
 materialised op graph (the reference has no gradient tests: SURVEY.md 8c).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -1469,6 +1470,30 @@ def test_every_recorded_launch_with_a_ticket_state_owns_its_slot():
     torch.cuda.synchronize()
     assert torch.equal(outs[0], ref) and torch.equal(outs[1], ref)
     _assert_tickets_zero()
+
+
+def test_graded_builder_of_the_lambdarank_kernel_matches_the_general_builder_bit_for_bit(tmp_path):
+    """round 6 (lambdarank_group.h: grp_build_graded -- lane-major loads, one packed scan for the compaction and the grade
+    order) against the general builder on the config-3 batch, list sizes of every IPL, 8 / 9 / 13 grades, non-integer and
+    large labels (the graded builder declines and hands over through LDS), ties, an outlier, an empty list, weights,
+    T != 1, DCG: every output identical.  The switch is read once per process, hence two processes."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'lgraded_check.py')
+    files = []
+    for v in ('1', '0'):
+        f = str(tmp_path / ('graded_%s.pt' % v))
+        env = dict(os.environ, TFR_LAMBDARANK_GRADED=v)
+        r = subprocess.run([sys.executable, tool, f], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        files.append(torch.load(f))
+    a, b = files
+    assert a.keys() == b.keys() and len(a) >= 10
+    for name in a:
+        for i, (x, y) in enumerate(zip(a[name], b[name])):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y), '%s: output %d differs (max |d| %g)' % (name, i, (x - y).abs().max().item())
 
 
 # ------------------------------------------------------------------ UniqueSoftmax (SURVEY 8f #2)

@@ -127,6 +127,11 @@ for what in "$@"; do
         python tools/rocpd_summary.py stats $OUT/prof_$w/r_results.db > $OUT/stats_$w.txt 2>&1; head -n 6 $OUT/stats_$w.txt | cut -c1-130
       done
       find $OUT -name '*.db' -size +4M -delete ;;
+    lgraded)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "graded_builder" > $OUT/t_graded.log 2>&1; echo "graded test rc=$?"; tail -n 6 $OUT/t_graded.log | cut -c1-300
+      timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "pairwise or lambda" > $OUT/t_pw.log 2>&1; echo "pairwise tests rc=$?"; tail -n 3 $OUT/t_pw.log | cut -c1-200
+      for v in 1 0 1 0; do ab "graded=$v" pairwise_lambda 200 TFR_LAMBDARANK_GRADED=$v; done
+      ab "graded=1" e2e_pairwise_lambda 20 TFR_LAMBDARANK_GRADED=1 ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
