@@ -778,7 +778,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
     // publish: release at workgroup scope (every LDS store above is ordered before the flag; the sweepers acquire it)
     WAVE_LDS_SYNC();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&H->state, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (the pass count travels in the flag word: state = 2 | npass << 8 -- one LDS read per poll; reading H->npass through
+    //  a volatile pointer was a FLAT load with a vmcnt(0) wait on the polling path)
+    if (lane == 0) __hip_atomic_store(&H->state, 2 | (b >= 0 ? H->npass << 8 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   GRP_STAMP(5);
 
@@ -797,9 +799,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6))) void 
       int st = 0;
       if (lane == 0) st = __hip_atomic_load(&H->state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       st = __builtin_amdgcn_readfirstlane(st);
-      if (st == 2) {
+      if ((st & 0xff) == 2) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // the image and the header fields below were written before the flag
-        npass = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(&H->npass));
+        npass = st >> 8;
         int t = 0;
         if (lane == 0) t = (npass > 0) ? atomicAdd(&H->next_pass, 1) : 0;
         q = __builtin_amdgcn_readfirstlane(t);
