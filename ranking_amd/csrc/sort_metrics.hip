@@ -1469,10 +1469,10 @@ __global__ __launch_bounds__(1024) void list_scatter_kernel(int B, int L, const 
 //     over the column sums + the column sums of the workgroups before it: lane = class, coalesced 256-byte rows) and
 //     places its 256 lists with LDS cursors.  Workspace: cls (B bytes) + partial (64 ints per workgroup) <= B ints.
 constexpr int kOrderParallelMin = 512;
-constexpr int kOrderLists = 256;    // lists per workgroup
+constexpr int kOrderLists = 256;    // lists per workgroup (LPB below; 128 from 8 192 lists on: twice the workgroups, round 6)
 
-template <bool DEEP>
-__global__ __launch_bounds__(1024) void list_class_kernel(const float* __restrict__ labels,
+template <bool DEEP, int LPB>
+__global__ __launch_bounds__(4 * LPB) void list_class_kernel(const float* __restrict__ labels,
                                                           const uint8_t* __restrict__ mask, int B, int L,
                                                           uint8_t* __restrict__ cls, int* __restrict__ partial) {
   __shared__ int s_hist[kOrderClasses];
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(1024) void list_class_kernel(const float* __restric
   // flight per thread), no wave-wide ballot to wait for.  (A wave per list, 64 lists one after the other, measured
   // 90 us here -- every ballot waits for its own load; one thread per list 11 us.)
   const int t = threadIdx.x & 3;
-  const int b = blockIdx.x * kOrderLists + (threadIdx.x >> 2);
+  const int b = blockIdx.x * LPB + (threadIdx.x >> 2);
   int n = 0;
   if (b < B) {
     const size_t base = (size_t)b * L;
@@ -1532,6 +1532,7 @@ __global__ __launch_bounds__(1024) void list_class_kernel(const float* __restric
   if (threadIdx.x < kOrderClasses) partial[blockIdx.x * kOrderClasses + threadIdx.x] = s_hist[threadIdx.x];
 }
 
+template <int LPB>
 __global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const uint8_t* __restrict__ cls,
                                                          const int* __restrict__ partial, int* __restrict__ order_out) {
   __shared__ int s_cur[kOrderClasses];
@@ -1556,8 +1557,8 @@ __global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const 
     s_cur[lane] = inc - t + bf;
   }
   __syncthreads();
-  const int b = blockIdx.x * kOrderLists + threadIdx.x;
-  if (b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
+  const int b = blockIdx.x * LPB + threadIdx.x;
+  if ((int)threadIdx.x < LPB && b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
 }
 
 inline int block_threads_for(int P) {
@@ -1735,13 +1736,25 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
   hipStream_t st = (hipStream_t)stream;
   static const int env_par = [] { const char* e = getenv("TFR_ORDER_PARALLEL"); return (e && *e) ? atoi(e) : 1; }();
   if (env_par && B >= kOrderParallelMin) {
-    const int nblk = (B + kOrderLists - 1) / kOrderLists;
+    // 128 lists per workgroup from 8 192 lists on: with 256 a batch of 16 384 lists ran on 64 of the 256 CUs
+    static const int env_lpb = [] { const char* e = getenv("TFR_ORDER_LPB"); return (e && *e) ? atoi(e) : 0; }();
+    const bool half = env_lpb ? env_lpb == 128 : B >= 8192;
+    const int lpb = half ? 128 : kOrderLists;
+    const int nblk = (B + lpb - 1) / lpb;
     uint8_t* cls = reinterpret_cast<uint8_t*>(workspace);                    // B bytes
-    int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 4 + 64 <= B - B/4)
-    if (nblk < 32) hipLaunchKernelGGL(list_class_kernel<true>, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
-    else hipLaunchKernelGGL(list_class_kernel<false>, dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
-    hipLaunchKernelGGL(list_place_kernel, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
-                       (const int*)partial, (int*)order_out);
+    int* partial = reinterpret_cast<int*>(workspace) + (B + 3) / 4;         // nblk * 64 ints (<= B / 2 + 64 <= B - B / 4)
+    static const int env_deep = [] { const char* e = getenv("TFR_ORDER_DEEP"); return (e && *e) ? atoi(e) : -1; }();
+    if (half) {
+      if (env_deep == 1) hipLaunchKernelGGL((list_class_kernel<true, 128>), dim3(nblk), dim3(512), 0, st, labels, mask, B, L, cls, partial);
+      else hipLaunchKernelGGL((list_class_kernel<false, 128>), dim3(nblk), dim3(512), 0, st, labels, mask, B, L, cls, partial);
+      hipLaunchKernelGGL(list_place_kernel<128>, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
+                         (const int*)partial, (int*)order_out);
+    } else {
+      if (nblk < 32) hipLaunchKernelGGL((list_class_kernel<true, 256>), dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
+      else hipLaunchKernelGGL((list_class_kernel<false, 256>), dim3(nblk), dim3(1024), 0, st, labels, mask, B, L, cls, partial);
+      hipLaunchKernelGGL(list_place_kernel<256>, dim3(nblk), dim3(256), 0, st, B, nblk, (const uint8_t*)cls,
+                         (const int*)partial, (int*)order_out);
+    }
     return (int)hipGetLastError();
   }
   hipLaunchKernelGGL(list_count_kernel, dim3((B + 3) / 4), dim3(256), 0, st, labels, mask, B, L, (int*)workspace);

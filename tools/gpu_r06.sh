@@ -132,6 +132,18 @@ for what in "$@"; do
       timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_baseline_configs.py -x -q -m gpu -k "pairwise or lambda" > $OUT/t_pw.log 2>&1; echo "pairwise tests rc=$?"; tail -n 3 $OUT/t_pw.log | cut -c1-200
       for v in 1 0 1 0; do ab "graded=$v" pairwise_lambda 200 TFR_LAMBDARANK_GRADED=$v; done
       ab "graded=1" e2e_pairwise_lambda 20 TFR_LAMBDARANK_GRADED=1 ;;
+    order_lpb)
+      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "order" > $OUT/t_order.log 2>&1; echo "order tests rc=$?"; tail -n 2 $OUT/t_order.log | cut -c1-200
+      for v in 256 128 256 128; do ab "lpb=$v" approx_ndcg 200 TFR_ORDER_LPB=$v; done
+      ab "lpb=128 deep" approx_ndcg 200 TFR_ORDER_LPB=128 TFR_ORDER_DEEP=1
+      ab "lpb=128 at 4096" pairwise_lambda 200 TFR_ORDER_LPB=128
+      ab "lpb=128 deep at 4096" pairwise_lambda 200 TFR_ORDER_LPB=128 TFR_ORDER_DEEP=1
+      ab "default at 4096" pairwise_lambda 200 TFR_DUMMY=0
+      for v in 256 128; do
+        TFR_ORDER_LPB=$v timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_lpb$v -o r -- python bench.py --workload approx_ndcg --steps 50 --warmup 5 $ONE > $OUT/prof_lpb$v.log 2>&1
+        python tools/rocpd_summary.py stats $OUT/prof_lpb$v/r_results.db > $OUT/stats_lpb$v.txt 2>&1; head -n 5 $OUT/stats_lpb$v.txt | cut -c1-130
+      done
+      find $OUT -name '*.db' -size +4M -delete ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
