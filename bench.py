@@ -354,10 +354,32 @@ def build_e2e_step(workload, labels, dropout=0.0, use_graph=False):
         info.update(step=eager_step, all_reduce=lambda: bucket.all_reduce(scal, average=True))
         return info
 
+    ss, split_requested = None, bool(split)
     if split:
-        ss = D.SplitStep(scorer, bucket, early_numel, split, lambda: fwd_bwd(zero=False), sgd, average=True,
-                         graph_generators=graph_generators)
-
+        # The overlapped step has run on two gloo ranks sharing one GPU and at N = 1, never on RCCL with N > 1 (no such box
+        # in any session): if it cannot be built or replayed once here, say so on stderr and measure the serial step below
+        # (one graph, ONE all-reduce, the optimizer graph) instead of losing the line.
+        try:
+            ss = D.SplitStep(scorer, bucket, early_numel, split, lambda: fwd_bwd(zero=False), sgd, average=True,
+                             graph_generators=graph_generators)
+            ss()
+            torch.cuda.synchronize()
+        except Exception as e:                              # noqa: BLE001 -- any failure of the optional form
+            sys.stderr.write('bench: the overlapped gradient exchange (SplitStep) failed, serial exchange instead: %r\n' % (e,))
+            ss, split = None, 0
+            for m in scorer.modules():
+                if hasattr(m, 'grad_split'):
+                    m.grad_split, m.grad_split_hook = 0, None
+    if split_requested and world > 1:                       # every rank takes the same form
+        import torch.distributed as dist
+        ok = torch.tensor([1.0 if ss is not None else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1.0 and ss is not None:
+            ss, split = None, 0
+            for m in scorer.modules():
+                if hasattr(m, 'grad_split'):
+                    m.grad_split, m.grad_split_hook = 0, None
+    if ss is not None:
         def split_step():
             return ss()[0] / max(world, 1)
 
