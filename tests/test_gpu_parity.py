@@ -1379,6 +1379,7 @@ def test_list_mle_shuffles_tied_labels_like_the_reference(B, L):
     if L >= 100:
         # (round 6: the seeds come from a private generator keyed on torch.initial_seed() -- it restarts when the user
         #  seeds torch with ANOTHER value, and never touches the global generator's stream)
+        torch.manual_seed(7); fresh.compute(lb, lg, None, red)      # (whatever seed an earlier test left: move away from 1 first)
         torch.manual_seed(1); a1, a2 = fresh.compute(lb, lg, None, red).item(), fresh.compute(lb, lg, None, red).item()
         torch.manual_seed(2); fresh.compute(lb, lg, None, red)
         torch.manual_seed(1); b1 = fresh.compute(lb, lg, None, red).item()
