@@ -34,5 +34,22 @@ def pmc(db, substr=''):
                                                                     r[5], r[6], r[7], r[8], r[9]))
 
 
+def seq(db, n='120'):
+    """the last n kernel dispatches in start order: start offset, duration, gap to the previous one (us)"""
+    con = sqlite3.connect(db)
+    cur = con.cursor()
+    try:
+        rows = list(cur.execute('select name, start, end from kernels order by start'))
+    except sqlite3.Error as e:
+        print('no `kernels` view (%s); objects: %s' % (e, [r[0] for r in cur.execute("select name from sqlite_master")]))
+        return
+    rows = rows[-int(n):]
+    t0, prev_end = rows[0][1], None
+    for name, st, en in rows:
+        gap = (st - prev_end) / 1000.0 if prev_end is not None else 0.0
+        print('%10.1f %8.2f %7.2f  %s' % ((st - t0) / 1000.0, (en - st) / 1000.0, gap, short(name, 90)))
+        prev_end = en
+
+
 if __name__ == '__main__':
-    {'stats': stats, 'pmc': pmc}[sys.argv[1]](*sys.argv[2:])
+    {'stats': stats, 'pmc': pmc, 'seq': seq}[sys.argv[1]](*sys.argv[2:])
