@@ -460,6 +460,11 @@ int tfr_tower_weight_cast(const float* w, int R, int C, int transpose, int pitch
  * of a training step -- forward operands and transposed dgrad operands -- together. */
 int tfr_tower_weight_cast_batch(const float* const* w, const int* R, const int* C, const int* transpose,
                                 const int* pitch, void* const* out_bf16, int count, void* stream);
+/* The same launch also advances the Dropout step counter (tfr_tower_dropout.step): *step += 1, *step_copy = the new
+ * value -- one-element int32 device tensors (both or neither); a captured step draws new masks at every replay. */
+int tfr_tower_weight_cast_batch_step(const float* const* w, const int* R, const int* C, const int* transpose,
+                                     const int* pitch, void* const* out_bf16, int count, int32_t* step,
+                                     int32_t* step_copy, void* stream);
 /* Dense (+ fused neighbours): C[M, N] = prologue(A)[M, K] . B[N, K]^T + bias, bf16 out. */
 int tfr_tower_gemm_bf16(const void* A, long lda, const void* B, long ldb, void* C, long ldc,
                         int M, int N, int K, int prologue, const float* a_scale, const float* a_shift,
@@ -517,6 +522,12 @@ int tfr_tower_reduce_partials(const float* partial, int T, int W, float* out, fl
 int tfr_tower_reduce_partials_coeffs(const float* partial, int T, int J, int N, float* out, float* scratch,
                                      const float* gamma, const float* rstd, const float* mean, long M,
                                      float* pqr, void* stream);
+/* The same launch also adds up the columns of dl[Mr][O] (O <= 4: the output layer's bias gradient) into db[O] -- only in
+ * the one-launch form (tfr_tower_reduce_partials_serves_db(T, J) == 1); dl = NULL: exactly the call above. */
+int tfr_tower_reduce_partials_serves_db(int T, int J);
+int tfr_tower_reduce_partials_coeffs_db(const float* partial, int T, int J, int N, float* out, float* scratch,
+                                        const float* gamma, const float* rstd, const float* mean, long M,
+                                        float* pqr, const float* dl, long Mr, int O, float* db, void* stream);
 /* Output Dense(output_units <= 4): out[M, O] = prologue(z)[M, K] . w[O, K]^T + b (fp32). */
 int tfr_tower_out_f32(const void* z, long ldz, int M, int K, int prologue, const float* scale,
                       const float* shift, const float* w, const float* b, int O, float* out,

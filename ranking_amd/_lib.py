@@ -105,12 +105,17 @@ _SIGNATURES = {
     'tfr_tower_reduce_partials': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
     'tfr_tower_reduce_partials_coeffs': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
                                          + [ctypes.c_long] + [ctypes.c_void_p] * 2),
+    'tfr_tower_reduce_partials_serves_db': (ctypes.c_int, [ctypes.c_int] * 2),
+    'tfr_tower_reduce_partials_coeffs_db': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 5
+                                            + [ctypes.c_long] + [ctypes.c_void_p] * 2 + [ctypes.c_long, ctypes.c_int]
+                                            + [ctypes.c_void_p] * 2),
     'tfr_tower_out_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                           + [ctypes.c_void_p] * 4 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
     'tfr_tower_out_bwd': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3
                           + [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p, ctypes.c_long]
                           + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_weight_cast_batch': (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int, ctypes.c_void_p]),
+    'tfr_tower_weight_cast_batch_step': (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] + [ctypes.c_void_p] * 3),
     'tfr_tower_multi_add': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     'tfr_flatten_row_index': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_out_bwd2': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long] + [ctypes.c_int] * 3

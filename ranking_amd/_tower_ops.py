@@ -197,8 +197,10 @@ def cast_weight(w: torch.Tensor, transpose: bool = False, pitch: Optional[int] =
     return out
 
 
-def cast_weights(specs):
-    """[(w fp32 [R, C], transpose, pitch | None), ...] -> the bf16 operands of cast_weight, one launch per 8."""
+def cast_weights(specs, step=None):
+    """[(w fp32 [R, C], transpose, pitch | None), ...] -> the bf16 operands of cast_weight, one launch per 8.
+    ``step`` = (counter, copy), one-element int32 device tensors: the launch also advances the Dropout step counter
+    (counter += 1, copy = counter) instead of an add_ and a clone launch of their own."""
     ws, outs, Rs, Cs, trs, ps = [], [], [], [], [], []
     for w, transpose, pitch in specs:
         require_device(w, 'w')
@@ -210,9 +212,21 @@ def cast_weights(specs):
     n = len(ws)
     if n:
         arr = lambda xs: (ctypes.c_int * n)(*xs)
+        if step is not None:
+            counter, copy = step
+            for t in (counter, copy):
+                if t.numel() != 1 or t.dtype != torch.int32 or not t.is_cuda:
+                    raise ValueError('step tensors must be one-element int32 device tensors')
+            _lib.check(_lib.load().tfr_tower_weight_cast_batch_step(
+                (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws]), arr(Rs), arr(Cs), arr(trs), arr(ps),
+                (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n, counter.data_ptr(), copy.data_ptr(), _stream()),
+                'tfr_tower_weight_cast_batch_step')
+            return outs
         _lib.check(_lib.load().tfr_tower_weight_cast_batch(
             (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws]), arr(Rs), arr(Cs), arr(trs), arr(ps),
             (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), n, _stream()), 'tfr_tower_weight_cast_batch')
+    elif step is not None:
+        step[0].add_(1); step[1].copy_(step[0])
     return outs
 
 
@@ -272,25 +286,35 @@ def bn_finalize(partial, M, gamma, beta, eps, momentum, moving_mean, moving_var)
 _FUSED_ROWS = 1024          # tfr_tower_reduce_partials_coeffs / tfr_tower_bn_finalize: one launch up to this many rows
 
 
-def reduce_partials(partial, bn=None):
+def reduce_partials(partial, bn=None, colsum_of=None):
     """[T, J, N] per-workgroup column partials -> [J, N] sums.  ``bn = (gamma, rstd, mean, M)``: also the
     BatchNorm-backward coefficients pqr [3, N] of the layer whose (sum dy, sum dy zhat) are rows 0 / 1, from the same
-    launch; returns (sums, pqr) then."""
+    launch; returns (sums, pqr) then.  ``colsum_of`` = fp32 [Mr, O <= 4] (the output layer's dlogits): its column sums
+    ride in the same launch when the one-launch form serves the shape, and are appended to the result (None when not)."""
     T, J, N = partial.shape
     out = torch.empty((J, N), dtype=torch.float32, device=partial.device)
     fused = T <= _FUSED_ROWS and J <= 6
     scratch = None if fused else _scratch(T, J * N, partial.device)
-    if bn is None:
-        _lib.check(_lib.load().tfr_tower_reduce_partials_coeffs(_ptr(partial), T, J, N, _ptr(out), _ptr(scratch), None,
-                                                               None, None, 0, None, _stream()),
-                   'tfr_tower_reduce_partials_coeffs')
-        return out
-    gamma, rstd, mean, M = bn
-    pqr = torch.empty((3, N), dtype=torch.float32, device=partial.device)
-    _lib.check(_lib.load().tfr_tower_reduce_partials_coeffs(_ptr(partial), T, J, N, _ptr(out), _ptr(scratch),
-                                                           _ptr(gamma.detach()), _ptr(rstd), _ptr(mean), M, _ptr(pqr),
-                                                           _stream()), 'tfr_tower_reduce_partials_coeffs')
-    return out, pqr
+    lib = _lib.load()
+    db = None
+    if colsum_of is not None and colsum_of.dim() == 2 and 1 <= colsum_of.shape[1] <= 4 and colsum_of.is_contiguous() \
+            and lib.tfr_tower_reduce_partials_serves_db(T, J):
+        db = torch.empty((colsum_of.shape[1],), dtype=torch.float32, device=partial.device)
+    gamma, rstd, mean, M = bn if bn is not None else (None, None, None, 0)
+    pqr = torch.empty((3, N), dtype=torch.float32, device=partial.device) if bn is not None else None
+    if db is not None:
+        _lib.check(lib.tfr_tower_reduce_partials_coeffs_db(
+            _ptr(partial), T, J, N, _ptr(out), _ptr(scratch), _ptr(gamma.detach()) if bn is not None else None, _ptr(rstd),
+            _ptr(mean), M, _ptr(pqr), _ptr(colsum_of), colsum_of.shape[0], colsum_of.shape[1], _ptr(db), _stream()),
+            'tfr_tower_reduce_partials_coeffs_db')
+    else:
+        _lib.check(lib.tfr_tower_reduce_partials_coeffs(
+            _ptr(partial), T, J, N, _ptr(out), _ptr(scratch), _ptr(gamma.detach()) if bn is not None else None, _ptr(rstd),
+            _ptr(mean), M, _ptr(pqr), _stream()), 'tfr_tower_reduce_partials_coeffs')
+    res = (out,) if bn is None else (out, pqr)
+    if colsum_of is not None:
+        return res + (db,)
+    return res[0] if bn is None else res
 
 
 def out_layer(z, K, prologue, scale, shift, w, b, dropout=None):
@@ -310,9 +334,10 @@ _OUT_BWD_ROWS = int(os.environ.get('TFR_OUT_BWD_ROWS', '128'))   # rows per work
 
 
 def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks=1024, dropout=None, bn=None):
-    """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K]) with
+    """Output-layer backward: returns (dy bf16 [M, K], sums [2 + O, K], db) with
     sums[0] = sum dy, sums[1] = sum dy * zhat, sums[2 + o] = d w[o, :]; with ``bn = (gamma, rstd, mean, M)`` of the
-    last hidden layer a third value: its BatchNorm-backward coefficients pqr (same launch as the sums)."""
+    last hidden layer (dy, sums, pqr, db): its BatchNorm-backward coefficients pqr (same launch as the sums).
+    db = the column sums of dlogits [O] from the same launch, or None (large M: the caller adds them up itself)."""
     _bf16(z, 'z')
     M = z.shape[0]
     w = w.detach().to(torch.float32).contiguous()
@@ -326,15 +351,16 @@ def out_layer_bwd(z, K, prologue, scale, shift, mean, rstd, w, dlogits, n_blocks
                                              dy.stride(0), _ptr(partial), n_blocks, _dp(dropout), _stream()),
                'tfr_tower_out_bwd')
     if bn is None:
-        return dy, reduce_partials(partial)
-    sums, pqr = reduce_partials(partial, bn)
-    return dy, sums, pqr
+        sums, db = reduce_partials(partial, None, colsum_of=dlogits)
+        return dy, sums, db
+    sums, pqr, db = reduce_partials(partial, bn, colsum_of=dlogits)
+    return dy, sums, pqr, db
 
 
 def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits, n_blocks=1024, dropout=None):
     """Output-layer backward when the last hidden layer is BatchNorm'd, in two passes over z so the
     [M, K] gradient is written once: pass 1 = column sums only, pass 2 recomputes dy and writes
-    dz = p * bf16(dy) + q * z + r.  Returns (dz bf16 [M, K], sums [2 + O, K]) -- bit-identical to
+    dz = p * bf16(dy) + q * z + r.  Returns (dz bf16 [M, K], sums [2 + O, K], db | None) -- dz and sums bit-identical to
     out_layer_bwd + bn_bwd_coeffs + bn_bwd_apply_."""
     _bf16(z, 'z')
     M = z.shape[0]
@@ -347,13 +373,13 @@ def out_layer_bwd_bn(z, K, prologue, scale, shift, mean, rstd, gamma, w, dlogits
     _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
                                       _ptr(rstd), _ptr(w), _ptr(dlogits), O, None, K, _ptr(partial), n_blocks,
                                       _dp(dropout), None, _stream()), 'tfr_tower_out_bwd2')
-    sums, pqr = reduce_partials(partial, (gamma, rstd, mean, M))
+    sums, pqr, db = reduce_partials(partial, (gamma, rstd, mean, M), colsum_of=dlogits)
     dz = torch.empty((M, K), dtype=torch.bfloat16, device=z.device)
     n2 = max(1, min(4096, (M + 15) // 16))
     _lib.check(lib.tfr_tower_out_bwd2(_ptr(z), z.stride(0), M, K, prologue, _ptr(scale), _ptr(shift), _ptr(mean),
                                       _ptr(rstd), _ptr(w), _ptr(dlogits), O, _ptr(dz), dz.stride(0), None, n2,
                                       _dp(dropout), _ptr(pqr), _stream()), 'tfr_tower_out_bwd2')
-    return dz, sums
+    return dz, sums, db
 
 
 def bn_bwd_coeffs(gamma, rstd, mean, c, M):

@@ -1417,8 +1417,11 @@ __global__ void tower_weight_cast_kernel(const float* __restrict__ w, int R, int
 
 // The same for up to 8 matrices in one launch (blockIdx.y = matrix): every weight cast of a training step
 // (forward operands and the transposed dgrad operands) together.
-struct WCastBatch { const float* w[8]; uint16_t* out[8]; int R[8], C[8], transpose[8], pitch[8]; };
+struct WCastBatch { const float* w[8]; uint16_t* out[8]; int R[8], C[8], transpose[8], pitch[8]; int* step; int* step_copy; };
 __global__ void tower_weight_cast_batch_kernel(const WCastBatch a) {
+  // the training-step counter of the Dropout masks advances HERE (round 6: it was an add_ and a clone launch of their own):
+  // nothing earlier in the step reads it, everything later reads the copy
+  if (a.step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { const int c = *a.step + 1; *a.step = c; *a.step_copy = c; }
   const int j = blockIdx.y;
   const float* __restrict__ w = a.w[j];
   uint16_t* __restrict__ out = a.out[j];
@@ -1588,10 +1591,64 @@ __global__ __launch_bounds__(1024) void tower_bn_finalize_fused_kernel(
 
 // out[j][n] = sum_t partial[t][j][n] for the J <= 6 stacked rows, and -- when gamma is given -- the BatchNorm-backward
 // coefficients pqr[3][N] of tower_bn_bwd_coeffs_kernel from rows 0 / 1 (sum dy, sum dy * zhat) in the same launch.
+// `dl` (optional, round 6): one more workgroup adds up the columns of dl[Mr][O] (the output layer's bias gradient, O <= 4) --
+// it was a torch reduction launch of its own (12.8 us of the 0.49 ms config-5 step).  Fixed order: thread t takes rows t,
+// t + 1024, ... in fp64, the 64 lanes of a wave meet in a shuffle tree, wave 0 adds the 16 wave sums in wave order.
 __global__ __launch_bounds__(1024) void tower_reduce_partials_fused_kernel(
     const float* __restrict__ partial, int T, int J, int N, float* __restrict__ out, const float* __restrict__ gamma,
-    const float* __restrict__ rstd, const float* __restrict__ mean, float inv_m, float* __restrict__ pqr) {
+    const float* __restrict__ rstd, const float* __restrict__ mean, float inv_m, float* __restrict__ pqr,
+    const float* __restrict__ dl, long Mr, int O, float* __restrict__ db) {
   __shared__ float part[kFusedWaves][6][64];
+  if (dl && blockIdx.x == gridDim.x - 1) {
+    double (*ws)[4] = reinterpret_cast<double (*)[4]>(&part[0][0][0]);      // [16 waves][4] doubles
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const long nel = Mr * O;
+    if ((O == 1 || O == 2 || O == 4) && (nel & 3) == 0 && (reinterpret_cast<uintptr_t>(dl) & 15) == 0) {
+      // the matrix as a flat run of float4: element e belongs to column e % O, a fixed pattern inside a float4; eight
+      // 16-byte loads of a thread in flight -- [25 600, 2] is two memory round trips (25 dependent loads took 11 us; sixteen in
+      // flight pushed the kernel to 128 registers and into scratch)
+      const float4* p4 = reinterpret_cast<const float4*>(dl);
+      const long n4 = nel >> 2;
+      for (long k0 = threadIdx.x; k0 < n4; k0 += 8 * 1024) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const long k = k0 + (long)u * 1024; v[u] = k < n4 ? p4[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (O == 1) { acc[0] += (double)v[u].x; acc[0] += (double)v[u].y; acc[0] += (double)v[u].z; acc[0] += (double)v[u].w; }
+          else if (O == 2) { acc[0] += (double)v[u].x; acc[1] += (double)v[u].y; acc[0] += (double)v[u].z; acc[1] += (double)v[u].w; }
+          else { acc[0] += (double)v[u].x; acc[1] += (double)v[u].y; acc[2] += (double)v[u].z; acc[3] += (double)v[u].w; }
+        }
+      }
+    } else {
+      for (long m0 = threadIdx.x; m0 < Mr; m0 += 8 * 1024) {
+        float v[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const long m = m0 + (long)u * 1024;
+#pragma unroll
+          for (int o = 0; o < 4; ++o) v[u][o] = (m < Mr && o < O) ? dl[m * O + o] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] += (double)v[u][o];
+      }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 0; o < O; ++o) {
+      double v = acc[o];
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+      if (lane == 0) ws[wave][o] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < O) {
+      double t = 0.0;
+      for (int w = 0; w < kFusedWaves; ++w) t += ws[w][threadIdx.x];
+      db[threadIdx.x] = (float)t;
+    }
+    return;
+  }
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   double sums[6];
   fused_column_sums<6>(partial, T, J, N, n, part, sums);
@@ -2537,9 +2594,19 @@ extern "C" int tfr_tower_weight_cast(const float* w, int R, int C, int transpose
   return (int)hipGetLastError();
 }
 
+extern "C" int tfr_tower_weight_cast_batch_step(const float* const* w, const int* R, const int* C, const int* transpose,
+                                                const int* pitch, void* const* out_bf16, int count, int32_t* step,
+                                                int32_t* step_copy, void* stream);
 extern "C" int tfr_tower_weight_cast_batch(const float* const* w, const int* R, const int* C, const int* transpose,
                                            const int* pitch, void* const* out_bf16, int count, void* stream) {
+  return tfr_tower_weight_cast_batch_step(w, R, C, transpose, pitch, out_bf16, count, nullptr, nullptr, stream);
+}
+
+extern "C" int tfr_tower_weight_cast_batch_step(const float* const* w, const int* R, const int* C, const int* transpose,
+                                                const int* pitch, void* const* out_bf16, int count, int32_t* step,
+                                                int32_t* step_copy, void* stream) {
   if (count < 0 || (count > 0 && (!w || !R || !C || !transpose || !pitch || !out_bf16))) return TFR_EINVAL;
+  if ((step != nullptr) != (step_copy != nullptr) || (step && count == 0)) return TFR_EINVAL;
   for (int j = 0; j < count; ++j)
     if (!w[j] || !out_bf16[j] || R[j] <= 0 || C[j] <= 0 || pitch[j] < (transpose[j] ? R[j] : C[j])) return TFR_EINVAL;
   for (int c0 = 0; c0 < count; c0 += 8) {
@@ -2553,6 +2620,7 @@ extern "C" int tfr_tower_weight_cast_batch(const float* const* w, const int* R, 
       const int total = (transpose[s] ? C[s] : R[s]) * pitch[s];
       if (j < c && total > tmax) tmax = total;
     }
+    a.step = c0 == 0 ? step : nullptr; a.step_copy = step_copy;
     hipLaunchKernelGGL(tower_weight_cast_batch_kernel, dim3(grid_for(tmax, 256), c), dim3(256), 0,
                        (hipStream_t)stream, a);
   }
@@ -2786,15 +2854,29 @@ extern "C" int tfr_tower_slab_reduce(const float* slab, int S, long n, float* ou
   return (int)hipGetLastError();
 }
 
+extern "C" int tfr_tower_reduce_partials_coeffs_db(const float* partial, int T, int J, int N, float* out, float* scratch,
+                                                   const float* gamma, const float* rstd, const float* mean, long M,
+                                                   float* pqr, const float* dl, long Mr, int O, float* db, void* stream);
 extern "C" int tfr_tower_reduce_partials_coeffs(const float* partial, int T, int J, int N, float* out, float* scratch,
                                                 const float* gamma, const float* rstd, const float* mean, long M,
                                                 float* pqr, void* stream) {
+  return tfr_tower_reduce_partials_coeffs_db(partial, T, J, N, out, scratch, gamma, rstd, mean, M, pqr, nullptr, 0, 0, nullptr,
+                                             stream);
+}
+
+// 1 when tfr_tower_reduce_partials_coeffs_db also serves `db` for this shape (the one-launch form)
+extern "C" int tfr_tower_reduce_partials_serves_db(int T, int J) { return (T <= kFusedRows && J <= 6) ? 1 : 0; }
+
+extern "C" int tfr_tower_reduce_partials_coeffs_db(const float* partial, int T, int J, int N, float* out, float* scratch,
+                                                   const float* gamma, const float* rstd, const float* mean, long M,
+                                                   float* pqr, const float* dl, long Mr, int O, float* db, void* stream) {
   if (!partial || T <= 0 || J <= 0 || N <= 0 || !out) return TFR_EINVAL;
   if (gamma && (!rstd || !mean || !pqr || M <= 0 || J < 2)) return TFR_EINVAL;
+  if (dl && (!db || Mr <= 0 || O < 1 || O > 4 || !(T <= kFusedRows && J <= 6))) return TFR_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   if (T <= kFusedRows && J <= 6) {
-    hipLaunchKernelGGL(tower_reduce_partials_fused_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, partial, T, J, N, out,
-                       gamma, rstd, mean, gamma ? 1.0f / (float)M : 0.0f, pqr);
+    hipLaunchKernelGGL(tower_reduce_partials_fused_kernel, dim3((N + 63) / 64 + (dl ? 1 : 0)), dim3(1024), 0, st, partial, T, J,
+                       N, out, gamma, rstd, mean, gamma ? 1.0f / (float)M : 0.0f, pqr, dl, Mr, O, db);
     return (int)hipGetLastError();
   }
   const int rc = tfr_tower_reduce_partials(partial, T, J * N, out, scratch, stream);

@@ -139,10 +139,10 @@ class _TowerFn(torch.autograd.Function):
         rate = tower.dropout if training else 0.0
         step_t = None
         if rate > 0.0:
-            # the step counter lives on the device (one add + one copy launch): a hipGraph replay of this forward draws a
-            # new mask, and the backward of THIS forward reads the copy it saved whatever runs in between
-            tower._drop_counter.add_(1)
-            step_t = tower._drop_counter.clone()
+            # the step counter lives on the device: a hipGraph replay of this forward draws a new mask, and the backward of
+            # THIS forward reads the copy it saved whatever runs in between.  Counter += 1 and the copy happen inside the
+            # weight-cast launch below (round 6; they were an add_ and a clone launch of their own)
+            step_t = torch.empty_like(tower._drop_counter)
             base = torch.initial_seed() & 0xffffffff
         # every weight cast of the step in one launch: [N, k_in] forward operands (k_in = staged width of the layer
         # input) and, when a backward will follow, the transposed [K, pad8(N)] dgrad operands of layers >= 1
@@ -150,7 +150,7 @@ class _TowerFn(torch.autograd.Function):
         want_bwd = any(ctx.needs_input_grad[4:])
         if want_bwd:
             specs += [(Ws[l], True, None) for l in range(1, n_h)]
-        cast = T.cast_weights(specs)
+        cast = T.cast_weights(specs, step=(tower._drop_counter, step_t) if step_t is not None else None)
         wbs, ctx.wts = cast[:n_h], [None] + cast[n_h:]
         a_outs = [None] * n_h
         for l in range(n_h):
@@ -227,15 +227,16 @@ class _TowerFn(torch.autograd.Function):
                       and not os.environ.get('TFR_TOWER_NO_FUSED_LAST'))
         pqr = None                                         # BatchNorm-backward coefficients of the layer at hand
         if fused_last:                                     # dz of the last hidden layer directly (two passes over z)
-            dy, sums = T.out_layer_bwd_bn(zs[-1], n_last, pro, sc, sh, mean, rstd, gammas[-1], w_out, dlogits,
-                                          dropout=drop)
+            dy, sums, db_out = T.out_layer_bwd_bn(zs[-1], n_last, pro, sc, sh, mean, rstd, gammas[-1], w_out, dlogits,
+                                                  dropout=drop)
         elif use_bn:                                       # (sum dy, sum dy zhat) and the coefficients in one launch
-            dy, sums, pqr = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop,
-                                            bn=(gammas[-1], rstd, mean, M))
+            dy, sums, pqr, db_out = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop,
+                                                    bn=(gammas[-1], rstd, mean, M))
         else:
-            dy, sums = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
+            dy, sums, db_out = T.out_layer_bwd(zs[-1], n_last, pro, sc, sh, mean, rstd, w_out, dlogits, dropout=drop)
         dw_out = sums[2:].contiguous()
-        db_out = dlogits.sum(dim=0)
+        if db_out is None:                                 # (large M: the partial reduction is not the one-launch form)
+            db_out = dlogits.sum(dim=0)
         cc = sums                                          # rows 0 / 1: sum dy, sum dy * zhat of the layer below
         # (a bias below BatchNorm has no gradient: zeros for autograd; the in-place mode skips them -- no fill launch)
         db_zero = (torch.zeros(sum(z.shape[1] for z in zs), device=dev).split([z.shape[1] for z in zs])

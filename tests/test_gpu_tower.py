@@ -163,7 +163,8 @@ def test_out_layer_bwd_and_bn_apply():
         a = torch.relu(y) if pro == 2 else y
         da = dl @ w
         dy_want = da * (y > 0) if pro == 2 else da
-        dy, sums = t.out_layer_bwd(z, K, pro, sc if pro else None, sh if pro else None, mean, rstd, w, dl, n_blocks=7)
+        dy, sums, db = t.out_layer_bwd(z, K, pro, sc if pro else None, sh if pro else None, mean, rstd, w, dl, n_blocks=7)
+        assert db is not None and torch.allclose(db, dl.sum(dim=0), rtol=1e-5, atol=1e-6)
         bf16_close(dy, dy_want, 'dy')
         zhat = (zf - mean) * rstd
         tol = 2e-3 * M ** 0.5
@@ -245,9 +246,10 @@ def test_out_layer_bwd_bn_two_pass_is_bit_identical_to_three_kernels(M, K, O, pr
     mean = zf.mean(0); rstd = torch.rsqrt(zf.var(0, unbiased=False) + 1e-3)
     sc = gamma * rstd; sh = beta - mean * sc
     w = rnd((O, K), 53, 0.2).to(DEV); dl = rnd((M, O), 54).to(DEV)
-    dy, sums = t.out_layer_bwd(z, K, pro, sc, sh, mean, rstd, w, dl)
+    dy, sums, _ = t.out_layer_bwd(z, K, pro, sc, sh, mean, rstd, w, dl)
     want = t.bn_bwd_apply_(dy, z, K, t.bn_bwd_coeffs(gamma, rstd, mean, sums[:2], M))
-    got, sums2 = t.out_layer_bwd_bn(z, K, pro, sc, sh, mean, rstd, gamma, w, dl)
+    got, sums2, db2 = t.out_layer_bwd_bn(z, K, pro, sc, sh, mean, rstd, gamma, w, dl)
+    assert db2 is None or torch.allclose(db2, dl.float().sum(dim=0), rtol=1e-5, atol=1e-6)
     assert torch.equal(sums, sums2)
     assert torch.equal(got.view(torch.int16), want.view(torch.int16))
 

@@ -144,6 +144,10 @@ for what in "$@"; do
         python tools/rocpd_summary.py stats $OUT/prof_lpb$v/r_results.db > $OUT/stats_lpb$v.txt 2>&1; head -n 5 $OUT/stats_lpb$v.txt | cut -c1-130
       done
       find $OUT -name '*.db' -size +4M -delete ;;
+    tower_quick)
+      timeout 1500 python -m pytest tests/test_gpu_tower.py tests/test_gpu_groupwise.py tests/test_gpu_distributed.py tests/test_gpu_baseline_configs.py -x -q -m gpu > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 3 $OUT/t_tower.log | cut -c1-200
+      for w in e2e_groupwise_gumbel e2e_softmax e2e_approx_ndcg_l1000; do ab "now" $w 50 TFR_DUMMY=0; done
+      ab "now again" e2e_groupwise_gumbel 50 TFR_DUMMY=0 ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
