@@ -148,6 +148,11 @@ for what in "$@"; do
       timeout 1500 python -m pytest tests/test_gpu_tower.py tests/test_gpu_groupwise.py tests/test_gpu_distributed.py tests/test_gpu_baseline_configs.py -x -q -m gpu > $OUT/t_tower.log 2>&1; echo "tower tests rc=$?"; tail -n 3 $OUT/t_tower.log | cut -c1-200
       for w in e2e_groupwise_gumbel e2e_softmax e2e_approx_ndcg_l1000; do ab "now" $w 50 TFR_DUMMY=0; done
       ab "now again" e2e_groupwise_gumbel 50 TFR_DUMMY=0 ;;
+    softmax_sweep)
+      for g in 1024 1536 2048 3072; do for d in 1 2; do ab "groups=$g depth=$d" softmax_hbm 50 TFR_SOFTMAX_PACK_GROUPS=$g TFR_SOFTMAX_PACK_DEPTH=$d; done; done
+      ab "nt=0" softmax_hbm 50 TFR_SOFTMAX_NT=0
+      ab "nt=1" softmax_hbm 50 TFR_SOFTMAX_NT=1
+      ab "default" softmax_hbm 50 TFR_DUMMY=0 ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
