@@ -842,9 +842,10 @@ static int sm_pack_grid(int B, int L) {
   const int S = sm_pack_lists_per_wave(L);
   const int groups = (B + S - 1) / S;
   const int wg = (groups + 3) / 4;
-  // (six workgroups per CU: 65 536 x 100 from HBM 20.7 us with 2 048 workgroups, 20.0 with 1 024 or 1 536 -- profiles/r05_softmax_ab.txt)
-  static const int env_pg = [] { const char* e = getenv("TFR_SOFTMAX_PACK_GROUPS"); return (e && *e) ? atoi(e) : 1536; }();
-  const int cap = env_pg >= 1 ? env_pg : 1536;
+  // (round 5: 65 536 x 100 from HBM 20.7 us with 2 048 workgroups, 20.0 with 1 024 or 1 536 -- profiles/r05_softmax_ab.txt;
+  //  round 6, with the 16-byte accesses and non-temporal accesses: 17.1 / 16.8 / 16.8 / 17.1 us with 768 / 1 024 / 1 280 / 1 536)
+  static const int env_pg = [] { const char* e = getenv("TFR_SOFTMAX_PACK_GROUPS"); return (e && *e) ? atoi(e) : 1024; }();
+  const int cap = env_pg >= 1 ? env_pg : 1024;
   return wg < cap ? wg : cap;
 }
 
@@ -883,7 +884,8 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
   if (env_wave && lambda_kind == TFR_LAMBDA_NONE && L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
     static const int env_nt = [] { const char* e = getenv("TFR_SOFTMAX_NT"); return (e && *e) ? atoi(e) : -1; }();
-    const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (128L << 20));
+    // non-temporal from 64 MB per launch on (round 6: 65 536 x 100 = 79 MB per launch, 18.0 -> 17.2 us; it was 128 MB)
+    const bool nt = env_nt >= 0 ? env_nt != 0 : ((long)B * L * 12 > (64L << 20));
     const int env_groups = sm_stream_groups();
     if (sm_packs(B, L, mask != nullptr, item_weights && !weights_per_list, lambda_kind, dlogits_out != nullptr)) {
       const int grid = sm_pack_grid(B, L);

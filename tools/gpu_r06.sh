@@ -149,9 +149,13 @@ for what in "$@"; do
       for w in e2e_groupwise_gumbel e2e_softmax e2e_approx_ndcg_l1000; do ab "now" $w 50 TFR_DUMMY=0; done
       ab "now again" e2e_groupwise_gumbel 50 TFR_DUMMY=0 ;;
     softmax_sweep)
-      for g in 1024 1536 2048 3072; do for d in 1 2; do ab "groups=$g depth=$d" softmax_hbm 50 TFR_SOFTMAX_PACK_GROUPS=$g TFR_SOFTMAX_PACK_DEPTH=$d; done; done
-      ab "nt=0" softmax_hbm 50 TFR_SOFTMAX_NT=0
-      ab "nt=1" softmax_hbm 50 TFR_SOFTMAX_NT=1
+      for g in 768 1024 1280 1536; do ab "groups=$g nt=1" softmax_hbm 50 TFR_SOFTMAX_PACK_GROUPS=$g TFR_SOFTMAX_NT=1; done
+      ab "groups=1024 nt=0" softmax_hbm 50 TFR_SOFTMAX_PACK_GROUPS=1024 TFR_SOFTMAX_NT=0
+      ab "groups=1024 nt=1 again" softmax_hbm 50 TFR_SOFTMAX_PACK_GROUPS=1024 TFR_SOFTMAX_NT=1
+      ab "groups=1024 nt=1 e2e" e2e_softmax 20 TFR_SOFTMAX_PACK_GROUPS=1024 TFR_SOFTMAX_NT=1
+      ab "default e2e" e2e_softmax 20 TFR_DUMMY=0
+      ab "groups=1024 nt=1 small" softmax 200 TFR_SOFTMAX_PACK_GROUPS=1024 TFR_SOFTMAX_NT=1
+      ab "default small" softmax 200 TFR_DUMMY=0
       ab "default" softmax_hbm 50 TFR_DUMMY=0 ;;
     one:*)
       w=${what#one:}
