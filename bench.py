@@ -148,7 +148,7 @@ def launch_command(n_gpus: int, argv, port: int):
 def respawn_under_torchrun(args, argv) -> int:
     if not args.plumbing_check:
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if n_dev < args.gpus:
+        if n_dev < args.gpus and not (os.environ.get('TFR_BENCH_SHARED_GPU') == '1' and n_dev >= 1):
             raise SystemExit('bench.py --gpus %d needs %d MI355X GPUs, %d visible (no CPU fallback)'
                              % (args.gpus, args.gpus, n_dev))
     env = dict(os.environ)
@@ -1124,6 +1124,12 @@ def main(argv=None):
         return plumbing_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (torch.cuda.is_available() is False)')
+    # TFR_BENCH_SHARED_GPU=1 (developer check, never a measurement): every rank on device 0, collectives on `gloo` over
+    # device tensors -- the whole N > 1 control flow of this file (rank plumbing, sharded batches, the overlapped gradient
+    # exchange, max-over-ranks timing, the extras' own torchrun) on a box with ONE GPU, where RCCL refuses duplicate devices
+    shared_gpu = world > 1 and os.environ.get('TFR_BENCH_SHARED_GPU') == '1'
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -1131,7 +1137,10 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if shared_gpu:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                               # a real RCCL collective before anything is timed
         rccl_ranks = int(round(probe.item()))

@@ -222,3 +222,29 @@ def test_split_step_with_two_gloo_ranks_on_one_gpu_matches_the_serial_shards():
             assert abs(a - b) <= 2e-6 * max(1.0, abs(b)), (r, v, vals)
         for n in want:
             assert torch.allclose(named[n], want[n], rtol=2e-5, atol=2e-6 * max(1e-3, want[n].abs().max().item())), (r, n)
+
+
+def test_bench_with_two_ranks_on_one_gpu_runs_the_overlapped_step_end_to_end():
+    """`bench.py --gpus 2` has never seen two devices (every box of every session had one): TFR_BENCH_SHARED_GPU=1 puts
+    both ranks on device 0 with gloo collectives, so the WHOLE N > 1 control flow of the bench -- torchrun respawn, rank
+    plumbing, sharded batches, the overlapped gradient exchange (distributed.SplitStep), max-over-ranks timing, the JSON
+    line -- executes here.  The numbers mean nothing (two processes share a GPU); the line's shape is what is checked."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TFR_BENCH_SHARED_GPU='1')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'e2e_groupwise_gumbel',
+                        '--also', 'none', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--busy-seconds', '0',
+                        '--kernel-timing', 'none'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['steps'] == 5 and d['scaling'] == 'weak'
+    assert d['value'] > 0 and len(d['lists_per_s_per_rank']) == 2
+    ar = d['all_reduce']
+    assert ar['overlap_split'] == 1 and ar['early_bytes'] > 0 and ar['ms'] > 0 and ar['exposed_ms'] is not None
+    assert 'SplitStep) failed' not in r.stderr
