@@ -237,8 +237,8 @@ def test_bench_with_two_ranks_on_one_gpu_runs_the_overlapped_step_end_to_end():
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'e2e_groupwise_gumbel',
-                        '--also', 'none', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--busy-seconds', '0',
-                        '--kernel-timing', 'none'], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+                        '--also', 'none', '--steps', '5', '--warmup', '2', '--no-cpu-baseline', '--busy-seconds', '0'],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
