@@ -1550,7 +1550,13 @@ __device__ __forceinline__ void fused_column_sums(const float* __restrict__ part
 #pragma unroll
         for (int u = 0; u < 16; u += 4) { s0 += v[u]; s1 += v[u + 1]; s2 += v[u + 2]; s3 += v[u + 3]; }
       }
-      for (; t < T; t += kFusedWaves) s0 += partial[(long)t * W + col];
+      if (t < T) {                                            // the remaining (< 16) rows: all loads first (round 6 -- they were
+        float w[16];                                          // up to 15 DEPENDENT loads, ~0.3 us each: T = 400 has nine)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int tt = t + u * kFusedWaves; w[u] = tt < T ? partial[(long)tt * W + col] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s0 += w[u];              // same order as the one-at-a-time loop (+ 0.0f is exact)
+      }
     }
     part[wave][j][lane] = (s0 + s1) + (s2 + s3);
   }
@@ -2188,7 +2194,13 @@ __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, 
 #pragma unroll
       for (int u = 0; u < 16; ++u) t += v[u];
     }
-    for (; s < S; ++s) t += slab[(long)s * n + i];
+    if (s < S) {                                              // the remaining (< 16) slabs: all loads first, then the same adds
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = (s + u < S) ? slab[(long)(s + u) * n + i] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += w[u];
+    }
     out[i] = accumulate ? out[i] + t : t;
   }
 }
