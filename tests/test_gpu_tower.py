@@ -150,6 +150,26 @@ def test_wgrad(M, N, K, pro):
         assert err <= 2e-3 * max(1.0, want.abs().max().item()), (splits, err, want.abs().max().item())
 
 
+@pytest.mark.parametrize('Mr,O', [(1000, 1), (25600, 2), (4097, 2), (4099, 3), (6000, 4), (7, 4), (65536, 1)])
+def test_reduce_partials_also_adds_up_the_output_bias_gradient(Mr, O):
+    """round 6: the column sums of dlogits [Mr, O] ride in the one-launch partial reduction (16-byte loads for O in 1, 2, 4 with
+    Mr * O % 4 == 0, the scalar form otherwise); the sums of the partial matrix themselves are what they were"""
+    t = T()
+    Tn, J, N = 37, 3, 200
+    partial = rnd((Tn, J, N), 900 + Mr, 1.0).to(DEV)
+    dl = rnd((Mr, O), 901 + O, 1.0).to(DEV)
+    plain = t.reduce_partials(partial)
+    out, db = t.reduce_partials(partial, None, colsum_of=dl)
+    assert torch.equal(out, plain)
+    want = dl.double().sum(dim=0)
+    assert db is not None and db.shape == (O,)
+    assert (db.double() - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
+    # a partial matrix too tall for the one-launch form: no bias gradient from this call (the caller adds it up itself)
+    tall = rnd((1100, 2, 64), 77, 1.0).to(DEV)
+    out2, db2 = t.reduce_partials(tall, None, colsum_of=dl)
+    assert db2 is None and torch.allclose(out2, tall.sum(dim=0), rtol=1e-5, atol=1e-4)
+
+
 def test_out_layer_bwd_and_bn_apply():
     t = T()
     M, K, O = 1000, 264, 2
