@@ -385,6 +385,17 @@ int tfr_gumbel_sample_f32(const float* logits, const float* labels, const uint8_
 int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const uint8_t* mask,
                               const float* upstream, int B, int S, int L,
                               float gumbel_temperature, float* dlogits_out, void* stream);
+/* The same two for a training step that is REPLAYED from a hipGraph (lists the one-wavefront-per-list kernels take, up to a thousand items; TFR_EINVAL beyond): the Philox offset of the draw is
+ * `offset + *step` with `step` a uint64 in device memory, and the backward advances it (*step_inc += 1) -- every replay
+ * draws new noise (a host-side offset is frozen into the graph).  `labels_out` (nullable, [B * S, L]): the labels of the
+ * S copies of every list, written by the same launch (what the loss of the sampled lists consumes). */
+int tfr_gumbel_sample_step_f32(const float* logits, const float* labels, const uint8_t* mask,
+                               const float* uniform, uint64_t seed, uint64_t offset, const uint64_t* step,
+                               int B, int S, int L, float gumbel_temperature, float* sampled_out,
+                               float* labels_out, void* stream);
+int tfr_gumbel_sample_bwd_step_f32(const float* sampled, const float* labels, const uint8_t* mask,
+                                   const float* upstream, int B, int S, int L, float gumbel_temperature,
+                                   float* dlogits_out, uint64_t* step_inc, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Scorer tower: tfr.keras.layers.create_tower (keras/layers.py:26-77) on the flattened

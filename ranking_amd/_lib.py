@@ -77,6 +77,10 @@ _SIGNATURES = {
                               + [ctypes.c_float] + [ctypes.c_void_p] * 2),
     'tfr_gumbel_sample_bwd_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float]
                                   + [ctypes.c_void_p] * 2),
+    'tfr_gumbel_sample_step_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_uint64] * 2 + [ctypes.c_void_p]
+                                   + [ctypes.c_int] * 3 + [ctypes.c_float] + [ctypes.c_void_p] * 3),
+    'tfr_gumbel_sample_bwd_step_f32': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_float]
+                                       + [ctypes.c_void_p] * 3),
     # scorer tower (tower.hip)
     'tfr_tower_bn_bwd_coeffs': (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_long]
                                 + [ctypes.c_void_p] * 2),

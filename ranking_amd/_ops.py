@@ -705,7 +705,10 @@ def softmax_loss(logits, labels, mask=None, weights=None, lambda_kind=LAMBDA_NON
 
 
 def gumbel_sample(logits, labels, mask=None, uniform=None, seed=0, offset=0, sample_size=8,
-                  gumbel_temperature=1.0):
+                  gumbel_temperature=1.0, step=None, want_labels=False):
+    """``step`` (one-element int64 device tensor): the Philox offset of the draw is ``offset + step[0]`` -- a step replayed
+    from a hipGraph draws new noise when ``gumbel_sample_bwd(..., step_inc=step)`` advances it (list_size <= 1024).
+    ``want_labels``: also returns the labels of the S copies of every list, [B * S, L], written by the same launch."""
     logits = _f32(logits, 'logits'); labels = _f32(labels, 'labels')
     _check2d(logits, 'logits'); _same_shape(labels, logits, 'labels', 'logits')
     mask = _u8(mask, 'mask'); uniform = _f32(uniform, 'uniform')
@@ -714,19 +717,37 @@ def gumbel_sample(logits, labels, mask=None, uniform=None, seed=0, offset=0, sam
     if uniform is not None and tuple(uniform.shape) != (B, S, L):
         raise ValueError('uniform noise must have shape [B, S, L]')
     out = torch.empty((B * S, L), dtype=torch.float32, device=logits.device)
+    if (step is not None or want_labels) and L <= 1024:
+        if step is not None and (step.numel() != 1 or step.dtype != torch.int64 or not step.is_cuda):
+            raise ValueError('step must be a one-element int64 device tensor')
+        lab_out = torch.empty((B * S, L), dtype=torch.float32, device=logits.device) if want_labels else None
+        rc = _lib.load().tfr_gumbel_sample_step_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(uniform),
+                                                    int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), _ptr(step),
+                                                    B, S, L, float(gumbel_temperature), _ptr(out), _ptr(lab_out), _stream())
+        _lib.check(rc, 'tfr_gumbel_sample_step_f32')
+        return (out, lab_out) if want_labels else out
+    if step is not None:
+        raise ValueError('a device step counter needs list_size <= 1024')
     rc = _lib.load().tfr_gumbel_sample_f32(_ptr(logits), _ptr(labels), _ptr(mask), _ptr(uniform),
                                            int(seed) & (2 ** 64 - 1), int(offset) & (2 ** 64 - 1), B, S, L,
                                            float(gumbel_temperature), _ptr(out), _stream())
     _lib.check(rc, 'tfr_gumbel_sample_f32')
+    if want_labels:
+        return out, labels.unsqueeze(1).expand(B, S, L).reshape(B * S, L).contiguous()
     return out
 
 
-def gumbel_sample_bwd(sampled, labels, mask, upstream, sample_size, gumbel_temperature):
+def gumbel_sample_bwd(sampled, labels, mask, upstream, sample_size, gumbel_temperature, step_inc=None):
     sampled = _f32(sampled, 'sampled'); labels = _f32(labels, 'labels')
     upstream = _f32(upstream, 'upstream'); mask = _u8(mask, 'mask')
     B, L = labels.shape
     S = int(sample_size)
     out = torch.empty((B, L), dtype=torch.float32, device=labels.device)
+    if step_inc is not None and L <= 1024 and B > 0:
+        rc = _lib.load().tfr_gumbel_sample_bwd_step_f32(_ptr(sampled), _ptr(labels), _ptr(mask), _ptr(upstream),
+                                                        B, S, L, float(gumbel_temperature), _ptr(out), _ptr(step_inc), _stream())
+        _lib.check(rc, 'tfr_gumbel_sample_bwd_step_f32')
+        return out
     rc = _lib.load().tfr_gumbel_sample_bwd_f32(_ptr(sampled), _ptr(labels), _ptr(mask), _ptr(upstream),
                                                B, S, L, float(gumbel_temperature), _ptr(out), _stream())
     _lib.check(rc, 'tfr_gumbel_sample_bwd_f32')

@@ -238,10 +238,12 @@ template <int IPL>
 __global__ __launch_bounds__(256) void gumbel_sample_wave_kernel(
     const float* __restrict__ logits, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ uniform, uint64_t seed, uint64_t offset, int BS, int S, int L,
-    float gumbel_temperature, float* __restrict__ sampled_out) {
+    float gumbel_temperature, float* __restrict__ sampled_out, const unsigned long long* __restrict__ step,
+    float* __restrict__ labels_out) {
   const int lane = threadIdx.x & 63;
   const int bs = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bs >= BS) return;
+  if (step) offset += *step;                                 // round 6: the Philox offset of a replayed step lives on the device
   const int b = bs / S;
   const size_t ibase = (size_t)b * L, obase = (size_t)bs * L;
   float z[IPL];
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(256) void gumbel_sample_wave_kernel(
     z[r] = -INFINITY;
     if (i < L) {
       const float lab = labels[ibase + i];
+      if (labels_out) labels_out[obase + i] = lab;           // the labels of the S copies of a list (was an expand + copy launch)
       const bool v = mask ? (mask[ibase + i] != 0) : (lab >= 0.0f);
       float u;
       if (uniform) u = uniform[obase + i];
@@ -277,7 +280,9 @@ template <int IPL>
 __global__ __launch_bounds__(256) void gumbel_sample_bwd_wave_kernel(
     const float* __restrict__ sampled, const float* __restrict__ labels, const uint8_t* __restrict__ mask,
     const float* __restrict__ upstream, int B, int S, int L, float gumbel_temperature,
-    float* __restrict__ dlogits_out) {
+    float* __restrict__ dlogits_out, unsigned long long* __restrict__ step_inc) {
+  // the backward of a step runs after its forward and before the next one: it is where the step's Philox offset advances
+  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) *step_inc += 1ull;
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
@@ -946,18 +951,31 @@ static int softmax_dispatch(const float* logits, const float* labels, const uint
   return (int)hipGetLastError();
 }
 
+extern "C" int tfr_gumbel_sample_step_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* uniform, uint64_t seed, uint64_t offset, const uint64_t* step,
+                                          int B, int S, int L, float gumbel_temperature, float* sampled_out,
+                                          float* labels_out, void* stream);
 extern "C" int tfr_gumbel_sample_f32(const float* logits, const float* labels, const uint8_t* mask,
                                      const float* uniform, uint64_t seed, uint64_t offset, int B,
                                      int S, int L, float gumbel_temperature, float* sampled_out,
                                      void* stream) {
+  return tfr_gumbel_sample_step_f32(logits, labels, mask, uniform, seed, offset, nullptr, B, S, L, gumbel_temperature,
+                                    sampled_out, nullptr, stream);
+}
+
+extern "C" int tfr_gumbel_sample_step_f32(const float* logits, const float* labels, const uint8_t* mask,
+                                          const float* uniform, uint64_t seed, uint64_t offset, const uint64_t* step,
+                                          int B, int S, int L, float gumbel_temperature, float* sampled_out,
+                                          float* labels_out, void* stream) {
   if (!logits || !labels || !sampled_out || B < 0 || S <= 0 || L <= 0 || !(gumbel_temperature > 0.0f))
     return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if ((step || labels_out) && L > 1024) return TFR_EINVAL;    // the wavefront kernels only (list_size <= 1024)
   if (B == 0) return TFR_OK;
   if (L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
     const int BS = B * S;
-#define GW(I) hipLaunchKernelGGL(gumbel_sample_wave_kernel<I>, dim3((BS + 3) / 4), dim3(256), 0, st, logits, labels, mask, uniform, seed, offset, BS, S, L, gumbel_temperature, sampled_out)
+#define GW(I) hipLaunchKernelGGL(gumbel_sample_wave_kernel<I>, dim3((BS + 3) / 4), dim3(256), 0, st, logits, labels, mask, uniform, seed, offset, BS, S, L, gumbel_temperature, sampled_out, (const unsigned long long*)step, labels_out)
     if (L <= 64) GW(1); else if (L <= 128) GW(2); else if (L <= 256) GW(4); else if (L <= 512) GW(8); else GW(16);
 #undef GW
     return (int)hipGetLastError();
@@ -969,17 +987,28 @@ extern "C" int tfr_gumbel_sample_f32(const float* logits, const float* labels, c
   return (int)hipGetLastError();
 }
 
+extern "C" int tfr_gumbel_sample_bwd_step_f32(const float* sampled, const float* labels, const uint8_t* mask,
+                                              const float* upstream, int B, int S, int L, float gumbel_temperature,
+                                              float* dlogits_out, uint64_t* step_inc, void* stream);
 extern "C" int tfr_gumbel_sample_bwd_f32(const float* sampled, const float* labels, const uint8_t* mask,
                                          const float* upstream, int B, int S, int L,
                                          float gumbel_temperature, float* dlogits_out, void* stream) {
+  return tfr_gumbel_sample_bwd_step_f32(sampled, labels, mask, upstream, B, S, L, gumbel_temperature, dlogits_out, nullptr,
+                                        stream);
+}
+
+extern "C" int tfr_gumbel_sample_bwd_step_f32(const float* sampled, const float* labels, const uint8_t* mask,
+                                              const float* upstream, int B, int S, int L, float gumbel_temperature,
+                                              float* dlogits_out, uint64_t* step_inc, void* stream) {
   if (!sampled || !labels || !upstream || !dlogits_out || B < 0 || S <= 0 || L <= 0 ||
       !(gumbel_temperature > 0.0f))
     return TFR_EINVAL;
   if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (step_inc && (L > 1024 || B == 0)) return TFR_EINVAL;
   if (B == 0) return TFR_OK;
   if (L <= 1024) {
     hipStream_t st = (hipStream_t)stream;
-#define GB(I) hipLaunchKernelGGL(gumbel_sample_bwd_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, sampled, labels, mask, upstream, B, S, L, gumbel_temperature, dlogits_out)
+#define GB(I) hipLaunchKernelGGL(gumbel_sample_bwd_wave_kernel<I>, dim3((B + 3) / 4), dim3(256), 0, st, sampled, labels, mask, upstream, B, S, L, gumbel_temperature, dlogits_out, (unsigned long long*)step_inc)
     if (L <= 64) GB(1); else if (L <= 128) GB(2); else if (L <= 256) GB(4); else if (L <= 512) GB(8); else GB(16);
 #undef GB
     return (int)hipGetLastError();

@@ -674,10 +674,19 @@ class GumbelApproxNDCGLoss(ApproxNDCGLoss):
         seed = sampler._seed if sampler._seed is not None else 0
         offset = sampler._calls
         sampler._calls += 1
-        sampled = _ops.gumbel_sample(y_pred.detach(), y_true, None, uniform, seed, offset, s,
-                                     self._gumbel_temperature)
         b, l = y_true.shape
-        gl = y_true.unsqueeze(1).expand(b, s, l).reshape(b * s, l).contiguous()
+        # Round 6: the Philox offset of the training step also has a device part that the backward launch advances -- a step
+        # replayed from a hipGraph draws new noise (the host-side `offset` is frozen into the graph).  The counter is created
+        # by the first call outside a capture; the sampler kernel also writes the labels of the S copies of every list.
+        step = None
+        if uniform is None and l <= 1024:
+            key = str(y_pred.device)
+            steps = sampler.__dict__.setdefault('_device_steps', {})
+            step = steps.get(key)
+            if step is None and not torch.cuda.is_current_stream_capturing():
+                step = steps[key] = torch.zeros(1, dtype=torch.int64, device=y_pred.device)
+        sampled, gl = _ops.gumbel_sample(y_pred.detach(), y_true, None, uniform, seed, offset, s,
+                                         self._gumbel_temperature, step=step, want_labels=True)
         gw = None
         if sample_weight is not None:
             w = sample_weight.reshape(b, 1, 1) if sample_weight.dim() == 1 else sample_weight.unsqueeze(1)
@@ -687,7 +696,7 @@ class GumbelApproxNDCGLoss(ApproxNDCGLoss):
             loss, d_sampled = ApproxNDCGLoss.loss_and_grad(self, gl, sampled, gw)
         finally:
             self._ragged = saved
-        dlogits = _ops.gumbel_sample_bwd(sampled, y_true, None, d_sampled, s, self._gumbel_temperature)
+        dlogits = _ops.gumbel_sample_bwd(sampled, y_true, None, d_sampled, s, self._gumbel_temperature, step_inc=step)
         return loss, dlogits
 
 

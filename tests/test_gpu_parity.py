@@ -1386,6 +1386,49 @@ def test_list_mle_shuffles_tied_labels_like_the_reference(B, L):
         assert a1 != a2 and a1 == b1
 
 
+def test_gumbel_step_counter_on_the_device_advances_under_graph_replay():
+    """round 6: tfr_gumbel_sample_step_f32 / _bwd_step_f32 -- Philox offset = host offset + a device counter that the
+    backward launch advances, so a training step replayed from a hipGraph draws new noise (the host offset is frozen into
+    the graph); the sampler also writes the labels of the S copies of every list."""
+    from ranking_amd import _ops
+    B, L, S = 64, 50, 8
+    labels, logits = make_batch(B, L, seed=321)
+    lb, lg = labels.to(DEV), logits.to(DEV)
+    base = _ops.gumbel_sample(lg, lb, None, None, seed=7, offset=5, sample_size=S)
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    got, gl = _ops.gumbel_sample(lg, lb, None, None, seed=7, offset=5, sample_size=S, step=step, want_labels=True)
+    assert torch.equal(got, base)
+    assert torch.equal(gl, lb.unsqueeze(1).expand(B, S, L).reshape(B * S, L))
+    step.fill_(3)
+    assert torch.equal(_ops.gumbel_sample(lg, lb, None, None, seed=7, offset=5, sample_size=S, step=step),
+                       _ops.gumbel_sample(lg, lb, None, None, seed=7, offset=8, sample_size=S))
+    up = torch.ones_like(got)
+    d0 = _ops.gumbel_sample_bwd(got, lb, None, up, S, 1.0)
+    d1 = _ops.gumbel_sample_bwd(got, lb, None, up, S, 1.0, step_inc=step)
+    assert torch.equal(d0, d1) and int(step.item()) == 4
+    # the Keras loss: eager warm-up (creates the counter), capture, replays
+    k = ra().keras.losses
+    loss = k.GumbelApproxNDCGLoss(seed=11, sample_size=S)
+    v0, _ = loss.loss_and_grad(lb, lg)
+    ctr = loss._gumbel_sampler._device_steps[str(lg.device)]
+    c0 = int(ctr.item())
+    assert c0 >= 1
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            v, d = loss.loss_and_grad(lb, lg)
+    vals = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        vals.append(v.item())
+        assert bool(torch.isfinite(d).all())
+    assert int(ctr.item()) == c0 + 3
+    assert len(set(vals)) == 3                               # new noise in every replay
+
+
 # ------------------------------------------------------------------ longest-first launch order
 @pytest.mark.parametrize('B,L', [(1, 1), (5, 7), (300, 50), (2048, 200), (4100, 33), (16384, 200), (20001, 40)])
 def test_list_order_is_a_length_sorted_permutation_and_results_do_not_depend_on_it(B, L):
