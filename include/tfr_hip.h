@@ -566,6 +566,9 @@ int tfr_tower_wgrad_bf16(const void* DZ, long lddz, const void* A, long lda, int
                          int prologue, const float* a_scale, const float* a_shift, float* slab,
                          long ldw, int splits, const tfr_tower_dropout* dropout, void* stream);
 int tfr_tower_slab_reduce(const float* slab, int S, long n, float* out, int accumulate, void* stream);
+/* The same for slabs [S][R][Cs] whose rows are wider than the result's: out[R][Cout] (+)= sum_s slab[s][:, :Cout]. */
+int tfr_tower_slab_reduce_cols(const float* slab, int S, int R, int Cs, int Cout, float* out, int accumulate,
+                               void* stream);
 
 /* out[0] = sum_i x[i] * w[i] (w NULL: sum_i x[i]), n <= 65536, 16-byte aligned inputs: the scalar reduction of a per-list
  * loss vector (compute_weighted_loss / the Keras reduction, losses_impl.py:787-814) in one launch with a fixed

@@ -131,6 +131,7 @@ _SIGNATURES = {
                              + [ctypes.c_void_p] * 3 + [ctypes.c_long, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     'tfr_tower_slab_reduce': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_void_p]),
+    'tfr_tower_slab_reduce_cols': (ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     # fp32 Dense on the matrix cores (gemm_f32.hip)
     'tfr_tower_gemm_f32': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_long, ctypes.c_int] * 2 + [ctypes.c_void_p, ctypes.c_long]
                            + [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),

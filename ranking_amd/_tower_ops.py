@@ -404,9 +404,12 @@ def bn_bwd_apply_(dy, z, K, pqr):
 _WGRAD_BLOCKS = int(os.environ.get('TFR_WGRAD_BLOCKS', '512'))   # split-M target: workgroups per launch
 
 
-def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, dropout=None, accumulate_into=None):
+def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, dropout=None, accumulate_into=None,
+          out_cols=None):
     """dW[N, K] = dz[M, :N]^T . pro(A)[M, :K] (fp32).  ``accumulate_into`` (contiguous fp32 [N, K]): the split
-    reduction adds into it instead of returning a fresh tensor (gradient accumulation without another launch)."""
+    reduction adds into it instead of returning a fresh tensor (gradient accumulation without another launch).
+    ``out_cols`` < K: only the first out_cols columns are wanted (A is staged wider than the weight matrix: k-step
+    padding) -- the result / accumulate_into is [N, out_cols], written by the reduction itself."""
     _bf16(dz, 'dz'); _bf16(A, 'A')
     M = dz.shape[0]
     if splits <= 0:
@@ -423,14 +426,22 @@ def wgrad(dz, A, N, K, prologue=PRO_NONE, a_scale=None, a_shift=None, splits=0, 
     _lib.check(lib.tfr_tower_wgrad_bf16(_ptr(dz), dz.stride(0), _ptr(A), A.stride(0), M, N, K, prologue,
                                         _ptr(a_scale), _ptr(a_shift), _ptr(slab), K, splits, _dp(dropout), _stream()),
                'tfr_tower_wgrad_bf16')
+    Ko = K if out_cols is None else int(out_cols)
+    if not 0 < Ko <= K:
+        raise ValueError('out_cols must be in (0, K]')
     if accumulate_into is not None:
         out = accumulate_into
-        if out.shape != (N, K) or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError('accumulate_into must be a contiguous fp32 [%d, %d] tensor' % (N, K))
+        if out.shape != (N, Ko) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError('accumulate_into must be a contiguous fp32 [%d, %d] tensor' % (N, Ko))
     else:
-        out = torch.empty((N, K), dtype=torch.float32, device=dz.device)
-    _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 1 if accumulate_into is not None else 0,
-                                         _stream()), 'tfr_tower_slab_reduce')
+        out = torch.empty((N, Ko), dtype=torch.float32, device=dz.device)
+    if Ko == K:
+        _lib.check(lib.tfr_tower_slab_reduce(_ptr(slab), splits, N * K, _ptr(out), 1 if accumulate_into is not None else 0,
+                                             _stream()), 'tfr_tower_slab_reduce')
+    else:
+        _lib.check(lib.tfr_tower_slab_reduce_cols(_ptr(slab), splits, N, K, Ko, _ptr(out),
+                                                  1 if accumulate_into is not None else 0, _stream()),
+                   'tfr_tower_slab_reduce_cols')
     return out
 
 

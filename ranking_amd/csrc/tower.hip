@@ -2181,6 +2181,35 @@ __global__ __launch_bounds__(512, 1) void tower_wgrad256_kernel(const WgradArgs 
     }
 }
 
+// out[r][c] (+)= sum_s slab[s][r][c] for c < Cout, slab rows Cs >= Cout wide (the weight gradient of a layer whose input is
+// staged wider than the weight matrix: the k-step padding of the first layer) -- the reduction writes the gradient's own
+// layout, so it can accumulate in place there too (round 6: it was a slice + copy launch, and the in-place mode fell back)
+__global__ void tower_slab_reduce_cols_kernel(const float* __restrict__ slab, int S, int R, int Cs, int Cout,
+                                              float* __restrict__ out, int accumulate) {
+  const long n = (long)R * Cout, sn = (long)R * Cs;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / Cout, c = i - r * Cout;
+    const float* p = slab + r * Cs + c;
+    float t = 0.f;
+    int s = 0;
+    for (; s + 15 < S; s += 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(long)(s + u) * sn];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += v[u];
+    }
+    if (s < S) {
+      float w[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) w[u] = (s + u < S) ? p[(long)(s + u) * sn] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += w[u];
+    }
+    out[i] = accumulate ? out[i] + t : t;
+  }
+}
+
 // out[i] (+)= sum_s slab[s][i]
 __global__ void tower_slab_reduce_kernel(const float* __restrict__ slab, int S, long n, float* __restrict__ out,
                                          int accumulate) {
@@ -2863,6 +2892,14 @@ extern "C" int tfr_tower_slab_reduce(const float* slab, int S, long n, float* ou
   if (!slab || !out || S < 1 || n <= 0) return TFR_EINVAL;
   hipLaunchKernelGGL(tower_slab_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, S,
                      n, out, accumulate);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_tower_slab_reduce_cols(const float* slab, int S, int R, int Cs, int Cout, float* out, int accumulate,
+                                          void* stream) {
+  if (!slab || !out || S < 1 || R <= 0 || Cout <= 0 || Cs < Cout) return TFR_EINVAL;
+  hipLaunchKernelGGL(tower_slab_reduce_cols_kernel, dim3(grid_for((long)R * Cout, 256)), dim3(256), 0, (hipStream_t)stream,
+                     slab, S, R, Cs, Cout, out, accumulate);
   return (int)hipGetLastError();
 }
 

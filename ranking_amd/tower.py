@@ -257,17 +257,18 @@ class _TowerFn(torch.autograd.Function):
             else:
                 pro_p, sc_p, sh_p, mean_p, rstd_p, drop_p = T.PRO_NONE, None, None, None, None, None
                 a_prev, k_in = x0, x0.shape[1]
-            into = Ws[l].grad if (direct and k_in == Ws[l].shape[1] and Ws[l].grad.is_contiguous()) else None
+            into = Ws[l].grad if (direct and Ws[l].grad.is_contiguous()) else None
+            w_cols = Ws[l].shape[1] if k_in != Ws[l].shape[1] else None      # (input staged wider than W: k-step padding)
             if l == 0:
                 dz0 = dz
             if ctx.a_outs[l] is not None:                    # the forward GEMM left act(BN(z)) * mask behind: no prologue
-                g = T.wgrad(dz, ctx.a_outs[l], n_out, k_in, prologue=T.PRO_NONE, accumulate_into=into)
+                g = T.wgrad(dz, ctx.a_outs[l], n_out, k_in, prologue=T.PRO_NONE, accumulate_into=into, out_cols=w_cols)
                 ctx.a_outs[l] = None
             else:
                 g = T.wgrad(dz, a_prev, n_out, k_in, prologue=pro_p, a_scale=sc_p, a_shift=sh_p, dropout=drop_p,
-                            accumulate_into=into)
+                            accumulate_into=into, out_cols=w_cols)
             if into is None:
-                dW[l] = g[:, :Ws[l].shape[1]].contiguous() if g.shape[1] != Ws[l].shape[1] else g
+                dW[l] = g
             if l > 0:
                 wt = ctx.wts[l] if len(ctx.wts) > l else T.cast_weight(Ws[l], transpose=True)   # [K, pad8(N)]
                 epi = T.EPI_RELU_BWD
