@@ -803,7 +803,7 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         n_c = max(steps, 50)
         e_c = _timed_loop(step_c, n_c, dist)
         order_cached = {'ms_per_step': 1e3 * e_c / n_c, 'value': B * world * n_c / e_c, 'unit': 'lists/s',
-                        'note': 'the same step WITHOUT list_class + list_place inside it (a ready launch order: labels that do '
+                        'note': 'the same step WITHOUT the launch-order kernel inside it (a ready launch order: labels that do '
                                 'not change between steps -- evaluation, device-resident epochs); round 5 reported this as `value`'}
         info['keep_alive_c'] = (step_c, ready)
     all_reduce_ms = None
@@ -851,8 +851,9 @@ def run_workload(name, args, dist, rank, world, dev, steps, warmup, cpu_budget_s
         result['steady_state'] = steady
     if order_cached is not None:
         result['order_cached'] = order_cached
-        result['config']['launch_order'] = ('longest-first order of the lists, computed INSIDE every timed step (list_class + '
-                                            'list_place are nodes of the replayed graph); order_cached = the step handed a ready order')
+        result['config']['launch_order'] = ('(approximately) longest-first order of the lists, computed INSIDE every timed step (the one-launch '
+                                            'interleaved order, list_order_local_kernel, is a node of the replayed graph); order_cached = the '
+                                            'step handed a ready order')
     if kernel_ms is not None and not is_e2e:
         algo_bytes = bytes_per_list(L) * (B // cycle)        # per LAUNCH of the dominant kernel
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9

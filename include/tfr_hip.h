@@ -247,6 +247,11 @@ int tfr_pointwise_loss_sum_f32(int kind, const float* logits, const float* label
  *   workspace  int32[B] scratch owned by the caller. */
 int tfr_list_order_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
                        int32_t* workspace, void* stream);
+/* An APPROXIMATELY longest-first order from one launch (round 6): every workgroup sorts its 128 / 256 lists by length class
+ * and writes them interleaved with the other workgroups' (position = rank inside the segment * segments + segment): a
+ * permutation of [0, B) whose first `segments` entries are the longest list of every segment, and so on.  No workspace. */
+int tfr_list_order_interleaved_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
+                                   void* stream);
 
 /* losses_impl.ApproxMRRLoss._compute_unreduced_loss_impl fused with its backward
  * (losses_impl.py:77-106, 1606-1632): loss_b = -sum_i (l_i / sum l) / approx_rank_i; same

@@ -43,6 +43,7 @@ _SIGNATURES = {
     'tfr_approx_ndcg_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                             + [ctypes.c_int] + [ctypes.c_void_p] * 5),
     'tfr_list_order_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 3),
+    'tfr_list_order_interleaved_i32': (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] * 2),
     'tfr_grid_sum_state_ints': (ctypes.c_int, []),
     'tfr_approx_ndcg_sum_f32': (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_int] * 2 + [ctypes.c_float]
                                 + [ctypes.c_int] + [ctypes.c_void_p] * 7),

@@ -355,6 +355,25 @@ def list_order(labels, mask=None):
     return order
 
 
+_ORDER_INTERLEAVED = os.environ.get('TFR_ORDER_INTERLEAVED', '1') != '0'
+
+
+def launch_order_interleaved(labels, mask=None):
+    """tfr_list_order_interleaved_i32: an approximately longest-first permutation from ONE launch (every workgroup's
+    lists sorted by length class, interleaved with the other workgroups') -- what the O(n^2) losses use for load balance
+    since round 6 (TFR_ORDER_INTERLEAVED=0: the exact two-launch order of ``list_order``)."""
+    labels = _f32(labels, 'labels'); mask = _u8(mask, 'mask')
+    B, L = labels.shape
+    order = torch.empty((B,), dtype=torch.int32, device=labels.device)
+    rc = _lib.load().tfr_list_order_interleaved_i32(_ptr(labels), _ptr(mask), B, L, _ptr(order), _stream())
+    _lib.check(rc, 'tfr_list_order_interleaved_i32')
+    return order
+
+
+def _launch_order(labels, mask):
+    return launch_order_interleaved(labels, mask) if _ORDER_INTERLEAVED else list_order(labels, mask)
+
+
 # The launch order is a function of the LABELS (and the mask) alone and only steers load balance -- the loss kernels write
 # every list to its own rows, so their results do not depend on it.  EAGER calls cache it per label tensor (round 5): keyed
 # on the tensor object, its storage address and its version counter (bumped by every in-place write), so a batch whose
@@ -414,14 +433,14 @@ def _cached_order(labels, mask):
     if _FIXED_ORDER is not None and _FIXED_ORDER.shape[0] == labels.shape[0]:
         return _FIXED_ORDER
     if not _ORDER_CACHE_ON or torch.cuda.is_current_stream_capturing():
-        return list_order(labels, mask)         # inside a capture: two nodes of the graph, memory of the graph's pool
+        return _launch_order(labels, mask)      # inside a capture: a node of the graph, memory of the graph's pool
     key = (labels.data_ptr(), tuple(labels.shape), str(labels.device), None if mask is None else mask.data_ptr())
     stamp = (labels._version, None if mask is None else mask._version)
     ent = _order_lru.get(key)
     if ent is not None and ent[0] == stamp and ent[1]() is labels:       # (the mask is a fresh uint8 view per call: address + version)
         _order_lru.move_to_end(key)
         return ent[2]
-    order = list_order(labels, mask)
+    order = _launch_order(labels, mask)
     _order_lru[key] = (stamp, weakref.ref(labels), order)
     while len(_order_lru) > _ORDER_CACHE_CAPACITY:
         _order_lru.popitem(last=False)

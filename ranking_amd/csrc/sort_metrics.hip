@@ -1561,6 +1561,81 @@ __global__ __launch_bounds__(256) void list_place_kernel(int B, int nblk, const 
   if ((int)threadIdx.x < LPB && b < B) order_out[atomicAdd(&s_cur[cls[b]], 1)] = b;
 }
 
+// Round 6: the launch order from ONE launch with no global step (tfr_list_order_interleaved_i32).  Every workgroup sorts
+// ITS lists by length class (LDS counting sort: histogram, class prefix, cursors) and writes them interleaved with the other
+// workgroups' lists: the r-th longest list of segment s goes to position r * nseg + s -- the first nseg positions hold the
+// longest list of every segment, the next nseg the second longest, ...  The lengths of different segments are draws from the
+// same batch, so the interleaved order is longest-first up to the spread between segments' r-th order statistics, which is
+// all the load balance of the O(n^2) kernels needs (their results do not depend on the order), and the second launch + the
+// partial-histogram round trip of the exact order go away (headline step 0.119 -> see DESIGN 4.2).  The last segment may
+// be short (m lists): ranks below m interleave over all nseg segments, the rest over the nseg - 1 full ones.
+template <bool DEEP, int LPB>
+__global__ __launch_bounds__(4 * LPB) void list_order_local_kernel(const float* __restrict__ labels,
+                                                                   const uint8_t* __restrict__ mask, int B, int L,
+                                                                   int* __restrict__ order_out) {
+  __shared__ int s_hist[kOrderClasses];
+  __shared__ int s_cur[kOrderClasses];
+  if (threadIdx.x < kOrderClasses) s_hist[threadIdx.x] = 0;
+  __syncthreads();
+  const int t = threadIdx.x & 3;
+  const int b = blockIdx.x * LPB + (threadIdx.x >> 2);
+  int n = 0;
+  if (b < B) {
+    const size_t base = (size_t)b * L;
+    if (!mask && (L & 3) == 0 && ((reinterpret_cast<uintptr_t>(labels) & 15) == 0)) {
+      const float4* p = reinterpret_cast<const float4*>(labels + base);
+      const int q = L / 4;
+      int i = t;
+      if (!DEEP) {
+#pragma unroll 4
+        for (; i < q; i += 4) {
+          const float4 v = p[i];
+          n += (v.x >= 0.0f) + (v.y >= 0.0f) + (v.z >= 0.0f) + (v.w >= 0.0f);
+        }
+      }
+      for (; DEEP && i + 60 < q; i += 64) {
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = p[i + 4 * k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n += (v[k].x >= 0.0f) + (v[k].y >= 0.0f) + (v[k].z >= 0.0f) + (v[k].w >= 0.0f);
+      }
+      if (DEEP) {
+        float4 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (i + 4 * k < q) ? p[i + 4 * k] : make_float4(-1.f, -1.f, -1.f, -1.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) n += (v[k].x >= 0.0f) + (v[k].y >= 0.0f) + (v[k].z >= 0.0f) + (v[k].w >= 0.0f);
+      }
+    } else {
+      const int per = (L + 3) / 4, lo = t * per, hi = (lo + per < L) ? lo + per : L;
+      if (mask) { for (int i = lo; i < hi; ++i) n += mask[base + i] != 0; }
+      else { for (int i = lo; i < hi; ++i) n += labels[base + i] >= 0.0f; }
+    }
+  }
+  n += __shfl_xor(n, 1, 64);
+  n += __shfl_xor(n, 2, 64);
+  const bool own = b < B && t == 0;
+  int c = 0;
+  if (own) {
+    c = kOrderClasses - 1 - (n * kOrderClasses) / (L + 1);                             // 0 = longest
+    atomicAdd(&s_hist[c], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {                                     // class starts inside the segment: one wave scan
+    const int v = s_hist[threadIdx.x];
+    s_cur[threadIdx.x] = wave_scan_incl_i(v) - v;
+  }
+  __syncthreads();
+  if (own) {
+    const int r = atomicAdd(&s_cur[c], 1);                    // rank of the list inside its segment (arbitrary inside a class)
+    const int nseg = gridDim.x, seg = blockIdx.x;
+    const int m = B - (nseg - 1) * LPB;                       // lists of the last segment (1 .. LPB)
+    const int pos = r < m ? r * nseg + seg : m * nseg + (r - m) * (nseg - 1) + seg;
+    order_out[pos] = b;
+  }
+}
+
 inline int block_threads_for(int P) {
   int t = P / 2;
   if (t < 64) t = 64;
@@ -1759,5 +1834,21 @@ extern "C" int tfr_list_order_i32(const float* labels, const uint8_t* mask, int 
   }
   hipLaunchKernelGGL(list_count_kernel, dim3((B + 3) / 4), dim3(256), 0, st, labels, mask, B, L, (int*)workspace);
   hipLaunchKernelGGL(list_scatter_kernel, dim3(1), dim3(1024), 0, st, B, L, (const int*)workspace, (int*)order_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int tfr_list_order_interleaved_i32(const float* labels, const uint8_t* mask, int B, int L, int32_t* order_out,
+                                              void* stream) {
+  if ((!labels && !mask) || !order_out || B < 0 || L <= 0) return TFR_EINVAL;
+  if (L > TFR_MAX_LIST) return TFR_ETOOLARGE;
+  if (B == 0) return TFR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (B >= 8192) {
+    hipLaunchKernelGGL((list_order_local_kernel<false, 128>), dim3((B + 127) / 128), dim3(512), 0, st, labels, mask, B, L, (int*)order_out);
+  } else if ((B + 255) / 256 < 32) {
+    hipLaunchKernelGGL((list_order_local_kernel<true, 256>), dim3((B + 255) / 256), dim3(1024), 0, st, labels, mask, B, L, (int*)order_out);
+  } else {
+    hipLaunchKernelGGL((list_order_local_kernel<false, 256>), dim3((B + 255) / 256), dim3(1024), 0, st, labels, mask, B, L, (int*)order_out);
+  }
   return (int)hipGetLastError();
 }

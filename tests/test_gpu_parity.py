@@ -137,8 +137,8 @@ def test_launch_order_is_cached_per_label_tensor(monkeypatch):
     labels, logits = make_batch(B, L, seed=4242)
     lb, lg = labels.to(DEV), logits.to(DEV)
     calls = []
-    real = _ops.list_order
-    monkeypatch.setattr(_ops, 'list_order', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    real = _ops._launch_order
+    monkeypatch.setattr(_ops, '_launch_order', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
     _ops._order_lru.clear()
     with _ops.order_cache(False):
         ref = _ops.approx_ndcg(lg, lb, None, None, 0.1, 0, True)
@@ -1464,6 +1464,40 @@ def _check_order(order, labels, L):
     n = (labels.cpu() >= 0).sum(1)
     c = 63 - (n * 64) // (L + 1)                              # the kernels' 64 length classes, class 0 = longest
     assert bool((c[order][:-1] <= c[order][1:]).all())
+
+
+@pytest.mark.parametrize('B,L', [(1024, 200), (4096, 200), (16384, 200), (5000, 37), (8200, 64), (1030, 1000), (257, 50)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_interleaved_launch_order_is_a_permutation_sorted_inside_every_segment(B, L, masked):
+    """round 6 (tfr_list_order_interleaved_i32): one launch, no global step -- every workgroup's lists sorted by length
+    class and interleaved with the other workgroups'.  A permutation of [0, B); the lists of one segment appear in
+    non-increasing length class; the results of the losses do not depend on it (same bits as with the exact order)."""
+    from ranking_amd import _ops
+    labels, logits = make_batch(B, L, seed=31 + B)
+    lb = labels.to(DEV)
+    mask = None
+    n = (labels >= 0).sum(1)
+    if masked:
+        m = labels >= 0
+        m[:, ::3] = False
+        mask = m.to(DEV)
+        n = m.sum(1)
+    order = _ops.launch_order_interleaved(lb, mask).cpu().long()
+    assert torch.equal(torch.sort(order).values, torch.arange(B))
+    lpb = 128 if B >= 8192 else 256
+    cls = 63 - (n * 64) // (L + 1)                             # class 0 = longest
+    seg_of = order // lpb
+    nseg = (B + lpb - 1) // lpb
+    for sgm in range(min(nseg, 5)) :
+        c = cls[order[seg_of == sgm]]                          # the segment's lists in launch order
+        assert bool((c[:-1] <= c[1:]).all()), sgm
+    # the first nseg positions: one list of every segment, its longest
+    first = order[:nseg]
+    assert sorted((first // lpb).tolist()) == list(range(nseg))
+    if not masked and B in (4096, 16384):
+        a = _ops.approx_ndcg(logits.to(DEV), lb, None, None, 0.1, 0, True, balance=_ops.list_order(lb))
+        b2 = _ops.approx_ndcg(logits.to(DEV), lb, None, None, 0.1, 0, True, balance=_ops.launch_order_interleaved(lb))
+        assert all(torch.equal(x, y) for x, y in zip(a, b2))
 
 
 @pytest.mark.parametrize('B,L', [(512, 200), (4096, 200), (16384, 200), (5000, 37), (700, 1000), (600, 260)])
