@@ -1491,9 +1491,11 @@ def test_interleaved_launch_order_is_a_permutation_sorted_inside_every_segment(B
     for sgm in range(min(nseg, 5)) :
         c = cls[order[seg_of == sgm]]                          # the segment's lists in launch order
         assert bool((c[:-1] <= c[1:]).all()), sgm
-    # the first nseg positions: one list of every segment, its longest
-    first = order[:nseg]
-    assert sorted((first // lpb).tolist()) == list(range(nseg))
+    # the first row: the C longest lists of every segment (C = TFR_ORDER_CHUNK consecutive ranks stay together; default 1)
+    C = int(os.environ.get('TFR_ORDER_CHUNK', '1'))
+    if B % lpb == 0 or B - (nseg - 1) * lpb >= C:
+        first = order[:nseg * C]
+        assert sorted((first // lpb).tolist()) == sorted(list(range(nseg)) * C)
     if not masked and B in (4096, 16384):
         a = _ops.approx_ndcg(logits.to(DEV), lb, None, None, 0.1, 0, True, balance=_ops.list_order(lb))
         b2 = _ops.approx_ndcg(logits.to(DEV), lb, None, None, 0.1, 0, True, balance=_ops.launch_order_interleaved(lb))
