@@ -1849,7 +1849,8 @@ extern "C" int tfr_list_order_interleaved_i32(const float* labels, const uint8_t
   static const int env_c = [] { const char* e = getenv("TFR_ORDER_CHUNK"); return (e && *e) ? atoi(e) : 1; }();
   // (measured, headline step: 0.1159 / 0.1165 / 0.1175 / 0.1198 ms with chunks of 1 / 4 / 8 / 16 ranks; exact order 0.1193)
   const int C = (env_c == 1 || env_c == 2 || env_c == 4 || env_c == 8 || env_c == 16 || env_c == 32) ? env_c : 1;
-  if (B >= 8192) {
+  static const int env_il_lpb = [] { const char* e = getenv("TFR_ORDER_IL_LPB"); return (e && *e) ? atoi(e) : 0; }();
+  if (env_il_lpb ? env_il_lpb == 128 : B >= 8192) {
     hipLaunchKernelGGL((list_order_local_kernel<false, 128>), dim3((B + 127) / 128), dim3(512), 0, st, labels, mask, B, L, (int*)order_out, C);
   } else if ((B + 255) / 256 < 32) {
     hipLaunchKernelGGL((list_order_local_kernel<true, 256>), dim3((B + 255) / 256), dim3(1024), 0, st, labels, mask, B, L, (int*)order_out, C);

@@ -158,11 +158,8 @@ for what in "$@"; do
       ab "default small" softmax 200 TFR_DUMMY=0
       ab "default" softmax_hbm 50 TFR_DUMMY=0 ;;
     order_il)
-      timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "order" > $OUT/t_order.log 2>&1; echo "order tests rc=$?"; tail -n 2 $OUT/t_order.log | cut -c1-200
-      for c in 1 4 8 16 1 4 8 16; do ab "chunk=$c" approx_ndcg 200 TFR_ORDER_CHUNK=$c; done
-      ab "exact" approx_ndcg 200 TFR_ORDER_INTERLEAVED=0
-      for c in 1 4 8 16 1 4; do ab "chunk=$c" pairwise_lambda 200 TFR_ORDER_CHUNK=$c; done
-      ab "exact" pairwise_lambda 200 TFR_ORDER_INTERLEAVED=0 ;;
+      for v in 128 256 128 256; do ab "il_lpb=$v" approx_ndcg 200 TFR_ORDER_IL_LPB=$v; done
+      for v in 128 256 128 256; do ab "il_lpb=$v" pairwise_lambda 200 TFR_ORDER_IL_LPB=$v; done ;;
     one:*)
       w=${what#one:}
       timeout 400 python3 bench.py --workload $w $ONE --steps 50 --warmup 5 > $OUT/one_$w.out 2> $OUT/one_$w.err
